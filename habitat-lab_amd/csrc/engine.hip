@@ -1,0 +1,507 @@
+// engine.hip -- the policy engine: owns the layer program of one actor-critic (encoder -> recurrent
+// state encoder -> heads), the layout of the flat parameter / gradient arenas, and the activation
+// workspace; runs `act`, `evaluate` (forward, activations kept) and `backward` as sequences of the
+// kernels in this library on one HIP stream.  Python only makes one C call per policy invocation.
+//
+// Replaces (habitat-baselines/habitat_baselines/): rl/ppo/policy.py:324-402 (NetPolicy.act /
+// get_value / evaluate_actions) with PointNavBaselineNet :494-589, and the autograd backward that
+// total_loss.backward() (rl/ppo/ppo.py:253) runs through them.
+#include <string.h>
+
+#include <algorithm>
+
+#include <string>
+#include <vector>
+
+#include "heads.h"
+#include "ops.h"
+#include "problems.h"
+#include "../../include/habitat_amd.h"
+
+using namespace hab;
+
+namespace {
+
+struct ParamSpec {
+    std::string name;
+    int64_t shape[4];
+    int ndim;
+    int64_t offset;  // floats, 16-byte aligned
+    int64_t numel;
+};
+
+struct Arena {
+    int64_t used = 0;
+    int64_t take(int64_t n) {
+        const int64_t o = used;
+        used += (n + 63) & ~(int64_t)63;  // 256-byte granules
+        return o;
+    }
+};
+
+}  // namespace
+
+struct hab_policy {
+    hab_policy_desc d;
+    std::vector<ParamSpec> params;
+    int64_t param_floats = 0, packed_floats = 0, work_floats = 0;
+    float *P = nullptr, *G = nullptr, *PK = nullptr, *WK = nullptr;
+    int64_t work_bound = 0;
+    int Cin = 0;
+    ConvDesc c1, c2, c3;  // SimpleCNN geometry (B filled per call)
+    int fc_in = 0, rnn_in = 0, rnn_ld = 0, G_ = 3, L = 1;
+    // param indices
+    int i_c1w, i_c1b, i_c2w, i_c2b, i_c3w, i_c3b, i_fcw, i_fcb, i_aw, i_ab, i_cw, i_cb;
+    std::vector<int> i_wih, i_whh, i_bih, i_bhh;
+    // packed offsets
+    int64_t pk_c1f, pk_c2f, pk_c2d, pk_c3f, pk_c3d, pk_fc;
+    std::vector<int64_t> pk_whht;
+    // workspace offsets (floats)
+    int64_t w_a1, w_a2, w_a3, w_rnnin, w_da1, w_da2, w_da3, w_drnnin, w_hinit, w_cinit, w_feat_d, w_probs, w_logitsn, w_dzv,
+        w_dv, w_dfeat, w_scratch, w_ws, w_value, w_logp, w_ent, w_hmask, w_gistep, w_step_h;
+    std::vector<int64_t> w_gi, w_gates, w_hn, w_hprev, w_cprev, w_c, w_out, w_dgi, w_dgh, w_dlayer;
+    int64_t ws_floats = 0;
+    int last_B = 0, last_n = 0;
+    // probe
+    int probe_tag = -1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> probe_events;
+    size_t probe_used = 0;
+
+    float* p(int i) const { return P + params[i].offset; }
+    float* g(int i) const { return G + params[i].offset; }
+};
+
+static int add_param(hab_policy* e, const std::string& name, std::initializer_list<int64_t> shape) {
+    ParamSpec s;
+    s.name = name;
+    s.ndim = (int)shape.size();
+    s.numel = 1;
+    int k = 0;
+    for (auto v : shape) { s.shape[k++] = v; s.numel *= v; }
+    for (; k < 4; ++k) s.shape[k] = 1;
+    s.offset = e->param_floats;
+    e->param_floats += (s.numel + 3) & ~(int64_t)3;
+    e->params.push_back(s);
+    return (int)e->params.size() - 1;
+}
+
+static int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+static int build_baseline(hab_policy* e) {
+    const hab_policy_desc& d = e->d;
+    e->Cin = (d.has_rgb ? 3 : 0) + (d.has_depth ? 1 : 0);
+    if (e->Cin == 0) return HAB_ERR_UNSUPPORTED;  // blind policies are not on the benchmarked path
+    if (d.rnn_type != HAB_RNN_GRU && d.rnn_type != HAB_RNN_LSTM) return HAB_ERR_ARG;
+    const int H = d.hidden;
+    e->G_ = d.rnn_type == HAB_RNN_GRU ? 3 : 4;
+    e->L = d.rnn_layers;
+    // SimpleCNN (rl/models/simple_cnn.py:68-93)
+    e->c1 = ConvDesc{0, d.H, d.W, e->Cin, 32, 8, 8, 4, 0};
+    e->c2 = ConvDesc{0, conv_out(d.H, 8, 4, 0), conv_out(d.W, 8, 4, 0), 32, 64, 4, 4, 2, 0};
+    e->c3 = ConvDesc{0, e->c2.Ho(), e->c2.Wo(), 64, 32, 3, 3, 1, 0};
+    const int h3 = e->c3.Ho(), w3 = e->c3.Wo();
+    if (h3 <= 0 || w3 <= 0) return HAB_ERR_ARG;
+    e->fc_in = 32 * h3 * w3;
+    e->rnn_in = H + d.goal_dim;
+    e->rnn_ld = (e->rnn_in + 3) & ~3;
+    const std::string ve = "net.visual_encoder.cnn.";
+    e->i_c1w = add_param(e, ve + "0.weight", {32, e->Cin, 8, 8});
+    e->i_c1b = add_param(e, ve + "0.bias", {32});
+    e->i_c2w = add_param(e, ve + "2.weight", {64, 32, 4, 4});
+    e->i_c2b = add_param(e, ve + "2.bias", {64});
+    e->i_c3w = add_param(e, ve + "4.weight", {32, 64, 3, 3});
+    e->i_c3b = add_param(e, ve + "4.bias", {32});
+    e->i_fcw = add_param(e, ve + "6.weight", {H, e->fc_in});
+    e->i_fcb = add_param(e, ve + "6.bias", {H});
+    const std::string rn = "net.state_encoder.rnn.";
+    for (int l = 0; l < d.rnn_layers; ++l) {
+        const int in = l == 0 ? e->rnn_in : H;
+        const std::string sfx = "_l" + std::to_string(l);
+        e->i_wih.push_back(add_param(e, rn + "weight_ih" + sfx, {e->G_ * H, in}));
+        e->i_whh.push_back(add_param(e, rn + "weight_hh" + sfx, {e->G_ * H, H}));
+        e->i_bih.push_back(add_param(e, rn + "bias_ih" + sfx, {e->G_ * H}));
+        e->i_bhh.push_back(add_param(e, rn + "bias_hh" + sfx, {e->G_ * H}));
+    }
+    e->i_aw = add_param(e, "action_distribution.linear.weight", {d.num_actions, H});
+    e->i_ab = add_param(e, "action_distribution.linear.bias", {d.num_actions});
+    e->i_cw = add_param(e, "critic.fc.weight", {1, H});
+    e->i_cb = add_param(e, "critic.fc.bias", {1});
+
+    Arena pk;
+    e->pk_c1f = pk.take(32 * 64 * e->Cin);
+    e->pk_c2f = pk.take(64 * 16 * 32);
+    e->pk_c2d = pk.take(64 * 16 * 32);
+    e->pk_c3f = pk.take(32 * 9 * 64);
+    e->pk_c3d = pk.take(32 * 9 * 64);
+    e->pk_fc = pk.take((int64_t)H * e->fc_in);
+    for (int l = 0; l < d.rnn_layers; ++l) e->pk_whht.push_back(pk.take((int64_t)e->G_ * H * H));
+    e->packed_floats = pk.used;
+
+    Arena wk;
+    const int64_t B = d.max_frames;
+    const int64_t F = d.max_frames;  // worst case: every frame its own fragment
+    const int64_t m1 = (int64_t)e->c1.Ho() * e->c1.Wo() * 32, m2 = (int64_t)e->c2.Ho() * e->c2.Wo() * 64, m3 = e->fc_in;
+    e->w_a1 = wk.take(B * m1); e->w_a2 = wk.take(B * m2); e->w_a3 = wk.take(B * m3);
+    e->w_da1 = wk.take(B * m1); e->w_da2 = wk.take(B * m2); e->w_da3 = wk.take(B * m3);
+    e->w_rnnin = wk.take(B * e->rnn_ld); e->w_drnnin = wk.take(B * e->rnn_ld);
+    e->w_hinit = wk.take((int64_t)d.rnn_layers * F * H); e->w_cinit = wk.take((int64_t)d.rnn_layers * F * H);
+    for (int l = 0; l < d.rnn_layers; ++l) {
+        e->w_gi.push_back(wk.take(B * e->G_ * H)); e->w_gates.push_back(wk.take(B * e->G_ * H));
+        e->w_hn.push_back(wk.take(B * H)); e->w_hprev.push_back(wk.take(B * H));
+        e->w_cprev.push_back(wk.take(B * H)); e->w_c.push_back(wk.take(B * H)); e->w_out.push_back(wk.take(B * H));
+        e->w_dgi.push_back(wk.take(B * e->G_ * H)); e->w_dgh.push_back(wk.take(B * e->G_ * H));
+        e->w_dlayer.push_back(wk.take(B * H));
+    }
+    e->w_probs = wk.take(B * 8); e->w_logitsn = wk.take(B * 8); e->w_dzv = wk.take(B * 8); e->w_dv = wk.take(B);
+    e->w_dfeat = wk.take(B * H); e->w_scratch = wk.take(3 * F * H);
+    e->w_value = wk.take(B); e->w_logp = wk.take(B); e->w_ent = wk.take(B);
+    e->w_hmask = wk.take((int64_t)2 * d.rnn_layers * d.max_envs * H);
+    e->w_gistep = wk.take((int64_t)d.max_envs * e->G_ * H);
+    e->w_step_h = wk.take((int64_t)d.max_envs * H * 2);
+    // split-K / column-sum scratch: big enough for 64 slabs of the largest weight-gradient (fc) or 1024 colsum rows
+    e->ws_floats = std::max<int64_t>((int64_t)16 << 20, (int64_t)8 * H * e->fc_in / 4);
+    e->w_ws = wk.take(e->ws_floats);
+    e->work_floats = wk.used;
+    return HAB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int hab_policy_create(const hab_policy_desc* desc, hab_policy** out) {
+    if (!desc || !out) return HAB_ERR_ARG;
+    if (desc->hidden <= 0 || desc->hidden % 64 || desc->num_actions <= 0 || desc->num_actions > 8 || desc->max_frames <= 0 ||
+        desc->max_envs <= 0 || desc->rnn_layers <= 0 || desc->H <= 0 || desc->W <= 0 || desc->goal_dim < 0)
+        return HAB_ERR_ARG;
+    hab_policy* e = new hab_policy();
+    e->d = *desc;
+    int rc = HAB_ERR_UNSUPPORTED;
+    if (desc->arch == HAB_ARCH_SIMPLE_CNN) rc = build_baseline(e);
+    if (rc != HAB_OK) { delete e; return rc; }
+    *out = e;
+    return HAB_OK;
+}
+extern "C" void hab_policy_destroy(hab_policy* e) {
+    if (!e) return;
+    for (auto& ev : e->probe_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    delete e;
+}
+extern "C" int hab_policy_num_params(const hab_policy* e) { return e ? (int)e->params.size() : HAB_ERR_ARG; }
+extern "C" int hab_policy_param_info(const hab_policy* e, int i, char* name, int name_cap, int64_t* shape4, int* ndim,
+                                     int64_t* offset_floats) {
+    if (!e || i < 0 || i >= (int)e->params.size() || !name || name_cap <= 0) return HAB_ERR_ARG;
+    const ParamSpec& s = e->params[i];
+    strncpy(name, s.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = s.shape[k];
+    if (ndim) *ndim = s.ndim;
+    if (offset_floats) *offset_floats = s.offset;
+    return HAB_OK;
+}
+extern "C" int64_t hab_policy_param_floats(const hab_policy* e) { return e ? e->param_floats : -1; }
+extern "C" int64_t hab_policy_packed_floats(const hab_policy* e) { return e ? e->packed_floats : -1; }
+extern "C" int64_t hab_policy_work_floats(const hab_policy* e) { return e ? e->work_floats : -1; }
+
+extern "C" int hab_policy_bind(hab_policy* e, float* params, float* grads, float* packed, float* work, int64_t work_floats) {
+    if (!e || !params || !packed || !work) return HAB_ERR_ARG;
+    if (work_floats < e->work_floats) return HAB_ERR_ARG;
+    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)packed | (uintptr_t)work) & 255) != 0) return HAB_ERR_ARG;
+    e->P = params; e->G = grads; e->PK = packed; e->WK = work; e->work_bound = work_floats;
+    return HAB_OK;
+}
+
+// Re-derive the kernel-layout weight copies from the master parameters (call after every change
+// of the parameters: optimiser step, load_state_dict, broadcast).
+extern "C" int hab_policy_repack(hab_policy* e, hipStream_t stream) {
+    if (!e || !e->P) return HAB_ERR_ARG;
+    const int H = e->d.hidden;
+    HAB_TRY(repack_conv(e->p(e->i_c1w), e->PK + e->pk_c1f, nullptr, 32, e->Cin, 8, 8, e->Cin, stream));
+    HAB_TRY(repack_conv(e->p(e->i_c2w), e->PK + e->pk_c2f, e->PK + e->pk_c2d, 64, 32, 4, 4, 32, stream));
+    HAB_TRY(repack_conv(e->p(e->i_c3w), e->PK + e->pk_c3f, e->PK + e->pk_c3d, 32, 64, 3, 3, 64, stream));
+    HAB_TRY(repack_flatten(e->p(e->i_fcw), e->PK + e->pk_fc, H, 32, e->fc_in / 32, stream));
+    for (int l = 0; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_whh[l]), e->PK + e->pk_whht[l], e->G_ * H, H, stream));
+    return HAB_OK;
+}
+
+// ---- probes: HIP-event timing of one tagged kernel call site (bench.py's roofline leg) ----
+extern "C" int hab_policy_probe_enable(hab_policy* e, int tag) {
+    if (!e) return HAB_ERR_ARG;
+    e->probe_tag = tag;
+    e->probe_used = 0;
+    return HAB_OK;
+}
+extern "C" int hab_policy_probe_read(hab_policy* e, double* total_ms, int* count) {
+    if (!e || !total_ms || !count) return HAB_ERR_ARG;
+    double t = 0;
+    for (size_t i = 0; i < e->probe_used; ++i) {
+        hipError_t err = hipEventSynchronize(e->probe_events[i].second);
+        if (err != hipSuccess) return (int)err;
+        float ms = 0;
+        err = hipEventElapsedTime(&ms, e->probe_events[i].first, e->probe_events[i].second);
+        if (err != hipSuccess) return (int)err;
+        t += ms;
+    }
+    *total_ms = t;
+    *count = (int)e->probe_used;
+    e->probe_used = 0;
+    return HAB_OK;
+}
+namespace {
+struct Probe {
+    hab_policy* e; hipStream_t s; bool on;
+    Probe(hab_policy* e_, int tag, hipStream_t s_) : e(e_), s(s_), on(e_->probe_tag == tag) {
+        if (!on) return;
+        if (e->probe_used == e->probe_events.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a); hipEventCreate(&b);
+            e->probe_events.push_back({a, b});
+        }
+        hipEventRecord(e->probe_events[e->probe_used].first, s);
+    }
+    ~Probe() {
+        if (!on) return;
+        hipEventRecord(e->probe_events[e->probe_used].second, s);
+        e->probe_used++;
+    }
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// Encoder forward on B frames (shared by act / evaluate): obs -> rnn_in[B][rnn_ld]
+// ------------------------------------------------------------------------------------------
+static int encoder_forward(hab_policy* e, const hab_obs* obs, const int* rows, int B, hipStream_t s) {
+    float* W = e->WK;
+    float* ws = W + e->w_ws;
+    const int H = e->d.hidden;
+    ObsView ov;
+    ov.rgb = e->d.has_rgb ? obs->rgb : nullptr; ov.depth = e->d.has_depth ? obs->depth : nullptr; ov.rows = rows;
+    ov.H = e->d.H; ov.W = e->d.W; ov.C = e->Cin;
+    ConvDesc c1 = e->c1, c2 = e->c2, c3 = e->c3;
+    c1.B = c2.B = c3.B = B;
+    { Probe pr(e, HAB_PROBE_CONV1_FWD, s);
+      HAB_TRY(obs_conv_fwd(c1, ov, e->PK + e->pk_c1f, e->p(e->i_c1b), W + e->w_a1, 1, ws, e->ws_floats, s)); }
+    { Probe pr(e, HAB_PROBE_CONV2_FWD, s);
+      HAB_TRY(conv_fwd(c2, W + e->w_a1, e->PK + e->pk_c2f, e->p(e->i_c2b), W + e->w_a2, 1, ws, e->ws_floats, s)); }
+    { Probe pr(e, HAB_PROBE_CONV3_FWD, s);
+      HAB_TRY(conv_fwd(c3, W + e->w_a2, e->PK + e->pk_c3f, e->p(e->i_c3b), W + e->w_a3, 0, ws, e->ws_floats, s)); }
+    { Probe pr(e, HAB_PROBE_FC_FWD, s);
+      HAB_TRY(linear_fwd(W + e->w_a3, e->fc_in, e->PK + e->pk_fc, e->fc_in, e->p(e->i_fcb), W + e->w_rnnin, e->rnn_ld, B, H,
+                         e->fc_in, 1, 0, ws, e->ws_floats, s)); }
+    if (e->d.goal_dim > 0)
+        HAB_TRY(gather_cols(obs->goal, e->d.goal_dim, rows, W + e->w_rnnin, e->rnn_ld, H, e->d.goal_dim,
+                            e->rnn_ld - e->rnn_in, B, s));
+    return HAB_OK;
+}
+
+static RnnLayerParams layer_params(hab_policy* e, int l) {
+    RnnLayerParams lp;
+    lp.w_ih = e->p(e->i_wih[l]); lp.w_hh = e->p(e->i_whh[l]); lp.b_ih = e->p(e->i_bih[l]); lp.b_hh = e->p(e->i_bhh[l]);
+    lp.w_hh_t = e->PK + e->pk_whht[l];
+    if (e->G) { lp.dw_ih = e->g(e->i_wih[l]); lp.dw_hh = e->g(e->i_whh[l]); lp.db_ih = e->g(e->i_bih[l]); lp.db_hh = e->g(e->i_bhh[l]); }
+    else { lp.dw_ih = lp.dw_hh = lp.db_ih = lp.db_hh = nullptr; }
+    lp.in_dim = l == 0 ? e->rnn_in : e->d.hidden;
+    return lp;
+}
+static RnnWork layer_work(hab_policy* e, int l) {
+    float* W = e->WK;
+    RnnWork wk;
+    wk.gi = W + e->w_gi[l]; wk.gates = W + e->w_gates[l]; wk.hn = W + e->w_hn[l]; wk.hprev = W + e->w_hprev[l];
+    wk.cprev = W + e->w_cprev[l]; wk.c = W + e->w_c[l]; wk.out = W + e->w_out[l]; wk.dgi = W + e->w_dgi[l];
+    wk.dgh = W + e->w_dgh[l];
+    return wk;
+}
+
+// ------------------------------------------------------------------------------------------
+// NetPolicy.act / get_value (rl/ppo/policy.py:324-359) on n envs, all tensors dense over envs.
+// hidden_in/out: (n, Lh, H) with Lh = layers (GRU) or 2*layers (LSTM: h layers then c layers).
+// ------------------------------------------------------------------------------------------
+extern "C" int hab_policy_act(hab_policy* e, const hab_obs* obs, const float* hidden_in, const uint8_t* masks,
+                              const float* exp_noise, int deterministic, int n, float* values, int64_t* actions,
+                              float* action_log_probs, float* hidden_out, float* probs_out, hipStream_t stream) {
+    if (!e || !e->P || !obs || !hidden_in || !masks || !values || n <= 0 || n > e->d.max_envs) return HAB_ERR_ARG;
+    float* W = e->WK;
+    const int H = e->d.hidden, L = e->L;
+    const int Lh = e->d.rnn_type == HAB_RNN_LSTM ? 2 * L : L;
+    HAB_TRY(encoder_forward(e, obs, nullptr, n, stream));
+    const float* x = W + e->w_rnnin;
+    int ldx = e->rnn_ld;
+    float* hm = W + e->w_hmask;  // [2L][n][H] masked h (and c)
+    for (int l = 0; l < L; ++l) {
+        HAB_TRY(masked_rows(hidden_in + (size_t)l * H, Lh * H, masks, hm + (size_t)l * n * H, n, H, stream));
+        if (e->d.rnn_type == HAB_RNN_LSTM)
+            HAB_TRY(masked_rows(hidden_in + (size_t)(L + l) * H, Lh * H, masks, hm + (size_t)(L + l) * n * H, n, H, stream));
+    }
+    float* step_h = W + e->w_step_h;
+    for (int l = 0; l < L; ++l) {
+        RnnLayerParams lp = layer_params(e, l);
+        float* hout = hidden_out ? hidden_out + (size_t)l * H : step_h + (size_t)(l & 1) * n * H;
+        const int hstride = hidden_out ? Lh * H : H;
+        float* cout = (hidden_out && e->d.rnn_type == HAB_RNN_LSTM) ? hidden_out + (size_t)(L + l) * H : nullptr;
+        HAB_TRY(rnn_step_layer_forward(e->d.rnn_type, H, lp, x, ldx, hm + (size_t)l * n * H,
+                                       e->d.rnn_type == HAB_RNN_LSTM ? hm + (size_t)(L + l) * n * H : nullptr, n,
+                                       W + e->w_gistep, hout, hstride, cout, Lh * H, W + e->w_ws, e->ws_floats, stream));
+        // next layer's input: dense copy of this layer's output
+        float* dense = step_h + (size_t)(l & 1) * n * H;
+        if (hidden_out) HAB_TRY(copy_rows(hout, nullptr, hstride, dense, H, n, H, stream));
+        x = dense;
+        ldx = H;
+    }
+    HeadsArgs ha;
+    ha.B = n; ha.H = H; ha.A = e->d.num_actions;
+    ha.mode = actions ? (deterministic ? 2 : 1) : 2;
+    ha.feats = x; ha.w_actor = e->p(e->i_aw); ha.b_actor = e->p(e->i_ab); ha.w_critic = e->p(e->i_cw); ha.b_critic = e->p(e->i_cb);
+    ha.actions_in = nullptr; ha.rows = nullptr; ha.noise = exp_noise;
+    ha.actions_out = actions ? actions : reinterpret_cast<int64_t*>(W + e->w_dzv);
+    ha.value = values; ha.logp = action_log_probs ? action_log_probs : W + e->w_logp; ha.entropy = nullptr;
+    ha.probs = probs_out ? W + e->w_probs : nullptr; ha.logits_n = W + e->w_logitsn;
+    if (ha.mode == 1 && !exp_noise) return HAB_ERR_ARG;
+    HAB_TRY(heads_forward(ha, stream));
+    if (probs_out) HAB_TRY(copy_rows(W + e->w_probs, nullptr, 8, probs_out, 8, n, 8, stream));
+    return HAB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// NetPolicy.evaluate_actions (rl/ppo/policy.py:361-402) on B = T*n frames gathered from the
+// rollout arena through rows[f]; activations are kept for hab_policy_backward.
+// ------------------------------------------------------------------------------------------
+extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int* rows, const float* hidden0,
+                                   int hidden_env_stride, const uint8_t* masks, const int64_t* actions,
+                                   const hab_pack_info* pack, int B, int n, float* value, float* log_prob, float* entropy,
+                                   hipStream_t stream) {
+    if (!e || !e->P || !obs || !hidden0 || !masks || !actions || !pack || B <= 0 || n <= 0 || B > e->d.max_frames || B % n)
+        return HAB_ERR_ARG;
+    if (pack->P != B || pack->F <= 0 || pack->F > B || pack->max_len <= 0) return HAB_ERR_ARG;
+    float* W = e->WK;
+    const int H = e->d.hidden, L = e->L;
+    HAB_TRY(encoder_forward(e, obs, rows, B, stream));
+    PackInfo pk;
+    pk.select_inds = pack->select_inds; pk.step_offsets = pack->step_offsets_host; pk.num_seqs_at_step = pack->num_seqs_at_step_host;
+    pk.frag_env = pack->frag_env; pk.frag_start = pack->frag_start; pk.P = pack->P; pk.F = pack->F; pk.max_len = pack->max_len;
+    pk.n_envs = n;
+    const float* x = W + e->w_rnnin;
+    int ldx = e->rnn_ld;
+    for (int l = 0; l < L; ++l) {
+        float* hinit = W + e->w_hinit + (size_t)l * pk.F * H;
+        float* cinit = W + e->w_cinit + (size_t)l * pk.F * H;
+        // env j of the minibatch is frame j (t = 0); its arena row is rows[j]
+        HAB_TRY(rnn_frag_init(hidden0 + (size_t)l * H, rows, hidden_env_stride, masks, rows, pk.frag_env, pk.frag_start, pk.F, H,
+                              hinit, stream));
+        if (e->d.rnn_type == HAB_RNN_LSTM)
+            HAB_TRY(rnn_frag_init(hidden0 + (size_t)(L + l) * H, rows, hidden_env_stride, masks, rows, pk.frag_env,
+                                  pk.frag_start, pk.F, H, cinit, stream));
+        RnnLayerParams lp = layer_params(e, l);
+        RnnWork wk = layer_work(e, l);
+        HAB_TRY(rnn_seq_layer_forward(e->d.rnn_type, H, lp, wk, x, ldx, hinit, cinit, pk, W + e->w_ws, e->ws_floats, stream));
+        x = wk.out;
+        ldx = H;
+    }
+    HeadsArgs ha;
+    ha.B = B; ha.H = H; ha.A = e->d.num_actions; ha.mode = 0;
+    ha.feats = x; ha.w_actor = e->p(e->i_aw); ha.b_actor = e->p(e->i_ab); ha.w_critic = e->p(e->i_cw); ha.b_critic = e->p(e->i_cb);
+    ha.actions_in = actions; ha.rows = rows; ha.noise = nullptr; ha.actions_out = nullptr;
+    ha.value = value ? value : W + e->w_value; ha.logp = log_prob ? log_prob : W + e->w_logp;
+    ha.entropy = entropy ? entropy : W + e->w_ent;
+    ha.probs = W + e->w_probs; ha.logits_n = W + e->w_logitsn;
+    HAB_TRY(heads_forward(ha, stream));
+    e->last_B = B;
+    e->last_n = n;
+    return HAB_OK;
+}
+
+// Final hidden state of the last evaluate: (n, Lh, H) -- rnn_state_encoder.py:262-275.
+extern "C" int hab_policy_final_hidden(hab_policy* e, float* hidden_out, hipStream_t stream) {
+    if (!e || !hidden_out || e->last_B <= 0) return HAB_ERR_ARG;
+    const int H = e->d.hidden, L = e->L, n = e->last_n, B = e->last_B;
+    const int Lh = e->d.rnn_type == HAB_RNN_LSTM ? 2 * L : L;
+    for (int l = 0; l < L; ++l) {
+        HAB_TRY(copy_rows(e->WK + e->w_out[l] + (size_t)(B - n) * H, nullptr, H, hidden_out + (size_t)l * H, Lh * H, n, H, stream));
+        if (e->d.rnn_type == HAB_RNN_LSTM)
+            HAB_TRY(copy_rows(e->WK + e->w_c[l] + (size_t)(B - n) * H, nullptr, H, hidden_out + (size_t)(L + l) * H, Lh * H, n, H, stream));
+    }
+    return HAB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward of the last hab_policy_evaluate: given dL/dvalue, dL/dlog_prob, dL/dentropy per frame,
+// writes EVERY parameter gradient into the gradient arena (overwrites; no accumulation).
+// ------------------------------------------------------------------------------------------
+extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int* rows, const int64_t* actions,
+                                   const hab_pack_info* pack, const float* d_value, const float* d_log_prob,
+                                   const float* d_entropy, hipStream_t stream) {
+    if (!e || !e->P || !e->G || !obs || !actions || !pack || !d_value || !d_log_prob || !d_entropy || e->last_B <= 0)
+        return HAB_ERR_ARG;
+    float* W = e->WK;
+    float* ws = W + e->w_ws;
+    const int H = e->d.hidden, L = e->L, B = e->last_B, A = e->d.num_actions;
+    PackInfo pk;
+    pk.select_inds = pack->select_inds; pk.step_offsets = pack->step_offsets_host; pk.num_seqs_at_step = pack->num_seqs_at_step_host;
+    pk.frag_env = pack->frag_env; pk.frag_start = pack->frag_start; pk.P = pack->P; pk.F = pack->F; pk.max_len = pack->max_len;
+    pk.n_envs = e->last_n;
+    const float* feats = W + e->w_out[L - 1];
+    HeadsBwdArgs hb;
+    hb.B = B; hb.H = H; hb.A = A; hb.d_value = d_value; hb.d_logp = d_log_prob; hb.d_entropy = d_entropy;
+    hb.actions = actions; hb.rows = rows; hb.probs = W + e->w_probs; hb.logits_n = W + e->w_logitsn;
+    hb.w_actor = e->p(e->i_aw); hb.w_critic = e->p(e->i_cw); hb.dfeat = W + e->w_dfeat; hb.dzv = W + e->w_dzv; hb.dv_out = W + e->w_dv;
+    HAB_TRY(heads_backward(hb, stream));
+    HAB_TRY(linear_wgrad(W + e->w_dzv, 8, feats, H, e->g(e->i_aw), H, B, A, H, 0, 0, 0, ws, e->ws_floats, stream));
+    HAB_TRY(linear_wgrad(W + e->w_dv, 1, feats, H, e->g(e->i_cw), H, B, 1, H, 0, 0, 0, ws, e->ws_floats, stream));
+    HAB_TRY(colsum(W + e->w_dzv, 8, B, A, e->g(e->i_ab), 0, ws, e->ws_floats, stream));
+    HAB_TRY(colsum(W + e->w_dv, 1, B, 1, e->g(e->i_cb), 0, ws, e->ws_floats, stream));
+    // recurrent layers, top down
+    const float* dout = W + e->w_dfeat;
+    for (int l = L - 1; l >= 0; --l) {
+        RnnLayerParams lp = layer_params(e, l);
+        RnnWork wk = layer_work(e, l);
+        const float* x = l == 0 ? W + e->w_rnnin : W + e->w_out[l - 1];
+        const int ldx = l == 0 ? e->rnn_ld : H;
+        float* dx = l == 0 ? W + e->w_drnnin : W + e->w_dlayer[l];
+        const int lddx = l == 0 ? e->rnn_ld : H;
+        // layer 0: the first H columns of rnn_in are ReLU(fc) -> mask them here (fused ReLU backward)
+        HAB_TRY(rnn_seq_layer_backward(e->d.rnn_type, H, lp, wk, x, ldx, dout, dx, lddx, l == 0 ? x : nullptr, ldx, H, pk,
+                                       W + e->w_scratch, ws, e->ws_floats, stream));
+        dout = dx;
+    }
+    // fc (Flatten -> Linear -> ReLU): d_rnnin[:, :H] already carries the ReLU mask
+    const float* dfc = W + e->w_drnnin;
+    ConvDesc c1 = e->c1, c2 = e->c2, c3 = e->c3;
+    c1.B = c2.B = c3.B = B;
+    { Probe pr(e, HAB_PROBE_FC_WGRAD, stream);
+      HAB_TRY(linear_wgrad(dfc, e->rnn_ld, W + e->w_a3, e->fc_in, e->g(e->i_fcw), e->fc_in, B, H, e->fc_in, 32, e->fc_in / 32, 0,
+                           ws, e->ws_floats, stream)); }
+    HAB_TRY(colsum(dfc, e->rnn_ld, B, H, e->g(e->i_fcb), 0, ws, e->ws_floats, stream));
+    { Probe pr(e, HAB_PROBE_FC_DGRAD, stream);
+      HAB_TRY(linear_dgrad(dfc, e->rnn_ld, e->PK + e->pk_fc, e->fc_in, nullptr, 0, 0, W + e->w_da3, e->fc_in, B, e->fc_in, H, 0,
+                           ws, e->ws_floats, stream)); }
+    // conv3 (no ReLU after it; its input a2 is post-ReLU -> mask on the data gradient)
+    { Probe pr(e, HAB_PROBE_CONV3_WGRAD, stream);
+      HAB_TRY(conv_wgrad(c3, W + e->w_a2, W + e->w_da3, e->g(e->i_c3w), ws, e->ws_floats, stream)); }
+    HAB_TRY(colsum(W + e->w_da3, 32, B * c3.Ho() * c3.Wo(), 32, e->g(e->i_c3b), 0, ws, e->ws_floats, stream));
+    { Probe pr(e, HAB_PROBE_CONV3_DGRAD, stream);
+      HAB_TRY(conv_dgrad(c3, W + e->w_da3, e->PK + e->pk_c3d, W + e->w_a2, nullptr, W + e->w_da2, ws, e->ws_floats, stream)); }
+    { Probe pr(e, HAB_PROBE_CONV2_WGRAD, stream);
+      HAB_TRY(conv_wgrad(c2, W + e->w_a1, W + e->w_da2, e->g(e->i_c2w), ws, e->ws_floats, stream)); }
+    HAB_TRY(colsum(W + e->w_da2, 64, B * c2.Ho() * c2.Wo(), 64, e->g(e->i_c2b), 0, ws, e->ws_floats, stream));
+    { Probe pr(e, HAB_PROBE_CONV2_DGRAD, stream);
+      HAB_TRY(conv_dgrad(c2, W + e->w_da2, e->PK + e->pk_c2d, W + e->w_a1, nullptr, W + e->w_da1, ws, e->ws_floats, stream)); }
+    ObsView ov;
+    ov.rgb = e->d.has_rgb ? obs->rgb : nullptr; ov.depth = e->d.has_depth ? obs->depth : nullptr; ov.rows = rows;
+    ov.H = e->d.H; ov.W = e->d.W; ov.C = e->Cin;
+    { Probe pr(e, HAB_PROBE_CONV1_WGRAD, stream);
+      HAB_TRY(obs_conv_wgrad(c1, ov, W + e->w_da1, e->g(e->i_c1w), ws, e->ws_floats, stream)); }
+    HAB_TRY(colsum(W + e->w_da1, 32, B * c1.Ho() * c1.Wo(), 32, e->g(e->i_c1b), 0, ws, e->ws_floats, stream));
+    return HAB_OK;
+}
+
+// Debug / test taps into the activation workspace of the last evaluate.
+extern "C" int hab_policy_tap(hab_policy* e, int which, const float** ptr, int64_t* floats) {
+    if (!e || !ptr || !floats || e->last_B <= 0) return HAB_ERR_ARG;
+    const int64_t B = e->last_B;
+    float* W = e->WK;
+    switch (which) {
+        case HAB_TAP_CONV1: *ptr = W + e->w_a1; *floats = B * e->c1.Ho() * e->c1.Wo() * 32; break;
+        case HAB_TAP_CONV2: *ptr = W + e->w_a2; *floats = B * e->c2.Ho() * e->c2.Wo() * 64; break;
+        case HAB_TAP_CONV3: *ptr = W + e->w_a3; *floats = B * e->fc_in; break;
+        case HAB_TAP_RNN_IN: *ptr = W + e->w_rnnin; *floats = B * e->rnn_ld; break;
+        case HAB_TAP_RNN_OUT: *ptr = W + e->w_out[e->L - 1]; *floats = B * e->d.hidden; break;
+        default: return HAB_ERR_ARG;
+    }
+    return HAB_OK;
+}

@@ -1,0 +1,278 @@
+// gemm_ops.hip -- launchers that map conv / linear layers (fwd, dgrad, wgrad) onto igemm tiles,
+// plus the small HBM-bound helpers around them (weight repack, column sums for bias gradients).
+#include "igemm.h"
+#include "prob_build.h"
+#include "../../include/habitat_amd.h"
+
+namespace hab {
+
+// Tile choice by output width N (= Cout / out-features): tall-skinny tiles because the policy's
+// layers have N in 32..512 and M in 1e4..1e7.
+template <class P>
+static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream, int target_blocks = 1024) {
+    if (p.N <= 32) {
+        auto pl = igemm_plan<256, 32>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
+        if (p.M <= 64) {
+            auto pl2 = igemm_plan<64, 32>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
+            return igemm_launch<P, 1, 1, 2, 1>(p, pl2, ws, stream);
+        }
+        return igemm_launch<P, 2, 1, 4, 1>(p, pl, ws, stream);
+    } else if (p.N <= 64) {
+        if (p.M <= 64) {
+            auto pl2 = igemm_plan<64, 64>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
+            return igemm_launch<P, 1, 1, 2, 2>(p, pl2, ws, stream);
+        }
+        auto pl = igemm_plan<128, 64>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
+        return igemm_launch<P, 1, 2, 4, 1>(p, pl, ws, stream);
+    } else {
+        if (p.M <= 64) {
+            auto pl2 = igemm_plan<64, 128>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
+            return igemm_launch<P, 1, 2, 2, 2>(p, pl2, ws, stream);
+        }
+        auto pl = igemm_plan<128, 128>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
+        return igemm_launch<P, 2, 2, 2, 2>(p, pl, ws, stream);
+    }
+}
+
+int conv_fwd(const ConvDesc& d, const float* x, const float* wf, const float* bias, float* y, int relu, float* ws,
+             size_t ws_floats, hipStream_t stream) {
+    ConvFwdProb p;
+    HAB_TRY(build(p, d, x, wf, bias, y, relu));
+    return run_igemm(p, ws, ws_floats, stream);
+}
+int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const float* bias, float* y, int relu, float* ws,
+                 size_t ws_floats, hipStream_t stream) {
+    ObsConvFwdProb p;
+    HAB_TRY(build(p, d, obs, wf, bias, y, relu));
+    return run_igemm(p, ws, ws_floats, stream);
+}
+int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add, float* dx,
+               float* ws, size_t ws_floats, hipStream_t stream) {
+    ConvDgradProb p;
+    HAB_TRY(build(p, d, dy, wd, mask, add, dx));
+    return run_igemm(p, ws, ws_floats, stream);
+}
+int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_floats,
+               hipStream_t stream) {
+    ConvWgradProb p;
+    HAB_TRY(build(p, d, x, dy, dw_oihw));
+    return run_igemm(p, ws, ws_floats, stream);
+}
+int obs_conv_wgrad(const ConvDesc& d, const ObsView& obs, const float* dy, float* dw_oihw, float* ws, size_t ws_floats,
+                   hipStream_t stream) {
+    ObsConvWgradProb p;
+    HAB_TRY(build(p, d, obs, dy, dw_oihw));
+    return run_igemm(p, ws, ws_floats, stream);
+}
+int linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N, int K,
+               int relu, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+    LinearFwdProb p;
+    HAB_TRY(build(p, x, ldx, w, ldw, bias, y, ldy, M, N, K, relu, accumulate));
+    return run_igemm(p, ws, ws_floats, stream);
+}
+int linear_dgrad(const float* dy, int lddy, const float* w, int ldw, const float* mask, int ldmask, int mask_cols, float* dx,
+                 int lddx, int M, int Nin, int Kout, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+    LinearDgradProb p;
+    HAB_TRY(build(p, dy, lddy, w, ldw, mask, ldmask, mask_cols, dx, lddx, M, Nin, Kout, accumulate));
+    return run_igemm(p, ws, ws_floats, stream);
+}
+int linear_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int lddw, int Mrows, int Nout, int Kin,
+                 int perm_c, int perm_hw, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+    LinearWgradProb p;
+    HAB_TRY(build(p, dy, lddy, x, ldx, dw, lddw, Mrows, Nout, Kin, perm_c, perm_hw, accumulate));
+    return run_igemm(p, ws, ws_floats, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums (bias gradients): out[n] = sum_m a[m][n] * (mask ? mask[m][n] > 0 : 1).
+// Stage 1: each block reduces a row range into partial[block][N]; stage 2: fixed-order sum.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ a, int lda, int M, int N, int rows_per_block,
+                                                     float* __restrict__ partial) {
+    // thread layout: 256 threads = (256/cw) row lanes x cw columns, cw = min(N rounded, 64)
+    const int cw = N < 64 ? N : 64;
+    const int rl = 256 / cw;
+    const int c = threadIdx.x % cw, r = threadIdx.x / cw;
+    __shared__ float sm[256];
+    const int m_begin = blockIdx.x * rows_per_block, m_end = min(M, m_begin + rows_per_block);
+    for (int c0 = 0; c0 < N; c0 += cw) {
+        float s = 0.f;
+        if (r < rl && c0 + c < N)
+            for (int m = m_begin + r; m < m_end; m += rl) s += a[(size_t)m * lda + c0 + c];
+        sm[threadIdx.x] = (r < rl) ? s : 0.f;
+        __syncthreads();
+        if (r == 0 && c0 + c < N) {
+            float t = 0.f;
+            for (int q = 0; q < rl; ++q) t += sm[q * cw + c];
+            partial[(size_t)blockIdx.x * N + c0 + c] = t;
+        }
+        __syncthreads();
+    }
+}
+__global__ void colsum_stage2(const float* __restrict__ partial, int nblocks, int N, float* __restrict__ out, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+int colsum(const float* a, int lda, int M, int N, float* out, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || !a || !out || !ws) return HAB_ERR_ARG;
+    int blocks = cdiv(M, 512);
+    if (blocks > 1024) blocks = 1024;
+    while (blocks > 1 && (size_t)blocks * N > ws_floats) blocks >>= 1;
+    if ((size_t)blocks * N > ws_floats) return HAB_ERR_ARG;
+    const int rpb = cdiv(M, blocks);
+    blocks = cdiv(M, rpb);
+    colsum_stage1<<<blocks, 256, 0, stream>>>(a, lda, M, N, rpb, ws);
+    HAB_LAUNCH_CHECK();
+    colsum_stage2<<<cdiv(N, 64), 64, 0, stream>>>(ws, blocks, N, out, accumulate);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight repack: OIHW master -> Wf[co][(kh,kw,ci)] and Wd[ci][(kh,kw,co)].  cpad >= Cin pads the
+// packed input-channel dimension with zeros (stem conv: 4/5 obs channels -> 4/8).
+// ---------------------------------------------------------------------------------------------
+__global__ void repack_conv_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd, int Cout,
+                                   int Cin, int KH, int KW, int cpad) {
+    const int total = Cout * cpad * KH * KW;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        // e enumerates Wf: [co][kh][kw][ci(cpad)]
+        const int ci = e % cpad;
+        int t = e / cpad;
+        const int kw = t % KW; t /= KW;
+        const int kh = t % KH;
+        const int co = t / KH;
+        const float v = (ci < Cin) ? w[(((size_t)co * Cin + ci) * KH + kh) * KW + kw] : 0.f;
+        if (wf) wf[e] = v;
+        if (wd && ci < Cin) wd[(((size_t)ci * KH + kh) * KW + kw) * Cout + co] = v;
+    }
+}
+
+int repack_conv(const float* w_oihw, float* wf, float* wd, int Cout, int Cin, int KH, int KW, int cpad, hipStream_t stream) {
+    if (!w_oihw || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || cpad < Cin) return HAB_ERR_ARG;
+    if (wd && cpad != Cin) return HAB_ERR_UNSUPPORTED;
+    const int total = Cout * cpad * KH * KW;
+    repack_conv_kernel<<<min(1024, cdiv(total, 256)), 256, 0, stream>>>(w_oihw, wf, wd, Cout, Cin, KH, KW, cpad);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// Linear weight after nn.Flatten of an NCHW tensor: Wp[n][hw*C + c] = W[n][c*HW + hw].
+__global__ void repack_flatten_kernel(const float* __restrict__ w, float* __restrict__ wp, int N, int C, int HW) {
+    const size_t total = (size_t)N * C * HW;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const size_t t = e / C;
+        const int hw = (int)(t % HW);
+        const size_t n = t / HW;
+        wp[e] = w[(n * C + c) * HW + hw];
+    }
+}
+int repack_flatten(const float* w, float* wp, int N, int C, int HW, hipStream_t stream) {
+    if (!w || !wp || N <= 0 || C <= 0 || HW <= 0) return HAB_ERR_ARG;
+    const size_t total = (size_t)N * C * HW;
+    repack_flatten_kernel<<<(int)fmin(4096.0, (double)cdivl((long long)total, 256)), 256, 0, stream>>>(w, wp, N, C, HW);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// Transposed copy: wt[c][r] = w[r][c]   (RNN recurrent weights for the BPTT mat-vec)
+__global__ void transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int R, int C) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = by + j, c = bx + threadIdx.x;
+        tile[j][threadIdx.x] = (r < R && c < C) ? w[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (c < C && r < R) wt[(size_t)c * R + r] = tile[threadIdx.x][j];
+    }
+}
+int transpose2d(const float* w, float* wt, int R, int C, hipStream_t stream) {
+    if (!w || !wt || R <= 0 || C <= 0) return HAB_ERR_ARG;
+    transpose_kernel<<<dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, stream>>>(w, wt, R, C);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+}  // namespace hab
+
+// ------------------------------------------- C ABI -------------------------------------------
+using namespace hab;
+
+static ConvDesc mk(int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad) {
+    ConvDesc d;
+    d.B = B; d.H = H; d.W = W; d.C = C; d.Cout = Cout; d.KH = KH; d.KW = KW; d.stride = stride; d.pad = pad;
+    return d;
+}
+static ObsView mkobs(const uint8_t* rgb, const float* depth, const int* rows, int H, int W) {
+    ObsView o;
+    o.rgb = rgb; o.depth = depth; o.rows = rows; o.H = H; o.W = W; o.C = (rgb ? 3 : 0) + (depth ? 1 : 0);
+    return o;
+}
+
+extern "C" int hab_conv2d_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int H, int W, int C,
+                              int Cout, int KH, int KW, int stride, int pad, int relu, float* ws, size_t ws_floats,
+                              hipStream_t stream) {
+    if (!x || !w_fwd || !y) return HAB_ERR_ARG;
+    return conv_fwd(mk(B, H, W, C, Cout, KH, KW, stride, pad), x, w_fwd, bias, y, relu, ws, ws_floats, stream);
+}
+extern "C" int hab_obs_conv2d_fwd(const uint8_t* rgb, const float* depth, const int* rows, const float* w_fwd,
+                                  const float* bias, float* y, int B, int H, int W, int Cout, int KH, int KW, int stride,
+                                  int pad, int relu, float* ws, size_t ws_floats, hipStream_t stream) {
+    if ((!rgb && !depth) || !w_fwd || !y) return HAB_ERR_ARG;
+    ObsView o = mkobs(rgb, depth, rows, H, W);
+    return obs_conv_fwd(mk(B, H, W, o.C, Cout, KH, KW, stride, pad), o, w_fwd, bias, y, relu, ws, ws_floats, stream);
+}
+extern "C" int hab_conv2d_dgrad(const float* dy, const float* w_dgrad, const float* relu_mask, const float* add, float* dx,
+                                int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                                size_t ws_floats, hipStream_t stream) {
+    if (!dy || !w_dgrad || !dx) return HAB_ERR_ARG;
+    return conv_dgrad(mk(B, H, W, C, Cout, KH, KW, stride, pad), dy, w_dgrad, relu_mask, add, dx, ws, ws_floats, stream);
+}
+extern "C" int hab_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int C, int Cout, int KH,
+                                int KW, int stride, int pad, float* ws, size_t ws_floats, hipStream_t stream) {
+    if (!x || !dy || !dw_oihw) return HAB_ERR_ARG;
+    return conv_wgrad(mk(B, H, W, C, Cout, KH, KW, stride, pad), x, dy, dw_oihw, ws, ws_floats, stream);
+}
+extern "C" int hab_obs_conv2d_wgrad(const uint8_t* rgb, const float* depth, const int* rows, const float* dy, float* dw_oihw,
+                                    int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                                    size_t ws_floats, hipStream_t stream) {
+    if ((!rgb && !depth) || !dy || !dw_oihw) return HAB_ERR_ARG;
+    ObsView o = mkobs(rgb, depth, rows, H, W);
+    return obs_conv_wgrad(mk(B, H, W, o.C, Cout, KH, KW, stride, pad), o, dy, dw_oihw, ws, ws_floats, stream);
+}
+extern "C" int hab_linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M,
+                              int N, int K, int relu, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
+    return linear_fwd(x, ldx, w, ldw, bias, y, ldy, M, N, K, relu, accumulate, ws, ws_floats, stream);
+}
+extern "C" int hab_linear_dgrad(const float* dy, int lddy, const float* w, int ldw, const float* relu_mask, int ldmask,
+                                float* dx, int lddx, int M, int n_in, int n_out, int accumulate, float* ws, size_t ws_floats,
+                                hipStream_t stream) {
+    return linear_dgrad(dy, lddy, w, ldw, relu_mask, ldmask, n_in, dx, lddx, M, n_in, n_out, accumulate, ws, ws_floats, stream);
+}
+extern "C" int hab_linear_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int lddw, int M, int n_out,
+                                int n_in, int perm_c, int perm_hw, int accumulate, float* ws, size_t ws_floats,
+                                hipStream_t stream) {
+    return linear_wgrad(dy, lddy, x, ldx, dw, lddw, M, n_out, n_in, perm_c, perm_hw, accumulate, ws, ws_floats, stream);
+}
+extern "C" int hab_colsum(const float* a, int lda, int M, int N, float* out, int accumulate, float* ws, size_t ws_floats,
+                          hipStream_t stream) {
+    return colsum(a, lda, M, N, out, accumulate, ws, ws_floats, stream);
+}
+extern "C" int hab_repack_conv_weight(const float* w_oihw, float* w_fwd, float* w_dgrad, int Cout, int Cin, int KH, int KW,
+                                      int cin_padded, hipStream_t stream) {
+    return repack_conv(w_oihw, w_fwd, w_dgrad, Cout, Cin, KH, KW, cin_padded, stream);
+}
+extern "C" int hab_repack_flatten_weight(const float* w, float* w_packed, int N, int C, int HW, hipStream_t stream) {
+    return repack_flatten(w, w_packed, N, C, HW, stream);
+}
+extern "C" int hab_transpose2d(const float* w, float* wt, int R, int C, hipStream_t stream) {
+    return transpose2d(w, wt, R, C, stream);
+}

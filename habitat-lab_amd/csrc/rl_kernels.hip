@@ -1,0 +1,482 @@
+// RL-side kernels of the DD-PPO hot path for gfx950: synthetic observation source, GAE,
+// advantage statistics, fused PPO loss fwd+bwd, global-norm clip + Adam, action sampling.
+// All of these are HBM/latency-bound fp32 work (no MFMA): coalesced (T+1,N,*) row accesses,
+// wave shuffles for the reductions, one launch each.
+#include "hab_common.h"
+#include "../../include/habitat_amd.h"
+
+using namespace hab;
+
+// ------------------------------------------------------------------------------------------
+// Synthetic PointNav observation source.  Bit-identical to oracle/synth.py.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline uint32_t stream_key(uint32_t seed, uint32_t sensor, uint32_t env, uint32_t t) {
+    uint32_t h = mix32(seed + 0x9E3779B9u * (sensor + 1u));
+    h = mix32(h ^ env);
+    return mix32(h ^ t);
+}
+__device__ inline float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
+
+// grid: (blocks_per_env, N).  Writes rgb (u8, H*W*3 bytes as whole words) and depth (f32, H*W).
+__global__ void __launch_bounds__(256) synth_images_kernel(uint8_t* __restrict__ rgb, float* __restrict__ depth,
+                                                           const int64_t* __restrict__ env_t, uint32_t seed,
+                                                           uint32_t env_offset, int rgb_words, int depth_words) {
+    const int n = blockIdx.y;
+    const uint32_t t = (uint32_t)env_t[n];
+    const uint32_t env = env_offset + (uint32_t)n;
+    if (rgb) {
+        const uint32_t key = stream_key(seed, 0u, env, t);
+        uint4* dst = reinterpret_cast<uint4*>(rgb + (size_t)n * rgb_words * 4);
+        const int nv = rgb_words >> 2;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+            const uint32_t b = (uint32_t)i * 4u;
+            dst[i] = make_uint4(mix32(key ^ b), mix32(key ^ (b + 1)), mix32(key ^ (b + 2)), mix32(key ^ (b + 3)));
+        }
+        for (int i = (nv << 2) + blockIdx.x * blockDim.x + threadIdx.x; i < rgb_words; i += gridDim.x * blockDim.x)
+            reinterpret_cast<uint32_t*>(rgb + (size_t)n * rgb_words * 4)[i] = mix32(key ^ (uint32_t)i);
+    }
+    if (depth) {
+        const uint32_t key = stream_key(seed, 1u, env, t);
+        float4* dst = reinterpret_cast<float4*>(depth + (size_t)n * depth_words);
+        const int nv = depth_words >> 2;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+            const uint32_t b = (uint32_t)i * 4u;
+            dst[i] = make_float4(u01(mix32(key ^ b)), u01(mix32(key ^ (b + 1))), u01(mix32(key ^ (b + 2))),
+                                 u01(mix32(key ^ (b + 3))));
+        }
+        for (int i = (nv << 2) + blockIdx.x * blockDim.x + threadIdx.x; i < depth_words; i += gridDim.x * blockDim.x)
+            depth[(size_t)n * depth_words + i] = u01(mix32(key ^ (uint32_t)i));
+    }
+}
+
+// One thread per env: advance the env clock, then goal / reward / done for the new step.
+__global__ void synth_scalars_kernel(float* __restrict__ goal, float* __restrict__ reward, uint8_t* __restrict__ not_done,
+                                     int64_t* __restrict__ env_t, int64_t* __restrict__ since_reset, uint32_t seed,
+                                     uint32_t env_offset, int N, int advance) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    int64_t t64 = env_t[n];
+    if (advance) { t64 += 1; env_t[n] = t64; }
+    const uint32_t t = (uint32_t)t64, env = env_offset + (uint32_t)n;
+    {
+        const uint32_t key = stream_key(seed, 2u, env, t);
+        const float u0 = u01(mix32(key ^ 0u)), u1 = u01(mix32(key ^ 1u));
+        goal[2 * n + 0] = __fmul_rn(u0, 10.0f);
+        goal[2 * n + 1] = __fmul_rn(__fadd_rn(__fmul_rn(u1, 2.0f), -1.0f), 3.14159274101257324f);
+    }
+    if (advance) {
+        const uint32_t key = stream_key(seed, 3u, env, t);
+        const float u0 = u01(mix32(key ^ 0u)), u1 = u01(mix32(key ^ 1u)), u2 = u01(mix32(key ^ 2u)),
+                    u3 = u01(mix32(key ^ 3u));
+        const float s = __fadd_rn(__fadd_rn(u0, u1), __fadd_rn(u2, u3));
+        reward[n] = __fmul_rn(__fadd_rn(s, -2.0f), 1.73205077648162842f);
+        const uint32_t d = mix32(stream_key(seed, 4u, env, t) ^ 0u);
+        int64_t s2 = since_reset[n] + 1;
+        const bool done = (d < 171798691u) || (s2 >= 500);
+        since_reset[n] = done ? 0 : s2;
+        not_done[n] = done ? 0 : 1;
+    }
+}
+
+extern "C" int hab_synth_step(uint8_t* rgb, float* depth, float* goal, float* reward, uint8_t* not_done, int64_t* env_t,
+                              int64_t* since_reset, uint32_t seed, uint32_t env_offset, int N, int H, int W, int advance,
+                              hipStream_t stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || !goal || !env_t) return HAB_ERR_ARG;
+    if (advance && (!reward || !not_done || !since_reset)) return HAB_ERR_ARG;
+    if ((H * W * 3) % 4 != 0) return HAB_ERR_UNSUPPORTED;
+    synth_scalars_kernel<<<cdiv(N, 64), 64, 0, stream>>>(goal, reward, not_done, env_t, since_reset, seed, env_offset, N,
+                                                         advance);
+    HAB_LAUNCH_CHECK();
+    if (rgb || depth) {
+        const int rgb_words = H * W * 3 / 4, depth_words = H * W;
+        dim3 grid(cdiv(depth_words / 4, 256), N);
+        if (grid.x > 64) grid.x = 64;
+        synth_images_kernel<<<grid, 256, 0, stream>>>(rgb, depth, env_t, seed, env_offset, rgb_words, depth_words);
+        HAB_LAUNCH_CHECK();
+    }
+    return HAB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// GAE / discounted returns (K13).  Buffers are (T+1, N) fp32, masks (T+1, N) u8 (1 = not done).
+// Variant A (exact): one lane per env, reverse sequential recurrence in the reference's operation
+// order with explicit _rn ops (no fma contraction) -> bitwise equal to the PyTorch-CPU loop.
+// ------------------------------------------------------------------------------------------
+__global__ void gae_exact_kernel(const float* __restrict__ rewards, float* __restrict__ value_preds,
+                                 const uint8_t* __restrict__ masks, float* __restrict__ returns,
+                                 const float* __restrict__ next_value, int T, int N, float gamma, float gamma_tau,
+                                 int use_gae) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    if (use_gae) {
+        float v_next = next_value[n];
+        value_preds[(size_t)T * N + n] = v_next;
+        float gae = 0.0f;
+        for (int t = T - 1; t >= 0; --t) {
+            const float m = masks[(size_t)(t + 1) * N + n] ? 1.0f : 0.0f;
+            const float v = value_preds[(size_t)t * N + n];
+            // delta = r + gamma*v_next*m - v ; gae = delta + (gamma*tau)*gae*m ; ret = gae + v
+            const float delta = __fadd_rn(__fadd_rn(rewards[(size_t)t * N + n], __fmul_rn(__fmul_rn(gamma, v_next), m)), -v);
+            gae = __fadd_rn(delta, __fmul_rn(__fmul_rn(gamma_tau, gae), m));
+            returns[(size_t)t * N + n] = __fadd_rn(gae, v);
+            v_next = v;
+        }
+    } else {
+        float r_next = next_value[n];
+        returns[(size_t)T * N + n] = r_next;
+        for (int t = T - 1; t >= 0; --t) {
+            const float m = masks[(size_t)(t + 1) * N + n] ? 1.0f : 0.0f;
+            r_next = __fadd_rn(__fmul_rn(__fmul_rn(gamma, r_next), m), rewards[(size_t)t * N + n]);
+            returns[(size_t)t * N + n] = r_next;
+        }
+    }
+}
+
+// Variant B (scan): one wavefront per env.  A_t = delta_t + c_t * A_{t+1} is an affine recurrence;
+// each lane owns a contiguous chunk of time steps, composes its chunk's affine map (a,b), the wave
+// does a suffix scan of the maps with shuffles (6 rounds), then each lane replays its chunk.
+// Different association order than the reference loop => agrees to fp32 round-off, not bitwise.
+__global__ void __launch_bounds__(64) gae_scan_kernel(const float* __restrict__ rewards, float* __restrict__ value_preds,
+                                                      const uint8_t* __restrict__ masks, float* __restrict__ returns,
+                                                      const float* __restrict__ next_value, int T, int N, float gamma,
+                                                      float gamma_tau) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int per = cdiv(T, 64);
+    const int t0 = lane * per, t1 = min(T, t0 + per);  // this lane's steps [t0, t1)
+    if (lane == 0) value_preds[(size_t)T * N + n] = next_value[n];
+    // chunk map applied to the incoming A_{t1}:  A_{t0} = a * A_{t1} + b
+    float a = 1.0f, b = 0.0f;
+    for (int t = t1 - 1; t >= t0; --t) {
+        const float m = masks[(size_t)(t + 1) * N + n] ? 1.0f : 0.0f;
+        const float vn = (t + 1 == T) ? next_value[n] : value_preds[(size_t)(t + 1) * N + n];
+        const float delta = rewards[(size_t)t * N + n] + gamma * vn * m - value_preds[(size_t)t * N + n];
+        const float c = gamma_tau * m;
+        b = delta + c * b;
+        a = c * a;
+    }
+    // exclusive suffix scan over lanes: carry_in(lane) = composition of maps of lanes > lane applied to 0
+    float sa = a, sb = b;  // inclusive suffix composition: maps of lanes >= lane
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float oa = __shfl_down(sa, o, 64), ob = __shfl_down(sb, o, 64);
+        if (lane + o < 64) { sb = sa * ob + sb; sa = sa * oa; }
+    }
+    float carry = __shfl_down(sb, 1, 64);  // value of A at t1 for this lane (suffix of lanes > lane applied to 0)
+    if (lane == 63) carry = 0.0f;
+    float gae = carry;
+    for (int t = t1 - 1; t >= t0; --t) {
+        const float m = masks[(size_t)(t + 1) * N + n] ? 1.0f : 0.0f;
+        const float vn = (t + 1 == T) ? next_value[n] : value_preds[(size_t)(t + 1) * N + n];
+        const float v = value_preds[(size_t)t * N + n];
+        const float delta = rewards[(size_t)t * N + n] + gamma * vn * m - v;
+        gae = delta + gamma_tau * m * gae;
+        returns[(size_t)t * N + n] = gae + v;
+    }
+}
+
+extern "C" int hab_compute_returns(const float* rewards, float* value_preds, const uint8_t* masks, float* returns,
+                                   const float* next_value, int T, int N, float gamma, float tau, int use_gae,
+                                   int variant, hipStream_t stream) {
+    if (T < 0 || N <= 0 || !rewards || !value_preds || !masks || !returns || !next_value) return HAB_ERR_ARG;
+    // the reference forms gamma*tau in double (python floats) before it meets the fp32 tensor
+    const float gamma_tau = (float)((double)gamma * (double)tau);
+    if (variant == HAB_GAE_SCAN && use_gae && T > 0) {
+        gae_scan_kernel<<<N, 64, 0, stream>>>(rewards, value_preds, masks, returns, next_value, T, N, gamma, gamma_tau);
+    } else {
+        gae_exact_kernel<<<cdiv(N, 64), 64, 0, stream>>>(rewards, value_preds, masks, returns, next_value, T, N, gamma,
+                                                         gamma_tau, use_gae);
+    }
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Advantages (K14): adv = returns - value_preds over ALL rows (incl. the bootstrap row), then
+// optional (adv - mean) * rsqrt(var + 1e-5) over the finite entries.  Single 1024-thread block:
+// count <= ~1e5 elements.  stats_out = {mean, var} for the distributed variant.
+// Modes (HAB_ADV_*): RAW; LOCAL_NORMALIZE (torch.var_mean, unbiased -- ppo.py:147-153);
+// STATS_MEAN / STATS_VAR / EXT_NORMALIZE = the three phases of distributed_var_mean
+// (ddppo.py:59-84) with the two scalar all-reduces done by the caller in between.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) advantages_kernel(const float* __restrict__ returns, const float* __restrict__ value_preds,
+                                                          float* __restrict__ adv, int count, int mode,
+                                                          const float* __restrict__ ext_stats, float* __restrict__ stats_out) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    double s = 0.0, c = 0.0;
+    for (int i = tid; i < count; i += 1024) {
+        const float a = __fadd_rn(returns[i], -value_preds[i]);
+        adv[i] = a;
+        if (isfinite(a)) { s += (double)a; c += 1.0; }
+    }
+    if (mode == HAB_ADV_RAW) return;
+    auto block_sum = [&](double v) -> double {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        return t;
+    };
+    const double C = block_sum(c);
+    double mean;
+    if (mode == HAB_ADV_LOCAL_NORMALIZE || mode == HAB_ADV_STATS_MEAN) {
+        mean = (C > 0) ? block_sum(s) / C : 0.0;
+        if (mode == HAB_ADV_STATS_MEAN) {
+            if (tid == 0) { stats_out[0] = (float)mean; stats_out[2] = (float)C; }
+            return;
+        }
+    } else {
+        mean = (double)ext_stats[0];
+    }
+    double var;
+    if (mode == HAB_ADV_EXT_NORMALIZE) {
+        var = (double)ext_stats[1];
+    } else {
+        double q = 0.0;
+        for (int i = tid; i < count; i += 1024) {
+            const float a = adv[i];
+            if (isfinite(a)) { const double d = (double)a - mean; q += d * d; }
+        }
+        const double Q = block_sum(q);
+        if (mode == HAB_ADV_STATS_VAR) {  // biased second moment about the supplied (global) mean
+            if (tid == 0) { stats_out[1] = (float)(Q / fmax(C, 1.0)); stats_out[2] = (float)C; }
+            return;
+        }
+        var = Q / fmax(C - 1.0, 1.0);  // torch.var_mean default: unbiased
+        if (stats_out && tid == 0) { stats_out[0] = (float)mean; stats_out[1] = (float)var; stats_out[2] = (float)C; }
+    }
+    const float meanf = (float)mean, rstd = rsqrtf((float)var + 1e-5f);
+    for (int i = tid; i < count; i += 1024) adv[i] = __fmul_rn(__fadd_rn(adv[i], -meanf), rstd);
+}
+
+extern "C" int hab_advantages(const float* returns, const float* value_preds, float* adv, int count, int mode,
+                              const float* ext_stats, float* stats_out, hipStream_t stream) {
+    if (count <= 0 || !returns || !value_preds || !adv || mode < 0 || mode > 4) return HAB_ERR_ARG;
+    if ((mode == HAB_ADV_EXT_NORMALIZE || mode == HAB_ADV_STATS_VAR) && !ext_stats) return HAB_ERR_ARG;
+    if ((mode == HAB_ADV_STATS_MEAN || mode == HAB_ADV_STATS_VAR) && !stats_out) return HAB_ERR_ARG;
+    advantages_kernel<<<1, 1024, 0, stream>>>(returns, value_preds, adv, count, mode, ext_stats, stats_out);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused PPO clipped-surrogate loss, forward + backward (K15).
+// Per frame f (B frames, minibatch order): the new (value, log_prob, entropy) are dense [B];
+// the rollout-side quantities are gathered straight from the (T+1,N) storage through rows[f]
+// (rows == nullptr -> dense).  Emits dL/dvalue, dL/dlogp, dL/dentropy and 12 scalars:
+//  out[0..2] value_loss, action_loss, dist_entropy (means)   out[3] total loss
+//  out[4..6] value_pred min/mean/max   out[7..9] prob_ratio min/mean/max   out[10] fraction clipped
+//  out[11] B.  Single 1024-thread block -> deterministic reduction order.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) ppo_loss_kernel(const float* __restrict__ values, const float* __restrict__ logp,
+                                                        const float* __restrict__ entropy, const float* __restrict__ old_logp,
+                                                        const float* __restrict__ adv, const float* __restrict__ old_values,
+                                                        const float* __restrict__ returns, const int* __restrict__ rows, int B,
+                                                        float clip, float value_coef, float entropy_coef, int clip_value,
+                                                        float* __restrict__ d_value, float* __restrict__ d_logp,
+                                                        float* __restrict__ d_entropy, float* __restrict__ out) {
+    __shared__ float red[16][8];
+    __shared__ float redmm[16][4];
+    const int tid = threadIdx.x;
+    const float invB = 1.0f / (float)B;
+    float s_vl = 0, s_al = 0, s_en = 0, s_v = 0, s_r = 0, s_clip = 0;
+    float v_min = INFINITY, v_max = -INFINITY, r_min = INFINITY, r_max = -INFINITY;
+    for (int f = tid; f < B; f += 1024) {
+        const int g = rows ? rows[f] : f;
+        const float v = values[f], lp = logp[f], en = entropy[f];
+        const float a = adv[g], ov = old_values[g], ret = returns[g];
+        const float ratio = expf(lp - old_logp[g]);
+        const float lo = 1.0f - clip, hi = 1.0f + clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = a * ratio, s2 = a * rc;
+        const float al = -fminf(s1, s2);
+        const bool inr = (ratio >= lo) && (ratio <= hi);
+        // torch.min backward: ties split the gradient evenly; clamp backward passes inside [lo, hi]
+        const float w = (s1 < s2) ? 1.0f : ((s1 == s2) ? (0.5f + (inr ? 0.5f : 0.0f)) : (inr ? 1.0f : 0.0f));
+        d_logp[f] = -a * w * ratio * invB;
+        float vv = v;
+        float dv = 0.0f;
+        if (clip_value) {
+            const float delta = v - ov;
+            const bool keep = fabsf(delta) < clip;
+            vv = keep ? v : (ov + fminf(fmaxf(delta, -clip), clip));
+            dv = keep ? (v - ret) : 0.0f;
+        } else {
+            dv = v - ret;
+        }
+        const float e = vv - ret;
+        const float vl = 0.5f * (e * e);
+        d_value[f] = value_coef * dv * invB;
+        d_entropy[f] = -entropy_coef * invB;
+        s_vl += vl; s_al += al; s_en += en; s_v += v; s_r += ratio;
+        s_clip += ((ratio > hi) ? 1.0f : 0.0f) + ((ratio < lo) ? 1.0f : 0.0f);
+        v_min = fminf(v_min, v); v_max = fmaxf(v_max, v); r_min = fminf(r_min, ratio); r_max = fmaxf(r_max, ratio);
+    }
+    float sums[6] = {s_vl, s_al, s_en, s_v, s_r, s_clip};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sums[k] = wave_sum(sums[k]);
+    v_min = wave_min(v_min); r_min = wave_min(r_min); v_max = wave_max(v_max); r_max = wave_max(r_max);
+    const int w = tid >> 6;
+    if ((tid & 63) == 0) {
+        for (int k = 0; k < 6; ++k) red[w][k] = sums[k];
+        redmm[w][0] = v_min; redmm[w][1] = v_max; redmm[w][2] = r_min; redmm[w][3] = r_max;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t[6] = {0, 0, 0, 0, 0, 0};
+        float mn_v = INFINITY, mx_v = -INFINITY, mn_r = INFINITY, mx_r = -INFINITY;
+        for (int i = 0; i < 16; ++i) {
+            for (int k = 0; k < 6; ++k) t[k] += red[i][k];
+            mn_v = fminf(mn_v, redmm[i][0]); mx_v = fmaxf(mx_v, redmm[i][1]);
+            mn_r = fminf(mn_r, redmm[i][2]); mx_r = fmaxf(mx_r, redmm[i][3]);
+        }
+        const float vl = t[0] * invB, al = t[1] * invB, en = t[2] * invB;
+        out[0] = vl; out[1] = al; out[2] = en;
+        out[3] = value_coef * vl + al - entropy_coef * en;
+        out[4] = mn_v; out[5] = t[3] * invB; out[6] = mx_v;
+        out[7] = mn_r; out[8] = t[4] * invB; out[9] = mx_r;
+        out[10] = t[5] * invB; out[11] = (float)B;
+    }
+}
+
+extern "C" int hab_ppo_loss(const float* values, const float* logp, const float* entropy, const float* old_logp,
+                            const float* adv, const float* old_values, const float* returns, const int* rows, int B,
+                            float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
+                            float* d_value, float* d_logp, float* d_entropy, float* out12, hipStream_t stream) {
+    if (B <= 0 || !values || !logp || !entropy || !old_logp || !adv || !old_values || !returns || !d_value || !d_logp ||
+        !d_entropy || !out12)
+        return HAB_ERR_ARG;
+    ppo_loss_kernel<<<1, 1024, 0, stream>>>(values, logp, entropy, old_logp, adv, old_values, returns, rows, B, clip_param,
+                                            value_loss_coef, entropy_coef, use_clipped_value_loss, d_value, d_logp,
+                                            d_entropy, out12);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Global-norm clip + Adam on the flat parameter arena (K16): 2 launches.
+//  1) sumsq partials (grid-stride, float4) -> partial[blocks] doubles
+//  2) every block re-reduces the (<=1024) partials, derives clip coefficient, applies Adam.
+// The update mirrors torch.optim.Adam(foreach): lerp, mul/addcmul, sqrt/div/add eps, addcdiv.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, size_t n, float gscale,
+                                                    double* __restrict__ partial) {
+    __shared__ double red[4];
+    double s = 0.0;
+    const size_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = g4[i];
+        v.x *= gscale; v.y *= gscale; v.z *= gscale; v.w *= gscale;
+        s += (double)(v.x * v.x) + (double)(v.y * v.y) + (double)(v.z * v.z) + (double)(v.w * v.w);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = g[i] * gscale;
+        s += (double)(v * v);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256) clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                        const double* __restrict__ partial, int npartial, float gscale,
+                                                        float max_norm, float w1, float beta2, float w2, float step_size,
+                                                        float bc2_sqrt, float eps, float* __restrict__ norm_out) {
+    __shared__ double red[4];
+    __shared__ float coef_s;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < npartial; i += 256) s += partial[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        float c = (max_norm > 0.0f) ? max_norm / (norm + 1e-6f) : 1.0f;
+        coef_s = fminf(c, 1.0f) * gscale;
+        if (blockIdx.x == 0 && norm_out) norm_out[0] = norm;
+    }
+    __syncthreads();
+    const float coef = coef_s;
+    const size_t n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        gg *= coef;
+        mm = mm + w1 * (gg - mm);
+        vv = vv * beta2 + w2 * (gg * gg);
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp = pp - step_size * (mm / denom);
+    };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const float4 gg = g4[i];
+        upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        upd(p[i], g[i], m[i], v[i]);
+}
+
+extern "C" int hab_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                                  double* scratch_partials, int scratch_len, float grad_scale, float max_grad_norm,
+                                  float lr, float beta1, float beta2, float eps, int step, float* grad_norm_out,
+                                  hipStream_t stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n == 0 || !scratch_partials || scratch_len < 1 || step < 1)
+        return HAB_ERR_ARG;
+    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return HAB_ERR_ARG;
+    int blocks = (int)fmin((double)scratch_len, (double)cdivl((long long)(n >> 2) + 1, 256));
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    sumsq_kernel<<<blocks, 256, 0, stream>>>(grads, n, grad_scale, scratch_partials);
+    HAB_LAUNCH_CHECK();
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    int ablocks = (int)cdivl((long long)(n >> 2) + 1, 256);
+    if (ablocks > 2048) ablocks = 2048;
+    clip_adam_kernel<<<ablocks, 256, 0, stream>>>(params, grads, exp_avg, exp_avg_sq, n, scratch_partials, blocks,
+                                                  grad_scale, max_grad_norm, (float)(1.0 - (double)beta1), beta2,
+                                                  (float)(1.0 - (double)beta2), step_size, bc2_sqrt, eps, grad_norm_out);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Action sampling (K12): torch.multinomial(probs, 1, True) on CPU draws q ~ Exp(1) per
+// (row, class) and returns argmax(probs / q).  The noise is drawn on the host from the CPU
+// generator (same stream the reference consumes); the division/argmax run here.  First maximal
+// index wins (torch.argmax semantics).  deterministic=1 -> mode (argmax of probs).
+// ------------------------------------------------------------------------------------------
+__global__ void sample_kernel(const float* __restrict__ probs, const float* __restrict__ noise, int64_t* __restrict__ actions,
+                              int n, int A, int deterministic) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float best = -INFINITY;
+    int arg = 0;
+    for (int k = 0; k < A; ++k) {
+        const float p = probs[(size_t)i * A + k];
+        const float s = deterministic ? p : __fdiv_rn(p, noise[(size_t)i * A + k]);
+        if (s > best) { best = s; arg = k; }
+    }
+    actions[i] = arg;
+}
+
+extern "C" int hab_sample_actions(const float* probs, const float* exp_noise, int64_t* actions, int n, int A,
+                                  int deterministic, hipStream_t stream) {
+    if (n <= 0 || A <= 0 || !probs || !actions || (!deterministic && !exp_noise)) return HAB_ERR_ARG;
+    sample_kernel<<<cdiv(n, 64), 64, 0, stream>>>(probs, exp_noise, actions, n, A, deterministic);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}

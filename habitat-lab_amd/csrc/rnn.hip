@@ -1,0 +1,319 @@
+// rnn.hip -- sequence-packed GRU / LSTM state encoder (K9-K11) for gfx950.
+//
+// Reference: rl/models/rnn_state_encoder.py:187-277,301-350 wraps the minibatch into a
+// PackedSequence (one sequence per episode fragment, sorted by length) and calls cuDNN/ATen.
+// Here the same packing drives hand-written kernels:
+//   1. the input projections of ALL T*n frames are one MFMA contraction (igemm, frame order),
+//   2. the recurrence walks the packed steps s = 0..max_len-1; step s touches the first
+//      num_seqs_at_step[s] fragments.  One launch per step: a 16-row x 16-unit tile per workgroup,
+//      its 4 waves split the K=H reduction and meet in LDS, then the gate math is fused in the
+//      epilogue.  Operands go global->VGPR as 16-byte loads in MFMA fragment order
+//      (v_mfma_f32_16x16x4_f32; W_hh is 3-4 MB and L2-resident) -- no LDS staging, this phase is
+//      latency-bound, not bandwidth-bound.
+//   3. outputs are written straight in frame order (the inverse permutation of
+//      build_rnn_out_from_seq is free), the hidden state entering every step is kept for BPTT.
+// BPTT runs the steps in reverse (gate-gradient kernel + transposed mat-vec kernel per step) and
+// finishes with three contractions over all frames (dW_ih, dW_hh, dX) and two column sums.
+#include "ops.h"
+#include "../../include/habitat_amd.h"
+
+namespace hab {
+
+constexpr int RNN_GRU = 0, RNN_LSTM = 1;
+
+// hinit[q] = masks[frame frag_start[q]] ? h0[env frag_env[q]] : 0       (build_rnn_inputs :232-239)
+__global__ void rnn_frag_init_kernel(const float* __restrict__ h0, const int* __restrict__ env_rows, int env_stride,
+                                     const uint8_t* __restrict__ masks, const int* __restrict__ mask_rows,
+                                     const int* __restrict__ frag_env, const int* __restrict__ frag_start, int F, int H,
+                                     float* __restrict__ hinit) {
+    const int q = blockIdx.x;
+    if (q >= F) return;
+    const int f = frag_start ? frag_start[q] : q;
+    const int e = frag_env ? frag_env[q] : q;
+    const bool keep = masks[mask_rows ? mask_rows[f] : f] != 0;
+    const float* src = h0 + (size_t)(env_rows ? env_rows[e] : e) * env_stride;
+    for (int u = threadIdx.x; u < H; u += blockDim.x) hinit[(size_t)q * H + u] = keep ? src[u] : 0.f;
+}
+
+int rnn_frag_init(const float* h0, const int* env_rows, int env_stride, const uint8_t* masks, const int* mask_rows,
+                  const int* frag_env, const int* frag_start, int F, int H, float* hinit, hipStream_t stream) {
+    if (!h0 || !masks || !hinit || F <= 0 || H <= 0) return HAB_ERR_ARG;
+    rnn_frag_init_kernel<<<F, 128, 0, stream>>>(h0, env_rows, env_stride, masks, mask_rows, frag_env, frag_start, F, H, hinit);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+struct StepArgs {
+    int R, H;
+    const float* hp_base; const int* hp_idx; int hp_stride;   // hidden entering the step, row q
+    const float* cp_base; const int* cp_idx; int cp_stride;   // LSTM cell entering the step
+    const int* out_idx;                                        // row q -> frame (null = q)
+    const float* gi;                                           // [frames][G*H] input projection incl. b_ih
+    const float* w_hh; const float* b_hh;                      // [G*H][H]
+    float* gates; float* hn; float* hprev; float* cprev; float* c; // saved for BPTT (may be null in inference)
+    float* out; int out_stride;                                // h' per frame
+    float* c_out; int c_out_stride;                            // LSTM c' (inference path); training uses `c`
+};
+
+// One workgroup = 16 rows x 16 hidden units x G gates; 4 waves split K = H.
+template <int G>
+__global__ void __launch_bounds__(256) rnn_step_kernel(const StepArgs a) {
+    __shared__ float red[4][G][256];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
+    const int i = lane & 15, kg = lane >> 4;
+    const int H = a.H;
+    const int q = min(row0 + i, a.R - 1);
+    const float* hrow = a.hp_base + (size_t)(a.hp_idx ? a.hp_idx[q] : q) * a.hp_stride;
+    const int kq = H / 4;  // per-wave K range
+    const int kb = wave * kq;
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { acc[g][0] = 0.f; acc[g][1] = 0.f; acc[g][2] = 0.f; acc[g][3] = 0.f; }
+    const float* wrow[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) wrow[g] = a.w_hh + (size_t)(g * H + u0 + i) * H;
+    for (int c = 0; c < kq; c += 16) {
+        const int k = kb + c + 4 * kg;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + k);
+        f32x4 bv[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) bv[g] = *reinterpret_cast<const f32x4*>(wrow[g] + k);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[g][s], acc[g], 0, 0, 0);
+    }
+    // D layout (16x16): col = lane & 15 (unit), row = (lane >> 4) * 4 + v
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[wave][g][(kg * 4 + v) * 16 + i] = acc[g][v];
+    __syncthreads();
+    const int r = t >> 4, u = t & 15;  // one (row, unit) per thread
+    const int qq = row0 + r;
+    if (qq >= a.R) return;
+    float gh[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        gh[g] = ((red[0][g][t] + red[1][g][t]) + (red[2][g][t] + red[3][g][t])) + a.b_hh[g * H + u0 + u];
+    const int f = a.out_idx ? a.out_idx[qq] : qq;
+    const int uu = u0 + u;
+    const float hp = a.hp_base[(size_t)(a.hp_idx ? a.hp_idx[qq] : qq) * a.hp_stride + uu];
+    const float* gi = a.gi + (size_t)f * G * H;
+    if constexpr (G == 3) {
+        const float rg = sigmoidf_(gi[uu] + gh[0]);
+        const float zg = sigmoidf_(gi[H + uu] + gh[1]);
+        const float ng = tanhf(gi[2 * H + uu] + rg * gh[2]);
+        const float hnew = (1.0f - zg) * ng + zg * hp;
+        a.out[(size_t)f * a.out_stride + uu] = hnew;
+        if (a.gates) {
+            float* gs = a.gates + (size_t)f * 3 * H;
+            gs[uu] = rg; gs[H + uu] = zg; gs[2 * H + uu] = ng;
+            a.hn[(size_t)f * H + uu] = gh[2];
+            a.hprev[(size_t)f * H + uu] = hp;
+        }
+    } else {
+        const float cp = a.cp_base[(size_t)(a.cp_idx ? a.cp_idx[qq] : qq) * a.cp_stride + uu];
+        const float ig = sigmoidf_(gi[uu] + gh[0]);
+        const float fg = sigmoidf_(gi[H + uu] + gh[1]);
+        const float gg = tanhf(gi[2 * H + uu] + gh[2]);
+        const float og = sigmoidf_(gi[3 * H + uu] + gh[3]);
+        const float cn = fg * cp + ig * gg;
+        const float hnew = og * tanhf(cn);
+        a.out[(size_t)f * a.out_stride + uu] = hnew;
+        if (a.c_out) a.c_out[(size_t)f * a.c_out_stride + uu] = cn;
+        if (a.gates) {
+            float* gs = a.gates + (size_t)f * 4 * H;
+            gs[uu] = ig; gs[H + uu] = fg; gs[2 * H + uu] = gg; gs[3 * H + uu] = og;
+            a.hprev[(size_t)f * H + uu] = hp;
+            a.cprev[(size_t)f * H + uu] = cp;
+            a.c[(size_t)f * H + uu] = cn;
+        }
+    }
+}
+
+static int launch_step(int rnn_type, const StepArgs& a, hipStream_t stream) {
+    if (a.R <= 0) return HAB_OK;
+    if (a.H % 64) return HAB_ERR_UNSUPPORTED;
+    dim3 grid(cdiv(a.R, 16), a.H / 16);
+    if (rnn_type == RNN_GRU)
+        rnn_step_kernel<3><<<grid, 256, 0, stream>>>(a);
+    else
+        rnn_step_kernel<4><<<grid, 256, 0, stream>>>(a);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+int rnn_seq_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx,
+                          const float* hinit, const float* cinit, const PackInfo& pk, float* ws, size_t ws_floats,
+                          hipStream_t stream) {
+    const int G = rnn_type == RNN_GRU ? 3 : 4;
+    HAB_TRY(linear_fwd(x, ldx, lp.w_ih, lp.in_dim, lp.b_ih, wk.gi, G * H, pk.P, G * H, lp.in_dim, 0, 0, ws, ws_floats, stream));
+    for (int s = 0; s < pk.max_len; ++s) {
+        StepArgs a;
+        a.R = pk.num_seqs_at_step[s]; a.H = H;
+        if (s == 0) {
+            a.hp_base = hinit; a.hp_idx = nullptr; a.hp_stride = H;
+            a.cp_base = cinit; a.cp_idx = nullptr; a.cp_stride = H;
+        } else {
+            a.hp_base = wk.out; a.hp_idx = pk.select_inds + pk.step_offsets[s - 1]; a.hp_stride = H;
+            a.cp_base = wk.c; a.cp_idx = a.hp_idx; a.cp_stride = H;
+        }
+        a.out_idx = pk.select_inds + pk.step_offsets[s];
+        a.gi = wk.gi; a.w_hh = lp.w_hh; a.b_hh = lp.b_hh;
+        a.gates = wk.gates; a.hn = wk.hn; a.hprev = wk.hprev; a.cprev = wk.cprev; a.c = wk.c;
+        a.out = wk.out; a.out_stride = H; a.c_out = nullptr; a.c_out_stride = 0;
+        HAB_TRY(launch_step(rnn_type, a, stream));
+    }
+    return HAB_OK;
+}
+
+// Inference step (rollout `act`, rnn_state_encoder.py:301-316): n rows, masked state supplied dense.
+int rnn_step_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const float* x, int ldx, const float* h_in,
+                           const float* c_in, int n, float* gi_scratch, float* h_out, int h_out_stride, float* c_out,
+                           int c_out_stride, float* ws, size_t ws_floats, hipStream_t stream) {
+    const int G = rnn_type == RNN_GRU ? 3 : 4;
+    HAB_TRY(linear_fwd(x, ldx, lp.w_ih, lp.in_dim, lp.b_ih, gi_scratch, G * H, n, G * H, lp.in_dim, 0, 0, ws, ws_floats, stream));
+    StepArgs a;
+    a.R = n; a.H = H;
+    a.hp_base = h_in; a.hp_idx = nullptr; a.hp_stride = H;
+    a.cp_base = c_in; a.cp_idx = nullptr; a.cp_stride = H;
+    a.out_idx = nullptr; a.gi = gi_scratch; a.w_hh = lp.w_hh; a.b_hh = lp.b_hh;
+    a.gates = nullptr; a.hn = nullptr; a.hprev = nullptr; a.cprev = nullptr; a.c = nullptr;
+    a.out = h_out; a.out_stride = h_out_stride; a.c_out = c_out; a.c_out_stride = c_out_stride;
+    return launch_step(rnn_type, a, stream);
+}
+
+// ------------------------------------------- BPTT ---------------------------------------------
+struct BwdGateArgs {
+    int R, H, R_next;
+    const int* idx;        // row q -> frame
+    const float* dout;     // [frames][H] gradient wrt the layer output
+    const float* dh_carry; // [F][H] from step s+1 (rows < R_next valid)
+    float* dc_carry;       // LSTM [F][H] in/out
+    const float* gates; const float* hn; const float* hprev; const float* cprev; const float* c;
+    float* dgi; float* dgh;  // [frames][G*H]
+    float* dh_direct;        // [F][H]: part of dh_prev that does not go through W_hh (GRU: dh*z ; LSTM: 0)
+};
+
+template <int G>
+__global__ void __launch_bounds__(256) rnn_bwd_gate_kernel(const BwdGateArgs a) {
+    const int H = a.H;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)a.R * H) return;
+    const int q = (int)(e / H), u = (int)(e % H);
+    const int f = a.idx[q];
+    float dh = a.dout[(size_t)f * H + u];
+    if (q < a.R_next) dh += a.dh_carry[(size_t)q * H + u];
+    if constexpr (G == 3) {
+        const float* gs = a.gates + (size_t)f * 3 * H;
+        const float r = gs[u], z = gs[H + u], n = gs[2 * H + u];
+        const float hp = a.hprev[(size_t)f * H + u], hn = a.hn[(size_t)f * H + u];
+        const float dn = dh * (1.0f - z);
+        const float dz = dh * (hp - n);
+        const float dn_pre = dn * (1.0f - n * n);
+        const float dr = dn_pre * hn;
+        const float dr_pre = dr * r * (1.0f - r);
+        const float dz_pre = dz * z * (1.0f - z);
+        float* gi = a.dgi + (size_t)f * 3 * H;
+        float* gh = a.dgh + (size_t)f * 3 * H;
+        gi[u] = dr_pre; gi[H + u] = dz_pre; gi[2 * H + u] = dn_pre;
+        gh[u] = dr_pre; gh[H + u] = dz_pre; gh[2 * H + u] = dn_pre * r;
+        a.dh_direct[(size_t)q * H + u] = dh * z;
+    } else {
+        const float* gs = a.gates + (size_t)f * 4 * H;
+        const float ig = gs[u], fg = gs[H + u], gg = gs[2 * H + u], og = gs[3 * H + u];
+        const float cn = a.c[(size_t)f * H + u], cp = a.cprev[(size_t)f * H + u];
+        const float tc = tanhf(cn);
+        float dc = dh * og * (1.0f - tc * tc);
+        if (q < a.R_next) dc += a.dc_carry[(size_t)q * H + u];
+        const float d_o = dh * tc;
+        const float di = dc * gg, dg = dc * ig, df = dc * cp;
+        float* gi = a.dgi + (size_t)f * 4 * H;
+        gi[u] = di * ig * (1.0f - ig);
+        gi[H + u] = df * fg * (1.0f - fg);
+        gi[2 * H + u] = dg * (1.0f - gg * gg);
+        gi[3 * H + u] = d_o * og * (1.0f - og);
+        a.dc_carry[(size_t)q * H + u] = dc * fg;
+        a.dh_direct[(size_t)q * H + u] = 0.f;
+    }
+}
+
+// dh_carry[q][u] = dh_direct[q][u] + sum_k dgh[frame(q)][k] * W_hh[k][u]   (k over G*H), via W_hh^T [H][G*H].
+struct BwdMatArgs {
+    int R, H, K;  // K = G*H
+    const int* idx;
+    const float* dgh;     // [frames][K]
+    const float* w_hh_t;  // [H][K]
+    const float* dh_direct;
+    float* dh_carry;
+};
+__global__ void __launch_bounds__(256) rnn_bwd_mat_kernel(const BwdMatArgs a) {
+    __shared__ float red[4][256];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
+    const int i = lane & 15, kg = lane >> 4;
+    const int q = min(row0 + i, a.R - 1);
+    const float* arow = a.dgh + (size_t)a.idx[q] * a.K;
+    const float* brow = a.w_hh_t + (size_t)(u0 + i) * a.K;
+    const int kq = a.K / 4, kb = wave * kq;
+    f32x4 acc;
+    acc[0] = 0.f; acc[1] = 0.f; acc[2] = 0.f; acc[3] = 0.f;
+    for (int c = 0; c < kq; c += 16) {
+        const int k = kb + c + 4 * kg;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(arow + k);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + k);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[wave][(kg * 4 + v) * 16 + i] = acc[v];
+    __syncthreads();
+    const int r = t >> 4, u = t & 15, qq = row0 + r;
+    if (qq >= a.R) return;
+    const size_t o = (size_t)qq * a.H + u0 + u;
+    a.dh_carry[o] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + a.dh_direct[o];
+}
+
+int rnn_seq_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx,
+                           const float* dout, float* dx, int lddx, const float* dx_mask, int ldmask, int mask_cols,
+                           const PackInfo& pk, float* scratch /* 3*F*H floats */, float* ws, size_t ws_floats, hipStream_t stream) {
+    const int G = rnn_type == RNN_GRU ? 3 : 4;
+    if (H % 64) return HAB_ERR_UNSUPPORTED;
+    float* dh_carry = scratch;
+    float* dh_direct = scratch + (size_t)pk.F * H;
+    float* dc_carry = scratch + 2 * (size_t)pk.F * H;
+    float* dgh = (rnn_type == RNN_GRU) ? wk.dgh : wk.dgi;
+    for (int s = pk.max_len - 1; s >= 0; --s) {
+        const int R = pk.num_seqs_at_step[s];
+        BwdGateArgs g;
+        g.R = R; g.H = H; g.R_next = (s + 1 < pk.max_len) ? pk.num_seqs_at_step[s + 1] : 0;
+        g.idx = pk.select_inds + pk.step_offsets[s];
+        g.dout = dout; g.dh_carry = dh_carry; g.dc_carry = dc_carry;
+        g.gates = wk.gates; g.hn = wk.hn; g.hprev = wk.hprev; g.cprev = wk.cprev; g.c = wk.c;
+        g.dgi = wk.dgi; g.dgh = wk.dgh; g.dh_direct = dh_direct;
+        const int blocks = (int)cdivl((long long)R * H, 256);
+        if (rnn_type == RNN_GRU)
+            rnn_bwd_gate_kernel<3><<<blocks, 256, 0, stream>>>(g);
+        else
+            rnn_bwd_gate_kernel<4><<<blocks, 256, 0, stream>>>(g);
+        HAB_LAUNCH_CHECK();
+        if (s > 0) {
+            BwdMatArgs m;
+            m.R = R; m.H = H; m.K = G * H; m.idx = g.idx; m.dgh = dgh; m.w_hh_t = lp.w_hh_t; m.dh_direct = dh_direct;
+            m.dh_carry = dh_carry;
+            rnn_bwd_mat_kernel<<<dim3(cdiv(R, 16), H / 16), 256, 0, stream>>>(m);
+            HAB_LAUNCH_CHECK();
+        }
+    }
+    // parameter gradients over all frames
+    HAB_TRY(linear_wgrad(wk.dgi, G * H, x, ldx, lp.dw_ih, lp.in_dim, pk.P, G * H, lp.in_dim, 0, 0, 0, ws, ws_floats, stream));
+    HAB_TRY(linear_wgrad(dgh, G * H, wk.hprev, H, lp.dw_hh, H, pk.P, G * H, H, 0, 0, 0, ws, ws_floats, stream));
+    HAB_TRY(colsum(wk.dgi, G * H, pk.P, G * H, lp.db_ih, 0, ws, ws_floats, stream));
+    HAB_TRY(colsum(dgh, G * H, pk.P, G * H, lp.db_hh, 0, ws, ws_floats, stream));
+    if (dx) HAB_TRY(linear_dgrad(wk.dgi, G * H, lp.w_ih, lp.in_dim, dx_mask, ldmask, mask_cols, dx, lddx, pk.P, lp.in_dim, G * H, 0, ws, ws_floats, stream));
+    return HAB_OK;
+}
+
+}  // namespace hab

@@ -1,0 +1,116 @@
+"""ctypes binding of libhabitat_amd.so (the C-ABI declared in include/habitat_amd.h).
+
+The library is built in-tree (``make -C habitat-lab_amd/csrc`` or ``__graft_entry__.build()``).
+There is NO fallback: if the shared object is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhabitat_amd.so")
+
+vp = c_void_p
+
+
+class HabError(RuntimeError):
+    pass
+
+
+class PolicyDesc(C.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "arch", "backbone", "baseplanes", "normalize_visual_inputs", "rnn_type", "rnn_layers", "hidden", "num_actions",
+        "H", "W", "has_rgb", "has_depth", "goal_dim", "max_frames", "max_envs")]
+
+
+class Obs(C.Structure):
+    _fields_ = [("rgb", vp), ("depth", vp), ("goal", vp), ("prev_actions", vp)]
+
+
+class PackInfo(C.Structure):
+    _fields_ = [("select_inds", vp), ("frag_env", vp), ("frag_start", vp), ("step_offsets_host", vp),
+                ("num_seqs_at_step_host", vp), ("P", c_int32), ("F", c_int32), ("max_len", c_int32)]
+
+
+# name -> (restype, argtypes).  Every symbol of include/habitat_amd.h appears here; tests/test_capi.py
+# checks that the header, this table and the shared object agree.
+SIGNATURES = {
+    "hab_abi_version": (c_int, []),
+    "hab_error_string": (c_char_p, [c_int]),
+    "hab_synth_step": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_uint32, c_uint32, c_int, c_int, c_int, c_int, vp]),
+    "hab_compute_returns": (c_int, [vp, vp, vp, vp, vp, c_int, c_int, c_float, c_float, c_int, c_int, vp]),
+    "hab_advantages": (c_int, [vp, vp, vp, c_int, c_int, vp, vp, vp]),
+    "hab_ppo_loss": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_float, c_float, c_float, c_int, vp, vp, vp, vp, vp]),
+    "hab_clip_adam_step": (c_int, [vp, vp, vp, vp, c_size_t, vp, c_int, c_float, c_float, c_float, c_float, c_float,
+                                   c_float, c_int, vp, vp]),
+    "hab_sample_actions": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
+    "hab_conv2d_fwd": (c_int, [vp, vp, vp, vp] + [c_int] * 10 + [vp, c_size_t, vp]),
+    "hab_obs_conv2d_fwd": (c_int, [vp, vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
+    "hab_conv2d_dgrad": (c_int, [vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
+    "hab_conv2d_wgrad": (c_int, [vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
+    "hab_obs_conv2d_wgrad": (c_int, [vp, vp, vp, vp, vp] + [c_int] * 8 + [vp, c_size_t, vp]),
+    "hab_linear_fwd": (c_int, [vp, c_int, vp, c_int, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, c_size_t, vp]),
+    "hab_linear_dgrad": (c_int, [vp, c_int, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp, c_size_t, vp]),
+    "hab_linear_wgrad": (c_int, [vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, c_size_t, vp]),
+    "hab_colsum": (c_int, [vp, c_int, c_int, c_int, vp, c_int, vp, c_size_t, vp]),
+    "hab_repack_conv_weight": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
+    "hab_repack_flatten_weight": (c_int, [vp, vp, c_int, c_int, c_int, vp]),
+    "hab_transpose2d": (c_int, [vp, vp, c_int, c_int, vp]),
+    "hab_build_pack_info": (c_int, [vp, c_int, c_int] + [vp] * 12),
+    "hab_policy_create": (c_int, [POINTER(PolicyDesc), POINTER(vp)]),
+    "hab_policy_destroy": (None, [vp]),
+    "hab_policy_num_params": (c_int, [vp]),
+    "hab_policy_param_info": (c_int, [vp, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
+    "hab_policy_param_floats": (c_int64, [vp]),
+    "hab_policy_packed_floats": (c_int64, [vp]),
+    "hab_policy_work_floats": (c_int64, [vp]),
+    "hab_policy_bind": (c_int, [vp, vp, vp, vp, vp, c_int64]),
+    "hab_policy_repack": (c_int, [vp, vp]),
+    "hab_policy_act": (c_int, [vp, POINTER(Obs), vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp, vp]),
+    "hab_policy_evaluate": (c_int, [vp, POINTER(Obs), vp, vp, c_int, vp, vp, POINTER(PackInfo), c_int, c_int, vp, vp, vp, vp]),
+    "hab_policy_final_hidden": (c_int, [vp, vp, vp]),
+    "hab_policy_backward": (c_int, [vp, POINTER(Obs), vp, vp, POINTER(PackInfo), vp, vp, vp, vp]),
+    "hab_policy_probe_enable": (c_int, [vp, c_int]),
+    "hab_policy_probe_read": (c_int, [vp, POINTER(c_double), POINTER(c_int)]),
+    "hab_policy_tap": (c_int, [vp, c_int, POINTER(vp), POINTER(c_int64)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads the shared object (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HabError(
+                f"{LIB_PATH} is missing: build it with `make -C habitat-lab_amd/csrc` (or __graft_entry__.build()). "
+                "habitat_amd has no CPU / PyTorch fallback for its kernels.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = lib().hab_error_string(code)
+        raise HabError(f"{what or 'habitat_amd call'} failed: [{code}] {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

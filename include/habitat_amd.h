@@ -1,0 +1,239 @@
+/*
+ * habitat_amd.h -- C-ABI of libhabitat_amd.so, the MI355X (gfx950) kernel library behind the
+ * habitat_baselines PPO / DD-PPO training path.
+ *
+ * The reference (facebookresearch/habitat-lab) has NO native boundary on this path: every op is a
+ * PyTorch call reached from Python.  The drop-in boundary is therefore the
+ * Python plugin registry; THIS header is the boundary one level below it that a maintainer binds
+ * with ctypes (INTEGRATION.md shows the stubs).  Each entry point cites the reference op chain
+ * (file:line under habitat-baselines/habitat_baselines/) that it replaces.
+ *
+ * Conventions: plain device pointers + sizes, `hipStream_t` last, returns 0 on success, a negative
+ * HAB_ERR_* for bad arguments, or a positive hipError_t.  Nothing here owns memory except the
+ * `hab_policy` engine handle, whose arenas are caller-provided.  All tensors fp32 unless noted;
+ * masks are 1 byte per element (torch.bool), 1 = "not done".  Functions are asynchronous on
+ * `stream`; none of them synchronises the device.
+ */
+#ifndef HABITAT_AMD_H
+#define HABITAT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define HAB_ABI_VERSION 1
+int hab_abi_version(void);
+/* Human-readable name of the last HAB_ERR_* / hipError_t code. */
+const char* hab_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Synthetic PointNav environment source (replaces VectorEnv.wait_step_at + batch_obs for the
+ * synthetic-observation benchmark: habitat/core/vector_env.py:402-410, utils/common.py:191-330).
+ * Writes the observations of N envs straight into rollout-storage rows.  Counter-based integer
+ * hash, bit-identical to oracle/synth.py.  advance=0: (re)emit obs for the current env clock
+ * (reset); advance=1: env_t += 1 then emit obs, reward, not_done.  rgb/depth may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+int hab_synth_step(uint8_t* rgb /*N,H,W,3*/, float* depth /*N,H,W,1*/, float* goal /*N,2*/, float* reward /*N*/,
+                   uint8_t* not_done /*N*/, int64_t* env_t /*N*/, int64_t* since_reset /*N*/, uint32_t seed,
+                   uint32_t env_offset, int N, int H, int W, int advance, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RolloutStorage.compute_returns (common/rollout_storage.py:174-205).  Buffers are (T+1, N).
+ * Writes value_preds[T] = next_value and returns[0..T-1] (use_gae) / returns[0..T].
+ * variant HAB_GAE_EXACT: lane-per-env sequential recurrence in the reference's operation order,
+ * bitwise equal to the PyTorch-CPU loop.  HAB_GAE_SCAN: wavefront-per-env affine suffix scan
+ * with shuffles (fp32 round-off level agreement).
+ * ------------------------------------------------------------------------------------------- */
+#define HAB_GAE_EXACT 0
+#define HAB_GAE_SCAN 1
+int hab_compute_returns(const float* rewards, float* value_preds, const uint8_t* masks, float* returns,
+                        const float* next_value /*N*/, int T, int N, float gamma, float tau, int use_gae,
+                        int variant, hipStream_t stream);
+
+/* PPO.get_advantages (rl/ppo/ppo.py:139-153) and distributed_var_mean (rl/ddppo/algo/ddppo.py:59-84).
+ * count = (T+1)*N.  stats = {mean, var, finite_count}. */
+#define HAB_ADV_RAW 0             /* adv = returns - value_preds */
+#define HAB_ADV_LOCAL_NORMALIZE 1 /* + (adv-mean)*rsqrt(var+1e-5), unbiased var (torch.var_mean) */
+#define HAB_ADV_STATS_MEAN 2      /* adv + local mean -> stats_out[0] (caller all-reduces) */
+#define HAB_ADV_EXT_NORMALIZE 3   /* normalise with ext_stats = {global mean, global var} */
+#define HAB_ADV_STATS_VAR 4       /* biased 2nd moment about ext_stats[0] -> stats_out[1] */
+int hab_advantages(const float* returns, const float* value_preds, float* adv, int count, int mode,
+                   const float* ext_stats, float* stats_out, hipStream_t stream);
+
+/* PPO._update_from_batch loss terms + their gradient (rl/ppo/ppo.py:195-250, metrics :260-275).
+ * values/logp/entropy: dense [B] outputs of evaluate_actions.  old_logp/adv/old_values/returns are
+ * (T+1,N) storage buffers gathered through rows[f] (NULL = dense).  out12 = {value_loss,
+ * action_loss, dist_entropy, total, value_pred min/mean/max, prob_ratio min/mean/max,
+ * fraction_clipped, B}. */
+int hab_ppo_loss(const float* values, const float* logp, const float* entropy, const float* old_logp,
+                 const float* adv, const float* old_values, const float* returns, const int* rows, int B,
+                 float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
+                 float* d_value, float* d_logp, float* d_entropy, float* out12, hipStream_t stream);
+
+/* nn.utils.clip_grad_norm_ + optim.Adam(foreach).step (rl/ppo/ppo.py:347-371,112-137,257) over the
+ * flat parameter arena.  grads are first multiplied by grad_scale (1/world_size after a sum
+ * all-reduce).  scratch_partials: >= 1024 doubles.  step counts from 1.  All pointers 16-B aligned. */
+int hab_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                       double* scratch_partials, int scratch_len, float grad_scale, float max_grad_norm, float lr,
+                       float beta1, float beta2, float eps, int step, float* grad_norm_out, hipStream_t stream);
+
+/* CustomFixedCategorical.sample (utils/common.py:64-68) = torch.multinomial(probs,1,True):
+ * argmax_k probs[i,k] / exp_noise[i,k] with exp_noise ~ Exp(1) drawn by the caller from the CPU
+ * generator; deterministic=1 gives .mode(). */
+int hab_sample_actions(const float* probs, const float* exp_noise, int64_t* actions, int n, int A, int deterministic,
+                       hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layer-level contractions (all on the fp32 MFMA igemm kernel).  Activations NHWC fp32 with
+ * channels % 4 == 0; conv weights are consumed from packed copies made by hab_repack_conv_weight;
+ * weight gradients are written in the reference OIHW / [out][in] layouts.  ws = split-K / reduction
+ * scratch (may be NULL -> no split-K).
+ *   conv fwd/dgrad/wgrad  <- nn.Conv2d fwd + autograd (rl/models/simple_cnn.py:68-93,
+ *                            rl/ddppo/policy/resnet.py:19-34,207-219)
+ *   obs conv              <- the permute/.float()/255/cat ingest fused into conv1 (simple_cnn.py:139-156)
+ *   linear fwd/dgrad/wgrad<- nn.Linear (simple_cnn.py:92, policy.py:416-424, rnn input projections)
+ * ------------------------------------------------------------------------------------------- */
+int hab_conv2d_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int H, int W, int C, int Cout,
+                   int KH, int KW, int stride, int pad, int relu, float* ws, size_t ws_floats, hipStream_t stream);
+int hab_obs_conv2d_fwd(const uint8_t* rgb, const float* depth, const int* rows, const float* w_fwd, const float* bias,
+                       float* y, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, int relu, float* ws,
+                       size_t ws_floats, hipStream_t stream);
+int hab_conv2d_dgrad(const float* dy, const float* w_dgrad, const float* relu_mask, const float* add, float* dx, int B,
+                     int H, int W, int C, int Cout, int KH, int KW, int stride, int pad, float* ws, size_t ws_floats,
+                     hipStream_t stream);
+int hab_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int C, int Cout, int KH, int KW,
+                     int stride, int pad, float* ws, size_t ws_floats, hipStream_t stream);
+int hab_obs_conv2d_wgrad(const uint8_t* rgb, const float* depth, const int* rows, const float* dy, float* dw_oihw, int B,
+                         int H, int W, int Cout, int KH, int KW, int stride, int pad, float* ws, size_t ws_floats,
+                         hipStream_t stream);
+int hab_linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N,
+                   int K, int relu, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+int hab_linear_dgrad(const float* dy, int lddy, const float* w, int ldw, const float* relu_mask, int ldmask, float* dx,
+                     int lddx, int M, int n_in, int n_out, int accumulate, float* ws, size_t ws_floats,
+                     hipStream_t stream);
+int hab_linear_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int lddw, int M, int n_out, int n_in,
+                     int perm_c, int perm_hw, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
+int hab_colsum(const float* a, int lda, int M, int N, float* out, int accumulate, float* ws, size_t ws_floats,
+               hipStream_t stream);
+/* OIHW -> w_fwd[co][(kh,kw,ci)] (ci padded to cin_padded) and w_dgrad[ci][(kh,kw,co)] (either may be NULL). */
+int hab_repack_conv_weight(const float* w_oihw, float* w_fwd, float* w_dgrad, int Cout, int Cin, int KH, int KW,
+                           int cin_padded, hipStream_t stream);
+/* Linear weight behind nn.Flatten of an NCHW map: w_packed[n][hw*C + c] = w[n][c*HW + hw]. */
+int hab_repack_flatten_weight(const float* w, float* w_packed, int N, int C, int HW, hipStream_t stream);
+int hab_transpose2d(const float* w, float* wt, int R, int C, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * build_pack_info_from_dones (rl/models/rnn_state_encoder.py:35-168), HOST routine (no GPU).
+ * dones: (T,N) row-major bytes.  Output arrays sized: select_inds T*N; num_seqs_at_step T; the
+ * per-fragment arrays T*N (worst case); the per-env arrays N.  Ties between equal-length fragments
+ * are ordered by (episode id, env).
+ * ------------------------------------------------------------------------------------------- */
+int hab_build_pack_info(const uint8_t* dones, int T, int N, int64_t* select_inds, int64_t* num_seqs_at_step,
+                        int64_t* sequence_starts, int64_t* sequence_lengths, int64_t* rnn_state_batch_inds,
+                        uint8_t* last_sequence_in_batch_mask, uint8_t* first_sequence_in_batch_mask,
+                        int64_t* last_sequence_in_batch_inds, int64_t* first_episode_in_batch_inds,
+                        int64_t* first_step_for_env, int32_t* num_fragments, int32_t* max_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * Policy engine: NetPolicy.act / get_value / evaluate_actions (rl/ppo/policy.py:324-402) and the
+ * backward pass that total_loss.backward() runs through them (rl/ppo/ppo.py:253), for
+ * PointNavBaselinePolicy (policy.py:427-589) [arch 0] and PointNavResNetPolicy
+ * (rl/ddppo/policy/resnet_policy.py:50-767) [arch 1].  The engine defines the flat parameter
+ * arena layout (names/shapes = the reference state_dict()); all arenas are caller-allocated.
+ * ------------------------------------------------------------------------------------------- */
+#define HAB_ARCH_SIMPLE_CNN 0
+#define HAB_ARCH_RESNET 1
+#define HAB_RNN_GRU 0
+#define HAB_RNN_LSTM 1
+
+typedef struct hab_policy_desc {
+    int32_t arch;          /* HAB_ARCH_* */
+    int32_t backbone;      /* 18 or 50 (arch 1) */
+    int32_t baseplanes;    /* 32 */
+    int32_t normalize_visual_inputs;
+    int32_t rnn_type;      /* HAB_RNN_* */
+    int32_t rnn_layers;
+    int32_t hidden;        /* 512 */
+    int32_t num_actions;   /* Discrete(n) */
+    int32_t H, W;          /* observation size */
+    int32_t has_rgb, has_depth;
+    int32_t goal_dim;      /* pointgoal_with_gps_compass dims (2) */
+    int32_t max_frames;    /* largest T*n of an evaluate call */
+    int32_t max_envs;      /* largest n of an act call */
+} hab_policy_desc;
+
+typedef struct hab_obs {   /* arena base pointers; frame f lives at row rows[f] (or f) */
+    const uint8_t* rgb;    /* (rows, H, W, 3) */
+    const float* depth;    /* (rows, H, W, 1) */
+    const float* goal;     /* (rows, goal_dim) */
+    const int64_t* prev_actions; /* (rows, 1) */
+} hab_obs;
+
+typedef struct hab_pack_info { /* int32 copies of hab_build_pack_info's arrays */
+    const int32_t* select_inds;           /* device [P] */
+    const int32_t* frag_env;              /* device [F]  rnn_state_batch_inds */
+    const int32_t* frag_start;            /* device [F]  sequence_starts */
+    const int32_t* step_offsets_host;     /* host  [max_len+1] */
+    const int32_t* num_seqs_at_step_host; /* host  [max_len] */
+    int32_t P, F, max_len;
+} hab_pack_info;
+
+typedef struct hab_policy hab_policy;
+
+int hab_policy_create(const hab_policy_desc* desc, hab_policy** out);
+void hab_policy_destroy(hab_policy* p);
+int hab_policy_num_params(const hab_policy* p);
+int hab_policy_param_info(const hab_policy* p, int i, char* name, int name_cap, int64_t* shape4, int* ndim,
+                          int64_t* offset_floats);
+int64_t hab_policy_param_floats(const hab_policy* p);
+int64_t hab_policy_packed_floats(const hab_policy* p);
+int64_t hab_policy_work_floats(const hab_policy* p);
+/* All arenas 256-byte aligned device memory; grads may be NULL for inference-only use. */
+int hab_policy_bind(hab_policy* p, float* params, float* grads, float* packed, float* work, int64_t work_floats);
+int hab_policy_repack(hab_policy* p, hipStream_t stream);
+/* actions == NULL -> get_value only.  hidden_*: (n, Lh, H), Lh = layers (GRU) / 2*layers (LSTM). */
+int hab_policy_act(hab_policy* p, const hab_obs* obs, const float* hidden_in, const uint8_t* masks,
+                   const float* exp_noise, int deterministic, int n, float* values, int64_t* actions,
+                   float* action_log_probs, float* hidden_out, float* probs_out /* (n,8) or NULL */, hipStream_t stream);
+int hab_policy_evaluate(hab_policy* p, const hab_obs* obs, const int* rows, const float* hidden0, int hidden_env_stride,
+                        const uint8_t* masks, const int64_t* actions, const hab_pack_info* pack, int B, int n,
+                        float* value, float* log_prob, float* entropy, hipStream_t stream);
+int hab_policy_final_hidden(hab_policy* p, float* hidden_out, hipStream_t stream);
+int hab_policy_backward(hab_policy* p, const hab_obs* obs, const int* rows, const int64_t* actions,
+                        const hab_pack_info* pack, const float* d_value, const float* d_log_prob, const float* d_entropy,
+                        hipStream_t stream);
+
+/* HIP-event probe around one tagged call site (roofline measurement in bench.py). */
+#define HAB_PROBE_CONV1_FWD 0
+#define HAB_PROBE_CONV2_FWD 1
+#define HAB_PROBE_CONV3_FWD 2
+#define HAB_PROBE_FC_FWD 3
+#define HAB_PROBE_CONV1_WGRAD 4
+#define HAB_PROBE_CONV2_WGRAD 5
+#define HAB_PROBE_CONV3_WGRAD 6
+#define HAB_PROBE_CONV2_DGRAD 7
+#define HAB_PROBE_CONV3_DGRAD 8
+#define HAB_PROBE_FC_WGRAD 9
+#define HAB_PROBE_FC_DGRAD 10
+int hab_policy_probe_enable(hab_policy* p, int tag /* -1 = off */);
+int hab_policy_probe_read(hab_policy* p, double* total_ms, int* count);
+
+/* Test taps into the activation workspace of the last evaluate (NHWC). */
+#define HAB_TAP_CONV1 0
+#define HAB_TAP_CONV2 1
+#define HAB_TAP_CONV3 2
+#define HAB_TAP_RNN_IN 3
+#define HAB_TAP_RNN_OUT 4
+int hab_policy_tap(hab_policy* p, int which, const float** ptr, int64_t* floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HABITAT_AMD_H */

@@ -1,0 +1,532 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the DD-PPO visual-navigation hot path.
+
+A *restatement* (functional style, plain torch-CPU fp32 + numpy) of what the
+reference's PPOTrainer path computes, written against a flat ``params`` dict that
+uses the reference's ``state_dict()`` key names.  Every function cites the reference
+file:line it follows (paths relative to
+``/root/reference/habitat-baselines/habitat_baselines``).
+
+Pinning: ``tests/test_oracle_golden.py`` checks this file against fixtures under
+``tests/golden/`` that were produced by running the *real* reference code
+(``oracle/ref_loader.py`` + ``tests/golden/make_golden.py``), and -- when
+``/root/reference`` is present -- against the live reference.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this module.  The product package (``habitat-lab_amd/``) never does.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+GOAL_UUID = "pointgoal_with_gps_compass"  # habitat-lab/habitat/tasks/nav/nav.py:309
+EPS_PPO = 1e-5  # rl/ppo/ppo.py:30
+
+
+# ---------------------------------------------------------------------------------
+# Visual encoders
+# ---------------------------------------------------------------------------------
+def simple_cnn_input(obs: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """rl/models/simple_cnn.py:139-156: NHWC->NCHW, rgb/255.0, concat rgb then depth."""
+    parts = []
+    if "rgb" in obs:
+        parts.append(obs["rgb"].permute(0, 3, 1, 2).float() / 255.0)
+    if "depth" in obs:
+        parts.append(obs["depth"].permute(0, 3, 1, 2))
+    return torch.cat(parts, dim=1)
+
+
+def simple_cnn(params: Params, pre: str, obs, taps: Optional[dict] = None) -> torch.Tensor:
+    """rl/models/simple_cnn.py:68-93: conv8x8s4+ReLU, conv4x4s2+ReLU, conv3x3s1 (NO ReLU),
+    Flatten (NCHW order), Linear+ReLU.  `pre` = 'net.visual_encoder.cnn.'"""
+    x = simple_cnn_input(obs)
+    y1 = F.relu(F.conv2d(x, params[pre + "0.weight"], params[pre + "0.bias"], stride=4))
+    y2 = F.relu(F.conv2d(y1, params[pre + "2.weight"], params[pre + "2.bias"], stride=2))
+    y3 = F.conv2d(y2, params[pre + "4.weight"], params[pre + "4.bias"], stride=1)
+    flat = y3.flatten(1)
+    out = F.relu(F.linear(flat, params[pre + "6.weight"], params[pre + "6.bias"]))
+    if taps is not None:
+        taps.update(cnn_in=x, conv1=y1, conv2=y2, conv3=y3, cnn_out=out)
+    return out
+
+
+def resnet_input(obs, visual_keys: List[str]) -> torch.Tensor:
+    """rl/ddppo/policy/resnet_policy.py:259-271: per key permute, uint8 keys scaled by
+    fp32(1/255) (multiply, not divide), concat in observation-space key order, avg_pool2d(2)."""
+    parts = []
+    for k in visual_keys:
+        v = obs[k].permute(0, 3, 1, 2)
+        if v.dtype == torch.uint8:
+            v = v.float() * (1.0 / 255.0)
+        elif v.dtype != torch.float32:
+            v = v.float() if False else v  # int32 semantic is concatenated as-is by torch.cat type promotion
+        parts.append(v)
+    x = torch.cat(parts, dim=1)
+    return F.avg_pool2d(x.float(), 2)
+
+
+def running_mean_and_var(x, mean, var, count, training: bool, world_size: int = 1):
+    """rl/ddppo/policy/running_mean_and_var.py:24-78 (single process).  Returns
+    (normalised x, new_mean, new_var, new_count)."""
+    if training:
+        n = x.size(0)
+        xc = x.transpose(1, 0).contiguous().view(x.size(1), -1)
+        new_mean = xc.mean(-1, keepdim=True)
+        new_count = torch.full_like(count, n)
+        new_var = (xc - new_mean).pow(2).mean(dim=-1, keepdim=True)
+        new_mean = new_mean.view(1, -1, 1, 1)
+        new_var = new_var.view(1, -1, 1, 1)
+        m_a = var * count
+        m_b = new_var * new_count
+        M2 = m_a + m_b + (new_mean - mean).pow(2) * count * new_count / (count + new_count)
+        var = M2 / (count + new_count)
+        mean = (count * mean + new_count * new_mean) / (count + new_count)
+        count = count + new_count
+    inv_stdev = torch.rsqrt(torch.max(var, torch.full_like(var, 1e-2)))
+    return torch.addcmul(-mean * inv_stdev, x, inv_stdev), mean, var, count
+
+
+RESNET_LAYERS = {"resnet18": ("basic", [2, 2, 2, 2]), "resnet50": ("bottleneck", [3, 4, 6, 3])}
+
+
+def _gn(x, params, key, groups):
+    return F.group_norm(x, groups, params[key + ".weight"], params[key + ".bias"], eps=1e-5)
+
+
+def resnet_backbone(params: Params, pre: str, x, backbone: str, baseplanes: int, ngroups: int, taps=None):
+    """rl/ddppo/policy/resnet.py:196-281.  bias-free convs, GroupNorm(ngroups), 7x7/2 stem,
+    3x3/2 maxpool, 4 stages; BasicBlock :37-69, Bottleneck :116-152."""
+    kind, layers = RESNET_LAYERS[backbone]
+    x = F.conv2d(x, params[pre + "conv1.0.weight"], None, stride=2, padding=3)
+    x = F.relu(_gn(x, params, pre + "conv1.1", ngroups))
+    if taps is not None:
+        taps["stem"] = x
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    if taps is not None:
+        taps["pool"] = x
+    inplanes = baseplanes
+    expansion = 1 if kind == "basic" else 4
+    for li, nblocks in enumerate(layers):
+        planes = baseplanes * (2 ** li)
+        for bi in range(nblocks):
+            stride = 2 if (bi == 0 and li > 0) else 1
+            bp = f"{pre}layer{li + 1}.{bi}."
+            has_ds = bi == 0 and (stride != 1 or inplanes != planes * expansion)
+            residual = x
+            if kind == "basic":
+                out = F.conv2d(x, params[bp + "convs.0.weight"], None, stride=stride, padding=1)
+                out = F.relu(_gn(out, params, bp + "convs.1", ngroups))
+                out = F.conv2d(out, params[bp + "convs.3.weight"], None, stride=1, padding=1)
+                out = _gn(out, params, bp + "convs.4", ngroups)
+            else:
+                out = F.conv2d(x, params[bp + "convs.0.weight"], None)
+                out = F.relu(_gn(out, params, bp + "convs.1", ngroups))
+                out = F.conv2d(out, params[bp + "convs.3.weight"], None, stride=stride, padding=1)
+                out = F.relu(_gn(out, params, bp + "convs.4", ngroups))
+                out = F.conv2d(out, params[bp + "convs.6.weight"], None)
+                out = _gn(out, params, bp + "convs.7", ngroups)
+            if has_ds:
+                residual = F.conv2d(x, params[bp + "downsample.0.weight"], None, stride=stride)
+                residual = _gn(residual, params, bp + "downsample.1", ngroups)
+            x = F.relu(out + residual)
+            inplanes = planes * expansion
+        if taps is not None:
+            taps[f"layer{li + 1}"] = x
+    return x
+
+
+def resnet_encoder(params: Params, pre: str, obs, visual_keys, backbone, baseplanes, training,
+                   normalize: bool, taps=None, rmv_out: Optional[dict] = None):
+    """rl/ddppo/policy/resnet_policy.py:255-276.  `pre` = 'net.visual_encoder.'"""
+    x = resnet_input(obs, visual_keys)
+    if normalize:
+        x, m, v, c = running_mean_and_var(
+            x, params[pre + "running_mean_and_var._mean"], params[pre + "running_mean_and_var._var"],
+            params[pre + "running_mean_and_var._count"], training)
+        if rmv_out is not None:
+            rmv_out.update(mean=m, var=v, count=c)
+    if taps is not None:
+        taps["enc_in"] = x
+    x = resnet_backbone(params, pre + "backbone.", x, backbone, baseplanes, baseplanes // 2, taps)
+    x = F.conv2d(x, params[pre + "compression.0.weight"], None, padding=1)
+    x = F.relu(F.group_norm(x, 1, params[pre + "compression.1.weight"], params[pre + "compression.1.bias"], eps=1e-5))
+    if taps is not None:
+        taps["compression"] = x
+    return x
+
+
+# ---------------------------------------------------------------------------------
+# Recurrent state encoder -- restated as a masked time scan
+# ---------------------------------------------------------------------------------
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.GRU cell equations (gate order r,z,n); call site rl/models/rnn_state_encoder.py:405-420."""
+    gi = F.linear(x, w_ih, b_ih)
+    gh = F.linear(h, w_hh, b_hh)
+    i_r, i_z, i_n = gi.chunk(3, -1)
+    h_r, h_z, h_n = gh.chunk(3, -1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return (1.0 - z) * n + z * h
+
+
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.LSTM cell equations (gate order i,f,g,o); call site rl/models/rnn_state_encoder.py:374-402."""
+    g = F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+    i, f, gg, o = g.chunk(4, -1)
+    i, f, gg, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)
+    c2 = f * c + i * gg
+    return o * torch.tanh(c2), c2
+
+
+def rnn_step(params: Params, pre: str, rnn_type: str, num_layers: int, x, hidden):
+    """One time step over all layers.  hidden: (L, n, H) with L = num_layers (GRU) or
+    2*num_layers (LSTM: h layers then c layers -- rnn_state_encoder.py:391-402)."""
+    new = []
+    inp = x
+    if rnn_type == "GRU":
+        for l in range(num_layers):
+            h = gru_cell(inp, hidden[l], params[f"{pre}weight_ih_l{l}"], params[f"{pre}weight_hh_l{l}"],
+                         params[f"{pre}bias_ih_l{l}"], params[f"{pre}bias_hh_l{l}"])
+            new.append(h)
+            inp = h
+        return inp, torch.stack(new, 0)
+    hs, cs = [], []
+    for l in range(num_layers):
+        h, c = lstm_cell(inp, hidden[l], hidden[num_layers + l], params[f"{pre}weight_ih_l{l}"],
+                         params[f"{pre}weight_hh_l{l}"], params[f"{pre}bias_ih_l{l}"], params[f"{pre}bias_hh_l{l}"])
+        hs.append(h)
+        cs.append(c)
+        inp = h
+    return inp, torch.stack(hs + cs, 0)
+
+
+def rnn_forward(params: Params, pre: str, rnn_type: str, num_layers: int, x, hidden_bf, masks,
+                T: Optional[int] = None):
+    """rl/models/rnn_state_encoder.py:301-371.  hidden_bf is batch-first (n, L, H).
+    x: (n, in) single step, or (T*n, in) time-major sequence with masks (T*n, 1).
+    The packed-sequence path (:187-277) is equivalent to scanning each env column over time and
+    zeroing the hidden state wherever masks[t] is False (pinned by test/test_rnn_state_encoder.py:19-94);
+    this restatement uses that scan."""
+    hidden = hidden_bf.permute(1, 0, 2)
+    n = hidden.size(1)
+    if x.size(0) == n:
+        hidden = torch.where(masks.view(1, -1, 1), hidden, hidden.new_zeros(()))
+        out, hidden = rnn_step(params, pre, rnn_type, num_layers, x, hidden)
+        return out, hidden.permute(1, 0, 2)
+    T = x.size(0) // n
+    xs = x.view(T, n, -1)
+    ms = masks.view(T, n)
+    outs = []
+    for t in range(T):
+        hidden = torch.where(ms[t].view(1, -1, 1), hidden, hidden.new_zeros(()))
+        o, hidden = rnn_step(params, pre, rnn_type, num_layers, xs[t], hidden)
+        outs.append(o)
+    return torch.stack(outs, 0).view(T * n, -1), hidden.permute(1, 0, 2)
+
+
+# ---------------------------------------------------------------------------------
+# Nets and heads
+# ---------------------------------------------------------------------------------
+class NetSpec:
+    """What the oracle needs to know about the policy (mirrors ctor args of
+    PointNavBaselinePolicy rl/ppo/policy.py:427-460 and PointNavResNetPolicy
+    rl/ddppo/policy/resnet_policy.py:50-162)."""
+
+    def __init__(self, kind="baseline", rnn_type="GRU", num_layers=1, backbone="resnet18", baseplanes=32,
+                 visual_keys=("rgb", "depth"), normalize=True, num_actions=4, hidden=512):
+        self.kind = kind
+        self.rnn_type = rnn_type
+        self.num_layers = num_layers
+        self.backbone = backbone
+        self.baseplanes = baseplanes
+        self.visual_keys = list(visual_keys)
+        self.normalize = normalize
+        self.num_actions = num_actions
+        self.hidden = hidden
+
+
+def net_forward(params: Params, spec: NetSpec, obs, hidden_bf, prev_actions, masks, training=False,
+                taps=None, rmv_out=None):
+    """PointNavBaselineNet.forward rl/ppo/policy.py:557-589 / PointNavResNetNet.forward
+    rl/ddppo/policy/resnet_policy.py:625-767 (PointNav subset: visual + goal + prev-action)."""
+    if spec.kind == "baseline":
+        vis = simple_cnn(params, "net.visual_encoder.cnn.", obs, taps)
+        x = torch.cat([vis, obs[GOAL_UUID]], dim=1)
+    else:
+        feats = resnet_encoder(params, "net.visual_encoder.", obs, spec.visual_keys, spec.backbone,
+                               spec.baseplanes, training, spec.normalize, taps, rmv_out)
+        vis = F.relu(F.linear(feats.flatten(1), params["net.visual_fc.1.weight"], params["net.visual_fc.1.bias"]))
+        g = obs[GOAL_UUID]
+        g = torch.stack([g[:, 0], torch.cos(-g[:, 1]), torch.sin(-g[:, 1])], -1)  # :662-672
+        tgt = F.linear(g, params["net.tgt_embeding.weight"], params["net.tgt_embeding.bias"])
+        pa = prev_actions.squeeze(-1)
+        pa = torch.where(masks.view(-1), pa + 1, torch.zeros_like(pa))  # :747-753
+        pa = F.embedding(pa, params["net.prev_action_embedding.weight"])
+        x = torch.cat([vis, tgt, pa], dim=1)
+        if taps is not None:
+            taps["visual_fc"] = vis
+    if taps is not None:
+        taps["rnn_in"] = x
+    out, hidden = rnn_forward(params, "net.state_encoder.rnn.", spec.rnn_type, spec.num_layers, x, hidden_bf, masks)
+    if taps is not None:
+        taps["rnn_out"] = out
+    return out, hidden
+
+
+def heads(params: Params, feats):
+    """CategoricalNet utils/common.py:85-96 + CriticHead rl/ppo/policy.py:416-424.
+    Returns (normalised logits, probs, value) exactly as torch.distributions.Categorical(logits=) holds them."""
+    logits = F.linear(feats, params["action_distribution.linear.weight"], params["action_distribution.linear.bias"]).float()
+    logits = logits - logits.logsumexp(dim=-1, keepdim=True)
+    probs = F.softmax(logits, dim=-1)
+    value = F.linear(feats, params["critic.fc.weight"], params["critic.fc.bias"])
+    return logits, probs, value
+
+
+def sample_actions(probs, exp_noise=None, generator=None):
+    """CustomFixedCategorical.sample utils/common.py:64-68 -> torch.multinomial(probs, 1, True).
+    For one draw torch's CPU multinomial is argmax(probs / Exp(1) noise); passing the pre-drawn
+    noise reproduces the same stream (checked in tests/test_oracle_golden.py)."""
+    if exp_noise is None:
+        return torch.multinomial(probs, 1, True, generator=generator)
+    return torch.argmax(probs / exp_noise, dim=-1, keepdim=True)
+
+
+def act(params, spec, obs, hidden_bf, prev_actions, masks, exp_noise=None, deterministic=False):
+    """NetPolicy.act rl/ppo/policy.py:324-352."""
+    feats, hidden = net_forward(params, spec, obs, hidden_bf, prev_actions, masks, training=False)
+    logits, probs, value = heads(params, feats)
+    if deterministic:
+        action = probs.argmax(dim=-1, keepdim=True)
+    else:
+        action = sample_actions(probs, exp_noise)
+    logp = logits.gather(-1, action)
+    return dict(values=value, actions=action, action_log_probs=logp, rnn_hidden_states=hidden, probs=probs)
+
+
+def evaluate_actions(params, spec, obs, hidden_bf, prev_actions, masks, action, training=True, taps=None, rmv_out=None):
+    """NetPolicy.evaluate_actions rl/ppo/policy.py:361-402 -> (value, log_prob, entropy, hidden)."""
+    feats, hidden = net_forward(params, spec, obs, hidden_bf, prev_actions, masks, training, taps, rmv_out)
+    logits, probs, value = heads(params, feats)
+    logp = logits.gather(-1, action)
+    min_real = torch.finfo(logits.dtype).min
+    entropy = -(torch.clamp(logits, min=min_real) * probs).sum(-1, keepdim=True)
+    return value, logp, entropy, hidden
+
+
+# ---------------------------------------------------------------------------------
+# Returns, advantages, loss, optimiser
+# ---------------------------------------------------------------------------------
+def compute_returns(rewards, value_preds, masks, next_value, num_steps, use_gae, gamma, tau):
+    """common/rollout_storage.py:174-205.  Tensors are (T+1, N, 1); writes value_preds[num_steps]."""
+    value_preds = value_preds.clone()
+    returns = torch.zeros_like(value_preds)
+    m = masks.float()
+    if use_gae:
+        value_preds[num_steps] = next_value
+        gae = torch.zeros_like(next_value)
+        for step in reversed(range(num_steps)):
+            delta = rewards[step] + gamma * value_preds[step + 1] * m[step + 1] - value_preds[step]
+            gae = delta + gamma * tau * gae * m[step + 1]
+            returns[step] = gae + value_preds[step]
+    else:
+        returns[num_steps] = next_value
+        for step in reversed(range(num_steps)):
+            returns[step] = gamma * returns[step + 1] * m[step + 1] + rewards[step]
+    return returns, value_preds
+
+
+def get_advantages(returns, value_preds, use_normalized_advantage, world_size: int = 1):
+    """rl/ppo/ppo.py:139-153 (all T+1 rows; unbiased var_mean single process);
+    rl/ddppo/algo/ddppo.py:59-84 for the distributed (biased) statistics."""
+    adv = returns - value_preds
+    if not use_normalized_advantage:
+        return adv
+    finite = adv[torch.isfinite(adv)]
+    if world_size > 1:
+        mean = finite.mean()
+        var = (finite - mean).pow(2).mean()
+    else:
+        var, mean = torch.var_mean(finite)
+    return (adv - mean) * torch.rsqrt(var + EPS_PPO)
+
+
+def ppo_loss(values, action_log_probs, dist_entropy, batch, clip_param, value_loss_coef, entropy_coef,
+             use_clipped_value_loss=True):
+    """rl/ppo/ppo.py:195-250.  Returns (total, value_loss, action_loss, entropy, ratio)."""
+    ratio = torch.exp(action_log_probs - batch["action_log_probs"])
+    surr1 = batch["advantages"] * ratio
+    surr2 = batch["advantages"] * torch.clamp(ratio, 1.0 - clip_param, 1.0 + clip_param)
+    action_loss = -torch.min(surr1, surr2)
+    values = values.float()
+    if use_clipped_value_loss:
+        delta = values.detach() - batch["value_preds"]
+        clipped = batch["value_preds"] + delta.clamp(-clip_param, clip_param)
+        values = torch.where(delta.abs() < clip_param, values, clipped)
+    value_loss = 0.5 * F.mse_loss(values, batch["returns"], reduction="none")
+    action_loss, value_loss, ent = action_loss.mean(), value_loss.mean(), dist_entropy.mean()
+    total = torch.stack([value_loss_coef * value_loss, action_loss, -entropy_coef * ent]).sum()
+    return total, value_loss, action_loss, ent, ratio
+
+
+def clip_grad_norm(grads: List[torch.Tensor], max_norm: float) -> torch.Tensor:
+    """torch.nn.utils.clip_grad_norm_ (call site rl/ppo/ppo.py:361-364): L2 of per-tensor L2 norms,
+    coef = max_norm/(norm+1e-6) clamped to 1, applied in place."""
+    norms = torch.stack([torch.linalg.vector_norm(g, 2.0) for g in grads])
+    total = torch.linalg.vector_norm(norms, 2.0)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return total
+
+
+def adam_step(p, g, m, v, step: int, lr, eps, beta1=0.9, beta2=0.999):
+    """torch.optim.Adam single-tensor update (call site rl/ppo/ppo.py:118-135,257); in place."""
+    m.lerp_(g, 1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+# ---------------------------------------------------------------------------------
+# Pack-info (sequence packing index arrays), restated with plain loops
+# ---------------------------------------------------------------------------------
+def build_pack_info_from_dones(dones: np.ndarray) -> Dict[str, np.ndarray]:
+    """rl/models/rnn_state_encoder.py:35-168.  dones: (T, N) bool.  An episode fragment is a maximal
+    run of steps of one env with no done strictly inside it (a done at step t starts a new fragment
+    AT t).  Fragments are ordered by descending length (stable in (episode id, env) key order --
+    the order np.argsort(-lengths) yields on np.unique's sorted keys), and the packed data lists,
+    for step s = 0.., the s-th element of every fragment that is longer than s."""
+    T, N = dones.shape
+    ep = np.cumsum(dones.astype(np.int64), 0)  # episode id per (t, n)
+    frags = {}  # key (ep*N + n) -> list of flat indices t*N+n in time order
+    for t in range(T):
+        for n in range(N):
+            frags.setdefault(int(ep[t, n]) * N + n, []).append(t * N + n)
+    keys = sorted(frags.keys())
+    lengths = np.array([len(frags[k]) for k in keys], dtype=np.int64)
+    order = np.argsort(-lengths)  # same call as the reference so that tie-breaking is identical
+    keys = [keys[i] for i in order]
+    lengths = lengths[order]
+    max_len = int(lengths[0])
+    select, nseq = [], []
+    for s in range(max_len):
+        cnt = 0
+        for k in keys:
+            if len(frags[k]) > s:
+                select.append(frags[k][s])
+                cnt += 1
+        nseq.append(cnt)
+    select = np.array(select, dtype=np.int64)
+    nseq = np.array(nseq, dtype=np.int64)
+    starts = select[: nseq[0]]
+    env_of = starts % N
+    uniq_env, batch_inds = np.unique(env_of, return_inverse=True)
+    ep_of = np.array([k // N for k in keys], dtype=np.int64)
+    last_mask = np.zeros(len(keys), dtype=bool)
+    first_mask = np.zeros(len(keys), dtype=bool)
+    first_step = []
+    for e in uniq_env:
+        sel = env_of == e
+        last_mask[sel] = ep_of[sel] == ep_of[sel].max()
+        fm = ep_of[sel] == ep_of[sel].min()
+        first_mask[sel] = fm
+        first_step.append(int(starts[sel][fm][0]))
+    return {
+        "select_inds": select,
+        "num_seqs_at_step": nseq,
+        "sequence_starts": starts,
+        "sequence_lengths": lengths,
+        "rnn_state_batch_inds": batch_inds.astype(np.int64),
+        "last_sequence_in_batch_mask": last_mask,
+        "first_sequence_in_batch_mask": first_mask,
+        "last_sequence_in_batch_inds": np.nonzero(last_mask)[0],
+        "first_episode_in_batch_inds": np.nonzero(first_mask)[0],
+        "first_step_for_env": np.asarray(first_step),
+    }
+
+
+# ---------------------------------------------------------------------------------
+# Whole PPO update on a rollout (reference control flow, oracle arithmetic)
+# ---------------------------------------------------------------------------------
+def minibatch_env_indices(num_envs: int, num_mini_batch: int, generator=None):
+    """common/rollout_storage.py:236: torch.randperm(N).chunk(M) on the global CPU generator."""
+    return list(torch.randperm(num_envs, generator=generator).chunk(num_mini_batch))
+
+
+def gather_minibatch(buffers: dict, advantages, inds, num_steps):
+    """common/rollout_storage.py:237-246: rows 0..T-1 of the chosen env columns, flattened time-major;
+    recurrent_hidden_states keeps only row 0."""
+    def take(v):
+        return v[0:num_steps, inds].flatten(0, 1)
+
+    batch = {k: take(v) for k, v in buffers.items() if k not in ("observations", "recurrent_hidden_states")}
+    batch["observations"] = {k: take(v) for k, v in buffers["observations"].items()}
+    batch["recurrent_hidden_states"] = buffers["recurrent_hidden_states"][0:1, inds].flatten(0, 1)
+    batch["advantages"] = take(advantages)
+    return batch
+
+
+def ppo_update(params: Params, spec: NetSpec, buffers: dict, num_steps: int, cfg, opt_state: dict,
+               trainable: List[str], perms: Optional[List[List[torch.Tensor]]] = None, record=None):
+    """PPO.update rl/ppo/ppo.py:301-332 + _update_from_batch :164-299 on `buffers` (dict of (T+1,N,..)
+    tensors incl. 'returns').  `params` holds leaf tensors (requires_grad for names in `trainable`).
+    opt_state: {'step': int, 'm': {name: t}, 'v': {name: t}}.  Updates params in place, returns the
+    averaged learner metrics like the reference does."""
+    adv = get_advantages(buffers["returns"], buffers["value_preds"], cfg.use_normalized_advantage)
+    metrics: Dict[str, list] = {}
+
+    def rec(k, v):
+        metrics.setdefault(k, []).append(torch.as_tensor(v, dtype=torch.float32).detach())
+
+    N = buffers["returns"].size(1)
+    for epoch in range(cfg.ppo_epoch):
+        chunks = perms[epoch] if perms is not None else minibatch_env_indices(N, cfg.num_mini_batch)
+        for inds in chunks:
+            batch = gather_minibatch(buffers, adv, inds, num_steps)
+            for n in trainable:
+                params[n].grad = None
+            rmv = {}
+            values, logp, ent, _ = evaluate_actions(
+                params, spec, batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"],
+                batch["masks"], batch["actions"], training=True, rmv_out=rmv)
+            total, vl, al, de, ratio = ppo_loss(values, logp, ent, batch, cfg.clip_param, cfg.value_loss_coef,
+                                                cfg.entropy_coef, cfg.use_clipped_value_loss)
+            total.backward()
+            grads = [params[n].grad for n in trainable if params[n].grad is not None]
+            gnorm = clip_grad_norm(grads, cfg.max_grad_norm)
+            opt_state["step"] += 1
+            with torch.no_grad():
+                for n in trainable:
+                    if params[n].grad is None:
+                        continue
+                    adam_step(params[n], params[n].grad, opt_state["m"][n], opt_state["v"][n], opt_state["step"],
+                              cfg.lr, cfg.eps)
+                if rmv:
+                    pre = "net.visual_encoder.running_mean_and_var."
+                    params[pre + "_mean"], params[pre + "_var"], params[pre + "_count"] = rmv["mean"], rmv["var"], rmv["count"]
+            if record is not None:
+                record.append(dict(total=total.detach(), value_loss=vl.detach(), action_loss=al.detach(),
+                                   dist_entropy=de.detach(), grad_norm=gnorm.detach(), inds=inds.clone()))
+            v = values.detach().float()
+            for name, op in (("min", torch.min), ("mean", torch.mean), ("max", torch.max)):
+                rec(f"value_pred_{name}", op(v))
+            for name, op in (("min", torch.min), ("mean", torch.mean), ("max", torch.max)):
+                rec(f"prob_ratio_{name}", op(ratio.detach()))
+            rec("value_loss", vl)
+            rec("action_loss", al)
+            rec("dist_entropy", de)
+            if epoch == cfg.ppo_epoch - 1:
+                r = ratio.detach()
+                rec("ppo_fraction_clipped", (r > 1.0 + cfg.clip_param).float().mean() + (r < 1.0 - cfg.clip_param).float().mean())
+            rec("grad_norm", gnorm)
+    return {k: float(torch.stack(v).mean()) for k, v in metrics.items()}
