@@ -1,0 +1,184 @@
+"""Thin Python owner of a `hab_policy` engine handle (include/habitat_amd.h): allocates the flat
+parameter / gradient / packed-weight / workspace arenas with torch (device memory plumbing only) and
+forwards act / evaluate / backward to the C-ABI.  No arithmetic happens in this file."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Obs, PackInfo, PolicyDesc, check, ptr, stream_ptr
+
+ARCH = {"simple_cnn": 0, "resnet": 1}
+RNN = {"GRU": 0, "LSTM": 1}
+
+
+class DevicePackInfo:
+    """build_pack_info_from_dones (rl/models/rnn_state_encoder.py:155-168) through the C++ host builder,
+    plus int32 device copies for the kernels."""
+
+    def __init__(self, dones: np.ndarray, device=None):
+        dones = np.ascontiguousarray(dones, dtype=np.uint8)
+        T, N = dones.shape
+        P = T * N
+        L = _lib.lib()
+        a = {
+            "select_inds": np.empty(P, np.int64), "num_seqs_at_step": np.empty(T, np.int64),
+            "sequence_starts": np.empty(P, np.int64), "sequence_lengths": np.empty(P, np.int64),
+            "rnn_state_batch_inds": np.empty(P, np.int64), "last_sequence_in_batch_mask": np.zeros(P, np.uint8),
+            "first_sequence_in_batch_mask": np.zeros(P, np.uint8), "last_sequence_in_batch_inds": np.empty(N, np.int64),
+            "first_episode_in_batch_inds": np.empty(N, np.int64), "first_step_for_env": np.empty(N, np.int64),
+        }
+        nf, ml = C.c_int32(0), C.c_int32(0)
+        check(L.hab_build_pack_info(dones.ctypes.data, T, N, *[v.ctypes.data for v in a.values()], C.byref(nf), C.byref(ml)),
+              "hab_build_pack_info")
+        F, max_len = nf.value, ml.value
+        self.T, self.N, self.P, self.F, self.max_len = T, N, P, F, max_len
+        self.arrays = {
+            "select_inds": a["select_inds"], "num_seqs_at_step": a["num_seqs_at_step"][:max_len],
+            "sequence_starts": a["sequence_starts"][:F], "sequence_lengths": a["sequence_lengths"][:F],
+            "rnn_state_batch_inds": a["rnn_state_batch_inds"][:F],
+            "last_sequence_in_batch_mask": a["last_sequence_in_batch_mask"][:F].astype(bool),
+            "first_sequence_in_batch_mask": a["first_sequence_in_batch_mask"][:F].astype(bool),
+            "last_sequence_in_batch_inds": a["last_sequence_in_batch_inds"],
+            "first_episode_in_batch_inds": a["first_episode_in_batch_inds"], "first_step_for_env": a["first_step_for_env"],
+        }
+        self._nseq = np.ascontiguousarray(self.arrays["num_seqs_at_step"], dtype=np.int32)
+        self._off = np.zeros(max_len + 1, np.int32)
+        self._off[1:] = np.cumsum(self._nseq)
+        self.struct = None
+        if device is not None:
+            self.to(device)
+
+    def to(self, device):
+        packed = np.concatenate([self.arrays["select_inds"], self.arrays["rnn_state_batch_inds"],
+                                 self.arrays["sequence_starts"]]).astype(np.int32)
+        self._dev = torch.from_numpy(packed).to(device, non_blocking=True)
+        P, F = self.P, self.F
+        s = PackInfo()
+        base = self._dev.data_ptr()
+        s.select_inds = base
+        s.frag_env = base + 4 * P
+        s.frag_start = base + 4 * (P + F)
+        s.step_offsets_host = self._off.ctypes.data
+        s.num_seqs_at_step_host = self._nseq.ctypes.data
+        s.P, s.F, s.max_len = P, F, self.max_len
+        self.struct = s
+        return self
+
+
+class PolicyEngine:
+    def __init__(self, *, arch="simple_cnn", backbone=18, baseplanes=32, normalize_visual_inputs=False, rnn_type="GRU",
+                 rnn_layers=1, hidden=512, num_actions=4, H=256, W=256, has_rgb=True, has_depth=True, goal_dim=2,
+                 max_frames=4096, max_envs=64, device="cuda", with_grads=True):
+        L = _lib.lib()
+        self.L = L
+        d = PolicyDesc(ARCH[arch], backbone, baseplanes, int(normalize_visual_inputs), RNN[rnn_type.upper()], rnn_layers, hidden,
+                       num_actions, H, W, int(has_rgb), int(has_depth), goal_dim, max_frames, max_envs)
+        self.desc = d
+        h = C.c_void_p()
+        check(L.hab_policy_create(C.byref(d), C.byref(h)), "hab_policy_create")
+        self.h = h
+        self.device = torch.device(device)
+        self.hidden, self.rnn_layers, self.rnn_type = hidden, rnn_layers, rnn_type.upper()
+        self.Lh = rnn_layers * (2 if self.rnn_type == "LSTM" else 1)
+        self.num_actions = num_actions
+        n = L.hab_policy_num_params(h)
+        self.param_floats = L.hab_policy_param_floats(h)
+        self.specs = []
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        nd, off = C.c_int(0), C.c_int64(0)
+        for i in range(n):
+            check(L.hab_policy_param_info(h, i, name, 256, shape, C.byref(nd), C.byref(off)), "hab_policy_param_info")
+            self.specs.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value)), int(off.value)))
+        dev = self.device
+        self.params_flat = torch.zeros(self.param_floats, dtype=torch.float32, device=dev)
+        self.grads_flat = torch.zeros(self.param_floats, dtype=torch.float32, device=dev) if with_grads else None
+        self.packed = torch.zeros(L.hab_policy_packed_floats(h), dtype=torch.float32, device=dev)
+        self.work_floats = L.hab_policy_work_floats(h)
+        self.work = torch.empty(self.work_floats, dtype=torch.float32, device=dev)
+        check(L.hab_policy_bind(h, ptr(self.params_flat), ptr(self.grads_flat), ptr(self.packed), ptr(self.work), self.work_floats),
+              "hab_policy_bind")
+        self.views: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self.grad_views: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        for nm, shp, o in self.specs:
+            numel = int(np.prod(shp))
+            self.views[nm] = self.params_flat[o:o + numel].view(shp)
+            if with_grads:
+                self.grad_views[nm] = self.grads_flat[o:o + numel].view(shp)
+        self._packed_version = -1
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.hab_policy_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------------------------
+    def load(self, state: Dict[str, torch.Tensor]):
+        with torch.no_grad():
+            for nm, v in self.views.items():
+                v.copy_(state[nm])
+        self.repack()
+
+    def state(self) -> Dict[str, torch.Tensor]:
+        return OrderedDict((k, v.detach().clone()) for k, v in self.views.items())
+
+    def repack(self):
+        check(self.L.hab_policy_repack(self.h, stream_ptr()), "hab_policy_repack")
+        self._packed_version = self.params_flat._version
+
+    def _fresh(self):
+        if self._packed_version != self.params_flat._version:
+            self.repack()
+
+    # ---- calls ------------------------------------------------------------------------------
+    @staticmethod
+    def _obs(rgb, depth, goal, prev_actions=None):
+        return Obs(rgb.data_ptr() if rgb is not None else None, depth.data_ptr() if depth is not None else None,
+                   goal.data_ptr() if goal is not None else None, prev_actions.data_ptr() if prev_actions is not None else None)
+
+    def act(self, rgb, depth, goal, hidden_in, masks, n, *, exp_noise=None, deterministic=False, values, actions=None,
+            action_log_probs=None, hidden_out=None, probs_out=None, prev_actions=None):
+        self._fresh()
+        o = self._obs(rgb, depth, goal, prev_actions)
+        check(self.L.hab_policy_act(self.h, C.byref(o), ptr(hidden_in), ptr(masks), ptr(exp_noise), int(deterministic), n,
+                                    ptr(values), ptr(actions), ptr(action_log_probs), ptr(hidden_out), ptr(probs_out),
+                                    stream_ptr()), "hab_policy_act")
+
+    def evaluate(self, rgb, depth, goal, rows, hidden0, masks, actions, pack: DevicePackInfo, B, n, *, value=None,
+                 log_prob=None, entropy=None, prev_actions=None):
+        self._fresh()
+        o = self._obs(rgb, depth, goal, prev_actions)
+        check(self.L.hab_policy_evaluate(self.h, C.byref(o), ptr(rows), ptr(hidden0), self.Lh * self.hidden, ptr(masks),
+                                         ptr(actions), C.byref(pack.struct), B, n, ptr(value), ptr(log_prob), ptr(entropy),
+                                         stream_ptr()), "hab_policy_evaluate")
+
+    def final_hidden(self, out):
+        check(self.L.hab_policy_final_hidden(self.h, ptr(out), stream_ptr()), "hab_policy_final_hidden")
+
+    def backward(self, rgb, depth, goal, rows, actions, pack: DevicePackInfo, d_value, d_log_prob, d_entropy, prev_actions=None):
+        o = self._obs(rgb, depth, goal, prev_actions)
+        check(self.L.hab_policy_backward(self.h, C.byref(o), ptr(rows), ptr(actions), C.byref(pack.struct), ptr(d_value),
+                                         ptr(d_log_prob), ptr(d_entropy), stream_ptr()), "hab_policy_backward")
+
+    def tap(self, which: int) -> torch.Tensor:
+        p, n = C.c_void_p(), C.c_int64(0)
+        check(self.L.hab_policy_tap(self.h, which, C.byref(p), C.byref(n)), "hab_policy_tap")
+        off = (p.value - self.work.data_ptr()) // 4
+        return self.work[off:off + n.value]
+
+    def probe_enable(self, tag: int):
+        check(self.L.hab_policy_probe_enable(self.h, tag))
+
+    def probe_read(self):
+        ms, cnt = C.c_double(0), C.c_int(0)
+        check(self.L.hab_policy_probe_read(self.h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

@@ -1,0 +1,386 @@
+"""Actor-critic policies with the plugin surface of habitat_baselines/rl/ppo/policy.py
+(PolicyActionData :47-96, Policy :99-249, NetPolicy :252-413, PointNavBaselinePolicy :427-460) whose
+forward AND backward run in the HIP policy engine (habitat_amd/engine.py -> libhabitat_amd.so).
+
+The module is an ``nn.Module`` whose parameters carry the reference's ``state_dict()`` names; once the
+policy is moved to a GPU (``.to(device)``) every parameter is a view into ONE flat fp32 arena (and its
+``.grad`` a view into the flat gradient arena) that the kernels and the fused Adam step operate on.
+Initial values are drawn exactly like the reference does (same torch initialisers in the same order),
+so a seed gives the same initial policy in both code bases.
+"""
+from __future__ import annotations
+
+import abc
+from dataclasses import dataclass
+from typing import Any, Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+from torch import nn as nn
+
+from habitat_amd import _lib
+from habitat_amd.common.baseline_registry import baseline_registry
+from habitat_amd.common.spaces import get_num_actions
+from habitat_amd.engine import DevicePackInfo, PolicyEngine
+
+GOAL_UUID = "pointgoal_with_gps_compass"  # IntegratedPointGoalGPSAndCompassSensor.cls_uuid (tasks/nav/nav.py:309)
+
+
+@dataclass
+class PolicyActionData:
+    """Same fields as rl/ppo/policy.py:47-96."""
+    rnn_hidden_states: Optional[torch.Tensor] = None
+    actions: Optional[torch.Tensor] = None
+    values: Optional[torch.Tensor] = None
+    action_log_probs: Optional[torch.Tensor] = None
+    take_actions: Optional[torch.Tensor] = None
+    policy_info: Optional[List[Dict[str, Any]]] = None
+    should_inserts: Optional[torch.BoolTensor] = None
+
+    def write_action(self, write_idx: int, write_action: torch.Tensor) -> None:
+        self.actions[:, write_idx] = write_action
+
+    @property
+    def env_actions(self) -> torch.Tensor:
+        return self.actions if self.take_actions is None else self.take_actions
+
+
+class Policy(abc.ABC):
+    """rl/ppo/policy.py:99-249."""
+
+    def __init__(self, action_space):
+        self._action_space = action_space
+
+    @property
+    def should_load_agent_state(self): return True
+    @property
+    def policy_action_space(self): return self._action_space
+    @property
+    def policy_action_space_shape_lens(self): return [self._action_space]
+    @property
+    def num_recurrent_layers(self) -> int: return 0
+    @property
+    def recurrent_hidden_size(self) -> int: return 0
+    @property
+    def visual_encoder(self): return None
+
+    def _get_policy_components(self) -> List[nn.Module]: return []
+    def aux_loss_parameters(self) -> Dict[str, Iterable[torch.Tensor]]: return {}
+
+    def policy_parameters(self) -> Iterable[torch.Tensor]:
+        for c in self._get_policy_components():
+            yield from c.parameters()
+
+    def all_policy_tensors(self) -> Iterable[torch.Tensor]:
+        yield from self.policy_parameters()
+        for c in self._get_policy_components():
+            yield from c.buffers()
+
+    def get_value(self, observations, rnn_hidden_states, prev_actions, masks) -> torch.Tensor:
+        raise NotImplementedError
+
+    def get_extra(self, action_data: PolicyActionData, infos, dones):
+        return [] if action_data.policy_info is None else action_data.policy_info
+
+    def evaluate_actions(self, observations, rnn_hidden_states, prev_actions, masks, action, rnn_build_seq_info):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def act(self, observations, rnn_hidden_states, prev_actions, masks, deterministic=False) -> PolicyActionData:
+        raise NotImplementedError
+
+    def on_envs_pause(self, envs_to_pause: List[int]) -> None:
+        pass
+
+    def update_hidden_state(self, rnn_hxs, prev_actions, action_data: PolicyActionData) -> None:
+        for env_i, should_insert in enumerate(action_data.should_inserts):
+            if should_insert.item():
+                rnn_hxs[env_i] = action_data.rnn_hidden_states[env_i]
+                prev_actions[env_i].copy_(action_data.actions[env_i])
+
+    @classmethod
+    @abc.abstractmethod
+    def from_config(cls, config, observation_space, action_space, **kwargs):
+        pass
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    """Registers `param` under `dotted` ('a.b.0.weight'), creating bare container modules on the way."""
+    *path, leaf = dotted.split(".")
+    m = root
+    for p in path:
+        if p not in m._modules:
+            m.add_module(p, nn.Module())
+        m = m._modules[p]
+    m.register_parameter(leaf, param)
+
+
+class _EvaluateFn(torch.autograd.Function):
+    """Autograd bridge for reference-style callers (loss built with torch ops, loss.backward()).
+    The fused updater (habitat_amd PPO) bypasses this and calls the engine directly."""
+
+    @staticmethod
+    def forward(ctx, policy, call, *params):
+        ctx.policy, ctx.call = policy, call
+        v, lp, ent = policy._evaluate_dense(call)
+        return v, lp, ent
+
+    @staticmethod
+    def backward(ctx, dv, dlp, dent):
+        pol, call = ctx.policy, ctx.call
+        pol._backward_dense(call, dv.contiguous().view(-1), dlp.contiguous().view(-1), dent.contiguous().view(-1))
+        grads = tuple(g.clone() for g in pol.engine.grad_views.values())
+        return (None, None) + grads
+
+
+class NetPolicy(nn.Module, Policy):
+    """Engine-backed counterpart of rl/ppo/policy.py:252-413 (categorical action distribution)."""
+
+    action_distribution_type = "categorical"
+
+    def __init__(self, action_space, engine_kwargs: dict, init_fn):
+        Policy.__init__(self, action_space)
+        nn.Module.__init__(self)
+        self.dim_actions = get_num_actions(action_space)
+        self._engine_kwargs = dict(engine_kwargs, num_actions=self.dim_actions)
+        self.engine: Optional[PolicyEngine] = None
+        self.device = torch.device("cpu")
+        self._hidden = engine_kwargs["hidden"]
+        self._rnn_type = engine_kwargs["rnn_type"].upper()
+        self._rnn_layers = engine_kwargs["rnn_layers"]
+        # CPU staging of the parameters in reference state_dict order, initialised like the reference.
+        for name, value in init_fn().items():
+            _attach(self, name, nn.Parameter(value))
+        self.aux_loss_modules = nn.ModuleDict()
+        self.train()
+
+    # ---- reference properties -----------------------------------------------------------------
+    @property
+    def hidden_state_shape(self): return (self.num_recurrent_layers, self.recurrent_hidden_size)
+    @property
+    def hidden_state_shape_lens(self): return [self.recurrent_hidden_size]
+    @property
+    def recurrent_hidden_size(self) -> int: return self._hidden
+    @property
+    def num_recurrent_layers(self) -> int: return self._rnn_layers * (2 if self._rnn_type == "LSTM" else 1)
+    @property
+    def visual_encoder(self): return self._modules["net"]._modules.get("visual_encoder")
+
+    def _get_policy_components(self) -> List[nn.Module]:
+        return [self._modules["net"], self._modules["critic"], self._modules["action_distribution"]]
+
+    def aux_loss_parameters(self): return {}
+
+    def forward(self, *x):
+        raise NotImplementedError
+
+    # ---- device placement: builds the engine and re-homes parameters into its flat arena ---------
+    def to(self, *args, **kwargs):
+        device = None
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, (str, torch.device)):
+                device = torch.device(a)
+        if device is None:
+            raise _lib.HabError("habitat_amd policies are fp32-only; .to() accepts a device")
+        return self._materialize(device)
+
+    def cuda(self, device=None):
+        return self._materialize(torch.device("cuda" if device is None else device))
+
+    def _materialize(self, device: torch.device):
+        if device.type != "cuda":
+            if self.engine is None:
+                return self  # still staged on the CPU; nothing can be *computed* there
+            raise _lib.HabError("habitat_amd policies cannot be moved off the GPU (no CPU execution path)")
+        if self.engine is not None and self.device == device:
+            return self
+        state = {k: v.detach() for k, v in self.named_parameters()}
+        with torch.cuda.device(device):
+            eng = PolicyEngine(device=device, **self._engine_kwargs)
+        names = [s[0] for s in eng.specs]
+        assert names == list(state.keys()), "engine parameter table does not match the module's parameters"
+        for nm, shp, _ in eng.specs:
+            assert tuple(state[nm].shape) == shp, (nm, state[nm].shape, shp)
+        with torch.cuda.device(device):
+            eng.load({k: v.to(device) for k, v in state.items()})
+        for nm in names:  # swap the staged CPU parameters for views into the flat arena
+            *path, leaf = nm.split(".")
+            m = self
+            for p in path:
+                m = m._modules[p]
+            par = nn.Parameter(eng.views[nm])
+            par.grad = eng.grad_views[nm]
+            m._parameters[leaf] = par
+        self.engine, self.device = eng, device
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        out = super().load_state_dict(state_dict, strict=strict)
+        if self.engine is not None:
+            self.engine.repack()
+        return out
+
+    def _require_engine(self) -> PolicyEngine:
+        if self.engine is None:
+            raise _lib.HabError("policy is not on a GPU yet: call .to('cuda') first (habitat_amd has no CPU execution path)")
+        return self.engine
+
+    # ---- helpers --------------------------------------------------------------------------------
+    def _obs_ptrs(self, observations):
+        rgb = observations["rgb"] if self._engine_kwargs["has_rgb"] else None
+        depth = observations["depth"] if self._engine_kwargs["has_depth"] else None
+        goal = observations[GOAL_UUID]
+        for t in (rgb, depth, goal):
+            if t is not None and not t.is_contiguous():
+                raise _lib.HabError("observation tensors must be contiguous NHWC")
+        return rgb, depth, goal
+
+    def draw_noise(self, n: int) -> torch.Tensor:
+        """Exp(1) noise from the CPU generator -- the draw torch.multinomial would make (utils/common.py:64-68)."""
+        q = torch.empty(n, self.dim_actions).exponential_(1)
+        return q.pin_memory().to(self.device, non_blocking=True) if self.device.type == "cuda" else q
+
+    # ---- reference API --------------------------------------------------------------------------
+    @torch.no_grad()
+    def act(self, observations, rnn_hidden_states, prev_actions, masks, deterministic=False, exp_noise=None, out=None):
+        eng = self._require_engine()
+        rgb, depth, goal = self._obs_ptrs(observations)
+        n = goal.shape[0]
+        dev = self.device
+        if out is None:
+            out = dict(values=torch.empty(n, 1, device=dev), actions=torch.empty(n, 1, dtype=torch.long, device=dev),
+                       action_log_probs=torch.empty(n, 1, device=dev),
+                       rnn_hidden_states=torch.empty(n, self.num_recurrent_layers, self._hidden, device=dev))
+        if not deterministic and exp_noise is None:
+            exp_noise = self.draw_noise(n)
+        eng.act(rgb, depth, goal, rnn_hidden_states.contiguous(), masks.contiguous(), n, exp_noise=exp_noise,
+                deterministic=deterministic, values=out["values"], actions=out["actions"],
+                action_log_probs=out["action_log_probs"], hidden_out=out["rnn_hidden_states"],
+                prev_actions=prev_actions)
+        return PolicyActionData(values=out["values"], actions=out["actions"], action_log_probs=out["action_log_probs"],
+                                rnn_hidden_states=out["rnn_hidden_states"])
+
+    @torch.no_grad()
+    def get_value(self, observations, rnn_hidden_states, prev_actions, masks):
+        eng = self._require_engine()
+        rgb, depth, goal = self._obs_ptrs(observations)
+        n = goal.shape[0]
+        values = torch.empty(n, 1, device=self.device)
+        eng.act(rgb, depth, goal, rnn_hidden_states.contiguous(), masks.contiguous(), n, values=values, prev_actions=prev_actions)
+        return values
+
+    def evaluate_actions(self, observations, rnn_hidden_states, prev_actions, masks, action, rnn_build_seq_info):
+        """Dense-tensor entry (reference calling convention).  Differentiable through _EvaluateFn."""
+        self._require_engine()
+        rgb, depth, goal = self._obs_ptrs(observations)
+        B, n = goal.shape[0], rnn_hidden_states.shape[0]
+        pack = _pack_from_seq_info(rnn_build_seq_info, B, n, self.device)
+        call = dict(rgb=rgb, depth=depth, goal=goal, hidden0=rnn_hidden_states.contiguous(), masks=masks.contiguous(),
+                    actions=action.contiguous(), prev_actions=prev_actions, pack=pack, B=B, n=n)
+        if torch.is_grad_enabled():
+            v, lp, ent = _EvaluateFn.apply(self, call, *self.parameters())
+        else:
+            v, lp, ent = self._evaluate_dense(call)
+        hidden = torch.empty(n, self.num_recurrent_layers, self._hidden, device=self.device)
+        self.engine.final_hidden(hidden)
+        return v, lp, ent, hidden, {}
+
+    def _evaluate_dense(self, c):
+        dev, B = self.device, c["B"]
+        v, lp, ent = (torch.empty(B, 1, device=dev) for _ in range(3))
+        self.engine.evaluate(c["rgb"], c["depth"], c["goal"], None, c["hidden0"], c["masks"], c["actions"], c["pack"], B, c["n"],
+                             value=v, log_prob=lp, entropy=ent, prev_actions=c["prev_actions"])
+        return v, lp, ent
+
+    def _backward_dense(self, c, dv, dlp, dent):
+        self.engine.backward(c["rgb"], c["depth"], c["goal"], None, c["actions"], c["pack"], dv, dlp, dent,
+                             prev_actions=c["prev_actions"])
+
+
+def _pack_from_seq_info(info, B, n, device) -> DevicePackInfo:
+    """Accepts either our DevicePackInfo or a reference-style rnn_build_seq_info dict
+    (rl/models/rnn_state_encoder.py:171-184) and returns the engine's view of it."""
+    if isinstance(info, DevicePackInfo):
+        return info
+    if hasattr(info, "pack"):
+        return info.pack
+    g = lambda k: (info["cpu_" + k] if ("cpu_" + k) in info else info[k].cpu()).numpy()
+    T = B // n
+    # rebuild through the dones implied by the fragment starts (tie order of the caller's arrays is irrelevant)
+    starts = g("sequence_starts")
+    dones = np.zeros((T, n), dtype=np.uint8)
+    for s in starts:
+        t, e = divmod(int(s), n)
+        if t > 0:
+            dones[t, e] = 1
+    return DevicePackInfo(dones, device)
+
+
+def _baseline_init(cin, H, W, hidden, num_actions, goal_dim):
+    """Parameter values exactly as PointNavBaselinePolicy.__init__ produces them (same initialisers, same order of
+    RNG consumption): SimpleCNN.layer_init simple_cnn.py:126-133, RNNStateEncoder.layer_init
+    rnn_state_encoder.py:288-293, CategoricalNet utils/common.py:90-91, CriticHead policy.py:420-421."""
+    def co(x, k, s): return (x - k) // s + 1
+    h, w = co(co(co(H, 8, 4), 4, 2), 3, 1), co(co(co(W, 8, 4), 4, 2), 3, 1)
+    out = {}
+    # PointNavBaselineNet.__init__ builds SimpleCNN first (policy.py:530), then the RNN (:532-535)
+    layers = [("0", nn.Conv2d(cin, 32, 8, 4)), ("2", nn.Conv2d(32, 64, 4, 2)), ("4", nn.Conv2d(64, 32, 3, 1)),
+              ("6", nn.Linear(32 * h * w, hidden))]
+    for _, layer in layers:
+        nn.init.kaiming_normal_(layer.weight, nn.init.calculate_gain("relu"))
+        nn.init.constant_(layer.bias, val=0)
+    for idx, layer in layers:
+        out[f"net.visual_encoder.cnn.{idx}.weight"] = layer.weight.detach()
+        out[f"net.visual_encoder.cnn.{idx}.bias"] = layer.bias.detach()
+    rnn = nn.GRU(input_size=hidden + goal_dim, hidden_size=hidden, num_layers=1)
+    for name, param in rnn.named_parameters():
+        if "weight" in name:
+            nn.init.orthogonal_(param)
+        elif "bias" in name:
+            nn.init.constant_(param, 0)
+    for name, param in rnn.named_parameters():
+        out[f"net.state_encoder.rnn.{name}"] = param.detach()
+    # NetPolicy.__init__: CategoricalNet (policy.py:273-276) then CriticHead (:291)
+    lin = nn.Linear(hidden, num_actions)
+    nn.init.orthogonal_(lin.weight, gain=0.01)
+    nn.init.constant_(lin.bias, 0)
+    out["action_distribution.linear.weight"], out["action_distribution.linear.bias"] = lin.weight.detach(), lin.bias.detach()
+    fc = nn.Linear(hidden, 1)
+    nn.init.orthogonal_(fc.weight)
+    nn.init.constant_(fc.bias, 0)
+    out["critic.fc.weight"], out["critic.fc.bias"] = fc.weight.detach(), fc.bias.detach()
+    return out
+
+
+@baseline_registry.register_policy
+class PointNavBaselinePolicy(NetPolicy):
+    """SimpleCNN + GRU policy (rl/ppo/policy.py:427-589) on the HIP engine."""
+
+    def __init__(self, observation_space, action_space, hidden_size: int = 512, aux_loss_config=None, max_frames: int = 4096,
+                 max_envs: int = 64, **kwargs):
+        sp = observation_space.spaces
+        has_rgb, has_depth = "rgb" in sp, "depth" in sp
+        if not (has_rgb or has_depth):
+            raise _lib.HabError("blind PointNavBaselinePolicy is outside the accelerated path")
+        if GOAL_UUID not in sp:
+            raise _lib.HabError(f"PointNavBaselinePolicy on habitat_amd needs the '{GOAL_UUID}' sensor")
+        if aux_loss_config:
+            raise _lib.HabError("auxiliary losses are outside the accelerated path")
+        vis = sp["rgb"] if has_rgb else sp["depth"]
+        H, W = int(vis.shape[0]), int(vis.shape[1])
+        cin = (3 if has_rgb else 0) + (1 if has_depth else 0)
+        goal_dim = int(sp[GOAL_UUID].shape[0])
+        na = get_num_actions(action_space)
+        super().__init__(action_space,
+                         dict(arch="simple_cnn", rnn_type="GRU", rnn_layers=1, hidden=hidden_size, H=H, W=W, has_rgb=has_rgb,
+                              has_depth=has_depth, goal_dim=goal_dim, max_frames=max_frames, max_envs=max_envs),
+                         lambda: _baseline_init(cin, H, W, hidden_size, na, goal_dim))
+
+    @classmethod
+    def from_config(cls, config, observation_space, action_space, **kwargs):
+        hb = config.habitat_baselines
+        ppo = hb.rl.ppo
+        n_envs = int(hb.num_environments)
+        return cls(observation_space=observation_space, action_space=action_space, hidden_size=ppo.hidden_size,
+                   aux_loss_config=hb.rl.auxiliary_losses,
+                   max_frames=int(ppo.num_steps) * max(1, -(-n_envs // int(ppo.num_mini_batch))), max_envs=n_envs)

@@ -1,0 +1,222 @@
+"""PPO updater with the surface of habitat_baselines/rl/ppo/ppo.py:33-384 (`PPO.from_config`,
+`update(rollouts) -> Dict[str, float]`, `.optimizer`, hooks, `get_resume_state/load_state_dict`) whose
+minibatch step is a fixed sequence of HIP launches on the policy engine:
+
+    evaluate (fwd, gather through rows) -> hab_ppo_loss (loss + dL/d{value,logp,entropy} + metrics)
+    -> engine backward (all parameter grads into the flat arena) -> [DD-PPO: all-reduce of the arena]
+    -> hab_clip_adam_step (global-norm clip + Adam on the flat arena)
+
+No host synchronisation happens inside `update`; the learner metrics stay on the device and are
+read back once at the end (the reference reads ~15 scalars per minibatch)."""
+from __future__ import annotations
+
+import collections
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch import nn as nn
+
+from habitat_amd import _lib
+from habitat_amd._lib import check, ptr, stream_ptr
+from habitat_amd.common.baseline_registry import baseline_registry
+from habitat_amd.common.rollout_storage import MiniBatch, RolloutStorage
+
+EPS_PPO = 1e-5
+METRIC_KEYS = ["value_loss", "action_loss", "dist_entropy", "_total", "value_pred_min", "value_pred_mean", "value_pred_max",
+               "prob_ratio_min", "prob_ratio_mean", "prob_ratio_max", "ppo_fraction_clipped", "_B"]
+
+
+class Updater:
+    """Interface of rl/ppo/updater.py:11-39."""
+
+    def update(self, rollouts) -> Dict[str, float]: raise NotImplementedError
+    @classmethod
+    def from_config(cls, actor_critic, config): raise NotImplementedError
+    @property
+    def lr_scheduler(self): return None
+    def after_update(self) -> None: pass
+    def get_resume_state(self) -> Dict[str, Any]: raise NotImplementedError
+    def load_state_dict(self, state) -> None: raise NotImplementedError
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam-compatible shell (param_groups / lr for LambdaLR, state_dict for resume) around the fused
+    clip+Adam kernel that updates the policy's flat parameter arena in one pass (ppo.py:112-137,347-371)."""
+
+    def __init__(self, policy, lr, eps, betas=(0.9, 0.999)):
+        self.policy = policy
+        super().__init__([p for p in policy.parameters() if p.requires_grad], dict(lr=lr, eps=eps, betas=betas))
+        eng = policy.engine
+        self.exp_avg = torch.zeros_like(eng.params_flat)
+        self.exp_avg_sq = torch.zeros_like(eng.params_flat)
+        self.step_count = 0
+        self._scratch = torch.zeros(1024, dtype=torch.float64, device=eng.params_flat.device)
+
+    @torch.no_grad()
+    def step(self, closure=None, max_grad_norm: float = 0.0, grad_scale: float = 1.0, grad_norm_out=None):
+        eng = self.policy.engine
+        g = self.param_groups[0]
+        self.step_count += 1
+        check(_lib.lib().hab_clip_adam_step(ptr(eng.params_flat), ptr(eng.grads_flat), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                            eng.params_flat.numel(), ptr(self._scratch), 1024, float(grad_scale),
+                                            float(max_grad_norm or 0.0), float(g["lr"]), float(g["betas"][0]),
+                                            float(g["betas"][1]), float(g["eps"]), self.step_count, ptr(grad_norm_out),
+                                            stream_ptr()), "hab_clip_adam_step")
+        eng.repack()
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.policy.engine.grads_flat.zero_()
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg.cpu(), exp_avg_sq=self.exp_avg_sq.cpu(),
+                    param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({k: v for k, v in s.items() if k != "params"})
+
+
+@baseline_registry.register_updater
+class PPO(nn.Module, Updater):
+    @classmethod
+    def from_config(cls, actor_critic, config):
+        return cls(actor_critic=actor_critic, clip_param=config.clip_param, ppo_epoch=config.ppo_epoch,
+                   num_mini_batch=config.num_mini_batch, value_loss_coef=config.value_loss_coef,
+                   entropy_coef=config.entropy_coef, lr=config.lr, eps=config.eps, max_grad_norm=config.max_grad_norm,
+                   use_clipped_value_loss=config.use_clipped_value_loss,
+                   use_normalized_advantage=config.use_normalized_advantage,
+                   entropy_target_factor=getattr(config, "entropy_target_factor", 0.0),
+                   use_adaptive_entropy_pen=getattr(config, "use_adaptive_entropy_pen", False))
+
+    def __init__(self, actor_critic, clip_param: float, ppo_epoch: int, num_mini_batch: int, value_loss_coef: float,
+                 entropy_coef: float, lr: Optional[float] = None, eps: Optional[float] = None,
+                 max_grad_norm: Optional[float] = None, use_clipped_value_loss: bool = False,
+                 use_normalized_advantage: bool = True, entropy_target_factor: float = 0.0,
+                 use_adaptive_entropy_pen: bool = False) -> None:
+        super().__init__()
+        if use_adaptive_entropy_pen:
+            raise _lib.HabError("adaptive entropy penalty (Gaussian policies) is outside the accelerated path")
+        self.actor_critic = actor_critic
+        self.clip_param = clip_param
+        self.ppo_epoch = ppo_epoch
+        self.num_mini_batch = num_mini_batch
+        self.value_loss_coef = value_loss_coef
+        self.entropy_coef = entropy_coef
+        self.max_grad_norm = max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self.use_normalized_advantage = use_normalized_advantage
+        self.device = next(actor_critic.parameters()).device
+        if actor_critic.engine is None:
+            raise _lib.HabError("move the policy to a GPU before building the updater (policy.to('cuda'))")
+        self.optimizer = FlatAdam(actor_critic, lr, eps)
+        self.non_ac_params: List[torch.Tensor] = []
+        dev = self.device
+        self._stats = torch.zeros(4, device=dev)
+        self._adv: Optional[torch.Tensor] = None
+        self.last_minibatch_metrics: List[torch.Tensor] = []
+
+    # ---- distributed hooks (overridden by DDPPO) ------------------------------------------------
+    def _world_size(self) -> int:
+        return 1
+
+    def _all_reduce_grads(self) -> None:
+        pass
+
+    def _all_reduce_scalar_stats(self, t: torch.Tensor) -> None:
+        pass
+
+    # ---- advantages (ppo.py:139-153, ddppo.py:59-84) -----------------------------------------------
+    def get_advantages(self, rollouts: RolloutStorage) -> torch.Tensor:
+        L = _lib.lib()
+        B = rollouts.buffers
+        ret, vp = B["returns"], B["value_preds"]
+        if self._adv is None or self._adv.shape != ret.shape:
+            self._adv = torch.empty_like(ret)
+        adv, cnt, s = self._adv, ret.numel(), stream_ptr()
+        if not self.use_normalized_advantage:
+            check(L.hab_advantages(ptr(ret), ptr(vp), ptr(adv), cnt, 0, None, None, s), "hab_advantages")
+        elif self._world_size() == 1:
+            check(L.hab_advantages(ptr(ret), ptr(vp), ptr(adv), cnt, 1, None, ptr(self._stats), s), "hab_advantages")
+        else:
+            w = float(self._world_size())
+            check(L.hab_advantages(ptr(ret), ptr(vp), ptr(adv), cnt, 2, None, ptr(self._stats), s), "hab_advantages")
+            self._all_reduce_scalar_stats(self._stats[0:1])
+            self._stats[0:1].div_(w)
+            check(L.hab_advantages(ptr(ret), ptr(vp), ptr(adv), cnt, 4, ptr(self._stats), ptr(self._stats), s), "hab_advantages")
+            self._all_reduce_scalar_stats(self._stats[1:2])
+            self._stats[1:2].div_(w)
+            check(L.hab_advantages(ptr(ret), ptr(vp), ptr(adv), cnt, 3, ptr(self._stats), None, s), "hab_advantages")
+        return adv
+
+    # ---- one minibatch (ppo.py:164-299) -------------------------------------------------------------
+    def _update_from_batch(self, batch: MiniBatch, epoch: int, rollouts: RolloutStorage, slot: torch.Tensor):
+        eng = self.actor_critic.engine
+        L = _lib.lib()
+        st: RolloutStorage = batch.storage
+        Bf = st.buffers
+        obs = Bf["observations"]
+        rgb, depth = obs.get("rgb"), obs.get("depth")
+        goal = obs["pointgoal_with_gps_compass"]
+        Bn, n = batch.T * batch.n, batch.n
+        w = self._work(Bn)
+        eng.evaluate(rgb, depth, goal, batch.rows, Bf["recurrent_hidden_states"], Bf["masks"], Bf["actions"], batch.pack, Bn, n,
+                     value=w["v"], log_prob=w["lp"], entropy=w["ent"], prev_actions=Bf["prev_actions"])
+        check(L.hab_ppo_loss(ptr(w["v"]), ptr(w["lp"]), ptr(w["ent"]), ptr(Bf["action_log_probs"]), ptr(batch.advantages_full),
+                             ptr(Bf["value_preds"]), ptr(Bf["returns"]), ptr(batch.rows), Bn, float(self.clip_param),
+                             float(self.value_loss_coef), float(self.entropy_coef), int(self.use_clipped_value_loss),
+                             ptr(w["dv"]), ptr(w["dlp"]), ptr(w["dent"]), ptr(slot), stream_ptr()), "hab_ppo_loss")
+        eng.backward(rgb, depth, goal, batch.rows, Bf["actions"], batch.pack, w["dv"], w["dlp"], w["dent"],
+                     prev_actions=Bf["prev_actions"])
+        self.before_step()
+        self.optimizer.step(max_grad_norm=self.max_grad_norm, grad_scale=1.0 / self._world_size(), grad_norm_out=slot[12:13])
+        self.after_step()
+
+    def _work(self, B):
+        if getattr(self, "_wk", None) is None or self._wk["v"].numel() < B:
+            dev = self.device
+            self._wk = {k: torch.empty(B, device=dev) for k in ("v", "lp", "ent", "dv", "dlp", "dent")}
+        return self._wk
+
+    def update(self, rollouts: RolloutStorage) -> Dict[str, float]:
+        advantages = self.get_advantages(rollouts)
+        nmb = self.ppo_epoch * self.num_mini_batch
+        slots = torch.zeros(nmb + 1, 16, device=self.device)
+        k = 0
+        last_epoch_slots = []
+        for epoch in range(self.ppo_epoch):
+            for batch in rollouts.data_generator(advantages, self.num_mini_batch):
+                if k >= slots.shape[0]:
+                    slots = torch.cat([slots, torch.zeros_like(slots)], 0)
+                self._update_from_batch(batch, epoch, rollouts, slots[k])
+                if epoch == self.ppo_epoch - 1:
+                    last_epoch_slots.append(k)
+                k += 1
+        host = slots[:k].cpu()  # the single device->host read of the update
+        self.last_minibatch_metrics = host
+        out: Dict[str, float] = {}
+        for i, name in enumerate(METRIC_KEYS):
+            if name.startswith("_"):
+                continue
+            rows = last_epoch_slots if name == "ppo_fraction_clipped" else list(range(k))
+            out[name] = float(host[rows, i].mean())
+        out["grad_norm"] = float(host[:, 12].mean())
+        return out
+
+    # ---- hooks kept for subclass compatibility (ppo.py:341-375) ---------------------------------------
+    def before_backward(self, loss): return loss
+    def after_backward(self, loss): pass
+
+    def before_step(self):
+        self._all_reduce_grads()
+
+    def after_step(self): pass
+
+    def get_resume_state(self):
+        return {"optim_state": self.optimizer.state_dict()}
+
+    def load_state_dict(self, state):
+        if "optim_state" in state:
+            self.optimizer.load_state_dict(state["optim_state"])

@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory by running the REAL reference code
+(/root/reference, loaded in place through oracle/ref_loader.py) on deterministic inputs.
+
+  python tests/golden/make_golden.py          # needs /root/reference; writes tests/golden/*.npz
+
+Inputs are NOT stored: parameters come from `det_params(seed)` and observations from the
+counter-based synthetic generator (oracle/synth.py), both reproducible anywhere.  Only the
+reference's outputs are stored.  The tests (which must run where /root/reference does not exist)
+re-create the inputs and compare against these files.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import synth  # noqa: E402
+from oracle.fixtures import det_params, synth_rollout_inputs  # noqa: E402
+from oracle.ref_loader import load_reference, make_config  # noqa: E402
+
+GOAL = "pointgoal_with_gps_compass"
+
+
+def obs_space(ns, H, W, rgb=True, depth=True):
+    sp = ns.spaces
+    d = {}
+    if rgb:
+        d["rgb"] = sp.Box(0, 255, (H, W, 3), np.uint8)
+    if depth:
+        d["depth"] = sp.Box(0.0, 1.0, (H, W, 1), np.float32)
+    d[GOAL] = sp.Box(-1e9, 1e9, (2,), np.float32)
+    return sp.Dict(d)
+
+
+def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=True):
+    """Reference rollout (policy.act through RolloutStorage) + compute_returns + PPO.update."""
+    sd = policy.state_dict()
+    newp = det_params([(k, v.shape) for k, v in sd.items() if v.dtype == torch.float32 and "running_mean_and_var" not in k], seed)
+    sd.update(newp)
+    policy.load_state_dict(sd)
+    RolloutStorage = ns.rollout_storage.RolloutStorage
+    rollouts = RolloutStorage(T, N, space, ns.spaces.Discrete(4), policy)
+    envs = synth.SyntheticEnvs(N, H, W, seed=seed, use_rgb=rgb, use_depth=depth)
+    obs, rew, done = synth_rollout_inputs(envs, T)
+    to_t = lambda o: {k: torch.from_numpy(v) for k, v in o.items()}
+    rollouts.insert_first_observations(to_t(obs[0]))
+    out = {}
+    policy.eval()
+    torch.manual_seed(seed)
+    noises = []
+    for t in range(T):
+        step = rollouts.get_current_step(slice(0, N), 0)
+        with torch.no_grad():
+            rng_state = torch.get_rng_state()
+            noises.append(torch.empty(N, 4).exponential_(1))  # what multinomial is about to draw
+            torch.set_rng_state(rng_state)
+            ad = policy.act(step["observations"], step["recurrent_hidden_states"], step["prev_actions"], step["masks"])
+        rollouts.insert(next_recurrent_hidden_states=ad.rnn_hidden_states, actions=ad.actions,
+                        action_log_probs=ad.action_log_probs, value_preds=ad.values)
+        rollouts.insert(next_observations=to_t(obs[t + 1]), rewards=torch.from_numpy(rew[t]).unsqueeze(1),
+                        next_masks=torch.from_numpy(~done[t]).unsqueeze(1))
+        rollouts.advance_rollout()
+    out["exp_noise"] = torch.stack(noises).numpy()
+    with torch.no_grad():
+        last = rollouts.get_last_step()
+        next_value = policy.get_value(last["observations"], last["recurrent_hidden_states"], last["prev_actions"], last["masks"])
+    rollouts.compute_returns(next_value, cfg.use_gae, cfg.gamma, cfg.tau)
+    b = rollouts.buffers
+    for k in ("actions", "prev_actions", "action_log_probs", "value_preds", "returns", "rewards", "masks", "recurrent_hidden_states"):
+        out["roll_" + k] = b[k].numpy().copy()
+    out["next_value"] = next_value.numpy()
+
+    policy.train()
+    ppo = ns.ppo.PPO.from_config(policy, cfg)
+    out["advantages"] = ppo.get_advantages(rollouts).numpy().copy()
+    # first minibatch of a fixed permutation: evaluate_actions + grads (no optimiser step)
+    torch.manual_seed(seed + 1)
+    gen = rollouts.data_generator(ppo.get_advantages(rollouts), cfg.num_mini_batch)
+    batch = next(gen)
+    v, lp, ent, hfin, _ = policy.evaluate_actions(batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"],
+                                                  batch["masks"], batch["actions"], batch["rnn_build_seq_info"])
+    out["mb0_value"], out["mb0_logp"], out["mb0_entropy"], out["mb0_hidden"] = (
+        v.detach().numpy(), lp.detach().numpy(), ent.detach().numpy(), hfin.detach().numpy())
+    ratio = torch.exp(lp - batch["action_log_probs"])
+    s1 = batch["advantages"] * ratio
+    s2 = batch["advantages"] * torch.clamp(ratio, 1 - cfg.clip_param, 1 + cfg.clip_param)
+    al = -torch.min(s1, s2).mean()
+    delta = v.detach() - batch["value_preds"]
+    vc = batch["value_preds"] + delta.clamp(-cfg.clip_param, cfg.clip_param)
+    vv = torch.where(delta.abs() < cfg.clip_param, v, vc)
+    vl = (0.5 * (vv - batch["returns"]) ** 2).mean()
+    total = cfg.value_loss_coef * vl + al - cfg.entropy_coef * ent.mean()
+    policy.zero_grad()
+    total.backward()
+    out["mb0_losses"] = np.array([vl.item(), al.item(), ent.mean().item(), total.item()], dtype=np.float32)
+    for k, p_ in policy.named_parameters():
+        if p_.grad is not None:
+            out["grad/" + k] = p_.grad.numpy().copy()
+    policy.zero_grad()
+    # the full update (fresh generator state so the permutations are reproducible: seed + 2)
+    torch.manual_seed(seed + 2)
+    perm_state = torch.get_rng_state()
+    perms = [torch.randperm(N) for _ in range(cfg.ppo_epoch)]
+    torch.set_rng_state(perm_state)
+    out["perms"] = torch.stack(perms).numpy()
+    metrics = ppo.update(rollouts)
+    for k, val in metrics.items():
+        out["metric/" + k] = np.float32(val)
+    for k, p_ in policy.state_dict().items():
+        out["post/" + k] = p_.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "->", len(out), "arrays;", {k: float(v) for k, v in metrics.items()})
+
+
+def pack_cases(ns):
+    rng = np.random.default_rng(7)
+    out = {}
+    cases = [(1, 1), (4, 3), (8, 5), (16, 4), (32, 8), (13, 3), (64, 6), (128, 4)]
+    for i, (T, N) in enumerate(cases):
+        dones = rng.random((T, N)) < (1.0 / 6.0)
+        out[f"c{i}_dones"] = dones
+        info = ns.rnn_state_encoder.build_pack_info_from_dones(dones)
+        for k, v in info.items():
+            out[f"c{i}_{k}"] = np.asarray(v)
+    out["num_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(HERE, "pack_info.npz"), **out)
+    print("pack_info ->", len(cases), "cases")
+
+
+def rnn_case(ns):
+    """test/test_rnn_state_encoder.py semantics: packed seq_forward on random masks, GRU and LSTM."""
+    out = {}
+    for kind, layers in (("GRU", 2), ("LSTM", 2)):
+        torch.manual_seed(11)
+        enc = ns.rnn_state_encoder.build_rnn_state_encoder(16, 32, rnn_type=kind, num_layers=layers)
+        sd = enc.state_dict()
+        sd.update(det_params([(k, v.shape) for k, v in sd.items()], 5))
+        enc.load_state_dict(sd)
+        T, N = 12, 5
+        rng = np.random.default_rng(3)
+        x = torch.from_numpy(rng.standard_normal((T * N, 16)).astype(np.float32))
+        masks = torch.from_numpy(rng.random((T, N)) > (1.0 / 5.0)).view(T * N, 1)
+        h0 = torch.from_numpy(rng.standard_normal((N, enc.num_recurrent_layers, 32)).astype(np.float32))
+        info = ns.rnn_state_encoder.build_pack_info_from_dones(np.logical_not(masks.view(T, N).numpy()))
+        seq = ns.rnn_state_encoder.build_rnn_build_seq_info(torch.device("cpu"), info)
+        with torch.no_grad():
+            o, h = enc(x, h0, masks, seq)
+        out[kind + "_out"], out[kind + "_hidden"] = o.numpy(), h.numpy()
+    np.savez_compressed(os.path.join(HERE, "rnn_encoder.npz"), **out)
+    print("rnn_encoder -> GRU, LSTM")
+
+
+def main():
+    ns = load_reference()
+    torch.set_num_threads(4)
+    pack_cases(ns)
+    rnn_case(ns)
+    # A: PointNavBaselinePolicy (SimpleCNN + GRU), 44x44 RGB-D, hidden 64, T=6, N=4, iccv19 hyper-parameters
+    H = W = 44
+    space = obs_space(ns, H, W)
+    torch.manual_seed(0)
+    pol = ns.policy.PointNavBaselinePolicy(space, ns.spaces.Discrete(4), hidden_size=64)
+    cfg = make_config(clip_param=0.1, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.5, num_steps=6,
+                      use_normalized_advantage=True, hidden_size=64, lr=2.5e-4, eps=1e-5)
+    run_case(ns, "baseline_rgbd44", pol, space, cfg, T=6, N=4, seed=100, H=H, W=W)
+    # A2: depth-only 84x84 (BASELINE.json configs[0] shape), hidden 32, no advantage normalisation, unclipped value loss
+    space2 = obs_space(ns, 84, 84, rgb=False)
+    torch.manual_seed(0)
+    pol2 = ns.policy.PointNavBaselinePolicy(space2, ns.spaces.Discrete(4), hidden_size=64)
+    cfg2 = make_config(clip_param=0.2, ppo_epoch=1, num_mini_batch=1, max_grad_norm=0.2, num_steps=5,
+                       use_normalized_advantage=False, hidden_size=64, use_clipped_value_loss=False)
+    run_case(ns, "baseline_depth84", pol2, space2, cfg2, T=5, N=3, seed=7, H=84, W=84, rgb=False)
+
+
+if __name__ == "__main__":
+    main()

