@@ -1,0 +1,145 @@
+"""Environment source boundary.
+
+`VectorEnvFactory.construct_envs(...) -> VectorEnv` is the reference's hook
+(habitat_baselines/common/env_factory.py:14-38, selected through
+``habitat_baselines.vector_env_factory._target_``).  The benchmark of this path uses synthetic
+observations (BASELINE.json), so this module provides `SyntheticVectorEnvFactory` / `SyntheticVectorEnv`:
+a VectorEnv-API object (habitat/core/vector_env.py:229-232,380-410,451-484: num_envs,
+observation_spaces, action_spaces, orig_action_spaces, reset, async_step_at, wait_step_at, post_step,
+close) whose observations are produced ON THE DEVICE by `hab_synth_step` -- bit-identical to
+oracle/synth.py -- and which additionally offers `step_into(...)`, writing the next observations,
+rewards and masks straight into rollout-arena rows with no host round trip.  Any other object with the
+VectorEnv API (e.g. habitat's own process-per-env VectorEnv) can be returned by a user factory; the
+trainer then uses the generic host path."""
+from __future__ import annotations
+
+import abc
+import importlib
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from habitat_amd import _lib
+from habitat_amd._lib import check, ptr, stream_ptr
+from habitat_amd.common import spaces
+
+GOAL_UUID = "pointgoal_with_gps_compass"
+
+
+class VectorEnvFactory(abc.ABC):
+    @abc.abstractmethod
+    def construct_envs(self, config, workers_ignore_signals: bool = False, enforce_scenes_greater_eq_environments: bool = False,
+                       is_first_rank: bool = True):
+        ...
+
+
+def instantiate(target_cfg):
+    """hydra.utils.instantiate for a `{_target_: 'pkg.mod.Class', **kwargs}` node."""
+    target = target_cfg["_target_"]
+    mod, _, name = target.rpartition(".")
+    cls = getattr(importlib.import_module(mod), name)
+    return cls(**{k: v for k, v in target_cfg.items() if k != "_target_"})
+
+
+class SyntheticVectorEnv:
+    def __init__(self, num_envs: int, height: int, width: int, seed: int = 100, env_offset: int = 0, use_rgb: bool = True,
+                 use_depth: bool = True, num_actions: int = 4, device="cuda"):
+        self.num_envs, self.H, self.W = num_envs, height, width
+        self.seed, self.env_offset = int(seed) & 0xFFFFFFFF, int(env_offset)
+        self.use_rgb, self.use_depth = use_rgb, use_depth
+        self.device = torch.device(device)
+        d = {}
+        if use_rgb:
+            d["rgb"] = spaces.Box(0, 255, (height, width, 3), np.uint8)
+        if use_depth:
+            d["depth"] = spaces.Box(0.0, 1.0, (height, width, 1), np.float32)
+        d[GOAL_UUID] = spaces.Box(np.finfo(np.float32).min, np.finfo(np.float32).max, (2,), np.float32)
+        self.observation_spaces = [spaces.Dict(d) for _ in range(num_envs)]
+        self.action_spaces = [spaces.Discrete(num_actions) for _ in range(num_envs)]
+        self.orig_action_spaces = self.action_spaces
+        self.number_of_episodes = [None] * num_envs
+        if self.device.type != "cuda":
+            raise _lib.HabError("SyntheticVectorEnv generates observations on the GPU; no GPU device given")
+        dev = self.device
+        self._t = torch.zeros(num_envs, dtype=torch.int64, device=dev)
+        self._since = torch.zeros(num_envs, dtype=torch.int64, device=dev)
+        self._rgb = torch.zeros(num_envs, height, width, 3, dtype=torch.uint8, device=dev) if use_rgb else None
+        self._depth = torch.zeros(num_envs, height, width, 1, device=dev) if use_depth else None
+        self._goal = torch.zeros(num_envs, 2, device=dev)
+        self._rew = torch.zeros(num_envs, device=dev)
+        self._nd = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self._pending = False
+
+    # ---- device fast path ---------------------------------------------------------------------
+    def _emit(self, rgb, depth, goal, reward, not_done, advance: int):
+        check(_lib.lib().hab_synth_step(ptr(rgb), ptr(depth), ptr(goal), ptr(reward), ptr(not_done), ptr(self._t), ptr(self._since),
+                                        self.seed, self.env_offset, self.num_envs, self.H, self.W, advance, stream_ptr()),
+              "hab_synth_step")
+
+    def reset_into(self, rgb, depth, goal):
+        """Resets all envs and writes their first observations into the given (N, ...) device tensors."""
+        self._t.zero_()
+        self._since.zero_()
+        self._emit(rgb, depth, goal, None, None, 0)
+
+    def step_into(self, rgb, depth, goal, reward, not_done):
+        """Advances all envs one step (actions do not influence synthetic observations) and writes the new
+        observations / rewards (N,) / not-done masks (N,) bytes straight into the given device tensors."""
+        self._emit(rgb, depth, goal, reward, not_done, 1)
+
+    # ---- VectorEnv API (host path) ----------------------------------------------------------------
+    def _host_obs(self) -> List[Dict[str, np.ndarray]]:
+        rgb = self._rgb.cpu().numpy() if self.use_rgb else None
+        depth = self._depth.cpu().numpy() if self.use_depth else None
+        goal = self._goal.cpu().numpy()
+        out = []
+        for i in range(self.num_envs):
+            o = {}
+            if self.use_rgb:
+                o["rgb"] = rgb[i]
+            if self.use_depth:
+                o["depth"] = depth[i]
+            o[GOAL_UUID] = goal[i]
+            out.append(o)
+        return out
+
+    def reset(self):
+        self.reset_into(self._rgb, self._depth, self._goal)
+        return self._host_obs()
+
+    def async_step_at(self, index_env: int, action) -> None:
+        self._pending = True
+
+    def wait_step_at(self, index_env: int):
+        if self._pending:  # all envs advance together on the first wait of a step
+            self.step_into(self._rgb, self._depth, self._goal, self._rew, self._nd)
+            self._host_cache = (self._host_obs(), self._rew.cpu().numpy(), self._nd.cpu().numpy())
+            self._pending = False
+        obs, rew, nd = self._host_cache
+        return obs[index_env], float(rew[index_env]), not bool(nd[index_env]), {}
+
+    def post_step(self, observations):
+        return observations
+
+    def close(self):
+        pass
+
+
+class SyntheticVectorEnvFactory(VectorEnvFactory):
+    """Default `_target_`: N synthetic PointNav envs sized from habitat.simulator.sensors.*; per-rank env ids are
+    offset by rank * num_environments exactly like the reference offsets the seed (ppo_trainer.py:208-211)."""
+
+    def __init__(self, use_rgb: bool = True, use_depth: bool = True):
+        self.use_rgb, self.use_depth = use_rgb, use_depth
+
+    def construct_envs(self, config, workers_ignore_signals: bool = False, enforce_scenes_greater_eq_environments: bool = False,
+                       is_first_rank: bool = True, device="cuda", env_offset: int = 0):
+        hb, hab = config.habitat_baselines, config.habitat
+        sens = hab.simulator.sensors
+        use_rgb = self.use_rgb and "rgb" in sens
+        use_depth = self.use_depth and "depth" in sens
+        ref = sens["rgb"] if use_rgb else sens["depth"]
+        return SyntheticVectorEnv(int(hb.num_environments), int(ref.height), int(ref.width), seed=int(hab.seed),
+                                  env_offset=env_offset, use_rgb=use_rgb, use_depth=use_depth,
+                                  num_actions=len(hab.task.actions), device=device)

@@ -1,0 +1,165 @@
+"""Configuration tree for the PPO / DD-PPO path.
+
+The reference composes its config with hydra + omegaconf structured configs
+(habitat_baselines/config/default_structured_configs.py:288-316,343-363,412-419,444-507 and
+habitat_baselines/config/default.py:27-43).  Neither library is required here: this module carries the
+same key names and default values for the sub-tree the hot path reads, composes a YAML entrypoint on
+top of them (the ``habitat_baselines:`` / ``habitat:`` sections of the reference's experiment YAMLs are
+read as-is; its hydra ``defaults:`` list selects presets by name) and applies ``a.b.c=value`` overrides.
+
+    cfg = get_config("pointnav/ddppo_pointnav.yaml", ["habitat_baselines.num_environments=64"])
+"""
+from __future__ import annotations
+
+import contextlib
+import copy
+import os
+from typing import Any, List, Optional
+
+import yaml
+
+CONFIG_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+class Config(dict):
+    """dict with attribute access (enough of the DictConfig surface the trainer uses)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return Config({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+    @classmethod
+    def wrap(cls, d):
+        if isinstance(d, dict):
+            return cls({k: cls.wrap(v) for k, v in d.items()})
+        if isinstance(d, list):
+            return [cls.wrap(v) for v in d]
+        return d
+
+    def to_dict(self):
+        return {k: (v.to_dict() if isinstance(v, Config) else v) for k, v in self.items()}
+
+
+@contextlib.contextmanager
+def read_write(cfg):
+    """habitat.config.read_write (HL/config/read_write.py) -- configs here are always writable."""
+    yield cfg
+
+
+def _defaults() -> dict:
+    # Key names and values follow default_structured_configs.py (line refs in the module docstring).
+    ppo = dict(clip_param=0.2, ppo_epoch=4, num_mini_batch=2, value_loss_coef=0.5, entropy_coef=0.01, lr=2.5e-4, eps=1e-5,
+               max_grad_norm=0.5, num_steps=5, use_gae=True, use_linear_lr_decay=False, use_linear_clip_decay=False, gamma=0.99,
+               tau=0.95, reward_window_size=50, use_normalized_advantage=False, hidden_size=512, entropy_target_factor=0.0,
+               use_adaptive_entropy_pen=False, use_clipped_value_loss=True, use_double_buffered_sampler=False)
+    ddppo = dict(sync_frac=0.6, distrib_backend="GLOO", rnn_type="GRU", num_recurrent_layers=1, backbone="resnet18",
+                 pretrained_weights="data/ddppo-models/gibson-2plus-resnet50.pth", pretrained=False, pretrained_encoder=False,
+                 train_encoder=True, reset_critic=True, force_distributed=False)
+    policy = dict(name="PointNavResNetPolicy", action_distribution_type="categorical", obs_transforms={})
+    hb = dict(
+        evaluate=False, trainer_name="ppo", updater_name="PPO", distrib_updater_name="DDPPO", rollout_storage_name="RolloutStorage",
+        torch_gpu_id=0, tensorboard_dir="tb", writer_type="tb", video_dir="video_dir", video_fps=10, test_episode_count=-1,
+        eval_ckpt_path_dir="data/checkpoints", num_environments=16, num_processes=-1, checkpoint_folder="data/checkpoints",
+        num_updates=10000, num_checkpoints=10, checkpoint_interval=-1, total_num_steps=-1.0, log_interval=10, log_file="train.log",
+        force_blind_policy=False, verbose=True, force_torch_single_threaded=False, load_resume_state_config=True,
+        on_save_ckpt_callback=None, should_log_single_proc_infos=False,
+        eval=dict(split="val", use_ckpt_config=True, should_load_ckpt=True, evals_per_ep=1, video_option=[], extra_sim_sensors={}),
+        profiling=dict(capture_start_step=-1, num_steps_to_capture=-1),
+        vector_env_factory=dict(_target_="habitat_amd.common.env_factory.SyntheticVectorEnvFactory"),
+        rl=dict(agent=dict(type="SingleAgentAccessMgr"), preemption=dict(append_slurm_job_id=False, save_resume_state_interval=100,
+                                                                       save_state_batch_only=False),
+                policy=dict(main_agent=policy), ppo=ppo, ddppo=ddppo, auxiliary_losses={}),
+    )
+    habitat = dict(
+        seed=100,  # HL/config/default_structured_configs.py:1918
+        environment=dict(max_episode_steps=500),
+        simulator=dict(agents_order=["main_agent"],
+                       sensors=dict(rgb=dict(height=256, width=256), depth=dict(height=256, width=256, normalize_depth=True))),
+        task=dict(type="Nav-v0", goal_sensor_uuid="pointgoal_with_gps_compass", measurements={},
+                  actions=["stop", "move_forward", "turn_left", "turn_right"]),
+        synthetic=dict(done_probability=1.0 / 25.0),
+    )
+    return dict(habitat_baselines=hb, habitat=habitat)
+
+
+# presets the reference pulls in through `defaults: - /benchmark/nav/pointnav: <name>` (HL benchmark YAMLs)
+BENCHMARK_PRESETS = {
+    "pointnav_gibson": dict(habitat=dict(environment=dict(max_episode_steps=500),
+                                         simulator=dict(sensors=dict(rgb=dict(height=256, width=256), depth=dict(height=256, width=256))))),
+    "pointnav_habitat_test": dict(habitat=dict(environment=dict(max_episode_steps=500),
+                                               simulator=dict(sensors=dict(rgb=dict(height=256, width=256),
+                                                                           depth=dict(height=256, width=256))))),
+    "pointnav_mp3d": dict(habitat=dict(environment=dict(max_episode_steps=500))),
+}
+
+
+def _merge(dst: dict, src: dict):
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _merge(dst[k], v)
+        else:
+            dst[k] = copy.deepcopy(v)
+
+
+def _parse_value(s: str) -> Any:
+    try:
+        return yaml.safe_load(s)
+    except yaml.YAMLError:
+        return s
+
+
+def _apply_override(cfg: dict, ov: str):
+    key, _, val = ov.partition("=")
+    key = key.lstrip("+")
+    node = cfg
+    parts = key.split(".")
+    for p in parts[:-1]:
+        node = node.setdefault(p, {})
+    v = _parse_value(val)
+    if isinstance(v, str):
+        try:
+            v = float(v) if any(c in v for c in ".eE") else int(v)
+        except ValueError:
+            pass
+    node[parts[-1]] = v
+
+
+def _find_yaml(path: str, search: Optional[List[str]]):
+    cands = [path] + [os.path.join(d, path) for d in (search or []) + [CONFIG_DIR]]
+    for c in cands:
+        if os.path.isfile(c):
+            return c
+    raise FileNotFoundError(f"config '{path}' not found in {cands}")
+
+
+def get_config(config_path: Optional[str] = None, overrides: Optional[List[str]] = None, search_paths: Optional[List[str]] = None) -> Config:
+    """habitat_baselines.config.default.get_config(config_path, overrides) for the PPO path."""
+    cfg = _defaults()
+    if config_path:
+        with open(_find_yaml(config_path, search_paths)) as f:
+            y = yaml.safe_load(f) or {}
+        for item in y.pop("defaults", []) or []:
+            if isinstance(item, dict):
+                for grp, name in item.items():
+                    if "benchmark" in grp and name in BENCHMARK_PRESETS:
+                        _merge(cfg, BENCHMARK_PRESETS[name])
+        _merge(cfg, {k: v for k, v in y.items() if k in ("habitat", "habitat_baselines")})
+    for ov in overrides or []:
+        _apply_override(cfg, ov)
+    # YAML reads "2.5e9"-style numbers as strings when the sign of the exponent is missing
+    hb = cfg["habitat_baselines"]
+    for k in ("total_num_steps",):
+        if isinstance(hb.get(k), str):
+            hb[k] = float(hb[k])
+    for k in ("lr", "eps"):
+        if isinstance(hb["rl"]["ppo"].get(k), str):
+            hb["rl"]["ppo"][k] = float(hb["rl"]["ppo"][k])
+    return Config.wrap(cfg)

@@ -1,0 +1,1 @@
+from habitat_amd.rl.ddppo.ddppo import DDPPO  # noqa: F401

@@ -1,0 +1,128 @@
+"""Distributed helpers with the surface of habitat_baselines/rl/ddppo/ddp_utils.py
+(get_distrib_size :247-264, init_distrib_slurm :271-309, rank0_only :100-138, resume-state files :74-87,182-224,
+preemption signal flags :141-179).  One process per GPU; backend "nccl" is RCCL over xGMI on ROCm."""
+from __future__ import annotations
+
+import functools
+import os
+import signal
+import threading
+from typing import Any, Callable, Optional, Tuple
+
+import torch
+import torch.distributed as distrib
+
+EXIT = threading.Event()
+EXIT.clear()
+REQUEUE = threading.Event()
+REQUEUE.clear()
+SAVE_STATE = threading.Event()
+SAVE_STATE.clear()
+
+DEFAULT_PORT = 8738
+DEFAULT_PORT_RANGE = 127
+DEFAULT_MAIN_ADDR = "127.0.0.1"
+SLURM_JOBID = os.environ.get("SLURM_JOB_ID", None)
+RESUME_STATE_BASE_NAME = ".habitat-resume-state"
+
+
+def is_slurm_job() -> bool:
+    return SLURM_JOBID is not None
+
+
+def is_slurm_batch_job() -> bool:
+    return is_slurm_job() and os.environ.get("SLURM_JOB_NAME", None) not in (None, "bash")
+
+
+def _clean_exit_handler(signum, frame):
+    EXIT.set()
+
+
+def _requeue_handler(signum, frame):
+    EXIT.set()
+    REQUEUE.set()
+
+
+def _save_state_handler(signum, frame):
+    SAVE_STATE.set()
+
+
+def add_signal_handlers() -> None:
+    signal.signal(signal.SIGINT, _clean_exit_handler)
+    signal.signal(signal.SIGTERM, _clean_exit_handler)
+    signal.signal(signal.SIGUSR2, _requeue_handler)
+    signal.signal(signal.SIGUSR1, _save_state_handler)
+
+
+def resume_state_filename(config, filename_key: str = "") -> str:
+    fname = RESUME_STATE_BASE_NAME
+    if is_slurm_job() and config.habitat_baselines.rl.preemption.append_slurm_job_id:
+        fname += f"-{SLURM_JOBID}"
+    return os.path.join(config.habitat_baselines.checkpoint_folder, fname + filename_key + ".pth")
+
+
+def save_resume_state(state: Any, filename_or_config, filename_key: str = ""):
+    fn = filename_or_config if isinstance(filename_or_config, str) else resume_state_filename(filename_or_config, filename_key)
+    os.makedirs(os.path.dirname(fn) or ".", exist_ok=True)
+    torch.save(state, fn)
+
+
+def load_resume_state(filename_or_config, filename_key: str = "") -> Optional[Any]:
+    fn = filename_or_config if isinstance(filename_or_config, str) else resume_state_filename(filename_or_config, filename_key)
+    if not os.path.exists(fn):
+        return None
+    return torch.load(fn, map_location="cpu", weights_only=False)
+
+
+def requeue_job():
+    """SLURM requeue (ddp_utils.py:227-240); outside SLURM it only synchronises the ranks."""
+    if not REQUEUE.is_set():
+        return
+    if distrib.is_initialized():
+        distrib.barrier()
+    if SLURM_JOBID is not None and (not distrib.is_initialized() or distrib.get_rank() == 0):
+        import shlex
+        import subprocess
+        subprocess.check_call(shlex.split(f"scontrol requeue {SLURM_JOBID}"))
+
+
+def get_distrib_size() -> Tuple[int, int, int]:
+    """(local_rank, world_rank, world_size) from torchrun (LOCAL_RANK/RANK/WORLD_SIZE) or SLURM variables."""
+    if os.environ.get("LOCAL_RANK", None) is not None:
+        return int(os.environ["LOCAL_RANK"]), int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("SLURM_JOBID", None) is not None:
+        return int(os.environ["SLURM_LOCALID"]), int(os.environ["SLURM_PROCID"]), int(os.environ["SLURM_NTASKS"])
+    return 0, 0, 1
+
+
+def get_main_addr() -> str:
+    return os.environ.get("MAIN_ADDR", os.environ.get("MASTER_ADDR", DEFAULT_MAIN_ADDR))
+
+
+def init_distrib_slurm(backend: str = "nccl"):
+    """Explicit TCPStore rendezvous + process group (ddp_utils.py:271-309).  Returns (local_rank, tcp_store)."""
+    assert distrib.is_available(), "torch.distributed must be available"
+    local_rank, world_rank, world_size = get_distrib_size()
+    main_port = int(os.environ.get("MAIN_PORT", os.environ.get("MASTER_PORT", DEFAULT_PORT)))
+    if SLURM_JOBID is not None:
+        main_port += int(SLURM_JOBID) % int(os.environ.get("MAIN_PORT_RANGE", DEFAULT_PORT_RANGE))
+    main_addr = get_main_addr()
+    # the store lives one port above MASTER_PORT so that it never collides with torchrun's own rendezvous
+    store_port = main_port + 1 if "MASTER_PORT" in os.environ and "MAIN_PORT" not in os.environ else main_port
+    tcp_store = distrib.TCPStore(main_addr, store_port, world_size, world_rank == 0)
+    distrib.init_process_group(backend.lower(), store=tcp_store, rank=world_rank, world_size=world_size)
+    return local_rank, tcp_store
+
+
+def rank0_only(fn: Optional[Callable] = None):
+    """Predicate (`rank0_only()`) and decorator (`@rank0_only`) -- ddp_utils.py:100-138."""
+    if fn is None:
+        return (not distrib.is_available()) or (not distrib.is_initialized()) or distrib.get_rank() == 0
+
+    @functools.wraps(fn)
+    def _wrapper(*args, **kwargs):
+        if rank0_only():
+            return fn(*args, **kwargs)
+        return None
+
+    return _wrapper

@@ -1,0 +1,125 @@
+"""CPU, world_size 2, gloo on 127.0.0.1: the N > 1 host logic of DD-PPO -- rendezvous (TCPStore + process group), flat-arena
+gradient all-reduce + initial broadcast (DDPPO mixin), distributed advantage statistics protocol, statistics / loss coalescing and
+the preemptive straggler rule (PrefixStore counter).  Mirrors the method of the reference's test/test_ddppo_reduce.py:28-132
+(torch.multiprocessing.spawn, gloo, find_free_port)."""
+import os
+import socket
+import sys
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find_free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class FakeEngine:
+    """Flat parameter / gradient arenas on the CPU (the collective logic is device-agnostic)."""
+    def __init__(self, rank):
+        g = torch.Generator().manual_seed(100 + rank)
+        self.params_flat = torch.randn(1000, generator=g)
+        self.grads_flat = torch.randn(1000, generator=g)
+        self.repacked = 0
+
+    def repack(self):
+        self.repacked += 1
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "habitat-lab_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(LOCAL_RANK=str(rank), RANK=str(rank), WORLD_SIZE=str(world), MAIN_ADDR="127.0.0.1", MAIN_PORT=str(port))
+    from habitat_amd.rl.ddppo import ddp_utils
+    from habitat_amd.rl.ddppo.ddppo import DecentralizedDistributedMixin
+    local_rank, store = ddp_utils.init_distrib_slurm("gloo")
+    assert (local_rank, dist.get_rank(), dist.get_world_size()) == (rank, rank, world)
+    assert ddp_utils.rank0_only() == (rank == 0)
+    out = {}
+    # --- DDPPO mixin: broadcast of rank 0's parameters, summed gradients ---
+    upd = types.SimpleNamespace(actor_critic=types.SimpleNamespace(engine=FakeEngine(rank)))
+    g_local = upd.actor_critic.engine.grads_flat.clone()
+    DecentralizedDistributedMixin.init_distributed(upd)
+    DecentralizedDistributedMixin._all_reduce_grads(upd)
+    out["params"] = upd.actor_critic.engine.params_flat.clone()
+    out["grads"] = upd.actor_critic.engine.grads_flat.clone()
+    out["g_local"] = g_local
+    out["repacked"] = upd.actor_critic.engine.repacked
+    assert DecentralizedDistributedMixin._world_size(upd) == world
+    # --- distributed_var_mean protocol (mean all-reduce, then variance about the global mean) ---
+    x = torch.randn(257, generator=torch.Generator().manual_seed(7 + rank))
+    m = x.mean().view(1)
+    DecentralizedDistributedMixin._all_reduce_scalar_stats(upd, m)
+    m /= world
+    v = (x - m).pow(2).mean().view(1)
+    DecentralizedDistributedMixin._all_reduce_scalar_stats(upd, v)
+    v /= world
+    out["x"], out["mean"], out["var"] = x, m, v
+    # --- trainer coalescing + preemption rule, without building envs / policy ---
+    import habitat_amd.rl.ppo.ppo_trainer as tr
+    from habitat_amd.config.default import get_config
+    cfg = get_config("pointnav/ddppo_pointnav.yaml", ["habitat_baselines.num_updates=4", "habitat_baselines.total_num_steps=-1",
+                                                      "habitat_baselines.num_checkpoints=-1", "habitat_baselines.checkpoint_interval=100"])
+    t = tr.PPOTrainer(cfg)
+    assert t._is_distributed
+    t.device = torch.device("cpu")
+    t.num_rollouts_done_store = dist.PrefixStore("rollout_tracker", store)
+    if rank == 0:
+        t.num_rollouts_done_store.set("num_done", "0")
+    dist.barrier()
+    t.running_episode_stats = dict(count=torch.full((3, 1), float(rank + 1)), reward=torch.full((3, 1), 10.0 * (rank + 1)))
+    from collections import defaultdict, deque
+    t.window_episode_stats = defaultdict(lambda: deque(maxlen=50))
+    losses = t._coalesce_post_step(dict(value_loss=1.0 + rank, action_loss=-2.0 * (rank + 1)), 64 * (rank + 1))
+    out["losses"], out["steps"] = losses, t.num_steps_done
+    out["win_count"] = t.window_episode_stats["count"][-1].clone()
+    # preemptive sync: before 25% of the rollout never; afterwards once >= sync_frac * world ranks are done
+    T = cfg.habitat_baselines.rl.ppo.num_steps
+    dist.barrier()
+    early_before = t.should_end_early(T // 4 - 1)
+    none_done = t.should_end_early(T // 2)
+    dist.barrier()
+    if rank == 0:
+        t.num_rollouts_done_store.add("num_done", 1)  # rank 0 finished its rollout
+    dist.barrier()
+    one_done = t.should_end_early(T // 2)  # 1 < 0.6 * 2
+    dist.barrier()
+    if rank == 0:
+        t.num_rollouts_done_store.add("num_done", 1)
+    dist.barrier()
+    two_done = t.should_end_early(T // 2)
+    out["early"] = (early_before, none_done, one_done, two_done)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddppo_host_logic_world2_gloo():
+    world, port = 2, find_free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    assert torch.equal(a["params"], b["params"]) and torch.equal(a["params"], FakeEngine(0).params_flat)  # rank 0 broadcast
+    assert torch.allclose(a["grads"], a["g_local"] + b["g_local"]) and torch.equal(a["grads"], b["grads"])  # summed, identical
+    assert a["repacked"] == 1 and b["repacked"] == 1
+    allx = torch.cat([a["x"], b["x"]])
+    assert torch.allclose(a["mean"], allx.mean().view(1), atol=1e-6) and torch.equal(a["mean"], b["mean"])
+    assert torch.allclose(a["var"], allx.var(unbiased=False).view(1), atol=1e-6)
+    assert a["losses"] == b["losses"] and abs(a["losses"]["value_loss"] - 1.5) < 1e-6 and abs(a["losses"]["action_loss"] + 3.0) < 1e-6
+    assert a["steps"] == b["steps"] == 64 * 3
+    assert torch.equal(a["win_count"], torch.full((3, 1), 3.0))
+    assert a["early"] == b["early"] == (False, False, False, True)

@@ -19,8 +19,21 @@ def L():
     return _lib.lib()
 
 
+_KEEP = []  # tensors whose pointers were handed to the library stay alive until the test ends
+
+
+@pytest.fixture(autouse=True)
+def _release_kept_tensors():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
 def P(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    if t is None:
+        return None
+    _KEEP.append(t)  # a temporary like `x.cuda()` would otherwise be freed (and its block reused) before the launch
+    return C.c_void_p(t.data_ptr())
 
 
 def S():
@@ -109,7 +122,8 @@ def test_advantages(L):
         ref = O.get_advantages(ret, vp, norm)
         adv = torch.zeros(129, 64, 1, device="cuda")
         stats = torch.zeros(4, device="cuda")
-        ck(L.hab_advantages(P(ret.cuda()), P(vp.cuda()), P(adv), ret.numel(), mode, None, P(stats), S()))
+        rd, vd = ret.cuda(), vp.cuda()  # keep the device copies alive across the call
+        ck(L.hab_advantages(P(rd), P(vd), P(adv), ret.numel(), mode, None, P(stats), S()))
         assert torch.allclose(adv.cpu(), ref, rtol=1e-5, atol=1e-6)
     # three-phase distributed form on one rank == biased normalisation (ddppo.py:59-84)
     ref = O.get_advantages(ret, vp, True, world_size=2)

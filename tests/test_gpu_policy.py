@@ -103,7 +103,7 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
     T, N = c["T"], c["N"]
     fill_storage(st, buf, z, T)
     pol.train()
-    ppo = PPO.from_config(pol, types.SimpleNamespace(**vars(cfg), ppo_epoch=cfg.ppo_epoch))
+    ppo = PPO.from_config(pol, cfg)
     adv = ppo.get_advantages(st)
     assert rel_ok(adv.cpu().numpy(), z["advantages"])
     torch.manual_seed(c["seed"] + 1)

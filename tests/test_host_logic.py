@@ -1,0 +1,141 @@
+"""CPU: host-side plugin layer -- registry, config entrypoints, TensorDict, storage bookkeeping, policy construction."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_registry_names_match_reference_strings():
+    import habitat_amd.rl.ppo.ppo_trainer  # noqa: F401
+    from habitat_amd.common.baseline_registry import baseline_registry as r
+    assert r.get_trainer("ppo") is r.get_trainer("ddppo") and r.get_trainer("ppo").__name__ == "PPOTrainer"
+    assert r.get_policy("PointNavBaselinePolicy") is not None
+    assert r.get_updater("PPO") is not None and r.get_updater("DDPPO") is not None
+    assert r.get_storage("RolloutStorage") is not None
+    assert r.get_agent_access_mgr("SingleAgentAccessMgr") is not None
+    assert r.get_policy("nope") is None
+    with pytest.raises(AssertionError):
+        r.register_policy(int)
+
+
+def test_yaml_entrypoints_compose():
+    from habitat_amd.config.default import get_config
+    c = get_config("pointnav/ddppo_pointnav.yaml", ["habitat_baselines.num_environments=64", "habitat_baselines.rl.ddppo.backbone=resnet18"])
+    hb = c.habitat_baselines
+    assert hb.trainer_name == "ddppo" and hb.rl.policy.main_agent.name == "PointNavResNetPolicy"
+    assert (hb.rl.ppo.clip_param, hb.rl.ppo.ppo_epoch, hb.rl.ppo.num_mini_batch, hb.rl.ppo.max_grad_norm) == (0.2, 2, 2, 0.2)
+    assert hb.rl.ppo.num_steps == 128 and hb.rl.ppo.use_normalized_advantage is False and hb.rl.ppo.use_clipped_value_loss is True
+    assert hb.rl.ddppo.rnn_type == "LSTM" and hb.rl.ddppo.num_recurrent_layers == 2 and hb.rl.ddppo.backbone == "resnet18"
+    assert hb.num_environments == 64 and hb.total_num_steps == 2.5e9 and c.habitat.seed == 100
+    c2 = get_config("pointnav/ppo_pointnav_habitat_iccv19.yaml")
+    p = c2.habitat_baselines.rl.ppo
+    assert (p.clip_param, p.ppo_epoch, p.num_mini_batch, p.use_normalized_advantage, p.use_linear_lr_decay) == (0.1, 4, 4, True, True)
+    assert c2.habitat_baselines.rl.policy.main_agent.name == "PointNavBaselinePolicy"
+    c3 = get_config("pointnav/ppo_pointnav_example.yaml")
+    assert c3.habitat_baselines.rl.ppo.num_steps == 32 and c3.habitat_baselines.rl.ppo.ppo_epoch == 1
+
+
+def test_tensor_dict_semantics():
+    """Mirrors the reference's test/test_tensor_dict.py:21-90."""
+    from habitat_amd.common.tensor_dict import TensorDict
+    tree = dict(a=torch.randn(2, 2), b=dict(c=dict(d=np.random.randn(3, 3))))
+    td = TensorDict.from_tree(tree)
+    assert torch.is_tensor(td["b"]["c"]["d"]) and isinstance(td["b"], TensorDict)
+    back = td.to_tree()
+    assert not isinstance(back["b"], TensorDict) and torch.equal(back["a"], tree["a"])
+    t = TensorDict(a=torch.randn(5, 3), b=TensorDict(c=torch.randn(5, 2)))
+    assert t[1:3]["a"].shape == (2, 3) and t[0]["b"]["c"].shape == (2,)
+    t[0] = dict(a=torch.zeros(3), b=dict(c=torch.ones(2)))
+    assert t["a"][0].abs().sum() == 0 and (t["b"]["c"][0] == 1).all()
+    with pytest.raises(KeyError):
+        t.set(0, dict(a=torch.zeros(3)), strict=True)
+    t.set(0, dict(a=torch.ones(3)), strict=False)
+    assert (t["a"][0] == 1).all()
+    m = t.map(lambda v: v * 2)
+    assert torch.equal(m["b"]["c"], t["b"]["c"] * 2)
+    spec, leaves = t.flatten()
+    t2 = TensorDict.from_flattened(spec, leaves)
+    assert torch.equal(t2["b"]["c"], t["b"]["c"])
+
+
+def _space(H=44, W=44):
+    from habitat_amd.common import spaces as S
+    return S.Dict({"rgb": S.Box(0, 255, (H, W, 3), np.uint8), "depth": S.Box(0.0, 1.0, (H, W, 1), np.float32),
+                   "pointgoal_with_gps_compass": S.Box(-1e9, 1e9, (2,), np.float32)}), S.Discrete(4)
+
+
+def test_policy_staging_names_and_no_cpu_execution():
+    from habitat_amd import _lib
+    from habitat_amd.rl.ppo import PointNavBaselinePolicy
+    from oracle.fixtures import baseline_param_shapes
+    osp, asp = _space()
+    torch.manual_seed(0)
+    pol = PointNavBaselinePolicy(osp, asp, hidden_size=64)
+    assert [(k, tuple(v.shape)) for k, v in pol.state_dict().items()] == baseline_param_shapes(4, 44, 44, 64)
+    assert pol.num_recurrent_layers == 1 and pol.recurrent_hidden_size == 64 and pol.hidden_state_shape == (1, 64)
+    assert len(list(pol.policy_parameters())) == 16
+    # critic orthogonal init has unit row norm, biases are zero (policy.py:420-421)
+    assert abs(pol.state_dict()["critic.fc.weight"].norm().item() - 1.0) < 1e-5
+    assert pol.state_dict()["net.state_encoder.rnn.bias_ih_l0"].abs().sum() == 0
+    obs = {"rgb": torch.zeros(2, 44, 44, 3, dtype=torch.uint8), "depth": torch.zeros(2, 44, 44, 1), "pointgoal_with_gps_compass": torch.zeros(2, 2)}
+    with pytest.raises(_lib.HabError):  # no CPU fallback
+        pol.act(obs, torch.zeros(2, 1, 64), torch.zeros(2, 1, dtype=torch.long), torch.zeros(2, 1, dtype=torch.bool))
+
+
+def test_policy_init_identical_to_live_reference():
+    from oracle.ref_loader import load_reference, reference_available
+    if not reference_available():
+        pytest.skip("/root/reference not present")
+    from habitat_amd.rl.ppo import PointNavBaselinePolicy
+    ns = load_reference()
+    sp = ns.spaces
+    osp, asp = _space()
+    robs = sp.Dict({"rgb": sp.Box(0, 255, (44, 44, 3), np.uint8), "depth": sp.Box(0, 1, (44, 44, 1), np.float32),
+                    "pointgoal_with_gps_compass": sp.Box(-1e9, 1e9, (2,), np.float32)})
+    torch.manual_seed(123)
+    mine = PointNavBaselinePolicy(osp, asp, hidden_size=64).state_dict()
+    torch.manual_seed(123)
+    ref = ns.policy.PointNavBaselinePolicy(robs, sp.Discrete(4), hidden_size=64).state_dict()
+    assert list(mine.keys()) == list(ref.keys())
+    assert all(torch.equal(mine[k], ref[k]) for k in ref)
+
+
+def test_storage_bookkeeping_on_cpu():
+    """insert / advance / after_update / get_current_step index semantics (rollout_storage.py:113-172,265-275)."""
+    from habitat_amd.common.rollout_storage import RolloutStorage
+    osp, asp = _space(8, 8)
+    ac = type("AC", (), dict(num_recurrent_layers=1, recurrent_hidden_size=4, device=torch.device("cpu")))()
+    st = RolloutStorage(3, 2, osp, asp, ac)
+    assert st.buffers["observations"]["rgb"].shape == (4, 2, 8, 8, 3) and st.buffers["observations"]["rgb"].dtype == torch.uint8
+    assert st.buffers["actions"].dtype == torch.long and st.buffers["masks"].dtype == torch.bool
+    st.insert_first_observations({k: torch.ones_like(v[0]) for k, v in st.buffers["observations"].items()})
+    for t in range(3):
+        st.insert(next_recurrent_hidden_states=torch.full((2, 1, 4), t + 1.0), actions=torch.full((2, 1), t, dtype=torch.long),
+                  action_log_probs=torch.full((2, 1), -1.0 * t), value_preds=torch.full((2, 1), 0.5 * t))
+        st.insert(next_observations={k: torch.full_like(v[0], t + 2) for k, v in st.buffers["observations"].items()},
+                  rewards=torch.full((2, 1), 10.0 + t), next_masks=torch.ones(2, 1, dtype=torch.bool))
+        st.advance_rollout()
+    B = st.buffers
+    assert st.current_rollout_step_idx == 3
+    assert B["prev_actions"][3, 0, 0] == 2 and B["actions"][2, 0, 0] == 2 and B["rewards"][1, 0, 0] == 11
+    assert B["recurrent_hidden_states"][3].eq(3).all() and B["observations"]["depth"][3].eq(4).all()
+    assert st.get_last_step()["masks"].all()
+    st.after_update()
+    assert st.current_rollout_step_idx == 0 and B["observations"]["depth"][0].eq(4).all() and B["prev_actions"][0, 0, 0] == 2
+    with pytest.raises(Exception):
+        st.compute_returns(torch.zeros(2, 1), True, 0.99, 0.95)  # no CPU fallback for the kernel
+
+
+def test_base_trainer_schedules():
+    from habitat_amd.common.base_trainer import BaseRLTrainer
+    from habitat_amd.config.default import get_config
+    c = get_config("pointnav/ppo_pointnav_example.yaml", ["habitat_baselines.num_updates=10", "habitat_baselines.total_num_steps=-1",
+                                                          "habitat_baselines.num_checkpoints=5"])
+    t = BaseRLTrainer(c)
+    fired = []
+    for u in range(10):
+        t.num_updates_done = u + 1
+        fired.append(t.should_checkpoint())
+    # strict `last + 1/num_checkpoints < percent_done` (base_trainer.py:269-287): fires at 10%, 40%, 70%, 100%
+    assert fired[:7] == [True, False, False, True, False, False, True] and sum(fired) == 4 and t.is_done()
+    with pytest.raises(RuntimeError):
+        BaseRLTrainer(get_config("pointnav/ppo_pointnav_example.yaml", ["habitat_baselines.num_updates=10"]))
