@@ -46,11 +46,30 @@ int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const f
     HAB_TRY(build(p, d, obs, wf, bias, y, relu));
     return run_igemm(p, ws, ws_floats, stream);
 }
+// dX pixels whose class has no taps (possible only when stride > kernel size) receive no contribution:
+// they are written by the zero-tap path below so that dx is always fully defined.
+__global__ void dgrad_empty_class_kernel(ConvDgradProb p) {
+    const long long total = (long long)p.g.B * p.Hc * p.Wc * p.N;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x)
+        p.store((int)(e / p.N), (int)(e % p.N), 0.f);
+}
+
 int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add, float* dx,
                float* ws, size_t ws_floats, hipStream_t stream) {
-    ConvDgradProb p;
-    HAB_TRY(build(p, d, dy, wd, mask, add, dx));
-    return run_igemm(p, ws, ws_floats, stream);
+    for (int ph = 0; ph < d.stride; ++ph)
+        for (int pw = 0; pw < d.stride; ++pw) {
+            ConvDgradProb p;
+            HAB_TRY(build(p, d, dy, wd, mask, add, dx, ph, pw));
+            if (p.Hc <= 0 || p.Wc <= 0) continue;
+            if (p.K <= 0) {
+                p.M = d.B * p.Hc * p.Wc;
+                dgrad_empty_class_kernel<<<1024, 256, 0, stream>>>(p);
+                HAB_LAUNCH_CHECK();
+                continue;
+            }
+            HAB_TRY(run_igemm(p, ws, ws_floats, stream));
+        }
+    return HAB_OK;
 }
 int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_floats,
                hipStream_t stream) {

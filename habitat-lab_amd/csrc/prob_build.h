@@ -40,12 +40,13 @@ inline int build(ObsConvFwdProb& p, const ConvDesc& d, const ObsView& obs, const
     return HAB_OK;
 }
 inline int build(ConvDgradProb& p, const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add,
-                 float* dx) {
+                 float* dx, int ph = 0, int pw = 0) {
     HAB_TRY(check_conv(d));
     if (d.C % 4 || d.Cout % 4) return HAB_ERR_UNSUPPORTED;
+    if (ph < 0 || pw < 0 || ph >= d.stride || pw >= d.stride) return HAB_ERR_ARG;
     p.g = make_geom(d);
-    p.M = d.B * d.H * d.W; p.N = d.C; p.K = d.KH * d.KW * d.Cout;
     p.dy = dy; p.w = wd; p.mask = mask; p.add = add; p.dx = dx;
+    p.set_class(ph, pw);
     return HAB_OK;
 }
 inline int build(ConvWgradProb& p, const ConvDesc& d, const float* x, const float* dy, float* dw) {

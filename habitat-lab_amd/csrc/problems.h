@@ -161,53 +161,75 @@ struct ObsConvFwdProb {
 
 // ----------------------------------------------------------------------------------------------
 // Convolution data gradient: dX[(img,h,w)][ci] = sum_{kh,kw,co} dY[img,(h+p-kh)/s,(w+p-kw)/s,co] * Wd[ci][(kh,kw,co)]
-// (taps whose position is not a multiple of the stride contribute zero).  Epilogue: optional
-// add (residual gradient), optional ReLU mask of the producer's output.
+// For stride s only taps with kh == (h+p) mod s (and likewise kw) contribute, so the problem is
+// split into s*s "stride classes" (ph, pw): class (ph,pw) covers the input pixels with
+// (h+p) % s == ph, (w+p) % s == pw and contracts over the taps kh = ph + s*a, kw = pw + s*b only --
+// no multiply-by-zero work (4x4/s2: 4 classes x 2x2 taps instead of 16 taps).  One launch per class.
+// Epilogue: optional add (residual gradient), optional ReLU mask of the producer's output.
 // ----------------------------------------------------------------------------------------------
 struct ConvDgradProb {
     static constexpr bool A_RC = true, B_RC = true;
-    int M, N, K;  // M = B*H*W, N = Cin, K = KH*KW*Cout
+    int M, N, K;  // M = B*Hc*Wc (pixels of this class), N = Cin, K = KHs*KWs*Cout
     ConvGeom g;
+    int ph, pw;        // stride class
+    int h_first, w_first;  // first h / w of the class
+    int Hc, Wc;        // pixels of the class per image along h / w
+    int KHs, KWs;      // taps of the class
+    int Kfull;         // KH*KW*Cout (row length of Wd)
+    FastDiv dHcWc, dWc, dKWs;
     const float* dy;
-    const float* w;     // Wd packed [Cin][K]
+    const float* w;     // Wd packed [Cin][Kfull]
     const float* mask;  // same shape as dx, or null: dx *= (mask > 0)
     const float* add;   // same shape as dx, or null: dx += add   (applied before the mask)
     float* dx;
-    struct ACtx { const float* base; int hp, wp; };
+    void set_class(int ph_, int pw_) {
+        const int s = g.stride;
+        ph = ph_; pw = pw_;
+        h_first = ((ph - g.pad) % s + s) % s;
+        w_first = ((pw - g.pad) % s + s) % s;
+        Hc = h_first < g.H ? (g.H - h_first + s - 1) / s : 0;
+        Wc = w_first < g.W ? (g.W - w_first + s - 1) / s : 0;
+        KHs = ph < g.KH ? (g.KH - ph + s - 1) / s : 0;
+        KWs = pw < g.KW ? (g.KW - pw + s - 1) / s : 0;
+        Kfull = g.KH * g.KW * g.Cout;
+        M = g.B * Hc * Wc; N = g.C; K = KHs * KWs * g.Cout;
+        dHcWc = FastDiv(Hc * Wc > 0 ? Hc * Wc : 1); dWc = FastDiv(Wc > 0 ? Wc : 1); dKWs = FastDiv(KWs > 0 ? KWs : 1);
+    }
+    struct ACtx { const float* base; int hq, wq; };  // hq = (h + pad - ph) / s
     struct BCtx { const float* row; };
     HAB_HD ACtx a_ctx(int m) const {
         ACtx c;
-        if (m >= M) { c.base = nullptr; c.hp = 0; c.wp = 0; return c; }
-        int img, rem, h, w_;
-        g.dHW.divmod(m, img, rem);
-        g.dW.divmod(rem, h, w_);
+        if (m >= M) { c.base = nullptr; c.hq = 0; c.wq = 0; return c; }
+        int img, rem, hc, wc;
+        dHcWc.divmod(m, img, rem);
+        dWc.divmod(rem, hc, wc);
         c.base = dy + (size_t)img * g.Ho * g.Wo * g.Cout;
-        c.hp = h + g.pad;
-        c.wp = w_ + g.pad;
+        c.hq = (h_first + hc * g.stride + g.pad - ph) / g.stride;
+        c.wq = (w_first + wc * g.stride + g.pad - pw) / g.stride;
         return c;
     }
     HAB_HD f32x4 a_load(const ACtx& c, int k, int k_end) const {
         if (!c.base || k >= k_end) return zero4();
-        int tap, co, kh, kw;
+        int tap, co, a, b;
         g.dCout.divmod(k, tap, co);
-        g.dKW.divmod(tap, kh, kw);
-        int hs = c.hp - kh, ws = c.wp - kw;
-        if (hs < 0 || ws < 0) return zero4();
-        if (g.stride > 1) {
-            if ((hs % g.stride) | (ws % g.stride)) return zero4();
-            hs /= g.stride;
-            ws /= g.stride;
-        }
-        if (hs >= g.Ho || ws >= g.Wo) return zero4();
+        dKWs.divmod(tap, a, b);
+        const int hs = c.hq - a, ws = c.wq - b;  // output row / col that tap (ph + s*a, pw + s*b) reads
+        if ((unsigned)hs >= (unsigned)g.Ho || (unsigned)ws >= (unsigned)g.Wo) return zero4();
         return ld4(c.base + ((size_t)hs * g.Wo + ws) * g.Cout + co);
     }
-    HAB_HD BCtx b_ctx(int n) const { BCtx c; c.row = (n < N) ? w + (size_t)n * K : nullptr; return c; }
+    HAB_HD BCtx b_ctx(int n) const { BCtx c; c.row = (n < N) ? w + (size_t)n * Kfull : nullptr; return c; }
     HAB_HD f32x4 b_load(const BCtx& c, int k, int k_end) const {
         if (!c.row || k >= k_end) return zero4();
-        return ld4(c.row + k);
+        int tap, co, a, b;
+        g.dCout.divmod(k, tap, co);
+        dKWs.divmod(tap, a, b);
+        return ld4(c.row + ((size_t)(ph + g.stride * a) * g.KW + (pw + g.stride * b)) * g.Cout + co);
     }
     HAB_HD void store(int m, int n, float v) const {
-        const size_t i = (size_t)m * N + n;
+        int img, rem, hc, wc;
+        dHcWc.divmod(m, img, rem);
+        dWc.divmod(rem, hc, wc);
+        const size_t i = ((((size_t)img * g.H) + h_first + hc * g.stride) * g.W + w_first + wc * g.stride) * N + n;
         if (add) v += add[i];
         if (mask && !(mask[i] > 0.f)) v = 0.f;
         dx[i] = v;

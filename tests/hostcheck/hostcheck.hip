@@ -77,9 +77,18 @@ extern "C" int hc_obs_conv2d_fwd(const uint8_t* rgb, const float* depth, const i
 }
 extern "C" int hc_conv2d_dgrad(const float* dy, const float* wd, const float* mask, const float* add, float* dx, int B, int H,
                                int W, int C, int Cout, int KH, int KW, int stride, int pad) {
-    ConvDgradProb p;
-    HAB_TRY(build(p, mk(B, H, W, C, Cout, KH, KW, stride, pad), dy, wd, mask, add, dx));
-    host_igemm(p);
+    for (int ph = 0; ph < stride; ++ph)
+        for (int pw = 0; pw < stride; ++pw) {
+            ConvDgradProb p;
+            HAB_TRY(build(p, mk(B, H, W, C, Cout, KH, KW, stride, pad), dy, wd, mask, add, dx, ph, pw));
+            if (p.Hc <= 0 || p.Wc <= 0) continue;
+            if (p.K <= 0) {
+                for (int m = 0; m < p.M; ++m)
+                    for (int n = 0; n < p.N; ++n) p.store(m, n, 0.f);
+                continue;
+            }
+            host_igemm(p);
+        }
     return 0;
 }
 extern "C" int hc_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int Cout, int KH, int KW,
