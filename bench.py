@@ -60,7 +60,7 @@ def make_trainer(workload: str, total_updates: int):
     return trainer, cfg
 
 
-def cpu_baseline(sample_envs=4, sample_steps=8):
+def cpu_baseline(sample_envs=4, sample_steps=4):
     """The oracle (CPU restatement of the reference path, pinned to the reference by tests/golden) timed on the host
     cores on a bounded sample of the same workload: same obs size, same E=4 x M=4 update, fewer envs x steps."""
     import types
@@ -68,7 +68,7 @@ def cpu_baseline(sample_envs=4, sample_steps=8):
     from oracle import functional as O
     from oracle import synth
     from oracle.fixtures import baseline_param_shapes, det_params, synth_rollout_inputs
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))  # more threads than this slow the small-batch CPU convs down
     N, T, hidden = sample_envs, sample_steps, 512
     params = det_params(baseline_param_shapes(4, OBS, OBS, hidden), 1)
     spec = O.NetSpec(kind="baseline", hidden=hidden)

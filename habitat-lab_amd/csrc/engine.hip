@@ -472,21 +472,18 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
                            ws, e->ws_floats, stream)); }
     // conv3 (no ReLU after it; its input a2 is post-ReLU -> mask on the data gradient)
     { Probe pr(e, HAB_PROBE_CONV3_WGRAD, stream);
-      HAB_TRY(conv_wgrad(c3, W + e->w_a2, W + e->w_da3, e->g(e->i_c3w), ws, e->ws_floats, stream)); }
-    HAB_TRY(colsum(W + e->w_da3, 32, B * c3.Ho() * c3.Wo(), 32, e->g(e->i_c3b), 0, ws, e->ws_floats, stream));
+      HAB_TRY(conv_wgrad(c3, W + e->w_a2, W + e->w_da3, e->g(e->i_c3w), e->g(e->i_c3b), ws, e->ws_floats, stream)); }
     { Probe pr(e, HAB_PROBE_CONV3_DGRAD, stream);
       HAB_TRY(conv_dgrad(c3, W + e->w_da3, e->PK + e->pk_c3d, W + e->w_a2, nullptr, W + e->w_da2, ws, e->ws_floats, stream)); }
     { Probe pr(e, HAB_PROBE_CONV2_WGRAD, stream);
-      HAB_TRY(conv_wgrad(c2, W + e->w_a1, W + e->w_da2, e->g(e->i_c2w), ws, e->ws_floats, stream)); }
-    HAB_TRY(colsum(W + e->w_da2, 64, B * c2.Ho() * c2.Wo(), 64, e->g(e->i_c2b), 0, ws, e->ws_floats, stream));
+      HAB_TRY(conv_wgrad(c2, W + e->w_a1, W + e->w_da2, e->g(e->i_c2w), e->g(e->i_c2b), ws, e->ws_floats, stream)); }
     { Probe pr(e, HAB_PROBE_CONV2_DGRAD, stream);
       HAB_TRY(conv_dgrad(c2, W + e->w_da2, e->PK + e->pk_c2d, W + e->w_a1, nullptr, W + e->w_da1, ws, e->ws_floats, stream)); }
     ObsView ov;
     ov.rgb = e->d.has_rgb ? obs->rgb : nullptr; ov.depth = e->d.has_depth ? obs->depth : nullptr; ov.rows = rows;
     ov.H = e->d.H; ov.W = e->d.W; ov.C = e->Cin;
     { Probe pr(e, HAB_PROBE_CONV1_WGRAD, stream);
-      HAB_TRY(obs_conv_wgrad(c1, ov, W + e->w_da1, e->g(e->i_c1w), ws, e->ws_floats, stream)); }
-    HAB_TRY(colsum(W + e->w_da1, 32, B * c1.Ho() * c1.Wo(), 32, e->g(e->i_c1b), 0, ws, e->ws_floats, stream));
+      HAB_TRY(obs_conv_wgrad(c1, ov, W + e->w_da1, e->g(e->i_c1w), e->g(e->i_c1b), ws, e->ws_floats, stream)); }
     return HAB_OK;
 }
 

@@ -71,16 +71,16 @@ int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float*
         }
     return HAB_OK;
 }
-int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_floats,
+int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oihw, float* dbias, float* ws, size_t ws_floats,
                hipStream_t stream) {
     ConvWgradProb p;
-    HAB_TRY(build(p, d, x, dy, dw_oihw));
+    HAB_TRY(build(p, d, x, dy, dw_oihw, dbias));
     return run_igemm(p, ws, ws_floats, stream);
 }
-int obs_conv_wgrad(const ConvDesc& d, const ObsView& obs, const float* dy, float* dw_oihw, float* ws, size_t ws_floats,
-                   hipStream_t stream) {
+int obs_conv_wgrad(const ConvDesc& d, const ObsView& obs, const float* dy, float* dw_oihw, float* dbias, float* ws,
+                   size_t ws_floats, hipStream_t stream) {
     ObsConvWgradProb p;
-    HAB_TRY(build(p, d, obs, dy, dw_oihw));
+    HAB_TRY(build(p, d, obs, dy, dw_oihw, dbias));
     return run_igemm(p, ws, ws_floats, stream);
 }
 int linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N, int K,
@@ -128,12 +128,21 @@ __global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ a
         __syncthreads();
     }
 }
-__global__ void colsum_stage2(const float* __restrict__ partial, int nblocks, int N, float* __restrict__ out, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+__global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ partial, int nblocks, int N, float* __restrict__ out,
+                                                     int accumulate) {
+    // 64 columns per block, 4 row lanes
+    __shared__ float sm[4][64];
+    const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    if (n < N)
+        for (int b = r; b < nblocks; b += 4) s += partial[(size_t)b * N + n];
+    sm[r][c] = s;
+    __syncthreads();
+    if (r == 0 && n < N) {
+        const float t = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+        out[n] = accumulate ? out[n] + t : t;
+    }
 }
 
 int colsum(const float* a, int lda, int M, int N, float* out, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
@@ -146,7 +155,7 @@ int colsum(const float* a, int lda, int M, int N, float* out, int accumulate, fl
     blocks = cdiv(M, rpb);
     colsum_stage1<<<blocks, 256, 0, stream>>>(a, lda, M, N, rpb, ws);
     HAB_LAUNCH_CHECK();
-    colsum_stage2<<<cdiv(N, 64), 64, 0, stream>>>(ws, blocks, N, out, accumulate);
+    colsum_stage2<<<cdiv(N, 64), 256, 0, stream>>>(ws, blocks, N, out, accumulate);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -255,17 +264,17 @@ extern "C" int hab_conv2d_dgrad(const float* dy, const float* w_dgrad, const flo
     if (!dy || !w_dgrad || !dx) return HAB_ERR_ARG;
     return conv_dgrad(mk(B, H, W, C, Cout, KH, KW, stride, pad), dy, w_dgrad, relu_mask, add, dx, ws, ws_floats, stream);
 }
-extern "C" int hab_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int C, int Cout, int KH,
-                                int KW, int stride, int pad, float* ws, size_t ws_floats, hipStream_t stream) {
+extern "C" int hab_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, int B, int H, int W, int C, int Cout,
+                                int KH, int KW, int stride, int pad, float* ws, size_t ws_floats, hipStream_t stream) {
     if (!x || !dy || !dw_oihw) return HAB_ERR_ARG;
-    return conv_wgrad(mk(B, H, W, C, Cout, KH, KW, stride, pad), x, dy, dw_oihw, ws, ws_floats, stream);
+    return conv_wgrad(mk(B, H, W, C, Cout, KH, KW, stride, pad), x, dy, dw_oihw, dbias, ws, ws_floats, stream);
 }
 extern "C" int hab_obs_conv2d_wgrad(const uint8_t* rgb, const float* depth, const int* rows, const float* dy, float* dw_oihw,
-                                    int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                                    float* dbias, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, float* ws,
                                     size_t ws_floats, hipStream_t stream) {
     if ((!rgb && !depth) || !dy || !dw_oihw) return HAB_ERR_ARG;
     ObsView o = mkobs(rgb, depth, rows, H, W);
-    return obs_conv_wgrad(mk(B, H, W, o.C, Cout, KH, KW, stride, pad), o, dy, dw_oihw, ws, ws_floats, stream);
+    return obs_conv_wgrad(mk(B, H, W, o.C, Cout, KH, KW, stride, pad), o, dy, dw_oihw, dbias, ws, ws_floats, stream);
 }
 extern "C" int hab_linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M,
                               int N, int K, int relu, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {

@@ -24,6 +24,8 @@
 // ids are remapped to give each XCD (private 4 MiB L2) a contiguous run of M-tiles, which keeps the
 // im2col halo re-reads of neighbouring tiles in one L2.
 #pragma once
+#include <type_traits>
+
 #include "hab_common.h"
 
 namespace hab {
@@ -32,6 +34,14 @@ template <class P>
 struct IgemmLaunch;  // fwd
 
 constexpr int IGEMM_BK = 32;
+
+// Optional fused column sums of the B operand (bias gradients ride along with the weight-gradient
+// contraction: db[j] = sum_r Q(r, j)).  A problem opts in with `static constexpr bool COLSUM_B = true`,
+// a nullable `float* colsum` member and `store_colsum(j, v)`; B must be in the j-contiguous form.
+template <class P, class = void>
+struct ColsumB : std::false_type {};
+template <class P>
+struct ColsumB<P, std::void_t<decltype(P::COLSUM_B)>> : std::bool_constant<P::COLSUM_B && !P::B_RC> {};
 
 template <class P, int TM, int TN, int WM, int WN>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int k_per_split, float* __restrict__ partial) {
@@ -91,6 +101,12 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
         for (int j = 0; j < B_UNITS; ++j) bctx[j] = p.b_ctx(n0 + (t % (BN / 4)) * 4);
     }
     const bool b_active = !B_PARTIAL || (t < BN * BK / 4);
+    constexpr bool CS = ColsumB<P>::value;
+    bool do_cs = false;
+    if constexpr (CS) do_cs = (p.colsum != nullptr) && (tile_m == 0);
+    const int MP = p.M + ((CS && do_cs) ? 1 : 0);  // rows of a split-K slab (the extra row carries the column sums)
+    f32x4 cs;
+    cs[0] = 0.f; cs[1] = 0.f; cs[2] = 0.f; cs[3] = 0.f;
 
     f32x4 areg[A_UNITS], breg[B_UNITS];
     auto load_tile = [&](int kt) {
@@ -111,6 +127,12 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
             } else {
 #pragma unroll
                 for (int j = 0; j < B_UNITS; ++j) breg[j] = p.b_load(bctx[j], k0 + t / (BN / 4) + (NT / (BN / 4)) * j, k_end);
+                if constexpr (CS) {
+                    if (do_cs) {
+#pragma unroll
+                        for (int j = 0; j < B_UNITS; ++j) cs += breg[j];
+                    }
+                }
             }
         }
     };
@@ -195,6 +217,22 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
 
     // ---- epilogue ----
     const bool split = gridDim.z > 1;
+    if constexpr (CS) {
+        if (do_cs) {  // block-uniform: fold the per-thread partial column sums through LDS (the tile buffers are free now)
+            float* red = smem;
+            *reinterpret_cast<f32x4*>(red + t * 4) = cs;
+            __syncthreads();
+            if (t < BN && n0 + t < p.N) {
+                constexpr int GR = BN / 4;  // threads t, t+GR, t+2GR, ... hold the same 4 columns
+                float s = 0.f;
+                for (int q = (t >> 2); q < NT; q += GR) s += red[q * 4 + (t & 3)];
+                if (split)
+                    partial[((size_t)kz * MP + p.M) * p.N + n0 + t] = s;
+                else
+                    p.store_colsum(n0 + t, s);
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -205,7 +243,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
                 const int row = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
                 if (row < p.M && col < p.N) {
                     if (split)
-                        partial[((size_t)kz * p.M + row) * p.N + col] = acc[i][j][v];
+                        partial[((size_t)kz * MP + row) * p.N + col] = acc[i][j][v];
                     else
                         p.store(row, col, acc[i][j][v]);
                 }
@@ -216,11 +254,17 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
 // Second pass of a split-K launch: fixed-order sum of the partial slabs, then the problem's epilogue.
 template <class P>
 __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const P p, const float* __restrict__ partial, int splits) {
-    const size_t total = (size_t)p.M * p.N;
+    int MP = p.M;
+    if constexpr (ColsumB<P>::value) MP += (p.colsum != nullptr) ? 1 : 0;
+    const size_t total = (size_t)MP * p.N;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         float s = 0.0f;
         for (int z = 0; z < splits; ++z) s += partial[(size_t)z * total + e];
-        p.store((int)(e / p.N), (int)(e % p.N), s);
+        const int m = (int)(e / p.N), n = (int)(e % p.N);
+        if constexpr (ColsumB<P>::value) {
+            if (m == p.M) { p.store_colsum(n, s); continue; }
+        }
+        p.store(m, n, s);
     }
 }
 
@@ -240,11 +284,11 @@ inline IgemmPlan igemm_plan(int M, int N, int K, int target_blocks, int max_spli
     const int ktiles = cdiv(K, IGEMM_BK);
     if (splits > ktiles) splits = ktiles;
     if (splits > max_splits) splits = max_splits;
-    while (splits > 1 && (size_t)splits * (size_t)M * (size_t)N > max_partial_floats) --splits;
+    while (splits > 1 && (size_t)splits * (size_t)(M + 1) * (size_t)N > max_partial_floats) --splits;
     if (splits < 1) splits = 1;
     pl.k_per_split = cdiv(ktiles, splits) * IGEMM_BK;
     pl.splits = cdiv(K, pl.k_per_split);
-    pl.partial_floats = pl.splits > 1 ? (size_t)pl.splits * M * N : 0;
+    pl.partial_floats = pl.splits > 1 ? (size_t)pl.splits * (M + 1) * N : 0;
     return pl;
 }
 
@@ -267,7 +311,7 @@ inline int igemm_launch(const P& p, const IgemmPlan& pl, float* partial, hipStre
     kern<<<grid, WM * WN * 64, LDS, stream>>>(p, pl.k_per_split, partial);
     HAB_LAUNCH_CHECK();
     if (pl.splits > 1) {
-        int blocks = (int)cdivl((long long)p.M * p.N, 256);
+        int blocks = (int)cdivl((long long)(p.M + 1) * p.N, 256);
         if (blocks > 4096) blocks = 4096;
         igemm_splitk_reduce_kernel<P><<<blocks, 256, 0, stream>>>(p, partial, pl.splits);
         HAB_LAUNCH_CHECK();

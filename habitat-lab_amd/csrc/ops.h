@@ -18,10 +18,10 @@ int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const f
                  size_t ws_floats, hipStream_t stream);
 int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add, float* dx,
                float* ws, size_t ws_floats, hipStream_t stream);
-int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_floats,
+int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oihw, float* dbias, float* ws, size_t ws_floats,
                hipStream_t stream);
-int obs_conv_wgrad(const ConvDesc& d, const ObsView& obs, const float* dy, float* dw_oihw, float* ws, size_t ws_floats,
-                   hipStream_t stream);
+int obs_conv_wgrad(const ConvDesc& d, const ObsView& obs, const float* dy, float* dw_oihw, float* dbias, float* ws,
+                   size_t ws_floats, hipStream_t stream);
 int linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N, int K,
                int relu, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
 int linear_dgrad(const float* dy, int lddy, const float* w, int ldw, const float* mask, int ldmask, int mask_cols, float* dx,

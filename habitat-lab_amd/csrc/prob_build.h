@@ -49,20 +49,20 @@ inline int build(ConvDgradProb& p, const ConvDesc& d, const float* dy, const flo
     p.set_class(ph, pw);
     return HAB_OK;
 }
-inline int build(ConvWgradProb& p, const ConvDesc& d, const float* x, const float* dy, float* dw) {
+inline int build(ConvWgradProb& p, const ConvDesc& d, const float* x, const float* dy, float* dw, float* dbias = nullptr) {
     HAB_TRY(check_conv(d));
     if (d.C % 4 || d.Cout % 4) return HAB_ERR_UNSUPPORTED;
     p.g = make_geom(d);
     p.M = d.KH * d.KW * d.C; p.N = d.Cout; p.K = d.B * p.g.Ho * p.g.Wo;
-    p.x = x; p.dy = dy; p.dw = dw;
+    p.x = x; p.dy = dy; p.dw = dw; p.colsum = dbias;
     return HAB_OK;
 }
-inline int build(ObsConvWgradProb& p, const ConvDesc& d, const ObsView& obs, const float* dy, float* dw) {
+inline int build(ObsConvWgradProb& p, const ConvDesc& d, const ObsView& obs, const float* dy, float* dw, float* dbias = nullptr) {
     HAB_TRY(check_conv(d));
     if (d.C != obs.C || d.Cout % 4 || (d.KH * d.KW * d.C) % 4) return HAB_ERR_UNSUPPORTED;
     p.g = make_geom(d);
     p.M = d.KH * d.KW * d.C; p.N = d.Cout; p.K = d.B * p.g.Ho * p.g.Wo;
-    p.obs = obs; p.dy = dy; p.dw = dw;
+    p.obs = obs; p.dy = dy; p.dw = dw; p.colsum = dbias;
     return HAB_OK;
 }
 inline int build(LinearFwdProb& p, const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy,

@@ -243,11 +243,14 @@ struct ConvDgradProb {
 // ----------------------------------------------------------------------------------------------
 struct ConvWgradProb {
     static constexpr bool A_RC = false, B_RC = false;
+    static constexpr bool COLSUM_B = true;
     int M, N, K;
     ConvGeom g;
     const float* x;
     const float* dy;
-    float* dw;  // OIHW
+    float* dw;      // OIHW
+    float* colsum;  // bias gradient [Cout] (sum of dY over all pixels), or null
+    HAB_HD void store_colsum(int j, float v) const { colsum[j] = v; }
     struct ACtx { int kh, kw, ci; };
     struct BCtx { int co; };
     HAB_HD ACtx a_ctx(int i) const {
@@ -282,11 +285,14 @@ struct ConvWgradProb {
 
 struct ObsConvWgradProb {
     static constexpr bool A_RC = false, B_RC = false;
+    static constexpr bool COLSUM_B = true;
     int M, N, K;
     ConvGeom g;
     ObsView obs;
     const float* dy;
     float* dw;
+    float* colsum;  // bias gradient [Cout], or null
+    HAB_HD void store_colsum(int j, float v) const { colsum[j] = v; }
     struct ACtx { int i; };
     struct BCtx { int co; };
     HAB_HD ACtx a_ctx(int i) const { ACtx c; c.i = (i < M) ? i : -1; return c; }

@@ -49,8 +49,8 @@ SIGNATURES = {
     "hab_conv2d_fwd": (c_int, [vp, vp, vp, vp] + [c_int] * 10 + [vp, c_size_t, vp]),
     "hab_obs_conv2d_fwd": (c_int, [vp, vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
     "hab_conv2d_dgrad": (c_int, [vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
-    "hab_conv2d_wgrad": (c_int, [vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
-    "hab_obs_conv2d_wgrad": (c_int, [vp, vp, vp, vp, vp] + [c_int] * 8 + [vp, c_size_t, vp]),
+    "hab_conv2d_wgrad": (c_int, [vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
+    "hab_obs_conv2d_wgrad": (c_int, [vp, vp, vp, vp, vp, vp] + [c_int] * 8 + [vp, c_size_t, vp]),
     "hab_linear_fwd": (c_int, [vp, c_int, vp, c_int, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, c_size_t, vp]),
     "hab_linear_dgrad": (c_int, [vp, c_int, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp, c_size_t, vp]),
     "hab_linear_wgrad": (c_int, [vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, c_size_t, vp]),

@@ -108,11 +108,12 @@ int hab_obs_conv2d_fwd(const uint8_t* rgb, const float* depth, const int* rows, 
 int hab_conv2d_dgrad(const float* dy, const float* w_dgrad, const float* relu_mask, const float* add, float* dx, int B,
                      int H, int W, int C, int Cout, int KH, int KW, int stride, int pad, float* ws, size_t ws_floats,
                      hipStream_t stream);
-int hab_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int C, int Cout, int KH, int KW,
-                     int stride, int pad, float* ws, size_t ws_floats, hipStream_t stream);
-int hab_obs_conv2d_wgrad(const uint8_t* rgb, const float* depth, const int* rows, const float* dy, float* dw_oihw, int B,
-                         int H, int W, int Cout, int KH, int KW, int stride, int pad, float* ws, size_t ws_floats,
-                         hipStream_t stream);
+/* dbias (nullable): bias gradient [Cout] = column sums of dy, produced by the same launch. */
+int hab_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* dbias, int B, int H, int W, int C, int Cout,
+                     int KH, int KW, int stride, int pad, float* ws, size_t ws_floats, hipStream_t stream);
+int hab_obs_conv2d_wgrad(const uint8_t* rgb, const float* depth, const int* rows, const float* dy, float* dw_oihw,
+                         float* dbias, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                         size_t ws_floats, hipStream_t stream);
 int hab_linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N,
                    int K, int relu, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
 int hab_linear_dgrad(const float* dy, int lddy, const float* w, int ldw, const float* relu_mask, int ldmask, float* dx,

@@ -94,7 +94,7 @@ extern "C" int hc_conv2d_dgrad(const float* dy, const float* wd, const float* ma
 extern "C" int hc_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int Cout, int KH, int KW,
                                int stride, int pad) {
     ConvWgradProb p;
-    HAB_TRY(build(p, mk(B, H, W, C, Cout, KH, KW, stride, pad), x, dy, dw));
+    HAB_TRY(build(p, mk(B, H, W, C, Cout, KH, KW, stride, pad), x, dy, dw, nullptr));
     host_igemm(p);
     return 0;
 }
@@ -102,7 +102,7 @@ extern "C" int hc_obs_conv2d_wgrad(const uint8_t* rgb, const float* depth, const
                                    int H, int W, int Cout, int KH, int KW, int stride, int pad) {
     ObsView o = mkobs(rgb, depth, rows, H, W);
     ObsConvWgradProb p;
-    HAB_TRY(build(p, mk(B, H, W, o.C, Cout, KH, KW, stride, pad), o, dy, dw));
+    HAB_TRY(build(p, mk(B, H, W, o.C, Cout, KH, KW, stride, pad), o, dy, dw, nullptr));
     host_igemm(p);
     return 0;
 }

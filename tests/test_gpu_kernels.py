@@ -259,9 +259,12 @@ def test_conv_fwd_dgrad_wgrad(L, B, H, W, Cc, Cout, K, s, p, use_ws):
         ck(L.hab_conv2d_dgrad(P(dy), P(wdg), None, None, P(dx), B, H, W, Cc, Cout, K, K, s, p, P(ws), wsn, S()))
         assert torch.allclose(dx.cpu(), nhwc(x.grad), atol=2e-5, rtol=1e-4)
         dw = torch.zeros(Cout, Cc, K, K, device="cuda")
-        ck(L.hab_conv2d_wgrad(P(xh), P(dy), P(dw), B, H, W, Cc, Cout, K, K, s, p, P(ws), wsn, S()))
+        db = torch.full((Cout,), 7.0, device="cuda")
+        ck(L.hab_conv2d_wgrad(P(xh), P(dy), P(dw), P(db), B, H, W, Cc, Cout, K, K, s, p, P(ws), wsn, S()))
         scale = w.grad.abs().max().item()
         assert (dw.cpu() - w.grad).abs().max().item() <= 1e-4 * scale + 1e-5
+        db_ref = (gy * (y_ref > 0)).sum((0, 2, 3))  # fused bias gradient = column sums of dY
+        assert torch.allclose(db.cpu(), db_ref, rtol=1e-4, atol=1e-4 * db_ref.abs().max().item() + 1e-5)
 
 
 @pytest.mark.parametrize("has_rgb,has_depth,H,W,B", [(1, 1, 256, 256, 2), (0, 1, 84, 84, 4), (1, 0, 64, 96, 3)])
@@ -292,7 +295,12 @@ def test_obs_conv(L, has_rgb, has_depth, H, W, B):
     y_ref.backward(gy)
     dy = nhwc(gy * (y_ref > 0)).cuda()
     dw = torch.zeros(32, Cin, 8, 8, device="cuda")
-    ck(L.hab_obs_conv2d_wgrad(P(rg), P(dp), P(rows.cuda()), P(dy), P(dw), B, H, W, 32, 8, 8, 4, 0, P(ws), ws.numel(), S()))
+    db = torch.full((32,), 7.0, device="cuda")
+    ck(L.hab_obs_conv2d_wgrad(P(rg), P(dp), P(rows.cuda()), P(dy), P(dw), P(db), B, H, W, 32, 8, 8, 4, 0, P(ws), ws.numel(), S()))
+    assert (dw.cpu() - w.grad).abs().max().item() <= 1e-4 * w.grad.abs().max().item() + 1e-5
+    db_ref = (gy * (y_ref > 0)).sum((0, 2, 3))
+    assert torch.allclose(db.cpu(), db_ref, rtol=1e-4, atol=1e-4 * db_ref.abs().max().item() + 1e-5)
+    ck(L.hab_obs_conv2d_wgrad(P(rg), P(dp), P(rows.cuda()), P(dy), P(dw), None, B, H, W, 32, 8, 8, 4, 0, None, 0, S()))  # no ws, no bias
     assert (dw.cpu() - w.grad).abs().max().item() <= 1e-4 * w.grad.abs().max().item() + 1e-5
 
 

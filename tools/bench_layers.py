@@ -44,7 +44,7 @@ def conv_case(name, B, H, W, Cc, Cout, K, s, p, ws):
     print(f"{name:28s} fwd   {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
     t = timeit(lambda: _lib.check(L.hab_conv2d_dgrad(P(dy), P(wd), None, None, P(dx), B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S())))
     print(f"{name:28s} dgrad {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (algorithmic)")
-    t = timeit(lambda: _lib.check(L.hab_conv2d_wgrad(P(x), P(dy), P(dw), B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S())))
+    t = timeit(lambda: _lib.check(L.hab_conv2d_wgrad(P(x), P(dy), P(dw), P(b), B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S())))
     print(f"{name:28s} wgrad {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
 
 
@@ -61,7 +61,7 @@ def main():
     t = timeit(lambda: _lib.check(L.hab_obs_conv2d_fwd(P(rgb), P(depth), None, P(wf), P(b), P(y), B, H, W, 32, 8, 8, 4, 0, 1, P(ws), ws.numel(), S())))
     print(f"{'simplecnn conv1 (obs ingest)':28s} fwd   {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s  obs {B * 458752 / t / 1e6:6.1f} GB/s")
     dw = torch.empty(32, 4, 8, 8, device="cuda")
-    t = timeit(lambda: _lib.check(L.hab_obs_conv2d_wgrad(P(rgb), P(depth), None, P(y), P(dw), B, H, W, 32, 8, 8, 4, 0, P(ws), ws.numel(), S())))
+    t = timeit(lambda: _lib.check(L.hab_obs_conv2d_wgrad(P(rgb), P(depth), None, P(y), P(dw), P(b), B, H, W, 32, 8, 8, 4, 0, P(ws), ws.numel(), S())))
     print(f"{'simplecnn conv1 (obs ingest)':28s} wgrad {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
     conv_case("simplecnn conv2 4x4s2 32>64", B, 63, 63, 32, 64, 4, 2, 0, ws)
     conv_case("simplecnn conv3 3x3s1 64>32", B, 30, 30, 64, 32, 3, 1, 0, ws)
