@@ -1,0 +1,106 @@
+// engine.h -- shared definition of the policy engine object (engine.hip, engine_resnet.hip).
+#pragma once
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "heads.h"
+#include "ops.h"
+#include "problems.h"
+#include "resnet_ops.h"
+#include "../../include/habitat_amd.h"
+
+struct ParamSpec {
+    std::string name;
+    int64_t shape[4];
+    int ndim;
+    int64_t offset;  // floats, 16-byte aligned
+    int64_t numel;
+};
+
+struct Arena {
+    int64_t used = 0;
+    int64_t take(int64_t n) {
+        const int64_t o = used;
+        used += (n + 63) & ~(int64_t)63;  // 256-byte granules
+        return o;
+    }
+};
+
+struct hab_policy {
+    hab_policy_desc d;
+    std::vector<ParamSpec> params;
+    int64_t param_floats = 0, packed_floats = 0, work_floats = 0;
+    float *P = nullptr, *G = nullptr, *PK = nullptr, *WK = nullptr;
+    int64_t work_bound = 0;
+    int Cin = 0;
+    hab::ConvDesc c1, c2, c3;  // SimpleCNN geometry (B filled per call)
+    int fc_in = 0, rnn_in = 0, rnn_ld = 0, G_ = 3, L = 1;
+    // param indices
+    int i_c1w, i_c1b, i_c2w, i_c2b, i_c3w, i_c3b, i_fcw, i_fcb, i_aw, i_ab, i_cw, i_cb;
+    std::vector<int> i_wih, i_whh, i_bih, i_bhh;
+    // packed offsets
+    int64_t pk_c1f, pk_c2f, pk_c2d, pk_c3f, pk_c3d, pk_fc;
+    std::vector<int64_t> pk_whht;
+    // workspace offsets (floats)
+    int64_t w_a1, w_a2, w_a3, w_rnnin, w_da1, w_da2, w_da3, w_drnnin, w_hinit, w_cinit, w_feat_d, w_probs, w_logitsn, w_dzv,
+        w_dv, w_dfeat, w_scratch, w_ws, w_value, w_logp, w_ent, w_hmask, w_gistep, w_step_h;
+    std::vector<int64_t> w_gi, w_gates, w_hn, w_hprev, w_cprev, w_c, w_out, w_dgi, w_dgh, w_dlayer;
+    int64_t ws_floats = 0;
+    int last_B = 0, last_n = 0;
+    // ResNet policy (engine_resnet.hip)
+    struct ResNetPlan* rn = nullptr;
+    int training = 1;                                   // nn.Module.train()/eval(): RunningMeanAndVar updates only in training
+    void (*allreduce_cb)(float*, int, void*) = nullptr;  // optional in-place sum all-reduce of a small device buffer (DD-PPO RMV stats)
+    void* allreduce_ctx = nullptr;
+    int world_size = 1;
+    // probe
+    int probe_tag = -1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> probe_events;
+    size_t probe_used = 0;
+
+    float* p(int i) const { return P + params[i].offset; }
+    float* g(int i) const { return G + params[i].offset; }
+};
+
+inline int add_param(hab_policy* e, const std::string& name, std::initializer_list<int64_t> shape) {
+    ParamSpec s;
+    s.name = name;
+    s.ndim = (int)shape.size();
+    s.numel = 1;
+    int k = 0;
+    for (auto v : shape) { s.shape[k++] = v; s.numel *= v; }
+    for (; k < 4; ++k) s.shape[k] = 1;
+    s.offset = e->param_floats;
+    e->param_floats += (s.numel + 3) & ~(int64_t)3;
+    e->params.push_back(s);
+    return (int)e->params.size() - 1;
+}
+
+
+int build_resnet(hab_policy* e);
+void destroy_resnet(hab_policy* e);
+int resnet_repack(hab_policy* e, hipStream_t s);
+int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s);
+int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s);
+
+struct Probe {
+    hab_policy* e; hipStream_t s; bool on;
+    Probe(hab_policy* e_, int tag, hipStream_t s_) : e(e_), s(s_), on(e_->probe_tag == tag) {
+        if (!on) return;
+        if (e->probe_used == e->probe_events.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a); hipEventCreate(&b);
+            e->probe_events.push_back({a, b});
+        }
+        hipEventRecord(e->probe_events[e->probe_used].first, s);
+    }
+    ~Probe() {
+        if (!on) return;
+        hipEventRecord(e->probe_events[e->probe_used].second, s);
+        e->probe_used++;
+    }
+};
+

@@ -102,9 +102,10 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
     }
     const bool b_active = !B_PARTIAL || (t < BN * BK / 4);
     constexpr bool CS = ColsumB<P>::value;
-    bool do_cs = false;
-    if constexpr (CS) do_cs = (p.colsum != nullptr) && (tile_m == 0);
-    const int MP = p.M + ((CS && do_cs) ? 1 : 0);  // rows of a split-K slab (the extra row carries the column sums)
+    bool has_cs = false;
+    if constexpr (CS) has_cs = (p.colsum != nullptr);
+    const bool do_cs = has_cs && (tile_m == 0);  // only the first row of tiles accumulates the column sums
+    const int MP = p.M + (has_cs ? 1 : 0);       // rows of a split-K slab (the extra row carries the column sums)
     f32x4 cs;
     cs[0] = 0.f; cs[1] = 0.f; cs[2] = 0.f; cs[3] = 0.f;
 
