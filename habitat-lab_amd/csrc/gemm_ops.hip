@@ -6,31 +6,29 @@
 
 namespace hab {
 
-// Tile choice by output width N (= Cout / out-features): tall-skinny tiles because the policy's
-// layers have N in 32..512 and M in 1e4..1e7.
+// Tile choice by output width N (= Cout / out-features) and height M: tall-skinny tiles because the policy's
+// layers have N in 32..512 and M in 1e2..1e7.  Weight-gradient problems have small M x N and a
+// huge reduction: the 96-row tile (3 waves) avoids padding M = 288 / 576 / 1152 (3x3 taps x 32..128 channels).
 template <class P>
 static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream, int target_blocks = 1024) {
+    constexpr bool WG = !P::A_RC && !P::B_RC && AKv<P>::value == 4;  // weight-gradient form
     if (p.N <= 32) {
-        auto pl = igemm_plan<256, 32>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
-        if (p.M <= 64) {
-            auto pl2 = igemm_plan<64, 32>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
-            return igemm_launch<P, 1, 1, 2, 1>(p, pl2, ws, stream);
+        if (p.M <= 64) return igemm_launch<P, 1, 1, 2, 1>(p, ws, ws_floats, target_blocks, stream);
+        if constexpr (WG) {
+            if (p.M % 96 == 0 || cdiv(p.M, 96) * 96 < cdiv(p.M, 256) * 256)
+                return igemm_launch<P, 1, 1, 3, 1>(p, ws, ws_floats, target_blocks, stream);
         }
-        return igemm_launch<P, 2, 1, 4, 1>(p, pl, ws, stream);
+        return igemm_launch<P, 2, 1, 4, 1>(p, ws, ws_floats, target_blocks, stream);
     } else if (p.N <= 64) {
-        if (p.M <= 64) {
-            auto pl2 = igemm_plan<64, 64>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
-            return igemm_launch<P, 1, 1, 2, 2>(p, pl2, ws, stream);
+        if (p.M <= 64) return igemm_launch<P, 1, 1, 2, 2>(p, ws, ws_floats, target_blocks, stream);
+        if constexpr (WG) {
+            if (p.M % 96 == 0 || cdiv(p.M, 96) * 96 < cdiv(p.M, 128) * 128)
+                return igemm_launch<P, 1, 2, 3, 1>(p, ws, ws_floats, target_blocks, stream);
         }
-        auto pl = igemm_plan<128, 64>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
-        return igemm_launch<P, 1, 2, 4, 1>(p, pl, ws, stream);
+        return igemm_launch<P, 1, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
     } else {
-        if (p.M <= 64) {
-            auto pl2 = igemm_plan<64, 128>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
-            return igemm_launch<P, 1, 2, 2, 2>(p, pl2, ws, stream);
-        }
-        auto pl = igemm_plan<128, 128>(p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
-        return igemm_launch<P, 2, 2, 2, 2>(p, pl, ws, stream);
+        if (p.M <= 64) return igemm_launch<P, 1, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
+        return igemm_launch<P, 2, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
     }
 }
 

@@ -4,8 +4,8 @@
 //
 // Every dense contraction on the PPO hot path is an instance: conv fwd / dgrad / wgrad as implicit
 // GEMMs over NHWC activations, Linear fwd / dgrad / wgrad, RNN input projections.  A problem type
-// `Prob` supplies the operand gathers and the epilogue; the tile machinery (LDS staging, MFMA
-// fragments, split-K) is shared.
+// `Prob` (problems.h) supplies the operand gathers and the epilogue; the tile machinery (LDS
+// staging, MFMA fragments, split-K) is shared.
 //
 // MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles/SIMD, 157 TFLOP/s chip peak).  Lane l of a
 // wave supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; D: col = l&31,
@@ -16,9 +16,18 @@
 // Operand forms (per problem, compile time):
 //   *_RC = true : operand is r-contiguous in memory  -> LDS image [rows][BK+4], ds_read_b128
 //   *_RC = false: operand is i/j-contiguous in memory -> LDS image [BK][rows+4], ds_read_b32
-// Staging is global -> registers -> LDS with the loads of tile t+1 issued before the MFMAs of
-// tile t (one barrier per K-tile).  fp32 MFMA is slow enough (1/16 of bf16) that one wave per
-// SIMD saturates it; VALU index math of the gathers hides under the 64-cycle MFMAs.
+// A gather "unit" is KV consecutive elements along the contiguous direction (KV = 4: one 16-byte
+// load; the observation-ingest problems use KV = 16: four filter taps from 12 bytes of uint8 rgb +
+// 16 bytes of depth).
+//
+// Pipeline.  The tile is SINGLE-buffered in LDS (41 KB for the 256x32 tile) so that 3-5 workgroups
+// are resident per CU: while one workgroup sits in its barriers / address math / epilogue, the MFMA
+// pipe of each SIMD is fed by the waves of the others (fp32 MFMA is 64 cycles per instruction, one
+// ready wave per SIMD saturates it).  Global loads are split into `fetch` (branch-free: clamped
+// address + validity bit, issued right after the barrier, in flight across the MFMAs of the current
+// tile) and `cvt` (zero-fill / uint8 scaling, applied when the registers are written to LDS).
+// The epilogue pre-loads per-column data (bias) once and batches the optional per-element loads
+// (residual add, ReLU mask, accumulate) four rows at a time in front of the stores.
 //
 // Block -> tile mapping is XCD-aware: blocks are dispatched round-robin over the 8 XCDs, so tile
 // ids are remapped to give each XCD (private 4 MiB L2) a contiguous run of M-tiles, which keeps the
@@ -30,9 +39,6 @@
 
 namespace hab {
 
-template <class P>
-struct IgemmLaunch;  // fwd
-
 constexpr int IGEMM_BK = 32;
 
 // Optional fused column sums of the B operand (bias gradients ride along with the weight-gradient
@@ -43,23 +49,42 @@ struct ColsumB : std::false_type {};
 template <class P>
 struct ColsumB<P, std::void_t<decltype(P::COLSUM_B)>> : std::bool_constant<P::COLSUM_B && !P::B_RC> {};
 
+// Gather-unit width along the contiguous direction of the A operand (default 4 floats).
+template <class P, class = void>
+struct AKv : std::integral_constant<int, 4> {};
+template <class P>
+struct AKv<P, std::void_t<decltype(P::A_KV)>> : std::integral_constant<int, P::A_KV> {};
+
+template <class P, int TM, int TN, int WM, int WN>
+struct IgemmCfg {
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = IGEMM_BK;
+    static constexpr int LDK = BK + 4;
+    static constexpr int KV = AKv<P>::value;
+    static constexpr int A_TILE = P::A_RC ? BM * LDK : BK * (BM + 4);
+    static constexpr int B_TILE = P::B_RC ? BN * LDK : BK * (BN + 4);
+    static constexpr int A_TOTAL = BM * BK / KV, B_TOTAL = BN * BK / 4;  // gather units per tile
+    static constexpr int A_UNITS = (A_TOTAL + NT - 1) / NT, B_UNITS = (B_TOTAL + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES = (size_t)(A_TILE + B_TILE) * sizeof(float);
+    // unit -> (row, k) decomposition must be thread-invariant in the fixed coordinate
+    static_assert(P::A_RC ? (NT % (BK / KV) == 0) : (NT % (BM / KV) == 0), "A unit mapping");
+    static_assert(P::B_RC ? (NT % (BK / 4) == 0) : (NT % (BN / 4) == 0), "B unit mapping");
+    static_assert(NT * 4 <= A_TILE + B_TILE, "column-sum fold needs NT*4 floats of LDS");
+};
+
 template <class P, int TM, int TN, int WM, int WN>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int k_per_split, float* __restrict__ partial) {
-    constexpr int NT = WM * WN * 64;
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = IGEMM_BK;
-    constexpr int LDK = BK + 4;
-    constexpr int A_LD = P::A_RC ? LDK : (BM + 4);
-    constexpr int B_LD = P::B_RC ? LDK : (BN + 4);
-    constexpr int A_TILE = P::A_RC ? BM * LDK : BK * (BM + 4);
-    constexpr int B_TILE = P::B_RC ? BN * LDK : BK * (BN + 4);
-    constexpr int A_UNITS = BM * BK / 4 / NT;
-    constexpr int B_UNITS = (BN * BK / 4 + NT - 1) / NT;
-    constexpr bool B_PARTIAL = (BN * BK / 4) < NT;  // fewer units than threads
-    static_assert(A_UNITS >= 1, "tile too small for the block");
+    using Cfg = IgemmCfg<P, TM, TN, WM, WN>;
+    constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, LDK = Cfg::LDK, KV = Cfg::KV;
+    constexpr int A_TILE = Cfg::A_TILE;
+    constexpr int A_UNITS = Cfg::A_UNITS, B_UNITS = Cfg::B_UNITS, A_TOTAL = Cfg::A_TOTAL, B_TOTAL = Cfg::B_TOTAL;
+    constexpr int AKQ = BK / KV;   // A units per row            (RC form)
+    constexpr int AIQ = BM / KV;   // A units per k-row          (IC form)
+    constexpr int BJQ = BN / 4;    // B units per k-row          (IC form)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;               // [2][A_TILE]
-    float* Bs = smem + 2 * A_TILE;  // [2][B_TILE]
+    float* As = smem;
+    float* Bs = smem + A_TILE;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -82,82 +107,69 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
     const int k_end = min(p.K, k_begin + k_per_split);
     const int ntk = max(0, cdiv(k_end - k_begin, BK));
 
-    // ---- staging contexts ----
-    // RC: unit u = t + NT*j -> row = u / 8, kq = u % 8 (fixed per thread).  IC: r = u / (rows/4), i4 fixed.
+    // ---- staging contexts: unit u = t + NT*j ----
+    //   RC: row = u / AKQ, k-offset = (u % AKQ) * KV   (fixed per thread)
+    //   IC: k-row = u / AIQ, i-offset = (u % AIQ) * KV (fixed per thread)
     typename P::ACtx actx[A_UNITS];
     typename P::BCtx bctx[B_UNITS];
-    if constexpr (P::A_RC) {
 #pragma unroll
-        for (int j = 0; j < A_UNITS; ++j) actx[j] = p.a_ctx(m0 + (t >> 3) + (NT >> 3) * j);
-    } else {
-#pragma unroll
-        for (int j = 0; j < A_UNITS; ++j) actx[j] = p.a_ctx(m0 + (t % (BM / 4)) * 4);
+    for (int j = 0; j < A_UNITS; ++j) {
+        const int u = t + NT * j;
+        actx[j] = P::A_RC ? p.a_ctx(m0 + u / AKQ) : p.a_ctx(m0 + (u % AIQ) * KV);
     }
-    if constexpr (P::B_RC) {
 #pragma unroll
-        for (int j = 0; j < B_UNITS; ++j) bctx[j] = p.b_ctx(n0 + (t >> 3) + (NT >> 3) * j);
-    } else {
-#pragma unroll
-        for (int j = 0; j < B_UNITS; ++j) bctx[j] = p.b_ctx(n0 + (t % (BN / 4)) * 4);
+    for (int j = 0; j < B_UNITS; ++j) {
+        const int u = t + NT * j;
+        bctx[j] = P::B_RC ? p.b_ctx(n0 + (u >> 3)) : p.b_ctx(n0 + (u % BJQ) * 4);
     }
-    const bool b_active = !B_PARTIAL || (t < BN * BK / 4);
     constexpr bool CS = ColsumB<P>::value;
     bool has_cs = false;
     if constexpr (CS) has_cs = (p.colsum != nullptr);
     const bool do_cs = has_cs && (tile_m == 0);  // only the first row of tiles accumulates the column sums
     const int MP = p.M + (has_cs ? 1 : 0);       // rows of a split-K slab (the extra row carries the column sums)
-    f32x4 cs;
-    cs[0] = 0.f; cs[1] = 0.f; cs[2] = 0.f; cs[3] = 0.f;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 areg[A_UNITS], breg[B_UNITS];
-    auto load_tile = [&](int kt) {
-        const int k0 = k_begin + kt * BK;
-        if constexpr (P::A_RC) {
-            const int k = k0 + (t & 7) * 4;
+    typename P::ARaw araw[A_UNITS];
+    typename P::BRaw braw[B_UNITS];
+    auto a_k = [&](int kt, int j) {  // k coordinate of A unit j in K-tile kt
+        const int u = t + NT * j;
+        return k_begin + kt * BK + (P::A_RC ? (u % AKQ) * KV : u / AIQ);
+    };
+    auto b_k = [&](int kt, int j) {
+        const int u = t + NT * j;
+        return k_begin + kt * BK + (P::B_RC ? (u & 7) * 4 : u / BJQ);
+    };
+    auto fetch = [&](int kt) {
+        const typename P::KCtx kc = p.k_ctx(k_begin + kt * BK, k_end);  // block-uniform
 #pragma unroll
-            for (int j = 0; j < A_UNITS; ++j) areg[j] = p.a_load(actx[j], k, k_end);
-        } else {
+        for (int j = 0; j < A_UNITS; ++j)
+            if (A_TOTAL % NT == 0 || t + NT * j < A_TOTAL) araw[j] = p.a_fetch(actx[j], kc, a_k(kt, j), k_end);
 #pragma unroll
-            for (int j = 0; j < A_UNITS; ++j) areg[j] = p.a_load(actx[j], k0 + t / (BM / 4) + (NT / (BM / 4)) * j, k_end);
-        }
-        if (b_active) {
-            if constexpr (P::B_RC) {
-                const int k = k0 + (t & 7) * 4;
+        for (int j = 0; j < B_UNITS; ++j)
+            if (B_TOTAL % NT == 0 || t + NT * j < B_TOTAL) braw[j] = p.b_fetch(bctx[j], kc, b_k(kt, j), k_end);
+    };
+    auto stage = [&](int kt) {  // registers -> LDS (zero fill / conversion applied here)
 #pragma unroll
-                for (int j = 0; j < B_UNITS; ++j) breg[j] = p.b_load(bctx[j], k, k_end);
-            } else {
+        for (int j = 0; j < A_UNITS; ++j) {
+            const int u = t + NT * j;
+            if (A_TOTAL % NT == 0 || u < A_TOTAL) {
+                f32x4 v[KV / 4];
+                p.a_cvt(actx[j], araw[j], a_k(kt, j), k_end, v);
+                float* dst = P::A_RC ? As + (u / AKQ) * LDK + (u % AKQ) * KV : As + (u / AIQ) * (BM + 4) + (u % AIQ) * KV;
 #pragma unroll
-                for (int j = 0; j < B_UNITS; ++j) breg[j] = p.b_load(bctx[j], k0 + t / (BN / 4) + (NT / (BN / 4)) * j, k_end);
-                if constexpr (CS) {
-                    if (do_cs) {
-#pragma unroll
-                        for (int j = 0; j < B_UNITS; ++j) cs += breg[j];
-                    }
-                }
+                for (int q = 0; q < KV / 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = v[q];
             }
         }
-    };
-    auto store_tile = [&](int buf) {
-        float* a = As + buf * A_TILE;
-        float* b = Bs + buf * B_TILE;
-        if constexpr (P::A_RC) {
 #pragma unroll
-            for (int j = 0; j < A_UNITS; ++j)
-                *reinterpret_cast<f32x4*>(a + ((t >> 3) + (NT >> 3) * j) * LDK + (t & 7) * 4) = areg[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < A_UNITS; ++j)
-                *reinterpret_cast<f32x4*>(a + (t / (BM / 4) + (NT / (BM / 4)) * j) * (BM + 4) + (t % (BM / 4)) * 4) = areg[j];
-        }
-        if (b_active) {
-            if constexpr (P::B_RC) {
-#pragma unroll
-                for (int j = 0; j < B_UNITS; ++j)
-                    *reinterpret_cast<f32x4*>(b + ((t >> 3) + (NT >> 3) * j) * LDK + (t & 7) * 4) = breg[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < B_UNITS; ++j)
-                    *reinterpret_cast<f32x4*>(b + (t / (BN / 4) + (NT / (BN / 4)) * j) * (BN + 4) + (t % (BN / 4)) * 4) = breg[j];
+        for (int j = 0; j < B_UNITS; ++j) {
+            const int u = t + NT * j;
+            if (B_TOTAL % NT == 0 || u < B_TOTAL) {
+                const f32x4 v = p.b_cvt(braw[j]);
+                float* dst = P::B_RC ? Bs + (u >> 3) * LDK + (u & 7) * 4 : Bs + (u / BJQ) * (BN + 4) + (u % BJQ) * 4;
+                *reinterpret_cast<f32x4*>(dst) = v;
+                if constexpr (CS) {
+                    if (do_cs) cs += v;
+                }
             }
         }
     };
@@ -170,17 +182,11 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.0f;
 
-    if (ntk > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
-
+    if (ntk > 0) fetch(0);
     for (int kt = 0; kt < ntk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ntk) load_tile(kt + 1);
-        const float* a = As + buf * A_TILE;
-        const float* b = Bs + buf * B_TILE;
+        stage(kt);
+        __syncthreads();
+        if (kt + 1 < ntk) fetch(kt + 1);
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
             f32x4 af[TM], bf[TN];
@@ -188,20 +194,20 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
             for (int i = 0; i < TM; ++i) {
                 const int row = (wm * TM + i) * 32 + li;
                 if constexpr (P::A_RC) {
-                    af[i] = *reinterpret_cast<const f32x4*>(a + row * LDK + c * 8 + hi * 4);
+                    af[i] = *reinterpret_cast<const f32x4*>(As + row * LDK + c * 8 + hi * 4);
                 } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) af[i][s] = a[(c * 8 + hi * 4 + s) * (BM + 4) + row];
+                    for (int s = 0; s < 4; ++s) af[i][s] = As[(c * 8 + hi * 4 + s) * (BM + 4) + row];
                 }
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = (wn * TN + j) * 32 + li;
                 if constexpr (P::B_RC) {
-                    bf[j] = *reinterpret_cast<const f32x4*>(b + col * LDK + c * 8 + hi * 4);
+                    bf[j] = *reinterpret_cast<const f32x4*>(Bs + col * LDK + c * 8 + hi * 4);
                 } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) bf[j][s] = b[(c * 8 + hi * 4 + s) * (BN + 4) + col];
+                    for (int s = 0; s < 4; ++s) bf[j][s] = Bs[(c * 8 + hi * 4 + s) * (BN + 4) + col];
                 }
             }
 #pragma unroll
@@ -212,7 +218,6 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < ntk) store_tile(buf ^ 1);
         __syncthreads();
     }
 
@@ -224,9 +229,9 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
             *reinterpret_cast<f32x4*>(red + t * 4) = cs;
             __syncthreads();
             if (t < BN && n0 + t < p.N) {
-                constexpr int GR = BN / 4;  // threads t, t+GR, t+2GR, ... hold the same 4 columns
+                // thread q holds the columns (q % BJQ)*4 .. +3  (unit mapping of the IC form)
                 float s = 0.f;
-                for (int q = (t >> 2); q < NT; q += GR) s += red[q * 4 + (t & 3)];
+                for (int q = (t >> 2); q < NT; q += BJQ) s += red[q * 4 + (t & 3)];
                 if (split)
                     partial[((size_t)kz * MP + p.M) * p.N + n0 + t] = s;
                 else
@@ -234,21 +239,39 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
             }
         }
     }
+    if (split) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+                    if (row < p.M && col < p.N) partial[((size_t)kz * MP + row) * p.N + col] = acc[i][j][v];
+                }
+            }
+        return;
+    }
+    typename P::EpiCol ecol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) ecol[j] = p.epi_col(n0 + (wn * TN + j) * 32 + li);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + li;
+        for (int g = 0; g < 4; ++g) {  // four rows at a time: optional loads first, then the stores
+            typename P::EpiRow erow[4];
+            typename P::EpiAux eaux[4][TN];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
-                if (row < p.M && col < p.N) {
-                    if (split)
-                        partial[((size_t)kz * MP + row) * p.N + col] = acc[i][j][v];
-                    else
-                        p.store(row, col, acc[i][j][v]);
-                }
+            for (int q = 0; q < 4; ++q) {
+                erow[q] = p.epi_row(m0 + (wm * TM + i) * 32 + q + 8 * g + 4 * hi);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) eaux[q][j] = p.epi_fetch(erow[q], ecol[j]);
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) p.epi_store(erow[q], ecol[j], eaux[q][j], acc[i][j][g * 4 + q]);
         }
 }
 
@@ -276,8 +299,7 @@ struct IgemmPlan {
 };
 
 // Chooses a split-K factor so that the launch has roughly >= `target_blocks` workgroups.
-template <int BM, int BN>
-inline IgemmPlan igemm_plan(int M, int N, int K, int target_blocks, int max_splits, size_t max_partial_floats) {
+inline IgemmPlan igemm_plan(int BM, int BN, int M, int N, int K, int target_blocks, int max_splits, size_t max_partial_floats) {
     IgemmPlan pl;
     const long long tiles = (long long)cdiv(M, BM) * cdiv(N, BN);
     int splits = 1;
@@ -294,27 +316,25 @@ inline IgemmPlan igemm_plan(int M, int N, int K, int target_blocks, int max_spli
 }
 
 template <class P, int TM, int TN, int WM, int WN>
-inline int igemm_launch(const P& p, const IgemmPlan& pl, float* partial, hipStream_t stream) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = IGEMM_BK;
-    constexpr int A_TILE = P::A_RC ? BM * (BK + 4) : BK * (BM + 4);
-    constexpr int B_TILE = P::B_RC ? BN * (BK + 4) : BK * (BN + 4);
-    constexpr size_t LDS = (size_t)2 * (A_TILE + B_TILE) * sizeof(float);
+inline int igemm_launch(const P& p, float* ws, size_t ws_floats, int target_blocks, hipStream_t stream) {
+    using Cfg = IgemmCfg<P, TM, TN, WM, WN>;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return HAB_ERR_ARG;
-    if (pl.splits > 1 && !partial) return HAB_ERR_ARG;
+    const IgemmPlan pl = igemm_plan(Cfg::BM, Cfg::BN, p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
     auto kern = igemm_kernel<P, TM, TN, WM, WN>;
     static bool attr_set = false;
-    if (!attr_set && LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)Cfg::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), 1, pl.splits);
-    kern<<<grid, WM * WN * 64, LDS, stream>>>(p, pl.k_per_split, partial);
+    dim3 grid(cdiv(p.M, Cfg::BM) * cdiv(p.N, Cfg::BN), 1, pl.splits);
+    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, pl.k_per_split, ws);
     HAB_LAUNCH_CHECK();
     if (pl.splits > 1) {
         int blocks = (int)cdivl((long long)(p.M + 1) * p.N, 256);
         if (blocks > 4096) blocks = 4096;
-        igemm_splitk_reduce_kernel<P><<<blocks, 256, 0, stream>>>(p, partial, pl.splits);
+        igemm_splitk_reduce_kernel<P><<<blocks, 256, 0, stream>>>(p, ws, pl.splits);
         HAB_LAUNCH_CHECK();
     }
     return HAB_OK;

@@ -23,6 +23,13 @@ inline int check_conv(const ConvDesc& d) {
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// Conditions of the 4-tap observation gather (problems.h): four horizontally adjacent taps start on a
+// pixel index that is a multiple of 4, so their rgb bytes are 3 aligned dwords and their depth one aligned float4.
+inline int obs_quad_ok(const ConvDesc& d, const ObsView& obs) {
+    return obs.rgb && obs.depth && obs.C == 4 && d.KW % 4 == 0 && d.stride % 4 == 0 && d.pad == 0 && d.W % 4 == 0 &&
+           ((uintptr_t)obs.rgb & 3) == 0 && aligned16(obs.depth);
+}
+
 inline int build(ConvFwdProb& p, const ConvDesc& d, const float* x, const float* wf, const float* bias, float* y, int relu) {
     HAB_TRY(check_conv(d));
     if (d.C % 4) return HAB_ERR_UNSUPPORTED;
@@ -33,10 +40,11 @@ inline int build(ConvFwdProb& p, const ConvDesc& d, const float* x, const float*
 }
 inline int build(ObsConvFwdProb& p, const ConvDesc& d, const ObsView& obs, const float* wf, const float* bias, float* y, int relu) {
     HAB_TRY(check_conv(d));
-    if (d.C != obs.C || (d.KH * d.KW * d.C) % 4) return HAB_ERR_UNSUPPORTED;
+    if (d.C != obs.C) return HAB_ERR_UNSUPPORTED;
     p.g = make_geom(d);
     p.M = d.B * p.g.Ho * p.g.Wo; p.N = d.Cout; p.K = d.KH * d.KW * d.C;
     p.obs = obs; p.w = wf; p.bias = bias; p.y = y; p.relu = relu;
+    p.quad = obs_quad_ok(d, obs);
     return HAB_OK;
 }
 inline int build(ConvDgradProb& p, const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add,
@@ -59,10 +67,11 @@ inline int build(ConvWgradProb& p, const ConvDesc& d, const float* x, const floa
 }
 inline int build(ObsConvWgradProb& p, const ConvDesc& d, const ObsView& obs, const float* dy, float* dw, float* dbias = nullptr) {
     HAB_TRY(check_conv(d));
-    if (d.C != obs.C || d.Cout % 4 || (d.KH * d.KW * d.C) % 4) return HAB_ERR_UNSUPPORTED;
+    if (d.C != obs.C || d.Cout % 4) return HAB_ERR_UNSUPPORTED;
     p.g = make_geom(d);
     p.M = d.KH * d.KW * d.C; p.N = d.Cout; p.K = d.B * p.g.Ho * p.g.Wo;
     p.obs = obs; p.dy = dy; p.dw = dw; p.colsum = dbias;
+    p.quad = obs_quad_ok(d, obs);
     return HAB_OK;
 }
 inline int build(LinearFwdProb& p, const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy,

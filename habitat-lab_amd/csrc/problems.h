@@ -2,10 +2,22 @@
 // the igemm kernel (igemm.h).  Activations are NHWC fp32 (channels % 4 == 0 so a 16-byte gather never
 // straddles a filter tap); convolution weights are consumed from packed copies
 //   Wf[co][(kh,kw,ci)]  (forward)      Wd[ci][(kh,kw,co)]  (data gradient)
-// produced by repack.hip from the reference-layout (OIHW) master parameters; weight gradients are
-// scattered straight back into OIHW.  All functors are __host__ __device__ so that
+// produced by repack_conv (gemm_ops.hip) from the reference-layout (OIHW) master parameters; weight
+// gradients are scattered straight back into OIHW.  All functors are __host__ __device__ so that
 // tests/hostcheck can execute the very same index math on the CPU against the oracle.
+//
+// Interface of a problem type P (see igemm.h for how the kernel drives it):
+//   M, N, K; A_RC, B_RC (operand forms); optional A_KV (gather-unit width of A, default 4)
+//   KCtx k_ctx(k0, k_end)                       per K-tile, block-uniform
+//   ACtx a_ctx(i) / BCtx b_ctx(j)               per gather unit, once per tile
+//   ARaw a_fetch(ACtx, KCtx, k, k_end)          BRANCH-FREE global loads from a clamped address + validity
+//   void a_cvt(ACtx, ARaw, k, k_end, f32x4*)    zero fill / conversion, applied when staging to LDS
+//   BRaw b_fetch(BCtx, KCtx, k, k_end); f32x4 b_cvt(BRaw)
+//   EpiCol epi_col(n); EpiRow epi_row(m); EpiAux epi_fetch(row, col); epi_store(row, col, aux, v)
+//   store(m, n, v)                              = the four epilogue pieces in sequence
 #pragma once
+#include <math.h>
+
 #include "hab_common.h"
 
 namespace hab {
@@ -18,6 +30,26 @@ HAB_HD f32x4 zero4() {
     return z;
 }
 HAB_HD f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+struct Raw4 { f32x4 v; int ok; };
+HAB_HD f32x4 sel4(const Raw4& r) { return r.ok ? r.v : zero4(); }
+struct NoCtx {};
+struct NoAux {};
+
+constexpr int HAB_FAR = -(1 << 28);  // coordinate that fails every bounds test
+
+#define HAB_GENERIC_STORE                                    \
+    HAB_HD void store(int m, int n, float v) const {         \
+        const EpiRow r__ = epi_row(m);                       \
+        const EpiCol c__ = epi_col(n);                       \
+        epi_store(r__, c__, epi_fetch(r__, c__), v);         \
+    }
+#define HAB_NO_KCTX                                          \
+    using KCtx = NoCtx;                                      \
+    HAB_HD KCtx k_ctx(int, int) const { return KCtx(); }
+#define HAB_PLAIN_CVT                                                                                        \
+    HAB_HD void a_cvt(const ACtx&, const ARaw& r, int, int, f32x4* out) const { out[0] = sel4(r); }          \
+    HAB_HD f32x4 b_cvt(const BRaw& r) const { return sel4(r); }
 
 struct ConvGeom {
     int B, H, W, C;       // input  NHWC
@@ -32,9 +64,19 @@ struct ConvGeom {
     }
 };
 
+// A weight matrix row-major [rows][K] consumed as the r-contiguous B operand.
+struct WRowCtx { const float* row; int ok; };
+
+// Epilogue pieces shared by the NHWC-output problems.
+struct ColN { int n, ok; float bias; };
+struct RowBase { size_t base; int ok; };
+
 // ----------------------------------------------------------------------------------------------
 // Convolution forward: Y[(img,ho,wo)][co] = sum_{kh,kw,ci} X[img, ho*s-p+kh, wo*s-p+kw, ci] * Wf[co][(kh,kw,ci)]
 // Epilogue: + bias[co], optional ReLU.   (simple_cnn.py:68-93, resnet.py:19-34,207-219)
+// Optional loader-side affine + ReLU per (image, channel): x' = relu?(x * ss[img][ci][0] + ss[img][ci][1]) -- the
+// GroupNorm-apply of the producing layer fused into this conv's gather (resnet.py:51-57); zero padding
+// stays zero (it is applied to in-bounds taps only).
 // ----------------------------------------------------------------------------------------------
 struct ConvFwdProb {
     static constexpr bool A_RC = true, B_RC = true;
@@ -45,11 +87,14 @@ struct ConvFwdProb {
     const float* bias;
     float* y;
     int relu;
+    HAB_NO_KCTX
     struct ACtx { const float* base; int h0, w0; };
-    struct BCtx { const float* row; };
+    using BCtx = WRowCtx;
+    using ARaw = Raw4;
+    using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int m) const {
         ACtx c;
-        if (m >= M) { c.base = nullptr; c.h0 = 0; c.w0 = 0; return c; }
+        if (m >= M) { c.base = x; c.h0 = HAB_FAR; c.w0 = 0; return c; }
         int img, rem, ho, wo;
         g.dHoWo.divmod(m, img, rem);
         g.dWo.divmod(rem, ho, wo);
@@ -58,25 +103,38 @@ struct ConvFwdProb {
         c.w0 = wo * g.stride - g.pad;
         return c;
     }
-    HAB_HD f32x4 a_load(const ACtx& c, int k, int k_end) const {
-        if (!c.base || k >= k_end) return zero4();
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int k, int k_end) const {
         int tap, ci, kh, kw;
         g.dC.divmod(k, tap, ci);
         g.dKW.divmod(tap, kh, kw);
         const int h = c.h0 + kh, w_ = c.w0 + kw;
-        if ((unsigned)h >= (unsigned)g.H || (unsigned)w_ >= (unsigned)g.W) return zero4();
-        return ld4(c.base + ((size_t)h * g.W + w_) * g.C + ci);
+        ARaw r;
+        r.ok = (k < k_end) & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
+        const int off = r.ok ? (h * g.W + w_) * g.C + ci : 0;
+        r.v = ld4(c.base + off);
+        return r;
     }
-    HAB_HD BCtx b_ctx(int n) const { BCtx c; c.row = (n < N) ? w + (size_t)n * K : nullptr; return c; }
-    HAB_HD f32x4 b_load(const BCtx& c, int k, int k_end) const {
-        if (!c.row || k >= k_end) return zero4();
-        return ld4(c.row + k);
+    HAB_HD BCtx b_ctx(int n) const { BCtx c; c.ok = n < N; c.row = c.ok ? w + (size_t)n * K : w; return c; }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int k, int k_end) const {
+        BRaw r;
+        r.ok = c.ok & (k < k_end);
+        r.v = ld4(c.row + (r.ok ? k : 0));
+        return r;
     }
-    HAB_HD void store(int m, int n, float v) const {
-        if (bias) v += bias[n];
+    HAB_PLAIN_CVT
+    using EpiCol = ColN;
+    using EpiRow = RowBase;
+    using EpiAux = NoAux;
+    HAB_HD EpiCol epi_col(int n) const { EpiCol c; c.n = n; c.ok = n < N; c.bias = (bias && c.ok) ? bias[n] : 0.f; return c; }
+    HAB_HD EpiRow epi_row(int m) const { EpiRow r; r.ok = m < M; r.base = (size_t)m * N; return r; }
+    HAB_HD EpiAux epi_fetch(const EpiRow&, const EpiCol&) const { return EpiAux(); }
+    HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux&, float v) const {
+        if (!(r.ok & c.ok)) return;
+        v += c.bias;
         if (relu) v = v > 0.f ? v : 0.f;
-        y[(size_t)m * N + n] = v;
+        y[r.base + c.n] = v;
     }
+    HAB_GENERIC_STORE
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -84,7 +142,19 @@ struct ConvFwdProb {
 // fp32 NHWC are read in place from the rollout arena (frame -> arena row through `rows`), no
 // NCHW / float copy of the observation is ever materialised.  (simple_cnn.py:139-156,68-74)
 // Channel order: rgb (3) then depth (1).  CIN = n_rgb + n_depth in {1,3,4}.
+// Gather unit = 16 k-elements.  Fast path (`quad`: C == 4, KW % 4 == 0, stride % 4 == 0, pad == 0,
+// W % 4 == 0): the unit is four horizontally adjacent taps = 12 aligned bytes of rgb (3 dwords) +
+// 16 aligned bytes of depth.  Otherwise every element is gathered on its own (small configs only).
 // ----------------------------------------------------------------------------------------------
+// x / 255.0f for integer x in [0, 255]: multiply by the reciprocal + one Newton step; equal to the IEEE
+// division for all 256 inputs (checked exhaustively in tests/test_hostcheck.py).
+HAB_HD float div255(float x) {
+    const float rcp = 1.0f / 255.0f;
+    const float q = x * rcp;
+    const float r = fmaf(-q, 255.0f, x);
+    return fmaf(r, rcp, q);
+}
+
 struct ObsView {
     const uint8_t* rgb;   // [rows][H][W][3] or null
     const float* depth;   // [rows][H][W][1] or null
@@ -92,20 +162,40 @@ struct ObsView {
     int H, W, C;          // C = 3*(rgb!=0) + (depth!=0)
     HAB_HD float get(int srow, int h, int w, int c) const {
         const size_t pix = ((size_t)srow * H + h) * W + w;
-        if (rgb && c < 3) return (float)rgb[pix * 3 + c] / 255.0f;
+        if (rgb && c < 3) return div255((float)rgb[pix * 3 + c]);
         return depth[pix];
     }
-    HAB_HD f32x4 get4_rgbd(int srow, int h, int w) const {  // C == 4 fast path
-        const size_t pix = ((size_t)srow * H + h) * W + w;
-        const uint8_t* p = rgb + pix * 3;
-        f32x4 r;
-        r[0] = (float)p[0] / 255.0f; r[1] = (float)p[1] / 255.0f; r[2] = (float)p[2] / 255.0f; r[3] = depth[pix];
-        return r;
-    }
+    HAB_HD int srow(int img) const { return rows ? rows[img] : img; }
 };
+
+struct ObsRaw { uint32_t d0, d1, d2; f32x4 dep; int ok; };  // ok: 1 valid quad, 0 zero, -1 slow path
+
+HAB_HD void obs_quad_cvt(const ObsRaw& r, f32x4* out) {
+    if (!r.ok) { out[0] = zero4(); out[1] = zero4(); out[2] = zero4(); out[3] = zero4(); return; }
+    const uint32_t d[3] = {r.d0, r.d1, r.d2};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int i = 3 * q + c;
+            out[q][c] = div255((float)((d[i >> 2] >> (8 * (i & 3))) & 0xffu));
+        }
+        out[q][3] = r.dep[q];
+    }
+}
+HAB_HD ObsRaw obs_quad_fetch(const ObsView& obs, int srow, int h, int w, int ok) {
+    ObsRaw r;
+    r.ok = ok;
+    const size_t pix = ok ? ((size_t)srow * obs.H + h) * obs.W + w : 0;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(obs.rgb + pix * 3);
+    r.d0 = p[0]; r.d1 = p[1]; r.d2 = p[2];
+    r.dep = ld4(obs.depth + pix);
+    return r;
+}
 
 struct ObsConvFwdProb {
     static constexpr bool A_RC = true, B_RC = true;
+    static constexpr int A_KV = 16;
     int M, N, K;
     ConvGeom g;  // g.C = obs.C
     ObsView obs;
@@ -113,50 +203,78 @@ struct ObsConvFwdProb {
     const float* bias;
     float* y;
     int relu;
+    int quad;
+    HAB_NO_KCTX
     struct ACtx { int srow, h0, w0; };
-    struct BCtx { const float* row; };
+    using BCtx = WRowCtx;
+    using ARaw = ObsRaw;
+    using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int m) const {
         ACtx c;
-        if (m >= M) { c.srow = -1; c.h0 = 0; c.w0 = 0; return c; }
+        if (m >= M) { c.srow = 0; c.h0 = HAB_FAR; c.w0 = 0; return c; }
         int img, rem, ho, wo;
         g.dHoWo.divmod(m, img, rem);
         g.dWo.divmod(rem, ho, wo);
-        c.srow = obs.rows ? obs.rows[img] : img;
+        c.srow = obs.srow(img);
         c.h0 = ho * g.stride - g.pad;
         c.w0 = wo * g.stride - g.pad;
         return c;
     }
-    HAB_HD f32x4 a_load(const ACtx& c, int k, int k_end) const {
-        if (c.srow < 0 || k >= k_end) return zero4();
-        if (g.C == 4) {
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int k, int k_end) const {
+        if (quad) {
             int kh, kw;
             g.dKW.divmod(k >> 2, kh, kw);
             const int h = c.h0 + kh, w_ = c.w0 + kw;
-            if ((unsigned)h >= (unsigned)g.H || (unsigned)w_ >= (unsigned)g.W) return zero4();
-            return obs.get4_rgbd(c.srow, h, w_);
+            const int ok = (k < k_end) & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
+            return obs_quad_fetch(obs, c.srow, h, w_, ok);
         }
-        f32x4 r = zero4();
-        for (int e = 0; e < 4; ++e) {
+        ARaw r;
+        r.d0 = r.d1 = r.d2 = 0; r.dep = zero4(); r.ok = -1;
+        return r;
+    }
+    HAB_HD void a_cvt(const ACtx& c, const ARaw& r, int k, int k_end, f32x4* out) const {
+        if (r.ok >= 0) { obs_quad_cvt(r, out); return; }
+        for (int e = 0; e < 16; ++e) {  // slow path: element-wise gather
             const int kk = k + e;
-            if (kk >= k_end) break;
-            int tap, ci, kh, kw;
-            g.dC.divmod(kk, tap, ci);
-            g.dKW.divmod(tap, kh, kw);
-            const int h = c.h0 + kh, w_ = c.w0 + kw;
-            if ((unsigned)h < (unsigned)g.H && (unsigned)w_ < (unsigned)g.W) r[e] = obs.get(c.srow, h, w_, ci);
+            float v = 0.f;
+            if (kk < k_end && c.h0 != HAB_FAR) {
+                int tap, ci, kh, kw;
+                g.dC.divmod(kk, tap, ci);
+                g.dKW.divmod(tap, kh, kw);
+                const int h = c.h0 + kh, w_ = c.w0 + kw;
+                if ((unsigned)h < (unsigned)g.H && (unsigned)w_ < (unsigned)g.W) v = obs.get(c.srow, h, w_, ci);
+            }
+            out[e >> 2][e & 3] = v;
+        }
+    }
+    HAB_HD BCtx b_ctx(int n) const { BCtx c; c.ok = n < N; c.row = c.ok ? w + (size_t)n * K : w; return c; }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int k, int k_end) const {
+        BRaw r;
+        if ((K & 3) == 0) {
+            r.ok = c.ok & (k < k_end);
+            r.v = ld4(c.row + (r.ok ? k : 0));
+        } else {  // K = KH*KW*C not a multiple of 4 (C in {1,3} with odd taps): scalar gathers
+            r.ok = 1;
+            r.v = zero4();
+            for (int e = 0; e < 4; ++e)
+                if (c.ok && k + e < k_end) r.v[e] = c.row[k + e];
         }
         return r;
     }
-    HAB_HD BCtx b_ctx(int n) const { BCtx c; c.row = (n < N) ? w + (size_t)n * K : nullptr; return c; }
-    HAB_HD f32x4 b_load(const BCtx& c, int k, int k_end) const {
-        if (!c.row || k >= k_end) return zero4();
-        return ld4(c.row + k);
-    }
-    HAB_HD void store(int m, int n, float v) const {
-        if (bias) v += bias[n];
+    HAB_HD f32x4 b_cvt(const BRaw& r) const { return sel4(r); }
+    using EpiCol = ColN;
+    using EpiRow = RowBase;
+    using EpiAux = NoAux;
+    HAB_HD EpiCol epi_col(int n) const { EpiCol c; c.n = n; c.ok = n < N; c.bias = (bias && c.ok) ? bias[n] : 0.f; return c; }
+    HAB_HD EpiRow epi_row(int m) const { EpiRow r; r.ok = m < M; r.base = (size_t)m * N; return r; }
+    HAB_HD EpiAux epi_fetch(const EpiRow&, const EpiCol&) const { return EpiAux(); }
+    HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux&, float v) const {
+        if (!(r.ok & c.ok)) return;
+        v += c.bias;
         if (relu) v = v > 0.f ? v : 0.f;
-        y[(size_t)m * N + n] = v;
+        y[r.base + c.n] = v;
     }
+    HAB_GENERIC_STORE
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -195,11 +313,14 @@ struct ConvDgradProb {
         M = g.B * Hc * Wc; N = g.C; K = KHs * KWs * g.Cout;
         dHcWc = FastDiv(Hc * Wc > 0 ? Hc * Wc : 1); dWc = FastDiv(Wc > 0 ? Wc : 1); dKWs = FastDiv(KWs > 0 ? KWs : 1);
     }
+    HAB_NO_KCTX
     struct ACtx { const float* base; int hq, wq; };  // hq = (h + pad - ph) / s
-    struct BCtx { const float* row; };
+    using BCtx = WRowCtx;
+    using ARaw = Raw4;
+    using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int m) const {
         ACtx c;
-        if (m >= M) { c.base = nullptr; c.hq = 0; c.wq = 0; return c; }
+        if (m >= M) { c.base = dy; c.hq = HAB_FAR; c.wq = 0; return c; }
         int img, rem, hc, wc;
         dHcWc.divmod(m, img, rem);
         dWc.divmod(rem, hc, wc);
@@ -208,32 +329,56 @@ struct ConvDgradProb {
         c.wq = (w_first + wc * g.stride + g.pad - pw) / g.stride;
         return c;
     }
-    HAB_HD f32x4 a_load(const ACtx& c, int k, int k_end) const {
-        if (!c.base || k >= k_end) return zero4();
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int k, int k_end) const {
         int tap, co, a, b;
         g.dCout.divmod(k, tap, co);
         dKWs.divmod(tap, a, b);
         const int hs = c.hq - a, ws = c.wq - b;  // output row / col that tap (ph + s*a, pw + s*b) reads
-        if ((unsigned)hs >= (unsigned)g.Ho || (unsigned)ws >= (unsigned)g.Wo) return zero4();
-        return ld4(c.base + ((size_t)hs * g.Wo + ws) * g.Cout + co);
+        ARaw r;
+        r.ok = (k < k_end) & ((unsigned)hs < (unsigned)g.Ho) & ((unsigned)ws < (unsigned)g.Wo);
+        const int off = r.ok ? (hs * g.Wo + ws) * g.Cout + co : 0;
+        r.v = ld4(c.base + off);
+        return r;
     }
-    HAB_HD BCtx b_ctx(int n) const { BCtx c; c.row = (n < N) ? w + (size_t)n * Kfull : nullptr; return c; }
-    HAB_HD f32x4 b_load(const BCtx& c, int k, int k_end) const {
-        if (!c.row || k >= k_end) return zero4();
+    HAB_HD BCtx b_ctx(int n) const { BCtx c; c.ok = n < N; c.row = c.ok ? w + (size_t)n * Kfull : w; return c; }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int k, int k_end) const {
         int tap, co, a, b;
         g.dCout.divmod(k, tap, co);
         dKWs.divmod(tap, a, b);
-        return ld4(c.row + ((size_t)(ph + g.stride * a) * g.KW + (pw + g.stride * b)) * g.Cout + co);
+        BRaw r;
+        r.ok = c.ok & (k < k_end);
+        const int off = r.ok ? ((ph + g.stride * a) * g.KW + (pw + g.stride * b)) * g.Cout + co : 0;
+        r.v = ld4(c.row + off);
+        return r;
     }
-    HAB_HD void store(int m, int n, float v) const {
+    HAB_PLAIN_CVT
+    struct EpiCol { int n, ok; };
+    using EpiRow = RowBase;
+    struct EpiAux { float add, mask; };
+    HAB_HD EpiCol epi_col(int n) const { EpiCol c; c.n = n; c.ok = n < N; return c; }
+    HAB_HD EpiRow epi_row(int m) const {
+        EpiRow r;
+        r.ok = m < M;
         int img, rem, hc, wc;
-        dHcWc.divmod(m, img, rem);
+        dHcWc.divmod(r.ok ? m : 0, img, rem);
         dWc.divmod(rem, hc, wc);
-        const size_t i = ((((size_t)img * g.H) + h_first + hc * g.stride) * g.W + w_first + wc * g.stride) * N + n;
-        if (add) v += add[i];
-        if (mask && !(mask[i] > 0.f)) v = 0.f;
-        dx[i] = v;
+        r.base = ((((size_t)img * g.H) + h_first + hc * g.stride) * g.W + w_first + wc * g.stride) * N;
+        return r;
     }
+    HAB_HD EpiAux epi_fetch(const EpiRow& r, const EpiCol& c) const {
+        EpiAux a;
+        const size_t i = (r.ok & c.ok) ? r.base + c.n : 0;
+        a.add = add ? add[i] : 0.f;
+        a.mask = mask ? mask[i] : 1.f;
+        return a;
+    }
+    HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux& a, float v) const {
+        if (!(r.ok & c.ok)) return;
+        v += a.add;
+        if (!(a.mask > 0.f)) v = 0.f;
+        dx[r.base + c.n] = v;
+    }
+    HAB_GENERIC_STORE
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -241,6 +386,9 @@ struct ConvDgradProb {
 // GEMM view: i = (kh,kw,ci) (M), j = co (N), reduction r = (img,ho,wo) (K).  Both operands are
 // i/j-contiguous.  The result is scattered into the reference OIHW layout.
 // ----------------------------------------------------------------------------------------------
+struct OihwRow { int off, ok; };  // offset of (ci,kh,kw) inside one output channel's OIHW block
+struct ColOnly { int n, ok; };
+
 struct ConvWgradProb {
     static constexpr bool A_RC = false, B_RC = false;
     static constexpr bool COLSUM_B = true;
@@ -251,100 +399,192 @@ struct ConvWgradProb {
     float* dw;      // OIHW
     float* colsum;  // bias gradient [Cout] (sum of dY over all pixels), or null
     HAB_HD void store_colsum(int j, float v) const { colsum[j] = v; }
+    HAB_NO_KCTX
     struct ACtx { int kh, kw, ci; };
     struct BCtx { int co; };
+    using ARaw = Raw4;
+    using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int i) const {
         ACtx c;
-        if (i >= M) { c.kh = -1; c.kw = 0; c.ci = 0; return c; }
+        if (i >= M) { c.kh = HAB_FAR; c.kw = 0; c.ci = 0; return c; }
         int tap;
         g.dC.divmod(i, tap, c.ci);
         g.dKW.divmod(tap, c.kh, c.kw);
         return c;
     }
-    HAB_HD f32x4 a_load(const ACtx& c, int r, int k_end) const {
-        if (c.kh < 0 || r >= k_end) return zero4();
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int r, int k_end) const {
         int img, rem, ho, wo;
         g.dHoWo.divmod(r, img, rem);
         g.dWo.divmod(rem, ho, wo);
         const int h = ho * g.stride - g.pad + c.kh, w_ = wo * g.stride - g.pad + c.kw;
-        if ((unsigned)h >= (unsigned)g.H || (unsigned)w_ >= (unsigned)g.W) return zero4();
-        return ld4(x + (((size_t)img * g.H + h) * g.W + w_) * g.C + c.ci);
+        ARaw q;
+        q.ok = (r < k_end) & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
+        const size_t off = q.ok ? (((size_t)img * g.H + h) * g.W + w_) * g.C + c.ci : 0;
+        q.v = ld4(x + off);
+        return q;
     }
     HAB_HD BCtx b_ctx(int j) const { BCtx c; c.co = (j < N) ? j : -1; return c; }
-    HAB_HD f32x4 b_load(const BCtx& c, int r, int k_end) const {
-        if (c.co < 0 || r >= k_end) return zero4();
-        return ld4(dy + (size_t)r * N + c.co);
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int r, int k_end) const {
+        BRaw q;
+        q.ok = (c.co >= 0) & (r < k_end);
+        q.v = ld4(dy + (q.ok ? (size_t)r * N + c.co : 0));
+        return q;
     }
-    HAB_HD void store(int i, int j, float v) const {
+    HAB_PLAIN_CVT
+    using EpiCol = ColOnly;
+    using EpiRow = OihwRow;
+    using EpiAux = NoAux;
+    HAB_HD EpiCol epi_col(int n) const { EpiCol c; c.n = n; c.ok = n < N; return c; }
+    HAB_HD EpiRow epi_row(int i) const {
+        EpiRow r;
+        r.ok = i < M;
         int tap, ci, kh, kw;
-        g.dC.divmod(i, tap, ci);
+        g.dC.divmod(r.ok ? i : 0, tap, ci);
         g.dKW.divmod(tap, kh, kw);
-        dw[(((size_t)j * g.C + ci) * g.KH + kh) * g.KW + kw] = v;
+        r.off = (ci * g.KH + kh) * g.KW + kw;
+        return r;
     }
+    HAB_HD EpiAux epi_fetch(const EpiRow&, const EpiCol&) const { return EpiAux(); }
+    HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux&, float v) const {
+        if (!(r.ok & c.ok)) return;
+        dw[(size_t)c.n * g.C * g.KH * g.KW + r.off] = v;
+    }
+    HAB_GENERIC_STORE
 };
 
+// Weight gradient of the observation-ingest conv.  Gather unit of A = 16 consecutive i = (kh, kw..kw+3, ci)
+// at one output pixel r.  One K-tile (32 pixels) spans at most two frames when Ho*Wo >= 32, so the
+// frame -> arena row lookups are block-uniform (KCtx).
 struct ObsConvWgradProb {
     static constexpr bool A_RC = false, B_RC = false;
     static constexpr bool COLSUM_B = true;
+    static constexpr int A_KV = 16;
     int M, N, K;
     ConvGeom g;
     ObsView obs;
     const float* dy;
     float* dw;
     float* colsum;  // bias gradient [Cout], or null
+    int quad;
     HAB_HD void store_colsum(int j, float v) const { colsum[j] = v; }
-    struct ACtx { int i; };
+    struct KCtx { int img0, srow0, srow1; };
+    HAB_HD KCtx k_ctx(int k0, int) const {
+        KCtx c;
+        c.img0 = g.dHoWo.div(k0 < K ? k0 : K - 1);
+        c.srow0 = obs.srow(c.img0);
+        c.srow1 = obs.srow(c.img0 + 1 < g.B ? c.img0 + 1 : c.img0);
+        return c;
+    }
+    struct ACtx { int i, kh, kw; };
     struct BCtx { int co; };
-    HAB_HD ACtx a_ctx(int i) const { ACtx c; c.i = (i < M) ? i : -1; return c; }
-    HAB_HD f32x4 a_load(const ACtx& c, int r, int k_end) const {
-        if (c.i < 0 || r >= k_end) return zero4();
-        int img, rem, ho, wo;
-        g.dHoWo.divmod(r, img, rem);
-        g.dWo.divmod(rem, ho, wo);
-        const int srow = obs.rows ? obs.rows[img] : img;
-        const int h0 = ho * g.stride - g.pad, w0 = wo * g.stride - g.pad;
-        if (g.C == 4) {
-            int kh, kw;
-            g.dKW.divmod(c.i >> 2, kh, kw);
-            const int h = h0 + kh, w_ = w0 + kw;
-            if ((unsigned)h >= (unsigned)g.H || (unsigned)w_ >= (unsigned)g.W) return zero4();
-            return obs.get4_rgbd(srow, h, w_);
+    using ARaw = ObsRaw;
+    using BRaw = Raw4;
+    HAB_HD ACtx a_ctx(int i) const {
+        ACtx c;
+        c.i = i;
+        if (i >= M) { c.kh = HAB_FAR; c.kw = 0; return c; }
+        g.dKW.divmod(i >> 2, c.kh, c.kw);  // used by the quad path only (C == 4)
+        return c;
+    }
+    HAB_HD int srow_of(const KCtx& kc, int img) const {
+        if (g.Ho * g.Wo >= IGEMM_BK_) return img == kc.img0 ? kc.srow0 : kc.srow1;
+        return obs.srow(img < g.B ? img : g.B - 1);
+    }
+    static constexpr int IGEMM_BK_ = 32;
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx& kc, int r, int k_end) const {
+        if (quad) {
+            int img, rem, ho, wo;
+            g.dHoWo.divmod(r, img, rem);
+            g.dWo.divmod(rem, ho, wo);
+            const int h = ho * g.stride - g.pad + c.kh, w_ = wo * g.stride - g.pad + c.kw;
+            const int ok = (r < k_end) & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
+            return obs_quad_fetch(obs, srow_of(kc, img), h, w_, ok);
         }
-        f32x4 q = zero4();
-        for (int e = 0; e < 4; ++e) {
-            const int ii = c.i + e;
-            if (ii >= M) break;
-            int tap, ci, kh, kw;
-            g.dC.divmod(ii, tap, ci);
-            g.dKW.divmod(tap, kh, kw);
-            const int h = h0 + kh, w_ = w0 + kw;
-            if ((unsigned)h < (unsigned)g.H && (unsigned)w_ < (unsigned)g.W) q[e] = obs.get(srow, h, w_, ci);
-        }
+        ARaw q;
+        q.d0 = q.d1 = q.d2 = 0; q.dep = zero4(); q.ok = -1;
         return q;
     }
+    HAB_HD void a_cvt(const ACtx& c, const ARaw& q, int r, int k_end, f32x4* out) const {
+        if (q.ok >= 0) { obs_quad_cvt(q, out); return; }
+        int img = 0, rem = 0, ho = 0, wo = 0, srow = 0;
+        const bool rv = r < k_end;
+        if (rv) {
+            g.dHoWo.divmod(r, img, rem);
+            g.dWo.divmod(rem, ho, wo);
+            srow = obs.srow(img);
+        }
+        for (int e = 0; e < 16; ++e) {
+            const int ii = c.i + e;
+            float v = 0.f;
+            if (rv && ii < M) {
+                int tap, ci, kh, kw;
+                g.dC.divmod(ii, tap, ci);
+                g.dKW.divmod(tap, kh, kw);
+                const int h = ho * g.stride - g.pad + kh, w_ = wo * g.stride - g.pad + kw;
+                if ((unsigned)h < (unsigned)g.H && (unsigned)w_ < (unsigned)g.W) v = obs.get(srow, h, w_, ci);
+            }
+            out[e >> 2][e & 3] = v;
+        }
+    }
     HAB_HD BCtx b_ctx(int j) const { BCtx c; c.co = (j < N) ? j : -1; return c; }
-    HAB_HD f32x4 b_load(const BCtx& c, int r, int k_end) const {
-        if (c.co < 0 || r >= k_end) return zero4();
-        return ld4(dy + (size_t)r * N + c.co);
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int r, int k_end) const {
+        BRaw q;
+        q.ok = (c.co >= 0) & (r < k_end);
+        q.v = ld4(dy + (q.ok ? (size_t)r * N + c.co : 0));
+        return q;
     }
-    HAB_HD void store(int i, int j, float v) const {
+    HAB_HD f32x4 b_cvt(const BRaw& r) const { return sel4(r); }
+    using EpiCol = ColOnly;
+    using EpiRow = OihwRow;
+    using EpiAux = NoAux;
+    HAB_HD EpiCol epi_col(int n) const { EpiCol c; c.n = n; c.ok = n < N; return c; }
+    HAB_HD EpiRow epi_row(int i) const {
+        EpiRow r;
+        r.ok = i < M;
         int tap, ci, kh, kw;
-        g.dC.divmod(i, tap, ci);
+        g.dC.divmod(r.ok ? i : 0, tap, ci);
         g.dKW.divmod(tap, kh, kw);
-        dw[(((size_t)j * g.C + ci) * g.KH + kh) * g.KW + kw] = v;
+        r.off = (ci * g.KH + kh) * g.KW + kw;
+        return r;
     }
+    HAB_HD EpiAux epi_fetch(const EpiRow&, const EpiCol&) const { return EpiAux(); }
+    HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux&, float v) const {
+        if (!(r.ok & c.ok)) return;
+        dw[(size_t)c.n * g.C * g.KH * g.KW + r.off] = v;
+    }
+    HAB_GENERIC_STORE
 };
 
 // ----------------------------------------------------------------------------------------------
 // Linear layers.  x: [M][K] (ldx), w: [N][K] (ldw) as torch.nn.Linear stores it.
 // vec = 1 requires ldx, ldw, K multiples of 4 and 16-byte aligned bases; vec = 0 gathers scalars.
 // ----------------------------------------------------------------------------------------------
-HAB_HD f32x4 row_load4(const float* row, int k, int k_end, int vec) {
-    if (vec) return (k < k_end) ? ld4(row + k) : zero4();
-    f32x4 r = zero4();
-    for (int e = 0; e < 4; ++e)
-        if (k + e < k_end) r[e] = row[k + e];
+HAB_HD Raw4 row_fetch4(const float* row, int row_ok, int k, int k_end, int vec) {
+    Raw4 r;
+    if (vec) {
+        r.ok = row_ok & (k < k_end);
+        r.v = ld4(row + (r.ok ? k : 0));
+    } else {
+        r.ok = 1;
+        r.v = zero4();
+        for (int e = 0; e < 4; ++e)
+            if (row_ok && k + e < k_end) r.v[e] = row[k + e];
+    }
     return r;
+}
+// four consecutive columns j..j+3 of row-major `base` (ld) at row r; n = number of columns
+HAB_HD Raw4 col_fetch4(const float* base, int ld, int r, int r_ok, int j, int n) {
+    Raw4 q;
+    if (((ld & 3) == 0) && (j + 3 < n || j >= n)) {
+        q.ok = r_ok & (j < n);
+        q.v = ld4(base + (q.ok ? (size_t)r * ld + j : 0));
+    } else {
+        q.ok = 1;
+        q.v = zero4();
+        for (int e = 0; e < 4; ++e)
+            if (r_ok && j + e < n) q.v[e] = base[(size_t)r * ld + j + e];
+    }
+    return q;
 }
 
 // Y = X W^T + b (+ReLU), written with row stride ldy (lets a layer write into a concat buffer).
@@ -357,19 +597,34 @@ struct LinearFwdProb {
     float* y; int ldy;
     int relu, vec;
     int accumulate;  // y += (used for the second operand of a fused two-input projection)
-    struct ACtx { const float* row; };
-    struct BCtx { const float* row; };
-    HAB_HD ACtx a_ctx(int m) const { ACtx c; c.row = (m < M) ? x + (size_t)m * ldx : nullptr; return c; }
-    HAB_HD f32x4 a_load(const ACtx& c, int k, int k_end) const { return c.row ? row_load4(c.row, k, k_end, vec) : zero4(); }
-    HAB_HD BCtx b_ctx(int n) const { BCtx c; c.row = (n < N) ? w + (size_t)n * ldw : nullptr; return c; }
-    HAB_HD f32x4 b_load(const BCtx& c, int k, int k_end) const { return c.row ? row_load4(c.row, k, k_end, vec) : zero4(); }
-    HAB_HD void store(int m, int n, float v) const {
-        float* o = y + (size_t)m * ldy + n;
-        if (bias) v += bias[n];
-        if (accumulate) v += *o;
-        if (relu) v = v > 0.f ? v : 0.f;
-        *o = v;
+    HAB_NO_KCTX
+    using ACtx = WRowCtx;
+    using BCtx = WRowCtx;
+    using ARaw = Raw4;
+    using BRaw = Raw4;
+    HAB_HD ACtx a_ctx(int m) const { ACtx c; c.ok = m < M; c.row = c.ok ? x + (size_t)m * ldx : x; return c; }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int k, int k_end) const { return row_fetch4(c.row, c.ok, k, k_end, vec); }
+    HAB_HD BCtx b_ctx(int n) const { BCtx c; c.ok = n < N; c.row = c.ok ? w + (size_t)n * ldw : w; return c; }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int k, int k_end) const { return row_fetch4(c.row, c.ok, k, k_end, vec); }
+    HAB_PLAIN_CVT
+    using EpiCol = ColN;
+    using EpiRow = RowBase;
+    struct EpiAux { float old; };
+    HAB_HD EpiCol epi_col(int n) const { EpiCol c; c.n = n; c.ok = n < N; c.bias = (bias && c.ok) ? bias[n] : 0.f; return c; }
+    HAB_HD EpiRow epi_row(int m) const { EpiRow r; r.ok = m < M; r.base = (size_t)m * ldy; return r; }
+    HAB_HD EpiAux epi_fetch(const EpiRow& r, const EpiCol& c) const {
+        EpiAux a;
+        a.old = accumulate ? y[(r.ok & c.ok) ? r.base + c.n : 0] : 0.f;
+        return a;
     }
+    HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux& a, float v) const {
+        if (!(r.ok & c.ok)) return;
+        v += c.bias;
+        v += a.old;
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[r.base + c.n] = v;
+    }
+    HAB_GENERIC_STORE
 };
 
 // dX[m][k] = sum_n dY[m][n] W[n][k]   (M = rows, N = in-features, reduction over out-features)
@@ -383,26 +638,35 @@ struct LinearDgradProb {
     float* dx; int lddx;
     int vec_a;
     int accumulate;
-    struct ACtx { const float* row; };
+    HAB_NO_KCTX
+    using ACtx = WRowCtx;
     struct BCtx { int j; };
-    HAB_HD ACtx a_ctx(int m) const { ACtx c; c.row = (m < M) ? dy + (size_t)m * lddy : nullptr; return c; }
-    HAB_HD f32x4 a_load(const ACtx& c, int k, int k_end) const { return c.row ? row_load4(c.row, k, k_end, vec_a) : zero4(); }
+    using ARaw = Raw4;
+    using BRaw = Raw4;
+    HAB_HD ACtx a_ctx(int m) const { ACtx c; c.ok = m < M; c.row = c.ok ? dy + (size_t)m * lddy : dy; return c; }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int k, int k_end) const { return row_fetch4(c.row, c.ok, k, k_end, vec_a); }
     HAB_HD BCtx b_ctx(int j) const { BCtx c; c.j = j; return c; }
-    HAB_HD f32x4 b_load(const BCtx& c, int r, int k_end) const {
-        if (r >= k_end || c.j >= N) return zero4();
-        const float* p = w + (size_t)r * ldw + c.j;
-        if (c.j + 3 < N && ((ldw & 3) == 0)) return ld4(p);
-        f32x4 q = zero4();
-        for (int e = 0; e < 4; ++e)
-            if (c.j + e < N) q[e] = p[e];
-        return q;
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int r, int k_end) const { return col_fetch4(w, ldw, r, r < k_end, c.j, N); }
+    HAB_PLAIN_CVT
+    using EpiCol = ColOnly;
+    struct EpiRow { size_t base, mbase; int ok; };
+    struct EpiAux { float old, mask; };
+    HAB_HD EpiCol epi_col(int n) const { EpiCol c; c.n = n; c.ok = n < N; return c; }
+    HAB_HD EpiRow epi_row(int m) const { EpiRow r; r.ok = m < M; r.base = (size_t)m * lddx; r.mbase = (size_t)m * ldmask; return r; }
+    HAB_HD EpiAux epi_fetch(const EpiRow& r, const EpiCol& c) const {
+        EpiAux a;
+        const int ok = r.ok & c.ok;
+        a.old = accumulate ? dx[ok ? r.base + c.n : 0] : 0.f;
+        a.mask = (mask && c.n < mask_cols) ? mask[ok ? r.mbase + c.n : 0] : 1.f;
+        return a;
     }
-    HAB_HD void store(int m, int n, float v) const {
-        float* o = dx + (size_t)m * lddx + n;
-        if (accumulate) v += *o;
-        if (mask && n < mask_cols && !(mask[(size_t)m * ldmask + n] > 0.f)) v = 0.f;
-        *o = v;
+    HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux& a, float v) const {
+        if (!(r.ok & c.ok)) return;
+        v += a.old;
+        if (!(a.mask > 0.f)) v = 0.f;
+        dx[r.base + c.n] = v;
     }
+    HAB_GENERIC_STORE
 };
 
 // dW[n][k] = sum_m dY[m][n] X[m][k]   (M = out-features, N = in-features, reduction over rows).
@@ -417,39 +681,41 @@ struct LinearWgradProb {
     int perm_c, perm_hw;
     FastDiv dPermC;
     int accumulate;
+    HAB_NO_KCTX
     struct ACtx { int i; };
     struct BCtx { int j; };
+    using ARaw = Raw4;
+    using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int i) const { ACtx c; c.i = i; return c; }
-    HAB_HD f32x4 a_load(const ACtx& c, int r, int k_end) const {
-        if (r >= k_end || c.i >= M) return zero4();
-        const float* p = dy + (size_t)r * lddy + c.i;
-        if (c.i + 3 < M && ((lddy & 3) == 0)) return ld4(p);
-        f32x4 q = zero4();
-        for (int e = 0; e < 4; ++e)
-            if (c.i + e < M) q[e] = p[e];
-        return q;
-    }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int r, int k_end) const { return col_fetch4(dy, lddy, r, r < k_end, c.i, M); }
     HAB_HD BCtx b_ctx(int j) const { BCtx c; c.j = j; return c; }
-    HAB_HD f32x4 b_load(const BCtx& c, int r, int k_end) const {
-        if (r >= k_end || c.j >= N) return zero4();
-        const float* p = x + (size_t)r * ldx + c.j;
-        if (c.j + 3 < N && ((ldx & 3) == 0)) return ld4(p);
-        f32x4 q = zero4();
-        for (int e = 0; e < 4; ++e)
-            if (c.j + e < N) q[e] = p[e];
-        return q;
-    }
-    HAB_HD void store(int i, int j, float v) const {
-        int col = j;
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int r, int k_end) const { return col_fetch4(x, ldx, r, r < k_end, c.j, N); }
+    HAB_PLAIN_CVT
+    struct EpiCol { int col, ok; };
+    using EpiRow = RowBase;
+    struct EpiAux { float old; };
+    HAB_HD EpiCol epi_col(int j) const {
+        EpiCol c;
+        c.ok = j < N;
+        c.col = j;
         if (perm_c > 0) {
-            int hw, c;
-            dPermC.divmod(j, hw, c);
-            col = c * perm_hw + hw;
+            int hw, cc;
+            dPermC.divmod(c.ok ? j : 0, hw, cc);
+            c.col = cc * perm_hw + hw;
         }
-        float* o = dw + (size_t)i * lddw + col;
-        if (accumulate) v += *o;
-        *o = v;
+        return c;
     }
+    HAB_HD EpiRow epi_row(int i) const { EpiRow r; r.ok = i < M; r.base = (size_t)i * lddw; return r; }
+    HAB_HD EpiAux epi_fetch(const EpiRow& r, const EpiCol& c) const {
+        EpiAux a;
+        a.old = accumulate ? dw[(r.ok & c.ok) ? r.base + c.col : 0] : 0.f;
+        return a;
+    }
+    HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux& a, float v) const {
+        if (!(r.ok & c.ok)) return;
+        dw[r.base + c.col] = v + a.old;
+    }
+    HAB_GENERIC_STORE
 };
 
 }  // namespace hab

@@ -10,43 +10,69 @@
 #include <algorithm>
 #include <vector>
 
+#include "../../habitat-lab_amd/csrc/igemm.h"
 #include "../../habitat-lab_amd/csrc/prob_build.h"
 
 using namespace hab;
 
+// Element (m, k) of the A operand / (k, n) of the B operand, through the same fetch + cvt functors the kernel uses.
+template <class P>
+static float host_a(const P& p, int m, int k) {
+    constexpr int KV = AKv<P>::value;
+    f32x4 out[KV / 4];
+    const typename P::KCtx kc = p.k_ctx(k - k % IGEMM_BK, p.K);
+    if constexpr (P::A_RC) {
+        const int kb = k - k % KV;
+        const typename P::ACtx c = p.a_ctx(m);
+        p.a_cvt(c, p.a_fetch(c, kc, kb, p.K), kb, p.K, out);
+        return out[(k - kb) >> 2][(k - kb) & 3];
+    } else {
+        const int mb = m - m % KV;
+        const typename P::ACtx c = p.a_ctx(mb);
+        p.a_cvt(c, p.a_fetch(c, kc, k, p.K), k, p.K, out);
+        return out[(m - mb) >> 2][(m - mb) & 3];
+    }
+}
+template <class P>
+static float host_b(const P& p, int k, int n) {
+    const typename P::KCtx kc = p.k_ctx(k - k % IGEMM_BK, p.K);
+    if constexpr (P::B_RC) {
+        const int kb = k & ~3;
+        const f32x4 v = p.b_cvt(p.b_fetch(p.b_ctx(n), kc, kb, p.K));
+        return v[k - kb];
+    } else {
+        const int nb = n & ~3;
+        const f32x4 v = p.b_cvt(p.b_fetch(p.b_ctx(nb), kc, k, p.K));
+        return v[n - nb];
+    }
+}
+
 template <class P>
 static void host_igemm(const P& p) {
+    std::vector<float> bm((size_t)p.K * p.N);
+    for (int k = 0; k < p.K; ++k)
+        for (int n = 0; n < p.N; ++n) bm[(size_t)k * p.N + n] = host_b(p, k, n);
     std::vector<double> acc((size_t)p.N);
     for (int m = 0; m < p.M; ++m) {
         std::fill(acc.begin(), acc.end(), 0.0);
-        for (int k = 0; k < p.K; k += 4) {
-            float av[4];
-            if constexpr (P::A_RC) {
-                const f32x4 a = p.a_load(p.a_ctx(m), k, p.K);
-                for (int e = 0; e < 4; ++e) av[e] = a[e];
-            } else {
-                for (int e = 0; e < 4; ++e) {
-                    if (k + e >= p.K) { av[e] = 0.f; continue; }
-                    const f32x4 a = p.a_load(p.a_ctx(m & ~3), k + e, p.K);
-                    av[e] = a[m & 3];
-                }
-            }
-            for (int n4 = 0; n4 < p.N; n4 += 4) {
-                if constexpr (P::B_RC) {
-                    for (int j = 0; j < 4 && n4 + j < p.N; ++j) {
-                        const f32x4 b = p.b_load(p.b_ctx(n4 + j), k, p.K);
-                        for (int e = 0; e < 4; ++e) acc[n4 + j] += (double)av[e] * (double)b[e];
-                    }
-                } else {
-                    for (int e = 0; e < 4 && k + e < p.K; ++e) {
-                        const f32x4 b = p.b_load(p.b_ctx(n4), k + e, p.K);
-                        for (int j = 0; j < 4 && n4 + j < p.N; ++j) acc[n4 + j] += (double)av[e] * (double)b[j];
-                    }
-                }
-            }
+        for (int k = 0; k < p.K; ++k) {
+            const double a = (double)host_a(p, m, k);
+            if (a == 0.0) continue;
+            const float* br = &bm[(size_t)k * p.N];
+            for (int n = 0; n < p.N; ++n) acc[n] += a * (double)br[n];
         }
         for (int n = 0; n < p.N; ++n) p.store(m, n, (float)acc[n]);
     }
+}
+
+// exhaustive check of the uint8 scaling used by the observation gathers: returns the number of mismatches
+extern "C" int hc_div255_mismatches() {
+    int bad = 0;
+    for (int x = 0; x < 256; ++x) {
+        volatile float ref = (float)x / 255.0f;
+        if (div255((float)x) != ref) ++bad;
+    }
+    return bad;
 }
 
 static ConvDesc mk(int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad) {

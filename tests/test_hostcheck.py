@@ -82,7 +82,7 @@ def test_conv_fwd_dgrad_wgrad(hc, B, H, W, Cc, Cout, K, s, p):
         assert torch.allclose(dw, w.grad, atol=2e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("has_rgb,has_depth,H,W", [(1, 1, 36, 36), (0, 1, 28, 32), (1, 0, 20, 24)])
+@pytest.mark.parametrize("has_rgb,has_depth,H,W", [(1, 1, 36, 36), (1, 1, 12, 16), (1, 1, 18, 22), (0, 1, 28, 32), (1, 0, 20, 24)])
 def test_obs_conv(hc, has_rgb, has_depth, H, W):
     torch.manual_seed(1)
     nrows, B = 7, 3
@@ -110,6 +110,11 @@ def test_obs_conv(hc, has_rgb, has_depth, H, W):
     dw = torch.zeros_like(w)
     assert hc.hc_obs_conv2d_wgrad(P(rgb), P(depth), P(rows), P(dy), P(dw), B, H, W, 32, 8, 8, 4, 0) == 0
     assert torch.allclose(dw, w.grad, atol=2e-4, rtol=1e-4)
+
+
+def test_div255_equals_ieee_division_for_all_bytes(hc):
+    """The observation gathers scale uint8 by a reciprocal multiply + one Newton step; it must equal x / 255.0f."""
+    assert hc.hc_div255_mismatches() == 0
 
 
 def test_linear_family(hc):
