@@ -18,6 +18,7 @@ struct ParamSpec {
     int ndim;
     int64_t offset;  // floats, 16-byte aligned
     int64_t numel;
+    int is_buffer = 0;  // registered buffer of the reference module (no gradient, not an optimiser parameter)
 };
 
 struct Arena {
@@ -50,10 +51,11 @@ struct hab_policy {
     std::vector<int64_t> w_gi, w_gates, w_hn, w_hprev, w_cprev, w_c, w_out, w_dgi, w_dgh, w_dlayer;
     int64_t ws_floats = 0;
     int last_B = 0, last_n = 0;
+    const uint8_t* last_masks = nullptr;
     // ResNet policy (engine_resnet.hip)
     struct ResNetPlan* rn = nullptr;
     int training = 1;                                   // nn.Module.train()/eval(): RunningMeanAndVar updates only in training
-    void (*allreduce_cb)(float*, int, void*) = nullptr;  // optional in-place sum all-reduce of a small device buffer (DD-PPO RMV stats)
+    hab_allreduce_fn allreduce_cb = nullptr;            // optional in-place all-reduce of a small device buffer (DD-PPO RMV stats)
     void* allreduce_ctx = nullptr;
     int world_size = 1;
     // probe
@@ -85,6 +87,7 @@ void destroy_resnet(hab_policy* e);
 int resnet_repack(hab_policy* e, hipStream_t s);
 int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s);
 int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s);
+int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats);
 
 struct Probe {
     hab_policy* e; hipStream_t s; bool on;
@@ -92,14 +95,14 @@ struct Probe {
         if (!on) return;
         if (e->probe_used == e->probe_events.size()) {
             hipEvent_t a, b;
-            hipEventCreate(&a); hipEventCreate(&b);
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
             e->probe_events.push_back({a, b});
         }
-        hipEventRecord(e->probe_events[e->probe_used].first, s);
+        (void)hipEventRecord(e->probe_events[e->probe_used].first, s);
     }
     ~Probe() {
         if (!on) return;
-        hipEventRecord(e->probe_events[e->probe_used].second, s);
+        (void)hipEventRecord(e->probe_events[e->probe_used].second, s);
         e->probe_used++;
     }
 };

@@ -107,13 +107,15 @@ extern "C" int hab_policy_create(const hab_policy_desc* desc, hab_policy** out) 
     e->d = *desc;
     int rc = HAB_ERR_UNSUPPORTED;
     if (desc->arch == HAB_ARCH_SIMPLE_CNN) rc = build_baseline(e);
-    if (rc != HAB_OK) { delete e; return rc; }
+    else if (desc->arch == HAB_ARCH_RESNET) rc = build_resnet(e);
+    if (rc != HAB_OK) { destroy_resnet(e); delete e; return rc; }
     *out = e;
     return HAB_OK;
 }
 extern "C" void hab_policy_destroy(hab_policy* e) {
     if (!e) return;
-    for (auto& ev : e->probe_events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    for (auto& ev : e->probe_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    destroy_resnet(e);
     delete e;
 }
 extern "C" int hab_policy_num_params(const hab_policy* e) { return e ? (int)e->params.size() : HAB_ERR_ARG; }
@@ -126,6 +128,20 @@ extern "C" int hab_policy_param_info(const hab_policy* e, int i, char* name, int
     if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = s.shape[k];
     if (ndim) *ndim = s.ndim;
     if (offset_floats) *offset_floats = s.offset;
+    return HAB_OK;
+}
+extern "C" int hab_policy_param_is_buffer(const hab_policy* e, int i) {
+    if (!e || i < 0 || i >= (int)e->params.size()) return HAB_ERR_ARG;
+    return e->params[i].is_buffer;
+}
+extern "C" int hab_policy_set_training(hab_policy* e, int training) {
+    if (!e) return HAB_ERR_ARG;
+    e->training = training ? 1 : 0;
+    return HAB_OK;
+}
+extern "C" int hab_policy_set_allreduce(hab_policy* e, hab_allreduce_fn fn, void* ctx, int world_size) {
+    if (!e || world_size < 1) return HAB_ERR_ARG;
+    e->allreduce_cb = fn; e->allreduce_ctx = ctx; e->world_size = world_size;
     return HAB_OK;
 }
 extern "C" int64_t hab_policy_param_floats(const hab_policy* e) { return e ? e->param_floats : -1; }
@@ -144,6 +160,7 @@ extern "C" int hab_policy_bind(hab_policy* e, float* params, float* grads, float
 // of the parameters: optimiser step, load_state_dict, broadcast).
 extern "C" int hab_policy_repack(hab_policy* e, hipStream_t stream) {
     if (!e || !e->P) return HAB_ERR_ARG;
+    if (e->rn) return resnet_repack(e, stream);
     const int H = e->d.hidden;
     HAB_TRY(repack_conv(e->p(e->i_c1w), e->PK + e->pk_c1f, nullptr, 32, e->Cin, 8, 8, e->Cin, stream));
     HAB_TRY(repack_conv(e->p(e->i_c2w), e->PK + e->pk_c2f, e->PK + e->pk_c2d, 64, 32, 4, 4, 32, stream));
@@ -181,7 +198,8 @@ extern "C" int hab_policy_probe_read(hab_policy* e, double* total_ms, int* count
 // ------------------------------------------------------------------------------------------
 // Encoder forward on B frames (shared by act / evaluate): obs -> rnn_in[B][rnn_ld]
 // ------------------------------------------------------------------------------------------
-static int encoder_forward(hab_policy* e, const hab_obs* obs, const int* rows, int B, hipStream_t s) {
+static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s) {
+    if (e->rn) return resnet_encoder_forward(e, obs, masks, rows, B, s);
     float* W = e->WK;
     float* ws = W + e->w_ws;
     const int H = e->d.hidden;
@@ -234,7 +252,7 @@ extern "C" int hab_policy_act(hab_policy* e, const hab_obs* obs, const float* hi
     float* W = e->WK;
     const int H = e->d.hidden, L = e->L;
     const int Lh = e->d.rnn_type == HAB_RNN_LSTM ? 2 * L : L;
-    HAB_TRY(encoder_forward(e, obs, nullptr, n, stream));
+    HAB_TRY(encoder_forward(e, obs, masks, nullptr, n, stream));
     const float* x = W + e->w_rnnin;
     int ldx = e->rnn_ld;
     float* hm = W + e->w_hmask;  // [2L][n][H] masked h (and c)
@@ -285,7 +303,7 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
     if (pack->P != B || pack->F <= 0 || pack->F > B || pack->max_len <= 0) return HAB_ERR_ARG;
     float* W = e->WK;
     const int H = e->d.hidden, L = e->L;
-    HAB_TRY(encoder_forward(e, obs, rows, B, stream));
+    HAB_TRY(encoder_forward(e, obs, masks, rows, B, stream));
     PackInfo pk;
     pk.select_inds = pack->select_inds; pk.step_offsets = pack->step_offsets_host; pk.num_seqs_at_step = pack->num_seqs_at_step_host;
     pk.frag_env = pack->frag_env; pk.frag_start = pack->frag_start; pk.P = pack->P; pk.F = pack->F; pk.max_len = pack->max_len;
@@ -317,6 +335,7 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
     HAB_TRY(heads_forward(ha, stream));
     e->last_B = B;
     e->last_n = n;
+    e->last_masks = masks;
     return HAB_OK;
 }
 
@@ -373,6 +392,7 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
                                        W + e->w_scratch, ws, e->ws_floats, stream));
         dout = dx;
     }
+    if (e->rn) return resnet_encoder_backward(e, obs, e->last_masks, rows, B, stream);
     // fc (Flatten -> Linear -> ReLU): d_rnnin[:, :H] already carries the ReLU mask
     const float* dfc = W + e->w_drnnin;
     ConvDesc c1 = e->c1, c2 = e->c2, c3 = e->c3;
@@ -406,6 +426,7 @@ extern "C" int hab_policy_tap(hab_policy* e, int which, const float** ptr, int64
     if (!e || !ptr || !floats || e->last_B <= 0) return HAB_ERR_ARG;
     const int64_t B = e->last_B;
     float* W = e->WK;
+    if (e->rn && which != HAB_TAP_RNN_IN && which != HAB_TAP_RNN_OUT) return resnet_tap(e, which, ptr, floats);
     switch (which) {
         case HAB_TAP_CONV1: *ptr = W + e->w_a1; *floats = B * e->c1.Ho() * e->c1.Wo() * 32; break;
         case HAB_TAP_CONV2: *ptr = W + e->w_a2; *floats = B * e->c2.Ho() * e->c2.Wo() * 64; break;

@@ -1,0 +1,485 @@
+// engine_resnet.hip -- the GroupNorm-ResNet visual encoder of PointNavResNetPolicy inside the policy engine:
+// layer program (stem, BasicBlock / Bottleneck stages, compression, visual_fc, goal + previous-action embeddings),
+// its parameter table in the reference's state_dict() order, forward with saved activations and the full backward.
+//
+// Replaces (habitat-baselines/habitat_baselines/rl/ddppo/policy/): resnet_policy.py:162-276 (ResNetEncoder),
+// resnet.py:37-69,116-152,196-281 (blocks, ResNet), running_mean_and_var.py:24-78, resnet_policy.py:625-767
+// (PointNavResNetNet.forward: visual_fc, tgt_embeding, prev_action_embedding, concat) and the autograd backward
+// through them (rl/ppo/ppo.py:253).
+//
+// Dataflow per frame batch (all NHWC fp32, contractions on the igemm kernel, the rest in resnet_ops.hip):
+//   obs --ingest(uint8*1/255, avg_pool2d(2), concat)--> x0 --RunningMeanAndVar--> x0
+//   x0 --conv7x7/2--> raw --GN+ReLU--> n0 --maxpool3x3/2--> pool --blocks--> ... --conv3x3--> raw --GN(1)+ReLU--> comp
+//   comp --Flatten(NCHW order)+Linear+ReLU--> rnn_in[:, :H];  embeddings --> rnn_in[:, H:H+64]
+// Block: conv_i -> raw_i -> GN(+ReLU) -> n_i ... last: GN + residual + ReLU -> out.  raw_i (GroupNorm input) and
+// n_i (next conv's input) are both kept for the backward pass, exactly what autograd keeps in the reference.
+#include "engine.h"
+
+using namespace hab;
+
+namespace {
+
+struct RnConv {
+    ConvDesc cd;                 // B = 0 until a call
+    int groups = 0;
+    int i_w = -1, i_gamma = -1, i_beta = -1;
+    int64_t pk_f = -1, pk_d = -1;   // packed weights (pk_d < 0: no data gradient needed)
+    int64_t w_raw = -1, w_mean = -1, w_rstd = -1, w_out = -1;
+    int64_t out_floats() const { return (int64_t)cd.Ho() * cd.Wo() * cd.Cout; }
+    int64_t in_floats() const { return (int64_t)cd.H * cd.W * cd.C; }
+};
+
+struct RnBlock {
+    std::vector<int> convs;  // main branch
+    int ds = -1;             // downsample conv or -1
+    int64_t w_in = -1;       // block input (previous block's out / pool)
+    int64_t w_out = -1;      // block output
+};
+
+}  // namespace
+
+struct ResNetPlan {
+    int cpad = 4, creal = 4, H2 = 0, W2 = 0;
+    int64_t w_x0 = -1;
+    RnConv stem;
+    int64_t w_pool = -1, w_pool_idx = -1;
+    int poolH = 0, poolW = 0;
+    std::vector<RnConv> convs;
+    std::vector<RnBlock> blocks;
+    RnConv comp;
+    int i_fcw = -1, i_fcb = -1, i_emb = -1, i_tgw = -1, i_tgb = -1, i_mean = -1, i_var = -1, i_count = -1;
+    int64_t pk_fc = -1;
+    int fc_in = 0, comp_c = 0, comp_hw = 0;
+    // gradient scratch
+    int64_t w_gstem[2] = {-1, -1};
+    std::vector<int64_t> w_gbuf;
+    int64_t gbuf_floats = 0;  // per frame
+    int64_t w_chansums = -1;  // [B][2][Cmax]
+    int64_t w_stats = -1;     // RunningMeanAndVar batch moments: mean[8], var[8] (+ padding)
+    int64_t w_dscratch = -1;  // doubles for chan_moment partials
+    int64_t w_embsave = -1;   // [B][4] goal features + previous-action token of the last forward
+    int cmax = 0;
+};
+
+static int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+static int add_conv_gn(hab_policy* e, RnConv& c, const std::string& wname, const std::string& gnname, int cin_real) {
+    c.i_w = add_param(e, wname + ".weight", {c.cd.Cout, cin_real, c.cd.KH, c.cd.KW});
+    c.i_gamma = add_param(e, gnname + ".weight", {c.cd.Cout});
+    c.i_beta = add_param(e, gnname + ".bias", {c.cd.Cout});
+    return HAB_OK;
+}
+
+int build_resnet(hab_policy* e) {
+    const hab_policy_desc& d = e->d;
+    if (d.backbone != 18 && d.backbone != 50) return HAB_ERR_UNSUPPORTED;
+    if (d.baseplanes <= 0 || d.baseplanes % 8) return HAB_ERR_UNSUPPORTED;
+    if ((d.H & 1) || (d.W & 1)) return HAB_ERR_UNSUPPORTED;
+    if (d.rnn_type != HAB_RNN_GRU && d.rnn_type != HAB_RNN_LSTM) return HAB_ERR_ARG;
+    if (d.goal_dim != 2) return HAB_ERR_UNSUPPORTED;  // 2-D polar pointgoal (resnet_policy.py:662-672)
+    ResNetPlan* r = new ResNetPlan();
+    e->rn = r;
+    const int H = d.hidden;
+    e->G_ = d.rnn_type == HAB_RNN_GRU ? 3 : 4;
+    e->L = d.rnn_layers;
+    r->creal = (d.has_rgb ? 3 : 0) + (d.has_depth ? 1 : 0);
+    if (r->creal == 0) return HAB_ERR_UNSUPPORTED;
+    e->Cin = r->creal;
+    r->cpad = 4;
+    r->H2 = d.H / 2; r->W2 = d.W / 2;
+    const int bp = d.baseplanes, ng = bp / 2;
+    const bool bottleneck = d.backbone == 50;
+    const int expansion = bottleneck ? 4 : 1;
+    static const int L18[4] = {2, 2, 2, 2}, L50[4] = {3, 4, 6, 3};
+    const int* layers = bottleneck ? L50 : L18;
+
+    // ---- parameter table in the reference's state_dict order (resnet_policy.py:389-396,454-456 first) ----
+    r->i_emb = add_param(e, "net.prev_action_embedding.weight", {d.num_actions + 1, 32});
+    r->i_tgw = add_param(e, "net.tgt_embeding.weight", {32, 3});
+    r->i_tgb = add_param(e, "net.tgt_embeding.bias", {32});
+    const std::string ve = "net.visual_encoder.";
+    if (d.normalize_visual_inputs) {
+        r->i_mean = add_param(e, ve + "running_mean_and_var._mean", {1, r->creal, 1, 1});
+        r->i_var = add_param(e, ve + "running_mean_and_var._var", {1, r->creal, 1, 1});
+        r->i_count = add_param(e, ve + "running_mean_and_var._count", {});
+        e->params[r->i_mean].is_buffer = e->params[r->i_var].is_buffer = e->params[r->i_count].is_buffer = 1;
+    }
+    const std::string bb = ve + "backbone.";
+    r->stem.cd = ConvDesc{0, r->H2, r->W2, r->cpad, bp, 7, 7, 2, 3};
+    r->stem.cd.Creal = r->creal;
+    r->stem.groups = ng;
+    add_conv_gn(e, r->stem, bb + "conv1.0", bb + "conv1.1", r->creal);
+    const int sh = r->stem.cd.Ho(), sw = r->stem.cd.Wo();
+    r->poolH = conv_out(sh, 3, 2, 1); r->poolW = conv_out(sw, 3, 2, 1);
+    int inplanes = bp, curH = r->poolH, curW = r->poolW;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = bp << li;
+        for (int bi = 0; bi < layers[li]; ++bi) {
+            const int stride = (bi == 0 && li > 0) ? 2 : 1;
+            const std::string bpfx = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+            const bool has_ds = bi == 0 && (stride != 1 || inplanes != planes * expansion);
+            RnBlock blk;
+            auto push = [&](int cin, int cout, int k, int s, int p, int hh, int ww, const std::string& w, const std::string& g) {
+                RnConv c;
+                c.cd = ConvDesc{0, hh, ww, cin, cout, k, k, s, p};
+                c.groups = ng;
+                add_conv_gn(e, c, w, g, cin);
+                r->convs.push_back(c);
+                return (int)r->convs.size() - 1;
+            };
+            const int oh = conv_out(curH, 3, stride, 1), ow = conv_out(curW, 3, stride, 1);
+            if (!bottleneck) {
+                blk.convs.push_back(push(inplanes, planes, 3, stride, 1, curH, curW, bpfx + "convs.0", bpfx + "convs.1"));
+                blk.convs.push_back(push(planes, planes, 3, 1, 1, oh, ow, bpfx + "convs.3", bpfx + "convs.4"));
+            } else {
+                blk.convs.push_back(push(inplanes, planes, 1, 1, 0, curH, curW, bpfx + "convs.0", bpfx + "convs.1"));
+                blk.convs.push_back(push(planes, planes, 3, stride, 1, curH, curW, bpfx + "convs.3", bpfx + "convs.4"));
+                blk.convs.push_back(push(planes, planes * expansion, 1, 1, 0, oh, ow, bpfx + "convs.6", bpfx + "convs.7"));
+            }
+            if (has_ds) blk.ds = push(inplanes, planes * expansion, 1, stride, 0, curH, curW, bpfx + "downsample.0", bpfx + "downsample.1");
+            r->blocks.push_back(blk);
+            inplanes = planes * expansion;
+            curH = oh; curW = ow;
+        }
+    }
+    // compression (resnet_policy.py:213-234)
+    const int fh = (int)ceil(r->H2 / 32.0), fw = (int)ceil(r->W2 / 32.0);
+    if (fh != curH || fw != curW) return HAB_ERR_UNSUPPORTED;
+    const int ncomp = (int)lrint(2048.0 / (fh * fw));
+    if (ncomp <= 0 || ncomp % 4) return HAB_ERR_UNSUPPORTED;
+    r->comp.cd = ConvDesc{0, curH, curW, inplanes, ncomp, 3, 3, 1, 1};
+    r->comp.groups = 1;
+    add_conv_gn(e, r->comp, ve + "compression.0", ve + "compression.1", inplanes);
+    r->comp_c = ncomp; r->comp_hw = fh * fw; r->fc_in = ncomp * fh * fw;
+    r->i_fcw = add_param(e, "net.visual_fc.1.weight", {H, r->fc_in});
+    r->i_fcb = add_param(e, "net.visual_fc.1.bias", {H});
+    e->fc_in = r->fc_in;
+    e->rnn_in = H + 32 + 32;
+    e->rnn_ld = (e->rnn_in + 3) & ~3;
+    const std::string rn = "net.state_encoder.rnn.";
+    for (int l = 0; l < d.rnn_layers; ++l) {
+        const int in = l == 0 ? e->rnn_in : H;
+        const std::string sfx = "_l" + std::to_string(l);
+        e->i_wih.push_back(add_param(e, rn + "weight_ih" + sfx, {e->G_ * H, in}));
+        e->i_whh.push_back(add_param(e, rn + "weight_hh" + sfx, {e->G_ * H, H}));
+        e->i_bih.push_back(add_param(e, rn + "bias_ih" + sfx, {e->G_ * H}));
+        e->i_bhh.push_back(add_param(e, rn + "bias_hh" + sfx, {e->G_ * H}));
+    }
+    e->i_aw = add_param(e, "action_distribution.linear.weight", {d.num_actions, H});
+    e->i_ab = add_param(e, "action_distribution.linear.bias", {d.num_actions});
+    e->i_cw = add_param(e, "critic.fc.weight", {1, H});
+    e->i_cb = add_param(e, "critic.fc.bias", {1});
+
+    // ---- packed weights ----
+    Arena pk;
+    auto pack_conv = [&](RnConv& c, bool need_d) {
+        const int64_t n = (int64_t)c.cd.Cout * c.cd.KH * c.cd.KW * c.cd.C;
+        c.pk_f = pk.take(n);
+        if (need_d) c.pk_d = pk.take(n);
+    };
+    pack_conv(r->stem, false);
+    for (auto& c : r->convs) pack_conv(c, true);
+    pack_conv(r->comp, true);
+    r->pk_fc = pk.take((int64_t)H * r->fc_in);
+    for (int l = 0; l < d.rnn_layers; ++l) e->pk_whht.push_back(pk.take((int64_t)e->G_ * H * H));
+    e->packed_floats = pk.used;
+
+    // ---- workspace ----
+    Arena wk;
+    const int64_t B = d.max_frames, F = d.max_frames;
+    r->w_x0 = wk.take(B * r->H2 * r->W2 * r->cpad);
+    auto place = [&](RnConv& c, bool own_out) {
+        c.w_raw = wk.take(B * c.out_floats());
+        c.w_mean = wk.take(B * c.groups);
+        c.w_rstd = wk.take(B * c.groups);
+        if (own_out) c.w_out = wk.take(B * c.out_floats());
+        r->cmax = std::max(r->cmax, c.cd.Cout);
+    };
+    place(r->stem, true);
+    r->w_pool = wk.take(B * r->poolH * r->poolW * bp);
+    r->w_pool_idx = wk.take((B * r->poolH * r->poolW * bp + 3) / 4);
+    int64_t prev = r->w_pool;
+    r->gbuf_floats = (int64_t)r->poolH * r->poolW * bp;
+    for (auto& blk : r->blocks) {
+        blk.w_in = prev;
+        for (size_t q = 0; q < blk.convs.size(); ++q) {
+            RnConv& c = r->convs[blk.convs[q]];
+            place(c, true);  // last conv's w_out is the block output
+            r->gbuf_floats = std::max(r->gbuf_floats, c.out_floats());
+        }
+        if (blk.ds >= 0) { place(r->convs[blk.ds], true); r->gbuf_floats = std::max(r->gbuf_floats, r->convs[blk.ds].out_floats()); }
+        blk.w_out = r->convs[blk.convs.back()].w_out;
+        prev = blk.w_out;
+    }
+    place(r->comp, true);
+    r->gbuf_floats = std::max(r->gbuf_floats, r->comp.out_floats());
+    for (int k = 0; k < 2; ++k) r->w_gstem[k] = wk.take(B * r->stem.out_floats());
+    for (int k = 0; k < 6; ++k) r->w_gbuf.push_back(wk.take(B * r->gbuf_floats));
+    r->w_chansums = wk.take(B * 2 * r->cmax);
+    r->w_stats = wk.take(64);
+    r->w_dscratch = wk.take(2 * 1024 * 8);  // 1024 blocks x 8 channels of double
+    r->w_embsave = wk.take(B * 4);
+    // shared tail (RNN, heads) -- same layout as the SimpleCNN engine
+    e->w_rnnin = wk.take(B * e->rnn_ld); e->w_drnnin = wk.take(B * e->rnn_ld);
+    e->w_hinit = wk.take((int64_t)d.rnn_layers * F * H); e->w_cinit = wk.take((int64_t)d.rnn_layers * F * H);
+    for (int l = 0; l < d.rnn_layers; ++l) {
+        e->w_gi.push_back(wk.take(B * e->G_ * H)); e->w_gates.push_back(wk.take(B * e->G_ * H));
+        e->w_hn.push_back(wk.take(B * H)); e->w_hprev.push_back(wk.take(B * H));
+        e->w_cprev.push_back(wk.take(B * H)); e->w_c.push_back(wk.take(B * H)); e->w_out.push_back(wk.take(B * H));
+        e->w_dgi.push_back(wk.take(B * e->G_ * H)); e->w_dgh.push_back(wk.take(B * e->G_ * H));
+        e->w_dlayer.push_back(wk.take(B * H));
+    }
+    e->w_probs = wk.take(B * 8); e->w_logitsn = wk.take(B * 8); e->w_dzv = wk.take(B * 8); e->w_dv = wk.take(B);
+    e->w_dfeat = wk.take(B * H); e->w_scratch = wk.take(3 * F * H);
+    e->w_value = wk.take(B); e->w_logp = wk.take(B); e->w_ent = wk.take(B);
+    e->w_hmask = wk.take((int64_t)2 * d.rnn_layers * d.max_envs * H);
+    e->w_gistep = wk.take((int64_t)d.max_envs * e->G_ * H);
+    e->w_step_h = wk.take((int64_t)d.max_envs * H * 2);
+    e->ws_floats = (int64_t)32 << 20;
+    e->w_ws = wk.take(e->ws_floats);
+    e->work_floats = wk.used;
+    return HAB_OK;
+}
+
+void destroy_resnet(hab_policy* e) {
+    delete e->rn;
+    e->rn = nullptr;
+}
+
+int resnet_repack(hab_policy* e, hipStream_t s) {
+    ResNetPlan* r = e->rn;
+    const int H = e->d.hidden;
+    auto rp = [&](const RnConv& c, int cin_real) {
+        return repack_conv(e->p(c.i_w), e->PK + c.pk_f, c.pk_d >= 0 ? e->PK + c.pk_d : nullptr, c.cd.Cout, cin_real, c.cd.KH, c.cd.KW,
+                           c.cd.C, s);
+    };
+    HAB_TRY(rp(r->stem, r->creal));
+    for (const auto& c : r->convs) HAB_TRY(rp(c, c.cd.C));
+    HAB_TRY(rp(r->comp, r->comp.cd.C));
+    HAB_TRY(repack_flatten(e->p(r->i_fcw), e->PK + r->pk_fc, H, r->comp_c, r->comp_hw, s));
+    for (int l = 0; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_whh[l]), e->PK + e->pk_whht[l], e->G_ * H, H, s));
+    return HAB_OK;
+}
+
+// conv -> raw, GroupNorm (+residual, +ReLU) -> out
+static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, const float* residual, int relu, int B, hipStream_t s) {
+    float* W = e->WK;
+    ConvDesc cd = c.cd;
+    cd.B = B;
+    HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, W + c.w_raw, 0, W + e->w_ws, e->ws_floats, s));
+    GnArgs g;
+    g.x = W + c.w_raw; g.y = W + c.w_out; g.gamma = e->p(c.i_gamma); g.beta = e->p(c.i_beta); g.residual = residual;
+    g.mean = W + c.w_mean; g.rstd = W + c.w_rstd; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = c.groups;
+    g.relu = relu; g.eps = 1e-5f;
+    return groupnorm_forward(g, s);
+}
+
+int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s) {
+    ResNetPlan* r = e->rn;
+    float* W = e->WK;
+    const hab_policy_desc& d = e->d;
+    const int H = d.hidden;
+    float* x0 = W + r->w_x0;
+    HAB_TRY(ingest_pool(d.has_rgb ? obs->rgb : nullptr, d.has_depth ? obs->depth : nullptr, rows, x0, B, d.H, d.W, r->cpad,
+                        d.depth_first, s));
+    const long long npix = (long long)B * r->H2 * r->W2;
+    if (d.normalize_visual_inputs) {
+        float* st = W + r->w_stats;  // [0..7] batch mean, [8..15] batch var
+        if (e->training) {
+            double* ds = reinterpret_cast<double*>(W + r->w_dscratch);
+            HAB_TRY(chan_moment(x0, npix, r->cpad, 0, nullptr, st, ds, 1024 * 8, s));
+            if (e->allreduce_cb && e->world_size > 1) {  // running_mean_and_var.py:38-41
+                e->allreduce_cb(st, 8, 1.0f / e->world_size, e->allreduce_ctx);
+            }
+            HAB_TRY(chan_moment(x0, npix, r->cpad, 1, st, st + 8, ds, 1024 * 8, s));
+            if (e->allreduce_cb && e->world_size > 1) e->allreduce_cb(st + 8, 8, 1.0f / e->world_size, e->allreduce_ctx);
+            HAB_TRY(rmv_update(e->p(r->i_mean), e->p(r->i_var), e->p(r->i_count), st, st + 8, (float)B * (float)e->world_size,
+                               r->creal, s));
+        }
+        HAB_TRY(rmv_normalize(x0, npix, r->cpad, r->creal, e->p(r->i_mean), e->p(r->i_var), s));
+    }
+    // stem
+    HAB_TRY(conv_gn_forward(e, r->stem, x0, nullptr, 1, B, s));
+    HAB_TRY(maxpool_forward(W + r->stem.w_out, W + r->w_pool, reinterpret_cast<uint8_t*>(W + r->w_pool_idx), B, r->stem.cd.Ho(),
+                            r->stem.cd.Wo(), r->stem.cd.Cout, s));
+    for (const auto& blk : r->blocks) {
+        const float* in = W + blk.w_in;
+        const float* residual = in;
+        if (blk.ds >= 0) {
+            HAB_TRY(conv_gn_forward(e, r->convs[blk.ds], in, nullptr, 0, B, s));
+            residual = W + r->convs[blk.ds].w_out;
+        }
+        const float* cur = in;
+        for (size_t q = 0; q < blk.convs.size(); ++q) {
+            const RnConv& c = r->convs[blk.convs[q]];
+            const bool last = q + 1 == blk.convs.size();
+            HAB_TRY(conv_gn_forward(e, c, cur, last ? residual : nullptr, 1, B, s));
+            cur = W + c.w_out;
+        }
+    }
+    HAB_TRY(conv_gn_forward(e, r->comp, W + r->blocks.back().w_out, nullptr, 1, B, s));
+    // visual_fc (Flatten in NCHW order -> packed weight is permuted) + ReLU, written into rnn_in[:, :H]
+    float* ws = W + e->w_ws;
+    HAB_TRY(linear_fwd(W + r->comp.w_out, r->fc_in, e->PK + r->pk_fc, r->fc_in, e->p(r->i_fcb), W + e->w_rnnin, e->rnn_ld, B, H,
+                       r->fc_in, 1, 0, ws, e->ws_floats, s));
+    EmbedArgs ea;
+    ea.goal = obs->goal; ea.prev_actions = obs->prev_actions; ea.masks = masks; ea.rows = rows;
+    ea.w_t = e->p(r->i_tgw); ea.b_t = e->p(r->i_tgb); ea.emb = e->p(r->i_emb);
+    ea.out = W + e->w_rnnin; ea.ld = e->rnn_ld; ea.col0 = H; ea.B = B; ea.saved = W + r->w_embsave;
+    if (!obs->goal || !obs->prev_actions || !masks) return HAB_ERR_ARG;
+    return embed_forward(ea, s);
+}
+
+namespace {
+struct GPool {  // tiny allocator over the gradient scratch buffers
+    float* buf[6];
+    bool used[6] = {false, false, false, false, false, false};
+    float* get() {
+        for (int i = 0; i < 6; ++i)
+            if (!used[i]) { used[i] = true; return buf[i]; }
+        return nullptr;
+    }
+    void put(const float* p) {
+        for (int i = 0; i < 6; ++i)
+            if (buf[i] == p) used[i] = false;
+    }
+};
+}  // namespace
+
+// GroupNorm backward of conv c: dy (optionally masked by relu_out) -> d_raw; gamma / beta gradients.
+static int gn_backward(hab_policy* e, const RnConv& c, const float* dy, const float* relu_out, float* d_raw, float* dy_masked, int B,
+                       hipStream_t s) {
+    float* W = e->WK;
+    ResNetPlan* r = e->rn;
+    GnBwdArgs g;
+    g.x = W + c.w_raw; g.dy = dy; g.relu_out = relu_out; g.dx = d_raw; g.dy_masked = dy_masked; g.gamma = e->p(c.i_gamma);
+    g.mean = W + c.w_mean; g.rstd = W + c.w_rstd; g.chan_sums = W + r->w_chansums; g.B = B; g.HW = c.cd.Ho() * c.cd.Wo();
+    g.C = c.cd.Cout; g.groups = c.groups;
+    HAB_TRY(groupnorm_backward(g, s));
+    const int C = c.cd.Cout;
+    HAB_TRY(colsum(W + r->w_chansums, 2 * C, B, C, e->g(c.i_beta), 0, W + e->w_ws, e->ws_floats, s));
+    HAB_TRY(colsum(W + r->w_chansums + C, 2 * C, B, C, e->g(c.i_gamma), 0, W + e->w_ws, e->ws_floats, s));
+    return HAB_OK;
+}
+
+int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s) {
+    ResNetPlan* r = e->rn;
+    float* W = e->WK;
+    float* ws = W + e->w_ws;
+    const int H = e->d.hidden;
+    const float* dfc = W + e->w_drnnin;  // [B][rnn_ld]; first H columns already carry visual_fc's ReLU mask
+    EmbedBwdArgs eb;
+    eb.saved = W + r->w_embsave; eb.dout = dfc; eb.ld = e->rnn_ld;
+    eb.col0 = H; eb.B = B; eb.num_tokens = e->d.num_actions + 1;
+    eb.dw_t = e->g(r->i_tgw); eb.db_t = e->g(r->i_tgb); eb.demb = e->g(r->i_emb);
+    HAB_TRY(embed_backward(eb, s));
+    GPool gp;
+    for (int i = 0; i < 6; ++i) gp.buf[i] = W + r->w_gbuf[i];
+    // visual_fc
+    HAB_TRY(linear_wgrad(dfc, e->rnn_ld, W + r->comp.w_out, r->fc_in, e->g(r->i_fcw), r->fc_in, B, H, r->fc_in, r->comp_c, r->comp_hw,
+                         0, ws, e->ws_floats, s));
+    HAB_TRY(colsum(dfc, e->rnn_ld, B, H, e->g(r->i_fcb), 0, ws, e->ws_floats, s));
+    float* d_comp = gp.get();  // gradient wrt compression output, masked by its ReLU
+    HAB_TRY(linear_dgrad(dfc, e->rnn_ld, e->PK + r->pk_fc, r->fc_in, W + r->comp.w_out, r->fc_in, r->fc_in, d_comp, r->fc_in, B,
+                         r->fc_in, H, 0, ws, e->ws_floats, s));
+    // compression conv + GN(1)
+    float* d_raw = gp.get();
+    HAB_TRY(gn_backward(e, r->comp, d_comp, nullptr, d_raw, nullptr, B, s));
+    gp.put(d_comp);
+    ConvDesc cd = r->comp.cd;
+    cd.B = B;
+    const float* comp_in = W + r->blocks.back().w_out;
+    HAB_TRY(conv_wgrad(cd, comp_in, d_raw, e->g(r->comp.i_w), nullptr, ws, e->ws_floats, s));
+    float* d_out = gp.get();  // gradient wrt the last block's output (pre ReLU mask)
+    HAB_TRY(conv_dgrad(cd, d_raw, e->PK + r->comp.pk_d, nullptr, nullptr, d_out, ws, e->ws_floats, s));
+    gp.put(d_raw);
+    // blocks, last to first
+    for (int bi = (int)r->blocks.size() - 1; bi >= 0; --bi) {
+        const RnBlock& blk = r->blocks[bi];
+        const int n = (int)blk.convs.size();
+        const float* in = W + blk.w_in;
+        const float* out = W + blk.w_out;
+        float* d_pre = gp.get();
+        float* cur = gp.get();
+        if (!d_pre || !cur) return HAB_ERR_ARG;
+        HAB_TRY(gn_backward(e, r->convs[blk.convs[n - 1]], d_out, out, cur, d_pre, B, s));
+        gp.put(d_out);
+        for (int q = n - 1; q >= 1; --q) {
+            const RnConv& c = r->convs[blk.convs[q]];
+            const RnConv& pc = r->convs[blk.convs[q - 1]];
+            ConvDesc c2 = c.cd;
+            c2.B = B;
+            HAB_TRY(conv_wgrad(c2, W + pc.w_out, cur, e->g(c.i_w), nullptr, ws, e->ws_floats, s));
+            float* tmp = gp.get();
+            if (!tmp) return HAB_ERR_ARG;
+            HAB_TRY(conv_dgrad(c2, cur, e->PK + c.pk_d, W + pc.w_out /* ReLU mask */, nullptr, tmp, ws, e->ws_floats, s));
+            gp.put(cur);
+            float* nxt = gp.get();
+            if (!nxt) return HAB_ERR_ARG;
+            HAB_TRY(gn_backward(e, pc, tmp, nullptr, nxt, nullptr, B, s));
+            gp.put(tmp);
+            cur = nxt;
+        }
+        const float* add_ptr = d_pre;
+        if (blk.ds >= 0) {
+            const RnConv& dc = r->convs[blk.ds];
+            float* t1 = gp.get();
+            if (!t1) return HAB_ERR_ARG;
+            HAB_TRY(gn_backward(e, dc, d_pre, nullptr, t1, nullptr, B, s));
+            ConvDesc c2 = dc.cd;
+            c2.B = B;
+            HAB_TRY(conv_wgrad(c2, in, t1, e->g(dc.i_w), nullptr, ws, e->ws_floats, s));
+            float* t2 = gp.get();
+            if (!t2) return HAB_ERR_ARG;
+            HAB_TRY(conv_dgrad(c2, t1, e->PK + dc.pk_d, nullptr, nullptr, t2, ws, e->ws_floats, s));
+            gp.put(t1);
+            gp.put(d_pre);
+            add_ptr = t2;
+        }
+        const RnConv& c0 = r->convs[blk.convs[0]];
+        ConvDesc c2 = c0.cd;
+        c2.B = B;
+        HAB_TRY(conv_wgrad(c2, in, cur, e->g(c0.i_w), nullptr, ws, e->ws_floats, s));
+        float* d_in = gp.get();
+        if (!d_in) return HAB_ERR_ARG;
+        HAB_TRY(conv_dgrad(c2, cur, e->PK + c0.pk_d, nullptr, add_ptr, d_in, ws, e->ws_floats, s));
+        gp.put(cur);
+        gp.put(add_ptr);
+        d_out = d_in;
+    }
+    // maxpool + stem
+    float* d_n0 = W + r->w_gstem[0];
+    float* d_raw0 = W + r->w_gstem[1];
+    HAB_TRY(maxpool_backward(d_out, reinterpret_cast<const uint8_t*>(W + r->w_pool_idx), d_n0, B, r->stem.cd.Ho(), r->stem.cd.Wo(),
+                             r->stem.cd.Cout, s));
+    HAB_TRY(gn_backward(e, r->stem, d_n0, W + r->stem.w_out, d_raw0, nullptr, B, s));
+    ConvDesc c0 = r->stem.cd;
+    c0.B = B;
+    HAB_TRY(conv_wgrad(c0, W + r->w_x0, d_raw0, e->g(r->stem.i_w), nullptr, ws, e->ws_floats, s));
+    return HAB_OK;
+}
+
+int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats) {
+    ResNetPlan* r = e->rn;
+    float* W = e->WK;
+    const int64_t B = e->last_B;
+    switch (which) {
+        case HAB_TAP_ENC_IN: *ptr = W + r->w_x0; *floats = B * r->H2 * r->W2 * r->cpad; return HAB_OK;
+        case HAB_TAP_STEM: *ptr = W + r->stem.w_out; *floats = B * r->stem.out_floats(); return HAB_OK;
+        case HAB_TAP_POOL: *ptr = W + r->w_pool; *floats = B * r->poolH * r->poolW * r->stem.cd.Cout; return HAB_OK;
+        case HAB_TAP_COMPRESSION: *ptr = W + r->comp.w_out; *floats = B * r->comp.out_floats(); return HAB_OK;
+        default: break;
+    }
+    if (which >= HAB_TAP_LAYER1 && which < HAB_TAP_LAYER1 + 4) {
+        // last block of stage (which - HAB_TAP_LAYER1)
+        static const int L18[4] = {2, 2, 2, 2}, L50[4] = {3, 4, 6, 3};
+        const int* layers = e->d.backbone == 50 ? L50 : L18;
+        int idx = -1;
+        for (int li = 0; li <= which - HAB_TAP_LAYER1; ++li) idx += layers[li];
+        const RnBlock& blk = r->blocks[idx];
+        *ptr = W + blk.w_out;
+        *floats = B * r->convs[blk.convs.back()].out_floats();
+        return HAB_OK;
+    }
+    return HAB_ERR_ARG;
+}

@@ -104,26 +104,30 @@ int linear_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, 
 // Column sums (bias gradients): out[n] = sum_m a[m][n] * (mask ? mask[m][n] > 0 : 1).
 // Stage 1: each block reduces a row range into partial[block][N]; stage 2: fixed-order sum.
 // ---------------------------------------------------------------------------------------------
+// grid = (column blocks of cw = min(64, N) columns, row chunks); 256 threads = (256 / cw) row lanes x cw columns.
 __global__ void __launch_bounds__(256) colsum_stage1(const float* __restrict__ a, int lda, int M, int N, int rows_per_block,
                                                      float* __restrict__ partial) {
-    // thread layout: 256 threads = (256/cw) row lanes x cw columns, cw = min(N rounded, 64)
     const int cw = N < 64 ? N : 64;
     const int rl = 256 / cw;
     const int c = threadIdx.x % cw, r = threadIdx.x / cw;
+    const int n = blockIdx.x * cw + c;
     __shared__ float sm[256];
-    const int m_begin = blockIdx.x * rows_per_block, m_end = min(M, m_begin + rows_per_block);
-    for (int c0 = 0; c0 < N; c0 += cw) {
-        float s = 0.f;
-        if (r < rl && c0 + c < N)
-            for (int m = m_begin + r; m < m_end; m += rl) s += a[(size_t)m * lda + c0 + c];
-        sm[threadIdx.x] = (r < rl) ? s : 0.f;
-        __syncthreads();
-        if (r == 0 && c0 + c < N) {
-            float t = 0.f;
-            for (int q = 0; q < rl; ++q) t += sm[q * cw + c];
-            partial[(size_t)blockIdx.x * N + c0 + c] = t;
+    const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
+    float s0 = 0.f, s1 = 0.f;
+    if (r < rl && n < N) {
+        int m = m_begin + r;
+        for (; m + rl < m_end; m += 2 * rl) {
+            s0 += a[(size_t)m * lda + n];
+            s1 += a[(size_t)(m + rl) * lda + n];
         }
-        __syncthreads();
+        if (m < m_end) s0 += a[(size_t)m * lda + n];
+    }
+    sm[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (r == 0 && n < N) {
+        float t = 0.f;
+        for (int q = 0; q < rl; ++q) t += sm[q * cw + c];
+        partial[(size_t)blockIdx.y * N + n] = t;
     }
 }
 __global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ partial, int nblocks, int N, float* __restrict__ out,
@@ -145,15 +149,18 @@ __global__ void __launch_bounds__(256) colsum_stage2(const float* __restrict__ p
 
 int colsum(const float* a, int lda, int M, int N, float* out, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
     if (M <= 0 || N <= 0 || !a || !out || !ws) return HAB_ERR_ARG;
-    int blocks = cdiv(M, 512);
-    if (blocks > 1024) blocks = 1024;
-    while (blocks > 1 && (size_t)blocks * N > ws_floats) blocks >>= 1;
-    if ((size_t)blocks * N > ws_floats) return HAB_ERR_ARG;
-    const int rpb = cdiv(M, blocks);
-    blocks = cdiv(M, rpb);
-    colsum_stage1<<<blocks, 256, 0, stream>>>(a, lda, M, N, rpb, ws);
+    const int cw = N < 64 ? N : 64;
+    const int colblocks = cdiv(N, cw);
+    // enough row chunks for ~1024 workgroups, at least 16 rows each
+    int chunks = cdiv(1024, colblocks);
+    if (chunks > cdiv(M, 16)) chunks = cdiv(M, 16);
+    while (chunks > 1 && (size_t)chunks * N > ws_floats) chunks >>= 1;
+    if ((size_t)chunks * N > ws_floats) return HAB_ERR_ARG;
+    const int rpb = cdiv(M, chunks);
+    chunks = cdiv(M, rpb);
+    colsum_stage1<<<dim3(colblocks, chunks), 256, 0, stream>>>(a, lda, M, N, rpb, ws);
     HAB_LAUNCH_CHECK();
-    colsum_stage2<<<cdiv(N, 64), 256, 0, stream>>>(ws, blocks, N, out, accumulate);
+    colsum_stage2<<<cdiv(N, 64), 256, 0, stream>>>(ws, chunks, N, out, accumulate);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }

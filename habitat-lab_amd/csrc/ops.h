@@ -6,6 +6,7 @@ namespace hab {
 
 struct ConvDesc {
     int B, H, W, C, Cout, KH, KW, stride, pad;
+    int Creal = 0;  // weight-gradient only: number of real input channels when C is zero-padded (0 = C)
     int Ho() const { return (H + 2 * pad - KH) / stride + 1; }
     int Wo() const { return (W + 2 * pad - KW) / stride + 1; }
 };

@@ -63,6 +63,7 @@ inline int build(ConvWgradProb& p, const ConvDesc& d, const float* x, const floa
     p.g = make_geom(d);
     p.M = d.KH * d.KW * d.C; p.N = d.Cout; p.K = d.B * p.g.Ho * p.g.Wo;
     p.x = x; p.dy = dy; p.dw = dw; p.colsum = dbias;
+    p.Creal = d.Creal > 0 ? d.Creal : d.C;
     return HAB_OK;
 }
 inline int build(ObsConvWgradProb& p, const ConvDesc& d, const ObsView& obs, const float* dy, float* dw, float* dbias = nullptr) {

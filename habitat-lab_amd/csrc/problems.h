@@ -396,8 +396,9 @@ struct ConvWgradProb {
     ConvGeom g;
     const float* x;
     const float* dy;
-    float* dw;      // OIHW
+    float* dw;      // OIHW with Creal input channels (Creal <= g.C: the stem conv reads a zero-padded input)
     float* colsum;  // bias gradient [Cout] (sum of dY over all pixels), or null
+    int Creal;
     HAB_HD void store_colsum(int j, float v) const { colsum[j] = v; }
     HAB_NO_KCTX
     struct ACtx { int kh, kw, ci; };
@@ -441,13 +442,14 @@ struct ConvWgradProb {
         int tap, ci, kh, kw;
         g.dC.divmod(r.ok ? i : 0, tap, ci);
         g.dKW.divmod(tap, kh, kw);
+        r.ok &= ci < Creal;
         r.off = (ci * g.KH + kh) * g.KW + kw;
         return r;
     }
     HAB_HD EpiAux epi_fetch(const EpiRow&, const EpiCol&) const { return EpiAux(); }
     HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux&, float v) const {
         if (!(r.ok & c.ok)) return;
-        dw[(size_t)c.n * g.C * g.KH * g.KW + r.off] = v;
+        dw[(size_t)c.n * Creal * g.KH * g.KW + r.off] = v;
     }
     HAB_GENERIC_STORE
 };

@@ -15,6 +15,7 @@ struct GnArgs {
 struct GnBwdArgs {
     const float* x; const float* dy; const float* relu_out;  // relu_out: output of the fused ReLU (mask), or null
     float* dx;
+    float* dy_masked;                   // optional: dy * (relu_out > 0) written out (gradient of the residual branch)
     const float* gamma; const float* mean; const float* rstd;
     float* chan_sums;                   // [B][2][C]: per-frame sum dy', sum dy'*xhat
     int B, HW, C, groups;
@@ -23,14 +24,16 @@ struct EmbedArgs {
     const float* goal; const int64_t* prev_actions; const uint8_t* masks; const int* rows;
     const float* w_t; const float* b_t; const float* emb;
     float* out; int ld, col0, B;
+    float* saved;  // [B][4]: rho, cos(-phi), sin(-phi), token (as float) -- kept for the backward pass
 };
 struct EmbedBwdArgs {
-    const float* goal; const int64_t* prev_actions; const uint8_t* masks; const int* rows;
+    const float* saved;  // [B][4] written by the forward
     const float* dout; int ld, col0, B, num_tokens;
     float* dw_t; float* db_t; float* demb;
 };
 
-int ingest_pool(const uint8_t* rgb, const float* depth, const int* rows, float* y, int B, int H, int W, int cpad, hipStream_t s);
+int ingest_pool(const uint8_t* rgb, const float* depth, const int* rows, float* y, int B, int H, int W, int cpad, int depth_first,
+                hipStream_t s);
 int chan_moment(const float* x, long long npix, int cpad, int mode, const float* mean, float* out, double* scratch, int scratch_len,
                 hipStream_t s);
 int rmv_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C, hipStream_t s);

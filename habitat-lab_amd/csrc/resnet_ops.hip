@@ -15,7 +15,7 @@ namespace hab {
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
                                                           const int* __restrict__ rows, float* __restrict__ y, int B, int H, int W,
-                                                          int cpad) {
+                                                          int cpad, int depth_first) {
     const int Ho = H / 2, Wo = W / 2;
     const long long total = (long long)B * Ho * Wo;
     const float inv255 = (float)(1.0 / 255.0);
@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restr
         float out[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) out[c] = 0.f;
-        int nc = 0;
+        const int c_rgb = (depth && depth_first) ? 1 : 0, c_depth = (rgb && !depth_first) ? 3 : 0;
         if (rgb) {
             float s[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -40,8 +40,7 @@ __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restr
                     for (int c = 0; c < 3; ++c) s[c] = __fadd_rn(s[c], __fmul_rn((float)p[c], inv255));
                 }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) out[c] = __fmul_rn(s[c], 0.25f);
-            nc = 3;
+            for (int c = 0; c < 3; ++c) out[c_rgb + c] = __fmul_rn(s[c], 0.25f);
         }
         if (depth) {
             float s = 0.f;
@@ -49,17 +48,18 @@ __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restr
             for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
                 for (int dw = 0; dw < 2; ++dw) s = __fadd_rn(s, depth[(srow * H + 2 * ho + dh) * W + 2 * wo + dw]);
-            out[nc] = __fmul_rn(s, 0.25f);
+            out[c_depth] = __fmul_rn(s, 0.25f);
         }
         float* o = y + (size_t)e * cpad;
         for (int c = 0; c < cpad; c += 4) *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(out + c);
     }
 }
 
-int ingest_pool(const uint8_t* rgb, const float* depth, const int* rows, float* y, int B, int H, int W, int cpad, hipStream_t s) {
+int ingest_pool(const uint8_t* rgb, const float* depth, const int* rows, float* y, int B, int H, int W, int cpad, int depth_first,
+                hipStream_t s) {
     if ((!rgb && !depth) || !y || B <= 0 || (H & 1) || (W & 1) || (cpad != 4 && cpad != 8)) return HAB_ERR_ARG;
     const long long total = (long long)B * (H / 2) * (W / 2);
-    ingest_pool_kernel<<<(int)fmin(8192.0, (double)cdivl(total, 256)), 256, 0, s>>>(rgb, depth, rows, y, B, H, W, cpad);
+    ingest_pool_kernel<<<(int)fmin(8192.0, (double)cdivl(total, 256)), 256, 0, s>>>(rgb, depth, rows, y, B, H, W, cpad, depth_first);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -160,102 +160,129 @@ int rmv_normalize(float* x, long long npix, int cpad, int C, const float* mean, 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// GroupNorm (resnet.py:51-57,207-219; eps 1e-5) on NHWC.  One workgroup per frame.
-// forward : stats per (frame, group) by per-thread Welford + Chan merge; y = (x-mu)*rstd*gamma + beta
+// GroupNorm (resnet.py:51-57,207-219; eps 1e-5) on NHWC.  One workgroup (256 threads) per frame; the frame's
+// tensor (8 KB .. 512 KB) is read from HBM once and re-read from L2.
+// forward : two-pass statistics (mean, then squared deviations about it); y = (x-mu)*rstd*gamma + beta
 //           [+ residual] [ReLU].  mu / rstd saved for backward.
 // backward: dy' = dy * (relu_out > 0); per-channel sums S1 = sum dy', S2 = sum dy'*xhat are written per frame
 //           (reduced over frames afterwards -> dbeta, dgamma); dx = rstd*(g - mean_g(g) - xhat*mean_g(g*xhat)),
-//           g = dy'*gamma.
-// Thread mapping: C4 = C/4 float4 columns; thread t owns column (t % C4), pixels t / C4 + k * (256 / C4).
+//           g = dy'*gamma.  Optionally dy' itself is written out (gradient of the residual branch).
+// Thread mapping: C4 = C/4 float4 columns.  C4 <= 256: thread t owns column t % C4 and pixel lane t / C4 of
+// np = 256 / C4; C4 > 256: thread t owns columns t, t+256, ... and all pixels.  Reductions are fixed-order.
 // ------------------------------------------------------------------------------------------------------
-struct WF { float n, mean, m2; };
-__device__ inline void wf_add(WF& a, float x) {
-    a.n += 1.f;
-    const float d = x - a.mean;
-    a.mean += d / a.n;
-    a.m2 += d * (x - a.mean);
-}
-__device__ inline WF wf_merge(const WF& a, const WF& b) {
-    if (b.n == 0.f) return a;
-    if (a.n == 0.f) return b;
-    WF r;
-    r.n = a.n + b.n;
-    const float d = b.mean - a.mean;
-    r.mean = a.mean + d * (b.n / r.n);
-    r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
-    return r;
+struct GnMap {
+    int C4, np, ncc;  // float4 columns, pixel lanes, column chunks
+    __device__ GnMap(int C) { C4 = C >> 2; np = C4 >= 256 ? 1 : 256 / C4; ncc = C4 >= 256 ? C4 / 256 : 1; }
+    __device__ int col(int t, int cc) const { return C4 >= 256 ? cc * 256 + t : t % C4; }
+    __device__ int lane(int t) const { return C4 >= 256 ? 0 : t / C4; }
+};
+
+// per-channel reduction over the pixel lanes: red[t*4+k] (this chunk) -> ch[c]
+__device__ inline void gn_fold(const GnMap& m, int cc, const float* red, float* ch, int t) {
+    const int cols = m.C4 >= 256 ? 256 : m.C4;
+    for (int c = t; c < cols * 4; c += 256) {
+        const int c4 = c >> 2, k = c & 3;
+        float u = 0.f;
+        for (int q = 0; q < m.np; ++q) u += red[(q * cols + c4) * 4 + k];
+        ch[(m.C4 >= 256 ? cc * 1024 : 0) + c] = u;
+    }
 }
 
 __global__ void __launch_bounds__(256) groupnorm_fwd_kernel(const GnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int C = a.C, C4 = C >> 2, HW = a.HW, G = a.groups, cpg = C / G;
+    const int C = a.C, HW = a.HW, G = a.groups, cpg = C / G;
+    const GnMap m(C);
     const int f = blockIdx.x, t = threadIdx.x;
-    const int col = t % C4, pl = t / C4, np = 256 / C4;
+    const int pl = m.lane(t);
+    const bool act = pl < m.np;
+    float* red = sm;            // [256][4]
+    float* ch = sm + 1024;      // [C]
+    float* mu_s = ch + C;       // [G]
+    float* rs_s = mu_s + G;     // [G]
     const float* x = a.x + (size_t)f * HW * C;
-    // per-thread Welford per channel (4 channels)
-    WF w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { w[k].n = 0.f; w[k].mean = 0.f; w[k].m2 = 0.f; }
-    if (pl < np)
-        for (int p = pl; p < HW; p += np) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)p * C + col * 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wf_add(w[k], v[k]);
-        }
-    // fold the 4 channels of this thread if they belong to one group (cpg >= 4), else keep per channel
-    WF* red = reinterpret_cast<WF*>(sm);  // [256][4] worst case
-#pragma unroll
-    for (int k = 0; k < 4; ++k) red[t * 4 + k] = w[k];
+    const float inv_m = 1.0f / (float)(HW * cpg);
+    // pass 1: channel sums -> group means
+    for (int cc = 0; cc < m.ncc; ++cc) {
+        const int col = m.col(t, cc);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (act)
+            for (int p = pl; p < HW; p += m.np) s += *reinterpret_cast<const f32x4*>(x + (size_t)p * C + col * 4);
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(red + t * 4) = act ? s : f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        gn_fold(m, cc, red, ch, t);
+    }
     __syncthreads();
-    float* mu_s = sm + 256 * 4 * 3;       // [G]
-    float* rs_s = mu_s + G;               // [G]
     if (t < G) {
-        WF acc; acc.n = 0.f; acc.mean = 0.f; acc.m2 = 0.f;
-        const int c0 = t * cpg;
-        for (int c = c0; c < c0 + cpg; ++c) {
-            const int cc = c >> 2, k = c & 3;
-            for (int q = 0; q < np; ++q) acc = wf_merge(acc, red[(q * C4 + cc) * 4 + k]);
-        }
-        const float var = acc.m2 / acc.n;
-        mu_s[t] = acc.mean;
-        rs_s[t] = rsqrtf(var + a.eps);
-        a.mean[(size_t)f * G + t] = acc.mean;
-        a.rstd[(size_t)f * G + t] = rs_s[t];
+        float u = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) u += ch[c];
+        mu_s[t] = u * inv_m;
     }
     __syncthreads();
-    if (pl >= np) return;
-    float ga[4], be[4], mu[4], rs[4];
+    // pass 2: squared deviations -> rstd
+    for (int cc = 0; cc < m.ncc; ++cc) {
+        const int col = m.col(t, cc);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+            f32x4 mu;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = col * 4 + k, g = c / cpg;
-        ga[k] = a.gamma[c]; be[k] = a.beta[c]; mu[k] = mu_s[g]; rs[k] = rs_s[g];
+            for (int k = 0; k < 4; ++k) mu[k] = mu_s[(col * 4 + k) / cpg];
+            for (int p = pl; p < HW; p += m.np) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(x + (size_t)p * C + col * 4) - mu;
+                s += d * d;
+            }
+        }
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(red + t * 4) = act ? s : f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        gn_fold(m, cc, red, ch, t);
     }
+    __syncthreads();
+    if (t < G) {
+        float u = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) u += ch[c];
+        const float rs = rsqrtf(u * inv_m + a.eps);
+        rs_s[t] = rs;
+        a.mean[(size_t)f * G + t] = mu_s[t];
+        a.rstd[(size_t)f * G + t] = rs;
+    }
+    __syncthreads();
+    if (!act) return;
     float* y = a.y + (size_t)f * HW * C;
     const float* res = a.residual ? a.residual + (size_t)f * HW * C : nullptr;
-    for (int p = pl; p < HW; p += np) {
-        const size_t o = (size_t)p * C + col * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + o);
+    for (int cc = 0; cc < m.ncc; ++cc) {
+        const int col = m.col(t, cc);
+        f32x4 sc, sh;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (v[k] - mu[k]) * rs[k] * ga[k] + be[k];
-        if (res) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(res + o);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += r[k];
+        for (int k = 0; k < 4; ++k) {
+            const int c = col * 4 + k, g = c / cpg;
+            sc[k] = rs_s[g] * a.gamma[c];
+            sh[k] = a.beta[c] - mu_s[g] * sc[k];
         }
-        if (a.relu) {
+        for (int p = pl; p < HW; p += m.np) {
+            const size_t o = (size_t)p * C + col * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + o) * sc + sh;
+            if (res) v += *reinterpret_cast<const f32x4*>(res + o);
+            if (a.relu) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(y + o) = v;
         }
-        *reinterpret_cast<f32x4*>(y + o) = v;
     }
 }
 
+static int gn_check(int B, int C, int groups) {
+    if (B <= 0 || C <= 0 || groups <= 0 || C % 4 || C % groups || groups > 256) return HAB_ERR_ARG;
+    const int C4 = C / 4;
+    if (C4 < 256 ? (256 % C4 != 0) : (C4 % 256 != 0)) return HAB_ERR_UNSUPPORTED;
+    return HAB_OK;
+}
+
 int groupnorm_forward(const GnArgs& a, hipStream_t s) {
-    if (!a.x || !a.y || !a.gamma || !a.beta || !a.mean || !a.rstd || a.B <= 0 || a.C % 4 || a.C > 1024 || a.C % a.groups ||
-        (256 % (a.C / 4) && a.C / 4 < 256))
-        return HAB_ERR_ARG;
-    if (a.C / 4 > 256) return HAB_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)(256 * 4 * 3 + 2 * a.groups) * sizeof(float);
+    if (!a.x || !a.y || !a.gamma || !a.beta || !a.mean || !a.rstd) return HAB_ERR_ARG;
+    HAB_TRY(gn_check(a.B, a.C, a.groups));
+    const size_t lds = (size_t)(1024 + a.C + 2 * a.groups) * sizeof(float);
     groupnorm_fwd_kernel<<<a.B, 256, lds, s>>>(a);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
@@ -263,22 +290,76 @@ int groupnorm_forward(const GnArgs& a, hipStream_t s) {
 
 __global__ void __launch_bounds__(256) groupnorm_bwd_kernel(const GnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int C = a.C, C4 = C >> 2, HW = a.HW, G = a.groups, cpg = C / G;
+    const int C = a.C, HW = a.HW, G = a.groups, cpg = C / G;
+    const GnMap m(C);
     const int f = blockIdx.x, t = threadIdx.x;
-    const int col = t % C4, pl = t / C4, np = 256 / C4;
+    const int pl = m.lane(t);
+    const bool act = pl < m.np;
+    float* red = sm;            // [256][4]
+    float* c1 = sm + 1024;      // [C]  per-channel S1
+    float* c2 = c1 + C;         // [C]  per-channel S2
+    float* g1 = c2 + C;         // [G]  mean_g(g), mean_g(g*xhat)
+    float* g2 = g1 + G;
     const size_t base = (size_t)f * HW * C;
     const float* x = a.x + base;
     const float* dy = a.dy + base;
     const float* ro = a.relu_out ? a.relu_out + base : nullptr;
-    float mu[4], rs[4], ga[4];
+    float* dym = a.dy_masked ? a.dy_masked + base : nullptr;
+    const float* mean = a.mean + (size_t)f * G;
+    const float* rstd = a.rstd + (size_t)f * G;
+    for (int cc = 0; cc < m.ncc; ++cc) {
+        const int col = m.col(t, cc);
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+            f32x4 mu, rs;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = col * 4 + k, g = c / cpg;
-        mu[k] = a.mean[(size_t)f * G + g]; rs[k] = a.rstd[(size_t)f * G + g]; ga[k] = a.gamma[c];
+            for (int k = 0; k < 4; ++k) { const int g = (col * 4 + k) / cpg; mu[k] = mean[g]; rs[k] = rstd[g]; }
+            for (int p = pl; p < HW; p += m.np) {
+                const size_t o = (size_t)p * C + col * 4;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+                f32x4 dv = *reinterpret_cast<const f32x4*>(dy + o);
+                if (ro) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(ro + o);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dv[k] = rv[k] > 0.f ? dv[k] : 0.f;
+                }
+                if (dym) *reinterpret_cast<f32x4*>(dym + o) = dv;
+                s1 += dv;
+                s2 += dv * ((xv - mu) * rs);
+            }
+        }
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(red + t * 4) = act ? s1 : f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        gn_fold(m, cc, red, c1, t);
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(red + t * 4) = act ? s2 : f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        gn_fold(m, cc, red, c2, t);
     }
-    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    if (pl < np)
-        for (int p = pl; p < HW; p += np) {
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+        a.chan_sums[((size_t)f * 2 + 0) * C + c] = c1[c];   // -> dbeta after the reduction over frames
+        a.chan_sums[((size_t)f * 2 + 1) * C + c] = c2[c];   // -> dgamma
+    }
+    if (t < G) {
+        float u = 0.f, v = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { u += a.gamma[c] * c1[c]; v += a.gamma[c] * c2[c]; }
+        const float inv_m = 1.0f / (float)(HW * cpg);
+        g1[t] = u * inv_m; g2[t] = v * inv_m;
+    }
+    __syncthreads();
+    if (!act) return;
+    float* dx = a.dx + base;
+    for (int cc = 0; cc < m.ncc; ++cc) {
+        const int col = m.col(t, cc);
+        f32x4 mu, rs, ga, m1, m2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = col * 4 + k, g = c / cpg;
+            mu[k] = mean[g]; rs[k] = rstd[g]; ga[k] = a.gamma[c]; m1[k] = g1[g]; m2[k] = g2[g];
+        }
+        for (int p = pl; p < HW; p += m.np) {
             const size_t o = (size_t)p * C + col * 4;
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
             f32x4 dv = *reinterpret_cast<const f32x4*>(dy + o);
@@ -287,63 +368,17 @@ __global__ void __launch_bounds__(256) groupnorm_bwd_kernel(const GnBwdArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) dv[k] = rv[k] > 0.f ? dv[k] : 0.f;
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { s1[k] += dv[k]; s2[k] += dv[k] * (xv[k] - mu[k]) * rs[k]; }
+            const f32x4 xh = (xv - mu) * rs;
+            *reinterpret_cast<f32x4*>(dx + o) = rs * (dv * ga - m1 - xh * m2);
         }
-    float* r1 = sm;             // [256][4]
-    float* r2 = sm + 1024;      // [256][4]
-    float* c1 = sm + 2048;      // [C]  per-channel S1
-    float* c2 = c1 + C;         // [C]
-    float* g1 = c2 + C;         // [G]  mean_g(g), mean_g(g*xhat)
-    float* g2 = g1 + G;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { r1[t * 4 + k] = s1[k]; r2[t * 4 + k] = s2[k]; }
-    __syncthreads();
-    for (int c = t; c < C; c += 256) {
-        const int cc = c >> 2, k = c & 3;
-        float u = 0.f, v = 0.f;
-        for (int q = 0; q < np; ++q) { u += r1[(q * C4 + cc) * 4 + k]; v += r2[(q * C4 + cc) * 4 + k]; }
-        c1[c] = u; c2[c] = v;
-        a.chan_sums[((size_t)f * 2 + 0) * C + c] = u;   // -> dbeta after the reduction over frames
-        a.chan_sums[((size_t)f * 2 + 1) * C + c] = v;   // -> dgamma
-    }
-    __syncthreads();
-    if (t < G) {
-        float u = 0.f, v = 0.f;
-        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { u += a.gamma[c] * c1[c]; v += a.gamma[c] * c2[c]; }
-        const float inv_m = 1.0f / (float)(HW * cpg);
-        g1[t] = u * inv_m; g2[t] = v * inv_m;
-    }
-    __syncthreads();
-    if (pl >= np) return;
-    float m1[4], m2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const int g = (col * 4 + k) / cpg; m1[k] = g1[g]; m2[k] = g2[g]; }
-    float* dx = a.dx + base;
-    for (int p = pl; p < HW; p += np) {
-        const size_t o = (size_t)p * C + col * 4;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
-        f32x4 dv = *reinterpret_cast<const f32x4*>(dy + o);
-        if (ro) {
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(ro + o);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) dv[k] = rv[k] > 0.f ? dv[k] : 0.f;
-        }
-        f32x4 out;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float xh = (xv[k] - mu[k]) * rs[k];
-            out[k] = rs[k] * (dv[k] * ga[k] - m1[k] - xh * m2[k]);
-        }
-        *reinterpret_cast<f32x4*>(dx + o) = out;
     }
 }
 
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s) {
-    if (!a.x || !a.dy || !a.dx || !a.gamma || !a.mean || !a.rstd || !a.chan_sums || a.B <= 0 || a.C % 4 || a.C % a.groups)
-        return HAB_ERR_ARG;
-    if (a.C / 4 > 256 || (256 % (a.C / 4))) return HAB_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)(2048 + 2 * a.C + 2 * a.groups) * sizeof(float);
+    if (!a.x || !a.dy || !a.dx || !a.gamma || !a.mean || !a.rstd || !a.chan_sums) return HAB_ERR_ARG;
+    if (a.dx == a.dy && a.dy_masked) return HAB_ERR_ARG;
+    HAB_TRY(gn_check(a.B, a.C, a.groups));
+    const size_t lds = (size_t)(1024 + 2 * a.C + 2 * a.groups) * sizeof(float);
     groupnorm_bwd_kernel<<<a.B, 256, lds, s>>>(a);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
@@ -432,14 +467,17 @@ __global__ void embed_fwd_kernel(const EmbedArgs a) {
     if (f >= a.B) return;
     const int r = a.rows ? a.rows[f] : f;
     float* o = a.out + (size_t)f * a.ld + a.col0;
+    const int tok = a.masks[r] ? (int)a.prev_actions[r] + 1 : 0;
+    const float rho = a.goal[(size_t)r * 2], phi = a.goal[(size_t)r * 2 + 1];
+    const float g0 = rho, g1 = cosf(-phi), g2 = sinf(-phi);
     if (j < 32) {
-        const float rho = a.goal[(size_t)r * 2], phi = a.goal[(size_t)r * 2 + 1];
-        const float g0 = rho, g1 = cosf(-phi), g2 = sinf(-phi);
         o[j] = (a.w_t[j * 3] * g0 + a.w_t[j * 3 + 1] * g1) + a.w_t[j * 3 + 2] * g2 + a.b_t[j];
     } else {
-        const int jj = j - 32;
-        const int tok = a.masks[r] ? (int)a.prev_actions[r] + 1 : 0;
-        o[j] = a.emb[(size_t)tok * 32 + jj];
+        o[j] = a.emb[(size_t)tok * 32 + (j - 32)];
+    }
+    if (j == 0 && a.saved) {
+        float* sv = a.saved + (size_t)f * 4;
+        sv[0] = g0; sv[1] = g1; sv[2] = g2; sv[3] = (float)tok;
     }
 }
 int embed_forward(const EmbedArgs& a, hipStream_t s) {
@@ -449,35 +487,26 @@ int embed_forward(const EmbedArgs& a, hipStream_t s) {
     return HAB_OK;
 }
 
-// grid = 4 (w_t rows by gate g in 0..2 -> 3 blocks of 32 threads for dW_t[:, g], 1 for db_t) + (A+1) embedding rows
+// grid = 4 (dW_t[:, g] for g = 0..2, db_t) + (A+1) embedding rows; fixed-order frame loops (deterministic)
 __global__ void __launch_bounds__(64) embed_bwd_kernel(const EmbedBwdArgs a) {
     const int b = blockIdx.x, j = threadIdx.x;
     if (j >= 32) return;
     float s = 0.f;
     if (b < 4) {
         for (int f = 0; f < a.B; ++f) {
-            const int r = a.rows ? a.rows[f] : f;
             const float d = a.dout[(size_t)f * a.ld + a.col0 + j];
-            float g = 1.f;
-            if (b < 3) {
-                const float rho = a.goal[(size_t)r * 2], phi = a.goal[(size_t)r * 2 + 1];
-                g = b == 0 ? rho : (b == 1 ? cosf(-phi) : sinf(-phi));
-            }
-            s += d * g;
+            s += b < 3 ? d * a.saved[(size_t)f * 4 + b] : d;
         }
         if (b < 3) a.dw_t[j * 3 + b] = s; else a.db_t[j] = s;
     } else {
-        const int tok = b - 4;
-        for (int f = 0; f < a.B; ++f) {
-            const int r = a.rows ? a.rows[f] : f;
-            const int tk = a.masks[r] ? (int)a.prev_actions[r] + 1 : 0;
-            if (tk == tok) s += a.dout[(size_t)f * a.ld + a.col0 + 32 + j];
-        }
-        a.demb[(size_t)tok * 32 + j] = s;
+        const float tok = (float)(b - 4);
+        for (int f = 0; f < a.B; ++f)
+            if (a.saved[(size_t)f * 4 + 3] == tok) s += a.dout[(size_t)f * a.ld + a.col0 + 32 + j];
+        a.demb[(size_t)(b - 4) * 32 + j] = s;
     }
 }
 int embed_backward(const EmbedBwdArgs& a, hipStream_t s) {
-    if (!a.dout || !a.dw_t || !a.db_t || !a.demb || a.B <= 0) return HAB_ERR_ARG;
+    if (!a.saved || !a.dout || !a.dw_t || !a.db_t || !a.demb || a.B <= 0) return HAB_ERR_ARG;
     embed_bwd_kernel<<<4 + a.num_tokens, 64, 0, s>>>(a);
     HAB_LAUNCH_CHECK();
     return HAB_OK;

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhabitat_amd.so")
 
 vp = c_void_p
+ALLREDUCE_FN = C.CFUNCTYPE(None, c_void_p, c_int, c_float, c_void_p)  # hab_allreduce_fn
 
 
 class HabError(RuntimeError):
@@ -22,7 +23,7 @@ class HabError(RuntimeError):
 class PolicyDesc(C.Structure):
     _fields_ = [(n, c_int32) for n in (
         "arch", "backbone", "baseplanes", "normalize_visual_inputs", "rnn_type", "rnn_layers", "hidden", "num_actions",
-        "H", "W", "has_rgb", "has_depth", "goal_dim", "max_frames", "max_envs")]
+        "H", "W", "has_rgb", "has_depth", "goal_dim", "max_frames", "max_envs", "depth_first")]
 
 
 class Obs(C.Structure):
@@ -63,6 +64,9 @@ SIGNATURES = {
     "hab_policy_destroy": (None, [vp]),
     "hab_policy_num_params": (c_int, [vp]),
     "hab_policy_param_info": (c_int, [vp, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
+    "hab_policy_param_is_buffer": (c_int, [vp, c_int]),
+    "hab_policy_set_training": (c_int, [vp, c_int]),
+    "hab_policy_set_allreduce": (c_int, [vp, ALLREDUCE_FN, vp, c_int]),
     "hab_policy_param_floats": (c_int64, [vp]),
     "hab_policy_packed_floats": (c_int64, [vp]),
     "hab_policy_work_floats": (c_int64, [vp]),

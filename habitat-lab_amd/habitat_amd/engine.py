@@ -74,11 +74,11 @@ class DevicePackInfo:
 class PolicyEngine:
     def __init__(self, *, arch="simple_cnn", backbone=18, baseplanes=32, normalize_visual_inputs=False, rnn_type="GRU",
                  rnn_layers=1, hidden=512, num_actions=4, H=256, W=256, has_rgb=True, has_depth=True, goal_dim=2,
-                 max_frames=4096, max_envs=64, device="cuda", with_grads=True):
+                 max_frames=4096, max_envs=64, device="cuda", with_grads=True, depth_first=False):
         L = _lib.lib()
         self.L = L
         d = PolicyDesc(ARCH[arch], backbone, baseplanes, int(normalize_visual_inputs), RNN[rnn_type.upper()], rnn_layers, hidden,
-                       num_actions, H, W, int(has_rgb), int(has_depth), goal_dim, max_frames, max_envs)
+                       num_actions, H, W, int(has_rgb), int(has_depth), goal_dim, max_frames, max_envs, int(depth_first))
         self.desc = d
         h = C.c_void_p()
         check(L.hab_policy_create(C.byref(d), C.byref(h)), "hab_policy_create")
@@ -96,6 +96,7 @@ class PolicyEngine:
         for i in range(n):
             check(L.hab_policy_param_info(h, i, name, 256, shape, C.byref(nd), C.byref(off)), "hab_policy_param_info")
             self.specs.append((name.value.decode(), tuple(int(shape[k]) for k in range(nd.value)), int(off.value)))
+        self.buffer_names = {self.specs[i][0] for i in range(n) if L.hab_policy_param_is_buffer(h, i) == 1}
         dev = self.device
         self.params_flat = torch.zeros(self.param_floats, dtype=torch.float32, device=dev)
         self.grads_flat = torch.zeros(self.param_floats, dtype=torch.float32, device=dev) if with_grads else None
@@ -130,6 +131,20 @@ class PolicyEngine:
 
     def state(self) -> Dict[str, torch.Tensor]:
         return OrderedDict((k, v.detach().clone()) for k, v in self.views.items())
+
+    def set_training(self, mode: bool):
+        check(self.L.hab_policy_set_training(self.h, int(bool(mode))), "hab_policy_set_training")
+
+    def set_allreduce(self, fn, world_size: int):
+        """fn(tensor_view, scale): in-place all-reduce of a small fp32 view of the workspace (DD-PPO RunningMeanAndVar)."""
+        base = self.work.data_ptr()
+
+        def _cb(buf, n, scale, _ctx):
+            off = (buf - base) // 4
+            fn(self.work[off:off + n], scale)
+
+        self._allreduce_cb = _lib.ALLREDUCE_FN(_cb)  # keep the trampoline alive
+        check(self.L.hab_policy_set_allreduce(self.h, self._allreduce_cb, None, int(world_size)), "hab_policy_set_allreduce")
 
     def repack(self):
         check(self.L.hab_policy_repack(self.h, stream_ptr()), "hab_policy_repack")

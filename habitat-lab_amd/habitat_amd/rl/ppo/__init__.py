@@ -1,2 +1,3 @@
-from habitat_amd.rl.ppo.policy import NetPolicy, PointNavBaselinePolicy, Policy, PolicyActionData  # noqa: F401
+from habitat_amd.rl.ppo.policy import (NetPolicy, PointNavBaselinePolicy, PointNavResNetPolicy, Policy,  # noqa: F401
+                                       PolicyActionData)
 from habitat_amd.rl.ppo.ppo import PPO  # noqa: F401

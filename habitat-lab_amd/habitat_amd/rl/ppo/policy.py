@@ -104,15 +104,18 @@ class Policy(abc.ABC):
         pass
 
 
-def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
-    """Registers `param` under `dotted` ('a.b.0.weight'), creating bare container modules on the way."""
+def _attach(root: nn.Module, dotted: str, value, buffer: bool = False):
+    """Registers a parameter (or buffer) under `dotted` ('a.b.0.weight'), creating bare container modules on the way."""
     *path, leaf = dotted.split(".")
     m = root
     for p in path:
         if p not in m._modules:
             m.add_module(p, nn.Module())
         m = m._modules[p]
-    m.register_parameter(leaf, param)
+    if buffer:
+        m.register_buffer(leaf, value)
+    else:
+        m.register_parameter(leaf, value)
 
 
 class _EvaluateFn(torch.autograd.Function):
@@ -129,7 +132,7 @@ class _EvaluateFn(torch.autograd.Function):
     def backward(ctx, dv, dlp, dent):
         pol, call = ctx.policy, ctx.call
         pol._backward_dense(call, dv.contiguous().view(-1), dlp.contiguous().view(-1), dent.contiguous().view(-1))
-        grads = tuple(g.clone() for g in pol.engine.grad_views.values())
+        grads = tuple(g.clone() for k, g in pol.engine.grad_views.items() if k not in pol.engine.buffer_names)
         return (None, None) + grads
 
 
@@ -138,7 +141,7 @@ class NetPolicy(nn.Module, Policy):
 
     action_distribution_type = "categorical"
 
-    def __init__(self, action_space, engine_kwargs: dict, init_fn):
+    def __init__(self, action_space, engine_kwargs: dict, init_fn, buffer_names=()):
         Policy.__init__(self, action_space)
         nn.Module.__init__(self)
         self.dim_actions = get_num_actions(action_space)
@@ -150,7 +153,10 @@ class NetPolicy(nn.Module, Policy):
         self._rnn_layers = engine_kwargs["rnn_layers"]
         # CPU staging of the parameters in reference state_dict order, initialised like the reference.
         for name, value in init_fn().items():
-            _attach(self, name, nn.Parameter(value))
+            if name in buffer_names:
+                _attach(self, name, value, buffer=True)
+            else:
+                _attach(self, name, nn.Parameter(value))
         self.aux_loss_modules = nn.ModuleDict()
         self.train()
 
@@ -194,7 +200,7 @@ class NetPolicy(nn.Module, Policy):
             raise _lib.HabError("habitat_amd policies cannot be moved off the GPU (no CPU execution path)")
         if self.engine is not None and self.device == device:
             return self
-        state = {k: v.detach() for k, v in self.named_parameters()}
+        state = {k: v.detach() for k, v in self.state_dict().items()}
         with torch.cuda.device(device):
             eng = PolicyEngine(device=device, **self._engine_kwargs)
         names = [s[0] for s in eng.specs]
@@ -208,10 +214,21 @@ class NetPolicy(nn.Module, Policy):
             m = self
             for p in path:
                 m = m._modules[p]
+            if nm in eng.buffer_names:
+                m._buffers[leaf] = eng.views[nm]
+                continue
             par = nn.Parameter(eng.views[nm])
             par.grad = eng.grad_views[nm]
             m._parameters[leaf] = par
         self.engine, self.device = eng, device
+        eng.set_training(self.training)
+        return self
+
+    def train(self, mode: bool = True):
+        """nn.Module.train / eval: the engine's RunningMeanAndVar only updates in training mode."""
+        super().train(mode)
+        if getattr(self, "engine", None) is not None:
+            self.engine.set_training(mode)
         return self
 
     def load_state_dict(self, state_dict, strict: bool = True):
@@ -230,6 +247,9 @@ class NetPolicy(nn.Module, Policy):
         rgb = observations["rgb"] if self._engine_kwargs["has_rgb"] else None
         depth = observations["depth"] if self._engine_kwargs["has_depth"] else None
         goal = observations[GOAL_UUID]
+        if goal.dtype != torch.float32 or (depth is not None and depth.dtype != torch.float32) or \
+                (rgb is not None and rgb.dtype != torch.uint8):
+            raise _lib.HabError("observations must be uint8 rgb / float32 depth / float32 pointgoal")
         for t in (rgb, depth, goal):
             if t is not None and not t.is_contiguous():
                 raise _lib.HabError("observation tensors must be contiguous NHWC")
@@ -383,4 +403,130 @@ class PointNavBaselinePolicy(NetPolicy):
         n_envs = int(hb.num_environments)
         return cls(observation_space=observation_space, action_space=action_space, hidden_size=ppo.hidden_size,
                    aux_loss_config=hb.rl.auxiliary_losses,
+                   max_frames=int(ppo.num_steps) * max(1, -(-n_envs // int(ppo.num_mini_batch))), max_envs=n_envs)
+
+
+def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, baseplanes, H, W, normalize):
+    """Parameter / buffer values exactly as PointNavResNetPolicy.__init__ produces them: the torch modules are created in
+    the reference's order (resnet_policy.py:389-396 embedding, :454-456 tgt_embeding, :578-585 ResNetEncoder [default
+    Conv2d / GroupNorm initialisers -- ResNetEncoder.layer_init is never called], :588-595 visual_fc, :597-602 state encoder
+    with orthogonal / zero init rnn_state_encoder.py:288-293), then CategoricalNet and CriticHead (policy.py:273-291)."""
+    out = {}
+    emb = nn.Embedding(num_actions + 1, 32)
+    out["net.prev_action_embedding.weight"] = emb.weight.detach()
+    tgt = nn.Linear(3, 32)
+    out["net.tgt_embeding.weight"], out["net.tgt_embeding.bias"] = tgt.weight.detach(), tgt.bias.detach()
+    ve = "net.visual_encoder."
+    if normalize:
+        out[ve + "running_mean_and_var._mean"] = torch.zeros(1, n_in, 1, 1)
+        out[ve + "running_mean_and_var._var"] = torch.zeros(1, n_in, 1, 1)
+        out[ve + "running_mean_and_var._count"] = torch.zeros(())
+    ng = baseplanes // 2
+    bottleneck = backbone == "resnet50"
+    expansion = 4 if bottleneck else 1
+    layers = [3, 4, 6, 3] if bottleneck else [2, 2, 2, 2]
+
+    def conv_gn(prefix_w, prefix_g, cin, cout, k, groups):
+        conv = nn.Conv2d(cin, cout, kernel_size=k, bias=False)
+        gn = nn.GroupNorm(groups, cout)
+        out[prefix_w + ".weight"] = conv.weight.detach()
+        out[prefix_g + ".weight"], out[prefix_g + ".bias"] = gn.weight.detach(), gn.bias.detach()
+
+    bb = ve + "backbone."
+    conv_gn(bb + "conv1.0", bb + "conv1.1", n_in, baseplanes, 7, ng)
+    inplanes = baseplanes
+    for li, nblocks in enumerate(layers):
+        planes = baseplanes * (2 ** li)
+        for bi in range(nblocks):
+            stride = 2 if (bi == 0 and li > 0) else 1
+            bp = f"{bb}layer{li + 1}.{bi}."
+            has_ds = bi == 0 and (stride != 1 or inplanes != planes * expansion)
+            # resnet.py:_make_layer builds the downsample modules BEFORE the block's own convs
+            ds = None
+            if has_ds:
+                ds = (nn.Conv2d(inplanes, planes * expansion, kernel_size=1, bias=False), nn.GroupNorm(ng, planes * expansion))
+            if not bottleneck:
+                conv_gn(bp + "convs.0", bp + "convs.1", inplanes, planes, 3, ng)
+                conv_gn(bp + "convs.3", bp + "convs.4", planes, planes, 3, ng)
+            else:
+                conv_gn(bp + "convs.0", bp + "convs.1", inplanes, planes, 1, ng)
+                conv_gn(bp + "convs.3", bp + "convs.4", planes, planes, 3, ng)
+                conv_gn(bp + "convs.6", bp + "convs.7", planes, planes * expansion, 1, ng)
+            if ds is not None:
+                out[bp + "downsample.0.weight"] = ds[0].weight.detach()
+                out[bp + "downsample.1.weight"], out[bp + "downsample.1.bias"] = ds[1].weight.detach(), ds[1].bias.detach()
+            inplanes = planes * expansion
+    fh, fw = int(np.ceil((H // 2) / 32.0)), int(np.ceil((W // 2) / 32.0))
+    ncomp = int(round(2048 / (fh * fw)))
+    conv_gn(ve + "compression.0", ve + "compression.1", inplanes, ncomp, 3, 1)
+    fc = nn.Linear(ncomp * fh * fw, hidden)
+    out["net.visual_fc.1.weight"], out["net.visual_fc.1.bias"] = fc.weight.detach(), fc.bias.detach()
+    rnn_cls = nn.LSTM if rnn_type == "LSTM" else nn.GRU
+    rnn = rnn_cls(input_size=hidden + 64, hidden_size=hidden, num_layers=rnn_layers)
+    for name, param in rnn.named_parameters():
+        if "weight" in name:
+            nn.init.orthogonal_(param)
+        elif "bias" in name:
+            nn.init.constant_(param, 0)
+    for name, param in rnn.named_parameters():
+        out[f"net.state_encoder.rnn.{name}"] = param.detach()
+    lin = nn.Linear(hidden, num_actions)
+    nn.init.orthogonal_(lin.weight, gain=0.01)
+    nn.init.constant_(lin.bias, 0)
+    out["action_distribution.linear.weight"], out["action_distribution.linear.bias"] = lin.weight.detach(), lin.bias.detach()
+    fcv = nn.Linear(hidden, 1)
+    nn.init.orthogonal_(fcv.weight)
+    nn.init.constant_(fcv.bias, 0)
+    out["critic.fc.weight"], out["critic.fc.bias"] = fcv.weight.detach(), fcv.bias.detach()
+    return out
+
+
+@baseline_registry.register_policy
+class PointNavResNetPolicy(NetPolicy):
+    """GroupNorm-ResNet + GRU/LSTM policy (rl/ddppo/policy/resnet_policy.py:50-162,391-767) on the HIP engine.
+    Supported on the accelerated path: backbones resnet18 / resnet50, rgb and/or depth visual sensors, the
+    pointgoal_with_gps_compass goal (2-D polar), discrete actions."""
+
+    def __init__(self, observation_space, action_space, hidden_size: int = 512, num_recurrent_layers: int = 1,
+                 rnn_type: str = "GRU", resnet_baseplanes: int = 32, backbone: str = "resnet18",
+                 normalize_visual_inputs: bool = False, force_blind_policy: bool = False, policy_config=None,
+                 aux_loss_config=None, fuse_keys=None, max_frames: int = 4096, max_envs: int = 64, **kwargs):
+        sp = observation_space.spaces
+        if backbone not in ("resnet18", "resnet50"):
+            raise _lib.HabError(f"backbone {backbone!r} is outside the accelerated path (resnet18 / resnet50)")
+        if force_blind_policy or aux_loss_config:
+            raise _lib.HabError("blind policies / auxiliary losses are outside the accelerated path")
+        if policy_config is not None and getattr(policy_config, "action_distribution_type", "categorical") != "categorical":
+            raise _lib.HabError("Gaussian action heads are outside the accelerated path")
+        visual_keys = [k for k, v in sp.items() if len(v.shape) > 1]  # observation-space order (resnet_policy.py:178-182)
+        other = [k for k in sp.keys() if k not in visual_keys and k != GOAL_UUID]
+        if any(k not in ("rgb", "depth") for k in visual_keys) or not visual_keys or other or GOAL_UUID not in sp:
+            raise _lib.HabError(f"PointNavResNetPolicy on habitat_amd supports rgb/depth + '{GOAL_UUID}' (got {list(sp.keys())})")
+        has_rgb, has_depth = "rgb" in visual_keys, "depth" in visual_keys
+        vis = sp[visual_keys[0]]
+        H, W = int(vis.shape[0]), int(vis.shape[1])
+        n_in = (3 if has_rgb else 0) + (1 if has_depth else 0)
+        na = get_num_actions(action_space)
+        rnn_type = rnn_type.upper()
+        bufs = tuple("net.visual_encoder.running_mean_and_var." + k for k in ("_mean", "_var", "_count")) if normalize_visual_inputs else ()
+        super().__init__(action_space,
+                         dict(arch="resnet", backbone=int(backbone[6:]), baseplanes=resnet_baseplanes,
+                              normalize_visual_inputs=bool(normalize_visual_inputs), rnn_type=rnn_type,
+                              rnn_layers=num_recurrent_layers, hidden=hidden_size, H=H, W=W, has_rgb=has_rgb, has_depth=has_depth,
+                              goal_dim=2, max_frames=max_frames, max_envs=max_envs,
+                              depth_first=bool(has_rgb and has_depth and visual_keys[0] == "depth")),
+                         lambda: _resnet_init(n_in, hidden_size, na, rnn_type, num_recurrent_layers, backbone, resnet_baseplanes,
+                                              H, W, normalize_visual_inputs),
+                         buffer_names=bufs)
+
+    @classmethod
+    def from_config(cls, config, observation_space, action_space, **kwargs):
+        hb = config.habitat_baselines
+        ppo, dd = hb.rl.ppo, hb.rl.ddppo
+        n_envs = int(hb.num_environments)
+        return cls(observation_space=observation_space, action_space=action_space, hidden_size=ppo.hidden_size,
+                   rnn_type=dd.rnn_type, num_recurrent_layers=dd.num_recurrent_layers, backbone=dd.backbone,
+                   normalize_visual_inputs="rgb" in observation_space.spaces,
+                   force_blind_policy=getattr(hb, "force_blind_policy", False),
+                   aux_loss_config=getattr(hb.rl, "auxiliary_losses", None),
                    max_frames=int(ppo.num_steps) * max(1, -(-n_envs // int(ppo.num_mini_batch))), max_envs=n_envs)

@@ -168,6 +168,7 @@ typedef struct hab_policy_desc {
     int32_t goal_dim;      /* pointgoal_with_gps_compass dims (2) */
     int32_t max_frames;    /* largest T*n of an evaluate call */
     int32_t max_envs;      /* largest n of an act call */
+    int32_t depth_first;   /* arch 1: visual key order of the observation space: 0 = rgb,depth  1 = depth,rgb */
 } hab_policy_desc;
 
 typedef struct hab_obs {   /* arena base pointers; frame f lives at row rows[f] (or f) */
@@ -193,12 +194,21 @@ void hab_policy_destroy(hab_policy* p);
 int hab_policy_num_params(const hab_policy* p);
 int hab_policy_param_info(const hab_policy* p, int i, char* name, int name_cap, int64_t* shape4, int* ndim,
                           int64_t* offset_floats);
+/* 1 if entry i is a registered buffer of the reference module (RunningMeanAndVar statistics), 0 for a parameter. */
+int hab_policy_param_is_buffer(const hab_policy* p, int i);
 int64_t hab_policy_param_floats(const hab_policy* p);
 int64_t hab_policy_packed_floats(const hab_policy* p);
 int64_t hab_policy_work_floats(const hab_policy* p);
 /* All arenas 256-byte aligned device memory; grads may be NULL for inference-only use. */
 int hab_policy_bind(hab_policy* p, float* params, float* grads, float* packed, float* work, int64_t work_floats);
 int hab_policy_repack(hab_policy* p, hipStream_t stream);
+/* nn.Module.train()/eval(): RunningMeanAndVar updates its statistics only in training mode
+ * (rl/ddppo/policy/running_mean_and_var.py:24-25). */
+int hab_policy_set_training(hab_policy* p, int training);
+/* DD-PPO: in-place all-reduce (sum, then * scale) of n floats at device pointer buf, ordered on the engine's stream
+ * (running_mean_and_var.py:38-41,47-49).  The engine calls it during evaluate in training mode when world_size > 1. */
+typedef void (*hab_allreduce_fn)(float* buf, int n, float scale, void* ctx);
+int hab_policy_set_allreduce(hab_policy* p, hab_allreduce_fn fn, void* ctx, int world_size);
 /* actions == NULL -> get_value only.  hidden_*: (n, Lh, H), Lh = layers (GRU) / 2*layers (LSTM). */
 int hab_policy_act(hab_policy* p, const hab_obs* obs, const float* hidden_in, const uint8_t* masks,
                    const float* exp_noise, int deterministic, int n, float* values, int64_t* actions,
@@ -232,6 +242,11 @@ int hab_policy_probe_read(hab_policy* p, double* total_ms, int* count);
 #define HAB_TAP_CONV3 2
 #define HAB_TAP_RNN_IN 3
 #define HAB_TAP_RNN_OUT 4
+#define HAB_TAP_ENC_IN 5       /* arch 1: avg-pooled, normalised encoder input (NHWC, channels padded to 4) */
+#define HAB_TAP_STEM 6
+#define HAB_TAP_POOL 7
+#define HAB_TAP_COMPRESSION 8
+#define HAB_TAP_LAYER1 9       /* 9..12: output of stage 1..4 */
 int hab_policy_tap(hab_policy* p, int which, const float** ptr, int64_t* floats);
 
 #ifdef __cplusplus

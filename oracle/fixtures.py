@@ -56,3 +56,61 @@ def synth_rollout_inputs(envs: synth.SyntheticEnvs, T):
         rew.append(r)
         done.append(d)
     return obs, np.stack(rew), np.stack(done)
+
+
+def resnet_param_shapes(n_in, H, W, hidden, num_actions=4, rnn_type="LSTM", layers=2, backbone="resnet18", baseplanes=32,
+                        normalize=True, with_buffers=False):
+    """state_dict() names/shapes of PointNavResNetPolicy (rl/ddppo/policy/resnet_policy.py:50-162,391-602) in reference
+    order.  Buffers (RunningMeanAndVar statistics) are listed only with with_buffers=True."""
+    import math
+    shapes = [("net.prev_action_embedding.weight", (num_actions + 1, 32)), ("net.tgt_embeding.weight", (32, 3)),
+              ("net.tgt_embeding.bias", (32,))]
+    ve = "net.visual_encoder."
+    if normalize and with_buffers:
+        shapes += [(ve + "running_mean_and_var._mean", (1, n_in, 1, 1)), (ve + "running_mean_and_var._var", (1, n_in, 1, 1)),
+                   (ve + "running_mean_and_var._count", ())]
+    bottleneck = backbone == "resnet50"
+    exp = 4 if bottleneck else 1
+    nblocks = [3, 4, 6, 3] if bottleneck else [2, 2, 2, 2]
+
+    def cg(w, g, cin, cout, k):
+        return [(w + ".weight", (cout, cin, k, k)), (g + ".weight", (cout,)), (g + ".bias", (cout,))]
+
+    bb = ve + "backbone."
+    shapes += cg(bb + "conv1.0", bb + "conv1.1", n_in, baseplanes, 7)
+    inplanes = baseplanes
+    for li, nb in enumerate(nblocks):
+        planes = baseplanes * 2 ** li
+        for bi in range(nb):
+            stride = 2 if (bi == 0 and li > 0) else 1
+            bp = f"{bb}layer{li + 1}.{bi}."
+            has_ds = bi == 0 and (stride != 1 or inplanes != planes * exp)
+            if not bottleneck:
+                shapes += cg(bp + "convs.0", bp + "convs.1", inplanes, planes, 3) + cg(bp + "convs.3", bp + "convs.4", planes, planes, 3)
+            else:
+                shapes += (cg(bp + "convs.0", bp + "convs.1", inplanes, planes, 1) + cg(bp + "convs.3", bp + "convs.4", planes, planes, 3)
+                           + cg(bp + "convs.6", bp + "convs.7", planes, planes * exp, 1))
+            if has_ds:
+                shapes += cg(bp + "downsample.0", bp + "downsample.1", inplanes, planes * exp, 1)
+            inplanes = planes * exp
+    fh, fw = math.ceil((H // 2) / 32), math.ceil((W // 2) / 32)
+    ncomp = int(round(2048 / (fh * fw)))
+    shapes += cg(ve + "compression.0", ve + "compression.1", inplanes, ncomp, 3)
+    shapes += [("net.visual_fc.1.weight", (hidden, ncomp * fh * fw)), ("net.visual_fc.1.bias", (hidden,))]
+    G = 3 if rnn_type == "GRU" else 4
+    rn = "net.state_encoder.rnn."
+    for l in range(layers):
+        i = hidden + 64 if l == 0 else hidden
+        shapes += [(f"{rn}weight_ih_l{l}", (G * hidden, i)), (f"{rn}weight_hh_l{l}", (G * hidden, hidden)),
+                   (f"{rn}bias_ih_l{l}", (G * hidden,)), (f"{rn}bias_hh_l{l}", (G * hidden,))]
+    shapes += [("action_distribution.linear.weight", (num_actions, hidden)), ("action_distribution.linear.bias", (num_actions,)),
+               ("critic.fc.weight", (1, hidden)), ("critic.fc.bias", (1,))]
+    return shapes
+
+
+def golden_sample(x, max_elems=2048):
+    """Deterministic strided subsample used to keep golden fixtures of multi-million-element tensors small."""
+    flat = np.asarray(x).reshape(-1)
+    if flat.size <= max_elems:
+        return flat
+    return flat[:: flat.size // max_elems]

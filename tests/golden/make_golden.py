@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import synth  # noqa: E402
-from oracle.fixtures import det_params, synth_rollout_inputs  # noqa: E402
+from oracle.fixtures import det_params, golden_sample, synth_rollout_inputs  # noqa: E402
 from oracle.ref_loader import load_reference, make_config  # noqa: E402
 
 GOAL = "pointgoal_with_gps_compass"
@@ -38,7 +38,7 @@ def obs_space(ns, H, W, rgb=True, depth=True):
     return sp.Dict(d)
 
 
-def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=True):
+def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=True, sampled=False):
     """Reference rollout (policy.act through RolloutStorage) + compute_returns + PPO.update."""
     sd = policy.state_dict()
     newp = det_params([(k, v.shape) for k, v in sd.items() if v.dtype == torch.float32 and "running_mean_and_var" not in k], seed)
@@ -99,9 +99,12 @@ def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=Tru
     policy.zero_grad()
     total.backward()
     out["mb0_losses"] = np.array([vl.item(), al.item(), ent.mean().item(), total.item()], dtype=np.float32)
+    keep = (lambda a: golden_sample(a).copy()) if sampled else (lambda a: a.copy())
     for k, p_ in policy.named_parameters():
         if p_.grad is not None:
-            out["grad/" + k] = p_.grad.numpy().copy()
+            out["grad/" + k] = keep(p_.grad.numpy())
+            if sampled:
+                out["gradnorm/" + k] = np.float64(np.linalg.norm(p_.grad.numpy().astype(np.float64)))
     policy.zero_grad()
     # the full update (fresh generator state so the permutations are reproducible: seed + 2)
     torch.manual_seed(seed + 2)
@@ -113,7 +116,7 @@ def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=Tru
     for k, val in metrics.items():
         out["metric/" + k] = np.float32(val)
     for k, p_ in policy.state_dict().items():
-        out["post/" + k] = p_.numpy().copy()
+        out["post/" + k] = keep(p_.numpy())
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "->", len(out), "arrays;", {k: float(v) for k, v in metrics.items()})
 
@@ -176,6 +179,15 @@ def main():
     cfg2 = make_config(clip_param=0.2, ppo_epoch=1, num_mini_batch=1, max_grad_norm=0.2, num_steps=5,
                        use_normalized_advantage=False, hidden_size=64, use_clipped_value_loss=False)
     run_case(ns, "baseline_depth84", pol2, space2, cfg2, T=5, N=3, seed=7, H=84, W=84, rgb=False)
+    # B: PointNavResNetPolicy (resnet18 GroupNorm encoder + 2-layer LSTM, RunningMeanAndVar on), 256x256 RGB-D (BASELINE.json
+    # configs[2] geometry), hidden 64, ddppo_pointnav hyper-parameters.  Large tensors are stored as strided samples + norms.
+    space3 = obs_space(ns, 256, 256)
+    torch.manual_seed(0)
+    pol3 = ns.resnet_policy.PointNavResNetPolicy(space3, ns.spaces.Discrete(4), hidden_size=64, num_recurrent_layers=2,
+                                                 rnn_type="LSTM", backbone="resnet18", normalize_visual_inputs=True)
+    cfg3 = make_config(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2, num_steps=4,
+                       use_normalized_advantage=False, hidden_size=64, lr=2.5e-4, eps=1e-5)
+    run_case(ns, "resnet18_rgbd256", pol3, space3, cfg3, T=4, N=2, seed=21, H=256, W=256, sampled=True)
 
 
 if __name__ == "__main__":

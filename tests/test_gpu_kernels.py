@@ -232,6 +232,11 @@ CONVS = [  # B, H, W, C, Cout, K, stride, pad
     (2, 8, 8, 128, 256, 3, 2, 1),    # layer4 (N = 256 tile path)
     (1, 4, 4, 256, 128, 3, 1, 1),    # compression (tiny M)
     (2, 64, 64, 4, 32, 7, 2, 3),     # stem on 4 channels
+    (4, 8, 8, 128, 128, 3, 1, 1),    # resnet18 layer3 @256^2: M = 256 (two full 128-row tiles), split-K
+    (4, 16, 16, 64, 64, 3, 1, 1),    # layer2 @256^2
+    (4, 16, 16, 64, 128, 3, 2, 1),   # layer3.0 stride 2
+    (4, 16, 16, 64, 128, 1, 2, 0),   # layer3.0 downsample
+    (3, 128, 128, 4, 32, 7, 2, 3),   # stem @256^2
 ]
 
 
@@ -258,6 +263,12 @@ def test_conv_fwd_dgrad_wgrad(L, B, H, W, Cc, Cout, K, s, p, use_ws):
         dx = torch.zeros(B, H, W, Cc, device="cuda")
         ck(L.hab_conv2d_dgrad(P(dy), P(wdg), None, None, P(dx), B, H, W, Cc, Cout, K, K, s, p, P(ws), wsn, S()))
         assert torch.allclose(dx.cpu(), nhwc(x.grad), atol=2e-5, rtol=1e-4)
+        # fused epilogue: residual-gradient add, then the producer's ReLU mask
+        m = torch.randn(B, H, W, Cc)
+        add = torch.randn(B, H, W, Cc)
+        dx2 = torch.zeros(B, H, W, Cc, device="cuda")
+        ck(L.hab_conv2d_dgrad(P(dy), P(wdg), P(m.cuda()), P(add.cuda()), P(dx2), B, H, W, Cc, Cout, K, K, s, p, P(ws), wsn, S()))
+        assert torch.allclose(dx2.cpu(), (nhwc(x.grad) + add) * (m > 0), atol=2e-5, rtol=1e-4)
         dw = torch.zeros(Cout, Cc, K, K, device="cuda")
         db = torch.full((Cout,), 7.0, device="cuda")
         ck(L.hab_conv2d_wgrad(P(xh), P(dy), P(dw), P(db), B, H, W, Cc, Cout, K, K, s, p, P(ws), wsn, S()))

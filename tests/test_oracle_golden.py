@@ -9,7 +9,7 @@ import torch
 
 from oracle import functional as O
 from oracle import synth
-from oracle.fixtures import baseline_param_shapes, det_params, synth_rollout_inputs
+from oracle.fixtures import baseline_param_shapes, det_params, golden_sample, resnet_param_shapes, synth_rollout_inputs
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -89,7 +89,28 @@ CASES = {
     "baseline_depth84": dict(H=84, W=84, rgb=False, depth=True, T=5, N=3, seed=7, hidden=64,
                              cfg=dict(clip_param=0.2, ppo_epoch=1, num_mini_batch=1, max_grad_norm=0.2,
                                       use_normalized_advantage=False, use_clipped_value_loss=False)),
+    "resnet18_rgbd256": dict(kind="resnet", H=256, W=256, rgb=True, depth=True, T=4, N=2, seed=21, hidden=64, sampled=True,
+                             cfg=dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2,
+                                      use_normalized_advantage=False, use_clipped_value_loss=True)),
 }
+
+
+def case_params_spec(c):
+    """Deterministic parameters + oracle NetSpec of a golden case (the inputs make_golden.py gave the reference)."""
+    cin = (3 if c["rgb"] else 0) + (1 if c["depth"] else 0)
+    if c.get("kind", "baseline") == "baseline":
+        params = det_params(baseline_param_shapes(cin, c["H"], c["W"], c["hidden"]), c["seed"])
+        return params, O.NetSpec(kind="baseline", rnn_type="GRU", num_layers=1, hidden=c["hidden"]), 1
+    params = det_params(resnet_param_shapes(cin, c["H"], c["W"], c["hidden"]), c["seed"])
+    pre = "net.visual_encoder.running_mean_and_var."
+    params[pre + "_mean"], params[pre + "_var"], params[pre + "_count"] = torch.zeros(1, cin, 1, 1), torch.zeros(1, cin, 1, 1), torch.zeros(())
+    spec = O.NetSpec(kind="resnet", rnn_type="LSTM", num_layers=2, backbone="resnet18", baseplanes=32,
+                     visual_keys=("rgb", "depth"), normalize=True, hidden=c["hidden"])
+    return params, spec, 4
+
+
+def is_buffer(k):
+    return "running_mean_and_var" in k
 
 
 def make_cfg(**kw):
@@ -101,14 +122,12 @@ def make_cfg(**kw):
 def oracle_rollout(case, z):
     """Replays the rollout with the oracle policy; returns buffers dict shaped like RolloutStorage.buffers."""
     c = CASES[case]
-    cin = (3 if c["rgb"] else 0) + (1 if c["depth"] else 0)
-    params = det_params(baseline_param_shapes(cin, c["H"], c["W"], c["hidden"]), c["seed"])
-    spec = O.NetSpec(kind="baseline", rnn_type="GRU", num_layers=1, hidden=c["hidden"])
+    params, spec, Lh = case_params_spec(c)
     T, N = c["T"], c["N"]
     envs = synth.SyntheticEnvs(N, c["H"], c["W"], seed=c["seed"], use_rgb=c["rgb"], use_depth=c["depth"])
     obs, rew, done = synth_rollout_inputs(envs, T)
     buf = dict(observations={k: torch.from_numpy(np.stack([o[k] for o in obs])) for k in obs[0]})
-    buf["recurrent_hidden_states"] = torch.zeros(T + 1, N, 1, c["hidden"])
+    buf["recurrent_hidden_states"] = torch.zeros(T + 1, N, Lh, c["hidden"])
     buf["rewards"] = torch.zeros(T + 1, N, 1)
     buf["rewards"][:T] = torch.from_numpy(rew).unsqueeze(-1)
     buf["masks"] = torch.zeros(T + 1, N, 1, dtype=torch.bool)
@@ -162,9 +181,12 @@ def test_oracle_rollout_returns_update_vs_reference_golden(case):
     torch.manual_seed(c["seed"] + 1)
     inds = torch.randperm(N).chunk(cfg.num_mini_batch)[0]
     batch = O.gather_minibatch(buf, adv, inds, T)
-    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    samp = golden_sample if c.get("sampled") else (lambda a: a)
+    trainable = [k for k in params if not is_buffer(k)]
+    p = {k: (v.clone().requires_grad_(True) if not is_buffer(k) else v.clone()) for k, v in params.items()}
+    rmv0 = {}
     v, lp, ent, hfin = O.evaluate_actions(p, spec, batch["observations"], batch["recurrent_hidden_states"],
-                                          batch["prev_actions"], batch["masks"], batch["actions"])
+                                          batch["prev_actions"], batch["masks"], batch["actions"], rmv_out=rmv0)
     assert np.abs(v.detach().numpy() - z["mb0_value"]).max() < 2e-5
     assert np.abs(lp.detach().numpy() - z["mb0_logp"]).max() < 2e-5
     assert np.abs(ent.detach().numpy() - z["mb0_entropy"]).max() < 2e-5
@@ -173,22 +195,30 @@ def test_oracle_rollout_returns_update_vs_reference_golden(case):
     got = np.array([vl.item(), al.item(), de.item(), total.item()])
     assert np.allclose(got, z["mb0_losses"], rtol=1e-4, atol=1e-6)
     total.backward()
-    for k in params:
+    for k in trainable:
         g_ref = z["grad/" + k]
         g = p[k].grad.numpy()
-        assert np.abs(g - g_ref).max() <= 1e-4 * max(1e-3, np.abs(g_ref).max()), k
+        assert np.abs(samp(g).reshape(g_ref.shape) - g_ref).max() <= 1e-4 * max(1e-3, np.abs(g_ref).max()), k
+        if c.get("sampled"):
+            assert abs(np.linalg.norm(g.astype(np.float64)) - float(z["gradnorm/" + k])) <= 1e-4 * max(1e-3, float(z["gradnorm/" + k])), k
 
     # the whole update: metrics and post-update parameters
     perms = [list(torch.from_numpy(z["perms"][e]).chunk(cfg.num_mini_batch)) for e in range(cfg.ppo_epoch)]
-    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    opt = dict(step=0, m={k: torch.zeros_like(v) for k, v in p.items()}, v={k: torch.zeros_like(v) for k, v in p.items()})
-    metrics = O.ppo_update(p, spec, buf, T, cfg, opt, list(p.keys()), perms=perms)
+    p = {k: (v.clone().requires_grad_(True) if not is_buffer(k) else v.clone()) for k, v in params.items()}
+    for k, val in rmv0.items():  # the reference module kept the RunningMeanAndVar statistics of the mb0 evaluate above
+        p["net.visual_encoder.running_mean_and_var._" + k] = val.clone()
+    opt = dict(step=0, m={k: torch.zeros_like(p[k]) for k in trainable}, v={k: torch.zeros_like(p[k]) for k in trainable})
+    metrics = O.ppo_update(p, spec, buf, T, cfg, opt, trainable, perms=perms)
     for k, val in metrics.items():
         ref = float(z["metric/" + k])
         assert abs(val - ref) <= 1e-4 * max(1.0, abs(ref)), (k, val, ref)
     for k in params:
         ref = z["post/" + k]
-        assert np.abs(p[k].detach().numpy() - ref).max() <= 2e-5, k
+        got = samp(p[k].detach().numpy()).reshape(ref.shape)
+        # Adam normalises every gradient element by its own magnitude, so fp32 round-off in near-zero gradients of the deep
+        # GroupNorm encoder moves a parameter by a fraction of lr per step: bound = 10% of lr * steps for that case.
+        tol = 1e-4 if c.get("sampled") else 2e-5
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), k
 
 
 def test_multinomial_equals_exponential_argmax():
