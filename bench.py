@@ -33,6 +33,9 @@ NUM_ENVS, NUM_STEPS, OBS = 64, 128, 256
 WORKLOADS = {
     "c2": dict(yaml="pointnav/ppo_pointnav_habitat_iccv19.yaml", name="PointNav SimpleCNN+GRU, 64 envs x 128 steps, 256x256 RGB-D synthetic",
                overrides=[]),
+    # BASELINE.json configs[2]: ResNet18 + 2-layer LSTM with the ddppo_pointnav.yaml hyper-parameters (E=2, M=2)
+    "c3": dict(yaml="pointnav/ddppo_pointnav.yaml", name="PointNav ResNet18+LSTM, 64 envs x 128 steps, 256x256 RGB-D synthetic",
+               overrides=["habitat_baselines.rl.ddppo.backbone=resnet18"]),
 }
 
 # probe tag -> (description, flops per frame)   SimpleCNN @256^2 RGB-D (a4)
@@ -41,6 +44,9 @@ PROBES = {
     "fc_fwd": (3, 2.0 * 25088 * 512), "conv1_wgrad": (4, 2.0 * 63 * 63 * 32 * 256), "conv2_wgrad": (5, 2.0 * 30 * 30 * 64 * 512),
     "conv3_wgrad": (6, 2.0 * 28 * 28 * 32 * 576), "conv2_dgrad": (7, 2.0 * 30 * 30 * 64 * 512), "conv3_dgrad": (8, 2.0 * 28 * 28 * 32 * 576),
     "fc_wgrad": (9, 2.0 * 25088 * 512), "fc_dgrad": (10, 2.0 * 25088 * 512),
+    # ResNet18 encoder @256^2 RGB-D (a5): 168.82 MMAC forward; backward = dgrad + wgrad of every conv except the
+    # stem's dgrad (25.69 MMAC)
+    "enc_fwd": (11, 2.0 * 168.82e6), "enc_bwd": (12, 2.0 * (2 * 168.82e6 - 25.69e6)),
 }
 
 
@@ -115,9 +121,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
-    ap.add_argument("--probe", default="conv2_dgrad", choices=list(PROBES))
+    ap.add_argument("--probe", default=None, choices=list(PROBES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
+    if a.probe is None:
+        a.probe = "conv2_dgrad" if a.workload == "c2" else "enc_bwd"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != a.gpus:
@@ -160,6 +168,7 @@ def main():
     upd_frames = NUM_ENVS * NUM_STEPS * ppo.ppo_epoch * a.steps
     roll_frames = NUM_ENVS * (NUM_STEPS + 1) * a.steps
     frames = upd_frames + (roll_frames if a.probe.endswith("_fwd") else 0)
+    kname = f"igemm_kernel<{a.probe}>" if not a.probe.startswith("enc_") else f"resnet18 encoder {a.probe[4:]} (all kernels)"
     ach = flops_per_frame * frames / (probe_ms * 1e-3) / 1e12 if probe_ms > 0 else None
     out = {
         "metric": "env-steps/sec (SPS) PointNav RGB-D 256x256, 64 envs x 128 rollout",
@@ -168,11 +177,11 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOADS[a.workload]["name"], "envs_per_gpu": NUM_ENVS, "rollout_steps": NUM_STEPS,
                    "ppo_epoch": ppo.ppo_epoch, "num_mini_batch": ppo.num_mini_batch, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": f"igemm_kernel<{a.probe}>", "achieved": round(ach, 2) if ach else None,
+        "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2) if ach else None,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4) if ach else None,
                      "traffic": None, "launches": probe_cnt, "avg_launch_ms": round(probe_ms / max(probe_cnt, 1), 4)},
     }
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
 

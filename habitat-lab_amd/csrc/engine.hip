@@ -199,7 +199,7 @@ extern "C" int hab_policy_probe_read(hab_policy* e, double* total_ms, int* count
 // Encoder forward on B frames (shared by act / evaluate): obs -> rnn_in[B][rnn_ld]
 // ------------------------------------------------------------------------------------------
 static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s) {
-    if (e->rn) return resnet_encoder_forward(e, obs, masks, rows, B, s);
+    if (e->rn) { Probe pr(e, HAB_PROBE_ENC_FWD, s); return resnet_encoder_forward(e, obs, masks, rows, B, s); }
     float* W = e->WK;
     float* ws = W + e->w_ws;
     const int H = e->d.hidden;
@@ -392,7 +392,7 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
                                        W + e->w_scratch, ws, e->ws_floats, stream));
         dout = dx;
     }
-    if (e->rn) return resnet_encoder_backward(e, obs, e->last_masks, rows, B, stream);
+    if (e->rn) { Probe pr(e, HAB_PROBE_ENC_BWD, stream); return resnet_encoder_backward(e, obs, e->last_masks, rows, B, stream); }
     // fc (Flatten -> Linear -> ReLU): d_rnnin[:, :H] already carries the ReLU mask
     const float* dfc = W + e->w_drnnin;
     ConvDesc c1 = e->c1, c2 = e->c2, c3 = e->c3;

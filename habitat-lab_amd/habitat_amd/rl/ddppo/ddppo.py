@@ -24,6 +24,15 @@ class DecentralizedDistributedMixin:
         eng = self.actor_critic.engine
         distrib.broadcast(eng.params_flat, src=0)
         eng.repack()
+        world = distrib.get_world_size()
+        if world > 1:
+            # RunningMeanAndVar batch moments are averaged over ranks inside the engine's forward
+            # (rl/ddppo/policy/running_mean_and_var.py:38-41,47-49): all_reduce(sum) then / world_size
+            def _avg(view: torch.Tensor, scale: float) -> None:
+                distrib.all_reduce(view)
+                view.mul_(scale)
+
+            eng.set_allreduce(_avg, world)
         self._distributed = True
 
     def _all_reduce_grads(self) -> None:

@@ -233,6 +233,8 @@ int hab_policy_backward(hab_policy* p, const hab_obs* obs, const int* rows, cons
 #define HAB_PROBE_CONV3_DGRAD 8
 #define HAB_PROBE_FC_WGRAD 9
 #define HAB_PROBE_FC_DGRAD 10
+#define HAB_PROBE_ENC_FWD 11  /* arch 1: whole visual encoder forward (ingest .. visual_fc) */
+#define HAB_PROBE_ENC_BWD 12  /* arch 1: whole visual encoder backward */
 int hab_policy_probe_enable(hab_policy* p, int tag /* -1 = off */);
 int hab_policy_probe_read(hab_policy* p, double* total_ms, int* count);
 

@@ -32,6 +32,9 @@ class FakeEngine:
     def repack(self):
         self.repacked += 1
 
+    def set_allreduce(self, fn, world_size):
+        self.allreduce, self.world = fn, world_size
+
 
 def _worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "habitat-lab_amd")):
@@ -47,6 +50,10 @@ def _worker(rank, world, port, q):
     upd = types.SimpleNamespace(actor_critic=types.SimpleNamespace(engine=FakeEngine(rank)))
     g_local = upd.actor_critic.engine.grads_flat.clone()
     DecentralizedDistributedMixin.init_distributed(upd)
+    # the RunningMeanAndVar hook handed to the engine averages a small buffer over the ranks (running_mean_and_var.py:38-41)
+    stats = torch.full((8,), float(rank + 1))
+    upd.actor_critic.engine.allreduce(stats, 1.0 / world)
+    assert torch.allclose(stats, torch.full((8,), (world + 1) / 2.0)) and upd.actor_critic.engine.world == world
     DecentralizedDistributedMixin._all_reduce_grads(upd)
     out["params"] = upd.actor_critic.engine.params_flat.clone()
     out["grads"] = upd.actor_critic.engine.grads_flat.clone()
