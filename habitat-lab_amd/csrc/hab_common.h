@@ -60,29 +60,31 @@ __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 }  // namespace hab
 
 namespace hab {
-// Division by a runtime-invariant divisor d (1 <= d < 2^31) of 0 <= n < 2^31 via multiply-high:
-// l = ceil(log2 d), M = ceil(2^(31+l)/d) < 2^32, q = (n*M) >> (31+l)  (exact for n < 2^31).
+// Division by a runtime-invariant divisor d (1 <= d < 2^31) of 0 <= n < 2^31 via multiply-high, branch-free:
+// d >= 2: l = ceil(log2 d), M = ceil(2^(31+l)/d) < 2^32, q = mulhi(n, M) >> (l-1)  (exact for n < 2^31);
+// d == 1: M = 0, add = 1, shift = 0 -> q = n.
 struct FastDiv {
-    uint32_t mul, shift, d;
-    FastDiv() : mul(0), shift(0), d(1) {}
+    uint32_t mul, shift, d, add;
+    FastDiv() : mul(0), shift(0), d(1), add(1) {}
     explicit FastDiv(int dd) {
         d = (uint32_t)dd;
         mul = 0;
         shift = 0;
+        add = 1;
         if (dd <= 1) return;
         uint32_t l = 0;
         while ((1ull << l) < (uint64_t)d) ++l;
         mul = (uint32_t)((((uint64_t)1 << (31 + l)) + d - 1) / d);
         shift = l - 1;
+        add = 0;
     }
     __host__ __device__ inline int div(int n) const {
-        if (d == 1) return n;
 #ifdef __HIP_DEVICE_COMPILE__
         const uint32_t hi = __umulhi((uint32_t)n, mul);
 #else
         const uint32_t hi = (uint32_t)(((uint64_t)(uint32_t)n * mul) >> 32);
 #endif
-        return (int)(hi >> shift);
+        return (int)((hi + (uint32_t)n * add) >> shift);
     }
     __host__ __device__ inline void divmod(int n, int& q, int& r) const {
         q = div(n);

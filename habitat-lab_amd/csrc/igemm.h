@@ -141,12 +141,21 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
     };
     auto fetch = [&](int kt) {
         const typename P::KCtx kc = p.k_ctx(k_begin + kt * BK, k_end);  // block-uniform
+        // r-contiguous form: every unit of a thread has the same k -> one key (tap decode) per thread and K-tile
+        typename P::AKey ak = p.a_key(kc, a_k(kt, 0), k_end);
 #pragma unroll
         for (int j = 0; j < A_UNITS; ++j)
-            if (A_TOTAL % NT == 0 || t + NT * j < A_TOTAL) araw[j] = p.a_fetch(actx[j], kc, a_k(kt, j), k_end);
+            if (A_TOTAL % NT == 0 || t + NT * j < A_TOTAL) {
+                if (!P::A_RC && j > 0) ak = p.a_key(kc, a_k(kt, j), k_end);
+                araw[j] = p.a_fetch(actx[j], kc, ak);
+            }
+        typename P::BKey bk = p.b_key(kc, b_k(kt, 0), k_end);
 #pragma unroll
         for (int j = 0; j < B_UNITS; ++j)
-            if (B_TOTAL % NT == 0 || t + NT * j < B_TOTAL) braw[j] = p.b_fetch(bctx[j], kc, b_k(kt, j), k_end);
+            if (B_TOTAL % NT == 0 || t + NT * j < B_TOTAL) {
+                if (!P::B_RC && j > 0) bk = p.b_key(kc, b_k(kt, j), k_end);
+                braw[j] = p.b_fetch(bctx[j], kc, bk);
+            }
     };
     auto stage = [&](int kt) {  // registers -> LDS (zero fill / conversion applied here)
 #pragma unroll

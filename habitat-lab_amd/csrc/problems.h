@@ -10,9 +10,11 @@
 //   M, N, K; A_RC, B_RC (operand forms); optional A_KV (gather-unit width of A, default 4)
 //   KCtx k_ctx(k0, k_end)                       per K-tile, block-uniform
 //   ACtx a_ctx(i) / BCtx b_ctx(j)               per gather unit, once per tile
-//   ARaw a_fetch(ACtx, KCtx, k, k_end)          BRANCH-FREE global loads from a clamped address + validity
+//   AKey a_key(KCtx, k, k_end)                  decode of the reduction coordinate (filter tap / pixel), shared by all
+//                                               units of a thread in the r-contiguous form
+//   ARaw a_fetch(ACtx, KCtx, AKey)              BRANCH-FREE global loads from a masked offset + validity
 //   void a_cvt(ACtx, ARaw, k, k_end, f32x4*)    zero fill / conversion, applied when staging to LDS
-//   BRaw b_fetch(BCtx, KCtx, k, k_end); f32x4 b_cvt(BRaw)
+//   BKey b_key(KCtx, k, k_end); BRaw b_fetch(BCtx, KCtx, BKey); f32x4 b_cvt(BRaw)
 //   EpiCol epi_col(n); EpiRow epi_row(m); EpiAux epi_fetch(row, col); epi_store(row, col, aux, v)
 //   store(m, n, v)                              = the four epilogue pieces in sequence
 #pragma once
@@ -32,6 +34,8 @@ HAB_HD f32x4 zero4() {
 HAB_HD f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 struct Raw4 { f32x4 v; int ok; };
+struct KKey { int k, ok; };  // plain reduction coordinate + in-range flag
+HAB_HD KKey kkey(int k, int k_end) { KKey q; q.k = k; q.ok = k < k_end; return q; }
 HAB_HD f32x4 sel4(const Raw4& r) { return r.ok ? r.v : zero4(); }
 struct NoCtx {};
 struct NoAux {};
@@ -88,37 +92,46 @@ struct ConvFwdProb {
     float* y;
     int relu;
     HAB_NO_KCTX
-    struct ACtx { const float* base; int h0, w0; };
+    struct ACtx { const float* base; int h0, w0, off0; };  // off0 = (h0*W + w0)*C
+    struct AKey { int kh, kw, koff, ok; };                  // koff = (kh*W + kw)*C + ci
     using BCtx = WRowCtx;
+    using BKey = KKey;
     using ARaw = Raw4;
     using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int m) const {
         ACtx c;
-        if (m >= M) { c.base = x; c.h0 = HAB_FAR; c.w0 = 0; return c; }
+        if (m >= M) { c.base = x; c.h0 = HAB_FAR; c.w0 = 0; c.off0 = 0; return c; }
         int img, rem, ho, wo;
         g.dHoWo.divmod(m, img, rem);
         g.dWo.divmod(rem, ho, wo);
         c.base = x + (size_t)img * g.H * g.W * g.C;
         c.h0 = ho * g.stride - g.pad;
         c.w0 = wo * g.stride - g.pad;
+        c.off0 = (c.h0 * g.W + c.w0) * g.C;
         return c;
     }
-    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int k, int k_end) const {
-        int tap, ci, kh, kw;
+    HAB_HD AKey a_key(const KCtx&, int k, int k_end) const {
+        AKey q;
+        int tap, ci;
         g.dC.divmod(k, tap, ci);
-        g.dKW.divmod(tap, kh, kw);
-        const int h = c.h0 + kh, w_ = c.w0 + kw;
+        g.dKW.divmod(tap, q.kh, q.kw);
+        q.koff = (q.kh * g.W + q.kw) * g.C + ci;
+        q.ok = k < k_end;
+        return q;
+    }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, const AKey& q) const {
+        const int h = c.h0 + q.kh, w_ = c.w0 + q.kw;
         ARaw r;
-        r.ok = (k < k_end) & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
-        const int off = r.ok ? (h * g.W + w_) * g.C + ci : 0;
-        r.v = ld4(c.base + off);
+        r.ok = q.ok & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
+        r.v = ld4(c.base + ((c.off0 + q.koff) & -r.ok));
         return r;
     }
     HAB_HD BCtx b_ctx(int n) const { BCtx c; c.ok = n < N; c.row = c.ok ? w + (size_t)n * K : w; return c; }
-    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int k, int k_end) const {
+    HAB_HD BKey b_key(const KCtx&, int k, int k_end) const { return kkey(k, k_end); }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, const BKey& q) const {
         BRaw r;
-        r.ok = c.ok & (k < k_end);
-        r.v = ld4(c.row + (r.ok ? k : 0));
+        r.ok = c.ok & q.ok;
+        r.v = ld4(c.row + (q.k & -r.ok));
         return r;
     }
     HAB_PLAIN_CVT
@@ -206,7 +219,9 @@ struct ObsConvFwdProb {
     int quad;
     HAB_NO_KCTX
     struct ACtx { int srow, h0, w0; };
+    struct AKey { int kh, kw, ok; };
     using BCtx = WRowCtx;
+    using BKey = KKey;
     using ARaw = ObsRaw;
     using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int m) const {
@@ -220,12 +235,16 @@ struct ObsConvFwdProb {
         c.w0 = wo * g.stride - g.pad;
         return c;
     }
-    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int k, int k_end) const {
+    HAB_HD AKey a_key(const KCtx&, int k, int k_end) const {
+        AKey q;
+        g.dKW.divmod(k >> 2, q.kh, q.kw);  // used by the quad path only (C == 4)
+        q.ok = k < k_end;
+        return q;
+    }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, const AKey& q) const {
         if (quad) {
-            int kh, kw;
-            g.dKW.divmod(k >> 2, kh, kw);
-            const int h = c.h0 + kh, w_ = c.w0 + kw;
-            const int ok = (k < k_end) & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
+            const int h = c.h0 + q.kh, w_ = c.w0 + q.kw;
+            const int ok = q.ok & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
             return obs_quad_fetch(obs, c.srow, h, w_, ok);
         }
         ARaw r;
@@ -248,16 +267,17 @@ struct ObsConvFwdProb {
         }
     }
     HAB_HD BCtx b_ctx(int n) const { BCtx c; c.ok = n < N; c.row = c.ok ? w + (size_t)n * K : w; return c; }
-    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int k, int k_end) const {
+    HAB_HD BKey b_key(const KCtx&, int k, int k_end) const { return kkey(k, k_end); }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, const BKey& q) const {
         BRaw r;
         if ((K & 3) == 0) {
-            r.ok = c.ok & (k < k_end);
-            r.v = ld4(c.row + (r.ok ? k : 0));
+            r.ok = c.ok & q.ok;
+            r.v = ld4(c.row + (q.k & -r.ok));
         } else {  // K = KH*KW*C not a multiple of 4 (C in {1,3} with odd taps): scalar gathers
             r.ok = 1;
             r.v = zero4();
             for (int e = 0; e < 4; ++e)
-                if (c.ok && k + e < k_end) r.v[e] = c.row[k + e];
+                if (c.ok && q.ok && q.k + e < K) r.v[e] = c.row[q.k + e];
         }
         return r;
     }
@@ -314,41 +334,54 @@ struct ConvDgradProb {
         dHcWc = FastDiv(Hc * Wc > 0 ? Hc * Wc : 1); dWc = FastDiv(Wc > 0 ? Wc : 1); dKWs = FastDiv(KWs > 0 ? KWs : 1);
     }
     HAB_NO_KCTX
-    struct ACtx { const float* base; int hq, wq; };  // hq = (h + pad - ph) / s
+    struct ACtx { const float* base; int hq, wq, off0; };  // hq = (h + pad - ph) / s, off0 = (hq*Wo + wq)*Cout
+    struct AKey { int a, b, koff, ok; };                    // koff = co - (a*Wo + b)*Cout
     using BCtx = WRowCtx;
+    struct BKey { int off, ok; };                           // offset of (tap, co) inside a row of Wd
     using ARaw = Raw4;
     using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int m) const {
         ACtx c;
-        if (m >= M) { c.base = dy; c.hq = HAB_FAR; c.wq = 0; return c; }
+        if (m >= M) { c.base = dy; c.hq = HAB_FAR; c.wq = 0; c.off0 = 0; return c; }
         int img, rem, hc, wc;
         dHcWc.divmod(m, img, rem);
         dWc.divmod(rem, hc, wc);
         c.base = dy + (size_t)img * g.Ho * g.Wo * g.Cout;
         c.hq = (h_first + hc * g.stride + g.pad - ph) / g.stride;
         c.wq = (w_first + wc * g.stride + g.pad - pw) / g.stride;
+        c.off0 = (c.hq * g.Wo + c.wq) * g.Cout;
         return c;
     }
-    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int k, int k_end) const {
-        int tap, co, a, b;
+    HAB_HD AKey a_key(const KCtx&, int k, int k_end) const {
+        AKey q;
+        int tap, co;
         g.dCout.divmod(k, tap, co);
-        dKWs.divmod(tap, a, b);
-        const int hs = c.hq - a, ws = c.wq - b;  // output row / col that tap (ph + s*a, pw + s*b) reads
+        dKWs.divmod(tap, q.a, q.b);
+        q.koff = co - (q.a * g.Wo + q.b) * g.Cout;
+        q.ok = k < k_end;
+        return q;
+    }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, const AKey& q) const {
+        const int hs = c.hq - q.a, ws = c.wq - q.b;  // output row / col that tap (ph + s*a, pw + s*b) reads
         ARaw r;
-        r.ok = (k < k_end) & ((unsigned)hs < (unsigned)g.Ho) & ((unsigned)ws < (unsigned)g.Wo);
-        const int off = r.ok ? (hs * g.Wo + ws) * g.Cout + co : 0;
-        r.v = ld4(c.base + off);
+        r.ok = q.ok & ((unsigned)hs < (unsigned)g.Ho) & ((unsigned)ws < (unsigned)g.Wo);
+        r.v = ld4(c.base + ((c.off0 + q.koff) & -r.ok));
         return r;
     }
     HAB_HD BCtx b_ctx(int n) const { BCtx c; c.ok = n < N; c.row = c.ok ? w + (size_t)n * Kfull : w; return c; }
-    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int k, int k_end) const {
+    HAB_HD BKey b_key(const KCtx&, int k, int k_end) const {
+        BKey q;
         int tap, co, a, b;
         g.dCout.divmod(k, tap, co);
         dKWs.divmod(tap, a, b);
+        q.off = ((ph + g.stride * a) * g.KW + (pw + g.stride * b)) * g.Cout + co;
+        q.ok = k < k_end;
+        return q;
+    }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, const BKey& q) const {
         BRaw r;
-        r.ok = c.ok & (k < k_end);
-        const int off = r.ok ? ((ph + g.stride * a) * g.KW + (pw + g.stride * b)) * g.Cout + co : 0;
-        r.v = ld4(c.row + off);
+        r.ok = c.ok & q.ok;
+        r.v = ld4(c.row + (q.off & -r.ok));
         return r;
     }
     HAB_PLAIN_CVT
@@ -401,35 +434,47 @@ struct ConvWgradProb {
     int Creal;
     HAB_HD void store_colsum(int j, float v) const { colsum[j] = v; }
     HAB_NO_KCTX
-    struct ACtx { int kh, kw, ci; };
+    struct ACtx { int kh, kw, ioff; };                 // ioff = (kh*W + kw)*C + ci
+    struct AKey { size_t roff; int hb, wb, ok; };      // pixel r: hb = ho*s - p, wb = wo*s - p, roff = ((img*H + hb)*W + wb)*C
     struct BCtx { int co; };
+    struct BKey { size_t roff; int ok; };              // r * N
     using ARaw = Raw4;
     using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int i) const {
         ACtx c;
-        if (i >= M) { c.kh = HAB_FAR; c.kw = 0; c.ci = 0; return c; }
-        int tap;
-        g.dC.divmod(i, tap, c.ci);
+        if (i >= M) { c.kh = HAB_FAR; c.kw = 0; c.ioff = 0; return c; }
+        int tap, ci;
+        g.dC.divmod(i, tap, ci);
         g.dKW.divmod(tap, c.kh, c.kw);
+        c.ioff = (c.kh * g.W + c.kw) * g.C + ci;
         return c;
     }
-    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int r, int k_end) const {
+    HAB_HD AKey a_key(const KCtx&, int r, int k_end) const {
+        AKey q;
         int img, rem, ho, wo;
         g.dHoWo.divmod(r, img, rem);
         g.dWo.divmod(rem, ho, wo);
-        const int h = ho * g.stride - g.pad + c.kh, w_ = wo * g.stride - g.pad + c.kw;
-        ARaw q;
-        q.ok = (r < k_end) & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
-        const size_t off = q.ok ? (((size_t)img * g.H + h) * g.W + w_) * g.C + c.ci : 0;
-        q.v = ld4(x + off);
+        q.hb = ho * g.stride - g.pad;
+        q.wb = wo * g.stride - g.pad;
+        q.roff = (size_t)(((long long)img * g.H + q.hb) * g.W + q.wb) * (size_t)g.C;
+        q.ok = r < k_end;
         return q;
     }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, const AKey& q) const {
+        const int h = q.hb + c.kh, w_ = q.wb + c.kw;
+        ARaw v;
+        v.ok = q.ok & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
+        const size_t off = (q.roff + (size_t)(long long)c.ioff) & (size_t)(-(long long)v.ok);
+        v.v = ld4(x + off);
+        return v;
+    }
     HAB_HD BCtx b_ctx(int j) const { BCtx c; c.co = (j < N) ? j : -1; return c; }
-    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int r, int k_end) const {
-        BRaw q;
-        q.ok = (c.co >= 0) & (r < k_end);
-        q.v = ld4(dy + (q.ok ? (size_t)r * N + c.co : 0));
-        return q;
+    HAB_HD BKey b_key(const KCtx&, int r, int k_end) const { BKey q; q.roff = (size_t)r * N; q.ok = r < k_end; return q; }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, const BKey& q) const {
+        BRaw v;
+        v.ok = (c.co >= 0) & q.ok;
+        v.v = ld4(dy + ((q.roff + (size_t)c.co) & (size_t)(-(long long)v.ok)));
+        return v;
     }
     HAB_PLAIN_CVT
     using EpiCol = ColOnly;
@@ -478,7 +523,9 @@ struct ObsConvWgradProb {
         return c;
     }
     struct ACtx { int i, kh, kw; };
+    struct AKey { int srow, hb, wb, ok; };
     struct BCtx { int co; };
+    struct BKey { size_t roff; int ok; };
     using ARaw = ObsRaw;
     using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int i) const {
@@ -493,18 +540,26 @@ struct ObsConvWgradProb {
         return obs.srow(img < g.B ? img : g.B - 1);
     }
     static constexpr int IGEMM_BK_ = 32;
-    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx& kc, int r, int k_end) const {
-        if (quad) {
-            int img, rem, ho, wo;
-            g.dHoWo.divmod(r, img, rem);
-            g.dWo.divmod(rem, ho, wo);
-            const int h = ho * g.stride - g.pad + c.kh, w_ = wo * g.stride - g.pad + c.kw;
-            const int ok = (r < k_end) & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
-            return obs_quad_fetch(obs, srow_of(kc, img), h, w_, ok);
-        }
-        ARaw q;
-        q.d0 = q.d1 = q.d2 = 0; q.dep = zero4(); q.ok = -1;
+    HAB_HD AKey a_key(const KCtx& kc, int r, int k_end) const {
+        AKey q;
+        int img, rem, ho, wo;
+        g.dHoWo.divmod(r, img, rem);
+        g.dWo.divmod(rem, ho, wo);
+        q.hb = ho * g.stride - g.pad;
+        q.wb = wo * g.stride - g.pad;
+        q.ok = r < k_end;
+        q.srow = quad ? srow_of(kc, img) : 0;
         return q;
+    }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, const AKey& q) const {
+        if (quad) {
+            const int h = q.hb + c.kh, w_ = q.wb + c.kw;
+            const int ok = q.ok & ((unsigned)h < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);
+            return obs_quad_fetch(obs, q.srow, h, w_, ok);
+        }
+        ARaw v;
+        v.d0 = v.d1 = v.d2 = 0; v.dep = zero4(); v.ok = -1;
+        return v;
     }
     HAB_HD void a_cvt(const ACtx& c, const ARaw& q, int r, int k_end, f32x4* out) const {
         if (q.ok >= 0) { obs_quad_cvt(q, out); return; }
@@ -529,11 +584,12 @@ struct ObsConvWgradProb {
         }
     }
     HAB_HD BCtx b_ctx(int j) const { BCtx c; c.co = (j < N) ? j : -1; return c; }
-    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int r, int k_end) const {
-        BRaw q;
-        q.ok = (c.co >= 0) & (r < k_end);
-        q.v = ld4(dy + (q.ok ? (size_t)r * N + c.co : 0));
-        return q;
+    HAB_HD BKey b_key(const KCtx&, int r, int k_end) const { BKey q; q.roff = (size_t)r * N; q.ok = r < k_end; return q; }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, const BKey& q) const {
+        BRaw v;
+        v.ok = (c.co >= 0) & q.ok;
+        v.v = ld4(dy + ((q.roff + (size_t)c.co) & (size_t)(-(long long)v.ok)));
+        return v;
     }
     HAB_HD f32x4 b_cvt(const BRaw& r) const { return sel4(r); }
     using EpiCol = ColOnly;
@@ -561,16 +617,16 @@ struct ObsConvWgradProb {
 // Linear layers.  x: [M][K] (ldx), w: [N][K] (ldw) as torch.nn.Linear stores it.
 // vec = 1 requires ldx, ldw, K multiples of 4 and 16-byte aligned bases; vec = 0 gathers scalars.
 // ----------------------------------------------------------------------------------------------
-HAB_HD Raw4 row_fetch4(const float* row, int row_ok, int k, int k_end, int vec) {
+HAB_HD Raw4 row_fetch4(const float* row, int row_ok, const KKey& q, int K, int vec) {
     Raw4 r;
     if (vec) {
-        r.ok = row_ok & (k < k_end);
-        r.v = ld4(row + (r.ok ? k : 0));
-    } else {
+        r.ok = row_ok & q.ok;
+        r.v = ld4(row + (q.k & -r.ok));
+    } else {  // scalar gathers (K or the leading dimension not a multiple of 4)
         r.ok = 1;
         r.v = zero4();
         for (int e = 0; e < 4; ++e)
-            if (row_ok && k + e < k_end) r.v[e] = row[k + e];
+            if (row_ok && q.ok && q.k + e < K) r.v[e] = row[q.k + e];
     }
     return r;
 }
@@ -579,7 +635,7 @@ HAB_HD Raw4 col_fetch4(const float* base, int ld, int r, int r_ok, int j, int n)
     Raw4 q;
     if (((ld & 3) == 0) && (j + 3 < n || j >= n)) {
         q.ok = r_ok & (j < n);
-        q.v = ld4(base + (q.ok ? (size_t)r * ld + j : 0));
+        q.v = ld4(base + (((size_t)r * ld + j) & (size_t)(-(long long)q.ok)));
     } else {
         q.ok = 1;
         q.v = zero4();
@@ -605,9 +661,13 @@ struct LinearFwdProb {
     using ARaw = Raw4;
     using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int m) const { ACtx c; c.ok = m < M; c.row = c.ok ? x + (size_t)m * ldx : x; return c; }
-    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int k, int k_end) const { return row_fetch4(c.row, c.ok, k, k_end, vec); }
+    using AKey = KKey;
+    using BKey = KKey;
+    HAB_HD AKey a_key(const KCtx&, int k, int k_end) const { return kkey(k, k_end); }
+    HAB_HD BKey b_key(const KCtx&, int k, int k_end) const { return kkey(k, k_end); }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, const AKey& q) const { return row_fetch4(c.row, c.ok, q, K, vec); }
     HAB_HD BCtx b_ctx(int n) const { BCtx c; c.ok = n < N; c.row = c.ok ? w + (size_t)n * ldw : w; return c; }
-    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int k, int k_end) const { return row_fetch4(c.row, c.ok, k, k_end, vec); }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, const BKey& q) const { return row_fetch4(c.row, c.ok, q, K, vec); }
     HAB_PLAIN_CVT
     using EpiCol = ColN;
     using EpiRow = RowBase;
@@ -646,9 +706,13 @@ struct LinearDgradProb {
     using ARaw = Raw4;
     using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int m) const { ACtx c; c.ok = m < M; c.row = c.ok ? dy + (size_t)m * lddy : dy; return c; }
-    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int k, int k_end) const { return row_fetch4(c.row, c.ok, k, k_end, vec_a); }
+    using AKey = KKey;
+    using BKey = KKey;
+    HAB_HD AKey a_key(const KCtx&, int k, int k_end) const { return kkey(k, k_end); }
+    HAB_HD BKey b_key(const KCtx&, int k, int k_end) const { return kkey(k, k_end); }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, const AKey& q) const { return row_fetch4(c.row, c.ok, q, K, vec_a); }
     HAB_HD BCtx b_ctx(int j) const { BCtx c; c.j = j; return c; }
-    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int r, int k_end) const { return col_fetch4(w, ldw, r, r < k_end, c.j, N); }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, const BKey& q) const { return col_fetch4(w, ldw, q.k, q.ok, c.j, N); }
     HAB_PLAIN_CVT
     using EpiCol = ColOnly;
     struct EpiRow { size_t base, mbase; int ok; };
@@ -689,9 +753,13 @@ struct LinearWgradProb {
     using ARaw = Raw4;
     using BRaw = Raw4;
     HAB_HD ACtx a_ctx(int i) const { ACtx c; c.i = i; return c; }
-    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, int r, int k_end) const { return col_fetch4(dy, lddy, r, r < k_end, c.i, M); }
+    using AKey = KKey;
+    using BKey = KKey;
+    HAB_HD AKey a_key(const KCtx&, int k, int k_end) const { return kkey(k, k_end); }
+    HAB_HD BKey b_key(const KCtx&, int k, int k_end) const { return kkey(k, k_end); }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, const AKey& q) const { return col_fetch4(dy, lddy, q.k, q.ok, c.i, M); }
     HAB_HD BCtx b_ctx(int j) const { BCtx c; c.j = j; return c; }
-    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, int r, int k_end) const { return col_fetch4(x, ldx, r, r < k_end, c.j, N); }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, const BKey& q) const { return col_fetch4(x, ldx, q.k, q.ok, c.j, N); }
     HAB_PLAIN_CVT
     struct EpiCol { int col, ok; };
     using EpiRow = RowBase;

@@ -24,12 +24,12 @@ static float host_a(const P& p, int m, int k) {
     if constexpr (P::A_RC) {
         const int kb = k - k % KV;
         const typename P::ACtx c = p.a_ctx(m);
-        p.a_cvt(c, p.a_fetch(c, kc, kb, p.K), kb, p.K, out);
+        p.a_cvt(c, p.a_fetch(c, kc, p.a_key(kc, kb, p.K)), kb, p.K, out);
         return out[(k - kb) >> 2][(k - kb) & 3];
     } else {
         const int mb = m - m % KV;
         const typename P::ACtx c = p.a_ctx(mb);
-        p.a_cvt(c, p.a_fetch(c, kc, k, p.K), k, p.K, out);
+        p.a_cvt(c, p.a_fetch(c, kc, p.a_key(kc, k, p.K)), k, p.K, out);
         return out[(m - mb) >> 2][(m - mb) & 3];
     }
 }
@@ -38,11 +38,11 @@ static float host_b(const P& p, int k, int n) {
     const typename P::KCtx kc = p.k_ctx(k - k % IGEMM_BK, p.K);
     if constexpr (P::B_RC) {
         const int kb = k & ~3;
-        const f32x4 v = p.b_cvt(p.b_fetch(p.b_ctx(n), kc, kb, p.K));
+        const f32x4 v = p.b_cvt(p.b_fetch(p.b_ctx(n), kc, p.b_key(kc, kb, p.K)));
         return v[k - kb];
     } else {
         const int nb = n & ~3;
-        const f32x4 v = p.b_cvt(p.b_fetch(p.b_ctx(nb), kc, k, p.K));
+        const f32x4 v = p.b_cvt(p.b_fetch(p.b_ctx(nb), kc, p.b_key(kc, k, p.K)));
         return v[n - nb];
     }
 }
