@@ -372,7 +372,7 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
     eb.saved = W + r->w_embsave; eb.dout = dfc; eb.ld = e->rnn_ld;
     eb.col0 = H; eb.B = B; eb.num_tokens = e->d.num_actions + 1;
     eb.dw_t = e->g(r->i_tgw); eb.db_t = e->g(r->i_tgb); eb.demb = e->g(r->i_emb);
-    HAB_TRY(embed_backward(eb, s));
+    HAB_TRY(embed_backward(eb, ws, e->ws_floats, s));
     GPool gp;
     for (int i = 0; i < 6; ++i) gp.buf[i] = W + r->w_gbuf[i];
     // visual_fc

@@ -43,6 +43,6 @@ int groupnorm_backward(const GnBwdArgs& a, hipStream_t s);
 int maxpool_forward(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t s);
 int maxpool_backward(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t s);
 int embed_forward(const EmbedArgs& a, hipStream_t s);
-int embed_backward(const EmbedBwdArgs& a, hipStream_t s);
+int embed_backward(const EmbedBwdArgs& a, float* ws, size_t ws_floats, hipStream_t s);
 
 }  // namespace hab

@@ -16,6 +16,7 @@ namespace hab {
 __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
                                                           const int* __restrict__ rows, float* __restrict__ y, int B, int H, int W,
                                                           int cpad, int depth_first) {
+#pragma clang fp contract(off)  // the reference rounds the uint8 scaling and every addition of the 2x2 average separately
     const int Ho = H / 2, Wo = W / 2;
     const long long total = (long long)B * Ho * Wo;
     const float inv255 = (float)(1.0 / 255.0);
@@ -37,18 +38,18 @@ __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restr
                 for (int dw = 0; dw < 2; ++dw) {
                     const uint8_t* p = rgb + ((srow * H + 2 * ho + dh) * W + 2 * wo + dw) * 3;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) s[c] = __fadd_rn(s[c], __fmul_rn((float)p[c], inv255));
+                    for (int c = 0; c < 3; ++c) { const float m = (float)p[c] * inv255; s[c] = s[c] + m; }
                 }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) out[c_rgb + c] = __fmul_rn(s[c], 0.25f);
+            for (int c = 0; c < 3; ++c) out[c_rgb + c] = s[c] * 0.25f;
         }
         if (depth) {
             float s = 0.f;
 #pragma unroll
             for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
-                for (int dw = 0; dw < 2; ++dw) s = __fadd_rn(s, depth[(srow * H + 2 * ho + dh) * W + 2 * wo + dw]);
-            out[c_depth] = __fmul_rn(s, 0.25f);
+                for (int dw = 0; dw < 2; ++dw) s = s + depth[(srow * H + 2 * ho + dh) * W + 2 * wo + dw];
+            out[c_depth] = s * 0.25f;
         }
         float* o = y + (size_t)e * cpad;
         for (int c = 0; c < cpad; c += 4) *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(out + c);
@@ -390,68 +391,75 @@ int groupnorm_backward(const GnBwdArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
                                                           int B, int H, int W, int C) {
-    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const long long total = (long long)B * Ho * Wo * C;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, C4 = C >> 2;
+    const long long total = (long long)B * Ho * Wo * C4;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        long long t = e / C;
+        const int c4 = (int)(e % C4);
+        long long t = e / C4;
         const int wo = (int)(t % Wo); t /= Wo;
         const int ho = (int)(t % Ho);
         const int f = (int)(t / Ho);
-        float best = -INFINITY;
-        int bi = 0;
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int h = ho * 2 - 1 + kh;
             if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int w = wo * 2 - 1 + kw;
                 if ((unsigned)w >= (unsigned)W) continue;
-                const float v = x[(((size_t)f * H + h) * W + w) * C + c];
-                if (v > best || v != v) { best = v; bi = kh * 3 + kw; }
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((size_t)f * H + h) * W + w) * C + c4 * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; bi[k] = kh * 3 + kw; }  // first maximum in scan order (ATen)
             }
         }
-        y[e] = best;
-        idx[e] = (uint8_t)bi;
+        *reinterpret_cast<f32x4*>(y + e * 4) = best;
+        *reinterpret_cast<uint32_t*>(idx + e * 4) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     }
 }
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           float* __restrict__ dx, int B, int H, int W, int C) {
-    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const long long total = (long long)B * H * W * C;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, C4 = C >> 2;
+    const long long total = (long long)B * H * W * C4;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        long long t = e / C;
+        const int c4 = (int)(e % C4);
+        long long t = e / C4;
         const int w = (int)(t % W); t /= W;
         const int h = (int)(t % H);
         const int f = (int)(t / H);
-        float s = 0.f;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
         // windows (ho, wo) with ho*2-1 <= h <= ho*2+1
-        for (int ho = (h) / 2; ho <= (h + 1) / 2; ++ho) {
+        for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
             if (ho >= Ho) continue;
             const int kh = h - (ho * 2 - 1);
-            if (kh < 0 || kh > 2) continue;
-            for (int wo = (w) / 2; wo <= (w + 1) / 2; ++wo) {
+            for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
                 if (wo >= Wo) continue;
                 const int kw = w - (wo * 2 - 1);
-                if (kw < 0 || kw > 2) continue;
-                const size_t o = (((size_t)f * Ho + ho) * Wo + wo) * C + c;
-                if (idx[o] == kh * 3 + kw) s += dy[o];
+                const size_t o = (((size_t)f * Ho + ho) * Wo + wo) * C + c4 * 4;
+                const uint32_t id = *reinterpret_cast<const uint32_t*>(idx + o);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+                const uint32_t me = (uint32_t)(kh * 3 + kw);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (((id >> (8 * k)) & 0xffu) == me) s[k] += d[k];
             }
         }
-        dx[e] = s;
+        *reinterpret_cast<f32x4*>(dx + e * 4) = s;
     }
 }
 int maxpool_forward(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t s) {
-    if (!x || !y || !idx || B <= 0) return HAB_ERR_ARG;
-    const long long total = (long long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C;
-    maxpool_fwd_kernel<<<(int)fmin(16384.0, (double)cdivl(total, 256)), 256, 0, s>>>(x, y, idx, B, H, W, C);
+    if (!x || !y || !idx || B <= 0 || (C & 3)) return HAB_ERR_ARG;
+    const long long total = (long long)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 4);
+    maxpool_fwd_kernel<<<(int)fmin(32768.0, (double)cdivl(total, 256)), 256, 0, s>>>(x, y, idx, B, H, W, C);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
 int maxpool_backward(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t s) {
-    if (!dy || !idx || !dx || B <= 0) return HAB_ERR_ARG;
-    const long long total = (long long)B * H * W * C;
-    maxpool_bwd_kernel<<<(int)fmin(16384.0, (double)cdivl(total, 256)), 256, 0, s>>>(dy, idx, dx, B, H, W, C);
+    if (!dy || !idx || !dx || B <= 0 || (C & 3)) return HAB_ERR_ARG;
+    const long long total = (long long)B * H * W * (C / 4);
+    maxpool_bwd_kernel<<<(int)fmin(32768.0, (double)cdivl(total, 256)), 256, 0, s>>>(dy, idx, dx, B, H, W, C);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -487,29 +495,108 @@ int embed_forward(const EmbedArgs& a, hipStream_t s) {
     return HAB_OK;
 }
 
-// grid = 4 (dW_t[:, g] for g = 0..2, db_t) + (A+1) embedding rows; fixed-order frame loops (deterministic)
-__global__ void __launch_bounds__(64) embed_bwd_kernel(const EmbedBwdArgs a) {
-    const int b = blockIdx.x, j = threadIdx.x;
-    if (j >= 32) return;
+// Outputs: 4 + num_tokens rows of 32 floats (dW_t[:, 0..2], db_t, dE[tok]).  Stage 1: grid (rows, frame chunks), each
+// workgroup of 256 threads = 8 frame lanes x 32 columns sums its chunk in a fixed order; stage 2 folds the chunks.
+__global__ void __launch_bounds__(256) embed_bwd_stage1(const EmbedBwdArgs a, int frames_per_chunk, float* __restrict__ partial) {
+    __shared__ float sm[256];
+    const int b = blockIdx.x, j = threadIdx.x & 31, fl = threadIdx.x >> 5;
+    const int f0 = blockIdx.y * frames_per_chunk, f1 = min(a.B, f0 + frames_per_chunk);
     float s = 0.f;
     if (b < 4) {
-        for (int f = 0; f < a.B; ++f) {
+        for (int f = f0 + fl; f < f1; f += 8) {
             const float d = a.dout[(size_t)f * a.ld + a.col0 + j];
             s += b < 3 ? d * a.saved[(size_t)f * 4 + b] : d;
         }
-        if (b < 3) a.dw_t[j * 3 + b] = s; else a.db_t[j] = s;
     } else {
         const float tok = (float)(b - 4);
-        for (int f = 0; f < a.B; ++f)
+        for (int f = f0 + fl; f < f1; f += 8)
             if (a.saved[(size_t)f * 4 + 3] == tok) s += a.dout[(size_t)f * a.ld + a.col0 + 32 + j];
-        a.demb[(size_t)(b - 4) * 32 + j] = s;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (fl == 0) {
+        float t = 0.f;
+        for (int q = 0; q < 8; ++q) t += sm[q * 32 + j];
+        partial[((size_t)blockIdx.y * gridDim.x + b) * 32 + j] = t;
     }
 }
-int embed_backward(const EmbedBwdArgs& a, hipStream_t s) {
-    if (!a.saved || !a.dout || !a.dw_t || !a.db_t || !a.demb || a.B <= 0) return HAB_ERR_ARG;
-    embed_bwd_kernel<<<4 + a.num_tokens, 64, 0, s>>>(a);
+__global__ void __launch_bounds__(32) embed_bwd_stage2(const EmbedBwdArgs a, const float* __restrict__ partial, int chunks, int rows) {
+    const int b = blockIdx.x, j = threadIdx.x;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += partial[((size_t)c * rows + b) * 32 + j];
+    if (b < 3) a.dw_t[j * 3 + b] = s;
+    else if (b == 3) a.db_t[j] = s;
+    else a.demb[(size_t)(b - 4) * 32 + j] = s;
+}
+int embed_backward(const EmbedBwdArgs& a, float* ws, size_t ws_floats, hipStream_t s) {
+    if (!a.saved || !a.dout || !a.dw_t || !a.db_t || !a.demb || a.B <= 0 || !ws) return HAB_ERR_ARG;
+    const int rows = 4 + a.num_tokens;
+    int chunks = cdiv(a.B, 64);
+    if (chunks > 128) chunks = 128;
+    if ((size_t)chunks * rows * 32 > ws_floats) return HAB_ERR_ARG;
+    const int fpc = cdiv(a.B, chunks);
+    chunks = cdiv(a.B, fpc);
+    embed_bwd_stage1<<<dim3(rows, chunks), 256, 0, s>>>(a, fpc, ws);
+    HAB_LAUNCH_CHECK();
+    embed_bwd_stage2<<<rows, 32, 0, s>>>(a, ws, chunks, rows);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
 
 }  // namespace hab
+
+// ------------------------------------------- C ABI -------------------------------------------
+using namespace hab;
+
+extern "C" int hab_obs_ingest_pool(const uint8_t* rgb, const float* depth, const int* rows, float* y, int B, int H, int W, int cpad,
+                                   int depth_first, hipStream_t stream) {
+    return ingest_pool(rgb, depth, rows, y, B, H, W, cpad, depth_first, stream);
+}
+extern "C" int hab_channel_moments(const float* x, int64_t npix, int cpad, int mode, const float* mean, float* out, double* scratch,
+                                   int scratch_len, hipStream_t stream) {
+    return chan_moment(x, npix, cpad, mode, mean, out, scratch, scratch_len, stream);
+}
+extern "C" int hab_running_mean_var_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n,
+                                           int C, hipStream_t stream) {
+    return rmv_update(r_mean, r_var, r_count, b_mean, b_var, n, C, stream);
+}
+extern "C" int hab_running_mean_var_normalize(float* x, int64_t npix, int cpad, int C, const float* mean, const float* var,
+                                              hipStream_t stream) {
+    return rmv_normalize(x, npix, cpad, C, mean, var, stream);
+}
+extern "C" int hab_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* residual, float* mean,
+                                 float* rstd, int B, int HW, int C, int groups, int relu, float eps, hipStream_t stream) {
+    GnArgs a;
+    a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.residual = residual; a.mean = mean; a.rstd = rstd;
+    a.B = B; a.HW = HW; a.C = C; a.groups = groups; a.relu = relu; a.eps = eps;
+    return groupnorm_forward(a, stream);
+}
+extern "C" int hab_groupnorm_bwd(const float* x, const float* dy, const float* relu_out, float* dx, float* dy_masked, const float* gamma,
+                                 const float* mean, const float* rstd, float* chan_sums, int B, int HW, int C, int groups,
+                                 hipStream_t stream) {
+    GnBwdArgs a;
+    a.x = x; a.dy = dy; a.relu_out = relu_out; a.dx = dx; a.dy_masked = dy_masked; a.gamma = gamma; a.mean = mean; a.rstd = rstd;
+    a.chan_sums = chan_sums; a.B = B; a.HW = HW; a.C = C; a.groups = groups;
+    return groupnorm_backward(a, stream);
+}
+extern "C" int hab_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t stream) {
+    return maxpool_forward(x, y, idx, B, H, W, C, stream);
+}
+extern "C" int hab_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t stream) {
+    return maxpool_backward(dy, idx, dx, B, H, W, C, stream);
+}
+extern "C" int hab_nav_embed_fwd(const float* goal, const int64_t* prev_actions, const uint8_t* masks, const int* rows, const float* w_t,
+                                 const float* b_t, const float* emb, float* out, int ld, int col0, int B, float* saved,
+                                 hipStream_t stream) {
+    EmbedArgs a;
+    a.goal = goal; a.prev_actions = prev_actions; a.masks = masks; a.rows = rows; a.w_t = w_t; a.b_t = b_t; a.emb = emb;
+    a.out = out; a.ld = ld; a.col0 = col0; a.B = B; a.saved = saved;
+    return embed_forward(a, stream);
+}
+extern "C" int hab_nav_embed_bwd(const float* saved, const float* dout, int ld, int col0, int B, int num_tokens, float* dw_t, float* db_t,
+                                 float* demb, float* ws, size_t ws_floats, hipStream_t stream) {
+    EmbedBwdArgs a;
+    a.saved = saved; a.dout = dout; a.ld = ld; a.col0 = col0; a.B = B; a.num_tokens = num_tokens; a.dw_t = dw_t; a.db_t = db_t;
+    a.demb = demb;
+    return embed_backward(a, ws, ws_floats, stream);
+}

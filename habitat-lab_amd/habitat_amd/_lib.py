@@ -59,6 +59,16 @@ SIGNATURES = {
     "hab_repack_conv_weight": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
     "hab_repack_flatten_weight": (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     "hab_transpose2d": (c_int, [vp, vp, c_int, c_int, vp]),
+    "hab_obs_ingest_pool": (c_int, [vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
+    "hab_channel_moments": (c_int, [vp, c_int64, c_int, c_int, vp, vp, vp, c_int, vp]),
+    "hab_running_mean_var_update": (c_int, [vp, vp, vp, vp, vp, c_float, c_int, vp]),
+    "hab_running_mean_var_normalize": (c_int, [vp, c_int64, c_int, c_int, vp, vp, vp]),
+    "hab_groupnorm_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_float, vp]),
+    "hab_groupnorm_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
+    "hab_maxpool3x3s2_fwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
+    "hab_maxpool3x3s2_bwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
+    "hab_nav_embed_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp]),
+    "hab_nav_embed_bwd": (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]),
     "hab_build_pack_info": (c_int, [vp, c_int, c_int] + [vp] * 12),
     "hab_policy_create": (c_int, [POINTER(PolicyDesc), POINTER(vp)]),
     "hab_policy_destroy": (None, [vp]),

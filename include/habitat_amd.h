@@ -131,6 +131,41 @@ int hab_repack_flatten_weight(const float* w, float* w_packed, int N, int C, int
 int hab_transpose2d(const float* w, float* wt, int R, int C, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * HBM-bound kernels of the GroupNorm-ResNet encoder (rl/ddppo/policy/resnet_policy.py:255-276, resnet.py:196-281,
+ * running_mean_and_var.py:24-78).  All NHWC fp32, channel counts multiples of 4.
+ * ------------------------------------------------------------------------------------------- */
+/* Ingest: per visual key permute -> uint8 * fp32(1/255) -> cat (rgb,depth or depth,rgb) -> avg_pool2d(2); channels
+ * zero-padded to cpad (4 or 8); observations read in place through rows[] (resnet_policy.py:259-271). */
+int hab_obs_ingest_pool(const uint8_t* rgb, const float* depth, const int* rows, float* y, int B, int H, int W, int cpad,
+                        int depth_first, hipStream_t stream);
+/* Channel moments over all pixels: mode 0 -> out[c] = mean, mode 1 -> out[c] = mean((x - mean[c])^2)
+ * (running_mean_and_var.py:33-45).  scratch: >= 1024*cpad doubles. */
+int hab_channel_moments(const float* x, int64_t npix, int cpad, int mode, const float* mean, float* out, double* scratch,
+                        int scratch_len, hipStream_t stream);
+/* Chan merge of the running statistics with a batch of n frames (running_mean_and_var.py:54-71). */
+int hab_running_mean_var_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C,
+                                hipStream_t stream);
+/* x = addcmul(-mean*inv_std, x, inv_std), inv_std = rsqrt(max(var, 1e-2)), in place (running_mean_and_var.py:73-78). */
+int hab_running_mean_var_normalize(float* x, int64_t npix, int cpad, int C, const float* mean, const float* var, hipStream_t stream);
+/* nn.GroupNorm forward [+ residual] [+ ReLU] (resnet.py:51-57,67-69); mean / rstd ([B][groups]) are kept for backward. */
+int hab_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* residual, float* mean,
+                      float* rstd, int B, int HW, int C, int groups, int relu, float eps, hipStream_t stream);
+/* GroupNorm backward with the ReLU mask of the fused output (relu_out, nullable) applied to dy first; dy_masked (nullable)
+ * receives the masked dy (gradient of the residual branch); chan_sums [B][2][C] = per-frame sum dy', sum dy'*xhat
+ * (reduce over frames with hab_colsum -> dbeta, dgamma). */
+int hab_groupnorm_bwd(const float* x, const float* dy, const float* relu_out, float* dx, float* dy_masked, const float* gamma,
+                      const float* mean, const float* rstd, float* chan_sums, int B, int HW, int C, int groups, hipStream_t stream);
+/* nn.MaxPool2d(3, stride 2, padding 1) (resnet.py:220); idx = window offset of the first maximum (1 byte per output). */
+int hab_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t stream);
+int hab_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t stream);
+/* tgt_embeding([rho, cos(-phi), sin(-phi)]) and prev_action_embedding(mask ? a+1 : 0) written to out[:, col0:col0+64]
+ * (resnet_policy.py:662-692,747-753); saved [B][4] keeps the goal features + token for the backward pass. */
+int hab_nav_embed_fwd(const float* goal, const int64_t* prev_actions, const uint8_t* masks, const int* rows, const float* w_t,
+                      const float* b_t, const float* emb, float* out, int ld, int col0, int B, float* saved, hipStream_t stream);
+int hab_nav_embed_bwd(const float* saved, const float* dout, int ld, int col0, int B, int num_tokens, float* dw_t, float* db_t,
+                      float* demb, float* ws, size_t ws_floats, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * build_pack_info_from_dones (rl/models/rnn_state_encoder.py:35-168), HOST routine (no GPU).
  * dones: (T,N) row-major bytes.  Output arrays sized: select_inds T*N; num_seqs_at_step T; the
  * per-fragment arrays T*N (worst case); the per-env arrays N.  Ties between equal-length fragments

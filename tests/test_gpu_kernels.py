@@ -355,3 +355,115 @@ def test_igemm_transpose_detecting_identity(L):
     y = torch.zeros(M, N, device="cuda")
     ck(L.hab_linear_fwd(P(x.cuda()), K, P(w.cuda()), K, None, P(y), N, M, N, K, 0, 0, None, 0, S()))
     assert torch.equal(y.cpu(), w.t().contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
+# HBM-bound kernels of the GroupNorm-ResNet encoder
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,HW,Cc,groups,relu,res", [(3, 64 * 64, 32, 16, 1, 0), (2, 100, 64, 16, 1, 1), (5, 16, 256, 16, 0, 0),
+                                                      (2, 4, 1024, 16, 1, 1), (3, 16, 128, 1, 1, 0), (2, 1, 2048, 1, 1, 0)])
+def test_groupnorm_fwd_bwd(L, B, HW, Cc, groups, relu, res):
+    torch.manual_seed(B * 10 + Cc)
+    x = torch.randn(B, Cc, HW, 1, requires_grad=True)
+    g = (1 + 0.1 * torch.randn(Cc)).requires_grad_()
+    b = (0.1 * torch.randn(Cc)).requires_grad_()
+    r = torch.randn(B, Cc, HW, 1, requires_grad=True) if res else None
+    y_ref = F.group_norm(x, groups, g, b, eps=1e-5)
+    if res:
+        y_ref = y_ref + r
+    if relu:
+        y_ref = F.relu(y_ref)
+    xh, rh = nhwc(x.detach()).cuda(), (nhwc(r.detach()).cuda() if res else None)
+    y = torch.zeros(B, HW, Cc, device="cuda")
+    mean, rstd = torch.zeros(B, groups, device="cuda"), torch.zeros(B, groups, device="cuda")
+    ck(L.hab_groupnorm_fwd(P(xh), P(y), P(g.detach().cuda()), P(b.detach().cuda()), P(rh), P(mean), P(rstd), B, HW, Cc, groups, relu, 1e-5, S()))
+    assert torch.allclose(y.cpu().view(B, HW, 1, Cc), nhwc(y_ref), atol=2e-5, rtol=1e-4)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    dy = nhwc(gy).cuda().view(B, HW, Cc)
+    dx = torch.zeros(B, HW, Cc, device="cuda")
+    dym = torch.zeros(B, HW, Cc, device="cuda")
+    cs = torch.zeros(B, 2, Cc, device="cuda")
+    ck(L.hab_groupnorm_bwd(P(xh), P(dy), P(y) if relu else None, P(dx), P(dym), P(g.detach().cuda()), P(mean), P(rstd), P(cs), B, HW, Cc,
+                           groups, S()))
+    scale = x.grad.abs().max().item()
+    assert (dx.cpu().view(B, HW, 1, Cc) - nhwc(x.grad)).abs().max().item() <= 1e-4 * scale + 1e-6
+    assert torch.allclose(cs[:, 0].sum(0).cpu(), b.grad, rtol=1e-4, atol=1e-4 * b.grad.abs().max().item())
+    assert torch.allclose(cs[:, 1].sum(0).cpu(), g.grad, rtol=1e-4, atol=1e-4 * g.grad.abs().max().item())
+    if res:  # the masked dy is the gradient of the residual branch
+        assert torch.allclose(dym.cpu().view(B, HW, 1, Cc), nhwc(r.grad), atol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 64, 64, 32), (3, 9, 13, 32), (1, 7, 7, 64)])
+def test_maxpool_fwd_bwd(L, B, H, W, Cc):
+    torch.manual_seed(H)
+    x = torch.relu(torch.randn(B, Cc, H, W)).requires_grad_()  # post-ReLU input: many exact ties at 0
+    y_ref = F.max_pool2d(x, 3, 2, 1)
+    Ho, Wo = y_ref.shape[2:]
+    y = torch.zeros(B, Ho, Wo, Cc, device="cuda")
+    idx = torch.zeros(B, Ho, Wo, Cc, dtype=torch.uint8, device="cuda")
+    ck(L.hab_maxpool3x3s2_fwd(P(nhwc(x.detach()).cuda()), P(y), P(idx), B, H, W, Cc, S()))
+    assert torch.equal(y.cpu(), nhwc(y_ref))
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    dx = torch.zeros(B, H, W, Cc, device="cuda")
+    ck(L.hab_maxpool3x3s2_bwd(P(nhwc(gy).cuda()), P(idx), P(dx), B, H, W, Cc, S()))
+    assert torch.allclose(dx.cpu(), nhwc(x.grad), atol=1e-6)  # same arg-max choice as ATen on ties
+
+
+@pytest.mark.parametrize("keys", [("rgb", "depth"), ("depth", "rgb"), ("depth",), ("rgb",)])
+def test_ingest_and_running_mean_var(L, keys):
+    torch.manual_seed(3)
+    nrows, B, H, W = 7, 4, 20, 24
+    rows = torch.randperm(nrows)[:B].int()
+    obs_all = {"rgb": torch.randint(0, 256, (nrows, H, W, 3), dtype=torch.uint8), "depth": torch.rand(nrows, H, W, 1)}
+    obs = {k: obs_all[k][rows.long()] for k in keys}
+    x_ref = O.resnet_input(obs, list(keys))
+    n_in = x_ref.shape[1]
+    y = torch.full((B, H // 2, W // 2, 4), 9.0, device="cuda")
+    ck(L.hab_obs_ingest_pool(P(obs_all["rgb"].cuda()) if "rgb" in keys else None, P(obs_all["depth"].cuda()) if "depth" in keys else None,
+                             P(rows.cuda()), P(y), B, H, W, 4, int(keys[0] == "depth" and len(keys) == 2), S()))
+    assert torch.equal(y.cpu()[..., :n_in], nhwc(x_ref)), "uint8 scaling + 2x2 average must be bitwise the reference's arithmetic"
+    assert float(y[..., n_in:].abs().max()) == 0.0 if n_in < 4 else True
+    mean0, var0, cnt0 = torch.rand(1, n_in, 1, 1), torch.rand(1, n_in, 1, 1) * 0.1, torch.tensor(5.0)
+    xn_ref, m_ref, v_ref, c_ref = O.running_mean_and_var(x_ref, mean0, var0, cnt0, True)
+    npix = B * (H // 2) * (W // 2)
+    st = torch.zeros(16, device="cuda")
+    scratch = torch.zeros(1024 * 4, dtype=torch.float64, device="cuda")
+    rm, rv, rc = mean0.view(-1).cuda().contiguous(), var0.view(-1).cuda().contiguous(), cnt0.view(1).cuda().contiguous()
+    ck(L.hab_channel_moments(P(y), npix, 4, 0, None, P(st), P(scratch), scratch.numel(), S()))
+    ck(L.hab_channel_moments(P(y), npix, 4, 1, P(st), P(st[8:]), P(scratch), scratch.numel(), S()))
+    ck(L.hab_running_mean_var_update(P(rm), P(rv), P(rc), P(st), P(st[8:]), float(B), n_in, S()))
+    ck(L.hab_running_mean_var_normalize(P(y), npix, 4, n_in, P(rm), P(rv), S()))
+    assert torch.allclose(rm.cpu(), m_ref.view(-1), rtol=1e-5, atol=1e-6) and torch.allclose(rv.cpu(), v_ref.view(-1), rtol=1e-5, atol=1e-6)
+    assert float(rc.cpu()) == float(c_ref)
+    assert torch.allclose(y.cpu()[..., :n_in], nhwc(xn_ref), rtol=1e-5, atol=1e-5)
+
+
+def test_nav_embeddings_fwd_bwd(L):
+    torch.manual_seed(4)
+    B, nrows, ld, col0, A = 37, 50, 80, 12, 4
+    rows = torch.randperm(nrows)[:B].int()
+    goal = torch.stack([torch.rand(nrows) * 5, (torch.rand(nrows) - 0.5) * 6], 1)
+    pa = torch.randint(0, A, (nrows, 1))
+    masks = torch.rand(nrows, 1) > 0.3
+    w_t, b_t = torch.randn(32, 3, requires_grad=True), torch.randn(32, requires_grad=True)
+    emb = torch.randn(A + 1, 32, requires_grad=True)
+    g = goal[rows.long()]
+    g3 = torch.stack([g[:, 0], torch.cos(-g[:, 1]), torch.sin(-g[:, 1])], -1)
+    tok = torch.where(masks[rows.long()].view(-1), pa[rows.long()].view(-1) + 1, torch.zeros(B, dtype=torch.long))
+    ref = torch.cat([F.linear(g3, w_t, b_t), F.embedding(tok, emb)], 1)
+    out = torch.zeros(B, ld, device="cuda")
+    saved = torch.zeros(B, 4, device="cuda")
+    ck(L.hab_nav_embed_fwd(P(goal.cuda()), P(pa.cuda()), P(masks.cuda()), P(rows.cuda()), P(w_t.detach().cuda()), P(b_t.detach().cuda()),
+                           P(emb.detach().cuda()), P(out), ld, col0, B, P(saved), S()))
+    assert torch.allclose(out.cpu()[:, col0:col0 + 64], ref, atol=1e-5, rtol=1e-5)
+    gy = torch.randn(B, 64)
+    ref.backward(gy)
+    dout = torch.zeros(B, ld)
+    dout[:, col0:col0 + 64] = gy
+    dw, db, de = torch.zeros(32, 3, device="cuda"), torch.zeros(32, device="cuda"), torch.zeros(A + 1, 32, device="cuda")
+    ws = torch.zeros(1 << 16, device="cuda")
+    ck(L.hab_nav_embed_bwd(P(saved), P(dout.cuda()), ld, col0, B, A + 1, P(dw), P(db), P(de), P(ws), ws.numel(), S()))
+    assert torch.allclose(dw.cpu(), w_t.grad, atol=1e-4, rtol=1e-4) and torch.allclose(db.cpu(), b_t.grad, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(de.cpu(), emb.grad, atol=1e-4, rtol=1e-4)
