@@ -12,14 +12,6 @@ namespace hab {
 template <class P>
 static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream, int target_blocks = 1024) {
     constexpr bool WG = !P::A_RC && !P::B_RC && AKv<P>::value == 4;  // weight-gradient form
-    if constexpr (P::A_RC && P::B_RC) {  // narrow outputs: wave-private A staging, resident B chunk (igemm.h)
-        const int ktiles = cdiv(p.K, IGEMM_BK);
-        if (p.N <= 32 && p.M > 64) {
-            if (ktiles % 8 == 0) return igemm_wp_launch<P, 2, 1, 4, 8>(p, ws, ws_floats, target_blocks, stream);
-            return igemm_wp_launch<P, 2, 1, 4, 9>(p, ws, ws_floats, target_blocks, stream);
-        }
-        if (p.N > 32 && p.N <= 64 && p.M > 64) return igemm_wp_launch<P, 2, 2, 4, 4>(p, ws, ws_floats, target_blocks, stream);
-    }
     if (p.N <= 32) {
         if (p.M <= 64) return igemm_launch<P, 1, 1, 2, 1>(p, ws, ws_floats, target_blocks, stream);
         if constexpr (WG) {

@@ -284,174 +284,6 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
         }
 }
 
-// -------------------------------------------------------------------------------------------------------------
-// Wave-private variant for r-contiguous problems with a narrow output (N <= 64: Cout = 32 / 64 convolutions and
-// their data gradients).  With one wave column (WN = 1) no two waves share A rows, so
-//   * each wave stages ITS rows (TM*32 x 32 k) in a private LDS region: global -> registers -> LDS -> ds_read_b128
-//     fragments without any workgroup barrier (LDS operations of one wave execute in order);
-//   * the B operand (packed weights, <= 37 KB per chunk) is loaded once per chunk of KC K-tiles and stays resident,
-//     so the only barriers are the two around a chunk load (one chunk for K <= 288).
-// The waves of a workgroup run decoupled: while one waits for its gathers another issues MFMAs.  Measured on the
-// barrier-per-K-tile kernel above, the compute side alone (gathers removed) reached only 67 % of the fp32 MFMA peak
-// with 256x32 tiles because the four SIMDs of a CU had to rendezvous twice per 32 MFMAs.
-// -------------------------------------------------------------------------------------------------------------
-template <class P, int TM, int TN, int WM, int KC>
-struct IgemmWpCfg {
-    static constexpr int NT = WM * 64, BM = WM * TM * 32, BN = TN * 32, BK = IGEMM_BK, LDK = BK + 4, KV = AKv<P>::value;
-    static constexpr int LDB = KC * BK + 4;
-    static constexpr int A_WAVE = TM * 32 * LDK;
-    static constexpr int A_UNITS = TM * 32 * BK / KV / 64;
-    static constexpr int B_TOTAL = BN * KC * BK / 4, B_UNITS = (B_TOTAL + NT - 1) / NT;
-    static constexpr size_t LDS_BYTES = (size_t)(BN * LDB + WM * A_WAVE) * sizeof(float);
-    static_assert(P::A_RC && P::B_RC, "wave-private kernel needs r-contiguous operands");
-    static_assert((TM * 32 * BK / KV) % 64 == 0, "A units per wave");
-};
-
-template <class P, int TM, int TN, int WM, int KC>
-__global__ void __launch_bounds__(WM * 64) igemm_wp_kernel(const P p, const int k_per_split, float* __restrict__ partial) {
-    using Cfg = IgemmWpCfg<P, TM, TN, WM, KC>;
-    constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, LDK = Cfg::LDK, KV = Cfg::KV, LDB = Cfg::LDB;
-    constexpr int A_UNITS = Cfg::A_UNITS, B_UNITS = Cfg::B_UNITS, B_TOTAL = Cfg::B_TOTAL;
-    constexpr int AKQ = BK / KV;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Bs = smem;                                   // [BN][LDB]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    float* Aw = smem + BN * LDB + wave * Cfg::A_WAVE;   // this wave's [TM*32][LDK]
-    const int li = lane & 31, hi = lane >> 5;
-
-    const int nt_m = cdiv(p.M, BM), nt_n = cdiv(p.N, BN);
-    const int ntiles = nt_m * nt_n;
-    int tile;
-    {
-        const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, idx = b >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_n = tile % nt_n, tile_m = tile / nt_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int mw = m0 + wave * TM * 32;  // first row of this wave
-
-    const int kz = blockIdx.z;
-    const int k_begin = kz * k_per_split;
-    const int k_end = min(p.K, k_begin + k_per_split);
-    const int ntk = max(0, cdiv(k_end - k_begin, BK));
-
-    typename P::ACtx actx[A_UNITS];
-#pragma unroll
-    for (int j = 0; j < A_UNITS; ++j) actx[j] = p.a_ctx(mw + (lane + 64 * j) / AKQ);
-    const int akq = (lane % AKQ) * KV;  // k offset of this lane's units inside a K-tile (64 % AKQ == 0)
-    typename P::ARaw araw[A_UNITS];
-    auto fetch = [&](int kt) {
-        const int k = k_begin + kt * BK + akq;
-        const typename P::KCtx kc = p.k_ctx(k_begin + kt * BK, k_end);
-        const typename P::AKey ak = p.a_key(kc, k, k_end);
-#pragma unroll
-        for (int j = 0; j < A_UNITS; ++j) araw[j] = p.a_fetch(actx[j], kc, ak);
-    };
-    auto stage = [&](int kt) {
-        const int k = k_begin + kt * BK + akq;
-#pragma unroll
-        for (int j = 0; j < A_UNITS; ++j) {
-            f32x4 v[KV / 4];
-            p.a_cvt(actx[j], araw[j], k, k_end, v);
-            float* dst = Aw + ((lane + 64 * j) / AKQ) * LDK + akq;
-#pragma unroll
-            for (int q = 0; q < KV / 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = v[q];
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.0f;
-
-    if (ntk > 0) fetch(0);
-    for (int c0 = 0; c0 < ntk; c0 += KC) {
-        __syncthreads();  // every wave is done with the previous chunk of B
-        {
-            typename P::BRaw braw[B_UNITS];
-#pragma unroll
-            for (int j = 0; j < B_UNITS; ++j) {
-                const int u = t + NT * j;
-                if (B_TOTAL % NT == 0 || u < B_TOTAL) {
-                    const int col = u / (KC * 8), kk = u % (KC * 8);
-                    const int k = k_begin + c0 * BK + kk * 4;
-                    const typename P::KCtx kc = p.k_ctx(k - (k % BK), k_end);
-                    braw[j] = p.b_fetch(p.b_ctx(n0 + col), kc, p.b_key(kc, k, k_end));
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < B_UNITS; ++j) {
-                const int u = t + NT * j;
-                if (B_TOTAL % NT == 0 || u < B_TOTAL)
-                    *reinterpret_cast<f32x4*>(Bs + (u / (KC * 8)) * LDB + (u % (KC * 8)) * 4) = p.b_cvt(braw[j]);
-            }
-        }
-        __syncthreads();
-        const int kt_end = min(ntk, c0 + KC);
-        for (int kt = c0; kt < kt_end; ++kt) {
-            stage(kt);
-            __builtin_amdgcn_wave_barrier();
-            if (kt + 1 < ntk) fetch(kt + 1);
-            const float* bk = Bs + (kt - c0) * BK;
-#pragma unroll
-            for (int c = 0; c < BK / 8; ++c) {
-                f32x4 af[TM], bf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Aw + (i * 32 + li) * LDK + c * 8 + hi * 4);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bk + (j * 32 + li) * LDB + c * 8 + hi * 4);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-
-    // ---- epilogue (same as igemm_kernel) ----
-    if (gridDim.z > 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + j * 32 + li;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int row = mw + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
-                    if (row < p.M && col < p.N) partial[((size_t)kz * p.M + row) * p.N + col] = acc[i][j][v];
-                }
-            }
-        return;
-    }
-    typename P::EpiCol ecol[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) ecol[j] = p.epi_col(n0 + j * 32 + li);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            typename P::EpiRow erow[4];
-            typename P::EpiAux eaux[4][TN];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                erow[q] = p.epi_row(mw + i * 32 + q + 8 * g + 4 * hi);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) eaux[q][j] = p.epi_fetch(erow[q], ecol[j]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) p.epi_store(erow[q], ecol[j], eaux[q][j], acc[i][j][g * 4 + q]);
-        }
-}
-
 // Second pass of a split-K launch: fixed-order sum of the partial slabs, then the problem's epilogue.
 template <class P>
 __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const P p, const float* __restrict__ partial, int splits) {
@@ -498,32 +330,6 @@ inline int igemm_launch(const P& p, float* ws, size_t ws_floats, int target_bloc
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return HAB_ERR_ARG;
     const IgemmPlan pl = igemm_plan(Cfg::BM, Cfg::BN, p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
     auto kern = igemm_kernel<P, TM, TN, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    dim3 grid(cdiv(p.M, Cfg::BM) * cdiv(p.N, Cfg::BN), 1, pl.splits);
-    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, pl.k_per_split, ws);
-    HAB_LAUNCH_CHECK();
-    if (pl.splits > 1) {
-        int blocks = (int)cdivl((long long)(p.M + 1) * p.N, 256);
-        if (blocks > 4096) blocks = 4096;
-        igemm_splitk_reduce_kernel<P><<<blocks, 256, 0, stream>>>(p, ws, pl.splits);
-        HAB_LAUNCH_CHECK();
-    }
-    return HAB_OK;
-}
-
-template <class P, int TM, int TN, int WM, int KC>
-inline int igemm_wp_launch(const P& p, float* ws, size_t ws_floats, int target_blocks, hipStream_t stream) {
-    using Cfg = IgemmWpCfg<P, TM, TN, WM, KC>;
-    static_assert(!ColsumB<P>::value, "column sums ride on the weight-gradient form only");
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return HAB_ERR_ARG;
-    const IgemmPlan pl = igemm_plan(Cfg::BM, Cfg::BN, p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
-    auto kern = igemm_wp_kernel<P, TM, TN, WM, KC>;
     static bool attr_set = false;
     if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
