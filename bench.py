@@ -66,7 +66,7 @@ def make_trainer(workload: str, total_updates: int):
     return trainer, cfg
 
 
-def cpu_baseline(sample_envs=4, sample_steps=4):
+def cpu_baseline(sample_envs=16, sample_steps=16):
     """The oracle (CPU restatement of the reference path, pinned to the reference by tests/golden) timed on the host
     cores on a bounded sample of the same workload: same obs size, same E=4 x M=4 update, fewer envs x steps."""
     import types
@@ -113,6 +113,26 @@ def cpu_baseline(sample_envs=4, sample_steps=4):
     return {"value": round(N * T / dt, 2), "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{N} envs x {T} steps of the same workload (256x256 RGB-D, SimpleCNN+GRU, E=4 x M=4), oracle/functional.py on "
                       f"torch-CPU fp32, {dt:.1f} s (synthetic obs generation {t_env:.1f} s excluded)"}
+
+
+# kernel(s) launched by a probed call site, for the HBM-traffic lookup (conv2 dgrad = 4 stride-class launches)
+PROBE_KERNELS = {"conv2_dgrad": ("igemm_kernel<ConvDgradProb, 2, 1, 4, 1>", 4), "conv1_fwd": ("igemm_kernel<ObsConvFwdProb, 2, 1, 4, 1>", 1),
+                 "conv1_wgrad": ("igemm_kernel<ObsConvWgradProb, 2, 1, 4, 1>", 1)}
+
+
+def hbm_traffic(workload, probe):
+    """HBM bytes per probed call, from the committed rocprofv3 --pmc passes (profiles/r01_c2_hbm_traffic.json, produced by
+    tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate runs of this script, FETCH_SIZE doubled per the gfx950
+    note of MI355X_MICROARCH.md).  Hardware counters cannot be read from inside the timed run, so the figure is the profiled one;
+    null when the probed call site has no entry."""
+    path = os.path.join(ROOT, "profiles", "r01_c2_hbm_traffic.json")
+    if workload != "c2" or probe not in PROBE_KERNELS or not os.path.exists(path):
+        return None
+    name, launches = PROBE_KERNELS[probe]
+    for k, r in json.load(open(path)).items():
+        if name in k:
+            return round(launches * (r["fetch_bytes_per_call"] + r["write_bytes_per_call"]))
+    return None
 
 
 def main():
@@ -170,6 +190,7 @@ def main():
     frames = upd_frames + (roll_frames if a.probe.endswith("_fwd") else 0)
     kname = f"igemm_kernel<{a.probe}>" if not a.probe.startswith("enc_") else f"resnet18 encoder {a.probe[4:]} (all kernels)"
     ach = flops_per_frame * frames / (probe_ms * 1e-3) / 1e12 if probe_ms > 0 else None
+    traffic = hbm_traffic(a.workload, a.probe)
     out = {
         "metric": "env-steps/sec (SPS) PointNav RGB-D 256x256, 64 envs x 128 rollout",
         "value": round(steps_total / dt, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -179,7 +200,7 @@ def main():
                    "ppo_epoch": ppo.ppo_epoch, "num_mini_batch": ppo.num_mini_batch, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2) if ach else None,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4) if ach else None,
-                     "traffic": None, "launches": probe_cnt, "avg_launch_ms": round(probe_ms / max(probe_cnt, 1), 4)},
+                     "traffic": traffic, "launches": probe_cnt, "avg_launch_ms": round(probe_ms / max(probe_cnt, 1), 4)},
     }
     if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         out["cpu_baseline"] = cpu_baseline()
