@@ -100,16 +100,23 @@ def get_main_addr() -> str:
 
 
 def init_distrib_slurm(backend: str = "nccl"):
-    """Explicit TCPStore rendezvous + process group (ddp_utils.py:271-309).  Returns (local_rank, tcp_store)."""
+    """Rendezvous + process group (ddp_utils.py:271-309).  Returns (local_rank, store); the store also carries the
+    `num_done` counter of the preemptive straggler synchronisation (ppo_trainer.py:641-653).
+      * under torchrun (MASTER_ADDR / MASTER_PORT set, no MAIN_PORT): the launcher's own store is used
+        (`env://`), no extra port is opened;
+      * otherwise (SLURM / MAIN_ADDR + MAIN_PORT, as in the reference): an explicit TCPStore hosted by rank 0."""
     assert distrib.is_available(), "torch.distributed must be available"
     local_rank, world_rank, world_size = get_distrib_size()
-    main_port = int(os.environ.get("MAIN_PORT", os.environ.get("MASTER_PORT", DEFAULT_PORT)))
+    if "MASTER_PORT" in os.environ and "MAIN_PORT" not in os.environ and SLURM_JOBID is None:
+        os.environ.setdefault("MASTER_ADDR", DEFAULT_MAIN_ADDR)
+        distrib.init_process_group(backend.lower(), init_method="env://", rank=world_rank, world_size=world_size)
+        from torch.distributed import distributed_c10d
+        return local_rank, distributed_c10d._get_default_store()
+    main_port = int(os.environ.get("MAIN_PORT", DEFAULT_PORT))
     if SLURM_JOBID is not None:
         main_port += int(SLURM_JOBID) % int(os.environ.get("MAIN_PORT_RANGE", DEFAULT_PORT_RANGE))
     main_addr = get_main_addr()
-    # the store lives one port above MASTER_PORT so that it never collides with torchrun's own rendezvous
-    store_port = main_port + 1 if "MASTER_PORT" in os.environ and "MAIN_PORT" not in os.environ else main_port
-    tcp_store = distrib.TCPStore(main_addr, store_port, world_size, world_rank == 0)
+    tcp_store = distrib.TCPStore(main_addr, main_port, world_size, world_rank == 0)
     distrib.init_process_group(backend.lower(), store=tcp_store, rank=world_rank, world_size=world_size)
     return local_rank, tcp_store
 
