@@ -57,7 +57,7 @@ def make_trainer(workload: str, total_updates: int):
     cfg = get_config(w["yaml"], [f"habitat_baselines.num_environments={NUM_ENVS}", f"habitat_baselines.rl.ppo.num_steps={NUM_STEPS}",
                                  f"habitat_baselines.num_updates={total_updates}", "habitat_baselines.total_num_steps=-1",
                                  "habitat_baselines.num_checkpoints=-1", f"habitat_baselines.checkpoint_interval={10 ** 9}",
-                                 "habitat_baselines.rl.ddppo.distrib_backend=NCCL",
+                                 "habitat_baselines.rl.ddppo.distrib_backend=" + os.environ.get("HAB_BENCH_DISTRIB_BACKEND", "NCCL"),
                                  "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000",
                                  "habitat_baselines.checkpoint_folder=/tmp/habitat_amd_bench_ckpt",
                                  f"habitat.simulator.sensors.rgb.height={OBS}", f"habitat.simulator.sensors.rgb.width={OBS}",

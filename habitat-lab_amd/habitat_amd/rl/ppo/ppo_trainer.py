@@ -110,7 +110,8 @@ class PPOTrainer(BaseRLTrainer):
             if rank0_only():
                 logger.info("Initialized DD-PPO with {} workers".format(torch.distributed.get_world_size()))
             with read_write(self.config):
-                hb.torch_gpu_id = local_rank
+                # one GPU per rank; ranks wrap around when a box has fewer devices than ranks (debug runs on one GPU)
+                hb.torch_gpu_id = local_rank % max(1, torch.cuda.device_count()) if torch.cuda.is_available() else local_rank
                 # make sure every env of every rank gets a unique seed (ppo_trainer.py:208-211)
                 self.config.habitat.seed += torch.distributed.get_rank() * hb.num_environments
             random.seed(self.config.habitat.seed)
