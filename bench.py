@@ -66,7 +66,7 @@ def make_trainer(workload: str, total_updates: int):
     return trainer, cfg
 
 
-def cpu_baseline(sample_envs=16, sample_steps=16):
+def cpu_baseline(sample_envs=64, sample_steps=32):
     """The oracle (CPU restatement of the reference path, pinned to the reference by tests/golden) timed on the host
     cores on a bounded sample of the same workload: same obs size, same E=4 x M=4 update, fewer envs x steps."""
     import types

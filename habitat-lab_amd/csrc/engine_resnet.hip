@@ -48,6 +48,9 @@ struct ResNetPlan {
     std::vector<RnBlock> blocks;
     RnConv comp;
     int i_fcw = -1, i_fcb = -1, i_emb = -1, i_tgw = -1, i_tgb = -1, i_mean = -1, i_var = -1, i_count = -1;
+    int i_objw = -1, i_gpsw = -1, i_gpsb = -1, i_cmpw = -1, i_cmpb = -1;
+    int c_rgb = -1, c_depth = -1, c_sem = -1;  // first channel of each visual key in the concatenated encoder input
+    int nslots = 0;
     int64_t pk_fc = -1;
     int fc_in = 0, comp_c = 0, comp_hw = 0;
     // gradient scratch
@@ -76,16 +79,27 @@ int build_resnet(hab_policy* e) {
     if (d.baseplanes <= 0 || d.baseplanes % 8) return HAB_ERR_UNSUPPORTED;
     if ((d.H & 1) || (d.W & 1)) return HAB_ERR_UNSUPPORTED;
     if (d.rnn_type != HAB_RNN_GRU && d.rnn_type != HAB_RNN_LSTM) return HAB_ERR_ARG;
-    if (d.goal_dim != 2) return HAB_ERR_UNSUPPORTED;  // 2-D polar pointgoal (resnet_policy.py:662-672)
+    if (d.goal_dim != 0 && d.goal_dim != 2) return HAB_ERR_UNSUPPORTED;  // 2-D polar pointgoal (resnet_policy.py:662-672)
     ResNetPlan* r = new ResNetPlan();
     e->rn = r;
     const int H = d.hidden;
     e->G_ = d.rnn_type == HAB_RNN_GRU ? 3 : 4;
     e->L = d.rnn_layers;
-    r->creal = (d.has_rgb ? 3 : 0) + (d.has_depth ? 1 : 0);
+    r->creal = (d.has_rgb ? 3 : 0) + (d.has_depth ? 1 : 0) + (d.has_semantic ? 1 : 0);
     if (r->creal == 0) return HAB_ERR_UNSUPPORTED;
     e->Cin = r->creal;
-    r->cpad = 4;
+    r->cpad = r->creal <= 4 ? 4 : 8;
+    {   // channel offsets from the observation-space key order
+        int off = 0, seen = 0;
+        int order = d.visual_order ? d.visual_order : (1 | (2 << 2) | (3 << 4));
+        for (int q = 0; q < 3; ++q) {
+            const int key = (order >> (2 * q)) & 3;
+            if (key == 1 && d.has_rgb && r->c_rgb < 0) { r->c_rgb = off; off += 3; ++seen; }
+            else if (key == 2 && d.has_depth && r->c_depth < 0) { r->c_depth = off; off += 1; ++seen; }
+            else if (key == 3 && d.has_semantic && r->c_sem < 0) { r->c_sem = off; off += 1; ++seen; }
+        }
+        if (off != r->creal || seen != (d.has_rgb ? 1 : 0) + (d.has_depth ? 1 : 0) + (d.has_semantic ? 1 : 0)) return HAB_ERR_ARG;
+    }
     r->H2 = d.H / 2; r->W2 = d.W / 2;
     const int bp = d.baseplanes, ng = bp / 2;
     const bool bottleneck = d.backbone == 50;
@@ -95,8 +109,23 @@ int build_resnet(hab_policy* e) {
 
     // ---- parameter table in the reference's state_dict order (resnet_policy.py:389-396,454-456 first) ----
     r->i_emb = add_param(e, "net.prev_action_embedding.weight", {d.num_actions + 1, 32});
-    r->i_tgw = add_param(e, "net.tgt_embeding.weight", {32, 3});
-    r->i_tgb = add_param(e, "net.tgt_embeding.bias", {32});
+    r->nslots = 1;
+    if (d.goal_dim == 2) {
+        r->i_tgw = add_param(e, "net.tgt_embeding.weight", {32, 3});
+        r->i_tgb = add_param(e, "net.tgt_embeding.bias", {32});
+        ++r->nslots;
+    }
+    if (d.num_object_categories > 0) { r->i_objw = add_param(e, "net.obj_categories_embedding.weight", {d.num_object_categories, 32}); ++r->nslots; }
+    if (d.has_gps) {
+        r->i_gpsw = add_param(e, "net.gps_embedding.weight", {32, 2});
+        r->i_gpsb = add_param(e, "net.gps_embedding.bias", {32});
+        ++r->nslots;
+    }
+    if (d.has_compass) {
+        r->i_cmpw = add_param(e, "net.compass_embedding.weight", {32, 2});
+        r->i_cmpb = add_param(e, "net.compass_embedding.bias", {32});
+        ++r->nslots;
+    }
     const std::string ve = "net.visual_encoder.";
     if (d.normalize_visual_inputs) {
         r->i_mean = add_param(e, ve + "running_mean_and_var._mean", {1, r->creal, 1, 1});
@@ -154,7 +183,7 @@ int build_resnet(hab_policy* e) {
     r->i_fcw = add_param(e, "net.visual_fc.1.weight", {H, r->fc_in});
     r->i_fcb = add_param(e, "net.visual_fc.1.bias", {H});
     e->fc_in = r->fc_in;
-    e->rnn_in = H + 32 + 32;
+    e->rnn_in = H + 32 * r->nslots;
     e->rnn_ld = (e->rnn_in + 3) & ~3;
     const std::string rn = "net.state_encoder.rnn.";
     for (int l = 0; l < d.rnn_layers; ++l) {
@@ -218,7 +247,7 @@ int build_resnet(hab_policy* e) {
     r->w_chansums = wk.take(B * 2 * r->cmax);
     r->w_stats = wk.take(64);
     r->w_dscratch = wk.take(2 * 1024 * 8);  // 1024 blocks x 8 channels of double
-    r->w_embsave = wk.take(B * 4);
+    r->w_embsave = wk.take(B * 4 * EMB_MAX_SLOTS);
     // shared tail (RNN, heads) -- same layout as the SimpleCNN engine
     e->w_rnnin = wk.take(B * e->rnn_ld); e->w_drnnin = wk.take(B * e->rnn_ld);
     e->w_hinit = wk.take((int64_t)d.rnn_layers * F * H); e->w_cinit = wk.take((int64_t)d.rnn_layers * F * H);
@@ -261,6 +290,27 @@ int resnet_repack(hab_policy* e, hipStream_t s) {
     return HAB_OK;
 }
 
+// Embedding slots in the order PointNavResNetNet.forward concatenates them (resnet_policy.py:662-755):
+// pointgoal_with_gps_compass, objectgoal, compass, gps, previous action.
+static int fill_embed_slots(hab_policy* e, const hab_obs* obs, EmbedSlot* sl, bool grads) {
+    ResNetPlan* r = e->rn;
+    const hab_policy_desc& d = e->d;
+    int n = 0;
+    auto add = [&](int kind, const void* in, int iw, int ib, int ntok) {
+        EmbedSlot& q = sl[n++];
+        q.kind = kind; q.in = in; q.w = e->p(iw); q.b = ib >= 0 ? e->p(ib) : nullptr; q.ntok = ntok;
+        q.dw = grads ? e->g(iw) : nullptr; q.db = (grads && ib >= 0) ? e->g(ib) : nullptr;
+        return in != nullptr;
+    };
+    bool ok = true;
+    if (d.goal_dim == 2) ok &= add(EMB_POLAR, obs->goal, r->i_tgw, r->i_tgb, 0);
+    if (d.num_object_categories > 0) ok &= add(EMB_TOKEN, obs->objectgoal, r->i_objw, -1, d.num_object_categories);
+    if (d.has_compass) ok &= add(EMB_COSSIN, obs->compass, r->i_cmpw, r->i_cmpb, 0);
+    if (d.has_gps) ok &= add(EMB_LIN2, obs->gps, r->i_gpsw, r->i_gpsb, 0);
+    ok &= add(EMB_PREV, obs->prev_actions, r->i_emb, -1, d.num_actions + 1);
+    return (ok && n == r->nslots) ? HAB_OK : HAB_ERR_ARG;
+}
+
 // conv -> raw, GroupNorm (+residual, +ReLU) -> out
 static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, const float* residual, int relu, int B, hipStream_t s) {
     float* W = e->WK;
@@ -280,8 +330,9 @@ int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
     const hab_policy_desc& d = e->d;
     const int H = d.hidden;
     float* x0 = W + r->w_x0;
-    HAB_TRY(ingest_pool(d.has_rgb ? obs->rgb : nullptr, d.has_depth ? obs->depth : nullptr, rows, x0, B, d.H, d.W, r->cpad,
-                        d.depth_first, s));
+    if ((d.has_rgb && !obs->rgb) || (d.has_depth && !obs->depth) || (d.has_semantic && !obs->semantic)) return HAB_ERR_ARG;
+    HAB_TRY(ingest_pool(d.has_rgb ? obs->rgb : nullptr, d.has_depth ? obs->depth : nullptr, d.has_semantic ? obs->semantic : nullptr, rows,
+                        x0, B, d.H, d.W, r->cpad, r->c_rgb, r->c_depth, r->c_sem, s));
     const long long npix = (long long)B * r->H2 * r->W2;
     if (d.normalize_visual_inputs) {
         float* st = W + r->w_stats;  // [0..7] batch mean, [8..15] batch var
@@ -323,10 +374,10 @@ int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
     HAB_TRY(linear_fwd(W + r->comp.w_out, r->fc_in, e->PK + r->pk_fc, r->fc_in, e->p(r->i_fcb), W + e->w_rnnin, e->rnn_ld, B, H,
                        r->fc_in, 1, 0, ws, e->ws_floats, s));
     EmbedArgs ea;
-    ea.goal = obs->goal; ea.prev_actions = obs->prev_actions; ea.masks = masks; ea.rows = rows;
-    ea.w_t = e->p(r->i_tgw); ea.b_t = e->p(r->i_tgb); ea.emb = e->p(r->i_emb);
+    HAB_TRY(fill_embed_slots(e, obs, ea.slot, false));
+    ea.nslots = r->nslots; ea.masks = masks; ea.rows = rows;
     ea.out = W + e->w_rnnin; ea.ld = e->rnn_ld; ea.col0 = H; ea.B = B; ea.saved = W + r->w_embsave;
-    if (!obs->goal || !obs->prev_actions || !masks) return HAB_ERR_ARG;
+    if (!masks) return HAB_ERR_ARG;
     return embed_forward(ea, s);
 }
 
@@ -369,9 +420,8 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
     const int H = e->d.hidden;
     const float* dfc = W + e->w_drnnin;  // [B][rnn_ld]; first H columns already carry visual_fc's ReLU mask
     EmbedBwdArgs eb;
-    eb.saved = W + r->w_embsave; eb.dout = dfc; eb.ld = e->rnn_ld;
-    eb.col0 = H; eb.B = B; eb.num_tokens = e->d.num_actions + 1;
-    eb.dw_t = e->g(r->i_tgw); eb.db_t = e->g(r->i_tgb); eb.demb = e->g(r->i_emb);
+    HAB_TRY(fill_embed_slots(e, obs, eb.slot, true));
+    eb.nslots = r->nslots; eb.saved = W + r->w_embsave; eb.dout = dfc; eb.ld = e->rnn_ld; eb.col0 = H; eb.B = B;
     HAB_TRY(embed_backward(eb, ws, e->ws_floats, s));
     GPool gp;
     for (int i = 0; i < 6; ++i) gp.buf[i] = W + r->w_gbuf[i];

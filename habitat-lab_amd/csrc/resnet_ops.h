@@ -20,20 +20,39 @@ struct GnBwdArgs {
     float* chan_sums;                   // [B][2][C]: per-frame sum dy', sum dy'*xhat
     int B, HW, C, groups;
 };
+// 1-D sensor embeddings of PointNavResNetNet.forward (resnet_policy.py:662-753), each 32 wide, written side by side into
+// the RNN input.  Slot kinds:
+enum { EMB_POLAR = 0,   // pointgoal_with_gps_compass (rho, phi) -> Linear(3,32)([rho, cos(-phi), sin(-phi)])   :662-692
+       EMB_TOKEN = 1,   // objectgoal id -> Embedding(n_categories, 32)                                          :715-717
+       EMB_COSSIN = 2,  // compass x -> Linear(2,32)([cos x, sin x])                                             :719-729
+       EMB_LIN2 = 3,    // gps (x, y) -> Linear(2,32)                                                            :731-734
+       EMB_PREV = 4 };  // previous action -> Embedding(A+1, 32)(mask ? a + 1 : 0)                               :747-753
+constexpr int EMB_MAX_SLOTS = 5;
+struct EmbedSlot {
+    int kind;
+    const void* in;      // sensor buffer (arena rows): f32 [rows][2] / int64 [rows][1] / f32 [rows][1] / f32 [rows][2] / int64 [rows][1]
+    const float* w;      // Linear weight [32][nfeat] or embedding table [ntok][32]
+    const float* b;      // Linear bias or null
+    float* dw; float* db;  // gradients (backward only)
+    int ntok;
+};
+inline int emb_nfeat(int kind) { return kind == EMB_POLAR ? 3 : (kind == EMB_COSSIN || kind == EMB_LIN2) ? 2 : 0; }
 struct EmbedArgs {
-    const float* goal; const int64_t* prev_actions; const uint8_t* masks; const int* rows;
-    const float* w_t; const float* b_t; const float* emb;
+    EmbedSlot slot[EMB_MAX_SLOTS];
+    int nslots;
+    const uint8_t* masks; const int* rows;
     float* out; int ld, col0, B;
-    float* saved;  // [B][4]: rho, cos(-phi), sin(-phi), token (as float) -- kept for the backward pass
+    float* saved;  // [B][nslots][4]: features / token (as float) -- kept for the backward pass
 };
 struct EmbedBwdArgs {
-    const float* saved;  // [B][4] written by the forward
-    const float* dout; int ld, col0, B, num_tokens;
-    float* dw_t; float* db_t; float* demb;
+    EmbedSlot slot[EMB_MAX_SLOTS];
+    int nslots;
+    const float* saved;
+    const float* dout; int ld, col0, B;
 };
 
-int ingest_pool(const uint8_t* rgb, const float* depth, const int* rows, float* y, int B, int H, int W, int cpad, int depth_first,
-                hipStream_t s);
+int ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic, const int* rows, float* y, int B, int H, int W, int cpad,
+                int c_rgb, int c_depth, int c_sem, hipStream_t s);
 int chan_moment(const float* x, long long npix, int cpad, int mode, const float* mean, float* out, double* scratch, int scratch_len,
                 hipStream_t s);
 int rmv_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C, hipStream_t s);

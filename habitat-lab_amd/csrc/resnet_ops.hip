@@ -14,8 +14,9 @@ namespace hab {
 // Output y[f][h/2][w/2][cpad]: channels rgb(3), depth(1), zero padding up to cpad.
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
-                                                          const int* __restrict__ rows, float* __restrict__ y, int B, int H, int W,
-                                                          int cpad, int depth_first) {
+                                                          const int32_t* __restrict__ semantic, const int* __restrict__ rows,
+                                                          float* __restrict__ y, int B, int H, int W, int cpad, int c_rgb, int c_depth,
+                                                          int c_sem) {
 #pragma clang fp contract(off)  // the reference rounds the uint8 scaling and every addition of the 2x2 average separately
     const int Ho = H / 2, Wo = W / 2;
     const long long total = (long long)B * Ho * Wo;
@@ -29,7 +30,6 @@ __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restr
         float out[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) out[c] = 0.f;
-        const int c_rgb = (depth && depth_first) ? 1 : 0, c_depth = (rgb && !depth_first) ? 3 : 0;
         if (rgb) {
             float s[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -51,16 +51,28 @@ __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restr
                 for (int dw = 0; dw < 2; ++dw) s = s + depth[(srow * H + 2 * ho + dh) * W + 2 * wo + dw];
             out[c_depth] = s * 0.25f;
         }
+        if (semantic) {  // int32 ids are concatenated by type promotion (torch.cat) and averaged like any channel
+            float s = 0.f;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 2; ++dw) s = s + (float)semantic[(srow * H + 2 * ho + dh) * W + 2 * wo + dw];
+            out[c_sem] = s * 0.25f;
+        }
         float* o = y + (size_t)e * cpad;
         for (int c = 0; c < cpad; c += 4) *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(out + c);
     }
 }
 
-int ingest_pool(const uint8_t* rgb, const float* depth, const int* rows, float* y, int B, int H, int W, int cpad, int depth_first,
-                hipStream_t s) {
-    if ((!rgb && !depth) || !y || B <= 0 || (H & 1) || (W & 1) || (cpad != 4 && cpad != 8)) return HAB_ERR_ARG;
+int ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic, const int* rows, float* y, int B, int H, int W, int cpad,
+                int c_rgb, int c_depth, int c_sem, hipStream_t s) {
+    if ((!rgb && !depth && !semantic) || !y || B <= 0 || (H & 1) || (W & 1) || (cpad != 4 && cpad != 8)) return HAB_ERR_ARG;
+    const int n = (rgb ? 3 : 0) + (depth ? 1 : 0) + (semantic ? 1 : 0);
+    if (n > cpad || (rgb && (c_rgb < 0 || c_rgb + 3 > n)) || (depth && (c_depth < 0 || c_depth >= n)) || (semantic && (c_sem < 0 || c_sem >= n)))
+        return HAB_ERR_ARG;
     const long long total = (long long)B * (H / 2) * (W / 2);
-    ingest_pool_kernel<<<(int)fmin(8192.0, (double)cdivl(total, 256)), 256, 0, s>>>(rgb, depth, rows, y, B, H, W, cpad, depth_first);
+    ingest_pool_kernel<<<(int)fmin(8192.0, (double)cdivl(total, 256)), 256, 0, s>>>(rgb, depth, semantic, rows, y, B, H, W, cpad, c_rgb,
+                                                                                     c_depth, c_sem);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -465,54 +477,78 @@ int maxpool_backward(const float* dy, const uint8_t* idx, float* dx, int B, int 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Goal + previous-action embeddings (resnet_policy.py:662-692,747-753) written into the RNN input:
-//   out[f][col0 .. col0+32)    = W_t [rho, cos(-phi), sin(-phi)] + b_t
-//   out[f][col0+32 .. col0+64) = E[ mask ? prev_action + 1 : 0 ]
-// backward: dW_t, db_t, dE (deterministic: one workgroup per output row, fixed-order frame loop).
+// 1-D sensor embeddings (resnet_ops.h: EmbedSlot) written into the RNN input:
+//   out[f][col0 + 32*s .. +32) = slot s.   forward keeps features / tokens in saved[f][s][0..3].
+// backward: deterministic two-stage reduction (fixed-order frame loops), one output row per (slot, feature | bias | token).
 // ------------------------------------------------------------------------------------------------------
-__global__ void embed_fwd_kernel(const EmbedArgs a) {
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), j = threadIdx.x & 63;
+__device__ inline void emb_features(const EmbedSlot& sl, int r, int masked, float* v /*[4]*/) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    switch (sl.kind) {
+        case EMB_POLAR: {
+            const float* g = reinterpret_cast<const float*>(sl.in) + (size_t)r * 2;
+            v[0] = g[0]; v[1] = cosf(-g[1]); v[2] = sinf(-g[1]);
+            break;
+        }
+        case EMB_TOKEN: v[3] = (float)reinterpret_cast<const int64_t*>(sl.in)[r]; break;
+        case EMB_COSSIN: {
+            const float x = reinterpret_cast<const float*>(sl.in)[r];
+            v[0] = cosf(x); v[1] = sinf(x);
+            break;
+        }
+        case EMB_LIN2: {
+            const float* g = reinterpret_cast<const float*>(sl.in) + (size_t)r * 2;
+            v[0] = g[0]; v[1] = g[1];
+            break;
+        }
+        default: v[3] = masked ? (float)(reinterpret_cast<const int64_t*>(sl.in)[r] + 1) : 0.f; break;
+    }
+}
+
+__global__ void __launch_bounds__(256) embed_fwd_kernel(const EmbedArgs a) {
+    const int f = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
     if (f >= a.B) return;
     const int r = a.rows ? a.rows[f] : f;
+    const int m = a.masks ? (int)a.masks[r] : 1;
     float* o = a.out + (size_t)f * a.ld + a.col0;
-    const int tok = a.masks[r] ? (int)a.prev_actions[r] + 1 : 0;
-    const float rho = a.goal[(size_t)r * 2], phi = a.goal[(size_t)r * 2 + 1];
-    const float g0 = rho, g1 = cosf(-phi), g2 = sinf(-phi);
-    if (j < 32) {
-        o[j] = (a.w_t[j * 3] * g0 + a.w_t[j * 3 + 1] * g1) + a.w_t[j * 3 + 2] * g2 + a.b_t[j];
-    } else {
-        o[j] = a.emb[(size_t)tok * 32 + (j - 32)];
-    }
-    if (j == 0 && a.saved) {
-        float* sv = a.saved + (size_t)f * 4;
-        sv[0] = g0; sv[1] = g1; sv[2] = g2; sv[3] = (float)tok;
+    for (int s = 0; s < a.nslots; ++s) {
+        const EmbedSlot& sl = a.slot[s];
+        float v[4];
+        emb_features(sl, r, m, v);
+        const int nf = sl.kind == EMB_POLAR ? 3 : (sl.kind == EMB_COSSIN || sl.kind == EMB_LIN2) ? 2 : 0;
+        float y;
+        if (nf == 3) y = (sl.w[j * 3] * v[0] + sl.w[j * 3 + 1] * v[1]) + sl.w[j * 3 + 2] * v[2] + sl.b[j];
+        else if (nf == 2) y = sl.w[j * 2] * v[0] + sl.w[j * 2 + 1] * v[1] + sl.b[j];
+        else y = sl.w[(size_t)(int)v[3] * 32 + j];
+        o[s * 32 + j] = y;
+        if (j < 4 && a.saved) a.saved[((size_t)f * a.nslots + s) * 4 + j] = v[j];
     }
 }
 int embed_forward(const EmbedArgs& a, hipStream_t s) {
-    if (!a.goal || !a.prev_actions || !a.masks || !a.out || a.B <= 0) return HAB_ERR_ARG;
-    embed_fwd_kernel<<<cdiv(a.B, 4), 256, 0, s>>>(a);
+    if (!a.out || a.B <= 0 || a.nslots <= 0 || a.nslots > EMB_MAX_SLOTS) return HAB_ERR_ARG;
+    for (int i = 0; i < a.nslots; ++i)
+        if (!a.slot[i].in || !a.slot[i].w || (emb_nfeat(a.slot[i].kind) && !a.slot[i].b)) return HAB_ERR_ARG;
+    embed_fwd_kernel<<<cdiv(a.B, 8), 256, 0, s>>>(a);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
 
-// Outputs: 4 + num_tokens rows of 32 floats (dW_t[:, 0..2], db_t, dE[tok]).  Stage 1: grid (rows, frame chunks), each
-// workgroup of 256 threads = 8 frame lanes x 32 columns sums its chunk in a fixed order; stage 2 folds the chunks.
-__global__ void __launch_bounds__(256) embed_bwd_stage1(const EmbedBwdArgs a, int frames_per_chunk, float* __restrict__ partial) {
+struct EmbRowMap { int slot[64]; int sub[64]; int n; };  // output row -> (slot, feature index | nfeat = bias | token)
+
+__global__ void __launch_bounds__(256) embed_bwd_stage1(const EmbedBwdArgs a, const EmbRowMap rm, int frames_per_chunk,
+                                                        float* __restrict__ partial) {
     __shared__ float sm[256];
     const int b = blockIdx.x, j = threadIdx.x & 31, fl = threadIdx.x >> 5;
+    const int s = rm.slot[b], sub = rm.sub[b];
+    const int nf = a.slot[s].kind == EMB_POLAR ? 3 : (a.slot[s].kind == EMB_COSSIN || a.slot[s].kind == EMB_LIN2) ? 2 : 0;
     const int f0 = blockIdx.y * frames_per_chunk, f1 = min(a.B, f0 + frames_per_chunk);
-    float s = 0.f;
-    if (b < 4) {
-        for (int f = f0 + fl; f < f1; f += 8) {
-            const float d = a.dout[(size_t)f * a.ld + a.col0 + j];
-            s += b < 3 ? d * a.saved[(size_t)f * 4 + b] : d;
-        }
-    } else {
-        const float tok = (float)(b - 4);
-        for (int f = f0 + fl; f < f1; f += 8)
-            if (a.saved[(size_t)f * 4 + 3] == tok) s += a.dout[(size_t)f * a.ld + a.col0 + 32 + j];
+    float acc = 0.f;
+    for (int f = f0 + fl; f < f1; f += 8) {
+        const float d = a.dout[(size_t)f * a.ld + a.col0 + s * 32 + j];
+        const float* sv = a.saved + ((size_t)f * a.nslots + s) * 4;
+        if (nf) acc += sub < nf ? d * sv[sub] : d;
+        else if (sv[3] == (float)sub) acc += d;
     }
-    sm[threadIdx.x] = s;
+    sm[threadIdx.x] = acc;
     __syncthreads();
     if (fl == 0) {
         float t = 0.f;
@@ -520,25 +556,36 @@ __global__ void __launch_bounds__(256) embed_bwd_stage1(const EmbedBwdArgs a, in
         partial[((size_t)blockIdx.y * gridDim.x + b) * 32 + j] = t;
     }
 }
-__global__ void __launch_bounds__(32) embed_bwd_stage2(const EmbedBwdArgs a, const float* __restrict__ partial, int chunks, int rows) {
+__global__ void __launch_bounds__(32) embed_bwd_stage2(const EmbedBwdArgs a, const EmbRowMap rm, const float* __restrict__ partial,
+                                                       int chunks) {
     const int b = blockIdx.x, j = threadIdx.x;
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += partial[((size_t)c * rows + b) * 32 + j];
-    if (b < 3) a.dw_t[j * 3 + b] = s;
-    else if (b == 3) a.db_t[j] = s;
-    else a.demb[(size_t)(b - 4) * 32 + j] = s;
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) acc += partial[((size_t)c * rm.n + b) * 32 + j];
+    const EmbedSlot& sl = a.slot[rm.slot[b]];
+    const int nf = sl.kind == EMB_POLAR ? 3 : (sl.kind == EMB_COSSIN || sl.kind == EMB_LIN2) ? 2 : 0;
+    const int sub = rm.sub[b];
+    if (nf == 0) sl.dw[(size_t)sub * 32 + j] = acc;
+    else if (sub < nf) sl.dw[j * nf + sub] = acc;
+    else sl.db[j] = acc;
 }
 int embed_backward(const EmbedBwdArgs& a, float* ws, size_t ws_floats, hipStream_t s) {
-    if (!a.saved || !a.dout || !a.dw_t || !a.db_t || !a.demb || a.B <= 0 || !ws) return HAB_ERR_ARG;
-    const int rows = 4 + a.num_tokens;
+    if (!a.saved || !a.dout || a.B <= 0 || !ws || a.nslots <= 0 || a.nslots > EMB_MAX_SLOTS) return HAB_ERR_ARG;
+    EmbRowMap rm;
+    rm.n = 0;
+    for (int i = 0; i < a.nslots; ++i) {
+        const int nf = emb_nfeat(a.slot[i].kind);
+        const int rows = nf ? nf + 1 : a.slot[i].ntok;
+        if (!a.slot[i].dw || (nf && !a.slot[i].db) || rows <= 0 || rm.n + rows > 64) return HAB_ERR_ARG;
+        for (int q = 0; q < rows; ++q) { rm.slot[rm.n] = i; rm.sub[rm.n] = q; ++rm.n; }
+    }
     int chunks = cdiv(a.B, 64);
     if (chunks > 128) chunks = 128;
-    if ((size_t)chunks * rows * 32 > ws_floats) return HAB_ERR_ARG;
+    if ((size_t)chunks * rm.n * 32 > ws_floats) return HAB_ERR_ARG;
     const int fpc = cdiv(a.B, chunks);
     chunks = cdiv(a.B, fpc);
-    embed_bwd_stage1<<<dim3(rows, chunks), 256, 0, s>>>(a, fpc, ws);
+    embed_bwd_stage1<<<dim3(rm.n, chunks), 256, 0, s>>>(a, rm, fpc, ws);
     HAB_LAUNCH_CHECK();
-    embed_bwd_stage2<<<rows, 32, 0, s>>>(a, ws, chunks, rows);
+    embed_bwd_stage2<<<rm.n, 32, 0, s>>>(a, rm, ws, chunks);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -548,9 +595,9 @@ int embed_backward(const EmbedBwdArgs& a, float* ws, size_t ws_floats, hipStream
 // ------------------------------------------- C ABI -------------------------------------------
 using namespace hab;
 
-extern "C" int hab_obs_ingest_pool(const uint8_t* rgb, const float* depth, const int* rows, float* y, int B, int H, int W, int cpad,
-                                   int depth_first, hipStream_t stream) {
-    return ingest_pool(rgb, depth, rows, y, B, H, W, cpad, depth_first, stream);
+extern "C" int hab_obs_ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic, const int* rows, float* y, int B, int H,
+                                   int W, int cpad, int c_rgb, int c_depth, int c_sem, hipStream_t stream) {
+    return ingest_pool(rgb, depth, semantic, rows, y, B, H, W, cpad, c_rgb, c_depth, c_sem, stream);
 }
 extern "C" int hab_channel_moments(const float* x, int64_t npix, int cpad, int mode, const float* mean, float* out, double* scratch,
                                    int scratch_len, hipStream_t stream) {
@@ -585,18 +632,24 @@ extern "C" int hab_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int 
 extern "C" int hab_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t stream) {
     return maxpool_backward(dy, idx, dx, B, H, W, C, stream);
 }
-extern "C" int hab_nav_embed_fwd(const float* goal, const int64_t* prev_actions, const uint8_t* masks, const int* rows, const float* w_t,
-                                 const float* b_t, const float* emb, float* out, int ld, int col0, int B, float* saved,
-                                 hipStream_t stream) {
+static EmbedSlot mk_slot(const hab_embed_slot& q) {
+    EmbedSlot sl;
+    sl.kind = q.kind; sl.in = q.input; sl.w = q.weight; sl.b = q.bias; sl.dw = q.d_weight; sl.db = q.d_bias; sl.ntok = q.num_tokens;
+    return sl;
+}
+extern "C" int hab_nav_embed_fwd(const hab_embed_slot* slots, int nslots, const uint8_t* masks, const int* rows, float* out, int ld,
+                                 int col0, int B, float* saved, hipStream_t stream) {
+    if (!slots || nslots <= 0 || nslots > EMB_MAX_SLOTS) return HAB_ERR_ARG;
     EmbedArgs a;
-    a.goal = goal; a.prev_actions = prev_actions; a.masks = masks; a.rows = rows; a.w_t = w_t; a.b_t = b_t; a.emb = emb;
-    a.out = out; a.ld = ld; a.col0 = col0; a.B = B; a.saved = saved;
+    for (int i = 0; i < nslots; ++i) a.slot[i] = mk_slot(slots[i]);
+    a.nslots = nslots; a.masks = masks; a.rows = rows; a.out = out; a.ld = ld; a.col0 = col0; a.B = B; a.saved = saved;
     return embed_forward(a, stream);
 }
-extern "C" int hab_nav_embed_bwd(const float* saved, const float* dout, int ld, int col0, int B, int num_tokens, float* dw_t, float* db_t,
-                                 float* demb, float* ws, size_t ws_floats, hipStream_t stream) {
+extern "C" int hab_nav_embed_bwd(const hab_embed_slot* slots, int nslots, const float* saved, const float* dout, int ld, int col0, int B,
+                                 float* ws, size_t ws_floats, hipStream_t stream) {
+    if (!slots || nslots <= 0 || nslots > EMB_MAX_SLOTS) return HAB_ERR_ARG;
     EmbedBwdArgs a;
-    a.saved = saved; a.dout = dout; a.ld = ld; a.col0 = col0; a.B = B; a.num_tokens = num_tokens; a.dw_t = dw_t; a.db_t = db_t;
-    a.demb = demb;
+    for (int i = 0; i < nslots; ++i) a.slot[i] = mk_slot(slots[i]);
+    a.nslots = nslots; a.saved = saved; a.dout = dout; a.ld = ld; a.col0 = col0; a.B = B;
     return embed_backward(a, ws, ws_floats, stream);
 }

@@ -23,11 +23,17 @@ class HabError(RuntimeError):
 class PolicyDesc(C.Structure):
     _fields_ = [(n, c_int32) for n in (
         "arch", "backbone", "baseplanes", "normalize_visual_inputs", "rnn_type", "rnn_layers", "hidden", "num_actions",
-        "H", "W", "has_rgb", "has_depth", "goal_dim", "max_frames", "max_envs", "depth_first")]
+        "H", "W", "has_rgb", "has_depth", "goal_dim", "max_frames", "max_envs", "visual_order", "has_semantic",
+        "num_object_categories", "has_compass", "has_gps")]
 
 
 class Obs(C.Structure):
-    _fields_ = [("rgb", vp), ("depth", vp), ("goal", vp), ("prev_actions", vp)]
+    _fields_ = [("rgb", vp), ("depth", vp), ("goal", vp), ("prev_actions", vp), ("semantic", vp), ("objectgoal", vp), ("compass", vp),
+                ("gps", vp)]
+
+
+class EmbedSlot(C.Structure):
+    _fields_ = [("kind", c_int32), ("input", vp), ("weight", vp), ("bias", vp), ("d_weight", vp), ("d_bias", vp), ("num_tokens", c_int32)]
 
 
 class PackInfo(C.Structure):
@@ -59,7 +65,7 @@ SIGNATURES = {
     "hab_repack_conv_weight": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
     "hab_repack_flatten_weight": (c_int, [vp, vp, c_int, c_int, c_int, vp]),
     "hab_transpose2d": (c_int, [vp, vp, c_int, c_int, vp]),
-    "hab_obs_ingest_pool": (c_int, [vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]),
+    "hab_obs_ingest_pool": (c_int, [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     "hab_channel_moments": (c_int, [vp, c_int64, c_int, c_int, vp, vp, vp, c_int, vp]),
     "hab_running_mean_var_update": (c_int, [vp, vp, vp, vp, vp, c_float, c_int, vp]),
     "hab_running_mean_var_normalize": (c_int, [vp, c_int64, c_int, c_int, vp, vp, vp]),
@@ -67,8 +73,8 @@ SIGNATURES = {
     "hab_groupnorm_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
     "hab_maxpool3x3s2_fwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
     "hab_maxpool3x3s2_bwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
-    "hab_nav_embed_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp]),
-    "hab_nav_embed_bwd": (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_size_t, vp]),
+    "hab_nav_embed_fwd": (c_int, [POINTER(EmbedSlot), c_int, vp, vp, vp, c_int, c_int, c_int, vp, vp]),
+    "hab_nav_embed_bwd": (c_int, [POINTER(EmbedSlot), c_int, vp, vp, c_int, c_int, c_int, vp, c_size_t, vp]),
     "hab_build_pack_info": (c_int, [vp, c_int, c_int] + [vp] * 12),
     "hab_policy_create": (c_int, [POINTER(PolicyDesc), POINTER(vp)]),
     "hab_policy_destroy": (None, [vp]),

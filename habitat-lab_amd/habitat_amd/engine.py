@@ -74,11 +74,14 @@ class DevicePackInfo:
 class PolicyEngine:
     def __init__(self, *, arch="simple_cnn", backbone=18, baseplanes=32, normalize_visual_inputs=False, rnn_type="GRU",
                  rnn_layers=1, hidden=512, num_actions=4, H=256, W=256, has_rgb=True, has_depth=True, goal_dim=2,
-                 max_frames=4096, max_envs=64, device="cuda", with_grads=True, depth_first=False):
+                 max_frames=4096, max_envs=64, device="cuda", with_grads=True, visual_order=("rgb", "depth", "semantic"),
+                 has_semantic=False, num_object_categories=0, has_compass=False, has_gps=False):
         L = _lib.lib()
         self.L = L
         d = PolicyDesc(ARCH[arch], backbone, baseplanes, int(normalize_visual_inputs), RNN[rnn_type.upper()], rnn_layers, hidden,
-                       num_actions, H, W, int(has_rgb), int(has_depth), goal_dim, max_frames, max_envs, int(depth_first))
+                       num_actions, H, W, int(has_rgb), int(has_depth), goal_dim, max_frames, max_envs,
+                       sum({"rgb": 1, "depth": 2, "semantic": 3}[k] << (2 * i) for i, k in enumerate(visual_order)), int(has_semantic),
+                       int(num_object_categories), int(has_compass), int(has_gps))
         self.desc = d
         h = C.c_void_p()
         check(L.hab_policy_create(C.byref(d), C.byref(h)), "hab_policy_create")
@@ -156,22 +159,25 @@ class PolicyEngine:
 
     # ---- calls ------------------------------------------------------------------------------
     @staticmethod
-    def _obs(rgb, depth, goal, prev_actions=None):
-        return Obs(rgb.data_ptr() if rgb is not None else None, depth.data_ptr() if depth is not None else None,
-                   goal.data_ptr() if goal is not None else None, prev_actions.data_ptr() if prev_actions is not None else None)
+    def _obs(rgb, depth, goal, prev_actions=None, extra=None):
+        """extra: optional dict with the ObjectNav sensors `semantic` (int32), `objectgoal` (int64), `compass`, `gps`."""
+        dp = lambda t: t.data_ptr() if t is not None else None
+        e = extra or {}
+        return Obs(dp(rgb), dp(depth), dp(goal), dp(prev_actions), dp(e.get("semantic")), dp(e.get("objectgoal")), dp(e.get("compass")),
+                   dp(e.get("gps")))
 
     def act(self, rgb, depth, goal, hidden_in, masks, n, *, exp_noise=None, deterministic=False, values, actions=None,
-            action_log_probs=None, hidden_out=None, probs_out=None, prev_actions=None):
+            action_log_probs=None, hidden_out=None, probs_out=None, prev_actions=None, extra=None):
         self._fresh()
-        o = self._obs(rgb, depth, goal, prev_actions)
+        o = self._obs(rgb, depth, goal, prev_actions, extra)
         check(self.L.hab_policy_act(self.h, C.byref(o), ptr(hidden_in), ptr(masks), ptr(exp_noise), int(deterministic), n,
                                     ptr(values), ptr(actions), ptr(action_log_probs), ptr(hidden_out), ptr(probs_out),
                                     stream_ptr()), "hab_policy_act")
 
     def evaluate(self, rgb, depth, goal, rows, hidden0, masks, actions, pack: DevicePackInfo, B, n, *, value=None,
-                 log_prob=None, entropy=None, prev_actions=None):
+                 log_prob=None, entropy=None, prev_actions=None, extra=None):
         self._fresh()
-        o = self._obs(rgb, depth, goal, prev_actions)
+        o = self._obs(rgb, depth, goal, prev_actions, extra)
         check(self.L.hab_policy_evaluate(self.h, C.byref(o), ptr(rows), ptr(hidden0), self.Lh * self.hidden, ptr(masks),
                                          ptr(actions), C.byref(pack.struct), B, n, ptr(value), ptr(log_prob), ptr(entropy),
                                          stream_ptr()), "hab_policy_evaluate")
@@ -179,8 +185,9 @@ class PolicyEngine:
     def final_hidden(self, out):
         check(self.L.hab_policy_final_hidden(self.h, ptr(out), stream_ptr()), "hab_policy_final_hidden")
 
-    def backward(self, rgb, depth, goal, rows, actions, pack: DevicePackInfo, d_value, d_log_prob, d_entropy, prev_actions=None):
-        o = self._obs(rgb, depth, goal, prev_actions)
+    def backward(self, rgb, depth, goal, rows, actions, pack: DevicePackInfo, d_value, d_log_prob, d_entropy, prev_actions=None,
+                 extra=None):
+        o = self._obs(rgb, depth, goal, prev_actions, extra)
         check(self.L.hab_policy_backward(self.h, C.byref(o), ptr(rows), ptr(actions), C.byref(pack.struct), ptr(d_value),
                                          ptr(d_log_prob), ptr(d_entropy), stream_ptr()), "hab_policy_backward")
 

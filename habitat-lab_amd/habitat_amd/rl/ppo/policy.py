@@ -244,16 +244,30 @@ class NetPolicy(nn.Module, Policy):
 
     # ---- helpers --------------------------------------------------------------------------------
     def _obs_ptrs(self, observations):
-        rgb = observations["rgb"] if self._engine_kwargs["has_rgb"] else None
-        depth = observations["depth"] if self._engine_kwargs["has_depth"] else None
-        goal = observations[GOAL_UUID]
-        if goal.dtype != torch.float32 or (depth is not None and depth.dtype != torch.float32) or \
-                (rgb is not None and rgb.dtype != torch.uint8):
-            raise _lib.HabError("observations must be uint8 rgb / float32 depth / float32 pointgoal")
-        for t in (rgb, depth, goal):
-            if t is not None and not t.is_contiguous():
+        """(rgb, depth, goal, extra) tensors of an observation dict, checked for the dtypes / layout the kernels read in place."""
+        kw = self._engine_kwargs
+        rgb = observations["rgb"] if kw["has_rgb"] else None
+        depth = observations["depth"] if kw["has_depth"] else None
+        goal = observations[GOAL_UUID] if kw.get("goal_dim", 2) > 0 else None
+        extra = {}
+        if kw.get("has_semantic"):
+            extra["semantic"] = observations["semantic"]
+        if kw.get("num_object_categories", 0) > 0:
+            extra["objectgoal"] = observations["objectgoal"]
+        if kw.get("has_compass"):
+            extra["compass"] = observations["compass"]
+        if kw.get("has_gps"):
+            extra["gps"] = observations["gps"]
+        want = {"rgb": torch.uint8, "depth": torch.float32, "goal": torch.float32, "semantic": torch.int32, "objectgoal": torch.int64,
+                "compass": torch.float32, "gps": torch.float32}
+        for name, t in dict(rgb=rgb, depth=depth, goal=goal, **extra).items():
+            if t is None:
+                continue
+            if t.dtype != want[name]:
+                raise _lib.HabError(f"observation '{name}' must be {want[name]} (got {t.dtype})")
+            if not t.is_contiguous():
                 raise _lib.HabError("observation tensors must be contiguous NHWC")
-        return rgb, depth, goal
+        return rgb, depth, goal, extra
 
     def draw_noise(self, n: int) -> torch.Tensor:
         """Exp(1) noise from the CPU generator -- the draw torch.multinomial would make (utils/common.py:64-68)."""
@@ -264,8 +278,8 @@ class NetPolicy(nn.Module, Policy):
     @torch.no_grad()
     def act(self, observations, rnn_hidden_states, prev_actions, masks, deterministic=False, exp_noise=None, out=None):
         eng = self._require_engine()
-        rgb, depth, goal = self._obs_ptrs(observations)
-        n = goal.shape[0]
+        rgb, depth, goal, extra = self._obs_ptrs(observations)
+        n = rnn_hidden_states.shape[0]
         dev = self.device
         if out is None:
             out = dict(values=torch.empty(n, 1, device=dev), actions=torch.empty(n, 1, dtype=torch.long, device=dev),
@@ -276,26 +290,27 @@ class NetPolicy(nn.Module, Policy):
         eng.act(rgb, depth, goal, rnn_hidden_states.contiguous(), masks.contiguous(), n, exp_noise=exp_noise,
                 deterministic=deterministic, values=out["values"], actions=out["actions"],
                 action_log_probs=out["action_log_probs"], hidden_out=out["rnn_hidden_states"],
-                prev_actions=prev_actions)
+                prev_actions=prev_actions, extra=extra)
         return PolicyActionData(values=out["values"], actions=out["actions"], action_log_probs=out["action_log_probs"],
                                 rnn_hidden_states=out["rnn_hidden_states"])
 
     @torch.no_grad()
     def get_value(self, observations, rnn_hidden_states, prev_actions, masks):
         eng = self._require_engine()
-        rgb, depth, goal = self._obs_ptrs(observations)
-        n = goal.shape[0]
+        rgb, depth, goal, extra = self._obs_ptrs(observations)
+        n = rnn_hidden_states.shape[0]
         values = torch.empty(n, 1, device=self.device)
-        eng.act(rgb, depth, goal, rnn_hidden_states.contiguous(), masks.contiguous(), n, values=values, prev_actions=prev_actions)
+        eng.act(rgb, depth, goal, rnn_hidden_states.contiguous(), masks.contiguous(), n, values=values, prev_actions=prev_actions,
+                extra=extra)
         return values
 
     def evaluate_actions(self, observations, rnn_hidden_states, prev_actions, masks, action, rnn_build_seq_info):
         """Dense-tensor entry (reference calling convention).  Differentiable through _EvaluateFn."""
         self._require_engine()
-        rgb, depth, goal = self._obs_ptrs(observations)
-        B, n = goal.shape[0], rnn_hidden_states.shape[0]
+        rgb, depth, goal, extra = self._obs_ptrs(observations)
+        B, n = masks.shape[0], rnn_hidden_states.shape[0]
         pack = _pack_from_seq_info(rnn_build_seq_info, B, n, self.device)
-        call = dict(rgb=rgb, depth=depth, goal=goal, hidden0=rnn_hidden_states.contiguous(), masks=masks.contiguous(),
+        call = dict(rgb=rgb, depth=depth, goal=goal, extra=extra, hidden0=rnn_hidden_states.contiguous(), masks=masks.contiguous(),
                     actions=action.contiguous(), prev_actions=prev_actions, pack=pack, B=B, n=n)
         if torch.is_grad_enabled():
             v, lp, ent = _EvaluateFn.apply(self, call, *self.parameters())
@@ -309,12 +324,12 @@ class NetPolicy(nn.Module, Policy):
         dev, B = self.device, c["B"]
         v, lp, ent = (torch.empty(B, 1, device=dev) for _ in range(3))
         self.engine.evaluate(c["rgb"], c["depth"], c["goal"], None, c["hidden0"], c["masks"], c["actions"], c["pack"], B, c["n"],
-                             value=v, log_prob=lp, entropy=ent, prev_actions=c["prev_actions"])
+                             value=v, log_prob=lp, entropy=ent, prev_actions=c["prev_actions"], extra=c["extra"])
         return v, lp, ent
 
     def _backward_dense(self, c, dv, dlp, dent):
         self.engine.backward(c["rgb"], c["depth"], c["goal"], None, c["actions"], c["pack"], dv, dlp, dent,
-                             prev_actions=c["prev_actions"])
+                             prev_actions=c["prev_actions"], extra=c["extra"])
 
 
 def _pack_from_seq_info(info, B, n, device) -> DevicePackInfo:
@@ -406,7 +421,8 @@ class PointNavBaselinePolicy(NetPolicy):
                    max_frames=int(ppo.num_steps) * max(1, -(-n_envs // int(ppo.num_mini_batch))), max_envs=n_envs)
 
 
-def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, baseplanes, H, W, normalize):
+def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, baseplanes, H, W, normalize, has_goal=True, n_obj=0,
+                 has_gps=False, has_compass=False):
     """Parameter / buffer values exactly as PointNavResNetPolicy.__init__ produces them: the torch modules are created in
     the reference's order (resnet_policy.py:389-396 embedding, :454-456 tgt_embeding, :578-585 ResNetEncoder [default
     Conv2d / GroupNorm initialisers -- ResNetEncoder.layer_init is never called], :588-595 visual_fc, :597-602 state encoder
@@ -414,8 +430,23 @@ def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, base
     out = {}
     emb = nn.Embedding(num_actions + 1, 32)
     out["net.prev_action_embedding.weight"] = emb.weight.detach()
-    tgt = nn.Linear(3, 32)
-    out["net.tgt_embeding.weight"], out["net.tgt_embeding.bias"] = tgt.weight.detach(), tgt.bias.detach()
+    n_slots = 1
+    if has_goal:  # module creation order of PointNavResNetNet.__init__ (resnet_policy.py:441-528)
+        tgt = nn.Linear(3, 32)
+        out["net.tgt_embeding.weight"], out["net.tgt_embeding.bias"] = tgt.weight.detach(), tgt.bias.detach()
+        n_slots += 1
+    if n_obj > 0:
+        obj = nn.Embedding(n_obj, 32)
+        out["net.obj_categories_embedding.weight"] = obj.weight.detach()
+        n_slots += 1
+    if has_gps:
+        gps = nn.Linear(2, 32)
+        out["net.gps_embedding.weight"], out["net.gps_embedding.bias"] = gps.weight.detach(), gps.bias.detach()
+        n_slots += 1
+    if has_compass:
+        cmp_ = nn.Linear(2, 32)
+        out["net.compass_embedding.weight"], out["net.compass_embedding.bias"] = cmp_.weight.detach(), cmp_.bias.detach()
+        n_slots += 1
     ve = "net.visual_encoder."
     if normalize:
         out[ve + "running_mean_and_var._mean"] = torch.zeros(1, n_in, 1, 1)
@@ -462,7 +493,7 @@ def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, base
     fc = nn.Linear(ncomp * fh * fw, hidden)
     out["net.visual_fc.1.weight"], out["net.visual_fc.1.bias"] = fc.weight.detach(), fc.bias.detach()
     rnn_cls = nn.LSTM if rnn_type == "LSTM" else nn.GRU
-    rnn = rnn_cls(input_size=hidden + 64, hidden_size=hidden, num_layers=rnn_layers)
+    rnn = rnn_cls(input_size=hidden + 32 * n_slots, hidden_size=hidden, num_layers=rnn_layers)
     for name, param in rnn.named_parameters():
         if "weight" in name:
             nn.init.orthogonal_(param)
@@ -499,24 +530,34 @@ class PointNavResNetPolicy(NetPolicy):
         if policy_config is not None and getattr(policy_config, "action_distribution_type", "categorical") != "categorical":
             raise _lib.HabError("Gaussian action heads are outside the accelerated path")
         visual_keys = [k for k, v in sp.items() if len(v.shape) > 1]  # observation-space order (resnet_policy.py:178-182)
-        other = [k for k in sp.keys() if k not in visual_keys and k != GOAL_UUID]
-        if any(k not in ("rgb", "depth") for k in visual_keys) or not visual_keys or other or GOAL_UUID not in sp:
-            raise _lib.HabError(f"PointNavResNetPolicy on habitat_amd supports rgb/depth + '{GOAL_UUID}' (got {list(sp.keys())})")
-        has_rgb, has_depth = "rgb" in visual_keys, "depth" in visual_keys
+        known_1d = {GOAL_UUID, "objectgoal", "compass", "gps"}
+        other = [k for k in sp.keys() if k not in visual_keys and k not in known_1d]
+        if any(k not in ("rgb", "depth", "semantic") for k in visual_keys) or not visual_keys or other:
+            raise _lib.HabError("PointNavResNetPolicy on habitat_amd supports the rgb / depth / semantic visual sensors and the "
+                                f"pointgoal_with_gps_compass, objectgoal, compass, gps 1-D sensors (got {list(sp.keys())})")
+        has_rgb, has_depth, has_sem = "rgb" in visual_keys, "depth" in visual_keys, "semantic" in visual_keys
         vis = sp[visual_keys[0]]
         H, W = int(vis.shape[0]), int(vis.shape[1])
-        n_in = (3 if has_rgb else 0) + (1 if has_depth else 0)
+        n_in = (3 if has_rgb else 0) + (1 if has_depth else 0) + (1 if has_sem else 0)
         na = get_num_actions(action_space)
         rnn_type = rnn_type.upper()
+        has_goal = GOAL_UUID in sp
+        if has_goal and int(sp[GOAL_UUID].shape[0]) != 2:
+            raise _lib.HabError("only the 2-D polar pointgoal_with_gps_compass is on the accelerated path")
+        n_obj = int(sp["objectgoal"].high[0]) + 1 if "objectgoal" in sp else 0  # resnet_policy.py:468-476
+        has_gps, has_compass = "gps" in sp, "compass" in sp
+        if has_gps and int(sp["gps"].shape[0]) != 2:
+            raise _lib.HabError("gps sensor must be 2-D")
         bufs = tuple("net.visual_encoder.running_mean_and_var." + k for k in ("_mean", "_var", "_count")) if normalize_visual_inputs else ()
         super().__init__(action_space,
                          dict(arch="resnet", backbone=int(backbone[6:]), baseplanes=resnet_baseplanes,
                               normalize_visual_inputs=bool(normalize_visual_inputs), rnn_type=rnn_type,
                               rnn_layers=num_recurrent_layers, hidden=hidden_size, H=H, W=W, has_rgb=has_rgb, has_depth=has_depth,
-                              goal_dim=2, max_frames=max_frames, max_envs=max_envs,
-                              depth_first=bool(has_rgb and has_depth and visual_keys[0] == "depth")),
+                              goal_dim=2 if has_goal else 0, max_frames=max_frames, max_envs=max_envs,
+                              visual_order=tuple(visual_keys), has_semantic=has_sem, num_object_categories=n_obj,
+                              has_compass=has_compass, has_gps=has_gps),
                          lambda: _resnet_init(n_in, hidden_size, na, rnn_type, num_recurrent_layers, backbone, resnet_baseplanes,
-                                              H, W, normalize_visual_inputs),
+                                              H, W, normalize_visual_inputs, has_goal, n_obj, has_gps, has_compass),
                          buffer_names=bufs)
 
     @classmethod

@@ -159,17 +159,18 @@ class PPO(nn.Module, Updater):
         Bf = st.buffers
         obs = Bf["observations"]
         rgb, depth = obs.get("rgb"), obs.get("depth")
-        goal = obs["pointgoal_with_gps_compass"]
+        goal = obs.get("pointgoal_with_gps_compass")
+        extra = {k: obs[k] for k in ("semantic", "objectgoal", "compass", "gps") if k in obs}
         Bn, n = batch.T * batch.n, batch.n
         w = self._work(Bn)
         eng.evaluate(rgb, depth, goal, batch.rows, Bf["recurrent_hidden_states"], Bf["masks"], Bf["actions"], batch.pack, Bn, n,
-                     value=w["v"], log_prob=w["lp"], entropy=w["ent"], prev_actions=Bf["prev_actions"])
+                     value=w["v"], log_prob=w["lp"], entropy=w["ent"], prev_actions=Bf["prev_actions"], extra=extra)
         check(L.hab_ppo_loss(ptr(w["v"]), ptr(w["lp"]), ptr(w["ent"]), ptr(Bf["action_log_probs"]), ptr(batch.advantages_full),
                              ptr(Bf["value_preds"]), ptr(Bf["returns"]), ptr(batch.rows), Bn, float(self.clip_param),
                              float(self.value_loss_coef), float(self.entropy_coef), int(self.use_clipped_value_loss),
                              ptr(w["dv"]), ptr(w["dlp"]), ptr(w["dent"]), ptr(slot), stream_ptr()), "hab_ppo_loss")
         eng.backward(rgb, depth, goal, batch.rows, Bf["actions"], batch.pack, w["dv"], w["dlp"], w["dent"],
-                     prev_actions=Bf["prev_actions"])
+                     prev_actions=Bf["prev_actions"], extra=extra)
         self.before_step()
         self.optimizer.step(max_grad_norm=self.max_grad_norm, grad_scale=1.0 / self._world_size(), grad_norm_out=slot[12:13])
         self.after_step()

@@ -136,8 +136,9 @@ int hab_transpose2d(const float* w, float* wt, int R, int C, hipStream_t stream)
  * ------------------------------------------------------------------------------------------- */
 /* Ingest: per visual key permute -> uint8 * fp32(1/255) -> cat (rgb,depth or depth,rgb) -> avg_pool2d(2); channels
  * zero-padded to cpad (4 or 8); observations read in place through rows[] (resnet_policy.py:259-271). */
-int hab_obs_ingest_pool(const uint8_t* rgb, const float* depth, const int* rows, float* y, int B, int H, int W, int cpad,
-                        int depth_first, hipStream_t stream);
+int hab_obs_ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic, const int* rows, float* y, int B, int H, int W,
+                        int cpad, int c_rgb, int c_depth, int c_sem /* first output channel of each key, -1 = absent */,
+                        hipStream_t stream);
 /* Channel moments over all pixels: mode 0 -> out[c] = mean, mode 1 -> out[c] = mean((x - mean[c])^2)
  * (running_mean_and_var.py:33-45).  scratch: >= 1024*cpad doubles. */
 int hab_channel_moments(const float* x, int64_t npix, int cpad, int mode, const float* mean, float* out, double* scratch,
@@ -158,12 +159,26 @@ int hab_groupnorm_bwd(const float* x, const float* dy, const float* relu_out, fl
 /* nn.MaxPool2d(3, stride 2, padding 1) (resnet.py:220); idx = window offset of the first maximum (1 byte per output). */
 int hab_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t stream);
 int hab_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t stream);
-/* tgt_embeding([rho, cos(-phi), sin(-phi)]) and prev_action_embedding(mask ? a+1 : 0) written to out[:, col0:col0+64]
- * (resnet_policy.py:662-692,747-753); saved [B][4] keeps the goal features + token for the backward pass. */
-int hab_nav_embed_fwd(const float* goal, const int64_t* prev_actions, const uint8_t* masks, const int* rows, const float* w_t,
-                      const float* b_t, const float* emb, float* out, int ld, int col0, int B, float* saved, hipStream_t stream);
-int hab_nav_embed_bwd(const float* saved, const float* dout, int ld, int col0, int B, int num_tokens, float* dw_t, float* db_t,
-                      float* demb, float* ws, size_t ws_floats, hipStream_t stream);
+/* 1-D sensor embeddings of PointNavResNetNet.forward (resnet_policy.py:662-753), 32 wide each, written side by side to
+ * out[:, col0 + 32*slot ...]; saved [B][nslots][4] keeps the features / tokens for the backward pass. */
+#define HAB_EMB_POLAR 0   /* pointgoal_with_gps_compass (rho, phi): Linear(3,32)([rho, cos(-phi), sin(-phi)]) */
+#define HAB_EMB_TOKEN 1   /* objectgoal id: Embedding(num_tokens, 32) */
+#define HAB_EMB_COSSIN 2  /* compass x: Linear(2,32)([cos x, sin x]) */
+#define HAB_EMB_LIN2 3    /* gps (x, y): Linear(2,32) */
+#define HAB_EMB_PREV 4    /* previous action: Embedding(A+1, 32)(mask ? a+1 : 0) */
+typedef struct hab_embed_slot {
+    int32_t kind;
+    const void* input;     /* sensor values in arena rows: f32[2] / i64[1] / f32[1] / f32[2] / i64[1] per row */
+    const float* weight;   /* Linear weight [32][nfeat] or table [num_tokens][32] */
+    const float* bias;     /* Linear bias or NULL */
+    float* d_weight;       /* backward outputs (NULL in forward) */
+    float* d_bias;
+    int32_t num_tokens;
+} hab_embed_slot;
+int hab_nav_embed_fwd(const hab_embed_slot* slots, int nslots, const uint8_t* masks, const int* rows, float* out, int ld, int col0, int B,
+                      float* saved, hipStream_t stream);
+int hab_nav_embed_bwd(const hab_embed_slot* slots, int nslots, const float* saved, const float* dout, int ld, int col0, int B, float* ws,
+                      size_t ws_floats, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * build_pack_info_from_dones (rl/models/rnn_state_encoder.py:35-168), HOST routine (no GPU).
@@ -203,14 +218,22 @@ typedef struct hab_policy_desc {
     int32_t goal_dim;      /* pointgoal_with_gps_compass dims (2) */
     int32_t max_frames;    /* largest T*n of an evaluate call */
     int32_t max_envs;      /* largest n of an act call */
-    int32_t depth_first;   /* arch 1: visual key order of the observation space: 0 = rgb,depth  1 = depth,rgb */
+    /* arch 1 (PointNavResNetPolicy) only: */
+    int32_t visual_order;  /* visual keys in observation-space order, 2 bits each from the LSB: 1 rgb, 2 depth, 3 semantic, 0 end */
+    int32_t has_semantic;  /* int32 (H,W,1) semantic sensor */
+    int32_t num_object_categories; /* > 0: objectgoal sensor (ObjectNav) with that many categories */
+    int32_t has_compass, has_gps;  /* compass f32 (1,), gps f32 (2,) */
 } hab_policy_desc;
 
 typedef struct hab_obs {   /* arena base pointers; frame f lives at row rows[f] (or f) */
     const uint8_t* rgb;    /* (rows, H, W, 3) */
     const float* depth;    /* (rows, H, W, 1) */
-    const float* goal;     /* (rows, goal_dim) */
+    const float* goal;     /* (rows, goal_dim) pointgoal_with_gps_compass */
     const int64_t* prev_actions; /* (rows, 1) */
+    const int32_t* semantic;     /* (rows, H, W, 1) */
+    const int64_t* objectgoal;   /* (rows, 1) */
+    const float* compass;        /* (rows, 1) */
+    const float* gps;            /* (rows, 2) */
 } hab_obs;
 
 typedef struct hab_pack_info { /* int32 copies of hab_build_pack_info's arrays */

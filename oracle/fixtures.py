@@ -59,12 +59,24 @@ def synth_rollout_inputs(envs: synth.SyntheticEnvs, T):
 
 
 def resnet_param_shapes(n_in, H, W, hidden, num_actions=4, rnn_type="LSTM", layers=2, backbone="resnet18", baseplanes=32,
-                        normalize=True, with_buffers=False):
+                        normalize=True, with_buffers=False, has_goal=True, n_obj=0, has_gps=False, has_compass=False):
     """state_dict() names/shapes of PointNavResNetPolicy (rl/ddppo/policy/resnet_policy.py:50-162,391-602) in reference
     order.  Buffers (RunningMeanAndVar statistics) are listed only with with_buffers=True."""
     import math
-    shapes = [("net.prev_action_embedding.weight", (num_actions + 1, 32)), ("net.tgt_embeding.weight", (32, 3)),
-              ("net.tgt_embeding.bias", (32,))]
+    shapes = [("net.prev_action_embedding.weight", (num_actions + 1, 32))]
+    slots = 1
+    if has_goal:
+        shapes += [("net.tgt_embeding.weight", (32, 3)), ("net.tgt_embeding.bias", (32,))]
+        slots += 1
+    if n_obj:
+        shapes += [("net.obj_categories_embedding.weight", (n_obj, 32))]
+        slots += 1
+    if has_gps:
+        shapes += [("net.gps_embedding.weight", (32, 2)), ("net.gps_embedding.bias", (32,))]
+        slots += 1
+    if has_compass:
+        shapes += [("net.compass_embedding.weight", (32, 2)), ("net.compass_embedding.bias", (32,))]
+        slots += 1
     ve = "net.visual_encoder."
     if normalize and with_buffers:
         shapes += [(ve + "running_mean_and_var._mean", (1, n_in, 1, 1)), (ve + "running_mean_and_var._var", (1, n_in, 1, 1)),
@@ -100,7 +112,7 @@ def resnet_param_shapes(n_in, H, W, hidden, num_actions=4, rnn_type="LSTM", laye
     G = 3 if rnn_type == "GRU" else 4
     rn = "net.state_encoder.rnn."
     for l in range(layers):
-        i = hidden + 64 if l == 0 else hidden
+        i = hidden + 32 * slots if l == 0 else hidden
         shapes += [(f"{rn}weight_ih_l{l}", (G * hidden, i)), (f"{rn}weight_hh_l{l}", (G * hidden, hidden)),
                    (f"{rn}bias_ih_l{l}", (G * hidden,)), (f"{rn}bias_hh_l{l}", (G * hidden,))]
     shapes += [("action_distribution.linear.weight", (num_actions, hidden)), ("action_distribution.linear.bias", (num_actions,)),

@@ -260,16 +260,25 @@ def net_forward(params: Params, spec: NetSpec, obs, hidden_bf, prev_actions, mas
         vis = simple_cnn(params, "net.visual_encoder.cnn.", obs, taps)
         x = torch.cat([vis, obs[GOAL_UUID]], dim=1)
     else:
-        feats = resnet_encoder(params, "net.visual_encoder.", obs, spec.visual_keys, spec.backbone,
+        feats = resnet_encoder(params, "net.visual_encoder.", {k: obs[k] for k in spec.visual_keys}, spec.visual_keys, spec.backbone,
                                spec.baseplanes, training, spec.normalize, taps, rmv_out)
         vis = F.relu(F.linear(feats.flatten(1), params["net.visual_fc.1.weight"], params["net.visual_fc.1.bias"]))
-        g = obs[GOAL_UUID]
-        g = torch.stack([g[:, 0], torch.cos(-g[:, 1]), torch.sin(-g[:, 1])], -1)  # :662-672
-        tgt = F.linear(g, params["net.tgt_embeding.weight"], params["net.tgt_embeding.bias"])
+        parts = [vis]
+        if GOAL_UUID in obs:
+            g = obs[GOAL_UUID]
+            g = torch.stack([g[:, 0], torch.cos(-g[:, 1]), torch.sin(-g[:, 1])], -1)  # :662-672
+            parts.append(F.linear(g, params["net.tgt_embeding.weight"], params["net.tgt_embeding.bias"]))
+        if "objectgoal" in obs:  # :715-717
+            parts.append(F.embedding(obs["objectgoal"].long(), params["net.obj_categories_embedding.weight"]).squeeze(dim=1))
+        if "compass" in obs:  # :719-729
+            c = torch.stack([torch.cos(obs["compass"]), torch.sin(obs["compass"])], -1)
+            parts.append(F.linear(c.squeeze(dim=1), params["net.compass_embedding.weight"], params["net.compass_embedding.bias"]))
+        if "gps" in obs:  # :731-734
+            parts.append(F.linear(obs["gps"], params["net.gps_embedding.weight"], params["net.gps_embedding.bias"]))
         pa = prev_actions.squeeze(-1)
         pa = torch.where(masks.view(-1), pa + 1, torch.zeros_like(pa))  # :747-753
-        pa = F.embedding(pa, params["net.prev_action_embedding.weight"])
-        x = torch.cat([vis, tgt, pa], dim=1)
+        parts.append(F.embedding(pa, params["net.prev_action_embedding.weight"]))
+        x = torch.cat(parts, dim=1)
         if taps is not None:
             taps["visual_fc"] = vis
     if taps is not None:

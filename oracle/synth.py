@@ -22,6 +22,8 @@ import numpy as np
 
 GOLD = np.uint32(0x9E3779B9)
 SENSOR_RGB, SENSOR_DEPTH, SENSOR_GOAL, SENSOR_REWARD, SENSOR_DONE = 0, 1, 2, 3, 4
+SENSOR_SEMANTIC, SENSOR_OBJECTGOAL, SENSOR_COMPASS, SENSOR_GPS = 5, 6, 7, 8
+NUM_SEMANTIC_IDS, NUM_OBJECT_CATEGORIES = 40, 21  # semantic ids in [0,40), objectgoal in [0,21)
 DONE_THRESHOLD = np.uint32((1 << 32) // 25)
 MAX_EPISODE_STEPS = 500
 
@@ -70,6 +72,28 @@ def goal(seed, env, t):
     return np.array([rho, phi], dtype=np.float32)
 
 
+def semantic(seed, env, t, H, W):
+    """int32 (H,W,1) instance/category ids, uniform in [0, 40)."""
+    return (words(seed, SENSOR_SEMANTIC, env, t, H * W) % np.uint32(NUM_SEMANTIC_IDS)).astype(np.int32).reshape(H, W, 1)
+
+
+def objectgoal(seed, env, t):
+    """int64 (1,) goal category, constant over an env's life (drawn from the env id only)."""
+    return np.array([int(words(seed, SENSOR_OBJECTGOAL, env, 0, 1)[0] % np.uint32(NUM_OBJECT_CATEGORIES))], dtype=np.int64)
+
+
+def compass(seed, env, t):
+    u = u01(words(seed, SENSOR_COMPASS, env, t, 1))
+    return ((u * np.float32(2.0) - np.float32(1.0)) * np.float32(np.pi)).astype(np.float32)
+
+
+def gps(seed, env, t):
+    u = u01(words(seed, SENSOR_GPS, env, t, 8))
+    a = (u[0] + u[1]) + (u[2] + u[3])
+    b = (u[4] + u[5]) + (u[6] + u[7])
+    return np.array([(a - np.float32(2.0)) * np.float32(np.sqrt(3.0)), (b - np.float32(2.0)) * np.float32(np.sqrt(3.0))], dtype=np.float32)
+
+
 def reward(seed, env, t):
     u = u01(words(seed, SENSOR_REWARD, env, t, 4))
     s = (u[0] + u[1]) + (u[2] + u[3])
@@ -84,9 +108,9 @@ class SyntheticEnvs:
     """N independent synthetic envs; `env_offset` makes ids globally unique across ranks
     (mirrors seed += rank * num_environments, rl/ppo/ppo_trainer.py:208-211)."""
 
-    def __init__(self, num_envs, H, W, seed=100, env_offset=0, use_rgb=True, use_depth=True):
+    def __init__(self, num_envs, H, W, seed=100, env_offset=0, use_rgb=True, use_depth=True, task="pointnav"):
         self.N, self.H, self.W, self.seed, self.off = num_envs, H, W, seed, env_offset
-        self.use_rgb, self.use_depth = use_rgb, use_depth
+        self.use_rgb, self.use_depth, self.task = use_rgb, use_depth, task
         self.t = np.zeros(num_envs, dtype=np.int64)
         self.since = np.zeros(num_envs, dtype=np.int64)
 
@@ -96,6 +120,12 @@ class SyntheticEnvs:
             o["rgb"] = np.stack([rgb(self.seed, self.off + n, self.t[n], self.H, self.W) for n in range(self.N)])
         if self.use_depth:
             o["depth"] = np.stack([depth(self.seed, self.off + n, self.t[n], self.H, self.W) for n in range(self.N)])
+        if self.task == "objectnav":  # rgb, depth, semantic + objectgoal, compass, gps (ddppo_objectnav.yaml sensor set)
+            o["semantic"] = np.stack([semantic(self.seed, self.off + n, self.t[n], self.H, self.W) for n in range(self.N)])
+            o["objectgoal"] = np.stack([objectgoal(self.seed, self.off + n, self.t[n]) for n in range(self.N)])
+            o["compass"] = np.stack([compass(self.seed, self.off + n, self.t[n]) for n in range(self.N)])
+            o["gps"] = np.stack([gps(self.seed, self.off + n, self.t[n]) for n in range(self.N)])
+            return o
         o["pointgoal_with_gps_compass"] = np.stack([goal(self.seed, self.off + n, self.t[n]) for n in range(self.N)])
         return o
 

@@ -27,26 +27,32 @@ from oracle.ref_loader import load_reference, make_config  # noqa: E402
 GOAL = "pointgoal_with_gps_compass"
 
 
-def obs_space(ns, H, W, rgb=True, depth=True):
+def obs_space(ns, H, W, rgb=True, depth=True, task="pointnav"):
     sp = ns.spaces
     d = {}
     if rgb:
         d["rgb"] = sp.Box(0, 255, (H, W, 3), np.uint8)
     if depth:
         d["depth"] = sp.Box(0.0, 1.0, (H, W, 1), np.float32)
-    d[GOAL] = sp.Box(-1e9, 1e9, (2,), np.float32)
+    if task == "objectnav":
+        d["semantic"] = sp.Box(0, synth.NUM_SEMANTIC_IDS - 1, (H, W, 1), np.int32)
+        d["objectgoal"] = sp.Box(0, synth.NUM_OBJECT_CATEGORIES - 1, (1,), np.int64)
+        d["compass"] = sp.Box(-np.pi, np.pi, (1,), np.float32)
+        d["gps"] = sp.Box(-1e9, 1e9, (2,), np.float32)
+    else:
+        d[GOAL] = sp.Box(-1e9, 1e9, (2,), np.float32)
     return sp.Dict(d)
 
 
-def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=True, sampled=False):
+def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=True, sampled=False, task="pointnav", num_actions=4):
     """Reference rollout (policy.act through RolloutStorage) + compute_returns + PPO.update."""
     sd = policy.state_dict()
     newp = det_params([(k, v.shape) for k, v in sd.items() if v.dtype == torch.float32 and "running_mean_and_var" not in k], seed)
     sd.update(newp)
     policy.load_state_dict(sd)
     RolloutStorage = ns.rollout_storage.RolloutStorage
-    rollouts = RolloutStorage(T, N, space, ns.spaces.Discrete(4), policy)
-    envs = synth.SyntheticEnvs(N, H, W, seed=seed, use_rgb=rgb, use_depth=depth)
+    rollouts = RolloutStorage(T, N, space, ns.spaces.Discrete(num_actions), policy)
+    envs = synth.SyntheticEnvs(N, H, W, seed=seed, use_rgb=rgb, use_depth=depth, task=task)
     obs, rew, done = synth_rollout_inputs(envs, T)
     to_t = lambda o: {k: torch.from_numpy(v) for k, v in o.items()}
     rollouts.insert_first_observations(to_t(obs[0]))
@@ -58,7 +64,7 @@ def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=Tru
         step = rollouts.get_current_step(slice(0, N), 0)
         with torch.no_grad():
             rng_state = torch.get_rng_state()
-            noises.append(torch.empty(N, 4).exponential_(1))  # what multinomial is about to draw
+            noises.append(torch.empty(N, num_actions).exponential_(1))  # what multinomial is about to draw
             torch.set_rng_state(rng_state)
             ad = policy.act(step["observations"], step["recurrent_hidden_states"], step["prev_actions"], step["masks"])
         rollouts.insert(next_recurrent_hidden_states=ad.rnn_hidden_states, actions=ad.actions,
@@ -188,6 +194,16 @@ def main():
     cfg3 = make_config(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2, num_steps=4,
                        use_normalized_advantage=False, hidden_size=64, lr=2.5e-4, eps=1e-5)
     run_case(ns, "resnet18_rgbd256", pol3, space3, cfg3, T=4, N=2, seed=21, H=256, W=256, sampled=True)
+    # C: ObjectNav inputs (BASELINE.json configs[4] geometry): ResNet50 on rgb + depth + semantic (5 channels), objectgoal /
+    # compass / gps embeddings, Discrete(6), 2-layer LSTM, ddppo_objectnav hyper-parameters (E=4 shortened to 2, M=2).
+    space4 = obs_space(ns, 256, 256, task="objectnav")
+    torch.manual_seed(0)
+    pol4 = ns.resnet_policy.PointNavResNetPolicy(space4, ns.spaces.Discrete(6), hidden_size=64, num_recurrent_layers=2,
+                                                 rnn_type="LSTM", backbone="resnet50", normalize_visual_inputs=True)
+    cfg4 = make_config(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2, num_steps=3,
+                       use_normalized_advantage=False, hidden_size=64, lr=2.5e-4, eps=1e-5)
+    run_case(ns, "objectnav_resnet50_256", pol4, space4, cfg4, T=3, N=2, seed=33, H=256, W=256, sampled=True, task="objectnav",
+             num_actions=6)
 
 
 if __name__ == "__main__":

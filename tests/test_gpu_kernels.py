@@ -411,20 +411,30 @@ def test_maxpool_fwd_bwd(L, B, H, W, Cc):
     assert torch.allclose(dx.cpu(), nhwc(x.grad), atol=1e-6)  # same arg-max choice as ATen on ties
 
 
-@pytest.mark.parametrize("keys", [("rgb", "depth"), ("depth", "rgb"), ("depth",), ("rgb",)])
+@pytest.mark.parametrize("keys", [("rgb", "depth"), ("depth", "rgb"), ("depth",), ("rgb",), ("rgb", "depth", "semantic"),
+                                  ("semantic", "rgb", "depth")])
 def test_ingest_and_running_mean_var(L, keys):
     torch.manual_seed(3)
     nrows, B, H, W = 7, 4, 20, 24
     rows = torch.randperm(nrows)[:B].int()
-    obs_all = {"rgb": torch.randint(0, 256, (nrows, H, W, 3), dtype=torch.uint8), "depth": torch.rand(nrows, H, W, 1)}
+    obs_all = {"rgb": torch.randint(0, 256, (nrows, H, W, 3), dtype=torch.uint8), "depth": torch.rand(nrows, H, W, 1),
+               "semantic": torch.randint(0, 40, (nrows, H, W, 1), dtype=torch.int32)}
     obs = {k: obs_all[k][rows.long()] for k in keys}
     x_ref = O.resnet_input(obs, list(keys))
     n_in = x_ref.shape[1]
-    y = torch.full((B, H // 2, W // 2, 4), 9.0, device="cuda")
-    ck(L.hab_obs_ingest_pool(P(obs_all["rgb"].cuda()) if "rgb" in keys else None, P(obs_all["depth"].cuda()) if "depth" in keys else None,
-                             P(rows.cuda()), P(y), B, H, W, 4, int(keys[0] == "depth" and len(keys) == 2), S()))
+    cpad = 4 if n_in <= 4 else 8
+    off, o = {"rgb": -1, "depth": -1, "semantic": -1}, 0
+    for k in keys:
+        off[k] = o
+        o += 3 if k == "rgb" else 1
+    y = torch.full((B, H // 2, W // 2, cpad), 9.0, device="cuda")
+    dev = {k: obs_all[k].cuda() for k in keys}
+    ck(L.hab_obs_ingest_pool(P(dev.get("rgb")), P(dev.get("depth")), P(dev.get("semantic")), P(rows.cuda()), P(y), B, H, W, cpad,
+                             off["rgb"], off["depth"], off["semantic"], S()))
     assert torch.equal(y.cpu()[..., :n_in], nhwc(x_ref)), "uint8 scaling + 2x2 average must be bitwise the reference's arithmetic"
-    assert float(y[..., n_in:].abs().max()) == 0.0 if n_in < 4 else True
+    assert n_in == cpad or float(y[..., n_in:].abs().max()) == 0.0
+    if cpad != 4:
+        return
     mean0, var0, cnt0 = torch.rand(1, n_in, 1, 1), torch.rand(1, n_in, 1, 1) * 0.1, torch.tensor(5.0)
     xn_ref, m_ref, v_ref, c_ref = O.running_mean_and_var(x_ref, mean0, var0, cnt0, True)
     npix = B * (H // 2) * (W // 2)
@@ -441,29 +451,49 @@ def test_ingest_and_running_mean_var(L, keys):
 
 
 def test_nav_embeddings_fwd_bwd(L):
+    """All five 1-D sensor embedding kinds of PointNavResNetNet.forward (PointNav: goal + previous action; ObjectNav: objectgoal,
+    compass, gps + previous action), forward and the deterministic backward reduction."""
+    from habitat_amd._lib import EmbedSlot
     torch.manual_seed(4)
-    B, nrows, ld, col0, A = 37, 50, 80, 12, 4
+    B, nrows, ld, col0, A, ncat = 300, 350, 200, 12, 6, 21
     rows = torch.randperm(nrows)[:B].int()
+    ridx = rows.long()
     goal = torch.stack([torch.rand(nrows) * 5, (torch.rand(nrows) - 0.5) * 6], 1)
+    objg = torch.randint(0, ncat, (nrows, 1))
+    compass = (torch.rand(nrows, 1) - 0.5) * 6
+    gps = torch.randn(nrows, 2)
     pa = torch.randint(0, A, (nrows, 1))
     masks = torch.rand(nrows, 1) > 0.3
-    w_t, b_t = torch.randn(32, 3, requires_grad=True), torch.randn(32, requires_grad=True)
-    emb = torch.randn(A + 1, 32, requires_grad=True)
-    g = goal[rows.long()]
-    g3 = torch.stack([g[:, 0], torch.cos(-g[:, 1]), torch.sin(-g[:, 1])], -1)
-    tok = torch.where(masks[rows.long()].view(-1), pa[rows.long()].view(-1) + 1, torch.zeros(B, dtype=torch.long))
-    ref = torch.cat([F.linear(g3, w_t, b_t), F.embedding(tok, emb)], 1)
+    w = {"tgt": torch.randn(32, 3), "tgt_b": torch.randn(32), "obj": torch.randn(ncat, 32), "cmp": torch.randn(32, 2), "cmp_b": torch.randn(32),
+         "gps": torch.randn(32, 2), "gps_b": torch.randn(32), "emb": torch.randn(A + 1, 32)}
+    for v in w.values():
+        v.requires_grad_()
+    g = goal[ridx]
+    tok = torch.where(masks[ridx].view(-1), pa[ridx].view(-1) + 1, torch.zeros(B, dtype=torch.long))
+    c = compass[ridx]
+    ref = torch.cat([F.linear(torch.stack([g[:, 0], torch.cos(-g[:, 1]), torch.sin(-g[:, 1])], -1), w["tgt"], w["tgt_b"]),
+                     F.embedding(objg[ridx], w["obj"]).squeeze(1),
+                     F.linear(torch.stack([torch.cos(c), torch.sin(c)], -1).squeeze(1), w["cmp"], w["cmp_b"]),
+                     F.linear(gps[ridx], w["gps"], w["gps_b"]), F.embedding(tok, w["emb"])], 1)
+    dw = {k: torch.zeros_like(v, device="cuda") for k, v in w.items()}
+    wd = {k: v.detach().cuda() for k, v in w.items()}
+    spec = [(0, goal, "tgt", "tgt_b", 0), (1, objg, "obj", None, ncat), (2, compass, "cmp", "cmp_b", 0), (3, gps, "gps", "gps_b", 0),
+            (4, pa, "emb", None, A + 1)]
+    slots = (EmbedSlot * 5)()
+    for i, (kind, inp, wk, bk, ntok) in enumerate(spec):
+        slots[i].kind, slots[i].num_tokens = kind, ntok
+        slots[i].input = P(inp.cuda()).value
+        slots[i].weight, slots[i].bias = wd[wk].data_ptr(), (wd[bk].data_ptr() if bk else None)
+        slots[i].d_weight, slots[i].d_bias = dw[wk].data_ptr(), (dw[bk].data_ptr() if bk else None)
     out = torch.zeros(B, ld, device="cuda")
-    saved = torch.zeros(B, 4, device="cuda")
-    ck(L.hab_nav_embed_fwd(P(goal.cuda()), P(pa.cuda()), P(masks.cuda()), P(rows.cuda()), P(w_t.detach().cuda()), P(b_t.detach().cuda()),
-                           P(emb.detach().cuda()), P(out), ld, col0, B, P(saved), S()))
-    assert torch.allclose(out.cpu()[:, col0:col0 + 64], ref, atol=1e-5, rtol=1e-5)
-    gy = torch.randn(B, 64)
+    saved = torch.zeros(B, 5, 4, device="cuda")
+    ck(L.hab_nav_embed_fwd(slots, 5, P(masks.cuda()), P(rows.cuda()), P(out), ld, col0, B, P(saved), S()))
+    assert torch.allclose(out.cpu()[:, col0:col0 + 160], ref, atol=1e-5, rtol=1e-5)
+    gy = torch.randn(B, 160)
     ref.backward(gy)
     dout = torch.zeros(B, ld)
-    dout[:, col0:col0 + 64] = gy
-    dw, db, de = torch.zeros(32, 3, device="cuda"), torch.zeros(32, device="cuda"), torch.zeros(A + 1, 32, device="cuda")
-    ws = torch.zeros(1 << 16, device="cuda")
-    ck(L.hab_nav_embed_bwd(P(saved), P(dout.cuda()), ld, col0, B, A + 1, P(dw), P(db), P(de), P(ws), ws.numel(), S()))
-    assert torch.allclose(dw.cpu(), w_t.grad, atol=1e-4, rtol=1e-4) and torch.allclose(db.cpu(), b_t.grad, atol=1e-4, rtol=1e-4)
-    assert torch.allclose(de.cpu(), emb.grad, atol=1e-4, rtol=1e-4)
+    dout[:, col0:col0 + 160] = gy
+    ws = torch.zeros(1 << 18, device="cuda")
+    ck(L.hab_nav_embed_bwd(slots, 5, P(saved), P(dout.cuda()), ld, col0, B, P(ws), ws.numel(), S()))
+    for k, v in w.items():
+        assert torch.allclose(dw[k].cpu(), v.grad, atol=2e-4, rtol=1e-4), k

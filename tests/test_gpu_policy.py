@@ -23,8 +23,19 @@ def space_for(c):
         d["rgb"] = S.Box(0, 255, (c["H"], c["W"], 3), np.uint8)
     if c["depth"]:
         d["depth"] = S.Box(0.0, 1.0, (c["H"], c["W"], 1), np.float32)
-    d[GOAL] = S.Box(-1e9, 1e9, (2,), np.float32)
-    return S.Dict(d), S.Discrete(4)
+    if c.get("task") == "objectnav":
+        from oracle import synth
+        d["semantic"] = S.Box(0, synth.NUM_SEMANTIC_IDS - 1, (c["H"], c["W"], 1), np.int32)
+        d["objectgoal"] = S.Box(0, synth.NUM_OBJECT_CATEGORIES - 1, (1,), np.int64)
+        d["compass"] = S.Box(-np.pi, np.pi, (1,), np.float32)
+        d["gps"] = S.Box(-1e9, 1e9, (2,), np.float32)
+    else:
+        d[GOAL] = S.Box(-1e9, 1e9, (2,), np.float32)
+    return S.Dict(d), S.Discrete(c.get("num_actions", 4))
+
+
+def extra_of(obs):
+    return {k: obs[k] for k in ("semantic", "objectgoal", "compass", "gps") if k in obs}
 
 
 def build(case, z):
@@ -35,8 +46,9 @@ def build(case, z):
     params, spec, buf, next_value = oracle_rollout(case, z)
     osp, asp = space_for(c)
     if c.get("kind", "baseline") == "resnet":
-        pol = PointNavResNetPolicy(osp, asp, hidden_size=c["hidden"], num_recurrent_layers=2, rnn_type="LSTM", backbone="resnet18",
-                                   normalize_visual_inputs=True, max_frames=c["T"] * c["N"], max_envs=c["N"])
+        pol = PointNavResNetPolicy(osp, asp, hidden_size=c["hidden"], num_recurrent_layers=2, rnn_type="LSTM",
+                                   backbone=c.get("backbone", "resnet18"), normalize_visual_inputs=True, max_frames=c["T"] * c["N"],
+                                   max_envs=c["N"])
     else:
         pol = PointNavBaselinePolicy(osp, asp, hidden_size=c["hidden"], max_frames=c["T"] * c["N"], max_envs=c["N"])
     pol.load_state_dict(params)
@@ -117,8 +129,9 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
     Bf = st.buffers
     obs = Bf["observations"]
     v, lp, ent = (torch.zeros(Bn, device="cuda") for _ in range(3))
-    eng.evaluate(obs.get("rgb"), obs.get("depth"), obs[GOAL], batch.rows, Bf["recurrent_hidden_states"], Bf["masks"],
-                 Bf["actions"], batch.pack, Bn, batch.n, value=v, log_prob=lp, entropy=ent, prev_actions=Bf["prev_actions"])
+    eng.evaluate(obs.get("rgb"), obs.get("depth"), obs.get(GOAL), batch.rows, Bf["recurrent_hidden_states"], Bf["masks"],
+                 Bf["actions"], batch.pack, Bn, batch.n, value=v, log_prob=lp, entropy=ent, prev_actions=Bf["prev_actions"],
+                 extra=extra_of(obs))
     assert rel_ok(v.cpu().numpy(), z["mb0_value"].reshape(-1))
     assert rel_ok(lp.cpu().numpy(), z["mb0_logp"].reshape(-1))
     assert rel_ok(ent.cpu().numpy(), z["mb0_entropy"].reshape(-1))
@@ -126,7 +139,7 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
     eng.final_hidden(hfin)
     assert rel_ok(hfin.cpu().numpy(), z["mb0_hidden"])
     # dict-style (reference-style) access to the lazily gathered batch equals the reference's gather
-    assert batch["observations"][GOAL].shape[0] == Bn
+    assert batch["observations"]["depth"].shape[0] == Bn
     # fused loss + backward
     from habitat_amd import _lib
     import ctypes as C
@@ -137,8 +150,8 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
                                        P(batch.rows), Bn, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef,
                                        int(cfg.use_clipped_value_loss), P(dv), P(dlp), P(dent), P(out), _lib.stream_ptr()))
     assert np.allclose(out[:4].cpu().numpy(), z["mb0_losses"], rtol=1e-4, atol=1e-6)
-    eng.backward(obs.get("rgb"), obs.get("depth"), obs[GOAL], batch.rows, Bf["actions"], batch.pack, dv, dlp, dent,
-                 prev_actions=Bf["prev_actions"])
+    eng.backward(obs.get("rgb"), obs.get("depth"), obs.get(GOAL), batch.rows, Bf["actions"], batch.pack, dv, dlp, dent,
+                 prev_actions=Bf["prev_actions"], extra=extra_of(obs))
     samp = golden_sample if c.get("sampled") else (lambda a: a)
     bad = []
     for k, g in eng.grad_views.items():
@@ -156,8 +169,8 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
             err = np.linalg.norm((got - ref).astype(np.float64)) / max(1e-12, np.linalg.norm(ref.astype(np.float64)))
             nr = float(z["gradnorm/" + k])
             nerr = abs(float(g.double().norm()) - nr) / max(1e-12, nr)
-            downstream = ("layer4" in k or "compression" in k or "visual_fc" in k or "state_encoder" in k or "tgt_" in k
-                          or "prev_action" in k or k.startswith("action_") or k.startswith("critic"))
+            downstream = ("compression" in k or "visual_fc" in k or "state_encoder" in k or "_embed" in k
+                          or k.startswith("action_") or k.startswith("critic") or (case == "resnet18_rgbd256" and "layer4" in k))
             lim = 2e-4 if downstream else 2e-2
             if err > lim or nerr > lim:
                 bad.append((k, err, nerr))
@@ -183,8 +196,8 @@ def test_full_ppo_update_vs_reference_golden(case, monkeypatch):
         torch.manual_seed(c["seed"] + 1)
         b0 = next(st.data_generator(ppo.get_advantages(st), cfg.num_mini_batch))
         Bf, obs = st.buffers, st.buffers["observations"]
-        pol.engine.evaluate(obs.get("rgb"), obs.get("depth"), obs[GOAL], b0.rows, Bf["recurrent_hidden_states"], Bf["masks"],
-                            Bf["actions"], b0.pack, b0.T * b0.n, b0.n, prev_actions=Bf["prev_actions"])
+        pol.engine.evaluate(obs.get("rgb"), obs.get("depth"), obs.get(GOAL), b0.rows, Bf["recurrent_hidden_states"], Bf["masks"],
+                            Bf["actions"], b0.pack, b0.T * b0.n, b0.n, prev_actions=Bf["prev_actions"], extra=extra_of(obs))
     perms = [torch.from_numpy(p) for p in z["perms"]]
     monkeypatch.setattr(torch, "randperm", lambda n, **kw: perms.pop(0))
     metrics = ppo.update(st)

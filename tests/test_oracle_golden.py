@@ -92,6 +92,10 @@ CASES = {
     "resnet18_rgbd256": dict(kind="resnet", H=256, W=256, rgb=True, depth=True, T=4, N=2, seed=21, hidden=64, sampled=True,
                              cfg=dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2,
                                       use_normalized_advantage=False, use_clipped_value_loss=True)),
+    "objectnav_resnet50_256": dict(kind="resnet", backbone="resnet50", task="objectnav", num_actions=6, H=256, W=256, rgb=True,
+                                   depth=True, T=3, N=2, seed=33, hidden=64, sampled=True,
+                                   cfg=dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2,
+                                            use_normalized_advantage=False, use_clipped_value_loss=True)),
 }
 
 
@@ -101,11 +105,17 @@ def case_params_spec(c):
     if c.get("kind", "baseline") == "baseline":
         params = det_params(baseline_param_shapes(cin, c["H"], c["W"], c["hidden"]), c["seed"])
         return params, O.NetSpec(kind="baseline", rnn_type="GRU", num_layers=1, hidden=c["hidden"]), 1
-    params = det_params(resnet_param_shapes(cin, c["H"], c["W"], c["hidden"]), c["seed"])
+    objnav = c.get("task") == "objectnav"
+    keys = ("rgb", "depth", "semantic") if objnav else ("rgb", "depth")
+    cin += 1 if objnav else 0
+    shapes = resnet_param_shapes(cin, c["H"], c["W"], c["hidden"], num_actions=c.get("num_actions", 4),
+                                 backbone=c.get("backbone", "resnet18"), has_goal=not objnav,
+                                 n_obj=synth.NUM_OBJECT_CATEGORIES if objnav else 0, has_gps=objnav, has_compass=objnav)
+    params = det_params(shapes, c["seed"])
     pre = "net.visual_encoder.running_mean_and_var."
     params[pre + "_mean"], params[pre + "_var"], params[pre + "_count"] = torch.zeros(1, cin, 1, 1), torch.zeros(1, cin, 1, 1), torch.zeros(())
-    spec = O.NetSpec(kind="resnet", rnn_type="LSTM", num_layers=2, backbone="resnet18", baseplanes=32,
-                     visual_keys=("rgb", "depth"), normalize=True, hidden=c["hidden"])
+    spec = O.NetSpec(kind="resnet", rnn_type="LSTM", num_layers=2, backbone=c.get("backbone", "resnet18"), baseplanes=32,
+                     visual_keys=keys, normalize=True, hidden=c["hidden"], num_actions=c.get("num_actions", 4))
     return params, spec, 4
 
 
@@ -124,7 +134,7 @@ def oracle_rollout(case, z):
     c = CASES[case]
     params, spec, Lh = case_params_spec(c)
     T, N = c["T"], c["N"]
-    envs = synth.SyntheticEnvs(N, c["H"], c["W"], seed=c["seed"], use_rgb=c["rgb"], use_depth=c["depth"])
+    envs = synth.SyntheticEnvs(N, c["H"], c["W"], seed=c["seed"], use_rgb=c["rgb"], use_depth=c["depth"], task=c.get("task", "pointnav"))
     obs, rew, done = synth_rollout_inputs(envs, T)
     buf = dict(observations={k: torch.from_numpy(np.stack([o[k] for o in obs])) for k in obs[0]})
     buf["recurrent_hidden_states"] = torch.zeros(T + 1, N, Lh, c["hidden"])
