@@ -65,8 +65,10 @@ __global__ void synth_scalars_kernel(float* __restrict__ goal, float* __restrict
     {
         const uint32_t key = stream_key(seed, 2u, env, t);
         const float u0 = u01(mix32(key ^ 0u)), u1 = u01(mix32(key ^ 1u));
-        goal[2 * n + 0] = __fmul_rn(u0, 10.0f);
-        goal[2 * n + 1] = __fmul_rn(__fadd_rn(__fmul_rn(u1, 2.0f), -1.0f), 3.14159274101257324f);
+        if (goal) {
+            goal[2 * n + 0] = __fmul_rn(u0, 10.0f);
+            goal[2 * n + 1] = __fmul_rn(__fadd_rn(__fmul_rn(u1, 2.0f), -1.0f), 3.14159274101257324f);
+        }
     }
     if (advance) {
         const uint32_t key = stream_key(seed, 3u, env, t);
@@ -85,7 +87,7 @@ __global__ void synth_scalars_kernel(float* __restrict__ goal, float* __restrict
 extern "C" int hab_synth_step(uint8_t* rgb, float* depth, float* goal, float* reward, uint8_t* not_done, int64_t* env_t,
                               int64_t* since_reset, uint32_t seed, uint32_t env_offset, int N, int H, int W, int advance,
                               hipStream_t stream) {
-    if (N <= 0 || H <= 0 || W <= 0 || !goal || !env_t) return HAB_ERR_ARG;
+    if (N <= 0 || H <= 0 || W <= 0 || !env_t) return HAB_ERR_ARG;
     if (advance && (!reward || !not_done || !since_reset)) return HAB_ERR_ARG;
     if ((H * W * 3) % 4 != 0) return HAB_ERR_UNSUPPORTED;
     synth_scalars_kernel<<<cdiv(N, 64), 64, 0, stream>>>(goal, reward, not_done, env_t, since_reset, seed, env_offset, N,
@@ -96,6 +98,48 @@ extern "C" int hab_synth_step(uint8_t* rgb, float* depth, float* goal, float* re
         dim3 grid(cdiv(depth_words / 4, 256), N);
         if (grid.x > 64) grid.x = 64;
         synth_images_kernel<<<grid, 256, 0, stream>>>(rgb, depth, env_t, seed, env_offset, rgb_words, depth_words);
+        HAB_LAUNCH_CHECK();
+    }
+    return HAB_OK;
+}
+
+// ObjectNav sensor set for the current env clock (oracle/synth.py: semantic, objectgoal, compass, gps).
+__global__ void __launch_bounds__(256) synth_semantic_kernel(int32_t* __restrict__ semantic, const int64_t* __restrict__ env_t,
+                                                             uint32_t seed, uint32_t env_offset, int words) {
+    const int n = blockIdx.y;
+    const uint32_t key = stream_key(seed, 5u, env_offset + (uint32_t)n, (uint32_t)env_t[n]);
+    int32_t* dst = semantic + (size_t)n * words;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) dst[i] = (int32_t)(mix32(key ^ (uint32_t)i) % 40u);
+}
+__global__ void synth_objectnav_scalars_kernel(int64_t* __restrict__ objectgoal, float* __restrict__ compass, float* __restrict__ gps,
+                                               const int64_t* __restrict__ env_t, uint32_t seed, uint32_t env_offset, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t t = (uint32_t)env_t[n], env = env_offset + (uint32_t)n;
+    if (objectgoal) objectgoal[n] = (int64_t)(mix32(stream_key(seed, 6u, env, 0u) ^ 0u) % 21u);
+    if (compass) {
+        const float u = u01(mix32(stream_key(seed, 7u, env, t) ^ 0u));
+        compass[n] = __fmul_rn(__fadd_rn(__fmul_rn(u, 2.0f), -1.0f), 3.14159274101257324f);
+    }
+    if (gps) {
+        const uint32_t key = stream_key(seed, 8u, env, t);
+        float u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = u01(mix32(key ^ (uint32_t)i));
+        const float a = __fadd_rn(__fadd_rn(u[0], u[1]), __fadd_rn(u[2], u[3]));
+        const float b = __fadd_rn(__fadd_rn(u[4], u[5]), __fadd_rn(u[6], u[7]));
+        gps[2 * n + 0] = __fmul_rn(__fadd_rn(a, -2.0f), 1.73205077648162842f);
+        gps[2 * n + 1] = __fmul_rn(__fadd_rn(b, -2.0f), 1.73205077648162842f);
+    }
+}
+extern "C" int hab_synth_objectnav_sensors(int32_t* semantic, int64_t* objectgoal, float* compass, float* gps, const int64_t* env_t,
+                                           uint32_t seed, uint32_t env_offset, int N, int H, int W, hipStream_t stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || !env_t) return HAB_ERR_ARG;
+    synth_objectnav_scalars_kernel<<<cdiv(N, 64), 64, 0, stream>>>(objectgoal, compass, gps, env_t, seed, env_offset, N);
+    HAB_LAUNCH_CHECK();
+    if (semantic) {
+        dim3 grid(min(64, cdiv(H * W, 256)), N);
+        synth_semantic_kernel<<<grid, 256, 0, stream>>>(semantic, env_t, seed, env_offset, H * W);
         HAB_LAUNCH_CHECK();
     }
     return HAB_OK;

@@ -25,6 +25,7 @@ from habitat_amd._lib import check, ptr, stream_ptr
 from habitat_amd.common import spaces
 
 GOAL_UUID = "pointgoal_with_gps_compass"
+NUM_SEMANTIC_IDS, NUM_OBJECT_CATEGORIES = 40, 21  # synthetic ObjectNav sensor ranges
 
 
 class VectorEnvFactory(abc.ABC):
@@ -44,17 +45,24 @@ def instantiate(target_cfg):
 
 class SyntheticVectorEnv:
     def __init__(self, num_envs: int, height: int, width: int, seed: int = 100, env_offset: int = 0, use_rgb: bool = True,
-                 use_depth: bool = True, num_actions: int = 4, device="cuda"):
+                 use_depth: bool = True, num_actions: int = 4, device="cuda", task: str = "pointnav"):
         self.num_envs, self.H, self.W = num_envs, height, width
         self.seed, self.env_offset = int(seed) & 0xFFFFFFFF, int(env_offset)
-        self.use_rgb, self.use_depth = use_rgb, use_depth
+        self.use_rgb, self.use_depth, self.task = use_rgb, use_depth, task
         self.device = torch.device(device)
         d = {}
         if use_rgb:
             d["rgb"] = spaces.Box(0, 255, (height, width, 3), np.uint8)
         if use_depth:
             d["depth"] = spaces.Box(0.0, 1.0, (height, width, 1), np.float32)
-        d[GOAL_UUID] = spaces.Box(np.finfo(np.float32).min, np.finfo(np.float32).max, (2,), np.float32)
+        fmin, fmax = np.finfo(np.float32).min, np.finfo(np.float32).max
+        if task == "objectnav":  # sensor set of the ObjectNav experiments (rgb, depth, semantic + objectgoal, compass, gps)
+            d["semantic"] = spaces.Box(0, NUM_SEMANTIC_IDS - 1, (height, width, 1), np.int32)
+            d["objectgoal"] = spaces.Box(0, NUM_OBJECT_CATEGORIES - 1, (1,), np.int64)
+            d["compass"] = spaces.Box(-np.pi, np.pi, (1,), np.float32)
+            d["gps"] = spaces.Box(fmin, fmax, (2,), np.float32)
+        else:
+            d[GOAL_UUID] = spaces.Box(fmin, fmax, (2,), np.float32)
         self.observation_spaces = [spaces.Dict(d) for _ in range(num_envs)]
         self.action_spaces = [spaces.Discrete(num_actions) for _ in range(num_envs)]
         self.orig_action_spaces = self.action_spaces
@@ -66,7 +74,12 @@ class SyntheticVectorEnv:
         self._since = torch.zeros(num_envs, dtype=torch.int64, device=dev)
         self._rgb = torch.zeros(num_envs, height, width, 3, dtype=torch.uint8, device=dev) if use_rgb else None
         self._depth = torch.zeros(num_envs, height, width, 1, device=dev) if use_depth else None
-        self._goal = torch.zeros(num_envs, 2, device=dev)
+        self._goal = torch.zeros(num_envs, 2, device=dev) if task != "objectnav" else None
+        self._obj = {}
+        if task == "objectnav":
+            self._obj = dict(semantic=torch.zeros(num_envs, height, width, 1, dtype=torch.int32, device=dev),
+                             objectgoal=torch.zeros(num_envs, 1, dtype=torch.int64, device=dev),
+                             compass=torch.zeros(num_envs, 1, device=dev), gps=torch.zeros(num_envs, 2, device=dev))
         self._rew = torch.zeros(num_envs, device=dev)
         self._nd = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
         self._pending = False
@@ -76,6 +89,13 @@ class SyntheticVectorEnv:
         check(_lib.lib().hab_synth_step(ptr(rgb), ptr(depth), ptr(goal), ptr(reward), ptr(not_done), ptr(self._t), ptr(self._since),
                                         self.seed, self.env_offset, self.num_envs, self.H, self.W, advance, stream_ptr()),
               "hab_synth_step")
+
+    def _emit_objectnav(self, obs):
+        if self.task != "objectnav":
+            return
+        check(_lib.lib().hab_synth_objectnav_sensors(ptr(obs.get("semantic")), ptr(obs.get("objectgoal")), ptr(obs.get("compass")),
+                                                     ptr(obs.get("gps")), ptr(self._t), self.seed, self.env_offset, self.num_envs,
+                                                     self.H, self.W, stream_ptr()), "hab_synth_objectnav_sensors")
 
     def reset_into(self, rgb, depth, goal):
         """Resets all envs and writes their first observations into the given (N, ...) device tensors."""
@@ -88,11 +108,21 @@ class SyntheticVectorEnv:
         observations / rewards (N,) / not-done masks (N,) bytes straight into the given device tensors."""
         self._emit(rgb, depth, goal, reward, not_done, 1)
 
+    def reset_into_obs(self, obs):
+        """Dict form: `obs` maps sensor uuid -> (N, ...) device tensor (a rollout-arena row)."""
+        self.reset_into(obs.get("rgb"), obs.get("depth"), obs.get(GOAL_UUID))
+        self._emit_objectnav(obs)
+
+    def step_into_obs(self, obs, reward, not_done):
+        self.step_into(obs.get("rgb"), obs.get("depth"), obs.get(GOAL_UUID), reward, not_done)
+        self._emit_objectnav(obs)
+
     # ---- VectorEnv API (host path) ----------------------------------------------------------------
     def _host_obs(self) -> List[Dict[str, np.ndarray]]:
         rgb = self._rgb.cpu().numpy() if self.use_rgb else None
         depth = self._depth.cpu().numpy() if self.use_depth else None
-        goal = self._goal.cpu().numpy()
+        goal = self._goal.cpu().numpy() if self._goal is not None else None
+        extra = {k: v.cpu().numpy() for k, v in self._obj.items()}
         out = []
         for i in range(self.num_envs):
             o = {}
@@ -100,12 +130,25 @@ class SyntheticVectorEnv:
                 o["rgb"] = rgb[i]
             if self.use_depth:
                 o["depth"] = depth[i]
-            o[GOAL_UUID] = goal[i]
+            for k, v in extra.items():
+                o[k] = v[i]
+            if goal is not None:
+                o[GOAL_UUID] = goal[i]
             out.append(o)
         return out
 
+    def _own_obs(self):
+        o = dict(self._obj)
+        if self.use_rgb:
+            o["rgb"] = self._rgb
+        if self.use_depth:
+            o["depth"] = self._depth
+        if self._goal is not None:
+            o[GOAL_UUID] = self._goal
+        return o
+
     def reset(self):
-        self.reset_into(self._rgb, self._depth, self._goal)
+        self.reset_into_obs(self._own_obs())
         return self._host_obs()
 
     def async_step_at(self, index_env: int, action) -> None:
@@ -113,7 +156,7 @@ class SyntheticVectorEnv:
 
     def wait_step_at(self, index_env: int):
         if self._pending:  # all envs advance together on the first wait of a step
-            self.step_into(self._rgb, self._depth, self._goal, self._rew, self._nd)
+            self.step_into_obs(self._own_obs(), self._rew, self._nd)
             self._host_cache = (self._host_obs(), self._rew.cpu().numpy(), self._nd.cpu().numpy())
             self._pending = False
         obs, rew, nd = self._host_cache
@@ -140,6 +183,7 @@ class SyntheticVectorEnvFactory(VectorEnvFactory):
         use_rgb = self.use_rgb and "rgb" in sens
         use_depth = self.use_depth and "depth" in sens
         ref = sens["rgb"] if use_rgb else sens["depth"]
+        task = "objectnav" if str(hab.task.type).lower().startswith("objectnav") else "pointnav"
         return SyntheticVectorEnv(int(hb.num_environments), int(ref.height), int(ref.width), seed=int(hab.seed),
                                   env_offset=env_offset, use_rgb=use_rgb, use_depth=use_depth,
-                                  num_actions=len(hab.task.actions), device=device)
+                                  num_actions=len(hab.task.actions), device=device, task=task)

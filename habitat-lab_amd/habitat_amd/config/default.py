@@ -98,6 +98,15 @@ BENCHMARK_PRESETS = {
                                                simulator=dict(sensors=dict(rgb=dict(height=256, width=256),
                                                                            depth=dict(height=256, width=256))))),
     "pointnav_mp3d": dict(habitat=dict(environment=dict(max_episode_steps=500))),
+    # HL/config/benchmark/nav/objectnav/objectnav_mp3d.yaml: ObjectNav-v1, 6 actions, objectgoal + compass + gps lab sensors.
+    # Visual sensors are the 256x256 rgb / depth / semantic set BASELINE.json quotes its ObjectNav configuration on (the reference
+    # renders 640x480 and resizes through obs transforms, which are outside the accelerated path).
+    "objectnav_mp3d": dict(habitat=dict(
+        environment=dict(max_episode_steps=500),
+        simulator=dict(sensors=dict(rgb=dict(height=256, width=256), depth=dict(height=256, width=256),
+                                    semantic=dict(height=256, width=256))),
+        task=dict(type="ObjectNav-v1", goal_sensor_uuid="objectgoal", lab_sensors=["objectgoal", "compass", "gps"],
+                  actions=["stop", "move_forward", "turn_left", "turn_right", "look_up", "look_down"]))),
 }
 
 

@@ -54,7 +54,7 @@ def batch_obs(observations, device):
 @baseline_registry.register_trainer(name="ddppo")
 @baseline_registry.register_trainer(name="ppo")
 class PPOTrainer(BaseRLTrainer):
-    supported_tasks = ["Nav-v0"]
+    supported_tasks = ["Nav-v0", "ObjectNav-v1"]
     SHORT_ROLLOUT_THRESHOLD: float = 0.25
 
     def __init__(self, config=None):
@@ -132,13 +132,12 @@ class PPOTrainer(BaseRLTrainer):
             self._agent.init_distributed(find_unused_params=False)
         self._agent.post_init()
         self._ppo_cfg = hb.rl.ppo
-        self._device_envs = hasattr(self.envs, "step_into") and self.device.type == "cuda"
+        self._device_envs = hasattr(self.envs, "step_into_obs") and self.device.type == "cuda"
         st = self._agent.rollouts
         N = self.envs.num_envs
         if self._device_envs:
             o0 = st.buffers["observations"]
-            self.envs.reset_into(o0["rgb"][0] if "rgb" in o0 else None, o0["depth"][0] if "depth" in o0 else None,
-                                 o0["pointgoal_with_gps_compass"][0])
+            self.envs.reset_into_obs({k: v[0] for k, v in o0.items()})
             stat_dev = self.device
         else:
             observations = self.envs.post_step(self.envs.reset())
@@ -182,8 +181,7 @@ class PPOTrainer(BaseRLTrainer):
                             rnn_hidden_states=B["recurrent_hidden_states"][t + 1]))
             B["prev_actions"][t + 1].copy_(B["actions"][t])
         with g_timer.avg_time("trainer.step_env"):
-            self.envs.step_into(obs["rgb"][t + 1] if "rgb" in obs else None, obs["depth"][t + 1] if "depth" in obs else None,
-                                obs["pointgoal_with_gps_compass"][t + 1], B["rewards"][t], B["masks"][t + 1])
+            self.envs.step_into_obs({k: v[t + 1] for k, v in obs.items()}, B["rewards"][t], B["masks"][t + 1])
         with g_timer.avg_time("trainer.update_stats"):
             rewards, not_done = B["rewards"][t], B["masks"][t + 1]
             self.current_episode_reward += rewards

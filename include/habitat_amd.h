@@ -43,6 +43,11 @@ const char* hab_error_string(int code);
 int hab_synth_step(uint8_t* rgb /*N,H,W,3*/, float* depth /*N,H,W,1*/, float* goal /*N,2*/, float* reward /*N*/,
                    uint8_t* not_done /*N*/, int64_t* env_t /*N*/, int64_t* since_reset /*N*/, uint32_t seed,
                    uint32_t env_offset, int N, int H, int W, int advance, hipStream_t stream);
+/* ObjectNav sensor set for the CURRENT env clock (call after hab_synth_step): semantic int32 (N,H,W,1) in [0,40),
+ * objectgoal int64 (N,1) in [0,21) (fixed per env), compass f32 (N,1), gps f32 (N,2).  Any pointer may be NULL.
+ * Bit-identical to oracle/synth.py. */
+int hab_synth_objectnav_sensors(int32_t* semantic, int64_t* objectgoal, float* compass, float* gps, const int64_t* env_t,
+                                uint32_t seed, uint32_t env_offset, int N, int H, int W, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * RolloutStorage.compute_returns (common/rollout_storage.py:174-205).  Buffers are (T+1, N).

@@ -75,6 +75,24 @@ def test_synth_bit_exact_vs_oracle(L):
         assert np.array_equal(nd.cpu().numpy().astype(bool), ~d)
 
 
+def test_synth_objectnav_sensors_bit_exact_vs_oracle(L):
+    N, H, W, seed, off = 4, 12, 16, 100, 3
+    dev = "cuda"
+    sem = torch.zeros(N, H, W, 1, dtype=torch.int32, device=dev)
+    og = torch.zeros(N, 1, dtype=torch.int64, device=dev)
+    cp, gps = torch.zeros(N, 1, device=dev), torch.zeros(N, 2, device=dev)
+    rew, nd = torch.zeros(N, device=dev), torch.zeros(N, dtype=torch.uint8, device=dev)
+    et, since = torch.zeros(N, dtype=torch.int64, device=dev), torch.zeros(N, dtype=torch.int64, device=dev)
+    env = synth.SyntheticEnvs(N, H, W, seed=seed, env_offset=off, task="objectnav")
+    o = env.reset()
+    for step in range(6):
+        ck(L.hab_synth_step(None, None, None, P(rew), P(nd), P(et), P(since), seed, off, N, H, W, int(step > 0), S()))
+        ck(L.hab_synth_objectnav_sensors(P(sem), P(og), P(cp), P(gps), P(et), seed, off, N, H, W, S()))
+        assert np.array_equal(sem.cpu().numpy(), o["semantic"]) and np.array_equal(og.cpu().numpy(), o["objectgoal"])
+        assert np.array_equal(cp.cpu().numpy(), o["compass"]) and np.array_equal(gps.cpu().numpy(), o["gps"])
+        o, r, d = env.step()
+
+
 @pytest.mark.parametrize("T,N", [(128, 64), (5, 3), (1, 1), (33, 70), (200, 2)])
 @pytest.mark.parametrize("use_gae", [1, 0])
 def test_compute_returns(L, T, N, use_gae):

@@ -32,6 +32,11 @@ def test_yaml_entrypoints_compose():
     assert c2.habitat_baselines.rl.policy.main_agent.name == "PointNavBaselinePolicy"
     c3 = get_config("pointnav/ppo_pointnav_example.yaml")
     assert c3.habitat_baselines.rl.ppo.num_steps == 32 and c3.habitat_baselines.rl.ppo.ppo_epoch == 1
+    c4 = get_config("objectnav/ddppo_objectnav.yaml", ["habitat_baselines.num_environments=32"])  # BASELINE.json configs[4]
+    p4 = c4.habitat_baselines.rl.ppo
+    assert (p4.ppo_epoch, p4.num_mini_batch, p4.num_steps, p4.max_grad_norm) == (4, 2, 64, 0.2)
+    assert c4.habitat_baselines.rl.ddppo.backbone == "resnet50" and c4.habitat.task.type == "ObjectNav-v1"
+    assert len(c4.habitat.task.actions) == 6 and "semantic" in c4.habitat.simulator.sensors
 
 
 def test_tensor_dict_semantics():
