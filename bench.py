@@ -36,6 +36,10 @@ WORKLOADS = {
     # BASELINE.json configs[2]: ResNet18 + 2-layer LSTM with the ddppo_pointnav.yaml hyper-parameters (E=2, M=2)
     "c3": dict(yaml="pointnav/ddppo_pointnav.yaml", name="PointNav ResNet18+LSTM, 64 envs x 128 steps, 256x256 RGB-D synthetic",
                overrides=["habitat_baselines.rl.ddppo.backbone=resnet18"]),
+    # BASELINE.json configs[4] (per GPU): ObjectNav ResNet50 on rgb + depth + semantic, 32 envs x 64 steps, E=4, M=2
+    "c5": dict(yaml="objectnav/ddppo_objectnav.yaml", name="ObjectNav ResNet50+LSTM RGB-D+semantic, 32 envs x 64 steps, 256x256 synthetic",
+               overrides=["habitat.simulator.sensors.semantic.height=256", "habitat.simulator.sensors.semantic.width=256"],
+               envs=32, steps=64),
 }
 
 # probe tag -> (description, flops per frame)   SimpleCNN @256^2 RGB-D (a4)
@@ -54,7 +58,8 @@ def make_trainer(workload: str, total_updates: int):
     from habitat_amd.config.default import get_config
     import habitat_amd.rl.ppo.ppo_trainer as tr
     w = WORKLOADS[workload]
-    cfg = get_config(w["yaml"], [f"habitat_baselines.num_environments={NUM_ENVS}", f"habitat_baselines.rl.ppo.num_steps={NUM_STEPS}",
+    cfg = get_config(w["yaml"], [f"habitat_baselines.num_environments={w.get('envs', NUM_ENVS)}",
+                                 f"habitat_baselines.rl.ppo.num_steps={w.get('steps', NUM_STEPS)}",
                                  f"habitat_baselines.num_updates={total_updates}", "habitat_baselines.total_num_steps=-1",
                                  "habitat_baselines.num_checkpoints=-1", f"habitat_baselines.checkpoint_interval={10 ** 9}",
                                  "habitat_baselines.rl.ddppo.distrib_backend=" + os.environ.get("HAB_BENCH_DISTRIB_BACKEND", "NCCL"),
@@ -146,6 +151,9 @@ def main():
     a = ap.parse_args()
     if a.probe is None:
         a.probe = "conv2_dgrad" if a.workload == "c2" else "enc_bwd"
+    if a.workload == "c5" and a.probe.startswith("enc_"):
+        # ResNet50 on 5 channels: 375.0 MMAC forward (a5); the stem's data gradient (7x7x8 pad -> 5 real ch) is not computed
+        PROBES["enc_fwd"], PROBES["enc_bwd"] = (11, 2.0 * 375.0e6), (12, 2.0 * (2 * 375.0e6 - 32.1e6))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != a.gpus:
@@ -183,12 +191,13 @@ def main():
     if rank != 0:
         return
     ppo = cfg.habitat_baselines.rl.ppo
-    steps_total = world * NUM_ENVS * NUM_STEPS * a.steps
+    n_envs, n_steps = WORKLOADS[a.workload].get("envs", NUM_ENVS), WORKLOADS[a.workload].get("steps", NUM_STEPS)
+    steps_total = world * n_envs * n_steps * a.steps
     # frames seen by the probed call site during the timed region
-    upd_frames = NUM_ENVS * NUM_STEPS * ppo.ppo_epoch * a.steps
-    roll_frames = NUM_ENVS * (NUM_STEPS + 1) * a.steps
+    upd_frames = n_envs * n_steps * ppo.ppo_epoch * a.steps
+    roll_frames = n_envs * (n_steps + 1) * a.steps
     frames = upd_frames + (roll_frames if a.probe.endswith("_fwd") else 0)
-    kname = f"igemm_kernel<{a.probe}>" if not a.probe.startswith("enc_") else f"resnet18 encoder {a.probe[4:]} (all kernels)"
+    kname = f"igemm_kernel<{a.probe}>" if not a.probe.startswith("enc_") else f"resnet encoder {a.probe[4:]} (all kernels)"
     ach = flops_per_frame * frames / (probe_ms * 1e-3) / 1e12 if probe_ms > 0 else None
     traffic = hbm_traffic(a.workload, a.probe)
     out = {
@@ -196,7 +205,7 @@ def main():
         "value": round(steps_total / dt, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": WORKLOADS[a.workload]["name"], "envs_per_gpu": NUM_ENVS, "rollout_steps": NUM_STEPS,
+        "config": {"workload": WORKLOADS[a.workload]["name"], "envs_per_gpu": n_envs, "rollout_steps": n_steps,
                    "ppo_epoch": ppo.ppo_epoch, "num_mini_batch": ppo.num_mini_batch, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2) if ach else None,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4) if ach else None,

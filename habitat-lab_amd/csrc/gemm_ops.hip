@@ -1,7 +1,10 @@
 // gemm_ops.hip -- launchers that map conv / linear layers (fwd, dgrad, wgrad) onto igemm tiles,
 // plus the small HBM-bound helpers around them (weight repack, column sums for bias gradients).
 #include "igemm.h"
+#include "igemm_dma.h"
 #include "prob_build.h"
+#include <stdlib.h>
+
 #include "../../include/habitat_amd.h"
 
 namespace hab {
@@ -12,6 +15,13 @@ namespace hab {
 template <class P>
 static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream, int target_blocks = 1024) {
     constexpr bool WG = !P::A_RC && !P::B_RC && AKv<P>::value == 4;  // weight-gradient form
+    if constexpr (std::is_same_v<P, ConvFwdProb> || std::is_same_v<P, ConvDgradProb>) {
+        if (p.dma_ok() && p.M > 64 && getenv("HAB_NO_DMA") == nullptr) {  // LDS-DMA staged variant (igemm_dma.h)
+            if (p.N <= 32) return igemm_dma_launch<P, 2, 1, 4, 1, false>(p, ws, ws_floats, target_blocks, stream);
+            if (p.N <= 64) return igemm_dma_launch<P, 1, 2, 4, 1, false>(p, ws, ws_floats, target_blocks, stream);
+            if (p.N <= 128) return igemm_dma_launch<P, 2, 2, 2, 2, true>(p, ws, ws_floats, target_blocks, stream);
+        }
+    }
     if (p.N <= 32) {
         if (p.M <= 64) return igemm_launch<P, 1, 1, 2, 1>(p, ws, ws_floats, target_blocks, stream);
         if constexpr (WG) {

@@ -68,6 +68,10 @@ struct ConvGeom {
     }
 };
 
+// LDS-DMA staging (igemm_dma.h): block-uniform buffer window of an operand + the index it is relative to.
+struct DmaTile { const float* base; uint32_t records; int origin; };
+HAB_HD uint32_t dma_records(size_t bytes) { return bytes > 0x7fffffffull ? 0x7fffffffu : (uint32_t)bytes; }
+
 // A weight matrix row-major [rows][K] consumed as the r-contiguous B operand.
 struct WRowCtx { const float* row; int ok; };
 
@@ -134,6 +138,43 @@ struct ConvFwdProb {
         r.v = ld4(c.row + (q.k & -r.ok));
         return r;
     }
+    // ---- LDS-DMA interface (igemm_dma.h): C % 32 == 0 so a K-tile is 32 channels of ONE filter tap ----
+    HAB_HD bool dma_ok() const { return (g.C % 32 == 0) && (g.KH * g.KW <= 32) && ((size_t)g.H * g.W * g.C * 4 * 64 < 0x7fffffffull); }
+    HAB_HD DmaTile dma_a_tile(int m0) const {
+        DmaTile t;
+        t.origin = g.dHoWo.div(m0 < M ? m0 : M - 1);  // first image of the tile
+        const size_t shift = (size_t)g.pad * (g.W + 1) * g.C;  // so that padded coordinates are >= 0
+        t.base = x + (size_t)t.origin * g.H * g.W * g.C - shift;
+        t.records = dma_records(((size_t)(g.B - t.origin) * g.H * g.W * g.C + shift) * 4);
+        return t;
+    }
+    HAB_HD uint32_t dma_a_row(const DmaTile& t, int m, uint32_t& mask) const {
+        mask = 0;
+        if (m >= M) return 0;
+        int img, rem, ho, wo;
+        g.dHoWo.divmod(m, img, rem);
+        g.dWo.divmod(rem, ho, wo);
+        const int h0 = ho * g.stride - g.pad, w0 = wo * g.stride - g.pad;
+        for (int kh = 0; kh < g.KH; ++kh)
+            for (int kw = 0; kw < g.KW; ++kw)
+                if ((unsigned)(h0 + kh) < (unsigned)g.H && (unsigned)(w0 + kw) < (unsigned)g.W) mask |= 1u << (kh * g.KW + kw);
+        return (uint32_t)((((img - t.origin) * g.H + h0 + g.pad) * g.W + w0 + g.pad) * g.C) * 4u;
+    }
+    HAB_HD void dma_tap(int k0, int& tap, uint32_t& sa, uint32_t& sb) const {
+        int c0, kh, kw;
+        g.dC.divmod(k0, tap, c0);
+        g.dKW.divmod(tap, kh, kw);
+        sa = (uint32_t)((kh * g.W + kw) * g.C + c0) * 4u;
+        sb = (uint32_t)k0 * 4u;
+    }
+    HAB_HD DmaTile dma_b_tile(int n0) const {
+        DmaTile t;
+        t.origin = n0;
+        t.base = w + (size_t)n0 * K;
+        t.records = dma_records((size_t)(N - n0) * K * 4);
+        return t;
+    }
+    HAB_HD uint32_t dma_b_row(const DmaTile& t, int n, uint32_t& ok) const { ok = n < N; return (uint32_t)(n - t.origin) * (uint32_t)K * 4u; }
     HAB_PLAIN_CVT
     using EpiCol = ColN;
     using EpiRow = RowBase;
@@ -384,6 +425,45 @@ struct ConvDgradProb {
         r.v = ld4(c.row + (q.off & -r.ok));
         return r;
     }
+    // ---- LDS-DMA interface (igemm_dma.h): Cout % 32 == 0 so a K-tile is 32 output channels of ONE tap of the class ----
+    HAB_HD bool dma_ok() const {
+        return (g.Cout % 32 == 0) && (KHs * KWs <= 32) && (K % 32 == 0) && ((size_t)g.Ho * g.Wo * g.Cout * 4 * 64 < 0x7fffffffull);
+    }
+    HAB_HD DmaTile dma_a_tile(int m0) const {
+        DmaTile t;
+        t.origin = dHcWc.div(m0 < M ? m0 : M - 1);
+        const size_t shift = (size_t)((KHs - 1) * g.Wo + (KWs - 1)) * g.Cout;  // taps read at (hq - a, wq - b): shift so offsets are >= 0
+        t.base = dy + (size_t)t.origin * g.Ho * g.Wo * g.Cout - shift;
+        t.records = dma_records(((size_t)(g.B - t.origin) * g.Ho * g.Wo * g.Cout + shift) * 4);
+        return t;
+    }
+    HAB_HD uint32_t dma_a_row(const DmaTile& t, int m, uint32_t& mask) const {
+        mask = 0;
+        if (m >= M) return 0;
+        int img, rem, hc, wc;
+        dHcWc.divmod(m, img, rem);
+        dWc.divmod(rem, hc, wc);
+        const int hq = (h_first + hc * g.stride + g.pad - ph) / g.stride, wq = (w_first + wc * g.stride + g.pad - pw) / g.stride;
+        for (int a = 0; a < KHs; ++a)
+            for (int b = 0; b < KWs; ++b)
+                if ((unsigned)(hq - a) < (unsigned)g.Ho && (unsigned)(wq - b) < (unsigned)g.Wo) mask |= 1u << (a * KWs + b);
+        return (uint32_t)((((img - t.origin) * g.Ho + hq) * g.Wo + wq) * g.Cout) * 4u;
+    }
+    HAB_HD void dma_tap(int k0, int& tap, uint32_t& sa, uint32_t& sb) const {
+        int co0, a, b;
+        g.dCout.divmod(k0, tap, co0);
+        dKWs.divmod(tap, a, b);
+        sa = (uint32_t)(((KHs - 1 - a) * g.Wo + (KWs - 1 - b)) * g.Cout + co0) * 4u;
+        sb = (uint32_t)(((ph + g.stride * a) * g.KW + (pw + g.stride * b)) * g.Cout + co0) * 4u;
+    }
+    HAB_HD DmaTile dma_b_tile(int n0) const {
+        DmaTile t;
+        t.origin = n0;
+        t.base = w + (size_t)n0 * Kfull;
+        t.records = dma_records((size_t)(N - n0) * Kfull * 4);
+        return t;
+    }
+    HAB_HD uint32_t dma_b_row(const DmaTile& t, int n, uint32_t& ok) const { ok = n < N; return (uint32_t)(n - t.origin) * (uint32_t)Kfull * 4u; }
     HAB_PLAIN_CVT
     struct EpiCol { int n, ok; };
     using EpiRow = RowBase;
