@@ -2,6 +2,7 @@
 // plus the small HBM-bound helpers around them (weight repack, column sums for bias gradients).
 #include "igemm.h"
 #include "igemm_dma.h"
+#include "igemm_dma_wgrad.h"
 #include "prob_build.h"
 #include <stdlib.h>
 
@@ -83,6 +84,17 @@ int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oih
                hipStream_t stream) {
     ConvWgradProb p;
     HAB_TRY(build(p, d, x, dy, dw_oihw, dbias));
+    // LDS-DMA staged variant (igemm_dma_wgrad.h): measured faster only for unpadded convolutions with Cout <= 32 (SimpleCNN conv3:
+    // 51 -> 64 TFLOP/s); with padding the per-pixel scalar decode + border tests cost more than the VGPR staging they replace.
+    if (ws && d.pad == 0 && p.N <= 32 && getenv("HAB_NO_DMA") == nullptr) {
+        ConvWgradProb q = p;
+        q.colsum = nullptr;  // the DMA path never sees dY in registers: the bias gradient is a separate column sum
+        if (wgrad_dma_ok(q)) {
+            if (dbias) HAB_TRY(colsum(dy, p.N, p.K, p.N, dbias, 0, ws, ws_floats, stream));
+            if ((q.M % 288 == 0) || (cdiv(q.M, 288) * 288 < cdiv(q.M, 256) * 256)) return igemm_dma_wgrad_launch<3, 3, 1>(q, ws, ws_floats, 1024, stream);
+            return igemm_dma_wgrad_launch<2, 4, 1>(q, ws, ws_floats, 1024, stream);
+        }
+    }
     return run_igemm(p, ws, ws_floats, stream);
 }
 int obs_conv_wgrad(const ConvDesc& d, const ObsView& obs, const float* dy, float* dw_oihw, float* dbias, float* ws,
