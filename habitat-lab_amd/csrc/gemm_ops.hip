@@ -3,6 +3,7 @@
 #include "igemm.h"
 #include "igemm_dma.h"
 #include "igemm_dma_wgrad.h"
+#include "wgrad3x3_patch.h"
 #include "prob_build.h"
 #include <stdlib.h>
 
@@ -84,6 +85,12 @@ int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oih
                hipStream_t stream) {
     ConvWgradProb p;
     HAB_TRY(build(p, d, x, dy, dw_oihw, dbias));
+    if (ws && wgrad3x3_patch_ok(p) && getenv("HAB_NO_PATCH") == nullptr) {  // 3x3/1/1 with W in {16, 32}: patch-resident kernel
+        ConvWgradProb q = p;
+        q.colsum = nullptr;
+        if (dbias) HAB_TRY(colsum(dy, p.N, p.K, p.N, dbias, 0, ws, ws_floats, stream));
+        return wgrad3x3_patch(q, ws, ws_floats, stream);
+    }
     // LDS-DMA staged variant (igemm_dma_wgrad.h): measured faster only for unpadded convolutions with Cout <= 32 (SimpleCNN conv3:
     // 51 -> 64 TFLOP/s); with padding the per-pixel scalar decode + border tests cost more than the VGPR staging they replace.
     if (ws && d.pad == 0 && p.N <= 32 && getenv("HAB_NO_DMA") == nullptr) {
