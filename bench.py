@@ -177,6 +177,7 @@ def main():
     tag, flops_per_frame = PROBES[a.probe]
     eng.probe_enable(tag)
     barrier()
+    steps_before, local_before = trainer.num_steps_done, getattr(trainer, "local_steps_done", 0)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         trainer.run_update_cycle()
@@ -192,10 +193,14 @@ def main():
         return
     ppo = cfg.habitat_baselines.rl.ppo
     n_envs, n_steps = WORKLOADS[a.workload].get("envs", NUM_ENVS), WORKLOADS[a.workload].get("steps", NUM_STEPS)
-    steps_total = world * n_envs * n_steps * a.steps
+    # env-steps actually collected over all ranks (the trainer's all-reduced counter): equals world * n_envs * n_steps * K unless
+    # DD-PPO's preemptive straggler rule cut a rollout short (ppo_trainer.py:641-653), in which case only the collected steps count
+    steps_total = trainer.num_steps_done - steps_before
+    assert 0 < steps_total <= world * n_envs * n_steps * a.steps
     # frames seen by the probed call site during the timed region
-    upd_frames = n_envs * n_steps * ppo.ppo_epoch * a.steps
-    roll_frames = n_envs * (n_steps + 1) * a.steps
+    local_steps = trainer.local_steps_done - local_before
+    upd_frames = local_steps * ppo.ppo_epoch
+    roll_frames = local_steps + n_envs * a.steps
     frames = upd_frames + (roll_frames if a.probe.endswith("_fwd") else 0)
     kname = f"igemm_kernel<{a.probe}>" if not a.probe.startswith("enc_") else f"resnet encoder {a.probe[4:]} (all kernels)"
     ach = flops_per_frame * frames / (probe_ms * 1e-3) / 1e12 if probe_ms > 0 else None

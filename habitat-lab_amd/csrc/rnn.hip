@@ -12,7 +12,7 @@
 //      latency-bound, not bandwidth-bound.
 //   3. outputs are written straight in frame order (the inverse permutation of
 //      build_rnn_out_from_seq is free), the hidden state entering every step is kept for BPTT.
-// BPTT runs the steps in reverse (gate-gradient kernel + transposed mat-vec kernel per step) and
+// BPTT runs the steps in reverse (one launch per step: transposed mat-vec of step s+1 fused with the gate gradients of step s) and
 // finishes with three contractions over all frames (dW_ih, dW_hh, dX) and two column sums.
 #include "ops.h"
 #include "../../include/habitat_amd.h"
@@ -55,17 +55,20 @@ struct StepArgs {
     float* c_out; int c_out_stride;                            // LSTM c' (inference path); training uses `c`
 };
 
-// One workgroup = 16 rows x 16 hidden units x G gates; 4 waves split K = H.
-template <int G>
-__global__ void __launch_bounds__(256) rnn_step_kernel(const StepArgs a) {
-    __shared__ float red[4][G][256];
+// One workgroup = 16 rows x 16 hidden units x G gates; NW waves split K = H.  The recurrence is latency-bound (a step is a
+// few MFLOP): each wave issues its loads in batches of U K-chunks before the dependent MFMAs, so a step costs ~1-2 L2 round
+// trips instead of one per chunk.
+template <int G, int NW>
+__global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
+    __shared__ float red[NW][G][256];
+    constexpr int U = 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
     const int i = lane & 15, kg = lane >> 4;
     const int H = a.H;
     const int q = min(row0 + i, a.R - 1);
     const float* hrow = a.hp_base + (size_t)(a.hp_idx ? a.hp_idx[q] : q) * a.hp_stride;
-    const int kq = H / 4;  // per-wave K range
+    const int kq = H / NW;  // per-wave K range (multiple of 16)
     const int kb = wave * kq;
     f32x4 acc[G];
 #pragma unroll
@@ -73,7 +76,24 @@ __global__ void __launch_bounds__(256) rnn_step_kernel(const StepArgs a) {
     const float* wrow[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) wrow[g] = a.w_hh + (size_t)(g * H + u0 + i) * H;
-    for (int c = 0; c < kq; c += 16) {
+    int c = 0;
+    for (; c + 16 * U <= kq; c += 16 * U) {
+        f32x4 av[U], bv[U][G];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int k = kb + c + 16 * j + 4 * kg;
+            av[j] = *reinterpret_cast<const f32x4*>(hrow + k);
+#pragma unroll
+            for (int g = 0; g < G; ++g) bv[j][g] = *reinterpret_cast<const f32x4*>(wrow[g] + k);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][s], bv[j][g][s], acc[g], 0, 0, 0);
+    }
+    for (; c < kq; c += 16) {
         const int k = kb + c + 4 * kg;
         const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + k);
         f32x4 bv[G];
@@ -90,13 +110,18 @@ __global__ void __launch_bounds__(256) rnn_step_kernel(const StepArgs a) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) red[wave][g][(kg * 4 + v) * 16 + i] = acc[g][v];
     __syncthreads();
+    if (t >= 256) return;
     const int r = t >> 4, u = t & 15;  // one (row, unit) per thread
     const int qq = row0 + r;
     if (qq >= a.R) return;
     float gh[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-        gh[g] = ((red[0][g][t] + red[1][g][t]) + (red[2][g][t] + red[3][g][t])) + a.b_hh[g * H + u0 + u];
+    for (int g = 0; g < G; ++g) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4) sum += (red[w][g][t] + red[w + 1][g][t]) + (red[w + 2][g][t] + red[w + 3][g][t]);
+        gh[g] = sum + a.b_hh[g * H + u0 + u];
+    }
     const int f = a.out_idx ? a.out_idx[qq] : qq;
     const int uu = u0 + u;
     const float hp = a.hp_base[(size_t)(a.hp_idx ? a.hp_idx[qq] : qq) * a.hp_stride + uu];
@@ -137,10 +162,14 @@ static int launch_step(int rnn_type, const StepArgs& a, hipStream_t stream) {
     if (a.R <= 0) return HAB_OK;
     if (a.H % 64) return HAB_ERR_UNSUPPORTED;
     dim3 grid(cdiv(a.R, 16), a.H / 16);
-    if (rnn_type == RNN_GRU)
-        rnn_step_kernel<3><<<grid, 256, 0, stream>>>(a);
-    else
-        rnn_step_kernel<4><<<grid, 256, 0, stream>>>(a);
+    const bool wide = a.H % 128 == 0;  // 8 waves need H / 8 to be a multiple of the 16-wide K chunk
+    if (rnn_type == RNN_GRU) {
+        if (wide) rnn_step_kernel<3, 8><<<grid, 512, 0, stream>>>(a);
+        else rnn_step_kernel<3, 4><<<grid, 256, 0, stream>>>(a);
+    } else {
+        if (wide) rnn_step_kernel<4, 8><<<grid, 512, 0, stream>>>(a);
+        else rnn_step_kernel<4, 4><<<grid, 256, 0, stream>>>(a);
+    }
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -186,94 +215,110 @@ int rnn_step_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const 
 }
 
 // ------------------------------------------- BPTT ---------------------------------------------
-struct BwdGateArgs {
-    int R, H, R_next;
-    const int* idx;        // row q -> frame
+// One launch per packed step s (walking backwards): workgroup (row tile, 16-unit tile)
+//   A. carry tile = dgh[frames of step s+1] * W_hh   (rows < R_next; K = G*H split over NW waves, reduced in LDS)
+//      -- the transposed mat-vec of step s+1, which only this step's gate math consumes;
+//   B. gate math of step s for the same (row, unit) elements: dh = dout + carry + direct term, then the pre-activation
+//      gradients dgi / dgh of all G gates of that unit, and the direct term / cell carry for step s-1.
+// Row q is the same fragment at every step (fragments are sorted by length), so a (row, unit) element is owned by the same
+// thread of the same workgroup in consecutive launches: the direct/cell carries are private read-modify-write.
+struct BwdStepArgs {
+    int R, H, K, R_next;
+    const int* idx;        // row q -> frame at step s
+    const int* idx_next;   // row q -> frame at step s+1
     const float* dout;     // [frames][H] gradient wrt the layer output
-    const float* dh_carry; // [F][H] from step s+1 (rows < R_next valid)
+    const float* w_hh_t;   // [H][K]
+    float* dh_direct;      // [F][H] in: direct part of dh from step s+1 (GRU dh*z); out: the same for step s-1
     float* dc_carry;       // LSTM [F][H] in/out
     const float* gates; const float* hn; const float* hprev; const float* cprev; const float* c;
-    float* dgi; float* dgh;  // [frames][G*H]
-    float* dh_direct;        // [F][H]: part of dh_prev that does not go through W_hh (GRU: dh*z ; LSTM: 0)
+    float* dgi; float* dgh;  // [frames][K]; LSTM: dgh == dgi
 };
 
-template <int G>
-__global__ void __launch_bounds__(256) rnn_bwd_gate_kernel(const BwdGateArgs a) {
+template <int G, int NW>
+__global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs a) {
+    __shared__ float red[NW][256];
+    constexpr int U = 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
     const int H = a.H;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (size_t)a.R * H) return;
-    const int q = (int)(e / H), u = (int)(e % H);
+    const bool has_carry = row0 < a.R_next;  // workgroup-uniform
+    if (has_carry) {
+        const int i = lane & 15, kg = lane >> 4;
+        const int q = min(row0 + i, a.R_next - 1);
+        const float* arow = a.dgh + (size_t)a.idx_next[q] * a.K;
+        const float* brow = a.w_hh_t + (size_t)(u0 + i) * a.K;
+        const int kq = a.K / NW, kb = wave * kq;
+        f32x4 acc;
+        acc[0] = 0.f; acc[1] = 0.f; acc[2] = 0.f; acc[3] = 0.f;
+        int c = 0;
+        for (; c + 16 * U <= kq; c += 16 * U) {
+            f32x4 av[U], bv[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int k = kb + c + 16 * j + 4 * kg;
+                av[j] = *reinterpret_cast<const f32x4*>(arow + k);
+                bv[j] = *reinterpret_cast<const f32x4*>(brow + k);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][s], bv[j][s], acc, 0, 0, 0);
+        }
+        for (; c < kq; c += 16) {
+            const int k = kb + c + 4 * kg;
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + k);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + k);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[wave][(kg * 4 + v) * 16 + i] = acc[v];
+        __syncthreads();
+    }
+    if (t >= 256) return;
+    const int r = t >> 4, uu = u0 + (t & 15), q = row0 + r;
+    if (q >= a.R) return;
     const int f = a.idx[q];
-    float dh = a.dout[(size_t)f * H + u];
-    if (q < a.R_next) dh += a.dh_carry[(size_t)q * H + u];
+    const size_t qo = (size_t)q * H + uu, fo = (size_t)f * H + uu;
+    float dh = a.dout[fo];
+    if (q < a.R_next) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4) sum += (red[w][t] + red[w + 1][t]) + (red[w + 2][t] + red[w + 3][t]);
+        dh += sum;
+        if constexpr (G == 3) dh += a.dh_direct[qo];
+    }
     if constexpr (G == 3) {
         const float* gs = a.gates + (size_t)f * 3 * H;
-        const float r = gs[u], z = gs[H + u], n = gs[2 * H + u];
-        const float hp = a.hprev[(size_t)f * H + u], hn = a.hn[(size_t)f * H + u];
+        const float rg = gs[uu], z = gs[H + uu], n = gs[2 * H + uu];
+        const float hp = a.hprev[fo], hn = a.hn[fo];
         const float dn = dh * (1.0f - z);
         const float dz = dh * (hp - n);
         const float dn_pre = dn * (1.0f - n * n);
         const float dr = dn_pre * hn;
-        const float dr_pre = dr * r * (1.0f - r);
+        const float dr_pre = dr * rg * (1.0f - rg);
         const float dz_pre = dz * z * (1.0f - z);
         float* gi = a.dgi + (size_t)f * 3 * H;
         float* gh = a.dgh + (size_t)f * 3 * H;
-        gi[u] = dr_pre; gi[H + u] = dz_pre; gi[2 * H + u] = dn_pre;
-        gh[u] = dr_pre; gh[H + u] = dz_pre; gh[2 * H + u] = dn_pre * r;
-        a.dh_direct[(size_t)q * H + u] = dh * z;
+        gi[uu] = dr_pre; gi[H + uu] = dz_pre; gi[2 * H + uu] = dn_pre;
+        gh[uu] = dr_pre; gh[H + uu] = dz_pre; gh[2 * H + uu] = dn_pre * rg;
+        a.dh_direct[qo] = dh * z;
     } else {
         const float* gs = a.gates + (size_t)f * 4 * H;
-        const float ig = gs[u], fg = gs[H + u], gg = gs[2 * H + u], og = gs[3 * H + u];
-        const float cn = a.c[(size_t)f * H + u], cp = a.cprev[(size_t)f * H + u];
+        const float ig = gs[uu], fg = gs[H + uu], gg = gs[2 * H + uu], og = gs[3 * H + uu];
+        const float cn = a.c[fo], cp = a.cprev[fo];
         const float tc = tanhf(cn);
         float dc = dh * og * (1.0f - tc * tc);
-        if (q < a.R_next) dc += a.dc_carry[(size_t)q * H + u];
+        if (q < a.R_next) dc += a.dc_carry[qo];
         const float d_o = dh * tc;
         const float di = dc * gg, dg = dc * ig, df = dc * cp;
         float* gi = a.dgi + (size_t)f * 4 * H;
-        gi[u] = di * ig * (1.0f - ig);
-        gi[H + u] = df * fg * (1.0f - fg);
-        gi[2 * H + u] = dg * (1.0f - gg * gg);
-        gi[3 * H + u] = d_o * og * (1.0f - og);
-        a.dc_carry[(size_t)q * H + u] = dc * fg;
-        a.dh_direct[(size_t)q * H + u] = 0.f;
+        gi[uu] = di * ig * (1.0f - ig);
+        gi[H + uu] = df * fg * (1.0f - fg);
+        gi[2 * H + uu] = dg * (1.0f - gg * gg);
+        gi[3 * H + uu] = d_o * og * (1.0f - og);
+        a.dc_carry[qo] = dc * fg;
     }
-}
-
-// dh_carry[q][u] = dh_direct[q][u] + sum_k dgh[frame(q)][k] * W_hh[k][u]   (k over G*H), via W_hh^T [H][G*H].
-struct BwdMatArgs {
-    int R, H, K;  // K = G*H
-    const int* idx;
-    const float* dgh;     // [frames][K]
-    const float* w_hh_t;  // [H][K]
-    const float* dh_direct;
-    float* dh_carry;
-};
-__global__ void __launch_bounds__(256) rnn_bwd_mat_kernel(const BwdMatArgs a) {
-    __shared__ float red[4][256];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int row0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
-    const int i = lane & 15, kg = lane >> 4;
-    const int q = min(row0 + i, a.R - 1);
-    const float* arow = a.dgh + (size_t)a.idx[q] * a.K;
-    const float* brow = a.w_hh_t + (size_t)(u0 + i) * a.K;
-    const int kq = a.K / 4, kb = wave * kq;
-    f32x4 acc;
-    acc[0] = 0.f; acc[1] = 0.f; acc[2] = 0.f; acc[3] = 0.f;
-    for (int c = 0; c < kq; c += 16) {
-        const int k = kb + c + 4 * kg;
-        const f32x4 av = *reinterpret_cast<const f32x4*>(arow + k);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + k);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) red[wave][(kg * 4 + v) * 16 + i] = acc[v];
-    __syncthreads();
-    const int r = t >> 4, u = t & 15, qq = row0 + r;
-    if (qq >= a.R) return;
-    const size_t o = (size_t)qq * a.H + u0 + u;
-    a.dh_carry[o] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + a.dh_direct[o];
 }
 
 int rnn_seq_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx,
@@ -281,31 +326,29 @@ int rnn_seq_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const 
                            const PackInfo& pk, float* scratch /* 3*F*H floats */, float* ws, size_t ws_floats, hipStream_t stream) {
     const int G = rnn_type == RNN_GRU ? 3 : 4;
     if (H % 64) return HAB_ERR_UNSUPPORTED;
-    float* dh_carry = scratch;
-    float* dh_direct = scratch + (size_t)pk.F * H;
-    float* dc_carry = scratch + 2 * (size_t)pk.F * H;
+    float* dh_direct = scratch;
+    float* dc_carry = scratch + (size_t)pk.F * H;
     float* dgh = (rnn_type == RNN_GRU) ? wk.dgh : wk.dgi;
+    const int K = G * H;
+    const bool wide = K % 128 == 0;  // 8 waves need K / 8 to be a multiple of the 16-wide K chunk
     for (int s = pk.max_len - 1; s >= 0; --s) {
-        const int R = pk.num_seqs_at_step[s];
-        BwdGateArgs g;
-        g.R = R; g.H = H; g.R_next = (s + 1 < pk.max_len) ? pk.num_seqs_at_step[s + 1] : 0;
+        BwdStepArgs g;
+        g.R = pk.num_seqs_at_step[s]; g.H = H; g.K = K;
+        g.R_next = (s + 1 < pk.max_len) ? pk.num_seqs_at_step[s + 1] : 0;
         g.idx = pk.select_inds + pk.step_offsets[s];
-        g.dout = dout; g.dh_carry = dh_carry; g.dc_carry = dc_carry;
+        g.idx_next = g.R_next ? pk.select_inds + pk.step_offsets[s + 1] : g.idx;
+        g.dout = dout; g.w_hh_t = lp.w_hh_t; g.dh_direct = dh_direct; g.dc_carry = dc_carry;
         g.gates = wk.gates; g.hn = wk.hn; g.hprev = wk.hprev; g.cprev = wk.cprev; g.c = wk.c;
-        g.dgi = wk.dgi; g.dgh = wk.dgh; g.dh_direct = dh_direct;
-        const int blocks = (int)cdivl((long long)R * H, 256);
-        if (rnn_type == RNN_GRU)
-            rnn_bwd_gate_kernel<3><<<blocks, 256, 0, stream>>>(g);
-        else
-            rnn_bwd_gate_kernel<4><<<blocks, 256, 0, stream>>>(g);
-        HAB_LAUNCH_CHECK();
-        if (s > 0) {
-            BwdMatArgs m;
-            m.R = R; m.H = H; m.K = G * H; m.idx = g.idx; m.dgh = dgh; m.w_hh_t = lp.w_hh_t; m.dh_direct = dh_direct;
-            m.dh_carry = dh_carry;
-            rnn_bwd_mat_kernel<<<dim3(cdiv(R, 16), H / 16), 256, 0, stream>>>(m);
-            HAB_LAUNCH_CHECK();
+        g.dgi = wk.dgi; g.dgh = dgh;
+        const dim3 grid(cdiv(g.R, 16), H / 16);
+        if (rnn_type == RNN_GRU) {
+            if (wide) rnn_bwd_step_kernel<3, 8><<<grid, 512, 0, stream>>>(g);
+            else rnn_bwd_step_kernel<3, 4><<<grid, 256, 0, stream>>>(g);
+        } else {
+            if (wide) rnn_bwd_step_kernel<4, 8><<<grid, 512, 0, stream>>>(g);
+            else rnn_bwd_step_kernel<4, 4><<<grid, 256, 0, stream>>>(g);
         }
+        HAB_LAUNCH_CHECK();
     }
     // parameter gradients over all frames
     HAB_TRY(linear_wgrad(wk.dgi, G * H, x, ldx, lp.dw_ih, lp.in_dim, pk.P, G * H, lp.in_dim, 0, 0, 0, ws, ws_floats, stream));

@@ -345,6 +345,7 @@ class PPOTrainer(BaseRLTrainer):
         self._agent.pre_rollout()
         self._agent.eval()
         count_steps_delta = self.collect_rollout()
+        self.local_steps_done = getattr(self, "local_steps_done", 0) + count_steps_delta  # this rank only (num_steps_done is global)
         if self._is_distributed:
             self.num_rollouts_done_store.add("num_done", 1)
         losses = self._update_agent()
