@@ -55,6 +55,70 @@ struct AKv : std::integral_constant<int, 4> {};
 template <class P>
 struct AKv<P, std::void_t<decltype(P::A_KV)>> : std::integral_constant<int, P::A_KV> {};
 
+// Vector epilogue.  A problem whose output is n-contiguous (NHWC activations / activation gradients) opts in with
+// `static constexpr bool EPI_VEC4 = true` and epi_col4 / epi_fetch4 / epi_store4.  The kernels then issue the MFMAs with the
+// operands swapped, which transposes the accumulator: lane l holds output row m = l & 31 and the FOUR CONSECUTIVE columns
+// n = 8*(v >> 2) + 4*(l >> 5) + (v & 3) per register quad, so the epilogue is one 16-byte load per optional operand and one
+// 16-byte store per quad (4 per 32x32 tile and lane instead of 16 scalar ones) and one row decode per tile instead of 16.
+// fp32 MFMA shares the issue port with everything else on the SIMD, so epilogue instructions are MFMA time lost.
+template <class P, class = void>
+struct EpiV4 : std::false_type {};
+template <class P>
+struct EpiV4<P, std::void_t<decltype(P::EPI_VEC4)>> : std::bool_constant<P::EPI_VEC4> {};
+
+template <class P, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue_v4(const P& p, const f32x16 (&acc)[TM][TN], int mbase, int nbase, int li, int hi) {
+    typename P::EpiCol4 ecol[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ecol[j][g] = p.epi_col4(nbase + j * 32 + 8 * g + 4 * hi);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const typename P::EpiRow erow = p.epi_row(mbase + i * 32 + li);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            typename P::EpiAux4 aux[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) aux[g] = p.epi_fetch4(erow, ecol[j][g]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+                v[0] = acc[i][j][4 * g]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+                p.epi_store4(erow, ecol[j][g], aux[g], v);
+            }
+        }
+    }
+}
+
+// split-K slab write of the transposed accumulator
+template <class P, int TM, int TN>
+__device__ __forceinline__ void igemm_partial_v4(const P& p, const f32x16 (&acc)[TM][TN], float* __restrict__ slab, int mbase, int nbase,
+                                                 int li, int hi) {
+    const bool vec = ((p.N & 3) == 0) && ((reinterpret_cast<uintptr_t>(slab) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = mbase + i * 32 + li;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = nbase + j * 32 + 8 * g + 4 * hi;
+                float* dst = slab + (size_t)row * p.N + col;
+                if (vec && col + 3 < p.N) {
+                    f32x4 v;
+                    v[0] = acc[i][j][4 * g]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < p.N) dst[e] = acc[i][j][4 * g + e];
+                }
+            }
+    }
+}
+
 template <class P, int TM, int TN, int WM, int WN>
 struct IgemmCfg {
     static constexpr int NT = WM * WN * 64;
@@ -225,7 +289,10 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        if constexpr (EpiV4<P>::value)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -247,6 +314,13 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
                     p.store_colsum(n0 + t, s);
             }
         }
+    }
+    if constexpr (EpiV4<P>::value) {
+        if (split)
+            igemm_partial_v4<P, TM, TN>(p, acc, partial + (size_t)kz * MP * p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, hi);
+        else
+            igemm_epilogue_v4<P, TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, li, hi);
+        return;
     }
     if (split) {
 #pragma unroll

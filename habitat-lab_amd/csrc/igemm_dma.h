@@ -145,7 +145,10 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_dma_kernel(const P p, const
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        if constexpr (EpiV4<P>::value)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][s], af[i][s], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
     };
     if constexpr (!DB) {
@@ -174,6 +177,13 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_dma_kernel(const P p, const
     }
 
     // ---- epilogue (as igemm_kernel) ----
+    if constexpr (EpiV4<P>::value) {
+        if (gridDim.z > 1)
+            igemm_partial_v4<P, TM, TN>(p, acc, partial + (size_t)kz * p.M * p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, hi);
+        else
+            igemm_epilogue_v4<P, TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, li, hi);
+        return;
+    }
     if (gridDim.z > 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)

@@ -78,6 +78,36 @@ struct WRowCtx { const float* row; int ok; };
 // Epilogue pieces shared by the NHWC-output problems.
 struct ColN { int n, ok; float bias; };
 struct RowBase { size_t base; int ok; };
+// Vector epilogue (igemm.h EpiV4): four consecutive columns n .. n+3, n % 4 == 0.  `ok` = all four exist and the output row
+// stride keeps them 16-byte aligned; `tail` = a partial quad (N % 4 != 0), handled element-wise.
+struct ColN4 { int n, ok, tail; f32x4 bias; };
+struct AddMask4 { f32x4 add, mask; };
+HAB_HD f32x4 splat4(float x) { f32x4 z; z[0] = x; z[1] = x; z[2] = x; z[3] = x; return z; }
+#define HAB_BIAS_RELU_VEC4                                                                                        \
+    static constexpr bool EPI_VEC4 = true;                                                                       \
+    using EpiCol4 = ColN4;                                                                                       \
+    using EpiAux4 = NoAux;                                                                                       \
+    HAB_HD EpiCol4 epi_col4(int n) const {                                                                       \
+        EpiCol4 c;                                                                                               \
+        c.n = n; c.ok = ((N & 3) == 0) & (n + 3 < N); c.tail = (n < N) & !c.ok;                                  \
+        c.bias = zero4();                                                                                        \
+        if (bias && c.ok) { c.bias[0] = bias[n]; c.bias[1] = bias[n + 1]; c.bias[2] = bias[n + 2]; c.bias[3] = bias[n + 3]; } \
+        return c;                                                                                                \
+    }                                                                                                            \
+    HAB_HD EpiAux4 epi_fetch4(const EpiRow&, const EpiCol4&) const { return EpiAux4(); }                         \
+    HAB_HD void epi_store4(const EpiRow& r, const EpiCol4& c, const EpiAux4&, f32x4 v) const {                   \
+        if (!r.ok) return;                                                                                       \
+        if (c.ok) {                                                                                              \
+            v += c.bias;                                                                                         \
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); } \
+            *reinterpret_cast<f32x4*>(y + r.base + c.n) = v;                                                     \
+        } else if (c.tail) {                                                                                     \
+            for (int e = 0; e < 4; ++e) {                                                                        \
+                const EpiCol ce = epi_col(c.n + e);                                                              \
+                epi_store(r, ce, epi_fetch(r, ce), v[e]);                                                        \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
 
 // ----------------------------------------------------------------------------------------------
 // Convolution forward: Y[(img,ho,wo)][co] = sum_{kh,kw,ci} X[img, ho*s-p+kh, wo*s-p+kw, ci] * Wf[co][(kh,kw,ci)]
@@ -188,6 +218,7 @@ struct ConvFwdProb {
         if (relu) v = v > 0.f ? v : 0.f;
         y[r.base + c.n] = v;
     }
+    HAB_BIAS_RELU_VEC4
     HAB_GENERIC_STORE
 };
 
@@ -335,6 +366,7 @@ struct ObsConvFwdProb {
         if (relu) v = v > 0.f ? v : 0.f;
         y[r.base + c.n] = v;
     }
+    HAB_BIAS_RELU_VEC4
     HAB_GENERIC_STORE
 };
 
@@ -490,6 +522,167 @@ struct ConvDgradProb {
         v += a.add;
         if (!(a.mask > 0.f)) v = 0.f;
         dx[r.base + c.n] = v;
+    }
+    static constexpr bool EPI_VEC4 = true;
+    struct EpiCol4 { int n, ok, tail; };
+    using EpiAux4 = AddMask4;
+    HAB_HD EpiCol4 epi_col4(int n) const { EpiCol4 c; c.n = n; c.ok = ((N & 3) == 0) & (n + 3 < N); c.tail = (n < N) & !c.ok; return c; }
+    HAB_HD EpiAux4 epi_fetch4(const EpiRow& r, const EpiCol4& c) const {
+        EpiAux4 a;
+        const size_t i = (r.ok & c.ok) ? r.base + c.n : 0;
+        a.add = add ? ld4(add + i) : zero4();
+        a.mask = mask ? ld4(mask + i) : splat4(1.f);
+        return a;
+    }
+    HAB_HD void epi_store4(const EpiRow& r, const EpiCol4& c, const EpiAux4& a, f32x4 v) const {
+        if (!r.ok) return;
+        if (c.ok) {
+            v += a.add;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!(a.mask[e] > 0.f)) v[e] = 0.f;
+            *reinterpret_cast<f32x4*>(dx + r.base + c.n) = v;
+        } else if (c.tail) {
+            for (int e = 0; e < 4; ++e) {
+                const EpiCol ce = epi_col(c.n + e);
+                epi_store(r, ce, epi_fetch(r, ce), v[e]);
+            }
+        }
+    }
+    HAB_GENERIC_STORE
+};
+
+// ----------------------------------------------------------------------------------------------
+// Data gradient with the stride classes MERGED into one contraction, for kernels whose size is a multiple of the stride
+// (SimpleCNN conv2: 4x4 / 2).  Then every class (ph, pw) has the same KH/s x KW/s taps and the s*s pixels
+// h = hq*s - pad + ph, w = wq*s - pad + pw of one quotient position (hq, wq) read the SAME dY neighbourhood
+// (hq - a, wq - b): the s*s class problems are one GEMM with
+//     rows    m = (img, hq, wq)            M = B * Hq * Wq,  Hq = (H - 1 + pad) / s + 1
+//     columns n = (ph, pw, ci)             N = s * s * Cin
+//     red.    k = (a, b, co)               K = (KH/s) * (KW/s) * Cout
+// i.e. a stride-1 convolution of dY followed by a depth-to-space scatter in the epilogue.  The dY gather is shared by the
+// s*s classes (4x less A traffic and LDS fill than the per-class launches) and the tile is 128 columns wide instead of 32.
+// LDS-DMA interface only (igemm_dma.h); conv_dgrad falls back to the per-class problems when dma_ok() is false.
+// ----------------------------------------------------------------------------------------------
+struct ConvDgradMergedProb {
+    int M, N, K;
+    ConvGeom g;
+    int Hq, Wq, KHs, KWs, Kfull;
+    FastDiv dHqWq, dWq, dKWs;
+    const float* dy;
+    const float* w;     // Wd packed [Cin][Kfull = KH*KW*Cout]
+    const float* mask;  // same shape as dx, or null: dx *= (mask > 0)
+    const float* add;   // same shape as dx, or null: dx += add   (applied before the mask)
+    float* dx;
+    static bool applicable(const ConvGeom& g) {
+        return g.stride > 1 && g.KH % g.stride == 0 && g.KW % g.stride == 0 && g.Cout % 32 == 0 && g.C % 8 == 0 &&
+               g.stride * g.stride * g.C <= 128;
+    }
+    void finish() {
+        const int s = g.stride;
+        Hq = (g.H - 1 + g.pad) / s + 1; Wq = (g.W - 1 + g.pad) / s + 1;
+        KHs = g.KH / s; KWs = g.KW / s;
+        Kfull = g.KH * g.KW * g.Cout;
+        M = g.B * Hq * Wq; N = s * s * g.C; K = KHs * KWs * g.Cout;
+        dHqWq = FastDiv(Hq * Wq); dWq = FastDiv(Wq); dKWs = FastDiv(KWs);
+    }
+    HAB_HD bool dma_ok() const { return (KHs * KWs <= 32) && ((size_t)g.Ho * g.Wo * g.Cout * 4 * 64 < 0x7fffffffull); }
+    HAB_HD DmaTile dma_a_tile(int m0) const {
+        DmaTile t;
+        t.origin = dHqWq.div(m0 < M ? m0 : M - 1);
+        const size_t shift = (size_t)((KHs - 1) * g.Wo + (KWs - 1)) * g.Cout;  // taps read at (hq - a, wq - b): shift so offsets are >= 0
+        t.base = dy + (size_t)t.origin * g.Ho * g.Wo * g.Cout - shift;
+        t.records = dma_records(((size_t)(g.B - t.origin) * g.Ho * g.Wo * g.Cout + shift) * 4);
+        return t;
+    }
+    HAB_HD uint32_t dma_a_row(const DmaTile& t, int m, uint32_t& mask_) const {
+        mask_ = 0;
+        if (m >= M) return 0;
+        int img, rem, hq, wq;
+        dHqWq.divmod(m, img, rem);
+        dWq.divmod(rem, hq, wq);
+        for (int a = 0; a < KHs; ++a)
+            for (int b = 0; b < KWs; ++b)
+                if ((unsigned)(hq - a) < (unsigned)g.Ho && (unsigned)(wq - b) < (unsigned)g.Wo) mask_ |= 1u << (a * KWs + b);
+        return (uint32_t)((((img - t.origin) * g.Ho + hq) * g.Wo + wq) * g.Cout) * 4u;
+    }
+    HAB_HD void dma_tap(int k0, int& tap, uint32_t& sa, uint32_t& sb) const {
+        int co0, a, b;
+        g.dCout.divmod(k0, tap, co0);
+        dKWs.divmod(tap, a, b);
+        sa = (uint32_t)(((KHs - 1 - a) * g.Wo + (KWs - 1 - b)) * g.Cout + co0) * 4u;
+        sb = (uint32_t)((g.stride * a * g.KW + g.stride * b) * g.Cout + co0) * 4u;
+    }
+    HAB_HD DmaTile dma_b_tile(int) const {
+        DmaTile t;
+        t.origin = 0;
+        t.base = w;
+        t.records = dma_records((size_t)g.C * Kfull * 4);
+        return t;
+    }
+    HAB_HD uint32_t dma_b_row(const DmaTile&, int n, uint32_t& ok) const {
+        ok = n < N;
+        int pp, ci;
+        g.dC.divmod(ok ? n : 0, pp, ci);
+        const int ph = pp / g.stride, pw = pp - ph * g.stride;
+        return (uint32_t)(ci * Kfull + (ph * g.KW + pw) * g.Cout) * 4u;
+    }
+    struct EpiCol { int off, ph, pw, ok; };        // off = (ph*W + pw)*Cin + ci
+    struct EpiRow { long long base; int hb, wb, ok; };  // hb = hq*s - pad, base = ((img*H + hb)*W + wb)*Cin
+    struct EpiAux { float add, mask; };
+    HAB_HD EpiCol epi_col(int n) const {
+        EpiCol c;
+        c.ok = n < N;
+        int pp, ci;
+        g.dC.divmod(c.ok ? n : 0, pp, ci);
+        c.ph = pp / g.stride; c.pw = pp - c.ph * g.stride;
+        c.off = (c.ph * g.W + c.pw) * g.C + ci;
+        return c;
+    }
+    HAB_HD EpiRow epi_row(int m) const {
+        EpiRow r;
+        r.ok = m < M;
+        int img, rem, hq, wq;
+        dHqWq.divmod(r.ok ? m : 0, img, rem);
+        dWq.divmod(rem, hq, wq);
+        r.hb = hq * g.stride - g.pad; r.wb = wq * g.stride - g.pad;
+        r.base = (((long long)img * g.H + r.hb) * g.W + r.wb) * g.C;
+        return r;
+    }
+    HAB_HD bool epi_ok(const EpiRow& r, const EpiCol& c) const {
+        return r.ok & c.ok & ((unsigned)(r.hb + c.ph) < (unsigned)g.H) & ((unsigned)(r.wb + c.pw) < (unsigned)g.W);
+    }
+    HAB_HD EpiAux epi_fetch(const EpiRow& r, const EpiCol& c) const {
+        EpiAux a;
+        const long long i = epi_ok(r, c) ? r.base + c.off : 0;
+        a.add = add ? add[i] : 0.f;
+        a.mask = mask ? mask[i] : 1.f;
+        return a;
+    }
+    HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux& a, float v) const {
+        if (!epi_ok(r, c)) return;
+        v += a.add;
+        if (!(a.mask > 0.f)) v = 0.f;
+        dx[r.base + c.off] = v;
+    }
+    static constexpr bool EPI_VEC4 = true;  // Cin % 8 == 0: a quad of columns is 4 channels of one (ph, pw) class
+    using EpiCol4 = EpiCol;
+    using EpiAux4 = AddMask4;
+    HAB_HD EpiCol4 epi_col4(int n) const { return epi_col(n); }
+    HAB_HD EpiAux4 epi_fetch4(const EpiRow& r, const EpiCol4& c) const {
+        EpiAux4 a;
+        const long long i = epi_ok(r, c) ? r.base + c.off : 0;
+        a.add = add ? ld4(add + i) : zero4();
+        a.mask = mask ? ld4(mask + i) : splat4(1.f);
+        return a;
+    }
+    HAB_HD void epi_store4(const EpiRow& r, const EpiCol4& c, const EpiAux4& a, f32x4 v) const {
+        if (!epi_ok(r, c)) return;
+        v += a.add;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (!(a.mask[e] > 0.f)) v[e] = 0.f;
+        *reinterpret_cast<f32x4*>(dx + r.base + c.off) = v;
     }
     HAB_GENERIC_STORE
 };

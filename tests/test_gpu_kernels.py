@@ -255,6 +255,9 @@ CONVS = [  # B, H, W, C, Cout, K, stride, pad
     (4, 16, 16, 64, 128, 3, 2, 1),   # layer3.0 stride 2
     (4, 16, 16, 64, 128, 1, 2, 0),   # layer3.0 downsample
     (3, 128, 128, 4, 32, 7, 2, 3),   # stem @256^2
+    (2, 16, 18, 32, 32, 4, 2, 1),    # kernel = 2 x stride with padding: merged-class data gradient, N = 128
+    (2, 17, 15, 16, 32, 2, 2, 0),    # kernel = stride, odd extent: merged-class data gradient, N = 64
+    (65, 63, 63, 32, 64, 4, 2, 0),   # SimpleCNN conv2, tiles that straddle images
 ]
 
 
@@ -278,13 +281,13 @@ def test_conv_fwd_dgrad_wgrad(L, B, H, W, Cc, Cout, K, s, p, use_ws):
     y_ref.backward(gy)
     dy = nhwc(gy * (y_ref > 0)).cuda()
     if Cc % 4 == 0:
-        dx = torch.zeros(B, H, W, Cc, device="cuda")
+        dx = torch.full((B, H, W, Cc), 7.0, device="cuda")  # every element must be written
         ck(L.hab_conv2d_dgrad(P(dy), P(wdg), None, None, P(dx), B, H, W, Cc, Cout, K, K, s, p, P(ws), wsn, S()))
         assert torch.allclose(dx.cpu(), nhwc(x.grad), atol=2e-5, rtol=1e-4)
         # fused epilogue: residual-gradient add, then the producer's ReLU mask
         m = torch.randn(B, H, W, Cc)
         add = torch.randn(B, H, W, Cc)
-        dx2 = torch.zeros(B, H, W, Cc, device="cuda")
+        dx2 = torch.full((B, H, W, Cc), 7.0, device="cuda")
         ck(L.hab_conv2d_dgrad(P(dy), P(wdg), P(m.cuda()), P(add.cuda()), P(dx2), B, H, W, Cc, Cout, K, K, s, p, P(ws), wsn, S()))
         assert torch.allclose(dx2.cpu(), (nhwc(x.grad) + add) * (m > 0), atol=2e-5, rtol=1e-4)
         dw = torch.zeros(Cout, Cc, K, K, device="cuda")

@@ -44,6 +44,9 @@ def conv_case(name, B, H, W, Cc, Cout, K, s, p, ws):
     print(f"{name:28s} fwd   {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
     t = timeit(lambda: _lib.check(L.hab_conv2d_dgrad(P(dy), P(wd), None, None, P(dx), B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S())))
     print(f"{name:28s} dgrad {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (algorithmic)")
+    mask = torch.randn(B, H, W, Cc, device="cuda")
+    t = timeit(lambda: _lib.check(L.hab_conv2d_dgrad(P(dy), P(wd), P(mask), None, P(dx), B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S())))
+    print(f"{name:28s} dgrad {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s (with the ReLU-mask epilogue)")
     t = timeit(lambda: _lib.check(L.hab_conv2d_wgrad(P(x), P(dy), P(dw), P(b), B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S())))
     print(f"{name:28s} wgrad {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
 
