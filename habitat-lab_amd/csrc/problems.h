@@ -268,6 +268,26 @@ HAB_HD void obs_quad_cvt(const ObsRaw& r, f32x4* out) {
         out[q][3] = r.dep[q];
     }
 }
+// Quad fast path of the fused convolutions: the uint8 channels enter the contraction as the INTEGER value (one
+// v_cvt_f32_ubyteN per element) and the 1/255 of `x / 255.0` (simple_cnn.py:143-146) is applied on the other, 8-64x smaller side:
+// to the rgb columns of the weight tile when it is staged (forward) or to the rgb rows of dW when they are stored (weight
+// gradient).  fp32 MFMA shares the SIMD issue port with the VALU, so the 3 extra VALU ops per gathered element of the exact
+// division cost ~15 % of the kernel; the products differ from (x / 255) * w by <= 1.5 ulp each, below the accumulation noise.
+constexpr float HAB_RCP255 = 1.0f / 255.0f;
+HAB_HD void obs_quad_cvt_raw(const ObsRaw& r, f32x4* out) {
+    if (!r.ok) { out[0] = zero4(); out[1] = zero4(); out[2] = zero4(); out[3] = zero4(); return; }
+    const uint32_t d[3] = {r.d0, r.d1, r.d2};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int i = 3 * q + c;
+            out[q][c] = (float)((d[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        }
+        out[q][3] = r.dep[q];
+    }
+}
+
 HAB_HD ObsRaw obs_quad_fetch(const ObsView& obs, int srow, int h, int w, int ok) {
     ObsRaw r;
     r.ok = ok;
@@ -324,7 +344,7 @@ struct ObsConvFwdProb {
         return r;
     }
     HAB_HD void a_cvt(const ACtx& c, const ARaw& r, int k, int k_end, f32x4* out) const {
-        if (r.ok >= 0) { obs_quad_cvt(r, out); return; }
+        if (r.ok >= 0) { obs_quad_cvt_raw(r, out); return; }
         for (int e = 0; e < 16; ++e) {  // slow path: element-wise gather
             const int kk = k + e;
             float v = 0.f;
@@ -353,7 +373,11 @@ struct ObsConvFwdProb {
         }
         return r;
     }
-    HAB_HD f32x4 b_cvt(const BRaw& r) const { return sel4(r); }
+    HAB_HD f32x4 b_cvt(const BRaw& r) const {
+        f32x4 v = sel4(r);
+        if (quad) { v[0] *= HAB_RCP255; v[1] *= HAB_RCP255; v[2] *= HAB_RCP255; }  // a unit = channels (r, g, b, depth) of one tap
+        return v;
+    }
     using EpiCol = ColN;
     using EpiRow = RowBase;
     using EpiAux = NoAux;
@@ -835,7 +859,7 @@ struct ObsConvWgradProb {
         return v;
     }
     HAB_HD void a_cvt(const ACtx& c, const ARaw& q, int r, int k_end, f32x4* out) const {
-        if (q.ok >= 0) { obs_quad_cvt(q, out); return; }
+        if (q.ok >= 0) { obs_quad_cvt_raw(q, out); return; }
         int img = 0, rem = 0, ho = 0, wo = 0, srow = 0;
         const bool rv = r < k_end;
         if (rv) {
@@ -866,7 +890,7 @@ struct ObsConvWgradProb {
     }
     HAB_HD f32x4 b_cvt(const BRaw& r) const { return sel4(r); }
     using EpiCol = ColOnly;
-    using EpiRow = OihwRow;
+    struct EpiRow { int off, ok; float scale; };  // scale: 1/255 for the rgb rows of the quad path (integer-valued gather)
     using EpiAux = NoAux;
     HAB_HD EpiCol epi_col(int n) const { EpiCol c; c.n = n; c.ok = n < N; return c; }
     HAB_HD EpiRow epi_row(int i) const {
@@ -876,12 +900,13 @@ struct ObsConvWgradProb {
         g.dC.divmod(r.ok ? i : 0, tap, ci);
         g.dKW.divmod(tap, kh, kw);
         r.off = (ci * g.KH + kh) * g.KW + kw;
+        r.scale = (quad && ci < 3) ? HAB_RCP255 : 1.0f;
         return r;
     }
     HAB_HD EpiAux epi_fetch(const EpiRow&, const EpiCol&) const { return EpiAux(); }
     HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux&, float v) const {
         if (!(r.ok & c.ok)) return;
-        dw[(size_t)c.n * g.C * g.KH * g.KW + r.off] = v;
+        dw[(size_t)c.n * g.C * g.KH * g.KW + r.off] = v * r.scale;
     }
     HAB_GENERIC_STORE
 };
