@@ -120,8 +120,8 @@ def cpu_baseline(sample_envs=64, sample_steps=32):
                       f"torch-CPU fp32, {dt:.1f} s (synthetic obs generation {t_env:.1f} s excluded)"}
 
 
-# kernel(s) launched by a probed call site, for the HBM-traffic lookup (conv2 dgrad = 4 stride-class launches)
-PROBE_KERNELS = {"conv2_dgrad": ("igemm_kernel<ConvDgradProb, 2, 1, 4, 1>", 4), "conv1_fwd": ("igemm_kernel<ObsConvFwdProb, 2, 1, 4, 1>", 1),
+# kernel(s) launched by a probed call site, for the HBM-traffic lookup (conv2 dgrad = one merged-stride-class launch)
+PROBE_KERNELS = {"conv2_dgrad": ("igemm_dma_kernel<ConvDgradMergedProb, 2, 2, 2, 2, false>", 1), "conv1_fwd": ("igemm_kernel<ObsConvFwdProb, 2, 1, 4, 1>", 1),
                  "conv1_wgrad": ("igemm_kernel<ObsConvWgradProb, 2, 1, 4, 1>", 1)}
 
 
@@ -202,11 +202,17 @@ def main():
     upd_frames = local_steps * ppo.ppo_epoch
     roll_frames = local_steps + n_envs * a.steps
     frames = upd_frames + (roll_frames if a.probe.endswith("_fwd") else 0)
-    kname = f"igemm_kernel<{a.probe}>" if not a.probe.startswith("enc_") else f"resnet encoder {a.probe[4:]} (all kernels)"
+    if a.probe.startswith("enc_"):
+        kname = f"resnet encoder {a.probe[4:]} (all kernels)"
+    elif a.workload == "c2" and a.probe in PROBE_KERNELS:
+        kname = f"{a.probe}: {PROBE_KERNELS[a.probe][0]}"
+    else:
+        kname = f"igemm contraction at call site {a.probe}"
     ach = flops_per_frame * frames / (probe_ms * 1e-3) / 1e12 if probe_ms > 0 else None
     traffic = hbm_traffic(a.workload, a.probe)
     out = {
-        "metric": "env-steps/sec (SPS) PointNav RGB-D 256x256, 64 envs x 128 rollout",
+        "metric": "env-steps/sec (SPS) PointNav RGB-D 256x256, 64 envs x 128 rollout" if a.workload != "c5" else
+                  "env-steps/sec (SPS) ObjectNav RGB-D+semantic 256x256, 32 envs x 64 rollout",
         "value": round(steps_total / dt, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

@@ -285,6 +285,222 @@ __global__ void __launch_bounds__(256) groupnorm_fwd_kernel(const GnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Register-resident GroupNorm: frames of <= 128 KB (every ResNet18 layer behind the stem's max-pool).  The frame is loaded
+// ONCE into VGPRs (NV float4 per thread, all loads in flight together), the exact two-pass statistics and the apply run from
+// registers: 1 read + 1 write of HBM per activation instead of 3 + 1 (forward) / 2x3 + 1 (backward), and one memory round
+// trip instead of three dependent ones when only 64 frames are in flight (rollout).  NT threads per frame; thread t owns the
+// float4s t, t + NT, ... (coalesced); C/4 is a power of two dividing NT, so the thread's channel column is fixed.
+// Per-channel reductions: xor-shuffle over the lanes of a wave that share the column, then a fixed-order LDS fold.
+// ------------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void gn_col_reduce(f32x4 s, int C4, float* red, float* ch, int C, int t) {
+    const int lane = t & 63, wave = t >> 6;
+    int nq;
+    __syncthreads();  // red / ch consumers of the previous round are done
+    if (C4 < 64) {
+        for (int off = C4; off < 64; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += __shfl_xor(s[k], off, 64);
+        }
+        if (lane < C4) *reinterpret_cast<f32x4*>(red + (wave * C4 + lane) * 4) = s;
+        nq = NT / 64;
+    } else {
+        *reinterpret_cast<f32x4*>(red + t * 4) = s;
+        nq = NT / C4;
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += NT) {
+        const int c4 = c >> 2, k = c & 3;
+        float u = 0.f;
+        for (int q = 0; q < nq; ++q) u += red[(q * C4 + c4) * 4 + k];
+        ch[c] = u;
+    }
+    __syncthreads();
+}
+
+template <int NT, int NV>
+__global__ void __launch_bounds__(NT) groupnorm_fwd_reg_kernel(const GnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
+    const int F4 = a.HW * C4;
+    const int f = blockIdx.x, t = threadIdx.x, col = t & (C4 - 1);
+    float* red = sm;             // [NT][4]
+    float* ch = sm + NT * 4;     // [C]
+    float* mu_s = ch + C;        // [G]
+    float* rs_s = mu_s + G;      // [G]
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + (size_t)f * a.HW * C);
+    const float inv_m = 1.0f / (float)(a.HW * cpg);
+    f32x4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = t + j * NT;
+        v[j] = i < F4 ? x4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += v[j];
+    gn_col_reduce<NT>(s, C4, red, ch, C, t);
+    if (t < G) {
+        float u = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) u += ch[c];
+        mu_s[t] = u * inv_m;
+    }
+    __syncthreads();
+    f32x4 mu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mu[k] = mu_s[(col * 4 + k) / cpg];
+    s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const f32x4 d = v[j] - mu;
+        if (t + j * NT < F4) s += d * d;
+    }
+    gn_col_reduce<NT>(s, C4, red, ch, C, t);
+    if (t < G) {
+        float u = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) u += ch[c];
+        const float rs = rsqrtf(u * inv_m + a.eps);
+        rs_s[t] = rs;
+        a.mean[(size_t)f * G + t] = mu_s[t];
+        a.rstd[(size_t)f * G + t] = rs;
+    }
+    __syncthreads();
+    f32x4 sc, sh;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = col * 4 + k, g = c / cpg;
+        sc[k] = rs_s[g] * a.gamma[c];
+        sh[k] = a.beta[c] - mu_s[g] * sc[k];
+    }
+    f32x4* y4 = reinterpret_cast<f32x4*>(a.y + (size_t)f * a.HW * C);
+    const f32x4* r4 = a.residual ? reinterpret_cast<const f32x4*>(a.residual + (size_t)f * a.HW * C) : nullptr;
+    if (r4) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = t + j * NT;
+            if (i < F4) v[j] = v[j] * sc + sh + r4[i];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = v[j] * sc + sh;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = t + j * NT;
+        if (a.relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[j][k] = v[j][k] > 0.f ? v[j][k] : 0.f;
+        }
+        if (i < F4) y4[i] = v[j];
+    }
+}
+
+template <int NT, int NV>
+__global__ void __launch_bounds__(NT) groupnorm_bwd_reg_kernel(const GnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
+    const int F4 = a.HW * C4;
+    const int f = blockIdx.x, t = threadIdx.x, col = t & (C4 - 1);
+    float* red = sm;            // [NT][4]
+    float* c1 = sm + NT * 4;    // [C]  per-channel S1 = sum dy'
+    float* c2 = c1 + C;         // [C]  per-channel S2 = sum dy' * xhat
+    float* g1 = c2 + C;         // [G]
+    float* g2 = g1 + G;
+    const size_t base = (size_t)f * a.HW * C;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + base);
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(a.dy + base);
+    const f32x4* ro4 = a.relu_out ? reinterpret_cast<const f32x4*>(a.relu_out + base) : nullptr;
+    f32x4* dym4 = a.dy_masked ? reinterpret_cast<f32x4*>(a.dy_masked + base) : nullptr;
+    const float* mean = a.mean + (size_t)f * G;
+    const float* rstd = a.rstd + (size_t)f * G;
+    f32x4 xh[NV], dv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = t + j * NT;
+        const bool ok = i < F4;
+        xh[j] = ok ? x4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[j] = ok ? dy4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (ro4) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = t + j * NT;
+            if (i < F4) {
+                const f32x4 rv = ro4[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dv[j][k] = rv[k] > 0.f ? dv[j][k] : 0.f;
+            }
+        }
+    }
+    f32x4 mu, rs, ga;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int c = col * 4 + k, g = c / cpg; mu[k] = mean[g]; rs[k] = rstd[g]; ga[k] = a.gamma[c]; }
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = t + j * NT;
+        if (dym4 && i < F4) dym4[i] = dv[j];
+        xh[j] = (xh[j] - mu) * rs;
+        if (i >= F4) xh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s1 += dv[j];
+        s2 += dv[j] * xh[j];
+    }
+    gn_col_reduce<NT>(s1, C4, red, c1, C, t);
+    gn_col_reduce<NT>(s2, C4, red, c2, C, t);
+    for (int c = t; c < C; c += NT) {
+        a.chan_sums[((size_t)f * 2 + 0) * C + c] = c1[c];   // -> dbeta after the reduction over frames
+        a.chan_sums[((size_t)f * 2 + 1) * C + c] = c2[c];   // -> dgamma
+    }
+    if (t < G) {
+        float u = 0.f, w = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { u += a.gamma[c] * c1[c]; w += a.gamma[c] * c2[c]; }
+        const float inv_m = 1.0f / (float)(a.HW * cpg);
+        g1[t] = u * inv_m; g2[t] = w * inv_m;
+    }
+    __syncthreads();
+    f32x4 m1, m2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int g = (col * 4 + k) / cpg; m1[k] = g1[g]; m2[k] = g2[g]; }
+    f32x4* dx4 = reinterpret_cast<f32x4*>(a.dx + base);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = t + j * NT;
+        if (i < F4) dx4[i] = rs * (dv[j] * ga - m1 - xh[j] * m2);
+    }
+}
+
+// Picks (NT, NV) for the register-resident kernels: 0 = not applicable (frame too large / channel count not a power of two).
+static int gn_reg_cfg(int HW, int C, int& nt, int& nv) {
+    const int C4 = C / 4;
+    if (C4 < 1 || (C4 & (C4 - 1)) || getenv("HAB_GN_STREAM") != nullptr) return 0;
+    const long long F4 = (long long)HW * C4;
+    nt = F4 > 2048 ? 1024 : 256;
+    if (C4 > nt) return 0;
+    const long long need = (F4 + nt - 1) / nt;
+    if (need > 8) return 0;  // 16 float4 per thread spill at 1024 threads (128-VGPR budget)
+    nv = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+    return 1;
+}
+#define HAB_GN_REG_DISPATCH(KERNEL, ARGS, LDS)                                                                 \
+    do {                                                                                                       \
+        if (nt == 256) {                                                                                       \
+            switch (nv) {                                                                                      \
+            case 1: KERNEL<256, 1><<<ARGS.B, 256, LDS, s>>>(ARGS); break;                                      \
+            case 2: KERNEL<256, 2><<<ARGS.B, 256, LDS, s>>>(ARGS); break;                                      \
+            case 4: KERNEL<256, 4><<<ARGS.B, 256, LDS, s>>>(ARGS); break;                                      \
+            default: KERNEL<256, 8><<<ARGS.B, 256, LDS, s>>>(ARGS); break;                                     \
+            }                                                                                                  \
+        } else {                                                                                               \
+            switch (nv) {                                                                                      \
+            case 1: KERNEL<1024, 1><<<ARGS.B, 1024, LDS, s>>>(ARGS); break;                                    \
+            case 2: KERNEL<1024, 2><<<ARGS.B, 1024, LDS, s>>>(ARGS); break;                                    \
+            case 4: KERNEL<1024, 4><<<ARGS.B, 1024, LDS, s>>>(ARGS); break;                                    \
+            default: KERNEL<1024, 8><<<ARGS.B, 1024, LDS, s>>>(ARGS); break;                                   \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+
 static int gn_check(int B, int C, int groups) {
     if (B <= 0 || C <= 0 || groups <= 0 || C % 4 || C % groups || groups > 256) return HAB_ERR_ARG;
     const int C4 = C / 4;
@@ -295,6 +511,13 @@ static int gn_check(int B, int C, int groups) {
 int groupnorm_forward(const GnArgs& a, hipStream_t s) {
     if (!a.x || !a.y || !a.gamma || !a.beta || !a.mean || !a.rstd) return HAB_ERR_ARG;
     HAB_TRY(gn_check(a.B, a.C, a.groups));
+    int nt, nv;
+    if (gn_reg_cfg(a.HW, a.C, nt, nv)) {
+        const size_t lds_r = (size_t)(nt * 4 + a.C + 2 * a.groups) * sizeof(float);
+        HAB_GN_REG_DISPATCH(groupnorm_fwd_reg_kernel, a, lds_r);
+        HAB_LAUNCH_CHECK();
+        return HAB_OK;
+    }
     const size_t lds = (size_t)(1024 + a.C + 2 * a.groups) * sizeof(float);
     groupnorm_fwd_kernel<<<a.B, 256, lds, s>>>(a);
     HAB_LAUNCH_CHECK();
@@ -391,6 +614,13 @@ int groupnorm_backward(const GnBwdArgs& a, hipStream_t s) {
     if (!a.x || !a.dy || !a.dx || !a.gamma || !a.mean || !a.rstd || !a.chan_sums) return HAB_ERR_ARG;
     if (a.dx == a.dy && a.dy_masked) return HAB_ERR_ARG;
     HAB_TRY(gn_check(a.B, a.C, a.groups));
+    int nt, nv;
+    if (gn_reg_cfg(a.HW, a.C, nt, nv)) {
+        const size_t lds_r = (size_t)(nt * 4 + 2 * a.C + 2 * a.groups) * sizeof(float);
+        HAB_GN_REG_DISPATCH(groupnorm_bwd_reg_kernel, a, lds_r);
+        HAB_LAUNCH_CHECK();
+        return HAB_OK;
+    }
     const size_t lds = (size_t)(1024 + 2 * a.C + 2 * a.groups) * sizeof(float);
     groupnorm_bwd_kernel<<<a.B, 256, lds, s>>>(a);
     HAB_LAUNCH_CHECK();

@@ -382,7 +382,10 @@ def test_igemm_transpose_detecting_identity(L):
 # HBM-bound kernels of the GroupNorm-ResNet encoder
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,HW,Cc,groups,relu,res", [(3, 64 * 64, 32, 16, 1, 0), (2, 100, 64, 16, 1, 1), (5, 16, 256, 16, 0, 0),
-                                                      (2, 4, 1024, 16, 1, 1), (3, 16, 128, 1, 1, 0), (2, 1, 2048, 1, 1, 0)])
+                                                      (2, 4, 1024, 16, 1, 1), (3, 16, 128, 1, 1, 0), (2, 1, 2048, 1, 1, 0),
+                                                      # register-resident kernels at 1024 threads per frame (resnet18 layer1 / layer2 @256^2)
+                                                      (3, 32 * 32, 32, 16, 1, 1), (2, 16 * 16, 64, 16, 1, 0), (2, 30 * 30, 32, 16, 0, 1),
+                                                      (2, 8 * 8, 128, 16, 1, 1)])
 def test_groupnorm_fwd_bwd(L, B, HW, Cc, groups, relu, res):
     torch.manual_seed(B * 10 + Cc)
     x = torch.randn(B, Cc, HW, 1, requires_grad=True)
