@@ -359,19 +359,72 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
 }
 
 // Second pass of a split-K launch: fixed-order sum of the partial slabs, then the problem's epilogue.
-template <class P>
+// A workgroup owns 64 consecutive output elements; its four waves each sum a contiguous quarter of the slabs (loads issued eight
+// at a time, added in slab order) and the quarters are combined in a fixed order through LDS.  Weight gradients have few output
+// elements and hundreds of slabs (M*N = 8k .. 600k, K = 10^6 .. 10^7): one thread per element walking all slabs serially made
+// this pass latency-bound at 30-40 workgroups.
+template <class P, bool WIDE>
 __global__ void __launch_bounds__(256) igemm_splitk_reduce_kernel(const P p, const float* __restrict__ partial, int splits) {
+    __shared__ float red[4][64];
     int MP = p.M;
     if constexpr (ColsumB<P>::value) MP += (p.colsum != nullptr) ? 1 : 0;
     const size_t total = (size_t)MP * p.N;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        float s = 0.0f;
-        for (int z = 0; z < splits; ++z) s += partial[(size_t)z * total + e];
-        const int m = (int)(e / p.N), n = (int)(e % p.N);
-        if constexpr (ColsumB<P>::value) {
-            if (m == p.M) { p.store_colsum(n, s); continue; }
+    if constexpr (!WIDE) {  // few slabs, many elements (rollout-time forward convolutions): one thread per element
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+            float s = 0.0f;
+            for (int z = 0; z < splits; ++z) s += partial[(size_t)z * total + e];
+            const int m = (int)(e / p.N), n = (int)(e % p.N);
+            if constexpr (ColsumB<P>::value) {
+                if (m == p.M) { p.store_colsum(n, s); continue; }
+            }
+            p.store(m, n, s);
         }
-        p.store(m, n, s);
+        return;
+    }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int chunk = (splits + 3) >> 2;
+    const int z0 = ty * chunk, z1 = min(splits, z0 + chunk);
+    for (size_t e0 = (size_t)blockIdx.x * 64; e0 < total; e0 += (size_t)gridDim.x * 64) {
+        const size_t e = e0 + tx;
+        float s = 0.0f;
+        if (e < total) {
+            const float* src = partial + e;
+            int z = z0;
+            for (; z + 8 <= z1; z += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(z + u) * total];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; z < z1; ++z) s += src[(size_t)z * total];
+        }
+        red[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && e < total) {
+            s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+            const int m = (int)(e / p.N), n = (int)(e % p.N);
+            bool done = false;
+            if constexpr (ColsumB<P>::value) {
+                if (m == p.M) { p.store_colsum(n, s); done = true; }
+            }
+            if (!done) p.store(m, n, s);
+        }
+        __syncthreads();
+    }
+}
+
+template <class P>
+inline void igemm_splitk_reduce(const P& p, const float* ws, int splits, hipStream_t stream) {
+    const long long total = (long long)(p.M + 1) * p.N;
+    if (splits >= 16) {
+        int blocks = (int)cdivl(total, 64);
+        if (blocks > 8192) blocks = 8192;
+        igemm_splitk_reduce_kernel<P, true><<<blocks, 256, 0, stream>>>(p, ws, splits);
+    } else {
+        int blocks = (int)cdivl(total, 256);
+        if (blocks > 4096) blocks = 4096;
+        igemm_splitk_reduce_kernel<P, false><<<blocks, 256, 0, stream>>>(p, ws, splits);
     }
 }
 
@@ -415,9 +468,7 @@ inline int igemm_launch(const P& p, float* ws, size_t ws_floats, int target_bloc
     kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, pl.k_per_split, ws);
     HAB_LAUNCH_CHECK();
     if (pl.splits > 1) {
-        int blocks = (int)cdivl((long long)(p.M + 1) * p.N, 256);
-        if (blocks > 4096) blocks = 4096;
-        igemm_splitk_reduce_kernel<P><<<blocks, 256, 0, stream>>>(p, ws, pl.splits);
+        igemm_splitk_reduce<P>(p, ws, pl.splits, stream);
         HAB_LAUNCH_CHECK();
     }
     return HAB_OK;

@@ -237,9 +237,7 @@ inline int igemm_dma_launch(const P& p, float* ws, size_t ws_floats, int target_
     kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, pl.k_per_split, ws);
     HAB_LAUNCH_CHECK();
     if (pl.splits > 1) {
-        int blocks = (int)cdivl((long long)(p.M + 1) * p.N, 256);
-        if (blocks > 4096) blocks = 4096;
-        igemm_splitk_reduce_kernel<P><<<blocks, 256, 0, stream>>>(p, ws, pl.splits);
+        igemm_splitk_reduce<P>(p, ws, pl.splits, stream);
         HAB_LAUNCH_CHECK();
     }
     return HAB_OK;

@@ -179,9 +179,7 @@ inline int igemm_dma_wgrad_launch(const ConvWgradProb& p, float* ws, size_t ws_f
     kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, pl.k_per_split, ws);
     HAB_LAUNCH_CHECK();
     if (pl.splits > 1) {
-        int blocks = (int)cdivl((long long)(p.M + 1) * p.N, 256);
-        if (blocks > 4096) blocks = 4096;
-        igemm_splitk_reduce_kernel<ConvWgradProb><<<blocks, 256, 0, stream>>>(p, ws, pl.splits);
+        igemm_splitk_reduce<ConvWgradProb>(p, ws, pl.splits, stream);
         HAB_LAUNCH_CHECK();
     }
     return HAB_OK;

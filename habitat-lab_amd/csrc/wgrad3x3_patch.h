@@ -179,9 +179,7 @@ inline int wgrad3x3_patch(const ConvWgradProb& p, float* ws, size_t ws_floats, h
     }
 #undef HAB_W3_LAUNCH
     HAB_LAUNCH_CHECK();
-    int blocks = (int)cdivl((long long)(p.M + 1) * p.N, 256);
-    if (blocks > 4096) blocks = 4096;
-    igemm_splitk_reduce_kernel<ConvWgradProb><<<blocks, 256, 0, stream>>>(p, ws, splits);
+    igemm_splitk_reduce<ConvWgradProb>(p, ws, splits, stream);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
