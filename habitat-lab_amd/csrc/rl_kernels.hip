@@ -103,6 +103,34 @@ extern "C" int hab_synth_step(uint8_t* rgb, float* depth, float* goal, float* re
     return HAB_OK;
 }
 
+// Per-step episode bookkeeping of the rollout loop (ppo_trainer.py:417-446) + the prev_actions write of
+// RolloutStorage.insert (rollout_storage.py:124-130), one launch instead of eight elementwise ones.
+__global__ void rollout_step_stats_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ not_done,
+                                          float* __restrict__ cur, float* __restrict__ stat_reward, float* __restrict__ stat_count,
+                                          const int64_t* __restrict__ actions, int64_t* __restrict__ prev_next, int N, int A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float c = cur[i] + rewards[i];          // current_episode_reward += rewards
+    if (!not_done[i]) {
+        stat_reward[i] += c;                // running_episode_stats["reward"] += current_episode_reward.where(done, 0)
+        stat_count[i] += 1.0f;              // running_episode_stats["count"] += done
+        c = 0.0f;                           // current_episode_reward.masked_fill_(done, 0)
+    }
+    cur[i] = c;
+    if (actions)
+        for (int a = 0; a < A; ++a) prev_next[(size_t)i * A + a] = actions[(size_t)i * A + a];
+}
+extern "C" int hab_rollout_step_stats(const float* rewards, const uint8_t* not_done, float* current_episode_reward, float* stat_reward,
+                                      float* stat_count, const int64_t* actions, int64_t* prev_actions_next, int N, int action_dim,
+                                      hipStream_t stream) {
+    if (!rewards || !not_done || !current_episode_reward || !stat_reward || !stat_count || N <= 0) return HAB_ERR_ARG;
+    if ((actions == nullptr) != (prev_actions_next == nullptr) || (actions && action_dim <= 0)) return HAB_ERR_ARG;
+    rollout_step_stats_kernel<<<cdiv(N, 64), 64, 0, stream>>>(rewards, not_done, current_episode_reward, stat_reward, stat_count,
+                                                              actions, prev_actions_next, N, action_dim);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
 // ObjectNav sensor set for the current env clock (oracle/synth.py: semantic, objectgoal, compass, gps).
 __global__ void __launch_bounds__(256) synth_semantic_kernel(int32_t* __restrict__ semantic, const int64_t* __restrict__ env_t,
                                                              uint32_t seed, uint32_t env_offset, int words) {

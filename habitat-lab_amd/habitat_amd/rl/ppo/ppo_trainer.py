@@ -22,6 +22,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
+from habitat_amd import _lib
 from habitat_amd.common.base_trainer import BaseRLTrainer
 from habitat_amd.common.baseline_registry import baseline_registry
 from habitat_amd.common.env_factory import instantiate
@@ -179,16 +180,15 @@ class PPOTrainer(BaseRLTrainer):
                    exp_noise=noise[t],
                    out=dict(values=B["value_preds"][t], actions=B["actions"][t], action_log_probs=B["action_log_probs"][t],
                             rnn_hidden_states=B["recurrent_hidden_states"][t + 1]))
-            B["prev_actions"][t + 1].copy_(B["actions"][t])
         with g_timer.avg_time("trainer.step_env"):
             self.envs.step_into_obs({k: v[t + 1] for k, v in obs.items()}, B["rewards"][t], B["masks"][t + 1])
         with g_timer.avg_time("trainer.update_stats"):
-            rewards, not_done = B["rewards"][t], B["masks"][t + 1]
-            self.current_episode_reward += rewards
-            done = ~not_done
-            self.running_episode_stats["reward"] += self.current_episode_reward * done
-            self.running_episode_stats["count"] += done
-            self.current_episode_reward *= not_done
+            # episode bookkeeping (ppo_trainer.py:417-446) and prev_actions[t+1] = actions[t], one launch
+            acts = B["actions"][t]
+            _lib.check(_lib.lib().hab_rollout_step_stats(
+                _lib.ptr(B["rewards"][t]), _lib.ptr(B["masks"][t + 1]), _lib.ptr(self.current_episode_reward),
+                _lib.ptr(self.running_episode_stats["reward"]), _lib.ptr(self.running_episode_stats["count"]),
+                _lib.ptr(acts), _lib.ptr(B["prev_actions"][t + 1]), self.envs.num_envs, acts.shape[-1], _lib.stream_ptr()))
         st.advance_rollout()
         return self.envs.num_envs
 

@@ -49,6 +49,14 @@ int hab_synth_step(uint8_t* rgb /*N,H,W,3*/, float* depth /*N,H,W,1*/, float* go
 int hab_synth_objectnav_sensors(int32_t* semantic, int64_t* objectgoal, float* compass, float* gps, const int64_t* env_t,
                                 uint32_t seed, uint32_t env_offset, int N, int H, int W, hipStream_t stream);
 
+/* Per-step episode bookkeeping of the rollout loop, fused (rl/ppo/ppo_trainer.py:417-446: current_episode_reward += rewards;
+ * running_episode_stats["reward"] += current_episode_reward.where(done, 0); ["count"] += done;
+ * current_episode_reward.masked_fill_(done, 0)) plus RolloutStorage.insert's prev_actions[t+1] = actions[t]
+ * (common/rollout_storage.py:124-130; actions / prev_actions_next may both be NULL).  All arrays have N rows. */
+int hab_rollout_step_stats(const float* rewards, const uint8_t* not_done, float* current_episode_reward, float* stat_reward,
+                           float* stat_count, const int64_t* actions /*N,action_dim*/, int64_t* prev_actions_next, int N,
+                           int action_dim, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * RolloutStorage.compute_returns (common/rollout_storage.py:174-205).  Buffers are (T+1, N).
  * Writes value_preds[T] = next_value and returns[0..T-1] (use_gae) / returns[0..T].

@@ -521,3 +521,24 @@ def test_nav_embeddings_fwd_bwd(L):
     ck(L.hab_nav_embed_bwd(slots, 5, P(saved), P(dout.cuda()), ld, col0, B, P(ws), ws.numel(), S()))
     for k, v in w.items():
         assert torch.allclose(dw[k].cpu(), v.grad, atol=2e-4, rtol=1e-4), k
+
+
+def test_rollout_step_stats(L):
+    """Fused per-step episode bookkeeping == the reference's elementwise sequence (ppo_trainer.py:417-446)."""
+    torch.manual_seed(11)
+    N = 70
+    cur, sr, sc = torch.randn(N, 1), torch.randn(N, 1).abs(), torch.randint(0, 5, (N, 1)).float()
+    d = [t.clone().cuda() for t in (cur, sr, sc)]
+    prev = torch.zeros(N, 1, dtype=torch.long, device="cuda")
+    for step in range(5):
+        rewards = torch.randn(N, 1)
+        not_done = torch.rand(N, 1) > 0.3
+        actions = torch.randint(0, 4, (N, 1))
+        done = ~not_done
+        cur += rewards
+        sr += cur.where(done, cur.new_zeros(()))
+        sc += done.float()
+        cur.masked_fill_(done, 0.0)
+        ck(L.hab_rollout_step_stats(P(rewards.cuda()), P(not_done.cuda()), P(d[0]), P(d[1]), P(d[2]), P(actions.cuda()), P(prev), N, 1, S()))
+        assert torch.equal(d[0].cpu(), cur) and torch.equal(d[1].cpu(), sr) and torch.equal(d[2].cpu(), sc)
+        assert torch.equal(prev.cpu(), actions)
