@@ -187,3 +187,31 @@ class SyntheticVectorEnvFactory(VectorEnvFactory):
         return SyntheticVectorEnv(int(hb.num_environments), int(ref.height), int(ref.width), seed=int(hab.seed),
                                   env_offset=env_offset, use_rgb=use_rgb, use_depth=use_depth,
                                   num_actions=len(hab.task.actions), device=device, task=task)
+
+
+class ProcessVectorEnvFactory(VectorEnvFactory):
+    """`_target_: habitat_amd.common.env_factory.ProcessVectorEnvFactory`: one worker PROCESS per environment behind the
+    reference's VectorEnv API (core/vector_env.py), observations through the shared-memory plane.  The worker env is
+    `core.host_env.HostSyntheticNavEnv` unless `make_env_fn` names another constructor ('pkg.mod.fn'); with habitat-sim the
+    reference's `make_gym_from_config` goes here (habitat_baselines/common/habitat_env_factory.py:80-119)."""
+
+    def __init__(self, make_env_fn: Optional[str] = None, shared_obs: bool = True, start_method: str = "forkserver", work_us: int = 0):
+        self.make_env_fn, self.shared_obs, self.start_method, self.work_us = make_env_fn, shared_obs, start_method, work_us
+
+    def construct_envs(self, config, workers_ignore_signals: bool = False, enforce_scenes_greater_eq_environments: bool = False,
+                       is_first_rank: bool = True, env_offset: int = 0):
+        from habitat_amd.core.host_env import make_host_env
+        from habitat_amd.core.vector_env import VectorEnv
+        hb, hab = config.habitat_baselines, config.habitat
+        sens = hab.simulator.sensors
+        use_rgb, use_depth = "rgb" in sens, "depth" in sens
+        ref = sens["rgb"] if use_rgb else sens["depth"]
+        fn = make_host_env
+        if self.make_env_fn:
+            mod, _, name = self.make_env_fn.rpartition(".")
+            fn = getattr(importlib.import_module(mod), name)
+        n = int(hb.num_environments)
+        args = [(int(hab.seed) + env_offset + i, int(ref.height), int(ref.width), use_rgb, use_depth, len(hab.task.actions),
+                 int(hab.environment.max_episode_steps), self.work_us) for i in range(n)]
+        return VectorEnv(fn, args, auto_reset_done=True, multiprocessing_start_method=self.start_method,
+                         workers_ignore_signals=workers_ignore_signals, shared_obs=self.shared_obs)

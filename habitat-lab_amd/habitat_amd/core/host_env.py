@@ -1,0 +1,78 @@
+"""A CPU stand-in for one simulator-backed environment (the `RLEnv` a VectorEnv worker owns: habitat/core/env.py:337-430):
+numpy-generated RGB-D + pointgoal observations of the benchmark's sizes, Bernoulli episode ends, a step budget.  It exists so
+that the process-per-env transport (core/vector_env.py) and the trainer's host path can be exercised and timed end to end
+without habitat-sim; it makes no attempt to be a navigation task."""
+from __future__ import annotations
+
+import numpy as np
+
+from habitat_amd.common import spaces
+
+GOAL_UUID = "pointgoal_with_gps_compass"
+
+
+class HostSyntheticNavEnv:
+    def __init__(self, seed: int = 0, height: int = 256, width: int = 256, use_rgb: bool = True, use_depth: bool = True,
+                 num_actions: int = 4, max_episode_steps: int = 500, p_done: float = 1.0 / 25.0, work_us: int = 0):
+        self._rng = np.random.default_rng(seed)
+        self._h, self._w, self._use_rgb, self._use_depth = height, width, use_rgb, use_depth
+        self._max_steps, self._p_done, self._work_us = max_episode_steps, p_done, work_us
+        sp = {}
+        if use_rgb:
+            sp["rgb"] = spaces.Box(0, 255, (height, width, 3), np.uint8)
+        if use_depth:
+            sp["depth"] = spaces.Box(0.0, 1.0, (height, width, 1), np.float32)
+        sp[GOAL_UUID] = spaces.Box(np.finfo(np.float32).min, np.finfo(np.float32).max, (2,), np.float32)
+        self.observation_space = spaces.Dict(sp)
+        self.action_space = spaces.Discrete(num_actions)
+        self.original_action_space = self.action_space
+        self.number_of_episodes = 1 << 30
+        self.episodes = ()
+        self._t = 0
+        self._episode = 0
+        self.episode_over = False
+        self._ret = 0.0
+
+    @property
+    def current_episode(self):
+        return {"episode_id": str(self._episode), "scene_id": "synthetic"}
+
+    def _obs(self):
+        o = {}
+        if self._use_rgb:
+            o["rgb"] = self._rng.integers(0, 256, (self._h, self._w, 3), dtype=np.uint8)
+        if self._use_depth:
+            o["depth"] = self._rng.random((self._h, self._w, 1), dtype=np.float32)
+        o[GOAL_UUID] = np.array([self._rng.uniform(0.0, 10.0), self._rng.uniform(-np.pi, np.pi)], dtype=np.float32)
+        return o
+
+    def reset(self):
+        self._t, self._ret, self.episode_over = 0, 0.0, False
+        self._episode += 1
+        return self._obs()
+
+    def step(self, action):
+        if isinstance(action, dict):
+            action = action.get("action", 0)
+        assert 0 <= int(action) < self.action_space.n, f"invalid action {action}"
+        if self._work_us:  # stand-in for simulator time
+            import time
+            time.sleep(self._work_us * 1e-6)
+        self._t += 1
+        reward = float(self._rng.standard_normal())
+        self._ret += reward
+        done = bool(self._rng.random() < self._p_done) or self._t >= self._max_steps
+        self.episode_over = done
+        info = {"episode_return": self._ret, "num_steps": float(self._t)}  # measures are present at every step, like habitat's
+        return self._obs(), reward, done, info
+
+    def get_metrics(self):
+        return {"episode_return": self._ret, "num_steps": float(self._t)}
+
+    def close(self):
+        pass
+
+
+def make_host_env(seed, height, width, use_rgb, use_depth, num_actions, max_episode_steps, work_us=0):
+    return HostSyntheticNavEnv(seed=seed, height=height, width=width, use_rgb=use_rgb, use_depth=use_depth, num_actions=num_actions,
+                               max_episode_steps=max_episode_steps, work_us=work_us)

@@ -218,7 +218,14 @@ class PPOTrainer(BaseRLTrainer):
             observations, rewards_l, dones, infos = [list(x) for x in zip(*outputs)]
         with g_timer.avg_time("trainer.update_stats"):
             observations = self.envs.post_step(observations)
-            batch = batch_obs(observations, self.device)
+            slab_keys = set(getattr(self.envs, "shared_obs_keys", ()))
+            if slab_keys:
+                # shared-memory observation plane (core/vector_env.py): one H2D copy per sensor from the rows the workers wrote
+                batch = self.envs.batched_obs(env_slice, self.device)
+                if any(k not in slab_keys for k in observations[0]):
+                    batch.update(batch_obs([{k: v for k, v in o.items() if k not in slab_keys} for o in observations], self.device))
+            else:
+                batch = batch_obs(observations, self.device)
             cdev = self.current_episode_reward.device
             rewards = torch.tensor(rewards_l, dtype=torch.float, device=cdev).unsqueeze(1)
             not_done_masks = torch.tensor([[not d] for d in dones], dtype=torch.bool, device=cdev)

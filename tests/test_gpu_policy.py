@@ -444,3 +444,55 @@ def test_trainer_update_cycles_from_yaml_entrypoints(yaml_path, overrides):
     assert float((pol.engine.params_flat - before).abs().max()) > 0
     assert set(losses) >= {"value_loss", "action_loss", "dist_entropy", "grad_norm"}
     trainer.envs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared_obs", [True, False])
+def test_trainer_host_path_with_process_vector_env(shared_obs):
+    """N1: the trainer's generic host path (async_step_at / wait_step_at per env, double-buffered halves) over worker PROCESSES.
+    With the shared-memory observation plane the rollout rows must hold exactly what the workers produced: the same envs are
+    replayed in-process with the actions the policy sent."""
+    from habitat_amd.config.default import get_config
+    from habitat_amd.common.baseline_registry import baseline_registry
+    from habitat_amd.core.host_env import make_host_env
+    import habitat_amd.rl.ppo.ppo_trainer  # noqa: F401
+    size, N, T = 64, 4, 6
+    ov = [f"habitat_baselines.num_environments={N}", f"habitat_baselines.rl.ppo.num_steps={T}", "habitat_baselines.num_updates=3",
+          "habitat_baselines.total_num_steps=-1", "habitat_baselines.num_checkpoints=-1", "habitat_baselines.checkpoint_interval=1000000",
+          "habitat_baselines.rl.ppo.hidden_size=64", "habitat_baselines.checkpoint_folder=/tmp/habitat_amd_test_ckpt",
+          "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000",
+          "habitat_baselines.vector_env_factory._target_=habitat_amd.common.env_factory.ProcessVectorEnvFactory",
+          f"habitat_baselines.vector_env_factory.shared_obs={shared_obs}"]
+    for sname in ("rgb", "depth"):
+        ov += [f"habitat.simulator.sensors.{sname}.height={size}", f"habitat.simulator.sensors.{sname}.width={size}"]
+    cfg = get_config("pointnav/ppo_pointnav_example.yaml", ov)
+    cfg.habitat.simulator.sensors.pop("semantic", None)
+    trainer = baseline_registry.get_trainer(cfg.habitat_baselines.trainer_name)(cfg)
+    trainer._init_train()
+    try:
+        assert not trainer._device_envs and trainer.envs.num_envs == N
+        assert bool(trainer.envs.shared_obs_keys) == shared_obs
+        st = trainer._agent.rollouts
+        trainer._agent.eval()
+        steps = trainer.collect_rollout()
+        assert steps == N * T
+        # replay: same seeds, same actions -> same observations / rewards / masks in the rollout rows
+        local = [make_host_env(int(cfg.habitat.seed) + i, size, size, True, True, len(cfg.habitat.task.actions),
+                               int(cfg.habitat.environment.max_episode_steps)) for i in range(N)]
+        obs = [e.reset() for e in local]
+        B = st.buffers
+        for k in obs[0]:
+            assert np.array_equal(B["observations"][k][0].cpu().numpy(), np.stack([o[k] for o in obs])), k
+        for t in range(T):
+            acts = B["actions"][t].cpu().numpy().reshape(N)
+            for i, e in enumerate(local):
+                o, r, d, _ = e.step(int(acts[i]))
+                if d:
+                    o = e.reset()
+                for k in o:
+                    assert np.array_equal(B["observations"][k][t + 1, i].cpu().numpy(), o[k]), (t, i, k)
+                assert abs(float(B["rewards"][t, i]) - r) < 1e-6 and bool(B["masks"][t + 1, i]) == (not d)
+        losses = trainer._update_agent()
+        assert all(np.isfinite(v) for v in losses.values()), losses
+    finally:
+        trainer.envs.close()
