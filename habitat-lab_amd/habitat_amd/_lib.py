@@ -48,6 +48,7 @@ SIGNATURES = {
     "hab_error_string": (c_char_p, [c_int]),
     "hab_synth_step": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_uint32, c_uint32, c_int, c_int, c_int, c_int, vp]),
     "hab_synth_objectnav_sensors": (c_int, [vp, vp, vp, vp, vp, c_uint32, c_uint32, c_int, c_int, c_int, vp]),
+    "hab_obs_resize_crop": (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     "hab_rollout_step_stats": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_int, c_int, vp]),
     "hab_compute_returns": (c_int, [vp, vp, vp, vp, vp, c_int, c_int, c_float, c_float, c_int, c_int, vp]),
     "hab_advantages": (c_int, [vp, vp, vp, c_int, c_int, vp, vp, vp]),

@@ -26,6 +26,8 @@ from habitat_amd import _lib
 from habitat_amd.common.base_trainer import BaseRLTrainer
 from habitat_amd.common.baseline_registry import baseline_registry
 from habitat_amd.common.env_factory import instantiate
+from habitat_amd.common.obs_transformers import (apply_obs_transforms_batch, apply_obs_transforms_obs_space,
+                                                 get_active_obs_transforms)
 from habitat_amd.config.default import read_write
 from habitat_amd.rl.ddppo.ddp_utils import (EXIT, get_distrib_size, init_distrib_slurm, load_resume_state, rank0_only,
                                             requeue_job, save_resume_state)
@@ -88,6 +90,9 @@ class PPOTrainer(BaseRLTrainer):
                                            is_first_rank=(not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0),
                                            **kw)
         self._env_spec = EnvironmentSpec(self.envs.observation_spaces[0], self.envs.action_spaces[0], self.envs.orig_action_spaces[0])
+        # ppo_trainer.py:110-115: the policy and the rollout storage see the TRANSFORMED observation space
+        self.obs_transforms = get_active_obs_transforms(config)
+        self._env_spec.observation_space = apply_obs_transforms_obs_space(self._env_spec.observation_space, self.obs_transforms)
         self._rank0_keys = set()
         self._single_proc_infos = {}
 
@@ -134,6 +139,8 @@ class PPOTrainer(BaseRLTrainer):
         self._agent.post_init()
         self._ppo_cfg = hb.rl.ppo
         self._device_envs = hasattr(self.envs, "step_into_obs") and self.device.type == "cuda"
+        if self._device_envs and self.obs_transforms:
+            raise ValueError("obs_transforms are applied on the host-env path; the device env source emits the policy's sensor size")
         st = self._agent.rollouts
         N = self.envs.num_envs
         if self._device_envs:
@@ -142,7 +149,7 @@ class PPOTrainer(BaseRLTrainer):
             stat_dev = self.device
         else:
             observations = self.envs.post_step(self.envs.reset())
-            st.insert_first_observations(batch_obs(observations, self.device))
+            st.insert_first_observations(apply_obs_transforms_batch(batch_obs(observations, self.device), self.obs_transforms))
             stat_dev = torch.device("cpu")
         self.current_episode_reward = torch.zeros(N, 1, device=stat_dev)
         self.running_episode_stats = dict(count=torch.zeros(N, 1, device=stat_dev), reward=torch.zeros(N, 1, device=stat_dev))
@@ -226,6 +233,7 @@ class PPOTrainer(BaseRLTrainer):
                     batch.update(batch_obs([{k: v for k, v in o.items() if k not in slab_keys} for o in observations], self.device))
             else:
                 batch = batch_obs(observations, self.device)
+            batch = apply_obs_transforms_batch(batch, self.obs_transforms)  # ppo_trainer.py:421
             cdev = self.current_episode_reward.device
             rewards = torch.tensor(rewards_l, dtype=torch.float, device=cdev).unsqueeze(1)
             not_done_masks = torch.tensor([[not d] for d in dones], dtype=torch.bool, device=cdev)

@@ -49,6 +49,22 @@ int hab_synth_step(uint8_t* rgb /*N,H,W,3*/, float* depth /*N,H,W,1*/, float* go
 int hab_synth_objectnav_sensors(int32_t* semantic, int64_t* objectgoal, float* compass, float* gps, const int64_t* env_t,
                                 uint32_t seed, uint32_t env_offset, int N, int H, int W, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Observation transformers, fused: ResizeShortestEdge followed by CenterCropper
+ * (habitat_baselines/common/obs_transformers.py:70-231; utils/common.py:481-557: F.interpolate(mode="area") -- "nearest" for
+ * the semantic sensor -- on the float NCHW view, cast back to the sensor dtype, then a center slice).  src (N,H,W,C) NHWC of
+ * `dtype`; the image is virtually resized to (resized_h, resized_w) and the window [crop_y0, crop_y0+out_h) x
+ * [crop_x0, crop_x0+out_w) of it is written to dst (N,out_h,out_w,C).  Resize only: crop = the whole resized image; crop only:
+ * resized extent = source extent.  Bit-identical to the ATen CPU kernels the reference calls.  C <= 4.
+ * ------------------------------------------------------------------------------------------- */
+#define HAB_DTYPE_U8 0
+#define HAB_DTYPE_F32 1
+#define HAB_DTYPE_I32 2
+#define HAB_RESIZE_AREA 0
+#define HAB_RESIZE_NEAREST 1
+int hab_obs_resize_crop(const void* src, void* dst, int dtype, int N, int H, int W, int C, int resized_h, int resized_w,
+                        int crop_y0, int crop_x0, int out_h, int out_w, int mode, hipStream_t stream);
+
 /* Per-step episode bookkeeping of the rollout loop, fused (rl/ppo/ppo_trainer.py:417-446: current_episode_reward += rewards;
  * running_episode_stats["reward"] += current_episode_reward.where(done, 0); ["count"] += done;
  * current_episode_reward.masked_fill_(done, 0)) plus RolloutStorage.insert's prev_actions[t+1] = actions[t]

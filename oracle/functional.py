@@ -539,3 +539,32 @@ def ppo_update(params: Params, spec: NetSpec, buffers: dict, num_steps: int, cfg
                 rec("ppo_fraction_clipped", (r > 1.0 + cfg.clip_param).float().mean() + (r < 1.0 - cfg.clip_param).float().mean())
             rec("grad_norm", gnorm)
     return {k: float(torch.stack(v).mean()) for k, v in metrics.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Observation transformers: habitat_baselines/utils/common.py:481-557, common/obs_transformers.py:69-231
+# ---------------------------------------------------------------------------------------------------------------------------
+def resize_shortest_edge(img: torch.Tensor, size: int, interpolation_mode: str = "area") -> torch.Tensor:
+    """image_resize_shortest_edge(img, size, channels_last=True) (utils/common.py:481-528) for NHWC batches."""
+    h, w = img.shape[-3], img.shape[-2]
+    x = img.permute(0, 3, 1, 2)
+    scale = size / min(h, w)
+    nh, nw = int(h * scale), int(w * scale)
+    x = F.interpolate(x.float(), size=(nh, nw), mode=interpolation_mode).to(dtype=img.dtype)
+    return x.permute(0, 2, 3, 1)
+
+
+def center_crop(img: torch.Tensor, size) -> torch.Tensor:
+    """center_crop(img, size, channels_last=True) (utils/common.py:531-557)."""
+    h, w = img.shape[-3], img.shape[-2]
+    cropy, cropx = (int(size), int(size)) if isinstance(size, int) else size
+    startx, starty = w // 2 - (cropx // 2), h // 2 - (cropy // 2)
+    return img[..., starty:starty + cropy, startx:startx + cropx, :]
+
+
+def obs_transform_inputs(seed: int, n: int, h: int, w: int) -> Dict[str, torch.Tensor]:
+    """Deterministic sensor batch for the transformer fixtures (rgb u8, depth f32, semantic i32; NHWC)."""
+    g = torch.Generator().manual_seed(seed)
+    return {"rgb": torch.randint(0, 256, (n, h, w, 3), generator=g, dtype=torch.uint8),
+            "depth": torch.rand((n, h, w, 1), generator=g, dtype=torch.float32),
+            "semantic": torch.randint(0, 40, (n, h, w, 1), generator=g, dtype=torch.int32)}

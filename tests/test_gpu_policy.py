@@ -496,3 +496,59 @@ def test_trainer_host_path_with_process_vector_env(shared_obs):
         assert all(np.isfinite(v) for v in losses.values()), losses
     finally:
         trainer.envs.close()
+
+
+@pytest.mark.gpu
+def test_trainer_host_path_applies_obs_transforms():
+    """N4 in the loop: 96x128 sensors from worker processes -> ResizeShortestEdge(64) -> CenterCropper(64) on the device -> the
+    policy and the rollout storage are built for 64x64, and the stored rows equal the oracle's transform of what the envs emitted."""
+    from habitat_amd.config.default import get_config
+    from habitat_amd.common.baseline_registry import baseline_registry
+    from habitat_amd.core.host_env import make_host_env
+    import habitat_amd.rl.ppo.ppo_trainer  # noqa: F401
+    N, T = 2, 3
+    pre = "habitat_baselines.rl.policy.main_agent.obs_transforms"
+    ov = [f"habitat_baselines.num_environments={N}", f"habitat_baselines.rl.ppo.num_steps={T}", "habitat_baselines.num_updates=2",
+          "habitat_baselines.total_num_steps=-1", "habitat_baselines.num_checkpoints=-1", "habitat_baselines.checkpoint_interval=1000000",
+          "habitat_baselines.rl.ppo.hidden_size=64", "habitat_baselines.checkpoint_folder=/tmp/habitat_amd_test_ckpt",
+          "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000",
+          "habitat_baselines.vector_env_factory._target_=habitat_amd.common.env_factory.ProcessVectorEnvFactory",
+          f"{pre}.resize.type=ResizeShortestEdge", f"{pre}.resize.size=64",
+          f"{pre}.crop.type=CenterCropper", f"{pre}.crop.height=64", f"{pre}.crop.width=64"]
+    for sname in ("rgb", "depth"):
+        ov += [f"habitat.simulator.sensors.{sname}.height=96", f"habitat.simulator.sensors.{sname}.width=128"]
+    cfg = get_config("pointnav/ppo_pointnav_example.yaml", ov)
+    cfg.habitat.simulator.sensors.pop("semantic", None)
+    trainer = baseline_registry.get_trainer(cfg.habitat_baselines.trainer_name)(cfg)
+    trainer._init_train()
+    try:
+        B = trainer._agent.rollouts.buffers
+        assert tuple(B["observations"]["rgb"].shape[2:]) == (64, 64, 3) and tuple(B["observations"]["depth"].shape[2:]) == (64, 64, 1)
+        trainer._agent.eval()
+        assert trainer.collect_rollout() == N * T
+        local = [make_host_env(int(cfg.habitat.seed) + i, 96, 128, True, True, len(cfg.habitat.task.actions),
+                               int(cfg.habitat.environment.max_episode_steps)) for i in range(N)]
+
+        def tf(o):
+            out = {}
+            for k in ("rgb", "depth"):
+                r = O.resize_shortest_edge(torch.from_numpy(o[k]).unsqueeze(0), 64)
+                out[k] = O.center_crop(r, 64)[0].numpy()
+            return out
+
+        obs = [e.reset() for e in local]
+        for i in range(N):
+            for k, v in tf(obs[i]).items():
+                assert np.array_equal(B["observations"][k][0, i].cpu().numpy(), v), (0, i, k)
+        for t in range(T):
+            acts = B["actions"][t].cpu().numpy().reshape(N)
+            for i, e in enumerate(local):
+                o, _, d, _ = e.step(int(acts[i]))
+                if d:
+                    o = e.reset()
+                for k, v in tf(o).items():
+                    assert np.array_equal(B["observations"][k][t + 1, i].cpu().numpy(), v), (t, i, k)
+        losses = trainer._update_agent()
+        assert all(np.isfinite(v) for v in losses.values()), losses
+    finally:
+        trainer.envs.close()
