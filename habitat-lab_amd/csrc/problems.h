@@ -72,6 +72,17 @@ struct ConvGeom {
 struct DmaTile { const float* base; uint32_t records; int origin; };
 HAB_HD uint32_t dma_records(size_t bytes) { return bytes > 0x7fffffffull ? 0x7fffffffu : (uint32_t)bytes; }
 
+// Validity mask of a KH x KW tap window (bit kh*KW + kw) when the valid taps form the rectangle [r_lo, r_hi) x [c_lo, c_hi):
+// (bits of one tap row) * (one bit per valid tap row) -- the product has no carries because the row pattern is < 2^KW.
+// Replaces a KH*KW loop of bounds tests in the prologue of every DMA-staged tile (fp32 MFMA shares its issue port with the VALU).
+HAB_HD uint32_t tap_rect_mask(int r_lo, int r_hi, int c_lo, int c_hi, int KW) {
+    if (r_lo >= r_hi || c_lo >= c_hi) return 0u;
+    const uint32_t cols = ((1u << (c_hi - c_lo)) - 1u) << c_lo;   // KW <= 31
+    uint32_t rows = 0;
+    for (int r = r_lo; r < r_hi; ++r) rows |= 1u << (r * KW);      // <= KH iterations of one OR
+    return cols * rows;
+}
+
 // A weight matrix row-major [rows][K] consumed as the r-contiguous B operand.
 struct WRowCtx { const float* row; int ok; };
 
@@ -169,7 +180,7 @@ struct ConvFwdProb {
         return r;
     }
     // ---- LDS-DMA interface (igemm_dma.h): C % 32 == 0 so a K-tile is 32 channels of ONE filter tap ----
-    HAB_HD bool dma_ok() const { return (g.C % 32 == 0) && (g.KH * g.KW <= 32) && ((size_t)g.H * g.W * g.C * 4 * 64 < 0x7fffffffull); }
+    HAB_HD bool dma_ok() const { return (g.C % 32 == 0) && (g.KH * g.KW <= 32) && (g.KW < 32) && ((size_t)g.H * g.W * g.C * 4 * 64 < 0x7fffffffull); }
     HAB_HD DmaTile dma_a_tile(int m0) const {
         DmaTile t;
         t.origin = g.dHoWo.div(m0 < M ? m0 : M - 1);  // first image of the tile
@@ -185,9 +196,8 @@ struct ConvFwdProb {
         g.dHoWo.divmod(m, img, rem);
         g.dWo.divmod(rem, ho, wo);
         const int h0 = ho * g.stride - g.pad, w0 = wo * g.stride - g.pad;
-        for (int kh = 0; kh < g.KH; ++kh)
-            for (int kw = 0; kw < g.KW; ++kw)
-                if ((unsigned)(h0 + kh) < (unsigned)g.H && (unsigned)(w0 + kw) < (unsigned)g.W) mask |= 1u << (kh * g.KW + kw);
+        // tap (kh, kw) is inside the image for kh in [-h0, H - h0) and kw in [-w0, W - w0), clipped to the kernel
+        mask = tap_rect_mask(h0 < 0 ? -h0 : 0, g.H - h0 < g.KH ? g.H - h0 : g.KH, w0 < 0 ? -w0 : 0, g.W - w0 < g.KW ? g.W - w0 : g.KW, g.KW);
         return (uint32_t)((((img - t.origin) * g.H + h0 + g.pad) * g.W + w0 + g.pad) * g.C) * 4u;
     }
     HAB_HD void dma_tap(int k0, int& tap, uint32_t& sa, uint32_t& sb) const {
@@ -483,7 +493,7 @@ struct ConvDgradProb {
     }
     // ---- LDS-DMA interface (igemm_dma.h): Cout % 32 == 0 so a K-tile is 32 output channels of ONE tap of the class ----
     HAB_HD bool dma_ok() const {
-        return (g.Cout % 32 == 0) && (KHs * KWs <= 32) && (K % 32 == 0) && ((size_t)g.Ho * g.Wo * g.Cout * 4 * 64 < 0x7fffffffull);
+        return (g.Cout % 32 == 0) && (KHs * KWs <= 32) && (KWs < 32) && (K % 32 == 0) && ((size_t)g.Ho * g.Wo * g.Cout * 4 * 64 < 0x7fffffffull);
     }
     HAB_HD DmaTile dma_a_tile(int m0) const {
         DmaTile t;
@@ -500,9 +510,9 @@ struct ConvDgradProb {
         dHcWc.divmod(m, img, rem);
         dWc.divmod(rem, hc, wc);
         const int hq = (h_first + hc * g.stride + g.pad - ph) / g.stride, wq = (w_first + wc * g.stride + g.pad - pw) / g.stride;
-        for (int a = 0; a < KHs; ++a)
-            for (int b = 0; b < KWs; ++b)
-                if ((unsigned)(hq - a) < (unsigned)g.Ho && (unsigned)(wq - b) < (unsigned)g.Wo) mask |= 1u << (a * KWs + b);
+        // tap (a, b) reads dY row hq - a in [0, Ho): a in (hq - Ho, hq], clipped to the class's taps; likewise b
+        mask = tap_rect_mask(hq - g.Ho + 1 > 0 ? hq - g.Ho + 1 : 0, hq + 1 < KHs ? hq + 1 : KHs,
+                             wq - g.Wo + 1 > 0 ? wq - g.Wo + 1 : 0, wq + 1 < KWs ? wq + 1 : KWs, KWs);
         return (uint32_t)((((img - t.origin) * g.Ho + hq) * g.Wo + wq) * g.Cout) * 4u;
     }
     HAB_HD void dma_tap(int k0, int& tap, uint32_t& sa, uint32_t& sb) const {
@@ -610,7 +620,7 @@ struct ConvDgradMergedProb {
         M = g.B * Hq * Wq; N = s * s * g.C; K = KHs * KWs * g.Cout;
         dHqWq = FastDiv(Hq * Wq); dWq = FastDiv(Wq); dKWs = FastDiv(KWs);
     }
-    HAB_HD bool dma_ok() const { return (KHs * KWs <= 32) && ((size_t)g.Ho * g.Wo * g.Cout * 4 * 64 < 0x7fffffffull); }
+    HAB_HD bool dma_ok() const { return (KHs * KWs <= 32) && (KWs < 32) && ((size_t)g.Ho * g.Wo * g.Cout * 4 * 64 < 0x7fffffffull); }
     HAB_HD DmaTile dma_a_tile(int m0) const {
         DmaTile t;
         t.origin = dHqWq.div(m0 < M ? m0 : M - 1);
@@ -625,9 +635,8 @@ struct ConvDgradMergedProb {
         int img, rem, hq, wq;
         dHqWq.divmod(m, img, rem);
         dWq.divmod(rem, hq, wq);
-        for (int a = 0; a < KHs; ++a)
-            for (int b = 0; b < KWs; ++b)
-                if ((unsigned)(hq - a) < (unsigned)g.Ho && (unsigned)(wq - b) < (unsigned)g.Wo) mask_ |= 1u << (a * KWs + b);
+        mask_ = tap_rect_mask(hq - g.Ho + 1 > 0 ? hq - g.Ho + 1 : 0, hq + 1 < KHs ? hq + 1 : KHs,
+                              wq - g.Wo + 1 > 0 ? wq - g.Wo + 1 : 0, wq + 1 < KWs ? wq + 1 : KWs, KWs);
         return (uint32_t)((((img - t.origin) * g.Ho + hq) * g.Wo + wq) * g.Cout) * 4u;
     }
     HAB_HD void dma_tap(int k0, int& tap, uint32_t& sa, uint32_t& sb) const {
