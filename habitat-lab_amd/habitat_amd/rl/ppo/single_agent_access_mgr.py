@@ -5,6 +5,8 @@ from __future__ import annotations
 from typing import Any, Callable, Dict, Optional
 
 import torch
+
+from habitat_amd import _lib
 from torch.optim.lr_scheduler import LambdaLR
 
 from habitat_amd.common.baseline_registry import baseline_registry
@@ -64,9 +66,11 @@ class SingleAgentAccessMgr:
                 own.update({"net.visual_encoder." + k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
                 actor_critic.load_state_dict(own)
         if self._is_static_encoder:
-            for n, p in actor_critic.named_parameters():
-                if n.startswith("net.visual_encoder."):
-                    p.requires_grad_(False)
+            # rl.ddppo.train_encoder=False (single_agent_access_mgr.py:213-216 + the `visual_features` rollout key of
+            # ppo_trainer.py:261-279): the fused update trains every parameter of the flat arena, so a frozen encoder must be
+            # refused rather than silently trained (not built yet).
+            raise _lib.HabError("habitat_baselines.rl.ddppo.train_encoder=False (frozen visual encoder) is not supported by the "
+                                "accelerated path yet")
         if dd.reset_critic and (dd.pretrained or dd.pretrained_encoder):
             torch.nn.init.orthogonal_(actor_critic._modules["critic"]._modules["fc"].weight)
             torch.nn.init.constant_(actor_critic._modules["critic"]._modules["fc"].bias, 0)
