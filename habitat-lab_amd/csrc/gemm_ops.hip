@@ -16,6 +16,12 @@ namespace hab {
 // huge reduction: the 96-row tile (3 waves) avoids padding M = 288 / 576 / 1152 (3x3 taps x 32..128 channels).
 template <class P>
 static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream, int target_blocks = 1024) {
+    // Split-K target.  Forward-form problems (activations x weights) split only until there is one workgroup per CU: their
+    // split-K second pass re-reads M*N*splits floats and, at rollout batch sizes, costs more than the idle CUs it fills
+    // (measured: target 1024 -> 256 is +4 % on C2, +6 % on C3, all of it in the 64-frame rollout forward passes).  Weight
+    // gradients (tiny M*N, K in the millions) keep the deeper split.
+    if (P::A_RC || P::B_RC) target_blocks = 256;
+    if (const char* tb = getenv("HAB_TARGET_BLOCKS_WG")) { if (!P::A_RC && !P::B_RC) target_blocks = atoi(tb); }
     constexpr bool WG = !P::A_RC && !P::B_RC && AKv<P>::value == 4;  // weight-gradient form
     if constexpr (std::is_same_v<P, ConvFwdProb> || std::is_same_v<P, ConvDgradProb>) {
         if (p.dma_ok() && p.M > 64 && getenv("HAB_NO_DMA") == nullptr) {  // LDS-DMA staged variant (igemm_dma.h)
