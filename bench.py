@@ -21,6 +21,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL between ranks needs it)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "habitat-lab_amd"))
 sys.path.insert(0, ROOT)
@@ -36,6 +37,10 @@ WORKLOADS = {
     # BASELINE.json configs[2]: ResNet18 + 2-layer LSTM with the ddppo_pointnav.yaml hyper-parameters (E=2, M=2)
     "c3": dict(yaml="pointnav/ddppo_pointnav.yaml", name="PointNav ResNet18+LSTM, 64 envs x 128 steps, 256x256 RGB-D synthetic",
                overrides=["habitat_baselines.rl.ddppo.backbone=resnet18"]),
+    # configs[2] with rl.ddppo.train_encoder=False: the rollout stores `visual_features`, the update never runs the encoder
+    "c3_frozen": dict(yaml="pointnav/ddppo_pointnav.yaml",
+                      name="PointNav ResNet18+LSTM, frozen encoder (visual_features), 64 envs x 128 steps, 256x256 RGB-D synthetic",
+                      overrides=["habitat_baselines.rl.ddppo.backbone=resnet18", "habitat_baselines.rl.ddppo.train_encoder=False"]),
     # BASELINE.json configs[4] (per GPU): ObjectNav ResNet50 on rgb + depth + semantic, 32 envs x 64 steps, E=4, M=2
     "c5": dict(yaml="objectnav/ddppo_objectnav.yaml", name="ObjectNav ResNet50+LSTM RGB-D+semantic, 32 envs x 64 steps, 256x256 synthetic",
                overrides=["habitat.simulator.sensors.semantic.height=256", "habitat.simulator.sensors.semantic.width=256"],
@@ -150,7 +155,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     if a.probe is None:
-        a.probe = "conv2_dgrad" if a.workload == "c2" else "enc_bwd"
+        a.probe = "conv2_dgrad" if a.workload == "c2" else ("enc_fwd" if a.workload == "c3_frozen" else "enc_bwd")
     if a.workload == "c5" and a.probe.startswith("enc_"):
         # ResNet50 on 5 channels: 375.0 MMAC forward (a5); the stem's data gradient (7x7x8 pad -> 5 real ch) is not computed
         PROBES["enc_fwd"], PROBES["enc_bwd"] = (11, 2.0 * 375.0e6), (12, 2.0 * (2 * 375.0e6 - 32.1e6))

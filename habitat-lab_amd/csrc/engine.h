@@ -85,6 +85,8 @@ inline int add_param(hab_policy* e, const std::string& name, std::initializer_li
 int build_resnet(hab_policy* e);
 void destroy_resnet(hab_policy* e);
 int resnet_repack(hab_policy* e, hipStream_t s);
+int resnet_feature_shape(const hab_policy* e, int* c, int* hf, int* wf);
+int resnet_encode(hab_policy* e, const hab_obs* obs, int n, float* out, hipStream_t s);
 int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s);
 int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s);
 int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats);

@@ -241,6 +241,18 @@ static RnnWork layer_work(hab_policy* e, int l) {
     return wk;
 }
 
+extern "C" int hab_policy_encode(hab_policy* e, const hab_obs* obs, int n, float* out, hipStream_t stream) {
+    if (!e || !e->P || !obs || !out || n <= 0 || n > e->d.max_frames) return HAB_ERR_ARG;
+    if (!e->rn) return HAB_ERR_UNSUPPORTED;  // the baseline net has no visual_features input (rl/ppo/policy.py:557-589)
+    Probe pr(e, HAB_PROBE_ENC_FWD, stream);
+    return resnet_encode(e, obs, n, out, stream);
+}
+extern "C" int hab_policy_visual_feature_shape(const hab_policy* e, int* c, int* hf, int* wf) {
+    if (!e || !c || !hf || !wf) return HAB_ERR_ARG;
+    if (!e->rn) return HAB_ERR_UNSUPPORTED;
+    return resnet_feature_shape(e, c, hf, wf);
+}
+
 // ------------------------------------------------------------------------------------------
 // NetPolicy.act / get_value (rl/ppo/policy.py:324-359) on n envs, all tensors dense over envs.
 // hidden_in/out: (n, Lh, H) with Lh = layers (GRU) or 2*layers (LSTM: h layers then c layers).

@@ -52,7 +52,7 @@ struct ResNetPlan {
     int c_rgb = -1, c_depth = -1, c_sem = -1;  // first channel of each visual key in the concatenated encoder input
     int nslots = 0;
     int64_t pk_fc = -1;
-    int fc_in = 0, comp_c = 0, comp_hw = 0;
+    int fc_in = 0, comp_c = 0, comp_hw = 0, comp_fh = 0, comp_fw = 0;
     // gradient scratch
     int64_t w_gstem[2] = {-1, -1};
     std::vector<int64_t> w_gbuf;
@@ -179,7 +179,7 @@ int build_resnet(hab_policy* e) {
     r->comp.cd = ConvDesc{0, curH, curW, inplanes, ncomp, 3, 3, 1, 1};
     r->comp.groups = 1;
     add_conv_gn(e, r->comp, ve + "compression.0", ve + "compression.1", inplanes);
-    r->comp_c = ncomp; r->comp_hw = fh * fw; r->fc_in = ncomp * fh * fw;
+    r->comp_c = ncomp; r->comp_hw = fh * fw; r->comp_fh = fh; r->comp_fw = fw; r->fc_in = ncomp * fh * fw;
     r->i_fcw = add_param(e, "net.visual_fc.1.weight", {H, r->fc_in});
     r->i_fcb = add_param(e, "net.visual_fc.1.bias", {H});
     e->fc_in = r->fc_in;
@@ -324,11 +324,74 @@ static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, cons
     return groupnorm_forward(g, s);
 }
 
+// (rows, C, HW) NCHW features of the rollout -> dense NHWC [B][HW][C] (the layout of the compression output), and back.
+__global__ void feats_nchw_to_nhwc_kernel(const float* __restrict__ src, const int* __restrict__ rows, float* __restrict__ dst,
+                                          int B, int C, int HW) {
+    const long long total = (long long)B * C * HW;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const long long t = e / C;
+        const int p = (int)(t % HW), f = (int)(t / HW);
+        dst[e] = src[((size_t)(rows ? rows[f] : f) * C + c) * HW + p];
+    }
+}
+__global__ void feats_nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int HW) {
+    const long long total = (long long)B * C * HW;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(e % HW);
+        const long long t = e / HW;
+        const int c = (int)(t % C), f = (int)(t / C);
+        dst[e] = src[((size_t)f * HW + p) * C + c];
+    }
+}
+
+static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int* rows, int B, hipStream_t s);
+
+int resnet_feature_shape(const hab_policy* e, int* c, int* hf, int* wf) {
+    const ResNetPlan* r = e->rn;
+    *c = r->comp_c; *hf = r->comp_fh; *wf = r->comp_fw;
+    return HAB_OK;
+}
+
+// ResNetEncoder.forward alone: obs -> (n, C, Hf, Wf) NCHW (hab_policy_encode)
+int resnet_encode(hab_policy* e, const hab_obs* obs, int n, float* out, hipStream_t s) {
+    ResNetPlan* r = e->rn;
+    HAB_TRY(resnet_backbone_forward(e, obs, nullptr, n, s));
+    const long long total = (long long)n * r->fc_in;
+    feats_nhwc_to_nchw_kernel<<<(int)cdivl(total, 256), 256, 0, s>>>(e->WK + r->comp.w_out, out, n, r->comp_c, r->comp_hw);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
 int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s) {
     ResNetPlan* r = e->rn;
     float* W = e->WK;
+    const int H = e->d.hidden;
+    if (obs->visual_features) {  // frozen encoder: the rollout already holds its output (resnet_policy.py:636-646)
+        const long long total = (long long)B * r->fc_in;
+        feats_nchw_to_nhwc_kernel<<<(int)cdivl(total, 256), 256, 0, s>>>(obs->visual_features, rows, W + r->comp.w_out, B, r->comp_c,
+                                                                         r->comp_hw);
+        HAB_LAUNCH_CHECK();
+    } else {
+        HAB_TRY(resnet_backbone_forward(e, obs, rows, B, s));
+    }
+    // visual_fc (Flatten in NCHW order -> packed weight is permuted) + ReLU, written into rnn_in[:, :H]
+    float* ws = W + e->w_ws;
+    HAB_TRY(linear_fwd(W + r->comp.w_out, r->fc_in, e->PK + r->pk_fc, r->fc_in, e->p(r->i_fcb), W + e->w_rnnin, e->rnn_ld, B, H,
+                       r->fc_in, 1, 0, ws, e->ws_floats, s));
+    EmbedArgs ea;
+    HAB_TRY(fill_embed_slots(e, obs, ea.slot, false));
+    ea.nslots = r->nslots; ea.masks = masks; ea.rows = rows;
+    ea.out = W + e->w_rnnin; ea.ld = e->rnn_ld; ea.col0 = H; ea.B = B; ea.saved = W + r->w_embsave;
+    if (!masks) return HAB_ERR_ARG;
+    return embed_forward(ea, s);
+}
+
+// input normalisation + backbone + compression: obs -> comp.w_out [B][Hf*Wf][C]
+static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int* rows, int B, hipStream_t s) {
+    ResNetPlan* r = e->rn;
+    float* W = e->WK;
     const hab_policy_desc& d = e->d;
-    const int H = d.hidden;
     float* x0 = W + r->w_x0;
     if ((d.has_rgb && !obs->rgb) || (d.has_depth && !obs->depth) || (d.has_semantic && !obs->semantic)) return HAB_ERR_ARG;
     HAB_TRY(ingest_pool(d.has_rgb ? obs->rgb : nullptr, d.has_depth ? obs->depth : nullptr, d.has_semantic ? obs->semantic : nullptr, rows,
@@ -368,17 +431,7 @@ int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
             cur = W + c.w_out;
         }
     }
-    HAB_TRY(conv_gn_forward(e, r->comp, W + r->blocks.back().w_out, nullptr, 1, B, s));
-    // visual_fc (Flatten in NCHW order -> packed weight is permuted) + ReLU, written into rnn_in[:, :H]
-    float* ws = W + e->w_ws;
-    HAB_TRY(linear_fwd(W + r->comp.w_out, r->fc_in, e->PK + r->pk_fc, r->fc_in, e->p(r->i_fcb), W + e->w_rnnin, e->rnn_ld, B, H,
-                       r->fc_in, 1, 0, ws, e->ws_floats, s));
-    EmbedArgs ea;
-    HAB_TRY(fill_embed_slots(e, obs, ea.slot, false));
-    ea.nslots = r->nslots; ea.masks = masks; ea.rows = rows;
-    ea.out = W + e->w_rnnin; ea.ld = e->rnn_ld; ea.col0 = H; ea.B = B; ea.saved = W + r->w_embsave;
-    if (!masks) return HAB_ERR_ARG;
-    return embed_forward(ea, s);
+    return conv_gn_forward(e, r->comp, W + r->blocks.back().w_out, nullptr, 1, B, s);
 }
 
 namespace {
@@ -429,6 +482,7 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
     HAB_TRY(linear_wgrad(dfc, e->rnn_ld, W + r->comp.w_out, r->fc_in, e->g(r->i_fcw), r->fc_in, B, H, r->fc_in, r->comp_c, r->comp_hw,
                          0, ws, e->ws_floats, s));
     HAB_TRY(colsum(dfc, e->rnn_ld, B, H, e->g(r->i_fcb), 0, ws, e->ws_floats, s));
+    if (obs->visual_features) return HAB_OK;  // frozen encoder: its parameters get no gradient (the arena slots stay zero)
     float* d_comp = gp.get();  // gradient wrt compression output, masked by its ReLU
     HAB_TRY(linear_dgrad(dfc, e->rnn_ld, e->PK + r->pk_fc, r->fc_in, W + r->comp.w_out, r->fc_in, r->fc_in, d_comp, r->fc_in, B,
                          r->fc_in, H, 0, ws, e->ws_floats, s));

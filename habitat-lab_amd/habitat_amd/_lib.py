@@ -29,7 +29,7 @@ class PolicyDesc(C.Structure):
 
 class Obs(C.Structure):
     _fields_ = [("rgb", vp), ("depth", vp), ("goal", vp), ("prev_actions", vp), ("semantic", vp), ("objectgoal", vp), ("compass", vp),
-                ("gps", vp)]
+                ("gps", vp), ("visual_features", vp)]
 
 
 class EmbedSlot(C.Structure):
@@ -91,6 +91,8 @@ SIGNATURES = {
     "hab_policy_work_floats": (c_int64, [vp]),
     "hab_policy_bind": (c_int, [vp, vp, vp, vp, vp, c_int64]),
     "hab_policy_repack": (c_int, [vp, vp]),
+    "hab_policy_encode": (c_int, [vp, POINTER(Obs), c_int, vp, vp]),
+    "hab_policy_visual_feature_shape": (c_int, [vp, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "hab_policy_act": (c_int, [vp, POINTER(Obs), vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp, vp]),
     "hab_policy_evaluate": (c_int, [vp, POINTER(Obs), vp, vp, c_int, vp, vp, POINTER(PackInfo), c_int, c_int, vp, vp, vp, vp]),
     "hab_policy_final_hidden": (c_int, [vp, vp, vp]),

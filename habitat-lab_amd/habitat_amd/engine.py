@@ -164,7 +164,19 @@ class PolicyEngine:
         dp = lambda t: t.data_ptr() if t is not None else None
         e = extra or {}
         return Obs(dp(rgb), dp(depth), dp(goal), dp(prev_actions), dp(e.get("semantic")), dp(e.get("objectgoal")), dp(e.get("compass")),
-                   dp(e.get("gps")))
+                   dp(e.get("gps")), dp(e.get("visual_features")))
+
+    def visual_feature_shape(self):
+        """(C, Hf, Wf) = ResNetEncoder.output_shape (resnet_policy.py:235-253)."""
+        c, h, w = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self.L.hab_policy_visual_feature_shape(self.h, C.byref(c), C.byref(h), C.byref(w)), "hab_policy_visual_feature_shape")
+        return (c.value, h.value, w.value)
+
+    def encode(self, rgb, depth, n, out, extra=None):
+        """The visual encoder alone on n frames -> out (n, C, Hf, Wf)."""
+        self._fresh()
+        o = self._obs(rgb, depth, None, None, extra)
+        check(self.L.hab_policy_encode(self.h, C.byref(o), n, ptr(out), stream_ptr()), "hab_policy_encode")
 
     def act(self, rgb, depth, goal, hidden_in, masks, n, *, exp_noise=None, deterministic=False, values, actions=None,
             action_log_probs=None, hidden_out=None, probs_out=None, prev_actions=None, extra=None):

@@ -23,6 +23,7 @@ from habitat_amd.common.baseline_registry import baseline_registry
 from habitat_amd.common.spaces import get_num_actions
 from habitat_amd.engine import DevicePackInfo, PolicyEngine
 
+VISUAL_FEATURES_KEY = "visual_features"  # PointNavResNetNet.PRETRAINED_VISUAL_FEATURES_KEY (resnet_policy.py:399)
 GOAL_UUID = "pointgoal_with_gps_compass"  # IntegratedPointGoalGPSAndCompassSensor.cls_uuid (tasks/nav/nav.py:309)
 
 
@@ -217,12 +218,33 @@ class NetPolicy(nn.Module, Policy):
             if nm in eng.buffer_names:
                 m._buffers[leaf] = eng.views[nm]
                 continue
-            par = nn.Parameter(eng.views[nm])
-            par.grad = eng.grad_views[nm]
+            par = nn.Parameter(eng.views[nm], requires_grad=m._parameters[leaf].requires_grad)
+            if par.requires_grad:
+                par.grad = eng.grad_views[nm]
             m._parameters[leaf] = par
         self.engine, self.device = eng, device
         eng.set_training(self.training)
+        ve = self.visual_encoder
+        if ve is not None and self._engine_kwargs.get("arch") == "resnet":
+            # the reference calls `actor_critic.visual_encoder(batch)` and reads `.output_shape` (ppo_trainer.py:271-279)
+            ve.output_shape = eng.visual_feature_shape()
+            ve.forward = self.encode_visual
         return self
+
+    @torch.no_grad()
+    def encode_visual(self, observations, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ResNetEncoder.forward alone (resnet_policy.py:255-276): (n, C, Hf, Wf), what the rollout stores under
+        `visual_features` when the encoder is frozen.  RunningMeanAndVar follows the module's training flag."""
+        eng = self._require_engine()
+        obs = {k: v for k, v in observations.items() if k != VISUAL_FEATURES_KEY}
+        rgb, depth, _, extra = self._obs_ptrs(obs)
+        ref = rgb if rgb is not None else depth
+        n = ref.shape[0]
+        if out is None:
+            out = torch.empty((n,) + tuple(eng.visual_feature_shape()), device=self.device)
+        assert out.is_contiguous() and out.shape[0] == n
+        eng.encode(rgb, depth, n, out, extra=extra)
+        return out
 
     def train(self, mode: bool = True):
         """nn.Module.train / eval: the engine's RunningMeanAndVar only updates in training mode."""
@@ -258,8 +280,10 @@ class NetPolicy(nn.Module, Policy):
             extra["compass"] = observations["compass"]
         if kw.get("has_gps"):
             extra["gps"] = observations["gps"]
+        if VISUAL_FEATURES_KEY in observations:  # frozen encoder: the rollout holds its output (resnet_policy.py:636-646)
+            extra["visual_features"] = observations[VISUAL_FEATURES_KEY]
         want = {"rgb": torch.uint8, "depth": torch.float32, "goal": torch.float32, "semantic": torch.int32, "objectgoal": torch.int64,
-                "compass": torch.float32, "gps": torch.float32}
+                "compass": torch.float32, "gps": torch.float32, "visual_features": torch.float32}
         for name, t in dict(rgb=rgb, depth=depth, goal=goal, **extra).items():
             if t is None:
                 continue

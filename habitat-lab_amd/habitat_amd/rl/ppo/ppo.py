@@ -160,7 +160,7 @@ class PPO(nn.Module, Updater):
         obs = Bf["observations"]
         rgb, depth = obs.get("rgb"), obs.get("depth")
         goal = obs.get("pointgoal_with_gps_compass")
-        extra = {k: obs[k] for k in ("semantic", "objectgoal", "compass", "gps") if k in obs}
+        extra = {k: obs[k] for k in ("semantic", "objectgoal", "compass", "gps", "visual_features") if k in obs}
         Bn, n = batch.T * batch.n, batch.n
         w = self._work(Bn)
         eng.evaluate(rgb, depth, goal, batch.rows, Bf["recurrent_hidden_states"], Bf["masks"], Bf["actions"], batch.pack, Bn, n,

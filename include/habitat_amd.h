@@ -263,6 +263,10 @@ typedef struct hab_obs {   /* arena base pointers; frame f lives at row rows[f] 
     const int64_t* objectgoal;   /* (rows, 1) */
     const float* compass;        /* (rows, 1) */
     const float* gps;            /* (rows, 2) */
+    const float* visual_features; /* arch 1, optional: (rows, C, Hf, Wf) output of the visual encoder stored by the rollout
+                                    (PointNavResNetNet.PRETRAINED_VISUAL_FEATURES_KEY, resnet_policy.py:399,636-646: frozen-encoder
+                                    training, rl.ddppo.train_encoder=False).  When non-NULL, act / evaluate use it instead of running
+                                    the encoder and backward stops at visual_fc (no encoder gradients are written). */
 } hab_obs;
 
 typedef struct hab_pack_info { /* int32 copies of hab_build_pack_info's arrays */
@@ -297,6 +301,12 @@ int hab_policy_set_training(hab_policy* p, int training);
 typedef void (*hab_allreduce_fn)(float* buf, int n, float scale, void* ctx);
 int hab_policy_set_allreduce(hab_policy* p, hab_allreduce_fn fn, void* ctx, int world_size);
 /* actions == NULL -> get_value only.  hidden_*: (n, Lh, H), Lh = layers (GRU) / 2*layers (LSTM). */
+/* The visual encoder alone (ResNetEncoder.forward, resnet_policy.py:255-276) on n frames: out (n, C, Hf, Wf) fp32 NCHW, the tensor
+ * ppo_trainer.py:271-279,467-471 stores under "visual_features" when the encoder is frozen.  Uses the current training flag
+ * (RunningMeanAndVar statistics are updated iff training, exactly like calling the module).  arch 1 only. */
+int hab_policy_encode(hab_policy* p, const hab_obs* obs, int n, float* out, hipStream_t stream);
+/* (C, Hf, Wf) of that tensor = ResNetEncoder.output_shape. */
+int hab_policy_visual_feature_shape(const hab_policy* p, int* c, int* hf, int* wf);
 int hab_policy_act(hab_policy* p, const hab_obs* obs, const float* hidden_in, const uint8_t* masks,
                    const float* exp_noise, int deterministic, int n, float* values, int64_t* actions,
                    float* action_log_probs, float* hidden_out, float* probs_out /* (n,8) or NULL */, hipStream_t stream);

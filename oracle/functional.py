@@ -260,8 +260,11 @@ def net_forward(params: Params, spec: NetSpec, obs, hidden_bf, prev_actions, mas
         vis = simple_cnn(params, "net.visual_encoder.cnn.", obs, taps)
         x = torch.cat([vis, obs[GOAL_UUID]], dim=1)
     else:
-        feats = resnet_encoder(params, "net.visual_encoder.", {k: obs[k] for k in spec.visual_keys}, spec.visual_keys, spec.backbone,
-                               spec.baseplanes, training, spec.normalize, taps, rmv_out)
+        if "visual_features" in obs:  # frozen encoder: PRETRAINED_VISUAL_FEATURES_KEY, resnet_policy.py:636-646
+            feats = obs["visual_features"]
+        else:
+            feats = resnet_encoder(params, "net.visual_encoder.", {k: obs[k] for k in spec.visual_keys}, spec.visual_keys, spec.backbone,
+                                   spec.baseplanes, training, spec.normalize, taps, rmv_out)
         vis = F.relu(F.linear(feats.flatten(1), params["net.visual_fc.1.weight"], params["net.visual_fc.1.bias"]))
         parts = [vis]
         if GOAL_UUID in obs:
