@@ -321,6 +321,7 @@ static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, cons
     g.x = W + c.w_raw; g.y = W + c.w_out; g.gamma = e->p(c.i_gamma); g.beta = e->p(c.i_beta); g.residual = residual;
     g.mean = W + c.w_mean; g.rstd = W + c.w_rstd; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = c.groups;
     g.relu = relu; g.eps = 1e-5f;
+    g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;  // chunk-parallel statistics for frames > 128 KB
     return groupnorm_forward(g, s);
 }
 
@@ -459,6 +460,7 @@ static int gn_backward(hab_policy* e, const RnConv& c, const float* dy, const fl
     g.x = W + c.w_raw; g.dy = dy; g.relu_out = relu_out; g.dx = d_raw; g.dy_masked = dy_masked; g.gamma = e->p(c.i_gamma);
     g.mean = W + c.w_mean; g.rstd = W + c.w_rstd; g.chan_sums = W + r->w_chansums; g.B = B; g.HW = c.cd.Ho() * c.cd.Wo();
     g.C = c.cd.Cout; g.groups = c.groups;
+    g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
     HAB_TRY(groupnorm_backward(g, s));
     const int C = c.cd.Cout;
     HAB_TRY(colsum(W + r->w_chansums, 2 * C, B, C, e->g(c.i_beta), 0, W + e->w_ws, e->ws_floats, s));

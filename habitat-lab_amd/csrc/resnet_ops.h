@@ -11,6 +11,8 @@ struct GnArgs {
     float* mean; float* rstd;           // [B][groups] saved for backward
     int B, HW, C, groups, relu;
     float eps;
+    float* scratch = nullptr;           // optional: partial statistics of the chunk-parallel path for frames > 128 KB
+    size_t scratch_floats = 0;          //   (>= B * ceil(HW*C / 16384) * groups * 2 floats), else the streaming kernel runs
 };
 struct GnBwdArgs {
     const float* x; const float* dy; const float* relu_out;  // relu_out: output of the fused ReLU (mask), or null
@@ -19,6 +21,8 @@ struct GnBwdArgs {
     const float* gamma; const float* mean; const float* rstd;
     float* chan_sums;                   // [B][2][C]: per-frame sum dy', sum dy'*xhat
     int B, HW, C, groups;
+    float* scratch = nullptr;           // optional, >= B * ceil(HW*C / 8192) * 2 * C floats (chunk-parallel path)
+    size_t scratch_floats = 0;
 };
 // 1-D sensor embeddings of PointNavResNetNet.forward (resnet_policy.py:662-753), each 32 wide, written side by side into
 // the RNN input.  Slot kinds:

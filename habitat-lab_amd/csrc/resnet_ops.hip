@@ -470,6 +470,258 @@ __global__ void __launch_bounds__(NT) groupnorm_bwd_reg_kernel(const GnBwdArgs a
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Chunk-parallel GroupNorm for frames that do not fit one workgroup's registers (> 128 KB: the 64x64x32 stem output, ResNet50's
+// 32x32x128 and 16x16x256 bottleneck outputs).  A frame is cut into chunks of NT*NV float4 (whole pixels); kernel 1 keeps its
+// chunk in registers and writes per-(chunk, group) partial statistics -- count is implied, (mean_k, M2_k) from an exact local
+// two-pass -- kernel 2 merges them with Chan's formula  M2 = sum M2_k + sum n_k (mean_k - mean)^2  (as accurate as a global
+// two-pass, fixed order) and applies.  HBM traffic 2 reads + 1 write instead of 3 + 1, and chunks x frames workgroups instead of
+// `frames` (a 32-frame rollout batch used 32 of 256 CUs).  Backward: kernel 1 = per-channel partial sums, kernel 2 = dx.
+// ------------------------------------------------------------------------------------------------------
+constexpr int GNC_NT = 256, GNC_NV_F = 16, GNC_NV_B = 8;
+
+template <int NT, int NV>
+__global__ void __launch_bounds__(NT) gn_chunk_stats_kernel(const GnArgs a, int nchunks, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
+    const int F4 = a.HW * C4;
+    const int f = blockIdx.x / nchunks, ck = blockIdx.x % nchunks, t = threadIdx.x, col = t & (C4 - 1);
+    const int base = ck * NT * NV;
+    float* red = sm;
+    float* ch = sm + NT * 4;
+    float* mu_s = ch + C;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + (size_t)f * a.HW * C);
+    f32x4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = base + t + j * NT;
+        v[j] = i < F4 ? x4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int len = min(NT * NV, F4 - base);             // float4s of this chunk (a multiple of C4: whole pixels)
+    const float inv_n = 1.0f / (float)((len / C4) * cpg);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += v[j];
+    gn_col_reduce<NT>(s, C4, red, ch, C, t);
+    if (t < G) {
+        float u = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) u += ch[c];
+        mu_s[t] = u * inv_n;
+    }
+    __syncthreads();
+    f32x4 mu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mu[k] = mu_s[(col * 4 + k) / cpg];
+    s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const f32x4 d = v[j] - mu;
+        if (base + t + j * NT < F4) s += d * d;
+    }
+    gn_col_reduce<NT>(s, C4, red, ch, C, t);
+    if (t < G) {
+        float u = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) u += ch[c];
+        float* o = part + ((size_t)blockIdx.x * G + t) * 2;
+        o[0] = mu_s[t];
+        o[1] = u;
+    }
+}
+
+template <int NT, int NV>
+__global__ void __launch_bounds__(NT) gn_chunk_apply_kernel(const GnArgs a, int nchunks, const float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
+    const int F4 = a.HW * C4;
+    const int f = blockIdx.x / nchunks, ck = blockIdx.x % nchunks, t = threadIdx.x, col = t & (C4 - 1);
+    const int base = ck * NT * NV;
+    float* mu_s = sm;
+    float* rs_s = sm + G;
+    if (t < G) {
+        const float* p = part + ((size_t)f * nchunks * G + t) * 2;
+        const float n = (float)(a.HW * cpg);
+        float mean = 0.f;
+        for (int k = 0; k < nchunks; ++k) {
+            const float nk = (float)((min(NT * NV, F4 - k * NT * NV) / C4) * cpg);
+            mean += nk * p[(size_t)k * G * 2];
+        }
+        mean /= n;
+        float m2 = 0.f;
+        for (int k = 0; k < nchunks; ++k) {
+            const float nk = (float)((min(NT * NV, F4 - k * NT * NV) / C4) * cpg);
+            const float d = p[(size_t)k * G * 2] - mean;
+            m2 += p[(size_t)k * G * 2 + 1] + nk * d * d;
+        }
+        const float rs = rsqrtf(m2 / n + a.eps);
+        mu_s[t] = mean;
+        rs_s[t] = rs;
+        if (ck == 0) { a.mean[(size_t)f * G + t] = mean; a.rstd[(size_t)f * G + t] = rs; }
+    }
+    __syncthreads();
+    f32x4 sc, sh;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = col * 4 + k, g = c / cpg;
+        sc[k] = rs_s[g] * a.gamma[c];
+        sh[k] = a.beta[c] - mu_s[g] * sc[k];
+    }
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + (size_t)f * a.HW * C);
+    f32x4* y4 = reinterpret_cast<f32x4*>(a.y + (size_t)f * a.HW * C);
+    const f32x4* r4 = a.residual ? reinterpret_cast<const f32x4*>(a.residual + (size_t)f * a.HW * C) : nullptr;
+    f32x4 v[NV], rr[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = base + t + j * NT;
+        v[j] = i < F4 ? x4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        rr[j] = (r4 && i < F4) ? r4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = base + t + j * NT;
+        f32x4 o = v[j] * sc + sh;
+        if (r4) o += rr[j];
+        if (a.relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
+        }
+        if (i < F4) y4[i] = o;
+    }
+}
+
+// backward, kernel 1: per-channel partial sums S1 = sum dy', S2 = sum dy' * xhat of the chunk (+ optional dy' write-out)
+template <int NT, int NV>
+__global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a, int nchunks, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
+    const int F4 = a.HW * C4;
+    const int f = blockIdx.x / nchunks, ck = blockIdx.x % nchunks, t = threadIdx.x, col = t & (C4 - 1);
+    const int base = ck * NT * NV;
+    float* red = sm;
+    float* c1 = sm + NT * 4;
+    const size_t fb = (size_t)f * a.HW * C;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + fb);
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(a.dy + fb);
+    const f32x4* ro4 = a.relu_out ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
+    f32x4* dym4 = a.dy_masked ? reinterpret_cast<f32x4*>(a.dy_masked + fb) : nullptr;
+    f32x4 mu, rs;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int g = (col * 4 + k) / cpg; mu[k] = a.mean[(size_t)f * G + g]; rs[k] = a.rstd[(size_t)f * G + g]; }
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 xv[NV], dv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = base + t + j * NT;
+        const bool ok = i < F4;
+        xv[j] = ok ? x4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[j] = ok ? dy4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (ro4) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = base + t + j * NT;
+            if (i < F4) {
+                const f32x4 rv = ro4[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dv[j][k] = rv[k] > 0.f ? dv[j][k] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = base + t + j * NT;
+        if (dym4 && i < F4) dym4[i] = dv[j];
+        f32x4 xh = (xv[j] - mu) * rs;
+        if (i >= F4) xh = f32x4{0.f, 0.f, 0.f, 0.f};
+        s1 += dv[j];
+        s2 += dv[j] * xh;
+    }
+    float* o = part + (size_t)blockIdx.x * 2 * C;
+    gn_col_reduce<NT>(s1, C4, red, c1, C, t);
+    for (int c = t; c < C; c += NT) o[c] = c1[c];
+    gn_col_reduce<NT>(s2, C4, red, c1, C, t);
+    for (int c = t; c < C; c += NT) o[C + c] = c1[c];
+}
+
+// backward, kernel 2: merge the partial sums of the frame (fixed order), then dx for the chunk
+template <int NT, int NV>
+__global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, int nchunks, const float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
+    const int F4 = a.HW * C4;
+    const int f = blockIdx.x / nchunks, ck = blockIdx.x % nchunks, t = threadIdx.x, col = t & (C4 - 1);
+    const int base = ck * NT * NV;
+    float* c1 = sm;          // [C]
+    float* c2 = sm + C;      // [C]
+    float* g1 = c2 + C;      // [G]
+    float* g2 = g1 + G;
+    const float* p = part + (size_t)f * nchunks * 2 * C;
+    for (int c = t; c < C; c += NT) {
+        float u = 0.f, w = 0.f;
+        for (int k = 0; k < nchunks; ++k) { u += p[(size_t)k * 2 * C + c]; w += p[(size_t)k * 2 * C + C + c]; }
+        c1[c] = u; c2[c] = w;
+        if (ck == 0) {
+            a.chan_sums[((size_t)f * 2 + 0) * C + c] = u;
+            a.chan_sums[((size_t)f * 2 + 1) * C + c] = w;
+        }
+    }
+    __syncthreads();
+    if (t < G) {
+        float u = 0.f, w = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { u += a.gamma[c] * c1[c]; w += a.gamma[c] * c2[c]; }
+        const float inv_m = 1.0f / (float)(a.HW * cpg);
+        g1[t] = u * inv_m; g2[t] = w * inv_m;
+    }
+    __syncthreads();
+    f32x4 mu, rs, ga, m1, m2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = col * 4 + k, g = c / cpg;
+        mu[k] = a.mean[(size_t)f * G + g]; rs[k] = a.rstd[(size_t)f * G + g]; ga[k] = a.gamma[c]; m1[k] = g1[g]; m2[k] = g2[g];
+    }
+    const size_t fb = (size_t)f * a.HW * C;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + fb);
+    // the masked gradient was written out by kernel 1 when the caller wanted it: read that instead of dy + relu_out
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>((a.dy_masked ? a.dy_masked : a.dy) + fb);
+    const f32x4* ro4 = (a.relu_out && !a.dy_masked) ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
+    f32x4* dx4 = reinterpret_cast<f32x4*>(a.dx + fb);
+    f32x4 xv[NV], dv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = base + t + j * NT;
+        const bool ok = i < F4;
+        xv[j] = ok ? x4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[j] = ok ? dy4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (ro4) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = base + t + j * NT;
+            if (i < F4) {
+                const f32x4 rv = ro4[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dv[j][k] = rv[k] > 0.f ? dv[j][k] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = base + t + j * NT;
+        const f32x4 xh = (xv[j] - mu) * rs;
+        if (i < F4) dx4[i] = rs * (dv[j] * ga - m1 - xh * m2);
+    }
+}
+
+// chunk-parallel path applicable?  (power-of-two C/4 that divides the workgroup, scratch large enough)
+static int gn_chunk_cfg(int B, int HW, int C, size_t need_per_chunk, size_t scratch_floats, int chunk_f4, int& nchunks) {
+    const int C4 = C / 4;
+    if (C4 < 1 || (C4 & (C4 - 1)) || C4 > GNC_NT || getenv("HAB_GN_STREAM") != nullptr) return 0;
+    const long long F4 = (long long)HW * C4;
+    nchunks = (int)((F4 + chunk_f4 - 1) / chunk_f4);
+    if (nchunks < 2 || (size_t)B * nchunks * need_per_chunk > scratch_floats) return 0;
+    if ((long long)B * nchunks > 0x7fffffffLL) return 0;
+    return 1;
+}
+
 // Picks (NT, NV) for the register-resident kernels: 0 = not applicable (frame too large / channel count not a power of two).
 static int gn_reg_cfg(int HW, int C, int& nt, int& nv) {
     const int C4 = C / 4;
@@ -515,6 +767,15 @@ int groupnorm_forward(const GnArgs& a, hipStream_t s) {
     if (gn_reg_cfg(a.HW, a.C, nt, nv)) {
         const size_t lds_r = (size_t)(nt * 4 + a.C + 2 * a.groups) * sizeof(float);
         HAB_GN_REG_DISPATCH(groupnorm_fwd_reg_kernel, a, lds_r);
+        HAB_LAUNCH_CHECK();
+        return HAB_OK;
+    }
+    int nchunks;
+    if (a.scratch && gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.groups * 2, a.scratch_floats, GNC_NT * GNC_NV_F, nchunks)) {
+        const size_t lds1 = (size_t)(GNC_NT * 4 + a.C + a.groups) * sizeof(float);
+        gn_chunk_stats_kernel<GNC_NT, GNC_NV_F><<<a.B * nchunks, GNC_NT, lds1, s>>>(a, nchunks, a.scratch);
+        HAB_LAUNCH_CHECK();
+        gn_chunk_apply_kernel<GNC_NT, GNC_NV_F><<<a.B * nchunks, GNC_NT, 2 * a.groups * sizeof(float), s>>>(a, nchunks, a.scratch);
         HAB_LAUNCH_CHECK();
         return HAB_OK;
     }
@@ -618,6 +879,16 @@ int groupnorm_backward(const GnBwdArgs& a, hipStream_t s) {
     if (gn_reg_cfg(a.HW, a.C, nt, nv)) {
         const size_t lds_r = (size_t)(nt * 4 + 2 * a.C + 2 * a.groups) * sizeof(float);
         HAB_GN_REG_DISPATCH(groupnorm_bwd_reg_kernel, a, lds_r);
+        HAB_LAUNCH_CHECK();
+        return HAB_OK;
+    }
+    int nchunks;
+    if (a.scratch && gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.C * 2, a.scratch_floats, GNC_NT * GNC_NV_B, nchunks)) {
+        const size_t lds1 = (size_t)(GNC_NT * 4 + a.C) * sizeof(float);
+        gn_chunk_bwd_sums_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds1, s>>>(a, nchunks, a.scratch);
+        HAB_LAUNCH_CHECK();
+        const size_t lds2 = (size_t)(2 * a.C + 2 * a.groups) * sizeof(float);
+        gn_chunk_bwd_dx_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds2, s>>>(a, nchunks, a.scratch);
         HAB_LAUNCH_CHECK();
         return HAB_OK;
     }
@@ -842,16 +1113,19 @@ extern "C" int hab_running_mean_var_normalize(float* x, int64_t npix, int cpad, 
     return rmv_normalize(x, npix, cpad, C, mean, var, stream);
 }
 extern "C" int hab_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* residual, float* mean,
-                                 float* rstd, int B, int HW, int C, int groups, int relu, float eps, hipStream_t stream) {
+                                 float* rstd, int B, int HW, int C, int groups, int relu, float eps, float* ws, int64_t ws_floats,
+                                 hipStream_t stream) {
     GnArgs a;
+    a.scratch = ws; a.scratch_floats = ws ? (size_t)ws_floats : 0;
     a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.residual = residual; a.mean = mean; a.rstd = rstd;
     a.B = B; a.HW = HW; a.C = C; a.groups = groups; a.relu = relu; a.eps = eps;
     return groupnorm_forward(a, stream);
 }
 extern "C" int hab_groupnorm_bwd(const float* x, const float* dy, const float* relu_out, float* dx, float* dy_masked, const float* gamma,
                                  const float* mean, const float* rstd, float* chan_sums, int B, int HW, int C, int groups,
-                                 hipStream_t stream) {
+                                 float* ws, int64_t ws_floats, hipStream_t stream) {
     GnBwdArgs a;
+    a.scratch = ws; a.scratch_floats = ws ? (size_t)ws_floats : 0;
     a.x = x; a.dy = dy; a.relu_out = relu_out; a.dx = dx; a.dy_masked = dy_masked; a.gamma = gamma; a.mean = mean; a.rstd = rstd;
     a.chan_sums = chan_sums; a.B = B; a.HW = HW; a.C = C; a.groups = groups;
     return groupnorm_backward(a, stream);

@@ -72,8 +72,8 @@ SIGNATURES = {
     "hab_channel_moments": (c_int, [vp, c_int64, c_int, c_int, vp, vp, vp, c_int, vp]),
     "hab_running_mean_var_update": (c_int, [vp, vp, vp, vp, vp, c_float, c_int, vp]),
     "hab_running_mean_var_normalize": (c_int, [vp, c_int64, c_int, c_int, vp, vp, vp]),
-    "hab_groupnorm_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_float, vp]),
-    "hab_groupnorm_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
+    "hab_groupnorm_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_float, vp, c_int64, vp]),
+    "hab_groupnorm_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, c_int64, vp]),
     "hab_maxpool3x3s2_fwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
     "hab_maxpool3x3s2_bwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
     "hab_nav_embed_fwd": (c_int, [POINTER(EmbedSlot), c_int, vp, vp, vp, c_int, c_int, c_int, vp, vp]),

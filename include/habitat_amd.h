@@ -177,14 +177,18 @@ int hab_running_mean_var_update(float* r_mean, float* r_var, float* r_count, con
                                 hipStream_t stream);
 /* x = addcmul(-mean*inv_std, x, inv_std), inv_std = rsqrt(max(var, 1e-2)), in place (running_mean_and_var.py:73-78). */
 int hab_running_mean_var_normalize(float* x, int64_t npix, int cpad, int C, const float* mean, const float* var, hipStream_t stream);
-/* nn.GroupNorm forward [+ residual] [+ ReLU] (resnet.py:51-57,67-69); mean / rstd ([B][groups]) are kept for backward. */
+/* nn.GroupNorm forward [+ residual] [+ ReLU] (resnet.py:51-57,67-69); mean / rstd ([B][groups]) are kept for backward.
+ * ws (nullable): scratch for the chunk-parallel path of frames > 128 KB, B * ceil(HW*C / 16384) * groups * 2 floats
+ * (backward: B * ceil(HW*C / 8192) * 2 * C); without it such frames take the slower streaming kernel. */
 int hab_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* residual, float* mean,
-                      float* rstd, int B, int HW, int C, int groups, int relu, float eps, hipStream_t stream);
+                      float* rstd, int B, int HW, int C, int groups, int relu, float eps, float* ws, int64_t ws_floats,
+                      hipStream_t stream);
 /* GroupNorm backward with the ReLU mask of the fused output (relu_out, nullable) applied to dy first; dy_masked (nullable)
  * receives the masked dy (gradient of the residual branch); chan_sums [B][2][C] = per-frame sum dy', sum dy'*xhat
  * (reduce over frames with hab_colsum -> dbeta, dgamma). */
 int hab_groupnorm_bwd(const float* x, const float* dy, const float* relu_out, float* dx, float* dy_masked, const float* gamma,
-                      const float* mean, const float* rstd, float* chan_sums, int B, int HW, int C, int groups, hipStream_t stream);
+                      const float* mean, const float* rstd, float* chan_sums, int B, int HW, int C, int groups, float* ws,
+                      int64_t ws_floats, hipStream_t stream);
 /* nn.MaxPool2d(3, stride 2, padding 1) (resnet.py:220); idx = window offset of the first maximum (1 byte per output). */
 int hab_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t stream);
 int hab_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t stream);

@@ -385,8 +385,16 @@ def test_igemm_transpose_detecting_identity(L):
                                                       (2, 4, 1024, 16, 1, 1), (3, 16, 128, 1, 1, 0), (2, 1, 2048, 1, 1, 0),
                                                       # register-resident kernels at 1024 threads per frame (resnet18 layer1 / layer2 @256^2)
                                                       (3, 32 * 32, 32, 16, 1, 1), (2, 16 * 16, 64, 16, 1, 0), (2, 30 * 30, 32, 16, 0, 1),
-                                                      (2, 8 * 8, 128, 16, 1, 1)])
-def test_groupnorm_fwd_bwd(L, B, HW, Cc, groups, relu, res):
+                                                      (2, 8 * 8, 128, 16, 1, 1),
+                                                      # chunk-parallel path (frames > 128 KB): stem 64x64x32, resnet50 32x32x128 and
+                                                      # 16x16x256, a ragged last chunk, one channel group
+                                                      (2, 32 * 32, 128, 16, 1, 1), (2, 16 * 16, 256, 16, 0, 0), (3, 50 * 41, 32, 16, 1, 1),
+                                                      (2, 40 * 40, 64, 1, 1, 0)])
+@pytest.mark.parametrize("with_ws", [1, 0])
+def test_groupnorm_fwd_bwd(L, B, HW, Cc, groups, relu, res, with_ws):
+    if not with_ws and HW * Cc <= 32768:
+        pytest.skip("scratch only matters for frames > 128 KB")
+    gws = torch.zeros(1 << 20, device="cuda") if with_ws else None
     torch.manual_seed(B * 10 + Cc)
     x = torch.randn(B, Cc, HW, 1, requires_grad=True)
     g = (1 + 0.1 * torch.randn(Cc)).requires_grad_()
@@ -400,7 +408,7 @@ def test_groupnorm_fwd_bwd(L, B, HW, Cc, groups, relu, res):
     xh, rh = nhwc(x.detach()).cuda(), (nhwc(r.detach()).cuda() if res else None)
     y = torch.zeros(B, HW, Cc, device="cuda")
     mean, rstd = torch.zeros(B, groups, device="cuda"), torch.zeros(B, groups, device="cuda")
-    ck(L.hab_groupnorm_fwd(P(xh), P(y), P(g.detach().cuda()), P(b.detach().cuda()), P(rh), P(mean), P(rstd), B, HW, Cc, groups, relu, 1e-5, S()))
+    ck(L.hab_groupnorm_fwd(P(xh), P(y), P(g.detach().cuda()), P(b.detach().cuda()), P(rh), P(mean), P(rstd), B, HW, Cc, groups, relu, 1e-5, P(gws), gws.numel() if gws is not None else 0, S()))
     assert torch.allclose(y.cpu().view(B, HW, 1, Cc), nhwc(y_ref), atol=2e-5, rtol=1e-4)
     gy = torch.randn_like(y_ref)
     y_ref.backward(gy)
@@ -409,7 +417,12 @@ def test_groupnorm_fwd_bwd(L, B, HW, Cc, groups, relu, res):
     dym = torch.zeros(B, HW, Cc, device="cuda")
     cs = torch.zeros(B, 2, Cc, device="cuda")
     ck(L.hab_groupnorm_bwd(P(xh), P(dy), P(y) if relu else None, P(dx), P(dym), P(g.detach().cuda()), P(mean), P(rstd), P(cs), B, HW, Cc,
-                           groups, S()))
+                           groups, P(gws), gws.numel() if gws is not None else 0, S()))
+    # without the optional dy' output and in place (dx aliases dy), as the engine calls it for non-residual layers
+    dy2 = dy.clone()
+    ck(L.hab_groupnorm_bwd(P(xh), P(dy2), P(y) if relu else None, P(dy2), None, P(g.detach().cuda()), P(mean), P(rstd), P(cs), B, HW, Cc,
+                           groups, P(gws), gws.numel() if gws is not None else 0, S()))
+    assert torch.equal(dy2, dx)
     scale = x.grad.abs().max().item()
     assert (dx.cpu().view(B, HW, 1, Cc) - nhwc(x.grad)).abs().max().item() <= 1e-4 * scale + 1e-6
     assert torch.allclose(cs[:, 0].sum(0).cpu(), b.grad, rtol=1e-4, atol=1e-4 * b.grad.abs().max().item())
