@@ -74,6 +74,7 @@ def _defaults() -> dict:
         eval=dict(split="val", use_ckpt_config=True, should_load_ckpt=True, evals_per_ep=1, video_option=[], extra_sim_sensors={}),
         profiling=dict(capture_start_step=-1, num_steps_to_capture=-1),
         vector_env_factory=dict(_target_="habitat_amd.common.env_factory.SyntheticVectorEnvFactory"),
+        evaluator=dict(_target_="habitat_amd.rl.ppo.evaluator.HabitatEvaluator"),
         rl=dict(agent=dict(type="SingleAgentAccessMgr"), preemption=dict(append_slurm_job_id=False, save_resume_state_interval=100,
                                                                        save_state_batch_only=False),
                 policy=dict(main_agent=policy), ppo=ppo, ddppo=ddppo, auxiliary_losses={}),
@@ -81,6 +82,7 @@ def _defaults() -> dict:
     habitat = dict(
         seed=100,  # HL/config/default_structured_configs.py:1918
         environment=dict(max_episode_steps=500),
+        dataset=dict(split="train"),
         simulator=dict(agents_order=["main_agent"],
                        sensors=dict(rgb=dict(height=256, width=256), depth=dict(height=256, width=256, normalize_depth=True))),
         task=dict(type="Nav-v0", goal_sensor_uuid="pointgoal_with_gps_compass", measurements={},

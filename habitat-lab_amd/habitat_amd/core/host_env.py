@@ -11,10 +11,25 @@ from habitat_amd.common import spaces
 GOAL_UUID = "pointgoal_with_gps_compass"
 
 
+class Episode:
+    """The two fields of habitat.core.dataset.Episode the trainer / evaluator read (habitat_evaluator.py:223-262)."""
+
+    def __init__(self, episode_id: str, scene_id: str):
+        self.episode_id, self.scene_id = episode_id, scene_id
+
+    def __eq__(self, other):
+        return isinstance(other, Episode) and (self.episode_id, self.scene_id) == (other.episode_id, other.scene_id)
+
+    def __repr__(self):
+        return f"Episode({self.scene_id}, {self.episode_id})"
+
+
 class HostSyntheticNavEnv:
     def __init__(self, seed: int = 0, height: int = 256, width: int = 256, use_rgb: bool = True, use_depth: bool = True,
-                 num_actions: int = 4, max_episode_steps: int = 500, p_done: float = 1.0 / 25.0, work_us: int = 0):
+                 num_actions: int = 4, max_episode_steps: int = 500, p_done: float = 1.0 / 25.0, work_us: int = 0,
+                 num_episodes: int = 0):
         self._rng = np.random.default_rng(seed)
+        self._seed = seed
         self._h, self._w, self._use_rgb, self._use_depth = height, width, use_rgb, use_depth
         self._max_steps, self._p_done, self._work_us = max_episode_steps, p_done, work_us
         sp = {}
@@ -26,7 +41,8 @@ class HostSyntheticNavEnv:
         self.observation_space = spaces.Dict(sp)
         self.action_space = spaces.Discrete(num_actions)
         self.original_action_space = self.action_space
-        self.number_of_episodes = 1 << 30
+        self._num_episodes = num_episodes  # > 0: a finite episode list that is cycled, like a dataset split
+        self.number_of_episodes = num_episodes if num_episodes > 0 else 1 << 30
         self.episodes = ()
         self._t = 0
         self._episode = 0
@@ -35,7 +51,8 @@ class HostSyntheticNavEnv:
 
     @property
     def current_episode(self):
-        return {"episode_id": str(self._episode), "scene_id": "synthetic"}
+        eid = self._episode % self._num_episodes if self._num_episodes > 0 else self._episode
+        return Episode(episode_id=str(eid), scene_id=f"synthetic-{self._seed}")
 
     def _obs(self):
         o = {}
@@ -73,6 +90,6 @@ class HostSyntheticNavEnv:
         pass
 
 
-def make_host_env(seed, height, width, use_rgb, use_depth, num_actions, max_episode_steps, work_us=0):
+def make_host_env(seed, height, width, use_rgb, use_depth, num_actions, max_episode_steps, work_us=0, num_episodes=0):
     return HostSyntheticNavEnv(seed=seed, height=height, width=width, use_rgb=use_rgb, use_depth=use_depth, num_actions=num_actions,
-                               max_episode_steps=max_episode_steps, work_us=work_us)
+                               max_episode_steps=max_episode_steps, work_us=work_us, num_episodes=num_episodes)

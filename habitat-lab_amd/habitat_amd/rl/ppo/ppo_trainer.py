@@ -407,5 +407,32 @@ class PPOTrainer(BaseRLTrainer):
                         break
         return count
 
-    def eval(self) -> None:
-        raise NotImplementedError("checkpoint evaluation needs simulator episodes and is outside the accelerated training path")
+    def _eval_checkpoint(self, checkpoint_path: str, writer, checkpoint_index: int = 0) -> None:
+        """ppo_trainer.py:803-902: load one checkpoint, rebuild envs + agent from its configuration, run the evaluator."""
+        if self._is_distributed:
+            raise RuntimeError("Evaluation does not support distributed mode")
+        hb = self.config.habitat_baselines
+        if hb.eval.should_load_ckpt:
+            ckpt_dict = self.load_checkpoint(checkpoint_path, map_location="cpu")
+            logger.info(f"Loaded checkpoint trained for {ckpt_dict.get('extra_state', {}).get('step')} steps")
+        else:
+            ckpt_dict = {"config": None}
+        config = self._get_resume_state_config_or_new_config(ckpt_dict.get("config") if hb.eval.use_ckpt_config else None)
+        with read_write(config):
+            config.habitat.dataset.split = hb.eval.split
+        self.device = torch.device("cuda", hb.torch_gpu_id) if torch.cuda.is_available() else torch.device("cpu")
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        self._init_envs(config, is_eval=True)
+        self._agent = self._create_agent(None)
+        if self._agent.actor_critic.should_load_agent_state and hb.eval.should_load_ckpt:
+            self._agent.load_state_dict(ckpt_dict)
+        step_id = checkpoint_index
+        if "extra_state" in ckpt_dict and "step" in ckpt_dict["extra_state"]:
+            step_id = ckpt_dict["extra_state"]["step"]
+        evaluator = instantiate(hb.evaluator)
+        from habitat_amd.rl.ppo.evaluator import Evaluator
+        assert isinstance(evaluator, Evaluator)
+        self.last_eval_stats = evaluator.evaluate_agent(self._agent, self.envs, self.config, checkpoint_index, step_id, writer, self.device,
+                                                        self.obs_transforms, self._env_spec, self._rank0_keys)
+        self.envs.close()

@@ -682,3 +682,40 @@ def test_trainer_frozen_encoder_update_cycles():
     again = pol.encode_visual({k: v[0] for k, v in o.items()})
     assert torch.equal(again, o["visual_features"][0])
     trainer.envs.close()
+
+
+@pytest.mark.gpu
+def test_train_checkpoint_then_eval_loop(tmp_path):
+    """N4: PPOTrainer.train() writes a checkpoint, PPOTrainer.eval() (base_trainer.py:66-168 -> _eval_checkpoint ->
+    HabitatEvaluator) reloads it and evaluates `test_episode_count` episodes over worker-process envs, pausing envs whose next
+    episode is already covered; the aggregated statistics are the means over the recorded episodes."""
+    from habitat_amd.config.default import get_config
+    from habitat_amd.common.baseline_registry import baseline_registry
+    import habitat_amd.rl.ppo.ppo_trainer  # noqa: F401
+    ck, tb = str(tmp_path / "ckpt"), str(tmp_path / "tb")
+    ov = ["habitat_baselines.num_environments=3", "habitat_baselines.rl.ppo.num_steps=4", "habitat_baselines.num_updates=2",
+          "habitat_baselines.total_num_steps=-1", "habitat_baselines.num_checkpoints=1", "habitat_baselines.checkpoint_interval=-1",
+          "habitat_baselines.rl.ppo.hidden_size=64", f"habitat_baselines.checkpoint_folder={ck}", f"habitat_baselines.tensorboard_dir={tb}",
+          f"habitat_baselines.eval_ckpt_path_dir={ck}", "habitat_baselines.test_episode_count=7",
+          "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000", "habitat.environment.max_episode_steps=5",
+          "habitat_baselines.vector_env_factory._target_=habitat_amd.common.env_factory.ProcessVectorEnvFactory"]
+    for sname in ("rgb", "depth"):
+        ov += [f"habitat.simulator.sensors.{sname}.height=64", f"habitat.simulator.sensors.{sname}.width=64"]
+    cfg = get_config("pointnav/ppo_pointnav_example.yaml", ov)
+    cfg.habitat.simulator.sensors.pop("semantic", None)
+    trainer = baseline_registry.get_trainer(cfg.habitat_baselines.trainer_name)(cfg)
+    trainer.train()
+    ckpts = [f for f in os.listdir(ck) if f.startswith("ckpt.")]
+    assert ckpts, os.listdir(ck)
+    trained = torch.load(os.path.join(ck, sorted(ckpts)[-1]), map_location="cpu", weights_only=False)["state_dict"]
+    ev = baseline_registry.get_trainer(cfg.habitat_baselines.trainer_name)(cfg)
+    ev.eval()
+    # the evaluated agent carries the checkpoint's weights
+    for k, v in ev._agent.actor_critic.state_dict().items():
+        assert torch.equal(v.cpu(), trained[k].cpu()), k
+    from habitat_amd.rl.ppo.evaluator import HabitatEvaluator
+    stats = ev.last_eval_stats
+    assert {"reward", "episode_return", "num_steps"} <= set(stats)
+    assert 1.0 <= stats["num_steps"] <= 5.0  # max_episode_steps = 5
+    # with this env the summed rewards of an episode ARE its `episode_return` measure
+    assert abs(stats["reward"] - stats["episode_return"]) < 1e-4

@@ -52,7 +52,7 @@ def test_vector_env_matches_inprocess_envs(shared):
         assert n_done > 0  # the 7-step budget guarantees episode ends -> auto reset exercised
         assert envs.call_at(1, "get_metrics") == local[1].get_metrics()
         assert envs.episode_over() == [e.episode_over for e in local]
-        assert [c["episode_id"] for c in envs.current_episodes()] == [e.current_episode["episode_id"] for e in local]
+        assert envs.current_episodes() == [e.current_episode for e in local]
         assert envs.count_episodes() == [0] * n
 
 
@@ -110,3 +110,71 @@ def test_trainer_host_path_with_process_envs_builds_batches():
         batch = envs.batched_obs(slice(0, n), torch.device("cpu"))
         for k in obs[0]:
             assert np.array_equal(batch[k].numpy(), np.stack([o[k] for o in obs]))
+
+
+def test_evaluator_loop_over_process_envs():
+    """HabitatEvaluator (habitat_evaluator.py:39-339) on CPU with a stand-in agent: every recorded episode must carry the return /
+    measures of exactly that (scene, episode) of the in-process replay, each episode is counted once, at least
+    `test_episode_count` are evaluated, envs pause when their next episode is already covered, aggregates are plain means."""
+    import types
+    from habitat_amd.common import spaces
+    from habitat_amd.config.default import get_config
+    from habitat_amd.rl.ppo.evaluator import HabitatEvaluator, extract_scalars_from_info
+    from habitat_amd.rl.ppo.policy import PolicyActionData
+
+    n, K = 3, 8
+    cfg = get_config("pointnav/ppo_pointnav_example.yaml", [f"habitat_baselines.num_environments={n}",
+                                                             f"habitat_baselines.test_episode_count={K}"])
+
+    class AC:
+        policy_action_space = spaces.Discrete(4)
+        hidden_state_shape = (1, 8)
+        paused = []
+
+        def act(self, obs, h, prev_actions, masks, deterministic=False):
+            b = h.shape[0]
+            assert obs["rgb"].shape[0] == b == prev_actions.shape[0] == masks.shape[0]
+            return PolicyActionData(rnn_hidden_states=h + 1, actions=torch.randint(0, 4, (b, 1)))
+
+        def get_extra(self, action_data, infos, dones):
+            return []
+
+        def on_envs_pause(self, idx):
+            self.paused.append(list(idx))
+
+    agent = types.SimpleNamespace(actor_critic=AC(), masks_shape=(1,), eval=lambda: None)
+    scalars = {}
+    writer = types.SimpleNamespace(add_scalar=lambda k, v, step: scalars.__setitem__(k, (v, step)))
+    ev = HabitatEvaluator()
+    with VectorEnv(make_host_env, _args(n, 6)) as envs:
+        agg = ev.evaluate_agent(agent, envs, cfg, 0, 123, writer, torch.device("cpu"), [], None, set())
+    rec = ev.last_stats_episodes
+    assert len(rec) >= K and all(cnt == 1 for (_, cnt) in rec)
+    # in-process replay of every env for long enough; rewards do not depend on the (valid) action taken
+    expect = {}
+    for a in _args(n, 6):
+        e = make_host_env(*a)
+        e.reset()
+        for _ in range(400):
+            ep = e.current_episode
+            _, r, d, info = e.step(0)
+            if d:
+                expect[(ep.scene_id, ep.episode_id)] = dict(reward=info["episode_return"], **extract_scalars_from_info(info))
+                e.reset()
+    for (key, _), st in rec.items():
+        assert key in expect, key
+        for k, v in st.items():
+            assert abs(v - expect[key][k]) < 1e-5, (key, k)
+    for k in ("reward", "episode_return", "num_steps"):
+        assert abs(agg[k] - np.mean([st[k] for st in rec.values()])) < 1e-6
+    assert scalars["eval_reward/average_reward"] == (agg["reward"], 123) and "eval_metrics/num_steps" in scalars
+    # finite episode lists (2 per env), test_episode_count = -1 -> every episode exactly once; an env is paused as soon as its
+    # next episode is one that has already been evaluated, the tensors shrink with it and the policy is told
+    cfg.habitat_baselines.test_episode_count = -1
+    agent.actor_critic.paused.clear()
+    with VectorEnv(make_host_env, [a + (2,) for a in _args(n, 6)]) as envs:
+        ev.evaluate_agent(agent, envs, cfg, 0, 5, writer, torch.device("cpu"), [], None, set())
+        assert envs.num_envs == 0  # all paused
+    keys = sorted(k for (k, _) in ev.last_stats_episodes)
+    assert keys == sorted((f"synthetic-{100 + i}", str(e)) for i in range(n) for e in (0, 1))
+    assert sum(len(p) for p in agent.actor_critic.paused) == n
