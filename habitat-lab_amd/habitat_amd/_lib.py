@@ -113,6 +113,10 @@ def lib():
             raise HabError(
                 f"{LIB_PATH} is missing: build it with `make -C habitat-lab_amd/csrc` (or __graft_entry__.build()). "
                 "habitat_amd has no CPU / PyTorch fallback for its kernels.")
+        # PyTorch-ROCm wheels bundle their own HIP / HSA runtime.  It must be in the process BEFORE this library is mapped, so that
+        # the library's libamdhip64 dependency resolves to the runtime torch uses: two runtimes in one process cannot share
+        # streams or allocations (the second one fails with hipErrorNoDevice on the first launch).
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
