@@ -19,12 +19,28 @@ __global__ void __launch_bounds__(256) heads_fwd_kernel(const HeadsArgs a) {
     float acc[MAX_A + 1];
 #pragma unroll
     for (int k = 0; k <= MAX_A; ++k) acc[k] = 0.f;
-    for (int j = lane; j < a.H; j += 64) {
-        const float xv = x[j];
+    if ((a.H & 255) == 0) {
+        // 16-byte loads, all of a 256-wide slice requested before any is used: one memory round trip per slice instead of one per
+        // 64 elements (the kernel is a chain of latencies: 64 waves, 5 dot products of 512)
+        for (int j = lane * 4; j < a.H; j += 256) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + j);
+            f32x4 wv[MAX_A + 1];
 #pragma unroll
-        for (int k = 0; k < MAX_A; ++k)
-            if (k < a.A) acc[k] += xv * a.w_actor[(size_t)k * a.H + j];
-        acc[MAX_A] += xv * a.w_critic[j];
+            for (int k = 0; k < MAX_A; ++k)
+                wv[k] = k < a.A ? *reinterpret_cast<const f32x4*>(a.w_actor + (size_t)k * a.H + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+            wv[MAX_A] = *reinterpret_cast<const f32x4*>(a.w_critic + j);
+#pragma unroll
+            for (int k = 0; k <= MAX_A; ++k)
+                acc[k] += (xv[0] * wv[k][0] + xv[1] * wv[k][1]) + (xv[2] * wv[k][2] + xv[3] * wv[k][3]);
+        }
+    } else {
+        for (int j = lane; j < a.H; j += 64) {
+            const float xv = x[j];
+#pragma unroll
+            for (int k = 0; k < MAX_A; ++k)
+                if (k < a.A) acc[k] += xv * a.w_actor[(size_t)k * a.H + j];
+            acc[MAX_A] += xv * a.w_critic[j];
+        }
     }
 #pragma unroll
     for (int k = 0; k <= MAX_A; ++k) acc[k] = wave_sum(acc[k]);

@@ -242,13 +242,14 @@ def test_autograd_bridge_matches_fused_path():
         assert rel_ok(p_.grad.cpu().numpy(), ref, tol=2e-4, floor=1e-4), k
 
 
-@pytest.mark.parametrize("rnn_type,layers", [("LSTM", 2), ("GRU", 2)])
-def test_engine_lstm_gru_multilayer_vs_oracle(rnn_type, layers):
+@pytest.mark.parametrize("rnn_type,layers,hidden", [("LSTM", 2, 64), ("GRU", 2, 64), ("GRU", 1, 512), ("LSTM", 1, 256)])
+def test_engine_lstm_gru_multilayer_vs_oracle(rnn_type, layers, hidden):
     """The engine also runs LSTM / multi-layer encoders on the baseline net; checked against the oracle's
-    masked-scan restatement incl. all gradients (autograd on the oracle)."""
+    masked-scan restatement incl. all gradients (autograd on the oracle).  hidden 512 / 256 = the benchmark width: the
+    8-wave recurrent kernels and the vector-load heads kernel only exist for hidden % 128 / % 256 == 0."""
     from habitat_amd.engine import DevicePackInfo, PolicyEngine
     H = W = 44
-    hidden, T, n = 64, 7, 3
+    T, n = 7, 3
     shapes = baseline_param_shapes(4, H, W, hidden, rnn_type=rnn_type, layers=layers)
     params = det_params(shapes, 11)
     eng = PolicyEngine(arch="simple_cnn", rnn_type=rnn_type, rnn_layers=layers, hidden=hidden, H=H, W=W, max_frames=T * n, max_envs=n)
