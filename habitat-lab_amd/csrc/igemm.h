@@ -40,6 +40,10 @@
 namespace hab {
 
 constexpr int IGEMM_BK = 32;
+// Row pitch padding of the i/j-contiguous LDS image [BK][rows + pad].  (pad 8 would put the two lane halves of a fragment read,
+// which are 4 k rows apart, on disjoint banks; measured: no difference end to end -- the ds_read_b32 stream is issue-bound, not
+// bank-bound -- so the smaller image stays.)
+constexpr int IGEMM_ICPAD = 4;
 
 // Optional fused column sums of the B operand (bias gradients ride along with the weight-gradient
 // contraction: db[j] = sum_r Q(r, j)).  A problem opts in with `static constexpr bool COLSUM_B = true`,
@@ -125,8 +129,8 @@ struct IgemmCfg {
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = IGEMM_BK;
     static constexpr int LDK = BK + 4;
     static constexpr int KV = AKv<P>::value;
-    static constexpr int A_TILE = P::A_RC ? BM * LDK : BK * (BM + 4);
-    static constexpr int B_TILE = P::B_RC ? BN * LDK : BK * (BN + 4);
+    static constexpr int A_TILE = P::A_RC ? BM * LDK : BK * (BM + IGEMM_ICPAD);
+    static constexpr int B_TILE = P::B_RC ? BN * LDK : BK * (BN + IGEMM_ICPAD);
     static constexpr int A_TOTAL = BM * BK / KV, B_TOTAL = BN * BK / 4;  // gather units per tile
     static constexpr int A_UNITS = (A_TOTAL + NT - 1) / NT, B_UNITS = (B_TOTAL + NT - 1) / NT;
     static constexpr size_t LDS_BYTES = (size_t)(A_TILE + B_TILE) * sizeof(float);
@@ -228,7 +232,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
             if (A_TOTAL % NT == 0 || u < A_TOTAL) {
                 f32x4 v[KV / 4];
                 p.a_cvt(actx[j], araw[j], a_k(kt, j), k_end, v);
-                float* dst = P::A_RC ? As + (u / AKQ) * LDK + (u % AKQ) * KV : As + (u / AIQ) * (BM + 4) + (u % AIQ) * KV;
+                float* dst = P::A_RC ? As + (u / AKQ) * LDK + (u % AKQ) * KV : As + (u / AIQ) * (BM + IGEMM_ICPAD) + (u % AIQ) * KV;
 #pragma unroll
                 for (int q = 0; q < KV / 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = v[q];
             }
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
             const int u = t + NT * j;
             if (B_TOTAL % NT == 0 || u < B_TOTAL) {
                 const f32x4 v = p.b_cvt(braw[j]);
-                float* dst = P::B_RC ? Bs + (u >> 3) * LDK + (u & 7) * 4 : Bs + (u / BJQ) * (BN + 4) + (u % BJQ) * 4;
+                float* dst = P::B_RC ? Bs + (u >> 3) * LDK + (u & 7) * 4 : Bs + (u / BJQ) * (BN + IGEMM_ICPAD) + (u % BJQ) * 4;
                 *reinterpret_cast<f32x4*>(dst) = v;
                 if constexpr (CS) {
                     if (do_cs) cs += v;
@@ -270,7 +274,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
                     af[i] = *reinterpret_cast<const f32x4*>(As + row * LDK + c * 8 + hi * 4);
                 } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) af[i][s] = As[(c * 8 + hi * 4 + s) * (BM + 4) + row];
+                    for (int s = 0; s < 4; ++s) af[i][s] = As[(c * 8 + hi * 4 + s) * (BM + IGEMM_ICPAD) + row];
                 }
             }
 #pragma unroll
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const P p, const int
                     bf[j] = *reinterpret_cast<const f32x4*>(Bs + col * LDK + c * 8 + hi * 4);
                 } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) bf[j][s] = Bs[(c * 8 + hi * 4 + s) * (BN + 4) + col];
+                    for (int s = 0; s < 4; ++s) bf[j][s] = Bs[(c * 8 + hi * 4 + s) * (BN + IGEMM_ICPAD) + col];
                 }
             }
 #pragma unroll
