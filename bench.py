@@ -71,7 +71,8 @@ def make_trainer(workload: str, total_updates: int):
                                  "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000",
                                  "habitat_baselines.checkpoint_folder=/tmp/habitat_amd_bench_ckpt",
                                  f"habitat.simulator.sensors.rgb.height={OBS}", f"habitat.simulator.sensors.rgb.width={OBS}",
-                                 f"habitat.simulator.sensors.depth.height={OBS}", f"habitat.simulator.sensors.depth.width={OBS}"] + w["overrides"])
+                                 f"habitat.simulator.sensors.depth.height={OBS}", f"habitat.simulator.sensors.depth.width={OBS}"] + w["overrides"]
+                     + [o for o in os.environ.get("HAB_BENCH_OVERRIDES", "").split(",") if o])  # development hook
     trainer = tr.PPOTrainer(cfg)
     return trainer, cfg
 
@@ -195,6 +196,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
+        torch.distributed.destroy_process_group()
         return
     ppo = cfg.habitat_baselines.rl.ppo
     n_envs, n_steps = WORKLOADS[a.workload].get("envs", NUM_ENVS), WORKLOADS[a.workload].get("steps", NUM_STEPS)
@@ -230,6 +232,8 @@ def main():
     if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
+    if dist:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
