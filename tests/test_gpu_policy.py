@@ -720,3 +720,51 @@ def test_train_checkpoint_then_eval_loop(tmp_path):
     assert 1.0 <= stats["num_steps"] <= 5.0  # max_episode_steps = 5
     # with this env the summed rewards of an episode ARE its `episode_return` measure
     assert abs(stats["reward"] - stats["episode_return"]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_update_from_preempted_short_rollout(monkeypatch):
+    """DD-PPO's preemptive straggler rule ends a rollout after t' < T steps (ppo_trainer.py:641-653); GAE and the minibatch
+    generator then use current_rollout_step_idx (rollout_storage.py:182,237).  A t' = 4 of T = 6 rollout: bootstrap value from
+    row t', returns, and the whole PPO.update (metrics, parameters) against the oracle run on the first t' steps only."""
+    from habitat_amd.rl.ppo import PPO
+    case, ts = "baseline_rgbd44", 4
+    z = np.load(os.path.join(G, case + ".npz"))
+    c, params, spec, buf, next_value, pol, st = build(case, z)
+    cfg = make_cfg(**c["cfg"])
+    T, N = c["T"], c["N"]
+    assert ts < T
+    fill_storage(st, buf, z, T)
+    st.current_rollout_step_idxs = [ts]
+    B = st.buffers
+    # rows >= t' keep whatever an earlier rollout left there; like the reference (ppo.py:139-153) the advantage statistics run
+    # over ALL T+1 rows, so those stale rows count -- the oracle gets the very same full buffers
+    B["returns"].fill_(0.0)
+    pol.eval()
+    last = st.get_last_step()
+    nv = pol.get_value({k: v.contiguous() for k, v in last["observations"].items()}, last["recurrent_hidden_states"], last["prev_actions"],
+                       last["masks"])
+    st.compute_returns(nv, True, cfg.gamma, cfg.tau)
+    cpu = lambda v: v.cpu().clone()
+    bufc = {k: ({kk: cpu(vv) for kk, vv in v.items()} if isinstance(v, dict) else cpu(v)) for k, v in B.items()}
+    with torch.no_grad():
+        feats, _ = O.net_forward(params, spec, {k: v[ts] for k, v in bufc["observations"].items()}, bufc["recurrent_hidden_states"][ts],
+                                 bufc["prev_actions"][ts], bufc["masks"][ts])
+        nv_ref = O.heads(params, feats)[2]
+    assert rel_ok(nv.cpu().numpy(), nv_ref.numpy())
+    ret_ref, vp_ref = O.compute_returns(bufc["rewards"], bufc["value_preds"], bufc["masks"], nv_ref, ts, True, cfg.gamma, cfg.tau)
+    assert rel_ok(B["returns"][:ts].cpu().numpy(), ret_ref[:ts].numpy())
+    bufc["returns"], bufc["value_preds"] = ret_ref, vp_ref
+    perm = torch.randperm(N)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    opt = dict(step=0, m={k: torch.zeros_like(v) for k, v in p.items()}, v={k: torch.zeros_like(v) for k, v in p.items()})
+    chunks = [list(perm.chunk(cfg.num_mini_batch)) for _ in range(cfg.ppo_epoch)]
+    ref_metrics = O.ppo_update(p, spec, bufc, ts, cfg, opt, list(p.keys()), perms=chunks)
+    pol.train()
+    ppo = PPO.from_config(pol, cfg)
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: perm)
+    metrics = ppo.update(st)
+    for k in ("value_loss", "action_loss", "dist_entropy", "grad_norm"):
+        assert abs(metrics[k] - ref_metrics[k]) <= 1e-4 * max(1.0, abs(ref_metrics[k])), (k, metrics[k], ref_metrics[k])
+    for k, v in pol.state_dict().items():
+        assert rel_ok(v.cpu().numpy(), p[k].detach().numpy(), tol=1e-4, floor=1e-2), k
