@@ -14,6 +14,10 @@ namespace hab {
 // Tile choice by output width N (= Cout / out-features) and height M: tall-skinny tiles because the policy's
 // layers have N in 32..512 and M in 1e2..1e7.  Weight-gradient problems have small M x N and a
 // huge reduction: the 96-row tile (3 waves) avoids padding M = 288 / 576 / 1152 (3x3 taps x 32..128 channels).
+static bool no_dma() { static const bool v = hab_env_flag("HAB_NO_DMA"); return v; }
+static bool no_merged_dgrad() { static const bool v = hab_env_flag("HAB_NO_MERGED_DGRAD"); return v; }
+static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); return v; }
+
 template <class P>
 static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream, int target_blocks = 1024) {
     // Split-K target.  Forward-form problems (activations x weights) split only until there is one workgroup per CU: their
@@ -21,10 +25,11 @@ static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream
     // (measured: target 1024 -> 256 is +4 % on C2, +6 % on C3, all of it in the 64-frame rollout forward passes).  Weight
     // gradients (tiny M*N, K in the millions) keep the deeper split.
     if (P::A_RC || P::B_RC) target_blocks = 256;
-    if (const char* tb = getenv("HAB_TARGET_BLOCKS_WG")) { if (!P::A_RC && !P::B_RC) target_blocks = atoi(tb); }
+    static const int wg_target = hab_env_int("HAB_TARGET_BLOCKS_WG", 0);
+    if (wg_target > 0 && !P::A_RC && !P::B_RC) target_blocks = wg_target;
     constexpr bool WG = !P::A_RC && !P::B_RC && AKv<P>::value == 4;  // weight-gradient form
     if constexpr (std::is_same_v<P, ConvFwdProb> || std::is_same_v<P, ConvDgradProb>) {
-        if (p.dma_ok() && p.M > 64 && getenv("HAB_NO_DMA") == nullptr) {  // LDS-DMA staged variant (igemm_dma.h)
+        if (p.dma_ok() && p.M > 64 && !no_dma()) {  // LDS-DMA staged variant (igemm_dma.h)
             if (p.N <= 32) return igemm_dma_launch<P, 2, 1, 4, 1, false>(p, ws, ws_floats, target_blocks, stream);
             if (p.N <= 64) return igemm_dma_launch<P, 1, 2, 4, 1, false>(p, ws, ws_floats, target_blocks, stream);
             if (p.N <= 128) return igemm_dma_launch<P, 2, 2, 2, 2, true>(p, ws, ws_floats, target_blocks, stream);
@@ -72,7 +77,7 @@ __global__ void dgrad_empty_class_kernel(ConvDgradProb p) {
 
 int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add, float* dx,
                float* ws, size_t ws_floats, hipStream_t stream) {
-    if (d.stride > 1 && getenv("HAB_NO_DMA") == nullptr && getenv("HAB_NO_MERGED_DGRAD") == nullptr) {
+    if (d.stride > 1 && !no_dma() && !no_merged_dgrad()) {
         // kernel size a multiple of the stride: the stride classes share their dY gather -> one contraction with N = s*s*Cin
         ConvDgradMergedProb q;
         HAB_TRY(check_conv(d));
@@ -108,7 +113,7 @@ int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oih
                hipStream_t stream) {
     ConvWgradProb p;
     HAB_TRY(build(p, d, x, dy, dw_oihw, dbias));
-    if (ws && wgrad3x3_patch_ok(p) && getenv("HAB_NO_PATCH") == nullptr) {  // 3x3/1/1 with W in {16, 32}: patch-resident kernel
+    if (ws && wgrad3x3_patch_ok(p) && !no_patch()) {  // 3x3/1/1 with W in {16, 32}: patch-resident kernel
         ConvWgradProb q = p;
         q.colsum = nullptr;
         if (dbias) HAB_TRY(colsum(dy, p.N, p.K, p.N, dbias, 0, ws, ws_floats, stream));
@@ -116,7 +121,7 @@ int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oih
     }
     // LDS-DMA staged variant (igemm_dma_wgrad.h): measured faster only for unpadded convolutions with Cout <= 32 (SimpleCNN conv3:
     // 51 -> 64 TFLOP/s); with padding the per-pixel scalar decode + border tests cost more than the VGPR staging they replace.
-    if (ws && d.pad == 0 && p.N <= 32 && getenv("HAB_NO_DMA") == nullptr) {
+    if (ws && d.pad == 0 && p.N <= 32 && !no_dma()) {
         ConvWgradProb q = p;
         q.colsum = nullptr;  // the DMA path never sees dY in registers: the bias gradient is a separate column sum
         if (wgrad_dma_ok(q)) {

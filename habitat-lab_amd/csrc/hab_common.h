@@ -1,5 +1,6 @@
 // Shared device/host helpers for the habitat_amd gfx950 kernel library.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -25,6 +26,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace hab {
 
 constexpr int WAVE = 64;
+
+// Development switches (HAB_NO_DMA, HAB_GN_STREAM, ...) select the older variant of a kernel for A/B measurements.  They are read
+// once per process: `static const bool off = hab_env_flag("HAB_...");` at the point of use.
+inline bool hab_env_flag(const char* name) { return getenv(name) != nullptr; }
+inline int hab_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline long long cdivl(long long a, long long b) { return (a + b - 1) / b; }

@@ -152,7 +152,8 @@ static int try_tile_launch(const ResizeCropArgs& a, hipStream_t stream) {
 
 template <class T>
 static int launch_resize_crop(const ResizeCropArgs& a, hipStream_t stream) {
-    if (a.mode == HAB_RESIZE_AREA && getenv("HAB_OBS_NO_TILE") == nullptr) {
+    static const bool no_tile = hab_env_flag("HAB_OBS_NO_TILE");
+    if (a.mode == HAB_RESIZE_AREA && !no_tile) {
         int rc = -1;
         if (a.C == 1) rc = try_tile_launch<T, 1>(a, stream);
         else if (a.C == 3) rc = try_tile_launch<T, 3>(a, stream);

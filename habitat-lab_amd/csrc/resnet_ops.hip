@@ -712,9 +712,10 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, 
 }
 
 // chunk-parallel path applicable?  (power-of-two C/4 that divides the workgroup, scratch large enough)
+static bool gn_stream_only() { static const bool v = hab_env_flag("HAB_GN_STREAM"); return v; }
 static int gn_chunk_cfg(int B, int HW, int C, size_t need_per_chunk, size_t scratch_floats, int chunk_f4, int& nchunks) {
     const int C4 = C / 4;
-    if (C4 < 1 || (C4 & (C4 - 1)) || C4 > GNC_NT || getenv("HAB_GN_STREAM") != nullptr) return 0;
+    if (C4 < 1 || (C4 & (C4 - 1)) || C4 > GNC_NT || gn_stream_only()) return 0;
     const long long F4 = (long long)HW * C4;
     nchunks = (int)((F4 + chunk_f4 - 1) / chunk_f4);
     if (nchunks < 2 || (size_t)B * nchunks * need_per_chunk > scratch_floats) return 0;
@@ -725,7 +726,7 @@ static int gn_chunk_cfg(int B, int HW, int C, size_t need_per_chunk, size_t scra
 // Picks (NT, NV) for the register-resident kernels: 0 = not applicable (frame too large / channel count not a power of two).
 static int gn_reg_cfg(int HW, int C, int& nt, int& nv) {
     const int C4 = C / 4;
-    if (C4 < 1 || (C4 & (C4 - 1)) || getenv("HAB_GN_STREAM") != nullptr) return 0;
+    if (C4 < 1 || (C4 & (C4 - 1)) || gn_stream_only()) return 0;
     const long long F4 = (long long)HW * C4;
     nt = F4 > 2048 ? 1024 : 256;
     if (C4 > nt) return 0;
