@@ -755,6 +755,7 @@ def test_update_from_preempted_short_rollout(monkeypatch):
     ret_ref, vp_ref = O.compute_returns(bufc["rewards"], bufc["value_preds"], bufc["masks"], nv_ref, ts, True, cfg.gamma, cfg.tau)
     assert rel_ok(B["returns"][:ts].cpu().numpy(), ret_ref[:ts].numpy())
     bufc["returns"], bufc["value_preds"] = ret_ref, vp_ref
+    torch.manual_seed(3)
     perm = torch.randperm(N)
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     opt = dict(step=0, m={k: torch.zeros_like(v) for k, v in p.items()}, v={k: torch.zeros_like(v) for k, v in p.items()})
