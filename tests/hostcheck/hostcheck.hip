@@ -86,6 +86,99 @@ static ObsView mkobs(const uint8_t* rgb, const float* depth, const int* rows, in
     return o;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Host emulation of the LDS-DMA staged kernels (igemm_dma.h): the SAME dma_a_tile / dma_a_row / dma_tap / dma_b_* functors produce
+// the buffer window, the per-row byte offset + tap-validity mask and the per-K-tile scalar offsets; a gather is
+// `window_base + row_offset + tap_offset + 16 * quad`, zero when the tap's mask bit is clear or the offset falls outside the
+// window (the hardware's buffer range check).  The epilogue goes through the vector (epi_*4) interface the kernels use, with the
+// transposed accumulator's quad order.  tile_rows = BM of the kernel (the window is per M-tile).
+// ---------------------------------------------------------------------------------------------------------------------
+template <class P>
+static float dma_load(const DmaTile& t, uint32_t off) {  // 4-byte element of a raw buffer load with range check
+    if (off + 4 > t.records) return 0.f;
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t.base) + off);
+}
+template <class P>
+static void host_dma_igemm(const P& p, int tile_rows, int tile_cols) {
+    constexpr uint32_t OOB = 0x80000000u;
+    const int ntk = (p.K + IGEMM_BK - 1) / IGEMM_BK;
+    std::vector<float> acc((size_t)4);
+    for (int m0 = 0; m0 < p.M; m0 += tile_rows) {
+        const DmaTile ta = p.dma_a_tile(m0);
+        for (int n0 = 0; n0 < p.N; n0 += tile_cols) {
+            const DmaTile tb = p.dma_b_tile(n0);
+            for (int m = m0; m < std::min(p.M, m0 + tile_rows); ++m) {
+                uint32_t amask;
+                const uint32_t aoff = p.dma_a_row(ta, m, amask);
+                const typename P::EpiRow er = p.epi_row(m);
+                for (int nq = n0; nq < std::min(p.N, n0 + tile_cols); nq += 4) {
+                    double s[4] = {0, 0, 0, 0};
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = nq + e;
+                        uint32_t bok;
+                        uint32_t boff = p.dma_b_row(tb, n, bok);
+                        if (!bok) boff = OOB;
+                        for (int kt = 0; kt < ntk; ++kt) {
+                            int tap;
+                            uint32_t sa, sb;
+                            p.dma_tap(kt * IGEMM_BK, tap, sa, sb);
+                            const bool a_ok = (amask >> tap) & 1u;
+                            for (int kk = 0; kk < IGEMM_BK && kt * IGEMM_BK + kk < p.K; ++kk) {
+                                const float a = a_ok ? dma_load<P>(ta, aoff + sa + 4u * kk) : 0.f;
+                                const float b = boff == OOB ? 0.f : dma_load<P>(tb, boff + sb + 4u * kk);
+                                s[e] += (double)a * (double)b;
+                            }
+                        }
+                    }
+                    const typename P::EpiCol4 ec = p.epi_col4(nq);
+                    f32x4 v;
+                    v[0] = (float)s[0]; v[1] = (float)s[1]; v[2] = (float)s[2]; v[3] = (float)s[3];
+                    p.epi_store4(er, ec, p.epi_fetch4(er, ec), v);
+                }
+            }
+        }
+    }
+}
+
+extern "C" int hc_conv2d_fwd_dma(const float* x, const float* wf, const float* bias, float* y, int B, int H, int W, int C, int Cout,
+                                 int KH, int KW, int stride, int pad, int relu) {
+    ConvFwdProb p;
+    HAB_TRY(build(p, mk(B, H, W, C, Cout, KH, KW, stride, pad), x, wf, bias, y, relu));
+    if (!p.dma_ok()) return -1;
+    host_dma_igemm(p, 128, 64);
+    return 0;
+}
+// per-class (merged = 0) or merged-stride-class (merged = 1) data gradient through the DMA interface
+extern "C" int hc_conv2d_dgrad_dma(const float* dy, const float* wd, const float* mask, const float* add, float* dx, int B, int H,
+                                   int W, int C, int Cout, int KH, int KW, int stride, int pad, int merged) {
+    const ConvDesc d = mk(B, H, W, C, Cout, KH, KW, stride, pad);
+    if (merged) {
+        ConvDgradMergedProb q;
+        HAB_TRY(check_conv(d));
+        q.g = make_geom(d);
+        if (!ConvDgradMergedProb::applicable(q.g)) return -2;
+        q.dy = dy; q.w = wd; q.mask = mask; q.add = add; q.dx = dx;
+        q.finish();
+        if (!q.dma_ok()) return -1;
+        host_dma_igemm(q, 128, 128);
+        return 0;
+    }
+    for (int ph = 0; ph < stride; ++ph)
+        for (int pw = 0; pw < stride; ++pw) {
+            ConvDgradProb p;
+            HAB_TRY(build(p, d, dy, wd, mask, add, dx, ph, pw));
+            if (p.Hc <= 0 || p.Wc <= 0) continue;
+            if (p.K <= 0) {
+                for (int m = 0; m < p.M; ++m)
+                    for (int n = 0; n < p.N; ++n) p.store(m, n, 0.f);
+                continue;
+            }
+            if (!p.dma_ok()) return -1;
+            host_dma_igemm(p, 256, 32);
+        }
+    return 0;
+}
+
 extern "C" int hc_conv2d_fwd(const float* x, const float* wf, const float* bias, float* y, int B, int H, int W, int C, int Cout,
                              int KH, int KW, int stride, int pad, int relu) {
     ConvFwdProb p;

@@ -174,3 +174,45 @@ def test_flatten_linear(hc):
     da = torch.zeros(B, K)
     assert hc.hc_linear_dgrad(P(gy), N, P(wp), K, None, 0, 0, P(da), K, B, K, N, 0) == 0
     assert torch.allclose(da.view(B, Hh, Ww, Cc), nhwc(a.grad), atol=1e-4)
+
+
+DMA_CONVS = [  # B, H, W, C, Cout, K, stride, pad   (C, Cout % 32 == 0: the LDS-DMA staged kernels)
+    (2, 20, 20, 32, 64, 4, 2, 0),   # SimpleCNN conv2 geometry: merged stride classes
+    (3, 9, 9, 64, 32, 3, 1, 0),
+    (2, 12, 10, 32, 32, 3, 1, 1),   # padding: buffer-range zero fill + tap masks
+    (2, 12, 12, 32, 64, 3, 2, 1),   # 3x3 / 2: unequal stride classes (per-class only)
+    (2, 11, 13, 32, 64, 1, 2, 0),   # 1x1 / 2: classes without taps
+    (2, 10, 12, 32, 32, 4, 2, 1),   # kernel = 2 x stride with padding: merged, N = 128
+    (2, 9, 7, 16, 32, 2, 2, 0),     # kernel = stride, odd extent: merged, N = 64
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cc,Cout,K,s,p", DMA_CONVS)
+def test_dma_staged_functors_on_host(hc, B, H, W, Cc, Cout, K, s, p):
+    """The LDS-DMA staged kernels' address functors (window, row offset, tap mask, scalar tap offsets, buffer range check) and
+    the vector epilogue, emulated on the host: forward, per-class data gradient and the merged-stride-class data gradient."""
+    torch.manual_seed(1)
+    x = torch.randn(B, Cc, H, W, requires_grad=True)
+    w = (torch.randn(Cout, Cc, K, K) * 0.1).requires_grad_()
+    b = torch.randn(Cout)
+    y_ref = F.relu(F.conv2d(x, w, b, stride=s, padding=p))
+    wf, wd = repack(hc, w.detach())
+    xh = nhwc(x.detach())
+    Ho, Wo = y_ref.shape[2:]
+    if Cc % 32 == 0:
+        y = torch.full((B, Ho, Wo, Cout), 7.0)
+        assert hc.hc_conv2d_fwd_dma(P(xh), P(wf), P(b), P(y), B, H, W, Cc, Cout, K, K, s, p, 1) == 0
+        assert torch.allclose(y, nhwc(y_ref), atol=1e-4, rtol=1e-4)
+    gy = torch.randn_like(y_ref)
+    y_ref.backward(gy)
+    dy_pre = nhwc(gy * (y_ref > 0))
+    m, add = torch.randn(B, H, W, Cc), torch.randn(B, H, W, Cc)
+    ref = (nhwc(x.grad) + add) * (m > 0)
+    for merged in (0, 1):
+        dx = torch.full((B, H, W, Cc), 7.0)  # every element must be written
+        rc = hc.hc_conv2d_dgrad_dma(P(dy_pre), P(wd), P(m), P(add), P(dx), B, H, W, Cc, Cout, K, K, s, p, merged)
+        if merged and (K % s != 0 or s == 1):
+            assert rc == -2  # merged form needs kernel % stride == 0
+            continue
+        assert rc == 0, rc
+        assert torch.allclose(dx, ref, atol=1e-4, rtol=1e-4), merged
