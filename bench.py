@@ -195,6 +195,9 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    if os.environ.get("HAB_BENCH_CHECKSUM"):  # development: parameters must not depend on how the gradient exchange is scheduled
+        pf = eng.params_flat.double()
+        print(f"[rank {rank}] params checksum {pf.sum().item():.12e} {pf.abs().sum().item():.12e}", flush=True)
     if rank != 0:
         torch.distributed.destroy_process_group()
         return

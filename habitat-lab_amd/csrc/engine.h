@@ -58,6 +58,8 @@ struct hab_policy {
     hab_allreduce_fn allreduce_cb = nullptr;            // optional in-place all-reduce of a small device buffer (DD-PPO RMV stats)
     void* allreduce_ctx = nullptr;
     int world_size = 1;
+    hab_grad_ready_fn grad_ready_cb = nullptr;          // optional: tail of the gradient arena is final (early DD-PPO all-reduce)
+    void* grad_ready_ctx = nullptr;
     // probe
     int probe_tag = -1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> probe_events;
@@ -85,6 +87,7 @@ inline int add_param(hab_policy* e, const std::string& name, std::initializer_li
 int build_resnet(hab_policy* e);
 void destroy_resnet(hab_policy* e);
 int resnet_repack(hab_policy* e, hipStream_t s);
+void grad_tail_ready(hab_policy* e, int first_param);
 int resnet_feature_shape(const hab_policy* e, int* c, int* hf, int* wf);
 int resnet_encode(hab_policy* e, const hab_obs* obs, int n, float* out, hipStream_t s);
 int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s);

@@ -139,6 +139,17 @@ extern "C" int hab_policy_set_training(hab_policy* e, int training) {
     e->training = training ? 1 : 0;
     return HAB_OK;
 }
+extern "C" int hab_policy_set_grad_ready(hab_policy* e, hab_grad_ready_fn fn, void* ctx) {
+    if (!e) return HAB_ERR_ARG;
+    e->grad_ready_cb = fn; e->grad_ready_ctx = ctx;
+    return HAB_OK;
+}
+// Everything from parameter `first_param` to the end of the gradient arena has been written (enqueued) for this backward.
+void grad_tail_ready(hab_policy* e, int first_param) {
+    if (!e->grad_ready_cb) return;
+    const int64_t first = e->g(first_param) - e->G;
+    e->grad_ready_cb(first, (int64_t)e->param_floats - first, e->grad_ready_ctx);
+}
 extern "C" int hab_policy_set_allreduce(hab_policy* e, hab_allreduce_fn fn, void* ctx, int world_size) {
     if (!e || world_size < 1) return HAB_ERR_ARG;
     e->allreduce_cb = fn; e->allreduce_ctx = ctx; e->world_size = world_size;
@@ -413,6 +424,7 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
       HAB_TRY(linear_wgrad(dfc, e->rnn_ld, W + e->w_a3, e->fc_in, e->g(e->i_fcw), e->fc_in, B, H, e->fc_in, 32, e->fc_in / 32, 0,
                            ws, e->ws_floats, stream)); }
     HAB_TRY(colsum(dfc, e->rnn_ld, B, H, e->g(e->i_fcb), 0, ws, e->ws_floats, stream));
+    grad_tail_ready(e, e->i_fcw);  // fc, recurrent encoder and heads are final; the conv stack's gradients follow
     { Probe pr(e, HAB_PROBE_FC_DGRAD, stream);
       HAB_TRY(linear_dgrad(dfc, e->rnn_ld, e->PK + e->pk_fc, e->fc_in, nullptr, 0, 0, W + e->w_da3, e->fc_in, B, e->fc_in, H, 0,
                            ws, e->ws_floats, stream)); }

@@ -484,6 +484,7 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
     HAB_TRY(linear_wgrad(dfc, e->rnn_ld, W + r->comp.w_out, r->fc_in, e->g(r->i_fcw), r->fc_in, B, H, r->fc_in, r->comp_c, r->comp_hw,
                          0, ws, e->ws_floats, s));
     HAB_TRY(colsum(dfc, e->rnn_ld, B, H, e->g(r->i_fcb), 0, ws, e->ws_floats, s));
+    grad_tail_ready(e, r->i_fcw);  // visual_fc, recurrent encoder, heads are final (the embeddings in front of the encoder are too)
     if (obs->visual_features) return HAB_OK;  // frozen encoder: its parameters get no gradient (the arena slots stay zero)
     float* d_comp = gp.get();  // gradient wrt compression output, masked by its ReLU
     HAB_TRY(linear_dgrad(dfc, e->rnn_ld, e->PK + r->pk_fc, r->fc_in, W + r->comp.w_out, r->fc_in, r->fc_in, d_comp, r->fc_in, B,

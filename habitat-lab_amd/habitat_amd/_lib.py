@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libhabitat_amd.so")
 
 vp = c_void_p
 ALLREDUCE_FN = C.CFUNCTYPE(None, c_void_p, c_int, c_float, c_void_p)  # hab_allreduce_fn
+GRAD_READY_FN = C.CFUNCTYPE(None, c_int64, c_int64, c_void_p)       # hab_grad_ready_fn
 
 
 class HabError(RuntimeError):
@@ -85,6 +86,7 @@ SIGNATURES = {
     "hab_policy_param_info": (c_int, [vp, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
     "hab_policy_param_is_buffer": (c_int, [vp, c_int]),
     "hab_policy_set_training": (c_int, [vp, c_int]),
+    "hab_policy_set_grad_ready": (c_int, [vp, GRAD_READY_FN, vp]),
     "hab_policy_set_allreduce": (c_int, [vp, ALLREDUCE_FN, vp, c_int]),
     "hab_policy_param_floats": (c_int64, [vp]),
     "hab_policy_packed_floats": (c_int64, [vp]),

@@ -149,6 +149,15 @@ class PolicyEngine:
         self._allreduce_cb = _lib.ALLREDUCE_FN(_cb)  # keep the trampoline alive
         check(self.L.hab_policy_set_allreduce(self.h, self._allreduce_cb, None, int(world_size)), "hab_policy_set_allreduce")
 
+    def set_grad_ready(self, fn):
+        """fn(first, count): called inside backward() once grads_flat[first:first + count] (the tail from the visual fc weight on)
+        has been produced -- DD-PPO starts its all-reduce of that range there, overlapped with the conv stack's backward."""
+        if fn is None:
+            self._grad_ready_cb = _lib.GRAD_READY_FN(0)
+        else:
+            self._grad_ready_cb = _lib.GRAD_READY_FN(lambda first, count, _ctx: fn(int(first), int(count)))
+        check(self.L.hab_policy_set_grad_ready(self.h, self._grad_ready_cb, None), "hab_policy_set_grad_ready")
+
     def repack(self):
         check(self.L.hab_policy_repack(self.h, stream_ptr()), "hab_policy_repack")
         self._packed_version = self.params_flat._version

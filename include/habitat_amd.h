@@ -304,6 +304,13 @@ int hab_policy_set_training(hab_policy* p, int training);
  * (running_mean_and_var.py:38-41,47-49).  The engine calls it during evaluate in training mode when world_size > 1. */
 typedef void (*hab_allreduce_fn)(float* buf, int n, float scale, void* ctx);
 int hab_policy_set_allreduce(hab_policy* p, hab_allreduce_fn fn, void* ctx, int world_size);
+/* DD-PPO: early gradient exchange.  During hab_policy_backward the engine calls fn(first, count, ctx) once, right after the last
+ * kernel that writes grads[first .. first + count) has been enqueued: the contiguous TAIL of the gradient arena from the visual
+ * fc weight to the end (fc / visual_fc, recurrent encoder, heads: 99.5 % of the bytes of the SimpleCNN policy, 63 % of ResNet18's),
+ * whose producers run BEFORE the convolution stack's backward.  The caller starts an asynchronous all-reduce of that range there
+ * (DistributedDataParallel's bucket overlap, ddppo.py:128-140, with one bucket) and reduces [0, first) after backward returns. */
+typedef void (*hab_grad_ready_fn)(int64_t first, int64_t count, void* ctx);
+int hab_policy_set_grad_ready(hab_policy* p, hab_grad_ready_fn fn, void* ctx);
 /* actions == NULL -> get_value only.  hidden_*: (n, Lh, H), Lh = layers (GRU) / 2*layers (LSTM). */
 /* The visual encoder alone (ResNetEncoder.forward, resnet_policy.py:255-276) on n frames: out (n, C, Hf, Wf) fp32 NCHW, the tensor
  * ppo_trainer.py:271-279,467-471 stores under "visual_features" when the encoder is frozen.  Uses the current training flag

@@ -35,6 +35,9 @@ class FakeEngine:
     def set_allreduce(self, fn, world_size):
         self.allreduce, self.world = fn, world_size
 
+    def set_grad_ready(self, fn):
+        self.grad_ready = fn
+
 
 def _worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "habitat-lab_amd")):
@@ -54,9 +57,20 @@ def _worker(rank, world, port, q):
     stats = torch.full((8,), float(rank + 1))
     upd.actor_critic.engine.allreduce(stats, 1.0 / world)
     assert torch.allclose(stats, torch.full((8,), (world + 1) / 2.0)) and upd.actor_critic.engine.world == world
+    g_first = upd.actor_critic.engine.grads_flat
+    # early exchange: the engine reports the tail [700, 1000) mid-backward, the head follows in _all_reduce_grads
+    upd.actor_critic.engine.grad_ready(700, 300)
+    assert upd._grad_work is not None and upd._grad_work[1] == 700
     DecentralizedDistributedMixin._all_reduce_grads(upd)
+    assert upd._grad_work is None
+    g_reduced = g_first.clone()
+    # a backward that never reports (e.g. a policy without the hook) falls back to the single all-reduce
+    g2 = torch.full((1000,), float(rank + 1))
+    upd.actor_critic.engine.grads_flat = g2
+    DecentralizedDistributedMixin._all_reduce_grads(upd)
+    assert torch.equal(g2, torch.full((1000,), float(sum(range(1, world + 1)))))
     out["params"] = upd.actor_critic.engine.params_flat.clone()
-    out["grads"] = upd.actor_critic.engine.grads_flat.clone()
+    out["grads"] = g_reduced
     out["g_local"] = g_local
     out["repacked"] = upd.actor_critic.engine.repacked
     assert DecentralizedDistributedMixin._world_size(upd) == world
