@@ -173,3 +173,21 @@ def test_base_trainer_schedules():
     assert fired[:7] == [True, False, False, True, False, False, True] and sum(fired) == 4 and t.is_done()
     with pytest.raises(RuntimeError):
         BaseRLTrainer(get_config("pointnav/ppo_pointnav_example.yaml", ["habitat_baselines.num_updates=10"]))
+
+
+def test_checkpoint_polling_helpers(tmp_path):
+    """utils/common.py:333-377 semantics used by BaseRLTrainer.eval: id from `ckpt.ID.pth`, folder polled in order of creation,
+    `latest` and hidden resume-state files skipped."""
+    import os
+    import time
+    from habitat_amd.common.base_trainer import get_checkpoint_id, poll_checkpoint_folder
+    assert get_checkpoint_id("/a/b/ckpt.12.pth") == 12 and get_checkpoint_id("ckpt.pth") is None and get_checkpoint_id("x.3.7.pth") == 7
+    d = str(tmp_path)
+    assert poll_checkpoint_folder(d, -1) is None
+    for i, name in enumerate(["ckpt.1.pth", "latest.pth", "ckpt.0.pth", ".habitat-resume-stateeval.pth"]):
+        with open(os.path.join(d, name), "w") as f:
+            f.write("x")
+        os.utime(os.path.join(d, name), (1000 + i, 1000 + i))
+    assert os.path.basename(poll_checkpoint_folder(d, -1)) == "ckpt.1.pth"   # oldest first, not by name
+    assert os.path.basename(poll_checkpoint_folder(d, 0)) == "ckpt.0.pth"
+    assert poll_checkpoint_folder(d, 1) is None
