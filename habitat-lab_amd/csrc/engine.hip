@@ -278,11 +278,11 @@ extern "C" int hab_policy_act(hab_policy* e, const hab_obs* obs, const float* hi
     HAB_TRY(encoder_forward(e, obs, masks, nullptr, n, stream));
     const float* x = W + e->w_rnnin;
     int ldx = e->rnn_ld;
-    float* hm = W + e->w_hmask;  // [2L][n][H] masked h (and c)
-    for (int l = 0; l < L; ++l) {
-        HAB_TRY(masked_rows(hidden_in + (size_t)l * H, Lh * H, masks, hm + (size_t)l * n * H, n, H, stream));
-        if (e->d.rnn_type == HAB_RNN_LSTM)
-            HAB_TRY(masked_rows(hidden_in + (size_t)(L + l) * H, Lh * H, masks, hm + (size_t)(L + l) * n * H, n, H, stream));
+    // The episode-start mask (h * masks, rnn_state_encoder.py:308-311) is applied to the state operand inside the step kernel and
+    // every layer reads / writes the caller's (n, Lh, H) tensors in place through row strides: no masked / dense staging copies.
+    if (hidden_out) {  // in-place update is not possible: a layer's workgroups read whole state rows while others write them
+        const float* a0 = hidden_in; const float* a1 = hidden_in + (size_t)n * Lh * H;
+        if (hidden_out < a1 && a0 < hidden_out + (size_t)n * Lh * H) return HAB_ERR_ARG;
     }
     float* step_h = W + e->w_step_h;
     for (int l = 0; l < L; ++l) {
@@ -290,19 +290,16 @@ extern "C" int hab_policy_act(hab_policy* e, const hab_obs* obs, const float* hi
         float* hout = hidden_out ? hidden_out + (size_t)l * H : step_h + (size_t)(l & 1) * n * H;
         const int hstride = hidden_out ? Lh * H : H;
         float* cout = (hidden_out && e->d.rnn_type == HAB_RNN_LSTM) ? hidden_out + (size_t)(L + l) * H : nullptr;
-        HAB_TRY(rnn_step_layer_forward(e->d.rnn_type, H, lp, x, ldx, hm + (size_t)l * n * H,
-                                       e->d.rnn_type == HAB_RNN_LSTM ? hm + (size_t)(L + l) * n * H : nullptr, n,
+        HAB_TRY(rnn_step_layer_forward(e->d.rnn_type, H, lp, x, ldx, hidden_in + (size_t)l * H, Lh * H,
+                                       e->d.rnn_type == HAB_RNN_LSTM ? hidden_in + (size_t)(L + l) * H : nullptr, Lh * H, masks, n,
                                        W + e->w_gistep, hout, hstride, cout, Lh * H, W + e->w_ws, e->ws_floats, stream));
-        // next layer's input: dense copy of this layer's output
-        float* dense = step_h + (size_t)(l & 1) * n * H;
-        if (hidden_out) HAB_TRY(copy_rows(hout, nullptr, hstride, dense, H, n, H, stream));
-        x = dense;
-        ldx = H;
+        x = hout;  // next layer's input / the heads' features, read with the same row stride
+        ldx = hstride;
     }
     HeadsArgs ha;
     ha.B = n; ha.H = H; ha.A = e->d.num_actions;
     ha.mode = actions ? (deterministic ? 2 : 1) : 2;
-    ha.feats = x; ha.w_actor = e->p(e->i_aw); ha.b_actor = e->p(e->i_ab); ha.w_critic = e->p(e->i_cw); ha.b_critic = e->p(e->i_cb);
+    ha.feats = x; ha.feats_ld = ldx; ha.w_actor = e->p(e->i_aw); ha.b_actor = e->p(e->i_ab); ha.w_critic = e->p(e->i_cw); ha.b_critic = e->p(e->i_cb);
     ha.actions_in = nullptr; ha.rows = nullptr; ha.noise = exp_noise;
     ha.actions_out = actions ? actions : reinterpret_cast<int64_t*>(W + e->w_dzv);
     ha.value = values; ha.logp = action_log_probs ? action_log_probs : W + e->w_logp; ha.entropy = nullptr;
@@ -350,7 +347,7 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
     }
     HeadsArgs ha;
     ha.B = B; ha.H = H; ha.A = e->d.num_actions; ha.mode = 0;
-    ha.feats = x; ha.w_actor = e->p(e->i_aw); ha.b_actor = e->p(e->i_ab); ha.w_critic = e->p(e->i_cw); ha.b_critic = e->p(e->i_cb);
+    ha.feats = x; ha.feats_ld = ldx; ha.w_actor = e->p(e->i_aw); ha.b_actor = e->p(e->i_ab); ha.w_critic = e->p(e->i_cw); ha.b_critic = e->p(e->i_cb);
     ha.actions_in = actions; ha.rows = rows; ha.noise = nullptr; ha.actions_out = nullptr;
     ha.value = value ? value : W + e->w_value; ha.logp = log_prob ? log_prob : W + e->w_logp;
     ha.entropy = entropy ? entropy : W + e->w_ent;

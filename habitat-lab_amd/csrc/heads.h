@@ -6,7 +6,7 @@ namespace hab {
 
 struct HeadsArgs {
     int B, H, A, mode;           // mode 0 evaluate, 1 sample (exp noise), 2 deterministic
-    const float* feats;          // [B][H]
+    const float* feats; int feats_ld;  // [B][feats_ld], first H columns (feats_ld = 0 -> H)
     const float* w_actor; const float* b_actor;    // [A][H], [A]
     const float* w_critic; const float* b_critic;  // [1][H], [1]
     const int64_t* actions_in;   // mode 0: arena (rows,1) gathered through rows

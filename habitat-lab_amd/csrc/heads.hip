@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) heads_fwd_kernel(const HeadsArgs a) {
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (f >= a.B) return;
-    const float* x = a.feats + (size_t)f * a.H;
+    const float* x = a.feats + (size_t)f * (a.feats_ld ? a.feats_ld : a.H);
     float acc[MAX_A + 1];
 #pragma unroll
     for (int k = 0; k <= MAX_A; ++k) acc[k] = 0.f;

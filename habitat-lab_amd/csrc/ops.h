@@ -68,9 +68,9 @@ int rnn_frag_init(const float* h0, const int* env_rows, int env_stride, const ui
 int rnn_seq_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx,
                           const float* hinit, const float* cinit, const PackInfo& pk, float* ws, size_t ws_floats,
                           hipStream_t stream);
-int rnn_step_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const float* x, int ldx, const float* h_in,
-                           const float* c_in, int n, float* gi_scratch, float* h_out, int h_out_stride, float* c_out,
-                           int c_out_stride, float* ws, size_t ws_floats, hipStream_t stream);
+int rnn_step_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const float* x, int ldx, const float* h_in, int h_in_stride,
+                           const float* c_in, int c_in_stride, const uint8_t* masks, int n, float* gi_scratch, float* h_out,
+                           int h_out_stride, float* c_out, int c_out_stride, float* ws, size_t ws_floats, hipStream_t stream);
 int rnn_seq_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx,
                            const float* dout, float* dx, int lddx, const float* dx_mask, int ldmask, int mask_cols,
                            const PackInfo& pk, float* scratch /* 3*F*H floats */, float* ws, size_t ws_floats,

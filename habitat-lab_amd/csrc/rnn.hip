@@ -47,6 +47,7 @@ struct StepArgs {
     int R, H;
     const float* hp_base; const int* hp_idx; int hp_stride;   // hidden entering the step, row q
     const float* cp_base; const int* cp_idx; int cp_stride;   // LSTM cell entering the step
+    const uint8_t* row_mask;                                   // optional [R]: state entering row q is zeroed where 0 (episode start)
     const int* out_idx;                                        // row q -> frame (null = q)
     const float* gi;                                           // [frames][G*H] input projection incl. b_ih
     const float* w_hh; const float* b_hh;                      // [G*H][H]
@@ -68,6 +69,7 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
     const int H = a.H;
     const int q = min(row0 + i, a.R - 1);
     const float* hrow = a.hp_base + (size_t)(a.hp_idx ? a.hp_idx[q] : q) * a.hp_stride;
+    const float keep = (a.row_mask && !a.row_mask[q]) ? 0.f : 1.f;  // h * mask (rnn_state_encoder.py:308-311), applied to the operand
     const int kq = H / NW;  // per-wave K range (multiple of 16)
     const int kb = wave * kq;
     f32x4 acc[G];
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int k = kb + c + 16 * j + 4 * kg;
-            av[j] = *reinterpret_cast<const f32x4*>(hrow + k);
+            av[j] = *reinterpret_cast<const f32x4*>(hrow + k) * keep;
 #pragma unroll
             for (int g = 0; g < G; ++g) bv[j][g] = *reinterpret_cast<const f32x4*>(wrow[g] + k);
         }
@@ -95,7 +97,7 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
     }
     for (; c < kq; c += 16) {
         const int k = kb + c + 4 * kg;
-        const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + k);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(hrow + k) * keep;
         f32x4 bv[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) bv[g] = *reinterpret_cast<const f32x4*>(wrow[g] + k);
@@ -124,7 +126,8 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
     }
     const int f = a.out_idx ? a.out_idx[qq] : qq;
     const int uu = u0 + u;
-    const float hp = a.hp_base[(size_t)(a.hp_idx ? a.hp_idx[qq] : qq) * a.hp_stride + uu];
+    const bool kept = !(a.row_mask && !a.row_mask[qq]);
+    const float hp = kept ? a.hp_base[(size_t)(a.hp_idx ? a.hp_idx[qq] : qq) * a.hp_stride + uu] : 0.f;
     const float* gi = a.gi + (size_t)f * G * H;
     if constexpr (G == 3) {
         const float rg = sigmoidf_(gi[uu] + gh[0]);
@@ -139,7 +142,7 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
             a.hprev[(size_t)f * H + uu] = hp;
         }
     } else {
-        const float cp = a.cp_base[(size_t)(a.cp_idx ? a.cp_idx[qq] : qq) * a.cp_stride + uu];
+        const float cp = kept ? a.cp_base[(size_t)(a.cp_idx ? a.cp_idx[qq] : qq) * a.cp_stride + uu] : 0.f;
         const float ig = sigmoidf_(gi[uu] + gh[0]);
         const float fg = sigmoidf_(gi[H + uu] + gh[1]);
         const float gg = tanhf(gi[2 * H + uu] + gh[2]);
@@ -189,6 +192,7 @@ int rnn_seq_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const R
             a.hp_base = wk.out; a.hp_idx = pk.select_inds + pk.step_offsets[s - 1]; a.hp_stride = H;
             a.cp_base = wk.c; a.cp_idx = a.hp_idx; a.cp_stride = H;
         }
+        a.row_mask = nullptr;
         a.out_idx = pk.select_inds + pk.step_offsets[s];
         a.gi = wk.gi; a.w_hh = lp.w_hh; a.b_hh = lp.b_hh;
         a.gates = wk.gates; a.hn = wk.hn; a.hprev = wk.hprev; a.cprev = wk.cprev; a.c = wk.c;
@@ -199,15 +203,16 @@ int rnn_seq_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const R
 }
 
 // Inference step (rollout `act`, rnn_state_encoder.py:301-316): n rows, masked state supplied dense.
-int rnn_step_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const float* x, int ldx, const float* h_in,
-                           const float* c_in, int n, float* gi_scratch, float* h_out, int h_out_stride, float* c_out,
-                           int c_out_stride, float* ws, size_t ws_floats, hipStream_t stream) {
+int rnn_step_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const float* x, int ldx, const float* h_in, int h_in_stride,
+                           const float* c_in, int c_in_stride, const uint8_t* masks, int n, float* gi_scratch, float* h_out,
+                           int h_out_stride, float* c_out, int c_out_stride, float* ws, size_t ws_floats, hipStream_t stream) {
     const int G = rnn_type == RNN_GRU ? 3 : 4;
     HAB_TRY(linear_fwd(x, ldx, lp.w_ih, lp.in_dim, lp.b_ih, gi_scratch, G * H, n, G * H, lp.in_dim, 0, 0, ws, ws_floats, stream));
     StepArgs a;
     a.R = n; a.H = H;
-    a.hp_base = h_in; a.hp_idx = nullptr; a.hp_stride = H;
-    a.cp_base = c_in; a.cp_idx = nullptr; a.cp_stride = H;
+    a.hp_base = h_in; a.hp_idx = nullptr; a.hp_stride = h_in_stride;
+    a.cp_base = c_in; a.cp_idx = nullptr; a.cp_stride = c_in_stride;
+    a.row_mask = masks;  // the episode-start mask is applied to the state operand inside the kernel
     a.out_idx = nullptr; a.gi = gi_scratch; a.w_hh = lp.w_hh; a.b_hh = lp.b_hh;
     a.gates = nullptr; a.hn = nullptr; a.hprev = nullptr; a.cprev = nullptr; a.c = nullptr;
     a.out = h_out; a.out_stride = h_out_stride; a.c_out = c_out; a.c_out_stride = c_out_stride;

@@ -318,6 +318,8 @@ int hab_policy_set_grad_ready(hab_policy* p, hab_grad_ready_fn fn, void* ctx);
 int hab_policy_encode(hab_policy* p, const hab_obs* obs, int n, float* out, hipStream_t stream);
 /* (C, Hf, Wf) of that tensor = ResNetEncoder.output_shape. */
 int hab_policy_visual_feature_shape(const hab_policy* p, int* c, int* hf, int* wf);
+/* actions == NULL -> get_value only.  hidden_*: (n, Lh, H), Lh = layers (GRU) / 2*layers (LSTM); hidden_out must not overlap hidden_in
+ * (the episode-start mask is applied to hidden_in on the fly and the layers update the state through row strides). */
 int hab_policy_act(hab_policy* p, const hab_obs* obs, const float* hidden_in, const uint8_t* masks,
                    const float* exp_noise, int deterministic, int n, float* values, int64_t* actions,
                    float* action_log_probs, float* hidden_out, float* probs_out /* (n,8) or NULL */, hipStream_t stream);
