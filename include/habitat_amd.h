@@ -311,7 +311,6 @@ int hab_policy_set_allreduce(hab_policy* p, hab_allreduce_fn fn, void* ctx, int 
  * (DistributedDataParallel's bucket overlap, ddppo.py:128-140, with one bucket) and reduces [0, first) after backward returns. */
 typedef void (*hab_grad_ready_fn)(int64_t first, int64_t count, void* ctx);
 int hab_policy_set_grad_ready(hab_policy* p, hab_grad_ready_fn fn, void* ctx);
-/* actions == NULL -> get_value only.  hidden_*: (n, Lh, H), Lh = layers (GRU) / 2*layers (LSTM). */
 /* The visual encoder alone (ResNetEncoder.forward, resnet_policy.py:255-276) on n frames: out (n, C, Hf, Wf) fp32 NCHW, the tensor
  * ppo_trainer.py:271-279,467-471 stores under "visual_features" when the encoder is frozen.  Uses the current training flag
  * (RunningMeanAndVar statistics are updated iff training, exactly like calling the module).  arch 1 only. */
