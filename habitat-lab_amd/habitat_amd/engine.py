@@ -143,8 +143,11 @@ class PolicyEngine:
         base = self.work.data_ptr()
 
         def _cb(buf, n, scale, _ctx):
-            off = (buf - base) // 4
-            fn(self.work[off:off + n], scale)
+            try:  # an exception must not vanish inside the ctypes trampoline: it is re-raised when the engine call returns
+                off = (buf - base) // 4
+                fn(self.work[off:off + n], scale)
+            except BaseException as exc:  # noqa: BLE001
+                self._cb_error = self._cb_error or exc
 
         self._allreduce_cb = _lib.ALLREDUCE_FN(_cb)  # keep the trampoline alive
         check(self.L.hab_policy_set_allreduce(self.h, self._allreduce_cb, None, int(world_size)), "hab_policy_set_allreduce")
@@ -155,8 +158,21 @@ class PolicyEngine:
         if fn is None:
             self._grad_ready_cb = _lib.GRAD_READY_FN(0)
         else:
-            self._grad_ready_cb = _lib.GRAD_READY_FN(lambda first, count, _ctx: fn(int(first), int(count)))
+            def _cb(first, count, _ctx):
+                try:
+                    fn(int(first), int(count))
+                except BaseException as exc:  # noqa: BLE001
+                    self._cb_error = self._cb_error or exc
+
+            self._grad_ready_cb = _lib.GRAD_READY_FN(_cb)
         check(self.L.hab_policy_set_grad_ready(self.h, self._grad_ready_cb, None), "hab_policy_set_grad_ready")
+
+    _cb_error = None
+
+    def _raise_cb_error(self):
+        if self._cb_error is not None:
+            exc, self._cb_error = self._cb_error, None
+            raise _lib.HabError("a collective callback failed inside the engine call") from exc
 
     def repack(self):
         check(self.L.hab_policy_repack(self.h, stream_ptr()), "hab_policy_repack")
@@ -186,6 +202,7 @@ class PolicyEngine:
         self._fresh()
         o = self._obs(rgb, depth, None, None, extra)
         check(self.L.hab_policy_encode(self.h, C.byref(o), n, ptr(out), stream_ptr()), "hab_policy_encode")
+        self._raise_cb_error()
 
     def act(self, rgb, depth, goal, hidden_in, masks, n, *, exp_noise=None, deterministic=False, values, actions=None,
             action_log_probs=None, hidden_out=None, probs_out=None, prev_actions=None, extra=None):
@@ -202,6 +219,7 @@ class PolicyEngine:
         check(self.L.hab_policy_evaluate(self.h, C.byref(o), ptr(rows), ptr(hidden0), self.Lh * self.hidden, ptr(masks),
                                          ptr(actions), C.byref(pack.struct), B, n, ptr(value), ptr(log_prob), ptr(entropy),
                                          stream_ptr()), "hab_policy_evaluate")
+        self._raise_cb_error()
 
     def final_hidden(self, out):
         check(self.L.hab_policy_final_hidden(self.h, ptr(out), stream_ptr()), "hab_policy_final_hidden")
@@ -211,6 +229,7 @@ class PolicyEngine:
         o = self._obs(rgb, depth, goal, prev_actions, extra)
         check(self.L.hab_policy_backward(self.h, C.byref(o), ptr(rows), ptr(actions), C.byref(pack.struct), ptr(d_value),
                                          ptr(d_log_prob), ptr(d_entropy), stream_ptr()), "hab_policy_backward")
+        self._raise_cb_error()
 
     def tap(self, which: int) -> torch.Tensor:
         p, n = C.c_void_p(), C.c_int64(0)
