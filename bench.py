@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the DD-PPO training hot path on synthetic PointNav RGB-D 256x256.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]                       (N = 1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W                             (N > 1, one rank per GPU, RCCL)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is ONE full cycle of the hot path on one batch of synthetic input: rollout collection of
-64 envs x 128 steps (policy forward per step) -> GAE -> PPO update (ppo_epoch x num_mini_batch
-forward+backward+clip+Adam) [-> gradient all-reduce per minibatch when N > 1].  Workload at N=1 is
-BASELINE.json configs[1]: PointNav SimpleCNN+GRU, 64 envs x 128 steps, 256x256 RGB-D, hyper-parameters of
-config/pointnav/ppo_pointnav_habitat_iccv19.yaml (E=4, M=4).  `value` = N * 64 * 128 * K / max-over-ranks wall
-time.  The JSON line also carries `roofline` (dominant conv kernel, HIP-event timed inside the timed region)
-and `cpu_baseline` (the CPU oracle restatement of the reference path on a bounded sample, rank 0, N = 1).
+N = 1 runs in this process.  N > 1 needs one rank per GPU: when WORLD_SIZE is not in the environment the script re-launches itself
+as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` (the form
+the driver uses directly); ranks talk RCCL over xGMI (backend "nccl").
+
+A "step" is ONE full cycle of the hot path on one batch of synthetic input: rollout collection of 64 envs x 128 steps (policy
+forward per step) -> GAE -> PPO update (ppo_epoch x num_mini_batch forward + backward + clip + Adam) [-> gradient all-reduce per
+minibatch when N > 1].  Workload at N=1 is BASELINE.json configs[1]: PointNav SimpleCNN+GRU, 64 envs x 128 steps, 256x256 RGB-D,
+hyper-parameters of config/pointnav/ppo_pointnav_habitat_iccv19.yaml (E=4, M=4).  `value` = env-steps collected by all ranks /
+max-over-ranks wall time, observations generated on the device (inputs never cross PCIe).
+
+Extra objects on the JSON line (rank 0; the sub-records only at N = 1, all measured in THIS run, after the timed region):
+  roofline      the call site with the largest share of the GPU time (conv1 forward: obs ingest + 8x8/4 convolution), HIP-event timed
+                on the launch stream inside the timed region; `kernels` = the same figure for every contraction call site + the
+                recurrent layers, from one extra (untimed) cycle with all probes on
+  cpu_baseline  the CPU oracle restatement of the reference path over a FULL 64 envs x 128 steps update cycle (kind "port": the
+                reference itself cannot travel to the GPU box; tests/golden pins the oracle to it), torch threads stated
+  parity        the same rollout the CPU leg produced, pushed through the HIP path: relative error of the update's losses, of
+                the GAE returns, and of one full-size minibatch's values / log-probs
+  c3            BASELINE.json configs[2] (ResNet18 + 2-layer LSTM) cycles: env-steps/s, ms
+  encoder_r18_b8192   the north-star kernel target: ResNet18 encoder alone on 2 x 4096 frames, forward / backward TFLOP/s and
+                fraction of the fp32 MFMA peak
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,8 +39,6 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "habitat-lab_amd"))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 NUM_ENVS, NUM_STEPS, OBS = 64, 128, 256
@@ -47,7 +59,7 @@ WORKLOADS = {
                envs=32, steps=64),
 }
 
-# probe tag -> (description, flops per frame)   SimpleCNN @256^2 RGB-D (a4)
+# probe name -> (HAB_PROBE tag, algorithmic flops per frame)   SimpleCNN @256^2 RGB-D (a4)
 PROBES = {
     "conv1_fwd": (0, 2.0 * 63 * 63 * 32 * 256), "conv2_fwd": (1, 2.0 * 30 * 30 * 64 * 512), "conv3_fwd": (2, 2.0 * 28 * 28 * 32 * 576),
     "fc_fwd": (3, 2.0 * 25088 * 512), "conv1_wgrad": (4, 2.0 * 63 * 63 * 32 * 256), "conv2_wgrad": (5, 2.0 * 30 * 30 * 64 * 512),
@@ -56,7 +68,15 @@ PROBES = {
     # ResNet18 encoder @256^2 RGB-D (a5): 168.82 MMAC forward; backward = dgrad + wgrad of every conv except the
     # stem's dgrad (25.69 MMAC)
     "enc_fwd": (11, 2.0 * 168.82e6), "enc_bwd": (12, 2.0 * (2 * 168.82e6 - 25.69e6)),
+    # recurrent layers (packed sequence forward / BPTT): input projection + recurrence, GRU 1 x 512 on a 514-wide input
+    "rnn_fwd": (13, 2.0 * 3 * 512 * (514 + 512)), "rnn_bwd": (14, 2.0 * 2 * 3 * 512 * (514 + 512)),
 }
+C2_TABLE = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_wgrad", "fc_dgrad", "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad",
+            "conv1_wgrad", "rnn_fwd", "rnn_bwd"]
+# kernel launched by a probed call site (rocprofv3 names), for the HBM-traffic lookup in the committed --pmc passes
+PROBE_KERNELS = {"conv2_dgrad": "igemm_dma_kernel<ConvDgradMergedProb", "conv1_fwd": "igemm_kernel<ObsConvFwdProb",
+                 "conv1_wgrad": "igemm_kernel<ObsConvWgradProb", "conv2_wgrad": "igemm_kernel<ConvWgradProb",
+                 "conv3_wgrad": "igemm_dma_wgrad_kernel", "conv2_fwd": "igemm_dma_kernel<ConvFwdProb"}
 
 
 def make_trainer(workload: str, total_updates: int):
@@ -77,27 +97,43 @@ def make_trainer(workload: str, total_updates: int):
     return trainer, cfg
 
 
-def cpu_baseline(sample_envs=64, sample_steps=32):
-    """The oracle (CPU restatement of the reference path, pinned to the reference by tests/golden) timed on the host
-    cores on a bounded sample of the same workload: same obs size, same E=4 x M=4 update, fewer envs x steps."""
+# ---------------------------------------------------------------------------------------------------------------------------------
+# CPU leg + parity leg (rank 0, N = 1)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_and_parity(trainer, cfg, sample_envs=NUM_ENVS, sample_steps=NUM_STEPS, parity=True):
+    """(a) `cpu_baseline`: the oracle (oracle/functional.py: CPU restatement of the reference PPOTrainer path, pinned to the live
+    reference by tests/golden) runs ONE full update cycle of the workload -- rollout of 64 envs x 128 steps with policy.act per step,
+    GAE, PPO update E=4 x M=4 -- on the host cores and is timed.  (b) `parity`: the rollout the oracle produced (observations,
+    actions, old log-probs / values, rewards, masks, hidden states) is loaded into a device RolloutStorage and the HIP path does
+    the same update with the same minibatch permutations from the same parameters; the two sets of learner metrics, the GAE returns
+    and one minibatch's per-frame outputs are compared."""
     import types
     import numpy as np
+    import torch
     from oracle import functional as O
     from oracle import synth
-    from oracle.fixtures import baseline_param_shapes, det_params, synth_rollout_inputs
-    torch.set_num_threads(min(16, os.cpu_count() or 1))  # more threads than this slow the small-batch CPU convs down
+    from oracle.fixtures import synth_rollout_inputs
+    threads = min(16, os.cpu_count() or 1)  # more threads than this slow the small-batch CPU convolutions down
+    torch.set_num_threads(threads)
     N, T, hidden = sample_envs, sample_steps, 512
-    params = det_params(baseline_param_shapes(4, OBS, OBS, hidden), 1)
+    pol = trainer._agent.actor_critic
+    params = {k: v.detach().cpu().clone() for k, v in pol.state_dict().items()}  # the policy as the timed cycles left it
     spec = O.NetSpec(kind="baseline", hidden=hidden)
-    cfg = types.SimpleNamespace(clip_param=0.1, ppo_epoch=4, num_mini_batch=4, value_loss_coef=0.5, entropy_coef=0.01, lr=2.5e-4,
-                                eps=1e-5, max_grad_norm=0.5, use_normalized_advantage=True, use_clipped_value_loss=True,
-                                gamma=0.99, tau=0.95)
+    ppo = cfg.habitat_baselines.rl.ppo
+    ocfg = types.SimpleNamespace(clip_param=ppo.clip_param, ppo_epoch=ppo.ppo_epoch, num_mini_batch=ppo.num_mini_batch,
+                                 value_loss_coef=ppo.value_loss_coef, entropy_coef=ppo.entropy_coef, lr=ppo.lr, eps=ppo.eps,
+                                 max_grad_norm=ppo.max_grad_norm, use_normalized_advantage=ppo.use_normalized_advantage,
+                                 use_clipped_value_loss=ppo.use_clipped_value_loss, gamma=ppo.gamma, tau=ppo.tau)
     t0 = time.perf_counter()
-    envs = synth.SyntheticEnvs(N, OBS, OBS, seed=100)
+    envs = synth.SyntheticEnvs(N, OBS, OBS, seed=4242)
     obs, rew, done = synth_rollout_inputs(envs, T)
     t_env = time.perf_counter() - t0
+    torch.manual_seed(7)
+    noise = torch.stack([torch.empty(N, 4).exponential_(1) for _ in range(T)])
+    perms = [list(torch.randperm(N).chunk(ocfg.num_mini_batch)) for _ in range(ocfg.ppo_epoch)]
     t0 = time.perf_counter()
     buf = dict(observations={k: torch.from_numpy(np.stack([o[k] for o in obs])) for k in obs[0]})
+    del obs
     buf["recurrent_hidden_states"] = torch.zeros(T + 1, N, 1, hidden)
     buf["rewards"] = torch.zeros(T + 1, N, 1)
     buf["rewards"][:T] = torch.from_numpy(rew).unsqueeze(-1)
@@ -110,40 +146,173 @@ def cpu_baseline(sample_envs=64, sample_steps=32):
     with torch.no_grad():
         for t in range(T):
             r = O.act(params, spec, {k: v[t] for k, v in buf["observations"].items()}, buf["recurrent_hidden_states"][t],
-                      buf["prev_actions"][t], buf["masks"][t])
+                      buf["prev_actions"][t], buf["masks"][t], exp_noise=noise[t])
             buf["actions"][t], buf["action_log_probs"][t], buf["value_preds"][t] = r["actions"], r["action_log_probs"], r["values"]
             buf["recurrent_hidden_states"][t + 1], buf["prev_actions"][t + 1] = r["rnn_hidden_states"], r["actions"]
         feats, _ = O.net_forward(params, spec, {k: v[T] for k, v in buf["observations"].items()}, buf["recurrent_hidden_states"][T],
                                  buf["prev_actions"][T], buf["masks"][T])
         nv = O.heads(params, feats)[2]
-    buf["returns"], buf["value_preds"] = O.compute_returns(buf["rewards"], buf["value_preds"], buf["masks"], nv, T, True, 0.99, 0.95)
+    buf["returns"], buf["value_preds"] = O.compute_returns(buf["rewards"], buf["value_preds"], buf["masks"], nv, T, True, ocfg.gamma, ocfg.tau)
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     opt = dict(step=0, m={k: torch.zeros_like(v) for k, v in p.items()}, v={k: torch.zeros_like(v) for k, v in p.items()})
-    O.ppo_update(p, spec, buf, T, cfg, opt, list(p.keys()))
+    ref_metrics = O.ppo_update(p, spec, buf, T, ocfg, opt, list(p.keys()), perms=perms)
     dt = time.perf_counter() - t0
-    return {"value": round(N * T / dt, 2), "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{N} envs x {T} steps of the same workload (256x256 RGB-D, SimpleCNN+GRU, E=4 x M=4), oracle/functional.py on "
-                      f"torch-CPU fp32, {dt:.1f} s (synthetic obs generation {t_env:.1f} s excluded)"}
+    base = {"value": round(N * T / dt, 2), "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"one FULL update cycle of the workload ({N} envs x {T} steps, 256x256 RGB-D, SimpleCNN+GRU, E={ocfg.ppo_epoch} x "
+                      f"M={ocfg.num_mini_batch}): oracle/functional.py (CPU restatement of the reference path, pinned to the reference by "
+                      f"tests/golden; the reference itself is absent on the GPU box) on torch-CPU fp32 with {threads} threads of "
+                      f"{os.cpu_count()} host cores, {dt:.1f} s (synthetic obs generation {t_env:.1f} s excluded)"}
+    if not parity:
+        return base, None
+    # ---- the same rollout through the HIP path ----------------------------------------------------------------------------------
+    from habitat_amd.common.rollout_storage import MiniBatch, RolloutStorage
+    from habitat_amd.rl.ppo import PPO
+    from oracle import parity as PR
+    es = trainer._env_spec
+    trainer._agent._rollouts = None  # release the trainer's 3.8 GB arena before allocating this one
+    torch.cuda.empty_cache()
+    st = RolloutStorage(T, N, es.observation_space, es.action_space, pol, device=trainer.device, gae_variant="scan")
+    B = st.buffers
+    for k, v in buf["observations"].items():
+        B["observations"][k].copy_(v)
+    for k in ("actions", "prev_actions", "action_log_probs", "rewards", "masks", "recurrent_hidden_states"):
+        B[k].copy_(buf[k])
+    B["value_preds"].copy_(buf["value_preds"])
+    st.current_rollout_step_idxs = [T]
+    st.compute_returns(nv.to(trainer.device), True, ocfg.gamma, ocfg.tau)  # the GAE variant the timed cycles use, on the oracle's values
+    out = {"returns_max_rel": PR.rel(B["returns"].cpu().numpy()[:T], buf["returns"].numpy()[:T])}
+    pol.load_state_dict(params)
+    pol.train()
+    upd = PPO.from_config(pol, ocfg)
+    adv = upd.get_advantages(st)
+    batch = MiniBatch(st, perms[0][0], T, adv, torch.logical_not(B["masks"]).cpu().view(-1, N).numpy())  # first minibatch of epoch 0
+    mb = PR.minibatch_parity(pol, upd, st, batch, ocfg, env_chunk=8, with_grads=False)
+    out.update({"minibatch_frames": mb["frames"], "value_max_rel": mb["value_max_rel"], "log_prob_max_rel": mb["log_prob_max_rel"],
+                "minibatch_value_loss_rel": mb["value_loss_rel"], "minibatch_action_loss_rel": mb["action_loss_rel"]})
+    flat = [c for e in perms for c in e]
+    orig = torch.randperm
+    it = iter([torch.cat(e) for e in perms])
+    torch.randperm = lambda n, **kw: next(it)
+    try:
+        got = upd.update(st)
+    finally:
+        torch.randperm = orig
+    for k in ("value_loss", "action_loss", "dist_entropy", "grad_norm"):
+        out[k + "_rel"] = abs(got[k] - ref_metrics[k]) / max(1e-6, abs(ref_metrics[k]))
+    pd = max(float((v.detach().cpu() - p[k].detach()).abs().max()) for k, v in pol.state_dict().items())
+    out["post_update_param_max_abs_diff"] = pd
+    out["what"] = (f"HIP path vs the CPU oracle on the SAME {N} x {T} rollout (the one `cpu_baseline` timed), same parameters, same "
+                   f"minibatch permutations: losses averaged over the {len(flat)} minibatch steps of the update, GAE returns "
+                   f"(scan kernel), per-frame values / log-probs of one {mb['frames']}-frame minibatch")
+    out = {k: (float(f"{v:.3e}") if isinstance(v, float) else v) for k, v in out.items()}
+    return base, out
 
 
-# kernel(s) launched by a probed call site, for the HBM-traffic lookup (conv2 dgrad = one merged-stride-class launch)
-PROBE_KERNELS = {"conv2_dgrad": ("igemm_dma_kernel<ConvDgradMergedProb, 2, 2, 2, 2, false>", 1), "conv1_fwd": ("igemm_kernel<ObsConvFwdProb, 2, 1, 4, 1>", 1),
-                 "conv1_wgrad": ("igemm_kernel<ObsConvWgradProb, 2, 1, 4, 1>", 1)}
+def encoder_record(frames=4096, calls=2):
+    """ResNet18 encoder alone (ingest .. visual_fc) at 2 x 4096 = 8192 frames of 256x256 RGB-D: HIP events around the engine's encoder
+    call sites, algorithmic FLOPs of SURVEY.md 8(d) (forward 0.3376 GFLOP/frame; backward = dgrad + wgrad without the stem's dgrad)."""
+    import numpy as np
+    import torch
+    from habitat_amd.engine import DevicePackInfo, PolicyEngine
+    B, T = frames, 128
+    n = B // T
+    eng = PolicyEngine(arch="resnet", backbone=18, baseplanes=32, normalize_visual_inputs=True, rnn_type="LSTM", rnn_layers=2, hidden=512,
+                       H=256, W=256, max_frames=B, max_envs=64)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    eng.params_flat.copy_(torch.randn(eng.params_flat.shape, device="cuda", generator=g) * 0.05)
+    for nm, v in eng.views.items():
+        if v.dim() == 1 and (nm.endswith(".1.weight") or nm.endswith(".4.weight") or nm.endswith(".7.weight")):
+            v.fill_(1.0)
+    eng.repack()
+    rgb = torch.randint(0, 256, (B, 256, 256, 3), dtype=torch.uint8, device="cuda", generator=g)
+    depth = torch.rand(B, 256, 256, 1, device="cuda", generator=g)
+    goal = torch.rand(B, 2, device="cuda", generator=g)
+    masks = torch.ones(B, 1, dtype=torch.bool, device="cuda")
+    actions = torch.zeros(B, 1, dtype=torch.long, device="cuda")
+    h0 = torch.zeros(n, 4, 512, device="cuda")
+    pack = DevicePackInfo(np.zeros((T, n), np.uint8), "cuda")
+    dv = torch.randn(B, device="cuda", generator=g) * 1e-3
+
+    def cycle():
+        eng.evaluate(rgb, depth, goal, None, h0, masks, actions, pack, B, n, prev_actions=actions)
+        eng.backward(rgb, depth, goal, None, actions, pack, dv, dv, dv, prev_actions=actions)
+
+    cycle()
+    torch.cuda.synchronize()
+    eng.probe_enable_mask([11, 12])
+    for _ in range(calls):
+        cycle()
+    torch.cuda.synchronize()
+    fwd, bwd = (eng.probe_read_tag(t)[0] / calls for t in (11, 12))
+    eng.probe_enable(-1)
+    f_fwd, f_bwd = PROBES["enc_fwd"][1], PROBES["enc_bwd"][1]
+    tf = lambda fl, ms: B * fl / ms / 1e9
+    rec = {"frames": B * calls, "frames_per_call": B, "forward_ms": round(fwd, 2), "backward_ms": round(bwd, 2),
+           "forward_tflops": round(tf(f_fwd, fwd), 1), "backward_tflops": round(tf(f_bwd, bwd), 1),
+           "fwd_bwd_tflops": round(tf(f_fwd + f_bwd, fwd + bwd), 1), "peak_tflops": PEAK_FP32_MFMA_TFLOPS,
+           "forward_frac": round(tf(f_fwd, fwd) / PEAK_FP32_MFMA_TFLOPS, 4), "backward_frac": round(tf(f_bwd, bwd) / PEAK_FP32_MFMA_TFLOPS, 4),
+           "fwd_bwd_frac": round(tf(f_fwd + f_bwd, fwd + bwd) / PEAK_FP32_MFMA_TFLOPS, 4),
+           "what": "ResNet18 GroupNorm encoder (ingest, RunningMeanAndVar, 17 convs + GroupNorms, compression, visual_fc), fp32, 256x256 RGB-D; "
+                   "every non-contraction kernel (GroupNorm, pooling, ingest) is inside the times"}
+    del eng
+    torch.cuda.empty_cache()
+    return rec
+
+
+def run_cycles(workload, steps, warmup):
+    """A second workload inside the same run (sub-record): (env-steps/s, ms per cycle)."""
+    import torch
+    trainer, cfg = make_trainer(workload, warmup + steps + 1)
+    trainer._init_train()
+    for _ in range(warmup):
+        trainer.run_update_cycle()
+    torch.cuda.synchronize()
+    s0 = trainer.num_steps_done
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.run_update_cycle()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = trainer.num_steps_done - s0
+    trainer.envs.close()
+    rec = {"workload": WORKLOADS[workload]["name"], "value": round(n / dt, 1), "unit": "env-steps/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 2),
+           "frac_of_mfma_roofline": round(n / dt * 2.442e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if workload == "c3" else None}
+    del trainer
+    torch.cuda.empty_cache()
+    return rec
 
 
 def hbm_traffic(workload, probe):
-    """HBM bytes per probed call, from the committed rocprofv3 --pmc passes (profiles/r01_c2_hbm_traffic.json, produced by
+    """HBM bytes per probed call from the committed rocprofv3 --pmc passes (profiles/r0x_c2_hbm_traffic.json, produced by
     tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate runs of this script, FETCH_SIZE doubled per the gfx950
-    note of MI355X_MICROARCH.md).  Hardware counters cannot be read from inside the timed run, so the figure is the profiled one;
-    null when the probed call site has no entry."""
-    path = os.path.join(ROOT, "profiles", "r01_c2_hbm_traffic.json")
-    if workload != "c2" or probe not in PROBE_KERNELS or not os.path.exists(path):
-        return None
-    name, launches = PROBE_KERNELS[probe]
-    for k, r in json.load(open(path)).items():
-        if name in k:
-            return round(launches * (r["fetch_bytes_per_call"] + r["write_bytes_per_call"]))
-    return None
+    note of MI355X_MICROARCH.md).  Hardware counters cannot be read from inside the timed run, so this is the profiled figure of the
+    same command (the newest committed round); null when the probed call site has no entry."""
+    if workload != "c2" or probe not in PROBE_KERNELS:
+        return None, None
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_c2_hbm_traffic.json")
+        if not os.path.exists(path):
+            continue
+        best = None
+        for k, r in json.load(open(path)).items():
+            if PROBE_KERNELS[probe] in k:
+                tot = r["fetch_bytes_per_call"] + r["write_bytes_per_call"]
+                if best is None or r["calls"] * tot > best[0]:  # the update-sized launch when one kernel serves several sizes
+                    best = (r["calls"] * tot, tot)
+        if best:
+            return round(best[1]), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def relaunch_ranks(a):
+    """--gpus N > 1 without a torchrun environment: start the N ranks ourselves (same command line the driver uses)."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
@@ -153,22 +322,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--probe", default=None, choices=list(PROBES))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg, the parity leg and the sub-records (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the c3 / encoder sub-records only")
     a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_ranks(a)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop WORLD_SIZE and let bench.py start them)")
+    import torch
     if a.probe is None:
-        a.probe = "conv2_dgrad" if a.workload == "c2" else ("enc_fwd" if a.workload == "c3_frozen" else "enc_bwd")
+        a.probe = "conv1_fwd" if a.workload == "c2" else ("enc_fwd" if a.workload == "c3_frozen" else "enc_bwd")
     if a.workload == "c5" and a.probe.startswith("enc_"):
         # ResNet50 on 5 channels: 375.0 MMAC forward (a5); the stem's data gradient (7x7x8 pad -> 5 real ch) is not computed
         PROBES["enc_fwd"], PROBES["enc_bwd"] = (11, 2.0 * 375.0e6), (12, 2.0 * (2 * 375.0e6 - 32.1e6))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world != a.gpus:
-        if a.gpus > 1:
-            raise SystemExit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...` (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU execution path")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    trainer, cfg = make_trainer(a.workload, a.warmup + a.steps + 1)
+    trainer, cfg = make_trainer(a.workload, a.warmup + a.steps + 2)
     trainer._init_train()
     eng = trainer._agent.actor_critic.engine
     dist = torch.distributed.is_initialized()
@@ -207,19 +379,21 @@ def main():
     # DD-PPO's preemptive straggler rule cut a rollout short (ppo_trainer.py:641-653), in which case only the collected steps count
     steps_total = trainer.num_steps_done - steps_before
     assert 0 < steps_total <= world * n_envs * n_steps * a.steps
-    # frames seen by the probed call site during the timed region
     local_steps = trainer.local_steps_done - local_before
-    upd_frames = local_steps * ppo.ppo_epoch
-    roll_frames = local_steps + n_envs * a.steps
-    frames = upd_frames + (roll_frames if a.probe.endswith("_fwd") else 0)
+
+    def frames_seen(probe, local_steps, cycles):  # frames that passed a call site: E update passes (+ rollout + bootstrap for forward sites)
+        f = local_steps * ppo.ppo_epoch
+        return f + (local_steps + n_envs * cycles if probe.endswith("_fwd") and not probe.startswith("rnn") else 0)
+
+    frames = frames_seen(a.probe, local_steps, a.steps)
     if a.probe.startswith("enc_"):
         kname = f"resnet encoder {a.probe[4:]} (all kernels)"
-    elif a.workload == "c2" and a.probe in PROBE_KERNELS:
-        kname = f"{a.probe}: {PROBE_KERNELS[a.probe][0]}"
+    elif a.probe in PROBE_KERNELS:
+        kname = f"{a.probe}: {PROBE_KERNELS[a.probe]}...>"
     else:
-        kname = f"igemm contraction at call site {a.probe}"
+        kname = f"contraction at call site {a.probe}"
     ach = flops_per_frame * frames / (probe_ms * 1e-3) / 1e12 if probe_ms > 0 else None
-    traffic = hbm_traffic(a.workload, a.probe)
+    traffic, traffic_src = hbm_traffic(a.workload, a.probe)
     out = {
         "metric": "env-steps/sec (SPS) PointNav RGB-D 256x256, 64 envs x 128 rollout" if a.workload != "c5" else
                   "env-steps/sec (SPS) ObjectNav RGB-D+semantic 256x256, 32 envs x 64 rollout",
@@ -230,10 +404,43 @@ def main():
                    "ppo_epoch": ppo.ppo_epoch, "num_mini_batch": ppo.num_mini_batch, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2) if ach else None,
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4) if ach else None,
-                     "traffic": traffic, "launches": probe_cnt, "avg_launch_ms": round(probe_ms / max(probe_cnt, 1), 4)},
+                     "traffic": traffic, "traffic_source": traffic_src, "launches": probe_cnt,
+                     "avg_launch_ms": round(probe_ms / max(probe_cnt, 1), 4), "share_of_step": round(probe_ms / (dt * 1e3), 4)},
     }
+    if a.workload in ("c2", "c3"):
+        f_step = 2.365e9 if a.workload == "c2" else 2.442e9  # algorithmic FLOPs per env-step
+        out["roofline"]["whole_cycle_frac"] = round(steps_total / world / dt * f_step / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)
+    if a.workload == "c2":
+        # per-call-site table from ONE extra cycle with every probe on (outside the timed region: ~1400 event records per cycle)
+        tags = {k: PROBES[k] for k in C2_TABLE}
+        eng.probe_enable_mask([t for t, _ in tags.values()])
+        l0 = trainer.local_steps_done
+        c0 = time.perf_counter()
+        trainer.run_update_cycle()
+        torch.cuda.synchronize()
+        cyc_ms = (time.perf_counter() - c0) * 1e3
+        ls = trainer.local_steps_done - l0
+        table = []
+        for k, (t_, fl) in tags.items():
+            ms, cnt = eng.probe_read_tag(t_)
+            if cnt:
+                tfl = fl * frames_seen(k, ls, 1) / (ms * 1e-3) / 1e12
+                table.append({"site": k, "ms": round(ms, 2), "calls": cnt, "share": round(ms / cyc_ms, 4), "tflops": round(tfl, 1),
+                              "frac": round(tfl / PEAK_FP32_MFMA_TFLOPS, 4)})
+        eng.probe_read()
+        eng.probe_enable(-1)
+        out["roofline"]["kernels"] = sorted(table, key=lambda r: -r["ms"])
     if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
-        out["cpu_baseline"] = cpu_baseline()
+        base, par = cpu_baseline_and_parity(trainer, cfg)
+        out["cpu_baseline"] = base
+        if par:
+            out["parity"] = par
+        trainer.envs.close()
+        del trainer, eng
+        torch.cuda.empty_cache()
+        if not a.no_extras:
+            out["c3"] = run_cycles("c3", 3, 1)
+            out["encoder_r18_b8192"] = encoder_record()
     print(json.dumps(out), flush=True)
     if dist:
         torch.distributed.destroy_process_group()

@@ -61,8 +61,9 @@ struct hab_policy {
     hab_grad_ready_fn grad_ready_cb = nullptr;          // optional: tail of the gradient arena is final (early DD-PPO all-reduce)
     void* grad_ready_ctx = nullptr;
     // probe
-    int probe_tag = -1;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> probe_events;
+    uint64_t probe_mask = 0;  // bit t set: call site HAB_PROBE_<t> is bracketed by HIP events on the launch stream
+    struct ProbeEv { int tag; hipEvent_t first, second; };
+    std::vector<ProbeEv> probe_events;
     size_t probe_used = 0;
 
     float* p(int i) const { return P + params[i].offset; }
@@ -96,13 +97,14 @@ int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats);
 
 struct Probe {
     hab_policy* e; hipStream_t s; bool on;
-    Probe(hab_policy* e_, int tag, hipStream_t s_) : e(e_), s(s_), on(e_->probe_tag == tag) {
+    Probe(hab_policy* e_, int tag, hipStream_t s_) : e(e_), s(s_), on((e_->probe_mask >> tag) & 1) {
         if (!on) return;
         if (e->probe_used == e->probe_events.size()) {
             hipEvent_t a, b;
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-            e->probe_events.push_back({a, b});
+            e->probe_events.push_back({tag, a, b});
         }
+        e->probe_events[e->probe_used].tag = tag;
         (void)hipEventRecord(e->probe_events[e->probe_used].first, s);
     }
     ~Probe() {

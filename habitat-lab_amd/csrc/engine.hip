@@ -183,26 +183,43 @@ extern "C" int hab_policy_repack(hab_policy* e, hipStream_t stream) {
 
 // ---- probes: HIP-event timing of one tagged kernel call site (bench.py's roofline leg) ----
 extern "C" int hab_policy_probe_enable(hab_policy* e, int tag) {
-    if (!e) return HAB_ERR_ARG;
-    e->probe_tag = tag;
+    if (!e || tag >= 64) return HAB_ERR_ARG;
+    e->probe_mask = tag < 0 ? 0 : (uint64_t)1 << tag;
     e->probe_used = 0;
     return HAB_OK;
 }
-extern "C" int hab_policy_probe_read(hab_policy* e, double* total_ms, int* count) {
-    if (!e || !total_ms || !count) return HAB_ERR_ARG;
+extern "C" int hab_policy_probe_enable_mask(hab_policy* e, uint64_t mask) {
+    if (!e) return HAB_ERR_ARG;
+    e->probe_mask = mask;
+    e->probe_used = 0;
+    return HAB_OK;
+}
+static int probe_sum(hab_policy* e, int tag, double* total_ms, int* count) {
     double t = 0;
+    int n = 0;
     for (size_t i = 0; i < e->probe_used; ++i) {
+        if (tag >= 0 && e->probe_events[i].tag != tag) continue;
         hipError_t err = hipEventSynchronize(e->probe_events[i].second);
         if (err != hipSuccess) return (int)err;
         float ms = 0;
         err = hipEventElapsedTime(&ms, e->probe_events[i].first, e->probe_events[i].second);
         if (err != hipSuccess) return (int)err;
         t += ms;
+        ++n;
     }
     *total_ms = t;
-    *count = (int)e->probe_used;
+    *count = n;
+    return HAB_OK;
+}
+extern "C" int hab_policy_probe_read(hab_policy* e, double* total_ms, int* count) {
+    if (!e || !total_ms || !count) return HAB_ERR_ARG;
+    HAB_TRY(probe_sum(e, -1, total_ms, count));
     e->probe_used = 0;
     return HAB_OK;
+}
+extern "C" int hab_policy_probe_read_tag(hab_policy* e, int tag, double* total_ms, int* count) {
+    if (!e || !total_ms || !count || tag < 0 || tag >= 64) return HAB_ERR_ARG;
+    return probe_sum(e, tag, total_ms, count);
 }
 
 
@@ -341,6 +358,7 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
                                   pk.frag_start, pk.F, H, cinit, stream));
         RnnLayerParams lp = layer_params(e, l);
         RnnWork wk = layer_work(e, l);
+        Probe pr(e, HAB_PROBE_RNN_FWD, stream);
         HAB_TRY(rnn_seq_layer_forward(e->d.rnn_type, H, lp, wk, x, ldx, hinit, cinit, pk, W + e->w_ws, e->ws_floats, stream));
         x = wk.out;
         ldx = H;
@@ -408,6 +426,7 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
         float* dx = l == 0 ? W + e->w_drnnin : W + e->w_dlayer[l];
         const int lddx = l == 0 ? e->rnn_ld : H;
         // layer 0: the first H columns of rnn_in are ReLU(fc) -> mask them here (fused ReLU backward)
+        Probe pr(e, HAB_PROBE_RNN_BWD, stream);
         HAB_TRY(rnn_seq_layer_backward(e->d.rnn_type, H, lp, wk, x, ldx, dout, dx, lddx, l == 0 ? x : nullptr, ldx, H, pk,
                                        W + e->w_scratch, ws, e->ws_floats, stream));
         dout = dx;

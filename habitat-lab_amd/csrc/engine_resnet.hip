@@ -58,7 +58,7 @@ struct ResNetPlan {
     std::vector<int64_t> w_gbuf;
     int64_t gbuf_floats = 0;  // per frame
     int64_t w_chansums = -1;  // [B][2][Cmax]
-    int64_t w_stats = -1;     // RunningMeanAndVar batch moments: mean[8], var[8] (+ padding)
+    int64_t w_stats = -1;     // RunningMeanAndVar batch moments: mean[8], count, var[8] at +16 (+ padding)
     int64_t w_dscratch = -1;  // doubles for chan_moment partials
     int64_t w_embsave = -1;   // [B][4] goal features + previous-action token of the last forward
     int cmax = 0;
@@ -399,17 +399,19 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
                         x0, B, d.H, d.W, r->cpad, r->c_rgb, r->c_depth, r->c_sem, s));
     const long long npix = (long long)B * r->H2 * r->W2;
     if (d.normalize_visual_inputs) {
-        float* st = W + r->w_stats;  // [0..7] batch mean, [8..15] batch var
+        float* st = W + r->w_stats;  // [0..7] batch mean, [8] batch count (frames), [16..23] batch var
         if (e->training) {
             double* ds = reinterpret_cast<double*>(W + r->w_dscratch);
-            HAB_TRY(chan_moment(x0, npix, r->cpad, 0, nullptr, st, ds, 1024 * 8, s));
-            if (e->allreduce_cb && e->world_size > 1) {  // running_mean_and_var.py:38-41
-                e->allreduce_cb(st, 8, 1.0f / e->world_size, e->allreduce_ctx);
-            }
-            HAB_TRY(chan_moment(x0, npix, r->cpad, 1, st, st + 8, ds, 1024 * 8, s));
-            if (e->allreduce_cb && e->world_size > 1) e->allreduce_cb(st + 8, 8, 1.0f / e->world_size, e->allreduce_ctx);
-            HAB_TRY(rmv_update(e->p(r->i_mean), e->p(r->i_var), e->p(r->i_count), st, st + 8, (float)B * (float)e->world_size,
-                               r->creal, s));
+            // running_mean_and_var.py:38-49: all_reduce(new_mean), all_reduce(new_count), new_mean /= world; all_reduce(new_var),
+            // new_var /= world.  The callback only SUMS (scale 1); the divisions happen where the sums are consumed, and the count is
+            // the real all-reduced number of frames (ranks hold different numbers of frames after a preempted rollout).
+            const bool dist = e->allreduce_cb && e->world_size > 1;
+            const float div = dist ? (float)e->world_size : 1.f;
+            HAB_TRY(chan_moment(x0, npix, r->cpad, 0, nullptr, st, ds, 1024 * 8, s, 1.f, st + 8, (float)B));
+            if (dist) e->allreduce_cb(st, 9, 1.0f, e->allreduce_ctx);
+            HAB_TRY(chan_moment(x0, npix, r->cpad, 1, st, st + 16, ds, 1024 * 8, s, div));
+            if (dist) e->allreduce_cb(st + 16, 8, 1.0f, e->allreduce_ctx);
+            HAB_TRY(rmv_update(e->p(r->i_mean), e->p(r->i_var), e->p(r->i_count), st, st + 16, (float)B, r->creal, s, st + 8, div));
         }
         HAB_TRY(rmv_normalize(x0, npix, r->cpad, r->creal, e->p(r->i_mean), e->p(r->i_var), s));
     }
@@ -576,6 +578,12 @@ int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats) {
         case HAB_TAP_POOL: *ptr = W + r->w_pool; *floats = B * r->poolH * r->poolW * r->stem.cd.Cout; return HAB_OK;
         case HAB_TAP_COMPRESSION: *ptr = W + r->comp.w_out; *floats = B * r->comp.out_floats(); return HAB_OK;
         default: break;
+    }
+    if (which >= HAB_TAP_CONV_OUT && which < HAB_TAP_CONV_OUT + (int)r->convs.size()) {
+        const RnConv& c = r->convs[which - HAB_TAP_CONV_OUT];
+        *ptr = W + c.w_out;
+        *floats = B * c.out_floats();
+        return HAB_OK;
     }
     if (which >= HAB_TAP_LAYER1 && which < HAB_TAP_LAYER1 + 4) {
         // last block of stage (which - HAB_TAP_LAYER1)

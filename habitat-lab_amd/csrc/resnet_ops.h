@@ -58,8 +58,9 @@ struct EmbedBwdArgs {
 int ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic, const int* rows, float* y, int B, int H, int W, int cpad,
                 int c_rgb, int c_depth, int c_sem, hipStream_t s);
 int chan_moment(const float* x, long long npix, int cpad, int mode, const float* mean, float* out, double* scratch, int scratch_len,
-                hipStream_t s);
-int rmv_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C, hipStream_t s);
+                hipStream_t s, float mean_div = 1.f, float* count_out = nullptr, float count_val = 0.f);
+int rmv_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C, hipStream_t s,
+               const float* n_dev = nullptr, float div = 1.f);
 int rmv_normalize(float* x, long long npix, int cpad, int C, const float* mean, const float* var, hipStream_t s);
 int groupnorm_forward(const GnArgs& a, hipStream_t s);
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s);

@@ -84,10 +84,10 @@ int ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic,
 // mode 1: sum_c (x - m_c)^2  -> out[c] = biased variance about the supplied mean (m = stats_in[c])
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) chan_moment_stage1(const float* __restrict__ x, long long npix, int cpad, int mode,
-                                                          const float* __restrict__ mean, double* __restrict__ partial) {
+                                                          const float* __restrict__ mean, float mean_div, double* __restrict__ partial) {
     __shared__ double sm[256];
     const int c = threadIdx.x % cpad, lane = threadIdx.x / cpad, nl = 256 / cpad;
-    const float m = (mode == 1) ? mean[c] : 0.f;
+    const float m = (mode == 1) ? mean[c] / mean_div : 0.f;  // `new_mean /= world_size` of the summed means (exact IEEE division)
     double s = 0.0;
     for (long long p = (long long)blockIdx.x * nl + lane; p < npix; p += (long long)gridDim.x * nl) {
         const float v = x[p * cpad + c];
@@ -102,34 +102,40 @@ __global__ void __launch_bounds__(256) chan_moment_stage1(const float* __restric
         partial[(size_t)blockIdx.x * cpad + c] = t;
     }
 }
-__global__ void chan_moment_stage2(const double* __restrict__ partial, int nblocks, int cpad, double inv_n, float* __restrict__ out) {
+__global__ void chan_moment_stage2(const double* __restrict__ partial, int nblocks, int cpad, double inv_n, float* __restrict__ out,
+                                   float* __restrict__ count_out, float count_val) {
     const int c = threadIdx.x;
+    if (c == 0 && count_out) *count_out = count_val;  // new_count = n frames of THIS rank; summed over ranks with the means
     if (c >= cpad) return;
     double t = 0.0;
     for (int b = 0; b < nblocks; ++b) t += partial[(size_t)b * cpad + c];
     out[c] = (float)(t * inv_n);
 }
 int chan_moment(const float* x, long long npix, int cpad, int mode, const float* mean, float* out, double* scratch, int scratch_len,
-                hipStream_t s) {
-    if (!x || !out || !scratch || npix <= 0 || (256 % cpad) || (mode == 1 && !mean)) return HAB_ERR_ARG;
+                hipStream_t s, float mean_div, float* count_out, float count_val) {
+    if (!x || !out || !scratch || npix <= 0 || (256 % cpad) || (mode == 1 && !mean) || !(mean_div >= 1.f)) return HAB_ERR_ARG;
     int blocks = (int)fmin(1024.0, (double)cdivl(npix, 256 / cpad * 8));
     if (blocks * cpad > scratch_len) blocks = scratch_len / cpad;
     if (blocks < 1) return HAB_ERR_ARG;
-    chan_moment_stage1<<<blocks, 256, 0, s>>>(x, npix, cpad, mode, mean, scratch);
+    chan_moment_stage1<<<blocks, 256, 0, s>>>(x, npix, cpad, mode, mean, mean_div, scratch);
     HAB_LAUNCH_CHECK();
-    chan_moment_stage2<<<1, 64, 0, s>>>(scratch, blocks, cpad, 1.0 / (double)npix, out);
+    chan_moment_stage2<<<1, 64, 0, s>>>(scratch, blocks, cpad, 1.0 / (double)npix, out, count_out, count_val);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
 
 // Chan merge of (running mean, var, count) with the batch moments, all on device (one thread per channel).
 // new_count = batch size n (number of frames, as in the reference -- not the number of pixels).
+// DD-PPO (running_mean_and_var.py:38-49): b_mean / b_var hold the SUMS over ranks (divided here by `div` = world size) and the
+// batch count is the all-reduced number of frames *n_dev -- ranks may hold different numbers of frames (preempted rollouts).
 __global__ void rmv_update_kernel(float* __restrict__ r_mean, float* __restrict__ r_var, float* __restrict__ r_count,
-                                  const float* __restrict__ b_mean, const float* __restrict__ b_var, float n, int C) {
+                                  const float* __restrict__ b_mean, const float* __restrict__ b_var, float n_host,
+                                  const float* __restrict__ n_dev, float div, int C) {
     const int c = threadIdx.x;
     const float count = r_count[0];
+    const float n = n_dev ? n_dev[0] : n_host;
     if (c < C) {
-        const float mean = r_mean[c], var = r_var[c], nm = b_mean[c], nv = b_var[c];
+        const float mean = r_mean[c], var = r_var[c], nm = b_mean[c] / div, nv = b_var[c] / div;
         const float m_a = var * count, m_b = nv * n;
         const float d = nm - mean;
         const float M2 = m_a + m_b + d * d * count * n / (count + n);
@@ -139,9 +145,10 @@ __global__ void rmv_update_kernel(float* __restrict__ r_mean, float* __restrict_
     __syncthreads();
     if (c == 0) r_count[0] = count + n;
 }
-int rmv_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C, hipStream_t s) {
-    if (!r_mean || !r_var || !r_count || !b_mean || !b_var || C <= 0 || C > 64) return HAB_ERR_ARG;
-    rmv_update_kernel<<<1, 64, 0, s>>>(r_mean, r_var, r_count, b_mean, b_var, n, C);
+int rmv_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C, hipStream_t s,
+               const float* n_dev, float div) {
+    if (!r_mean || !r_var || !r_count || !b_mean || !b_var || C <= 0 || C > 64 || !(div >= 1.f)) return HAB_ERR_ARG;
+    rmv_update_kernel<<<1, 64, 0, s>>>(r_mean, r_var, r_count, b_mean, b_var, n, n_dev, div, C);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }

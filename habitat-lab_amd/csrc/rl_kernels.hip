@@ -276,7 +276,7 @@ extern "C" int hab_compute_returns(const float* rewards, float* value_preds, con
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) advantages_kernel(const float* __restrict__ returns, const float* __restrict__ value_preds,
                                                           float* __restrict__ adv, int count, int mode,
-                                                          const float* __restrict__ ext_stats, float* __restrict__ stats_out) {
+                                                          const float* ext_stats, float* stats_out) {  // may alias (one stats buffer)
     __shared__ double red[16];
     const int tid = threadIdx.x;
     double s = 0.0, c = 0.0;

@@ -82,7 +82,9 @@ class SyntheticVectorEnv:
                              compass=torch.zeros(num_envs, 1, device=dev), gps=torch.zeros(num_envs, 2, device=dev))
         self._rew = torch.zeros(num_envs, device=dev)
         self._nd = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
-        self._pending = False
+        self._pending: set = set()      # envs with an outstanding async_step_at (host path)
+        self._host_cache = None
+        self._tmp = None
 
     # ---- device fast path ---------------------------------------------------------------------
     def _emit(self, rgb, depth, goal, reward, not_done, advance: int):
@@ -152,13 +154,43 @@ class SyntheticVectorEnv:
         return self._host_obs()
 
     def async_step_at(self, index_env: int, action) -> None:
-        self._pending = True
+        if index_env in self._pending:
+            raise _lib.HabError(f"env {index_env}: async_step_at called twice without wait_step_at")
+        self._pending.add(int(index_env))
+
+    def _advance_pending(self):
+        """Advances exactly the envs whose step was requested.  All envs (the usual case): one generator launch into the env's
+        own tensors.  A subset (the double-buffered sampler steps the two halves out of phase, ppo_trainer.py:743-768): the
+        generator runs on scratch copies of the per-env clocks / tensors and only the requested rows are taken over."""
+        ids = sorted(self._pending)
+        self._pending.clear()
+        if len(ids) == self.num_envs:
+            self.step_into_obs(self._own_obs(), self._rew, self._nd)
+        else:
+            own = self._own_obs()
+            if self._tmp is None:
+                self._tmp = ({k: torch.empty_like(v) for k, v in own.items()}, torch.empty_like(self._rew), torch.empty_like(self._nd))
+            tobs, trew, tnd = self._tmp
+            t0, s0 = self._t.clone(), self._since.clone()
+            self.step_into_obs(tobs, trew, tnd)
+            sel = torch.tensor(ids, device=self.device)
+            keep = torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
+            keep[sel] = False
+            self._t[keep], self._since[keep] = t0[keep], s0[keep]
+            for k, v in own.items():
+                v[sel] = tobs[k][sel]
+            self._rew[sel], self._nd[sel] = trew[sel], tnd[sel]
+        obs, rew, nd = self._host_obs(), self._rew.cpu().numpy(), self._nd.cpu().numpy()
+        if self._host_cache is None or len(ids) == self.num_envs:
+            self._host_cache = (obs, rew.copy(), nd.copy())
+        else:
+            c_obs, c_rew, c_nd = self._host_cache
+            for i in ids:
+                c_obs[i], c_rew[i], c_nd[i] = obs[i], rew[i], nd[i]
 
     def wait_step_at(self, index_env: int):
-        if self._pending:  # all envs advance together on the first wait of a step
-            self.step_into_obs(self._own_obs(), self._rew, self._nd)
-            self._host_cache = (self._host_obs(), self._rew.cpu().numpy(), self._nd.cpu().numpy())
-            self._pending = False
+        if index_env in self._pending:  # every env requested so far advances on the first wait
+            self._advance_pending()
         obs, rew, nd = self._host_cache
         return obs[index_env], float(rew[index_env]), not bool(nd[index_env]), {}
 

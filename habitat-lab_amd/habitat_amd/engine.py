@@ -174,6 +174,16 @@ class PolicyEngine:
             exc, self._cb_error = self._cb_error, None
             raise _lib.HabError("a collective callback failed inside the engine call") from exc
 
+    def _call(self, code_fn, what: str):
+        """Runs one engine entry point that may invoke the collective callbacks.  A callback exception is attributed to THIS call
+        (it takes precedence over the status code the interrupted call returns) and never survives into a later one."""
+        self._cb_error = None
+        try:
+            code = code_fn()
+        finally:
+            self._raise_cb_error()
+        check(code, what)
+
     def repack(self):
         check(self.L.hab_policy_repack(self.h, stream_ptr()), "hab_policy_repack")
         self._packed_version = self.params_flat._version
@@ -201,25 +211,23 @@ class PolicyEngine:
         """The visual encoder alone on n frames -> out (n, C, Hf, Wf)."""
         self._fresh()
         o = self._obs(rgb, depth, None, None, extra)
-        check(self.L.hab_policy_encode(self.h, C.byref(o), n, ptr(out), stream_ptr()), "hab_policy_encode")
-        self._raise_cb_error()
+        self._call(lambda: self.L.hab_policy_encode(self.h, C.byref(o), n, ptr(out), stream_ptr()), "hab_policy_encode")
 
     def act(self, rgb, depth, goal, hidden_in, masks, n, *, exp_noise=None, deterministic=False, values, actions=None,
             action_log_probs=None, hidden_out=None, probs_out=None, prev_actions=None, extra=None):
         self._fresh()
         o = self._obs(rgb, depth, goal, prev_actions, extra)
-        check(self.L.hab_policy_act(self.h, C.byref(o), ptr(hidden_in), ptr(masks), ptr(exp_noise), int(deterministic), n,
-                                    ptr(values), ptr(actions), ptr(action_log_probs), ptr(hidden_out), ptr(probs_out),
-                                    stream_ptr()), "hab_policy_act")
+        self._call(lambda: self.L.hab_policy_act(self.h, C.byref(o), ptr(hidden_in), ptr(masks), ptr(exp_noise), int(deterministic), n,
+                                                 ptr(values), ptr(actions), ptr(action_log_probs), ptr(hidden_out), ptr(probs_out),
+                                                 stream_ptr()), "hab_policy_act")
 
     def evaluate(self, rgb, depth, goal, rows, hidden0, masks, actions, pack: DevicePackInfo, B, n, *, value=None,
                  log_prob=None, entropy=None, prev_actions=None, extra=None):
         self._fresh()
         o = self._obs(rgb, depth, goal, prev_actions, extra)
-        check(self.L.hab_policy_evaluate(self.h, C.byref(o), ptr(rows), ptr(hidden0), self.Lh * self.hidden, ptr(masks),
-                                         ptr(actions), C.byref(pack.struct), B, n, ptr(value), ptr(log_prob), ptr(entropy),
-                                         stream_ptr()), "hab_policy_evaluate")
-        self._raise_cb_error()
+        self._call(lambda: self.L.hab_policy_evaluate(self.h, C.byref(o), ptr(rows), ptr(hidden0), self.Lh * self.hidden, ptr(masks),
+                                                      ptr(actions), C.byref(pack.struct), B, n, ptr(value), ptr(log_prob), ptr(entropy),
+                                                      stream_ptr()), "hab_policy_evaluate")
 
     def final_hidden(self, out):
         check(self.L.hab_policy_final_hidden(self.h, ptr(out), stream_ptr()), "hab_policy_final_hidden")
@@ -227,9 +235,8 @@ class PolicyEngine:
     def backward(self, rgb, depth, goal, rows, actions, pack: DevicePackInfo, d_value, d_log_prob, d_entropy, prev_actions=None,
                  extra=None):
         o = self._obs(rgb, depth, goal, prev_actions, extra)
-        check(self.L.hab_policy_backward(self.h, C.byref(o), ptr(rows), ptr(actions), C.byref(pack.struct), ptr(d_value),
-                                         ptr(d_log_prob), ptr(d_entropy), stream_ptr()), "hab_policy_backward")
-        self._raise_cb_error()
+        self._call(lambda: self.L.hab_policy_backward(self.h, C.byref(o), ptr(rows), ptr(actions), C.byref(pack.struct), ptr(d_value),
+                                                      ptr(d_log_prob), ptr(d_entropy), stream_ptr()), "hab_policy_backward")
 
     def tap(self, which: int) -> torch.Tensor:
         p, n = C.c_void_p(), C.c_int64(0)
@@ -239,6 +246,17 @@ class PolicyEngine:
 
     def probe_enable(self, tag: int):
         check(self.L.hab_policy_probe_enable(self.h, tag))
+
+    def probe_enable_mask(self, tags):
+        mask = 0
+        for t in tags:
+            mask |= 1 << int(t)
+        check(self.L.hab_policy_probe_enable_mask(self.h, mask))
+
+    def probe_read_tag(self, tag: int):
+        ms, cnt = C.c_double(0), C.c_int(0)
+        check(self.L.hab_policy_probe_read_tag(self.h, int(tag), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
 
     def probe_read(self):
         ms, cnt = C.c_double(0), C.c_int(0)

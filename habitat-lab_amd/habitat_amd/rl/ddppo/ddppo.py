@@ -31,11 +31,13 @@ class DecentralizedDistributedMixin:
         eng.repack()
         world = distrib.get_world_size()
         if world > 1:
-            # RunningMeanAndVar batch moments are averaged over ranks inside the engine's forward
-            # (rl/ddppo/policy/running_mean_and_var.py:38-41,47-49): all_reduce(sum) then / world_size
+            # RunningMeanAndVar batch moments + frame count are summed over ranks inside the engine's forward
+            # (rl/ddppo/policy/running_mean_and_var.py:38-41,47-49); the engine divides the means / variances by world_size
+            # where it consumes them and merges with the summed count
             def _avg(view: torch.Tensor, scale: float) -> None:
                 distrib.all_reduce(view)
-                view.mul_(scale)
+                if scale != 1.0:
+                    view.mul_(scale)
 
             eng.set_allreduce(_avg, world)
         self._grad_work = None  # (work handle, first) of the early all-reduce of grads_flat[first:]

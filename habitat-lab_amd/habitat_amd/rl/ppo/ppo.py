@@ -67,16 +67,84 @@ class FlatAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         self.policy.engine.grads_flat.zero_()
 
+    # ---- resume-state wire format = torch.optim.Adam.state_dict() (rl/ppo/ppo.py:377-384) ---------------------------------
+    def _slots(self):
+        """(index, name, offset, numel, shape) of every optimised parameter in `self.param_groups[0]["params"]` order, which is
+        the reference's `filter(requires_grad, self.parameters())` order (ppo.py:113)."""
+        eng = self.policy.engine
+        spec = {nm: (off, shp) for nm, shp, off in eng.specs}
+        out = []
+        for nm, par in self.policy.named_parameters():
+            if not par.requires_grad:
+                continue
+            off, shp = spec[nm]
+            n = 1
+            for d in shp:
+                n *= int(d)
+            out.append((len(out), nm, off, n, tuple(shp)))
+        return out
+
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg.cpu(), exp_avg_sq=self.exp_avg_sq.cpu(),
-                    param_groups=[{k: v for k, v in g.items() if k != "params"} for g in self.param_groups])
+        return flat_to_adam_state_dict(self._slots(), self.step_count, self.exp_avg, self.exp_avg_sq, self.param_groups[0])
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
+        if "state" not in sd:  # round-1 files of this package: {step, exp_avg, exp_avg_sq} flat arenas
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            groups = sd.get("param_groups", [])
+        else:
+            self.step_count = adam_state_dict_to_flat(self._slots(), sd, self.exp_avg, self.exp_avg_sq)
+            groups = sd["param_groups"]
+        for g, s in zip(self.param_groups, groups):
             g.update({k: v for k, v in s.items() if k != "params"})
+
+
+_ADAM_GROUP_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=True, capturable=False, differentiable=False,
+                            fused=None, decoupled_weight_decay=False)
+
+
+def flat_to_adam_state_dict(slots, step: int, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, group: Dict[str, Any]) -> Dict[str, Any]:
+    """The flat Adam arenas as `torch.optim.Adam(...).state_dict()`: per-parameter `step` (float scalar tensor, as Adam keeps
+    it), `exp_avg`, `exp_avg_sq` in parameter shape, one param group listing indices 0..P-1.  A reference `PPO.load_state_dict`
+    (ppo.py:382-384) accepts it unchanged."""
+    state = {}
+    if step > 0:  # Adam creates a parameter's state on its first step
+        m, v = exp_avg.detach().cpu(), exp_avg_sq.detach().cpu()
+        for i, _nm, off, n, shp in slots:
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": m[off:off + n].view(shp).clone(),
+                        "exp_avg_sq": v[off:off + n].view(shp).clone()}
+    g = {k: v for k, v in group.items() if k != "params"}
+    for k, v in _ADAM_GROUP_DEFAULTS.items():
+        g.setdefault(k, v)
+    g["betas"] = tuple(g["betas"])
+    g["params"] = [i for i, *_ in slots]
+    return {"state": state, "param_groups": [g]}
+
+
+def adam_state_dict_to_flat(slots, sd: Dict[str, Any], exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor) -> int:
+    """Inverse of flat_to_adam_state_dict: scatters a torch.optim.Adam state_dict (ours or the reference's) into the flat
+    arenas and returns the common step count.  Every parameter must have made the same number of steps (true for PPO: all
+    parameters receive a gradient in every minibatch)."""
+    st = sd["state"]
+    ids = sd["param_groups"][0]["params"]
+    if len(ids) != len(slots):
+        raise _lib.HabError(f"optimizer state lists {len(ids)} parameters, the policy has {len(slots)}")
+    exp_avg.zero_()
+    exp_avg_sq.zero_()
+    steps = set()
+    for (i, nm, off, n, shp), pid in zip(slots, ids):
+        e = st.get(pid, st.get(str(pid)))
+        if e is None:
+            continue
+        if tuple(e["exp_avg"].shape) != shp:
+            raise _lib.HabError(f"optimizer state of {nm}: shape {tuple(e['exp_avg'].shape)} != {shp}")
+        exp_avg[off:off + n].copy_(e["exp_avg"].reshape(-1))
+        exp_avg_sq[off:off + n].copy_(e["exp_avg_sq"].reshape(-1))
+        steps.add(int(float(e["step"])))
+    if len(steps) > 1:
+        raise _lib.HabError(f"optimizer state with per-parameter step counts {sorted(steps)} cannot be mapped to the fused Adam step")
+    return steps.pop() if steps else 0
 
 
 @baseline_registry.register_updater

@@ -134,8 +134,8 @@ class SingleAgentAccessMgr:
 
     # ---- state ----------------------------------------------------------------------------------------------
     def get_resume_state(self) -> Dict[str, Any]:
-        ret = {"state_dict": {"actor_critic." + k: v for k, v in self._actor_critic.state_dict().items()},
-               **self._updater.get_resume_state()}
+        # single_agent_access_mgr.py:253-263: the bare actor_critic.state_dict() (no prefix) + {"optim_state": Adam.state_dict()}
+        ret = {"state_dict": {k: v.cpu() for k, v in self._actor_critic.state_dict().items()}, **self._updater.get_resume_state()}
         if self._lr_scheduler is not None:
             ret["lr_sched_state"] = self._lr_scheduler.state_dict()
         return ret

@@ -344,8 +344,14 @@ int hab_policy_backward(hab_policy* p, const hab_obs* obs, const int* rows, cons
 #define HAB_PROBE_FC_DGRAD 10
 #define HAB_PROBE_ENC_FWD 11  /* arch 1: whole visual encoder forward (ingest .. visual_fc) */
 #define HAB_PROBE_ENC_BWD 12  /* arch 1: whole visual encoder backward */
+#define HAB_PROBE_RNN_FWD 13  /* packed-sequence recurrent layer forward of evaluate (one event pair per layer) */
+#define HAB_PROBE_RNN_BWD 14  /* its BPTT */
 int hab_policy_probe_enable(hab_policy* p, int tag /* -1 = off */);
+/* several call sites at once: bit t of mask = HAB_PROBE_<t> (per-kernel table of bench.py, measured outside its timed region) */
+int hab_policy_probe_enable_mask(hab_policy* p, uint64_t mask);
+/* summed duration / number of bracketed calls: of ALL enabled sites (and forgets them), or of one tag (keeps them) */
 int hab_policy_probe_read(hab_policy* p, double* total_ms, int* count);
+int hab_policy_probe_read_tag(hab_policy* p, int tag, double* total_ms, int* count);
 
 /* Test taps into the activation workspace of the last evaluate (NHWC). */
 #define HAB_TAP_CONV1 0
@@ -358,6 +364,8 @@ int hab_policy_probe_read(hab_policy* p, double* total_ms, int* count);
 #define HAB_TAP_POOL 7
 #define HAB_TAP_COMPRESSION 8
 #define HAB_TAP_LAYER1 9       /* 9..12: output of stage 1..4 */
+#define HAB_TAP_CONV_OUT 100   /* arch 1: 100 + k = normalised (+ReLU / +residual+ReLU) output of backbone conv k, k in build order:
+                                * per block its main-branch convs, then its downsample conv if it has one (resnet.py:37-69,116-152) */
 int hab_policy_tap(hab_policy* p, int which, const float** ptr, int64_t* floats);
 
 #ifdef __cplusplus

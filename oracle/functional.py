@@ -71,6 +71,15 @@ def resnet_input(obs, visual_keys: List[str]) -> torch.Tensor:
     return F.avg_pool2d(x.float(), 2)
 
 
+def rmv_merge(mean, var, count, new_mean, new_var, new_count):
+    """The Chan merge of rl/ddppo/policy/running_mean_and_var.py:54-71: running (mean, var, count) with the moments of a batch of
+    new_count frames.  Under DD-PPO new_mean / new_var are the rank AVERAGES and new_count the rank SUM (:38-49)."""
+    m_a = var * count
+    m_b = new_var * new_count
+    M2 = m_a + m_b + (new_mean - mean).pow(2) * count * new_count / (count + new_count)
+    return M2 / (count + new_count), (count * mean + new_count * new_mean) / (count + new_count), count + new_count
+
+
 def running_mean_and_var(x, mean, var, count, training: bool, world_size: int = 1):
     """rl/ddppo/policy/running_mean_and_var.py:24-78 (single process).  Returns
     (normalised x, new_mean, new_var, new_count)."""
@@ -80,14 +89,7 @@ def running_mean_and_var(x, mean, var, count, training: bool, world_size: int = 
         new_mean = xc.mean(-1, keepdim=True)
         new_count = torch.full_like(count, n)
         new_var = (xc - new_mean).pow(2).mean(dim=-1, keepdim=True)
-        new_mean = new_mean.view(1, -1, 1, 1)
-        new_var = new_var.view(1, -1, 1, 1)
-        m_a = var * count
-        m_b = new_var * new_count
-        M2 = m_a + m_b + (new_mean - mean).pow(2) * count * new_count / (count + new_count)
-        var = M2 / (count + new_count)
-        mean = (count * mean + new_count * new_mean) / (count + new_count)
-        count = count + new_count
+        var, mean, count = rmv_merge(mean, var, count, new_mean.view(1, -1, 1, 1), new_var.view(1, -1, 1, 1), new_count)
     inv_stdev = torch.rsqrt(torch.max(var, torch.full_like(var, 1e-2)))
     return torch.addcmul(-mean * inv_stdev, x, inv_stdev), mean, var, count
 
@@ -105,8 +107,16 @@ def resnet_backbone(params: Params, pre: str, x, backbone: str, baseplanes: int,
     kind, layers = RESNET_LAYERS[backbone]
     x = F.conv2d(x, params[pre + "conv1.0.weight"], None, stride=2, padding=3)
     x = F.relu(_gn(x, params, pre + "conv1.1", ngroups))
+    relu_log = taps.setdefault("relu", []) if taps is not None else None  # every post-ReLU activation, in forward order
+
+    def rl(name, t):
+        if relu_log is not None:
+            relu_log.append((name, t))
+        return t
+
     if taps is not None:
         taps["stem"] = x
+    rl("stem", x)
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     if taps is not None:
         taps["pool"] = x
@@ -121,20 +131,20 @@ def resnet_backbone(params: Params, pre: str, x, backbone: str, baseplanes: int,
             residual = x
             if kind == "basic":
                 out = F.conv2d(x, params[bp + "convs.0.weight"], None, stride=stride, padding=1)
-                out = F.relu(_gn(out, params, bp + "convs.1", ngroups))
+                out = rl(bp + "convs.1", F.relu(_gn(out, params, bp + "convs.1", ngroups)))
                 out = F.conv2d(out, params[bp + "convs.3.weight"], None, stride=1, padding=1)
                 out = _gn(out, params, bp + "convs.4", ngroups)
             else:
                 out = F.conv2d(x, params[bp + "convs.0.weight"], None)
-                out = F.relu(_gn(out, params, bp + "convs.1", ngroups))
+                out = rl(bp + "convs.1", F.relu(_gn(out, params, bp + "convs.1", ngroups)))
                 out = F.conv2d(out, params[bp + "convs.3.weight"], None, stride=stride, padding=1)
-                out = F.relu(_gn(out, params, bp + "convs.4", ngroups))
+                out = rl(bp + "convs.4", F.relu(_gn(out, params, bp + "convs.4", ngroups)))
                 out = F.conv2d(out, params[bp + "convs.6.weight"], None)
                 out = _gn(out, params, bp + "convs.7", ngroups)
             if has_ds:
                 residual = F.conv2d(x, params[bp + "downsample.0.weight"], None, stride=stride)
                 residual = _gn(residual, params, bp + "downsample.1", ngroups)
-            x = F.relu(out + residual)
+            x = rl(bp + "out", F.relu(out + residual))
             inplanes = planes * expansion
         if taps is not None:
             taps[f"layer{li + 1}"] = x
@@ -158,6 +168,7 @@ def resnet_encoder(params: Params, pre: str, obs, visual_keys, backbone, basepla
     x = F.relu(F.group_norm(x, 1, params[pre + "compression.1.weight"], params[pre + "compression.1.bias"], eps=1e-5))
     if taps is not None:
         taps["compression"] = x
+        taps["relu"].append((pre + "compression", x))
     return x
 
 
@@ -542,6 +553,81 @@ def ppo_update(params: Params, spec: NetSpec, buffers: dict, num_steps: int, cfg
                 rec("ppo_fraction_clipped", (r > 1.0 + cfg.clip_param).float().mean() + (r < 1.0 - cfg.clip_param).float().mean())
             rec("grad_norm", gnorm)
     return {k: float(torch.stack(v).mean()) for k, v in metrics.items()}
+
+
+def minibatch_chunked(params: Params, spec: NetSpec, buffers: dict, adv, inds, num_steps: int, cfg, trainable: List[str],
+                      env_chunk: int = 4, with_grads: bool = True, rmv_override: Optional[dict] = None, tap_hook=None):
+    """evaluate_actions + ppo_loss + backward (rl/ppo/ppo.py:195-258) of ONE minibatch (env columns `inds`, rows 0..T-1), evaluated
+    `env_chunk` env columns at a time so that host memory stays bounded at the benchmark shapes (4096 frames of a 256x256
+    ResNet18 keep ~40 GB of autograd state otherwise).  Exact, not an approximation: frames of different envs only interact
+    through (a) the batch means of the three losses -- each chunk contributes sum/B -- and (b) the RunningMeanAndVar batch
+    moments of the ResNet encoder, which are computed over the WHOLE minibatch first (two chunked passes) and merged like the
+    module does; the chunks are then normalised with the merged statistics (what the module's training forward uses).
+    Returns values / log-probs / entropy in the minibatch's time-major frame order, the four loss scalars, the gradients,
+    and the merged statistics.  `tap_hook(c0, k, taps)` (optional) receives the activation taps of every chunk (env columns
+    c0 .. c0+k of the minibatch; tensors are (T*k, ...) time-major)."""
+    n = len(inds)
+    B = num_steps * n
+    p = dict(params)
+    rmv = None
+    pre = "net.visual_encoder.running_mean_and_var."
+    if spec.kind == "resnet" and spec.normalize and "visual_features" not in buffers["observations"]:
+        C = params[pre + "_mean"].shape[1]
+        s1 = torch.zeros(C, dtype=torch.float64)
+        npix = 0
+        chunks = [inds[i:i + env_chunk] for i in range(0, n, env_chunk)]
+        for ci in chunks:
+            x = resnet_input({k: buffers["observations"][k][0:num_steps, ci].flatten(0, 1) for k in spec.visual_keys}, spec.visual_keys)
+            s1 += x.double().sum(dim=(0, 2, 3))
+            npix += x.numel() // C
+        new_mean = (s1 / npix).float().view(1, C, 1, 1)
+        s2 = torch.zeros(C, dtype=torch.float64)
+        for ci in chunks:
+            x = resnet_input({k: buffers["observations"][k][0:num_steps, ci].flatten(0, 1) for k in spec.visual_keys}, spec.visual_keys)
+            s2 += (x - new_mean).pow(2).double().sum(dim=(0, 2, 3))
+        new_var = (s2 / npix).float().view(1, C, 1, 1)
+        var, mean, count = rmv_merge(params[pre + "_mean"], params[pre + "_var"], params[pre + "_count"], new_mean, new_var,
+                                     torch.full_like(params[pre + "_count"], B))
+        rmv = dict(mean=mean, var=var, count=count)
+        if rmv_override is not None:  # (tests) the statistics of another evaluation of the same batch, bit for bit
+            rmv = dict(rmv_override)
+        p[pre + "_mean"], p[pre + "_var"], p[pre + "_count"] = rmv["mean"], rmv["var"], rmv["count"]
+    if with_grads:
+        for k in trainable:
+            p[k] = params[k].detach().clone().requires_grad_(True)
+    values, logps, ents = (torch.zeros(num_steps, n, 1) for _ in range(3))
+    sums = torch.zeros(3, dtype=torch.float64)
+    for c0 in range(0, n, env_chunk):
+        ci = inds[c0:c0 + env_chunk]
+        batch = gather_minibatch(buffers, adv, ci, num_steps)
+        with torch.set_grad_enabled(with_grads):
+            taps = {} if tap_hook is not None else None
+            v, lp, ent, _ = evaluate_actions(p, spec, batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"],
+                                             batch["masks"], batch["actions"], training=False, taps=taps)
+            if tap_hook is not None:
+                tap_hook(c0, len(ci), taps)
+                del taps
+            ratio = torch.exp(lp - batch["action_log_probs"])
+            s_1 = batch["advantages"] * ratio
+            s_2 = batch["advantages"] * torch.clamp(ratio, 1.0 - cfg.clip_param, 1.0 + cfg.clip_param)
+            al = -torch.min(s_1, s_2)
+            vv = v.float()
+            if cfg.use_clipped_value_loss:
+                delta = vv.detach() - batch["value_preds"]
+                clipped = batch["value_preds"] + delta.clamp(-cfg.clip_param, cfg.clip_param)
+                vv = torch.where(delta.abs() < cfg.clip_param, vv, clipped)
+            vl = 0.5 * F.mse_loss(vv, batch["returns"], reduction="none")
+            if with_grads:
+                ((cfg.value_loss_coef * vl.sum() + al.sum() - cfg.entropy_coef * ent.sum()) / B).backward()
+        k = len(ci)
+        values[:, c0:c0 + k], logps[:, c0:c0 + k], ents[:, c0:c0 + k] = (t.detach().view(num_steps, k, 1) for t in (v, lp, ent))
+        sums += torch.stack([vl.detach().double().sum(), al.detach().double().sum(), ent.detach().double().sum()])
+    vl_m, al_m, ent_m = (sums / B).tolist()
+    out = dict(value=values.view(B, 1), log_prob=logps.view(B, 1), entropy=ents.view(B, 1), value_loss=vl_m, action_loss=al_m,
+               dist_entropy=ent_m, total=cfg.value_loss_coef * vl_m + al_m - cfg.entropy_coef * ent_m, rmv=rmv)
+    if with_grads:
+        out["grads"] = {k: p[k].grad for k in trainable if p[k].grad is not None}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

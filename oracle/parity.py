@@ -1,0 +1,209 @@
+"""TEST INFRASTRUCTURE ONLY -- compares ONE PPO minibatch step of the HIP engine (evaluate -> fused loss -> backward) with the CPU
+oracle on the very same rollout arena, at any shape incl. BASELINE.json's (2048 SimpleCNN frames / 4096 ResNet18 frames of
+256x256 RGB-D).  Used by tests/test_gpu_fullshape.py and by bench.py's `parity` leg; never by the product package.
+
+The oracle side is `oracle.functional.minibatch_chunked` (exactly evaluate_actions + ppo_loss + backward of
+rl/ppo/ppo.py:195-258, evaluated a few env columns at a time so host memory stays bounded)."""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import functional as O
+
+GOAL = "pointgoal_with_gps_compass"
+
+
+def spec_of(policy) -> O.NetSpec:
+    """Oracle NetSpec of a habitat_amd policy (from the constructor arguments it keeps)."""
+    kw = policy._engine_kwargs
+    if kw["arch"] == "simple_cnn":
+        return O.NetSpec(kind="baseline", rnn_type=kw["rnn_type"], num_layers=kw["rnn_layers"], hidden=kw["hidden"],
+                         num_actions=kw["num_actions"])
+    return O.NetSpec(kind="resnet", rnn_type=kw["rnn_type"], num_layers=kw["rnn_layers"], backbone=f"resnet{kw['backbone']}",
+                     baseplanes=kw["baseplanes"], visual_keys=list(kw["visual_order"]),
+                     normalize=bool(kw["normalize_visual_inputs"]), hidden=kw["hidden"], num_actions=kw["num_actions"])
+
+
+def columns_to_cpu(storage, cols: torch.Tensor, T: int) -> dict:
+    """CPU copy of the env columns `cols` of a device RolloutStorage (rows 0..T), shaped like RolloutStorage.buffers."""
+    B = storage.buffers
+    dev_cols = cols.to(storage.device)
+    take = lambda v: v[0:T + 1].index_select(1, dev_cols).cpu()
+    out = {k: take(B[k]) for k in ("recurrent_hidden_states", "rewards", "value_preds", "returns", "action_log_probs", "actions",
+                                   "prev_actions", "masks")}
+    out["observations"] = {k: take(v) for k, v in B["observations"].items()}
+    return out
+
+
+def rel(got, ref, floor=1e-3) -> float:
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.abs(got - ref).max() / max(floor, np.abs(ref).max()))
+
+
+def resnet_relu_taps(eng, backbone: str):
+    """Engine views (flat, NHWC) of every post-ReLU activation of the ResNet encoder that the backward derives a mask from, in the
+    order of oracle.functional.resnet_backbone's `taps["relu"]`: stem, per block its inner convs and its output, compression."""
+    nblocks = [3, 4, 6, 3] if backbone == "resnet50" else [2, 2, 2, 2]
+    per_block = 3 if backbone == "resnet50" else 2
+    taps = [eng.tap(6)]  # HAB_TAP_STEM
+    k = 0
+    inplanes, exp = 32, (4 if backbone == "resnet50" else 1)
+    for li, nb in enumerate(nblocks):
+        planes = 32 << li
+        for bi in range(nb):
+            stride = 2 if (bi == 0 and li > 0) else 1
+            has_ds = bi == 0 and (stride != 1 or inplanes != planes * exp)
+            for q in range(per_block):
+                taps.append(eng.tap(100 + k + q))  # HAB_TAP_CONV_OUT: inner convs (GN + ReLU), last = block output (GN + residual + ReLU)
+            k += per_block + (1 if has_ds else 0)
+            inplanes = planes * exp
+    taps.append(eng.tap(8))  # HAB_TAP_COMPRESSION
+    return taps
+
+
+class MaskInjector:
+    """tap_hook for oracle.functional.minibatch_chunked: for every chunk of env columns, compares the sign pattern of the engine's
+    saved post-ReLU activations with the oracle's, counts the bits that differ and overwrites exactly those engine activations
+    with the oracle's sign (0, or a tiny positive value) -- so that a second backward uses the oracle's ReLU masks."""
+
+    def __init__(self, policy, T: int, n: int):
+        eng, kw = policy.engine, policy._engine_kwargs
+        self.T, self.n, self.hidden = T, n, kw["hidden"]
+        self.kind = kw["arch"]
+        self.rin = eng.tap(3).view(T, n, -1)  # HAB_TAP_RNN_IN: [..., :hidden] = ReLU(visual fc)
+        if self.kind == "resnet":
+            self.eng_taps = resnet_relu_taps(eng, f"resnet{kw['backbone']}")
+        else:
+            self.eng_taps = [eng.tap(0), eng.tap(1)]  # HAB_TAP_CONV1 / CONV2 (ReLU outputs of SimpleCNN)
+        self.flips: Dict[str, list] = {}
+        self.total = 0
+        self.n_act = 0
+
+    def _patch(self, name, ev, ov):
+        diff = (ev > 0) != (ov > 0)
+        nf = int(diff.sum())
+        self.n_act += ev.numel()
+        if nf:
+            mag = float(torch.maximum(ev, ov)[diff].max())
+            f = self.flips.setdefault(name, [0, 0.0])
+            f[0] += nf
+            f[1] = max(f[1], mag)
+            self.total += nf
+            ev.copy_(torch.where(ov > 0, torch.clamp_min(ev, 1e-20), torch.zeros_like(ev)))
+
+    def __call__(self, c0: int, k: int, taps: dict):
+        T, n = self.T, self.n
+        if self.kind == "resnet":
+            pairs = list(taps["relu"])
+            fc = taps["visual_fc"]
+        else:
+            pairs = [("conv1", taps["conv1"]), ("conv2", taps["conv2"])]
+            fc = taps["cnn_out"]
+        assert len(pairs) == len(self.eng_taps)
+        for (name, a), t in zip(pairs, self.eng_taps):
+            a = a.detach()
+            C_, H_, W_ = a.shape[1:]
+            ov = a.view(T, k, C_, H_, W_).permute(0, 1, 3, 4, 2).to(t.device, non_blocking=True)
+            ev = t.view(T, n, H_, W_, C_)[:, c0:c0 + k]
+            self._patch(name, ev, ov)
+        ov = fc.detach().view(T, k, -1).to(self.rin.device)
+        self._patch("visual_fc", self.rin[:, c0:c0 + k, :self.hidden], ov)
+
+
+def minibatch_parity(policy, ppo, storage, batch, cfg, env_chunk: int = 4, with_grads: bool = True, inject_masks: bool = False) -> Dict[str, object]:
+    """Runs the engine's minibatch step on `batch` (a habitat_amd MiniBatch of `storage`) WITHOUT the optimiser step and the oracle
+    on a CPU copy of the same columns.  Returns error figures (max |err| / max |ref| per tensor family, relative loss errors,
+    per-parameter gradient errors elementwise and norm-wise) plus timings; the caller decides on thresholds.
+    inject_masks: after the first backward the oracle's ReLU sign pattern is written over the engine's saved activations
+    (MaskInjector) and the backward is repeated; the report then carries both sets of gradient errors and the number of mask bits
+    that differed -- what remains after the injection is NOT attributable to ReLU's discontinuity."""
+    from habitat_amd import _lib
+    eng = policy.engine
+    T, n = batch.T, batch.n
+    Bn = T * n
+    Bf = storage.buffers
+    obs = Bf["observations"]
+    params = {k: v.detach().cpu().clone() for k, v in policy.state_dict().items()}  # BEFORE evaluate: RunningMeanAndVar not yet updated
+    spec = spec_of(policy)
+    adv = batch.advantages_full
+    extra = {k: obs[k] for k in ("semantic", "objectgoal", "compass", "gps", "visual_features") if k in obs}
+    dev = storage.device
+    v, lp, ent, dv, dlp, dent = (torch.zeros(Bn, device=dev) for _ in range(6))
+    out16 = torch.zeros(16, device=dev)
+    eng.evaluate(obs.get("rgb"), obs.get("depth"), obs.get(GOAL), batch.rows, Bf["recurrent_hidden_states"], Bf["masks"], Bf["actions"],
+                 batch.pack, Bn, n, value=v, log_prob=lp, entropy=ent, prev_actions=Bf["prev_actions"], extra=extra)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().hab_ppo_loss(P(v), P(lp), P(ent), P(Bf["action_log_probs"]), P(adv), P(Bf["value_preds"]), P(Bf["returns"]),
+                                       P(batch.rows), Bn, float(cfg.clip_param), float(cfg.value_loss_coef), float(cfg.entropy_coef),
+                                       int(cfg.use_clipped_value_loss), P(dv), P(dlp), P(dent), P(out16), _lib.stream_ptr()), "hab_ppo_loss")
+    def backward():
+        eng.backward(obs.get("rgb"), obs.get("depth"), obs.get(GOAL), batch.rows, Bf["actions"], batch.pack, dv, dlp, dent,
+                     prev_actions=Bf["prev_actions"], extra=extra)
+        return {k: g.detach().cpu().clone() for k, g in eng.grad_views.items() if k not in eng.buffer_names}
+
+    grads_first = backward() if with_grads else None
+    torch.cuda.synchronize()
+    injector = MaskInjector(policy, T, n) if (inject_masks and with_grads) else None
+    # ---- oracle on the same columns -------------------------------------------------------------------------------------
+    t0 = time.perf_counter()
+    cols = batch.inds.clone()
+    buf = columns_to_cpu(storage, cols, T)
+    adv_cpu = adv[0:T + 1].index_select(1, cols.to(dev)).cpu()
+    trainable = [k for k, p_ in policy.named_parameters() if p_.requires_grad]
+    ref = O.minibatch_chunked(params, spec, buf, adv_cpu, torch.arange(n), T, cfg, trainable, env_chunk=env_chunk, with_grads=with_grads,
+                              tap_hook=injector)
+    t_oracle = time.perf_counter() - t0
+    rep: Dict[str, object] = {"frames": Bn, "envs": n, "steps": T, "oracle_seconds": round(t_oracle, 1)}
+    rep["value_max_rel"] = rel(v.cpu().numpy(), ref["value"].view(-1).numpy())
+    rep["log_prob_max_rel"] = rel(lp.cpu().numpy(), ref["log_prob"].view(-1).numpy())
+    rep["entropy_max_rel"] = rel(ent.cpu().numpy(), ref["entropy"].view(-1).numpy())
+    got = out16[:4].cpu().numpy().astype(np.float64)
+    for i, k in enumerate(("value_loss", "action_loss", "dist_entropy", "total")):
+        rep[k] = float(got[i])
+        rep[k + "_ref"] = float(ref[k])
+        rep[k + "_rel"] = float(abs(got[i] - ref[k]) / max(1e-6, abs(ref[k])))
+    if ref["rmv"] is not None:
+        pre = "net.visual_encoder.running_mean_and_var."
+        sd = policy.state_dict()
+        rep["rmv_max_rel"] = max(rel(sd[pre + "_" + k].cpu().numpy(), ref["rmv"][k].numpy(), floor=1e-6) for k in ("mean", "var", "count"))
+    if with_grads:
+        def errors(grads):
+            per = {}
+            for k, g in grads.items():
+                if k not in ref["grads"]:
+                    continue
+                r = ref["grads"][k].numpy().astype(np.float64)
+                gg = g.numpy().astype(np.float64)
+                per[k] = (float(np.abs(gg - r).max() / max(1e-12, np.abs(r).max())),
+                          float(np.linalg.norm(gg - r) / max(1e-30, np.linalg.norm(r))))
+            return per
+
+        per = errors(grads_first)
+        rep["grad_max_rel_elementwise"] = max(v_[0] for v_ in per.values())
+        rep["grad_max_rel_normwise"] = max(v_[1] for v_ in per.values())
+        rep["grad_worst"] = sorted(((k, round(a, 7), round(b, 7)) for k, (a, b) in per.items()), key=lambda x: -x[2])[:6]
+        rep["_grads_per_param"] = per
+        if injector is not None:
+            per2 = errors(backward())
+            rep["relu_mask_bits_differing"] = injector.total
+            rep["relu_mask_bits_total"] = injector.n_act
+            rep["relu_mask_flips_by_layer"] = {k: (v_[0], float(f"{v_[1]:.3e}")) for k, v_ in injector.flips.items()}
+            rep["grad_max_rel_normwise_with_oracle_masks"] = max(v_[1] for v_ in per2.values())
+            rep["grad_max_rel_elementwise_with_oracle_masks"] = max(v_[0] for v_ in per2.values())
+            rep["grad_worst_with_oracle_masks"] = sorted(((k, round(a, 7), round(b, 7)) for k, (a, b) in per2.items()), key=lambda x: -x[2])[:6]
+            rep["_grads_per_param_with_oracle_masks"] = per2
+    return rep
+
+
+def returns_parity(storage, next_value: torch.Tensor, use_gae: bool, gamma: float, tau: float) -> float:
+    """max relative error of the device GAE (whatever variant the storage is configured with) against the reference loop
+    (common/rollout_storage.py:174-205) on the storage's own rewards / value predictions / masks."""
+    B = storage.buffers
+    T = storage.current_rollout_step_idx
+    r, _ = O.compute_returns(B["rewards"].cpu(), B["value_preds"].cpu(), B["masks"].cpu(), next_value.cpu().view(-1, 1), T, use_gae, gamma, tau)
+    return rel(B["returns"].cpu().numpy()[:T], r.numpy()[:T])

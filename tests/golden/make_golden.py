@@ -165,11 +165,29 @@ def rnn_case(ns):
     print("rnn_encoder -> GRU, LSTM")
 
 
+def c1_case(ns):
+    """BASELINE.json configs[0] EXACTLY: PointNavBaselinePolicy (SimpleCNN + GRU 512), 4 envs x 32 steps, 84x84 depth-only,
+    the ppo section of config/pointnav/ppo_pointnav_example.yaml (clip 0.1, E=1, M=1, lr 2.5e-4, max_grad_norm 0.5, T=32; advantage
+    normalisation off and clipped value loss on = default_structured_configs.py:303-316).  Multi-hundred-thousand-element tensors
+    are kept as strided samples + norms."""
+    space = obs_space(ns, 84, 84, rgb=False)
+    torch.manual_seed(0)
+    pol = ns.policy.PointNavBaselinePolicy(space, ns.spaces.Discrete(4), hidden_size=512)
+    cfg = make_config(clip_param=0.1, ppo_epoch=1, num_mini_batch=1, max_grad_norm=0.5, num_steps=32, value_loss_coef=0.5,
+                      entropy_coef=0.01, use_normalized_advantage=False, use_clipped_value_loss=True, hidden_size=512, lr=2.5e-4,
+                      eps=1e-5)
+    run_case(ns, "c1_depth84_h512_4x32", pol, space, cfg, T=32, N=4, seed=41, H=84, W=84, rgb=False, sampled=True)
+
+
 def main():
     ns = load_reference()
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "c1":
+        c1_case(ns)
+        return
     pack_cases(ns)
     rnn_case(ns)
+    c1_case(ns)
     # A: PointNavBaselinePolicy (SimpleCNN + GRU), 44x44 RGB-D, hidden 64, T=6, N=4, iccv19 hyper-parameters
     H = W = 44
     space = obs_space(ns, H, W)

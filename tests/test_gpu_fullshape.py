@@ -1,0 +1,80 @@
+"""GPU parity AT THE BENCHMARK SHAPES (BASELINE.json configs[1] / configs[2]): the trainer built from the YAML entrypoint collects a
+full 64 envs x 128 steps rollout of 256x256 RGB-D on the device, then ONE full-size PPO minibatch -- 2048 frames for SimpleCNN+GRU
+(M=4), 4096 frames for ResNet18 + 2-layer LSTM (M=2), hidden 512 -- is evaluated by the HIP engine (forward, fused loss, backward)
+and by the CPU oracle on the same arena columns (oracle.parity / oracle.functional.minibatch_chunked, bounded memory).  These are the
+code paths the golden fixtures (T <= 32, N <= 4) never reach: tile selection and split-K plans at M = 1.8e6 ... 1.7e7 rows,
+per-tile buffer re-basing of > 2 GB tensors, the patch-resident weight gradients at 4096 frames, chunked GroupNorm at full batch.
+
+Tolerance: 1e-4 relative on values / log-probs / entropy (all frames), on the three losses and on the returns (north_star);
+gradients: 1e-4 norm-wise for every parameter of the shallow SimpleCNN policy and for every parameter downstream of the 20-layer
+GroupNorm encoder.  The encoder's own weight gradients sit upstream of ~1e9 ReLU decisions per minibatch, a handful of which fall
+within fp32 round-off of zero and legitimately come out on the other side (two evaluations of the CPU oracle itself differ by
+2e-3 when ONE such bit flips: tests/test_oracle_golden.py::test_minibatch_chunked_equals_whole).  That is accounted for, not
+assumed: the mask bits on which engine and oracle disagree are counted (they must all belong to activations below 1e-4), the
+oracle's sign pattern is written over the engine's saved activations, the backward is repeated and every encoder gradient must then
+meet 3e-4 norm-wise.  The measured figures are written to gpurun_out/parity_<workload>.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _report(name, rep):
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"parity_{name}.json"), "w") as f:
+        json.dump({k: v for k, v in rep.items() if not k.startswith("_")}, f, indent=1)
+
+
+@pytest.mark.parametrize("workload,frames", [("c2", 2048), ("c3", 4096)])
+def test_full_minibatch_at_benchmark_shape_vs_oracle(workload, frames):
+    import bench
+    from oracle import parity
+    torch.manual_seed(1234)
+    trainer, cfg = bench.make_trainer(workload, 3)
+    trainer._init_train()
+    ppo_cfg = cfg.habitat_baselines.rl.ppo
+    agent = trainer._agent
+    st = agent.rollouts
+    assert (trainer.envs.num_envs, ppo_cfg.num_steps, ppo_cfg.hidden_size) == (64, 128, 512)
+    agent.eval()
+    assert trainer.collect_rollout() == 64 * 128
+    last = st.get_last_step()
+    nv = agent.actor_critic.get_value({k: v.contiguous() for k, v in last["observations"].items()}, last["recurrent_hidden_states"],
+                                      last["prev_actions"], last["masks"])
+    st.compute_returns(nv, ppo_cfg.use_gae, ppo_cfg.gamma, ppo_cfg.tau)  # the GAE variant the benchmark times (scan)
+    rep = {"workload": bench.WORKLOADS[workload]["name"], "gae_variant": st.gae_variant,
+           "returns_max_rel": parity.returns_parity(st, nv, ppo_cfg.use_gae, ppo_cfg.gamma, ppo_cfg.tau)}
+    agent.train()
+    ppo = agent.updater
+    adv = ppo.get_advantages(st)
+    torch.manual_seed(99)
+    batch = next(st.data_generator(adv, ppo_cfg.num_mini_batch))
+    assert batch.T * batch.n == frames
+    rep.update(parity.minibatch_parity(agent.actor_critic, ppo, st, batch, ppo_cfg, env_chunk=4, inject_masks=True))
+    per = rep.pop("_grads_per_param")
+    per2 = rep.pop("_grads_per_param_with_oracle_masks")
+    _report(workload, rep)
+    print(json.dumps(rep))
+    assert rep["returns_max_rel"] <= 1e-4, rep
+    for k in ("value_max_rel", "log_prob_max_rel", "entropy_max_rel", "value_loss_rel", "action_loss_rel", "dist_entropy_rel"):
+        assert rep[k] <= 1e-4, (k, rep[k])
+    if "rmv_max_rel" in rep:
+        assert rep["rmv_max_rel"] <= 1e-5, rep["rmv_max_rel"]
+    bad = []
+    for k, (elem, normw) in per.items():
+        deep = workload == "c3" and ("backbone" in k)
+        if normw > (3e-2 if deep else 1e-4):
+            bad.append((k, elem, normw))
+    assert not bad, bad
+    # ReLU accounting: only activations within round-off of zero may disagree in sign, and with the oracle's signs in place ...
+    assert all(mag < 1e-4 for _, mag in rep["relu_mask_flips_by_layer"].values()), rep["relu_mask_flips_by_layer"]
+    assert rep["relu_mask_bits_differing"] <= 1e-5 * rep["relu_mask_bits_total"]
+    bad2 = [(k, e, nw) for k, (e, nw) in per2.items() if nw > (3e-4 if (workload == "c3" and "backbone" in k) else 1e-4)]
+    assert not bad2, bad2  # ... every gradient agrees
+    trainer.envs.close()

@@ -160,7 +160,12 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
             continue
         ref = z["grad/" + k]
         got = samp(g.cpu().numpy()).reshape(ref.shape)
-        if c.get("sampled"):
+        if c.get("exact"):  # shallow encoder stored as strided samples + norms: full 1e-4 bar on both
+            nr = float(z["gradnorm/" + k])
+            nerr = abs(float(g.double().norm()) - nr) / max(1e-12, nr)
+            if not rel_ok(got, ref, tol=1e-4, floor=1e-4) or nerr > 1e-4:
+                bad.append((k, float(np.abs(got - ref).max()), float(np.abs(ref).max()), nerr))
+        elif c.get("sampled"):
             # ReLU boundary: in this fixture the reference's own pre-ReLU activations come within 2.5e-6 of zero
             # (layer3.1.convs.1; all 21 GroupNorm outputs have |y| < 1e-5 somewhere), i.e. inside fp32 round-off of ANY other
             # summation order, so single mask bits legitimately flip and perturb upstream weight gradients by ~1/(pixels).
@@ -177,6 +182,99 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
         elif not rel_ok(got, ref, tol=2e-4, floor=1e-4):
             bad.append((k, float(np.abs(got - ref).max()), float(np.abs(ref).max())))
     assert not bad, f"gradient mismatch: {bad}"
+
+
+@pytest.mark.parametrize("case", ["resnet18_rgbd256", "objectnav_resnet50_256"])
+def test_resnet_golden_mask_flip_accounting(case):
+    """The loosened bound on the deep encoder's upstream weight gradients in the golden test is attributed, not assumed: count the
+    ReLU mask bits on which the engine and the (reference-pinned) oracle disagree, overwrite exactly those saved activations with the
+    oracle's sign, rerun the backward -- every gradient must then meet the same 2e-4 bound as the parameters downstream of the
+    encoder, i.e. the residual of the golden test is the discontinuity of ReLU at pre-activations within fp32 round-off of zero
+    and nothing else."""
+    from habitat_amd.rl.ppo import PPO
+    from habitat_amd import _lib
+    import ctypes as C
+    z = np.load(os.path.join(G, case + ".npz"))
+    c, params, spec, buf, next_value, pol, st = build(case, z)
+    cfg = make_cfg(**c["cfg"])
+    T, N = c["T"], c["N"]
+    fill_storage(st, buf, z, T)
+    pol.train()
+    ppo = PPO.from_config(pol, cfg)
+    adv = ppo.get_advantages(st)
+    torch.manual_seed(c["seed"] + 1)
+    batch = next(st.data_generator(adv, cfg.num_mini_batch))
+    eng = pol.engine
+    Bn, Bf = batch.T * batch.n, st.buffers
+    obs = Bf["observations"]
+    v, lp, ent, dv, dlp, dent = (torch.zeros(Bn, device="cuda") for _ in range(6))
+    eng.evaluate(obs.get("rgb"), obs.get("depth"), obs.get(GOAL), batch.rows, Bf["recurrent_hidden_states"], Bf["masks"],
+                 Bf["actions"], batch.pack, Bn, batch.n, value=v, log_prob=lp, entropy=ent, prev_actions=Bf["prev_actions"],
+                 extra=extra_of(obs))
+    out = torch.zeros(16, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().hab_ppo_loss(P(v), P(lp), P(ent), P(Bf["action_log_probs"]), P(adv), P(Bf["value_preds"]), P(Bf["returns"]),
+                                       P(batch.rows), Bn, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef,
+                                       int(cfg.use_clipped_value_loss), P(dv), P(dlp), P(dent), P(out), _lib.stream_ptr()))
+
+    def backward_and_errors():
+        eng.backward(obs.get("rgb"), obs.get("depth"), obs.get(GOAL), batch.rows, Bf["actions"], batch.pack, dv, dlp, dent,
+                     prev_actions=Bf["prev_actions"], extra=extra_of(obs))
+        worst = {}
+        for k, g in eng.grad_views.items():
+            if is_buffer(k):
+                continue
+            ref = z["grad/" + k]
+            got = golden_sample(g.cpu().numpy()).reshape(ref.shape)
+            err = np.linalg.norm((got - ref).astype(np.float64)) / max(1e-12, np.linalg.norm(ref.astype(np.float64)))
+            nr = float(z["gradnorm/" + k])
+            worst[k] = max(err, abs(float(g.double().norm()) - nr) / max(1e-12, nr))
+        return worst
+
+    before = backward_and_errors()
+    # the oracle's activations for the same minibatch (training-mode RunningMeanAndVar from the same initial statistics)
+    ob = O.gather_minibatch(buf, adv.cpu(), batch.inds, T)
+    taps = {}
+    with torch.no_grad():
+        O.evaluate_actions(params, spec, ob["observations"], ob["recurrent_hidden_states"], ob["prev_actions"], ob["masks"], ob["actions"],
+                           training=True, taps=taps)
+    from oracle.parity import resnet_relu_taps
+    eng_taps = resnet_relu_taps(eng, c.get("backbone", "resnet18"))
+    assert len(eng_taps) == len(taps["relu"])
+    flips = {}
+    for (name, a), t in zip(taps["relu"], eng_taps):
+        ref_act = a.permute(0, 2, 3, 1).contiguous().view(-1).cuda()
+        assert ref_act.numel() == t.numel(), name
+        diff = (t > 0) != (ref_act > 0)
+        nflip = int(diff.sum())
+        if nflip:
+            flips[name] = (nflip, float(torch.maximum(t, ref_act)[diff].max()))  # how far from zero the disagreeing activations are
+            t.copy_(torch.where(ref_act > 0, torch.clamp_min(t, 1e-20), torch.zeros_like(t)))
+    rin = eng.tap(3).view(Bn, -1)  # HAB_TAP_RNN_IN: [:, :hidden] = ReLU(visual_fc)
+    vfc = taps["visual_fc"].cuda()
+    dfc = (rin[:, :c["hidden"]] > 0) != (vfc > 0)
+    if int(dfc.sum()):
+        flips["visual_fc"] = (int(dfc.sum()), float(torch.maximum(rin[:, :c["hidden"]], vfc)[dfc].max()))
+        rin[:, :c["hidden"]] = torch.where(vfc > 0, torch.clamp_min(rin[:, :c["hidden"]], 1e-20), torch.zeros_like(vfc))
+    pool_err = float((eng.tap(7) - taps["pool"].permute(0, 2, 3, 1).contiguous().view(-1).cuda()).abs().max())
+    after = backward_and_errors()
+    total = sum(v_[0] for v_ in flips.values())
+    n_act = sum(t.numel() for t in eng_taps)
+    print(f"[{case}] ReLU mask bits that differ: {total} of {n_act}: {flips}; worst gradient error before {max(before.values()):.2e} "
+          f"({max(before, key=before.get)}), after injecting the oracle's mask {max(after.values()):.2e} ({max(after, key=after.get)}); "
+          f"max-pool output max |err| {pool_err:.1e}")
+    rep = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(rep, exist_ok=True)
+    with open(os.path.join(rep, f"mask_flips_{case}.txt"), "w") as f:
+        f.write(f"differing ReLU mask bits: {total} of {n_act}\n{flips}\nworst gradient error (norm-wise, vs reference golden) before: "
+                f"{max(before.values()):.3e} after injecting the oracle's mask: {max(after.values()):.3e}\n"
+                f"max-pool output max |err| {pool_err:.2e}\n\nper parameter (before, after):\n")
+        for k in before:
+            f.write(f"  {before[k]:.3e} {after[k]:.3e}  {k}\n")
+    assert all(mag < 1e-4 for _, mag in flips.values()), flips  # only activations within round-off of zero may disagree
+    assert total <= 1e-5 * n_act, (total, n_act)
+    bad = {k: e for k, e in after.items() if e > 2e-4}
+    assert not bad, (bad, flips)
 
 
 @pytest.mark.parametrize("case", list(CASES))
@@ -205,7 +303,7 @@ def test_full_ppo_update_vs_reference_golden(case, monkeypatch):
         ref = float(z["metric/" + k])
         # losses: 1e-4 (BASELINE.json).  In the deep-encoder fixture the remaining learner statistics are taken after Adam
         # steps driven by gradients that contain legitimate ReLU-boundary flips (see the minibatch test): 1e-3 there.
-        tol = 1e-4 if (not c.get("sampled") or k in ("value_loss", "action_loss", "dist_entropy")) else 1e-3
+        tol = 1e-4 if (not c.get("sampled") or c.get("exact") or k in ("value_loss", "action_loss", "dist_entropy")) else 1e-3
         assert abs(val - ref) <= tol * max(1.0, abs(ref)), (k, val, ref)
     samp = golden_sample if c.get("sampled") else (lambda a: a)
     for k, v in pol.state_dict().items():
@@ -213,7 +311,7 @@ def test_full_ppo_update_vs_reference_golden(case, monkeypatch):
         got = samp(v.cpu().numpy()).reshape(ref.shape)
         # sampled (deep GroupNorm encoder) case: Adam turns a relative gradient perturbation into a fraction of lr per step;
         # 4 steps x lr 2.5e-4 bounds the drift by 1e-3, observed < 3e-4
-        tol = 5e-4 * max(1.0, np.abs(ref).max()) if c.get("sampled") else 1e-4 * max(1e-2, np.abs(ref).max())
+        tol = 5e-4 * max(1.0, np.abs(ref).max()) if (c.get("sampled") and not c.get("exact")) else 1e-4 * max(1e-2, np.abs(ref).max())
         assert np.abs(got - ref).max() <= tol, k
 
 
@@ -769,3 +867,117 @@ def test_update_from_preempted_short_rollout(monkeypatch):
         assert abs(metrics[k] - ref_metrics[k]) <= 1e-4 * max(1.0, abs(ref_metrics[k])), (k, metrics[k], ref_metrics[k])
     for k, v in pol.state_dict().items():
         assert rel_ok(v.cpu().numpy(), p[k].detach().numpy(), tol=1e-4, floor=1e-2), k
+
+
+def _small_trainer(extra=(), N=4, T=8, size=64, path="pointnav/ppo_pointnav_habitat_iccv19.yaml", ckpt="/tmp/habitat_amd_test_ckpt"):
+    from habitat_amd.config.default import get_config
+    from habitat_amd.common.baseline_registry import baseline_registry
+    import habitat_amd.rl.ppo.ppo_trainer  # noqa: F401
+    ov = [f"habitat_baselines.num_environments={N}", f"habitat_baselines.rl.ppo.num_steps={T}", "habitat_baselines.num_updates=6",
+          "habitat_baselines.total_num_steps=-1", "habitat_baselines.num_checkpoints=-1", "habitat_baselines.checkpoint_interval=1000000",
+          "habitat_baselines.rl.ppo.hidden_size=64", f"habitat_baselines.checkpoint_folder={ckpt}",
+          "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000"]
+    for s in ("rgb", "depth"):
+        ov += [f"habitat.simulator.sensors.{s}.height={size}", f"habitat.simulator.sensors.{s}.width={size}"]
+    cfg = get_config(path, ov + list(extra))
+    cfg.habitat.simulator.sensors.pop("semantic", None)
+    return baseline_registry.get_trainer(cfg.habitat_baselines.trainer_name)(cfg)
+
+
+def test_resume_state_is_the_reference_wire_format(tmp_path):
+    """`.habitat-resume-state.pth` contents (single_agent_access_mgr.py:253-263, ppo.py:377-384): the bare
+    `actor_critic.state_dict()` (no prefix), `optim_state` = `torch.optim.Adam.state_dict()` of the optimised parameters in
+    `parameters()` order, `lr_sched_state`.  A real torch.optim.Adam loads it and continues exactly like the fused optimiser; a new
+    trainer resumed from it continues bit-identically."""
+    tr = _small_trainer(ckpt=str(tmp_path))
+    tr._init_train()
+    for _ in range(2):
+        tr.run_update_cycle()
+    agent = tr._agent
+    pol, upd = agent.actor_critic, agent.updater
+    rs = agent.get_resume_state()
+    assert list(rs["state_dict"].keys()) == list(pol.state_dict().keys())  # un-prefixed, reference order
+    osd = rs["optim_state"]
+    assert set(osd) == {"state", "param_groups"} and osd["param_groups"][0]["params"] == list(range(len(list(pol.parameters()))))
+    n_steps = 2 * tr.config.habitat_baselines.rl.ppo.ppo_epoch * tr.config.habitat_baselines.rl.ppo.num_mini_batch
+    assert all(float(s["step"]) == n_steps for s in osd["state"].values())
+    # a genuine torch.optim.Adam over copies of the parameters accepts the state ...
+    clones = [torch.nn.Parameter(p.detach().clone()) for p in pol.parameters()]
+    adam = torch.optim.Adam(clones, lr=upd.optimizer.param_groups[0]["lr"], eps=upd.optimizer.param_groups[0]["eps"])
+    adam.load_state_dict(osd)
+    # ... and makes the same next step as the fused kernel (same gradients, no clipping)
+    eng = pol.engine
+    g = torch.randn_like(eng.grads_flat) * 1e-3
+    eng.grads_flat.copy_(g)
+    for c, (nm, p) in zip(clones, pol.named_parameters()):
+        c.grad = p.grad.detach().clone()
+    before = eng.params_flat.clone()
+    upd.optimizer.step(max_grad_norm=0.0, grad_scale=1.0)
+    adam.step()
+    assert float((eng.params_flat - before).abs().max()) > 0
+    for c, (nm, p) in zip(clones, pol.named_parameters()):
+        assert torch.allclose(p.detach(), c.detach(), rtol=0, atol=2e-7), nm
+    # a second trainer resumed from the state continues bit-identically
+    rs = agent.get_resume_state()
+    rs_cpu = {"state_dict": {k: v.cpu().clone() for k, v in rs["state_dict"].items()}, "optim_state": rs["optim_state"],
+              "lr_sched_state": rs["lr_sched_state"]}
+    tr2 = _small_trainer(ckpt=str(tmp_path))
+    tr2._init_train(resume_state=None)
+    tr2._agent.load_state_dict(rs_cpu)
+    e2 = tr2._agent.actor_critic.engine
+    for (k, v1), v2 in zip(pol.state_dict().items(), tr2._agent.actor_critic.state_dict().values()):
+        assert torch.equal(v1, v2), k
+    o1, o2 = upd.optimizer, tr2._agent.updater.optimizer
+    for _i, nm, off, n, _shp in o1._slots():  # (the arena's alignment padding is not part of the state)
+        assert torch.equal(o2.exp_avg[off:off + n], o1.exp_avg[off:off + n]), nm
+        assert torch.equal(o2.exp_avg_sq[off:off + n], o1.exp_avg_sq[off:off + n]), nm
+    assert o2.step_count == o1.step_count
+    # round-1 resume files ({step, exp_avg, exp_avg_sq} flat arenas, prefixed state_dict) still load
+    legacy = {"state_dict": {"actor_critic." + k: v for k, v in rs_cpu["state_dict"].items()},
+              "optim_state": dict(step=upd.optimizer.step_count, exp_avg=upd.optimizer.exp_avg.cpu(), exp_avg_sq=upd.optimizer.exp_avg_sq.cpu())}
+    tr2._agent.load_state_dict(legacy)
+    assert torch.equal(o2.exp_avg, o1.exp_avg)
+    tr.envs.close()
+    tr2.envs.close()
+
+
+def test_synthetic_env_host_path_double_buffered_halves_advance_once():
+    """Round-1 advisor finding: with the double-buffered sampler the two halves are stepped out of phase (async_step_at for half 0
+    while half 1 is awaited, ppo_trainer.py:743-768); every env must advance exactly once per rollout step.  The host-path rollout
+    rows must equal the oracle generator's stream env for env."""
+    from oracle import synth
+    N, T, size = 4, 5, 64
+    tr = _small_trainer(extra=["habitat_baselines.rl.ppo.use_double_buffered_sampler=True"], N=N, T=T, size=size)
+    tr._init_train()
+    tr._device_envs = False  # force the generic VectorEnv protocol on the synthetic source
+    st = tr._agent.rollouts
+    observations = tr.envs.post_step(tr.envs.reset())
+    from habitat_amd.rl.ppo.ppo_trainer import batch_obs
+    st.insert_first_observations(batch_obs(observations, tr.device))
+    tr.current_episode_reward = tr.current_episode_reward.cpu()
+    tr.running_episode_stats = {k: v.cpu() for k, v in tr.running_episode_stats.items()}
+    tr._agent.eval()
+    assert tr.collect_rollout() == N * T
+    ref = synth.SyntheticEnvs(N, size, size, seed=tr.config.habitat.seed)
+    o = ref.reset()
+    B = st.buffers
+    for t in range(T + 1):
+        for k in ("rgb", "depth", GOAL):
+            assert np.array_equal(B["observations"][k][t].cpu().numpy(), o[k]), (t, k)
+        if t < T:
+            o, r, d = ref.step()
+            assert np.array_equal(B["rewards"][t].cpu().numpy().reshape(-1), r)
+            assert np.array_equal(B["masks"][t + 1].cpu().numpy().reshape(-1), ~d)
+    # a genuinely partial request (one env only): that env advances, the others keep their clock and observations
+    envs = tr.envs
+    t_before = envs._t.clone()
+    rgb_before = envs._rgb.clone()
+    envs.async_step_at(1, 0)
+    ob1, r1, d1, _ = envs.wait_step_at(1)
+    o, r, d = ref.step()
+    assert np.array_equal(ob1["rgb"], o["rgb"][1]) and r1 == float(r[1]) and d1 == bool(d[1])
+    moved = (envs._t != t_before).cpu().numpy()
+    assert moved.tolist() == [False, True, False, False] or bool(d[1])  # (an episode end resets env 1's clock)
+    keep = [0, 2, 3]
+    assert torch.equal(envs._rgb[keep], rgb_before[keep])
+    tr.envs.close()

@@ -191,3 +191,78 @@ def test_checkpoint_polling_helpers(tmp_path):
     assert os.path.basename(poll_checkpoint_folder(d, -1)) == "ckpt.1.pth"   # oldest first, not by name
     assert os.path.basename(poll_checkpoint_folder(d, 0)) == "ckpt.0.pth"
     assert poll_checkpoint_folder(d, 1) is None
+
+
+def test_adam_resume_state_round_trip_through_live_reference():
+    """Resume-state wire format (rl/ppo/ppo.py:377-384): the flat Adam arenas serialise to exactly what the reference's
+    torch.optim.Adam.state_dict() holds.  A reference PPO takes one real update; its optimiser state is scattered into flat arenas
+    (`adam_state_dict_to_flat`), serialised back (`flat_to_adam_state_dict`) and loaded by a FRESH reference PPO through the
+    reference's own `PPO.load_state_dict`; the two reference optimisers must then hold identical state."""
+    from oracle import ref_loader
+    if not ref_loader.reference_available():
+        pytest.skip("needs /root/reference (live reference)")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden import obs_space
+    from oracle import synth
+    from oracle.fixtures import synth_rollout_inputs
+    from habitat_amd.rl.ppo.ppo import adam_state_dict_to_flat, flat_to_adam_state_dict
+    ns = ref_loader.load_reference()
+    H = W = 44
+    T, N = 4, 2
+    space = obs_space(ns, H, W)
+
+    def make():
+        torch.manual_seed(0)
+        pol = ns.policy.PointNavBaselinePolicy(space, ns.spaces.Discrete(4), hidden_size=32)
+        cfg = ref_loader.make_config(clip_param=0.1, ppo_epoch=1, num_mini_batch=1, num_steps=T, hidden_size=32)
+        return pol, ns.ppo.PPO.from_config(pol, cfg), cfg
+
+    pol, ppo, cfg = make()
+    rollouts = ns.rollout_storage.RolloutStorage(T, N, space, ns.spaces.Discrete(4), pol)
+    envs = synth.SyntheticEnvs(N, H, W, seed=5)
+    obs, rew, done = synth_rollout_inputs(envs, T)
+    to_t = lambda o: {k: torch.from_numpy(v) for k, v in o.items()}
+    rollouts.insert_first_observations(to_t(obs[0]))
+    for t in range(T):
+        step = rollouts.get_current_step(slice(0, N), 0)
+        with torch.no_grad():
+            ad = pol.act(step["observations"], step["recurrent_hidden_states"], step["prev_actions"], step["masks"])
+        rollouts.insert(next_recurrent_hidden_states=ad.rnn_hidden_states, actions=ad.actions, action_log_probs=ad.action_log_probs,
+                        value_preds=ad.values)
+        rollouts.insert(next_observations=to_t(obs[t + 1]), rewards=torch.from_numpy(rew[t]).unsqueeze(1),
+                        next_masks=torch.from_numpy(~done[t]).unsqueeze(1))
+        rollouts.advance_rollout()
+    rollouts.compute_returns(torch.zeros(N, 1), True, 0.99, 0.95)
+    ppo.update(rollouts)
+    sd_ref = ppo.get_resume_state()["optim_state"]
+    # the engine's arena layout: parameters in named_parameters order, each 16-byte aligned
+    slots, off = [], 0
+    for i, (nm, p) in enumerate(pol.named_parameters()):
+        slots.append((i, nm, off, p.numel(), tuple(p.shape)))
+        off += (p.numel() + 3) & ~3
+    m, v = torch.full((off,), 7.0), torch.full((off,), 7.0)
+    step = adam_state_dict_to_flat(slots, sd_ref, m, v)
+    assert step == 1
+    ours = flat_to_adam_state_dict(slots, step, m, v, dict(lr=cfg.lr, eps=cfg.eps, betas=(0.9, 0.999)))
+    pol2, ppo2, _ = make()
+    ppo2.load_state_dict({"optim_state": ours})  # the reference's own loader
+    sd2 = ppo2.optimizer.state_dict()
+    assert sd2["state"].keys() == sd_ref["state"].keys() and len(sd2["state"]) == len(slots)
+    for i in sd_ref["state"]:
+        for k in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(torch.as_tensor(sd2["state"][i][k]).float(), torch.as_tensor(sd_ref["state"][i][k]).float()), (i, k)
+    g_ref, g2 = sd_ref["param_groups"][0], sd2["param_groups"][0]
+    assert g2["params"] == g_ref["params"]
+    for k in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
+        assert g2[k] == g_ref[k], k
+    # one more reference step from both optimisers on identical gradients gives identical parameters
+    pol2.load_state_dict(pol.state_dict())
+    for p_a, p_b in zip(pol.parameters(), pol2.parameters()):
+        p_a.grad = torch.full_like(p_a, 1e-3)
+        p_b.grad = torch.full_like(p_b, 1e-3)
+    ppo.optimizer.step()
+    ppo2.optimizer.step()
+    for (k, a), b in zip(pol.state_dict().items(), pol2.state_dict().values()):
+        assert torch.equal(a, b), k

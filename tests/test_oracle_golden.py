@@ -89,6 +89,10 @@ CASES = {
     "baseline_depth84": dict(H=84, W=84, rgb=False, depth=True, T=5, N=3, seed=7, hidden=64,
                              cfg=dict(clip_param=0.2, ppo_epoch=1, num_mini_batch=1, max_grad_norm=0.2,
                                       use_normalized_advantage=False, use_clipped_value_loss=False)),
+    # BASELINE.json configs[0] exactly: 4 envs x 32 steps, 84x84 depth, hidden 512, ppo_pointnav_example.yaml hyper-parameters
+    "c1_depth84_h512_4x32": dict(H=84, W=84, rgb=False, depth=True, T=32, N=4, seed=41, hidden=512, sampled=True, exact=True,
+                                 cfg=dict(clip_param=0.1, ppo_epoch=1, num_mini_batch=1, max_grad_norm=0.5,
+                                          use_normalized_advantage=False, use_clipped_value_loss=True)),
     "resnet18_rgbd256": dict(kind="resnet", H=256, W=256, rgb=True, depth=True, T=4, N=2, seed=21, hidden=64, sampled=True,
                              cfg=dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2,
                                       use_normalized_advantage=False, use_clipped_value_loss=True)),
@@ -227,7 +231,7 @@ def test_oracle_rollout_returns_update_vs_reference_golden(case):
         got = samp(p[k].detach().numpy()).reshape(ref.shape)
         # Adam normalises every gradient element by its own magnitude, so fp32 round-off in near-zero gradients of the deep
         # GroupNorm encoder moves a parameter by a fraction of lr per step: bound = 10% of lr * steps for that case.
-        tol = 1e-4 if c.get("sampled") else 2e-5
+        tol = 1e-4 if (c.get("sampled") and not c.get("exact")) else 2e-5
         assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), k
 
 
@@ -255,3 +259,46 @@ def test_synth_generator_properties():
     assert np.array_equal(o1["rgb"], o1b["rgb"]) and np.array_equal(r, rb) and np.array_equal(d, db)
     # known-answer values of the hash (guards the constants against silent edits)
     assert int(synth.mix(np.uint32(1))) == 0x6E0C1B91 or True
+
+
+@pytest.mark.parametrize("case", ["baseline_rgbd44", "resnet18_rgbd256"])
+def test_minibatch_chunked_equals_whole(case):
+    """oracle.minibatch_chunked (the bounded-memory evaluator the benchmark-shape GPU tests and bench.py's parity leg use) must
+    give what evaluate_actions + ppo_loss + backward give on the whole minibatch at once."""
+    z = np.load(os.path.join(G, case + ".npz"))
+    c = CASES[case]
+    cfg = make_cfg(**c["cfg"])
+    T, N = c["T"], c["N"]
+    params, spec, buf, next_value = oracle_rollout(case, z)
+    buf["returns"], buf["value_preds"] = O.compute_returns(buf["rewards"], buf["value_preds"], buf["masks"], next_value, T, True, cfg.gamma, cfg.tau)
+    adv = O.get_advantages(buf["returns"], buf["value_preds"], cfg.use_normalized_advantage)
+    inds = torch.arange(N)
+    trainable = [k for k in params if not is_buffer(k)]
+    p = {k: (v.clone().requires_grad_(True) if not is_buffer(k) else v.clone()) for k, v in params.items()}
+    batch = O.gather_minibatch(buf, adv, inds, T)
+    rmv0 = {}
+    v, lp, ent, _ = O.evaluate_actions(p, spec, batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"],
+                                       batch["masks"], batch["actions"], rmv_out=rmv0)
+    total, vl, al, de, _ = O.ppo_loss(v, lp, ent, batch, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)
+    total.backward()
+    # the encoder statistics of the whole-batch evaluation are handed over bit for bit: the chunked pass sums the batch mean in
+    # another order (1e-7 relative), which is enough to move pre-activations across ReLU's kink in this fixture (see DESIGN 2)
+    out = O.minibatch_chunked(params, spec, buf, adv, inds, T, cfg, trainable, env_chunk=1, rmv_override=rmv0 or None)
+    own = O.minibatch_chunked(params, spec, buf, adv, inds, T, cfg, trainable, env_chunk=1, with_grads=False)
+    for got, ref in ((out["value"], v), (out["log_prob"], lp), (out["entropy"], ent)):
+        assert np.abs(got.numpy() - ref.detach().numpy()).max() < 2e-6
+    assert np.allclose([out["value_loss"], out["action_loss"], out["dist_entropy"], out["total"]],
+                       [vl.item(), al.item(), de.item(), total.item()], rtol=2e-6, atol=1e-7)
+    for k in trainable:
+        g, r = out["grads"][k].numpy(), p[k].grad.numpy()
+        if "backbone" in k:
+            # torch-CPU convolutions sum in a batch-size dependent order; on this fixture that alone flips ONE ReLU bit
+            # (layer2.1.convs.1, |pre-activation| ~1e-5) between the 8-frame and the 4-frame evaluation of the SAME oracle and
+            # moves the weight gradients upstream of it by up to 2e-3 -- the discontinuity DESIGN 2 describes, seen CPU vs CPU
+            assert np.linalg.norm((g - r).astype(np.float64)) <= 1e-2 * np.linalg.norm(r.astype(np.float64)), k
+        else:
+            assert np.abs(g - r).max() <= 2e-5 * max(1e-3, np.abs(r).max()), k
+    if rmv0:
+        for k in ("mean", "var", "count"):
+            assert np.allclose(own["rmv"][k].numpy(), rmv0[k].numpy(), rtol=1e-6, atol=1e-7)
+        assert np.abs(own["value"].numpy() - v.detach().numpy()).max() < 1e-5
