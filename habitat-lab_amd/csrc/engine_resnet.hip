@@ -577,6 +577,7 @@ int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats) {
         case HAB_TAP_STEM: *ptr = W + r->stem.w_out; *floats = B * r->stem.out_floats(); return HAB_OK;
         case HAB_TAP_POOL: *ptr = W + r->w_pool; *floats = B * r->poolH * r->poolW * r->stem.cd.Cout; return HAB_OK;
         case HAB_TAP_COMPRESSION: *ptr = W + r->comp.w_out; *floats = B * r->comp.out_floats(); return HAB_OK;
+        case HAB_TAP_POOL_IDX: *ptr = W + r->w_pool_idx; *floats = (B * r->poolH * r->poolW * r->stem.cd.Cout + 3) / 4; return HAB_OK;
         default: break;
     }
     if (which >= HAB_TAP_CONV_OUT && which < HAB_TAP_CONV_OUT + (int)r->convs.size()) {

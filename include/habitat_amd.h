@@ -364,6 +364,7 @@ int hab_policy_probe_read_tag(hab_policy* p, int tag, double* total_ms, int* cou
 #define HAB_TAP_POOL 7
 #define HAB_TAP_COMPRESSION 8
 #define HAB_TAP_LAYER1 9       /* 9..12: output of stage 1..4 */
+#define HAB_TAP_POOL_IDX 13    /* arch 1: arg-max bytes of the 3x3/2 max-pool, (B, Ho, Wo, C) uint8 = kh * 3 + kw (reinterpret the floats) */
 #define HAB_TAP_CONV_OUT 100   /* arch 1: 100 + k = normalised (+ReLU / +residual+ReLU) output of backbone conv k, k in build order:
                                 * per block its main-branch convs, then its downsample conv if it has one (resnet.py:37-69,116-152) */
 int hab_policy_tap(hab_policy* p, int which, const float** ptr, int64_t* floats);

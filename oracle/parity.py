@@ -80,6 +80,8 @@ class MaskInjector:
             self.eng_taps = resnet_relu_taps(eng, f"resnet{kw['backbone']}")
         else:
             self.eng_taps = [eng.tap(0), eng.tap(1)]  # HAB_TAP_CONV1 / CONV2 (ReLU outputs of SimpleCNN)
+        self.pool_idx = eng.tap(13).view(torch.uint8) if self.kind == "resnet" else None  # HAB_TAP_POOL_IDX
+        self.pool_diff = 0
         self.flips: Dict[str, list] = {}
         self.total = 0
         self.n_act = 0
@@ -113,6 +115,22 @@ class MaskInjector:
             self._patch(name, ev, ov)
         ov = fc.detach().view(T, k, -1).to(self.rin.device)
         self._patch("visual_fc", self.rin[:, c0:c0 + k, :self.hidden], ov)
+        if self.pool_idx is not None:
+            # the other discontinuity upstream of which weights sit (only the stem's): which element of a 3x3 window is the maximum.
+            # Near-ties within round-off resolve differently; the oracle's arg-max (ATen: first maximum in scan order) is written
+            # over the engine's arg-max bytes (kh * 3 + kw), the number of windows that differed is counted.
+            stem = taps["stem"].detach()
+            _, ind = torch.nn.functional.max_pool2d(stem, 3, 2, 1, return_indices=True)  # flat h * W + w of the input plane
+            Hs, Ws = stem.shape[2:]
+            Ho, Wo, C_ = ind.shape[2], ind.shape[3], ind.shape[1]
+            h, w = ind // Ws, ind % Ws
+            ho = torch.arange(Ho).view(1, 1, Ho, 1)
+            wo = torch.arange(Wo).view(1, 1, 1, Wo)
+            code = ((h - (ho * 2 - 1)) * 3 + (w - (wo * 2 - 1))).to(torch.uint8)
+            code = code.view(T, k, C_, Ho, Wo).permute(0, 1, 3, 4, 2).to(self.pool_idx.device)
+            ev = self.pool_idx[:T * n * Ho * Wo * C_].view(T, n, Ho, Wo, C_)[:, c0:c0 + k]
+            self.pool_diff += int((ev != code).sum())
+            ev.copy_(code)
 
 
 def minibatch_parity(policy, ppo, storage, batch, cfg, env_chunk: int = 4, with_grads: bool = True, inject_masks: bool = False) -> Dict[str, object]:
@@ -192,6 +210,7 @@ def minibatch_parity(policy, ppo, storage, batch, cfg, env_chunk: int = 4, with_
             per2 = errors(backward())
             rep["relu_mask_bits_differing"] = injector.total
             rep["relu_mask_bits_total"] = injector.n_act
+            rep["maxpool_argmax_differing"] = injector.pool_diff
             rep["relu_mask_flips_by_layer"] = {k: (v_[0], float(f"{v_[1]:.3e}")) for k, v_ in injector.flips.items()}
             rep["grad_max_rel_normwise_with_oracle_masks"] = max(v_[1] for v_ in per2.values())
             rep["grad_max_rel_elementwise_with_oracle_masks"] = max(v_[0] for v_ in per2.values())

@@ -196,7 +196,8 @@ def test_ddppo_real_engine_world2(workload):
     O.clip_grad_norm([g_avg], a["step_kwargs"]["max_grad_norm"])
     O.adam_step(p, g_avg, torch.zeros_like(p), torch.zeros_like(p), 1, a["lr"], 1e-5)
     upd_ref, upd_got = p - a["p_before"], a["p_after"] - a["p_before"]
-    assert float((upd_got - upd_ref).abs().max()) <= 1e-4 * float(upd_ref.abs().max()) + 1e-9
+    # (the update is read back as a difference of fp32 parameters: one ulp of the largest parameter is the floor)
+    assert float((upd_got - upd_ref).abs().max()) <= 1e-4 * float(upd_ref.abs().max()) + 2.4e-7 * max(1.0, float(p.abs().max()))
     # parameters after 2 full cycles: bit-identical across ranks
     assert torch.equal(a["p_final"], b["p_final"])
     assert a["steps_done"] == b["steps_done"] == 2 * 2 * 4 * 8 and a["losses"] == b["losses"]

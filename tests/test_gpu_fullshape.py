@@ -11,8 +11,8 @@ GroupNorm encoder.  The encoder's own weight gradients sit upstream of ~1e9 ReLU
 within fp32 round-off of zero and legitimately come out on the other side (two evaluations of the CPU oracle itself differ by
 2e-3 when ONE such bit flips: tests/test_oracle_golden.py::test_minibatch_chunked_equals_whole).  That is accounted for, not
 assumed: the mask bits on which engine and oracle disagree are counted (they must all belong to activations below 1e-4), the
-oracle's sign pattern is written over the engine's saved activations, the backward is repeated and every encoder gradient must then
-meet 3e-4 norm-wise.  The measured figures are written to gpurun_out/parity_<workload>.json."""
+oracle's sign pattern (and its max-pool arg-max, the one other discontinuity: near-tied window maxima) is written over the engine's
+saved activations, the backward is repeated and EVERY gradient must then meet 1e-4 norm-wise.  The measured figures are written to gpurun_out/parity_<workload>.json."""
 import json
 import os
 
@@ -68,13 +68,13 @@ def test_full_minibatch_at_benchmark_shape_vs_oracle(workload, frames):
         assert rep["rmv_max_rel"] <= 1e-5, rep["rmv_max_rel"]
     bad = []
     for k, (elem, normw) in per.items():
-        deep = workload == "c3" and ("backbone" in k)
+        deep = workload == "c3" and ("visual_encoder" in k)  # upstream of at least one of the ~1.5e9 ReLU decisions
         if normw > (3e-2 if deep else 1e-4):
             bad.append((k, elem, normw))
     assert not bad, bad
     # ReLU accounting: only activations within round-off of zero may disagree in sign, and with the oracle's signs in place ...
     assert all(mag < 1e-4 for _, mag in rep["relu_mask_flips_by_layer"].values()), rep["relu_mask_flips_by_layer"]
     assert rep["relu_mask_bits_differing"] <= 1e-5 * rep["relu_mask_bits_total"]
-    bad2 = [(k, e, nw) for k, (e, nw) in per2.items() if nw > (3e-4 if (workload == "c3" and "backbone" in k) else 1e-4)]
+    bad2 = [(k, e, nw) for k, (e, nw) in per2.items() if nw > 1e-4]
     assert not bad2, bad2  # ... every gradient agrees
     trainer.envs.close()
