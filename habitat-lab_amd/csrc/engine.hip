@@ -335,8 +335,8 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
                                    int hidden_env_stride, const uint8_t* masks, const int64_t* actions,
                                    const hab_pack_info* pack, int B, int n, float* value, float* log_prob, float* entropy,
                                    hipStream_t stream) {
-    if (!e || !e->P || !obs || !hidden0 || !masks || !actions || !pack || B <= 0 || n <= 0 || B > e->d.max_frames || B % n)
-        return HAB_ERR_ARG;
+    if (!e || !e->P || !obs || !hidden0 || !masks || !actions || !pack || B <= 0 || n <= 0 || B > e->d.max_frames) return HAB_ERR_ARG;
+    if (!pack->env_first_frame && (B % n)) return HAB_ERR_ARG;  // time-major T x n minibatch unless the pack info names the env frames
     if (pack->P != B || pack->F <= 0 || pack->F > B || pack->max_len <= 0) return HAB_ERR_ARG;
     float* W = e->WK;
     const int H = e->d.hidden, L = e->L;
@@ -352,10 +352,10 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
         float* cinit = W + e->w_cinit + (size_t)l * pk.F * H;
         // env j of the minibatch is frame j (t = 0); its arena row is rows[j]
         HAB_TRY(rnn_frag_init(hidden0 + (size_t)l * H, rows, hidden_env_stride, masks, rows, pk.frag_env, pk.frag_start, pk.F, H,
-                              hinit, stream));
+                              hinit, stream, pack->env_first_frame));
         if (e->d.rnn_type == HAB_RNN_LSTM)
             HAB_TRY(rnn_frag_init(hidden0 + (size_t)(L + l) * H, rows, hidden_env_stride, masks, rows, pk.frag_env,
-                                  pk.frag_start, pk.F, H, cinit, stream));
+                                  pk.frag_start, pk.F, H, cinit, stream, pack->env_first_frame));
         RnnLayerParams lp = layer_params(e, l);
         RnnWork wk = layer_work(e, l);
         Probe pr(e, HAB_PROBE_RNN_FWD, stream);
@@ -372,14 +372,14 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
     ha.probs = W + e->w_probs; ha.logits_n = W + e->w_logitsn;
     HAB_TRY(heads_forward(ha, stream));
     e->last_B = B;
-    e->last_n = n;
+    e->last_n = pack->env_first_frame ? 0 : n;  // (no "last n frames = final step of every env" in a VER minibatch)
     e->last_masks = masks;
     return HAB_OK;
 }
 
 // Final hidden state of the last evaluate: (n, Lh, H) -- rnn_state_encoder.py:262-275.
 extern "C" int hab_policy_final_hidden(hab_policy* e, float* hidden_out, hipStream_t stream) {
-    if (!e || !hidden_out || e->last_B <= 0) return HAB_ERR_ARG;
+    if (!e || !hidden_out || e->last_B <= 0 || e->last_n <= 0) return HAB_ERR_ARG;
     const int H = e->d.hidden, L = e->L, n = e->last_n, B = e->last_B;
     const int Lh = e->d.rnn_type == HAB_RNN_LSTM ? 2 * L : L;
     for (int l = 0; l < L; ++l) {

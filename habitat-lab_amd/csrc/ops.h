@@ -64,7 +64,8 @@ struct RnnWork {  // per-layer activations saved by the forward for BPTT; all [P
 };
 
 int rnn_frag_init(const float* h0, const int* env_rows, int env_stride, const uint8_t* masks, const int* mask_rows,
-                  const int* frag_env, const int* frag_start, int F, int H, float* hinit, hipStream_t stream);
+                  const int* frag_env, const int* frag_start, int F, int H, float* hinit, hipStream_t stream,
+                  const int* env_first = nullptr);
 int rnn_seq_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx,
                           const float* hinit, const float* cinit, const PackInfo& pk, float* ws, size_t ws_floats,
                           hipStream_t stream);

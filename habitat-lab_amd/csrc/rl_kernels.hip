@@ -352,13 +352,16 @@ __global__ void __launch_bounds__(1024) ppo_loss_kernel(const float* __restrict_
                                                         const float* __restrict__ returns, const int* __restrict__ rows, int B,
                                                         float clip, float value_coef, float entropy_coef, int clip_value,
                                                         float* __restrict__ d_value, float* __restrict__ d_logp,
-                                                        float* __restrict__ d_entropy, float* __restrict__ out) {
-    __shared__ float red[16][8];
-    __shared__ float redmm[16][4];
+                                                        float* __restrict__ d_entropy, float* __restrict__ out,
+                                                        const float* __restrict__ is_coeffs, const uint8_t* __restrict__ is_stale,
+                                                        const int64_t* __restrict__ policy_version, long long current_version) {
+    __shared__ float red[16][10];
+    __shared__ float redmm[16][8];
     const int tid = threadIdx.x;
     const float invB = 1.0f / (float)B;
-    float s_vl = 0, s_al = 0, s_en = 0, s_v = 0, s_r = 0, s_clip = 0;
+    float s_vl = 0, s_al = 0, s_en = 0, s_v = 0, s_r = 0, s_clip = 0, s_is = 0, s_stale = 0, s_pv = 0;
     float v_min = INFINITY, v_max = -INFINITY, r_min = INFINITY, r_max = -INFINITY;
+    float is_min = INFINITY, is_max = -INFINITY, pv_min = INFINITY, pv_max = -INFINITY;
     for (int f = tid; f < B; f += 1024) {
         const int g = rows ? rows[f] : f;
         const float v = values[f], lp = logp[f], en = entropy[f];
@@ -368,10 +371,13 @@ __global__ void __launch_bounds__(1024) ppo_loss_kernel(const float* __restrict_
         const float rc = fminf(fmaxf(ratio, lo), hi);
         const float s1 = a * ratio, s2 = a * rc;
         const float al = -fminf(s1, s2);
+        // VER importance weights (rl/ppo/ppo.py:226-231): every per-frame loss term is multiplied by min(is_coeffs, 1) before the mean
+        const float isc = is_coeffs ? is_coeffs[g] : 1.0f;
+        const float wf = fminf(isc, 1.0f);
         const bool inr = (ratio >= lo) && (ratio <= hi);
         // torch.min backward: ties split the gradient evenly; clamp backward passes inside [lo, hi]
         const float w = (s1 < s2) ? 1.0f : ((s1 == s2) ? (0.5f + (inr ? 0.5f : 0.0f)) : (inr ? 1.0f : 0.0f));
-        d_logp[f] = -a * w * ratio * invB;
+        d_logp[f] = -a * w * ratio * invB * wf;
         float vv = v;
         float dv = 0.0f;
         if (clip_value) {
@@ -384,29 +390,44 @@ __global__ void __launch_bounds__(1024) ppo_loss_kernel(const float* __restrict_
         }
         const float e = vv - ret;
         const float vl = 0.5f * (e * e);
-        d_value[f] = value_coef * dv * invB;
-        d_entropy[f] = -entropy_coef * invB;
-        s_vl += vl; s_al += al; s_en += en; s_v += v; s_r += ratio;
+        d_value[f] = value_coef * dv * invB * wf;
+        d_entropy[f] = -entropy_coef * invB * wf;
+        s_vl += wf * vl; s_al += wf * al; s_en += wf * en; s_v += v; s_r += ratio;
+        if (is_coeffs) { s_is += isc; is_min = fminf(is_min, isc); is_max = fmaxf(is_max, isc); }
+        if (is_stale) s_stale += is_stale[g] ? 1.0f : 0.0f;
+        if (policy_version) {
+            const float d = (float)(current_version - (long long)policy_version[g]);
+            s_pv += d; pv_min = fminf(pv_min, d); pv_max = fmaxf(pv_max, d);
+        }
         s_clip += ((ratio > hi) ? 1.0f : 0.0f) + ((ratio < lo) ? 1.0f : 0.0f);
         v_min = fminf(v_min, v); v_max = fmaxf(v_max, v); r_min = fminf(r_min, ratio); r_max = fmaxf(r_max, ratio);
     }
-    float sums[6] = {s_vl, s_al, s_en, s_v, s_r, s_clip};
+    float sums[9] = {s_vl, s_al, s_en, s_v, s_r, s_clip, s_is, s_stale, s_pv};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) sums[k] = wave_sum(sums[k]);
+    for (int k = 0; k < 9; ++k) sums[k] = wave_sum(sums[k]);
     v_min = wave_min(v_min); r_min = wave_min(r_min); v_max = wave_max(v_max); r_max = wave_max(r_max);
+    is_min = wave_min(is_min); is_max = wave_max(is_max); pv_min = wave_min(pv_min); pv_max = wave_max(pv_max);
     const int w = tid >> 6;
     if ((tid & 63) == 0) {
-        for (int k = 0; k < 6; ++k) red[w][k] = sums[k];
+        for (int k = 0; k < 9; ++k) red[w][k] = sums[k];
         redmm[w][0] = v_min; redmm[w][1] = v_max; redmm[w][2] = r_min; redmm[w][3] = r_max;
+        redmm[w][4] = is_min; redmm[w][5] = is_max; redmm[w][6] = pv_min; redmm[w][7] = pv_max;
     }
     __syncthreads();
     if (tid == 0) {
-        float t[6] = {0, 0, 0, 0, 0, 0};
+        float t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         float mn_v = INFINITY, mx_v = -INFINITY, mn_r = INFINITY, mx_r = -INFINITY;
+        float mn_i = INFINITY, mx_i = -INFINITY, mn_p = INFINITY, mx_p = -INFINITY;
         for (int i = 0; i < 16; ++i) {
-            for (int k = 0; k < 6; ++k) t[k] += red[i][k];
+            for (int k = 0; k < 9; ++k) t[k] += red[i][k];
             mn_v = fminf(mn_v, redmm[i][0]); mx_v = fmaxf(mx_v, redmm[i][1]);
             mn_r = fminf(mn_r, redmm[i][2]); mx_r = fmaxf(mx_r, redmm[i][3]);
+            mn_i = fminf(mn_i, redmm[i][4]); mx_i = fmaxf(mx_i, redmm[i][5]);
+            mn_p = fminf(mn_p, redmm[i][6]); mx_p = fmaxf(mx_p, redmm[i][7]);
+        }
+        if (is_coeffs || is_stale || policy_version) {  // VER learner metrics (ppo.py:262-263,285-299): out[13..19]
+            out[13] = mn_i; out[14] = t[6] * invB; out[15] = mx_i; out[16] = t[7] * invB;
+            out[17] = mn_p; out[18] = t[8] * invB; out[19] = mx_p;
         }
         const float vl = t[0] * invB, al = t[1] * invB, en = t[2] * invB;
         out[0] = vl; out[1] = al; out[2] = en;
@@ -426,7 +447,92 @@ extern "C" int hab_ppo_loss(const float* values, const float* logp, const float*
         return HAB_ERR_ARG;
     ppo_loss_kernel<<<1, 1024, 0, stream>>>(values, logp, entropy, old_logp, adv, old_values, returns, rows, B, clip_param,
                                             value_loss_coef, entropy_coef, use_clipped_value_loss, d_value, d_logp,
-                                            d_entropy, out12);
+                                            d_entropy, out12, nullptr, nullptr, nullptr, 0);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+extern "C" int hab_ppo_loss_ver(const float* values, const float* logp, const float* entropy, const float* old_logp,
+                                const float* adv, const float* old_values, const float* returns, const int* rows, int B,
+                                float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
+                                const float* is_coeffs, const uint8_t* is_stale, const int64_t* policy_version,
+                                int64_t current_policy_version, float* d_value, float* d_logp, float* d_entropy, float* out20,
+                                hipStream_t stream) {
+    if (B <= 0 || !values || !logp || !entropy || !old_logp || !adv || !old_values || !returns || !d_value || !d_logp ||
+        !d_entropy || !out20)
+        return HAB_ERR_ARG;
+    ppo_loss_kernel<<<1, 1024, 0, stream>>>(values, logp, entropy, old_logp, adv, old_values, returns, rows, B, clip_param,
+                                            value_loss_coef, entropy_coef, use_clipped_value_loss, d_value, d_logp,
+                                            d_entropy, out20, is_coeffs, is_stale, policy_version, (long long)current_policy_version);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// VER: returns over a LINEAR buffer of steps grouped into sequences (episode fragments), rl/ver/ver_rollout_storage.py:430-568.
+// One lane per sequence walks its steps backwards (sequence i, step s lives at buffer index select_inds[step_offset[s] + i]).
+// The reference runs this recursion in numpy float64 on float32 inputs and rounds the result to float32 on assignment: same
+// here.  gae restarts from 0 and bootstraps from 0 at every sequence end, except that the LAST step of the last sequence of an
+// environment is the bootstrap step itself: its return is NaN (marks "not a training step") and its value seeds last_value.
+// A step keeps its previous return when it is stale and that return is finite.
+// ------------------------------------------------------------------------------------------
+__global__ void ver_returns_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
+                                   const uint8_t* __restrict__ is_stale, float* __restrict__ returns,
+                                   const int* __restrict__ select_inds, const int* __restrict__ step_offsets,
+                                   const int* __restrict__ seq_len, const uint8_t* __restrict__ last_seq_mask, int F, double gamma,
+                                   double tau_gamma) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    const int len = seq_len[i];
+    const bool last_for_env = last_seq_mask[i] != 0;
+    double gae = 0.0, last_value = 0.0;
+    for (int s = len - 1; s >= 0; --s) {
+        const int b = select_inds[step_offsets[s] + i];
+        const double v = (double)values[b];
+        const double q_est = (double)rewards[b] + gamma * last_value;
+        const double delta = q_est - v;
+        gae = delta + tau_gamma * gae;
+        const bool boot = last_for_env && (s == len - 1);
+        if (boot) gae = 0.0;
+        const float old = returns[b];
+        if (!is_stale[b] || !isfinite(old)) returns[b] = (float)(gae + v);
+        if (boot) returns[b] = __builtin_nanf("");
+        last_value = v;
+    }
+}
+
+extern "C" int hab_ver_compute_returns(const float* rewards, const float* value_preds, const uint8_t* is_stale, float* returns,
+                                       const int32_t* select_inds, const int32_t* step_offsets, const int32_t* sequence_lengths,
+                                       const uint8_t* last_sequence_in_batch_mask, int F, double gamma, double tau,
+                                       hipStream_t stream) {
+    if (!rewards || !value_preds || !is_stale || !returns || !select_inds || !step_offsets || !sequence_lengths ||
+        !last_sequence_in_batch_mask || F <= 0)
+        return HAB_ERR_ARG;
+    ver_returns_kernel<<<cdiv(F, 64), 64, 0, stream>>>(rewards, value_preds, is_stale, returns, select_inds, step_offsets, sequence_lengths,
+                                                       last_sequence_in_batch_mask, F, gamma, tau * gamma);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// VER importance-sampling coefficients (ver_rollout_storage.py:399-428): steps per environment are counted over the whole buffer,
+// is_coeffs[b] = (num_steps + 1) / count[environment_ids[b]]  (fp32 division, as torch does).  counts: num_envs ints of scratch.
+__global__ void ver_count_kernel(const int64_t* __restrict__ env_ids, int n, int num_envs, int* __restrict__ counts) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) { const int64_t e = env_ids[b]; if (e >= 0 && e < num_envs) atomicAdd(counts + e, 1); }
+}
+__global__ void ver_is_coeffs_kernel(const int64_t* __restrict__ env_ids, int n, int num_envs, const int* __restrict__ counts,
+                                     float per_env, float* __restrict__ is_coeffs) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) { const int64_t e = env_ids[b]; is_coeffs[b] = (e >= 0 && e < num_envs) ? per_env / (float)counts[e] : 1.0f; }
+}
+extern "C" int hab_ver_is_coeffs(const int64_t* environment_ids, int n, int num_envs, int num_steps, int32_t* counts_scratch,
+                                 float* is_coeffs, hipStream_t stream) {
+    if (!environment_ids || !counts_scratch || !is_coeffs || n <= 0 || num_envs <= 0) return HAB_ERR_ARG;
+    hipError_t e = hipMemsetAsync(counts_scratch, 0, sizeof(int32_t) * num_envs, stream);
+    if (e != hipSuccess) return (int)e;
+    ver_count_kernel<<<cdiv(n, 256), 256, 0, stream>>>(environment_ids, n, num_envs, counts_scratch);
+    HAB_LAUNCH_CHECK();
+    ver_is_coeffs_kernel<<<cdiv(n, 256), 256, 0, stream>>>(environment_ids, n, num_envs, counts_scratch, (float)(num_steps + 1), is_coeffs);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }

@@ -25,20 +25,21 @@ constexpr int RNN_GRU = 0, RNN_LSTM = 1;
 __global__ void rnn_frag_init_kernel(const float* __restrict__ h0, const int* __restrict__ env_rows, int env_stride,
                                      const uint8_t* __restrict__ masks, const int* __restrict__ mask_rows,
                                      const int* __restrict__ frag_env, const int* __restrict__ frag_start, int F, int H,
-                                     float* __restrict__ hinit) {
+                                     float* __restrict__ hinit, const int* __restrict__ env_first) {
     const int q = blockIdx.x;
     if (q >= F) return;
     const int f = frag_start ? frag_start[q] : q;
-    const int e = frag_env ? frag_env[q] : q;
+    int e = frag_env ? frag_env[q] : q;
+    if (env_first) e = env_first[e];  // VER minibatch: the frame that holds batch environment e's stored hidden state
     const bool keep = masks[mask_rows ? mask_rows[f] : f] != 0;
     const float* src = h0 + (size_t)(env_rows ? env_rows[e] : e) * env_stride;
     for (int u = threadIdx.x; u < H; u += blockDim.x) hinit[(size_t)q * H + u] = keep ? src[u] : 0.f;
 }
 
 int rnn_frag_init(const float* h0, const int* env_rows, int env_stride, const uint8_t* masks, const int* mask_rows,
-                  const int* frag_env, const int* frag_start, int F, int H, float* hinit, hipStream_t stream) {
+                  const int* frag_env, const int* frag_start, int F, int H, float* hinit, hipStream_t stream, const int* env_first) {
     if (!h0 || !masks || !hinit || F <= 0 || H <= 0) return HAB_ERR_ARG;
-    rnn_frag_init_kernel<<<F, 128, 0, stream>>>(h0, env_rows, env_stride, masks, mask_rows, frag_env, frag_start, F, H, hinit);
+    rnn_frag_init_kernel<<<F, 128, 0, stream>>>(h0, env_rows, env_stride, masks, mask_rows, frag_env, frag_start, F, H, hinit, env_first);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }

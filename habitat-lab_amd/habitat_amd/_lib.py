@@ -39,7 +39,7 @@ class EmbedSlot(C.Structure):
 
 class PackInfo(C.Structure):
     _fields_ = [("select_inds", vp), ("frag_env", vp), ("frag_start", vp), ("step_offsets_host", vp),
-                ("num_seqs_at_step_host", vp), ("P", c_int32), ("F", c_int32), ("max_len", c_int32)]
+                ("num_seqs_at_step_host", vp), ("P", c_int32), ("F", c_int32), ("max_len", c_int32), ("env_first_frame", vp)]
 
 
 # name -> (restype, argtypes).  Every symbol of include/habitat_amd.h appears here; tests/test_capi.py
@@ -54,6 +54,10 @@ SIGNATURES = {
     "hab_compute_returns": (c_int, [vp, vp, vp, vp, vp, c_int, c_int, c_float, c_float, c_int, c_int, vp]),
     "hab_advantages": (c_int, [vp, vp, vp, c_int, c_int, vp, vp, vp]),
     "hab_ppo_loss": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_float, c_float, c_float, c_int, vp, vp, vp, vp, vp]),
+    "hab_ppo_loss_ver": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_float, c_float, c_float, c_int, vp, vp, vp, c_int64, vp, vp, vp,
+                                 vp, vp]),
+    "hab_ver_compute_returns": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_double, c_double, vp]),
+    "hab_ver_is_coeffs": (c_int, [vp, c_int, c_int, c_int, vp, vp, vp]),
     "hab_clip_adam_step": (c_int, [vp, vp, vp, vp, c_size_t, vp, c_int, c_float, c_float, c_float, c_float, c_float,
                                    c_float, c_int, vp, vp]),
     "hab_sample_actions": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
@@ -80,6 +84,7 @@ SIGNATURES = {
     "hab_nav_embed_fwd": (c_int, [POINTER(EmbedSlot), c_int, vp, vp, vp, c_int, c_int, c_int, vp, vp]),
     "hab_nav_embed_bwd": (c_int, [POINTER(EmbedSlot), c_int, vp, vp, c_int, c_int, c_int, vp, c_size_t, vp]),
     "hab_build_pack_info": (c_int, [vp, c_int, c_int] + [vp] * 12),
+    "hab_build_pack_info_from_ids": (c_int, [vp, vp, vp, c_int] + [vp] * 11),
     "hab_policy_create": (c_int, [POINTER(PolicyDesc), POINTER(vp)]),
     "hab_policy_destroy": (None, [vp]),
     "hab_policy_num_params": (c_int, [vp]),

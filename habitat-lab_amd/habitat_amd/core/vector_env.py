@@ -236,6 +236,33 @@ class VectorEnv:
         self._waiting[index_env] = False
         return self._obs_of(index_env, obs), reward, done, info
 
+    def poll_steps(self, timeout: float = 0.0, max_messages: Optional[int] = None) -> List[Tuple[int, Tuple[Any, float, bool, dict]]]:
+        """Non-blocking counterpart of wait_step_at for ANY environment (VER's inference queue, rl/ver/inference_worker.py:458-470):
+        results of the outstanding steps that have arrived within `timeout` seconds, as (index_env, (obs, reward, done, info))."""
+        from multiprocessing.connection import wait
+        pending = {self._conns[i]: i for i in range(len(self._conns)) if self._waiting[i]}
+        if not pending:
+            return []
+        out = []
+        for conn in wait(list(pending.keys()), timeout):
+            i = pending[conn]
+            obs, reward, done, info = conn.recv()
+            self._waiting[i] = False
+            out.append((i, (self._obs_of(i, obs), reward, done, info)))
+            if max_messages is not None and len(out) >= max_messages:
+                break
+        return out
+
+    def gather_obs(self, env_indices: Sequence[int], device) -> Dict[str, Any]:
+        """Observations of an arbitrary list of environments (whose steps have been received) as device tensors: one gather per
+        slab sensor on the host, one upload."""
+        import torch
+        assert self._slabs and not self._paused
+        rows = [self._rows[i] for i in env_indices]
+        dev = torch.device(device)
+        return {k: torch.from_numpy(self._slabs[k][rows]).to(dev, non_blocking=False) for k in
+                sorted(self._slabs, key=lambda k: -self._slabs[k][0].nbytes)}
+
     def step_at(self, index_env: int, action):
         self.async_step_at(index_env, action)
         return self.wait_step_at(index_env)

@@ -21,6 +21,39 @@ class DevicePackInfo:
     """build_pack_info_from_dones (rl/models/rnn_state_encoder.py:155-168) through the C++ host builder,
     plus int32 device copies for the kernels."""
 
+    env_first = None  # set by from_ids: first_step_for_env (frames in any order)
+
+    @classmethod
+    def from_ids(cls, episode_ids: np.ndarray, environment_ids: np.ndarray, step_ids: np.ndarray, device=None) -> "DevicePackInfo":
+        """build_pack_info_from_episode_ids (rnn_state_encoder.py:35-150) for P frames in ANY order -- a VER minibatch
+        (rl/ver/ver_rollout_storage.py:586-617)."""
+        self = cls.__new__(cls)
+        ep, env, st = (np.ascontiguousarray(a, dtype=np.int64).reshape(-1) for a in (episode_ids, environment_ids, step_ids))
+        P = ep.size
+        a = {"select_inds": np.empty(P, np.int64), "num_seqs_at_step": np.empty(P, np.int64), "sequence_starts": np.empty(P, np.int64),
+             "sequence_lengths": np.empty(P, np.int64), "rnn_state_batch_inds": np.empty(P, np.int64),
+             "last_sequence_in_batch_mask": np.zeros(P, np.uint8), "first_sequence_in_batch_mask": np.zeros(P, np.uint8),
+             "first_step_for_env": np.empty(P, np.int64)}
+        nf, ml, ne = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(_lib.lib().hab_build_pack_info_from_ids(ep.ctypes.data, env.ctypes.data, st.ctypes.data, P, *[v.ctypes.data for v in a.values()],
+                                                      C.byref(nf), C.byref(ml), C.byref(ne)), "hab_build_pack_info_from_ids")
+        F, max_len, n = nf.value, ml.value, ne.value
+        self.T, self.N, self.P, self.F, self.max_len = None, n, P, F, max_len
+        last, first = a["last_sequence_in_batch_mask"][:F].astype(bool), a["first_sequence_in_batch_mask"][:F].astype(bool)
+        self.arrays = {"select_inds": a["select_inds"], "num_seqs_at_step": a["num_seqs_at_step"][:max_len],
+                       "sequence_starts": a["sequence_starts"][:F], "sequence_lengths": a["sequence_lengths"][:F],
+                       "rnn_state_batch_inds": a["rnn_state_batch_inds"][:F], "last_sequence_in_batch_mask": last,
+                       "first_sequence_in_batch_mask": first, "last_sequence_in_batch_inds": np.nonzero(last)[0],
+                       "first_episode_in_batch_inds": np.nonzero(first)[0], "first_step_for_env": a["first_step_for_env"][:n]}
+        self.env_first = np.ascontiguousarray(self.arrays["first_step_for_env"], dtype=np.int32)
+        self._nseq = np.ascontiguousarray(self.arrays["num_seqs_at_step"], dtype=np.int32)
+        self._off = np.zeros(max_len + 1, np.int32)
+        self._off[1:] = np.cumsum(self._nseq)
+        self.struct = None
+        if device is not None:
+            self.to(device)
+        return self
+
     def __init__(self, dones: np.ndarray, device=None):
         dones = np.ascontiguousarray(dones, dtype=np.uint8)
         T, N = dones.shape
@@ -55,8 +88,10 @@ class DevicePackInfo:
             self.to(device)
 
     def to(self, device):
-        packed = np.concatenate([self.arrays["select_inds"], self.arrays["rnn_state_batch_inds"],
-                                 self.arrays["sequence_starts"]]).astype(np.int32)
+        parts = [self.arrays["select_inds"], self.arrays["rnn_state_batch_inds"], self.arrays["sequence_starts"]]
+        if self.env_first is not None:
+            parts.append(self.env_first)
+        packed = np.concatenate(parts).astype(np.int32)
         self._dev = torch.from_numpy(packed).to(device, non_blocking=True)
         P, F = self.P, self.F
         s = PackInfo()
@@ -64,6 +99,7 @@ class DevicePackInfo:
         s.select_inds = base
         s.frag_env = base + 4 * P
         s.frag_start = base + 4 * (P + F)
+        s.env_first_frame = (base + 4 * (P + 2 * F)) if self.env_first is not None else None
         s.step_offsets_host = self._off.ctypes.data
         s.num_seqs_at_step_host = self._nseq.ctypes.data
         s.P, s.F, s.max_len = P, F, self.max_len

@@ -24,6 +24,10 @@ from habitat_amd.common.rollout_storage import MiniBatch, RolloutStorage
 EPS_PPO = 1e-5
 METRIC_KEYS = ["value_loss", "action_loss", "dist_entropy", "_total", "value_pred_min", "value_pred_mean", "value_pred_max",
                "prob_ratio_min", "prob_ratio_mean", "prob_ratio_max", "ppo_fraction_clipped", "_B"]
+# VER learner statistics (rl/ppo/ppo.py:262-263,285-299), slots 13..19 of a minibatch's metric row
+VER_METRIC_KEYS = {13: "ver_is_coeffs_min", 14: "ver_is_coeffs_mean", 15: "ver_is_coeffs_max", 16: "fraction_stale",
+                   17: "policy_version_difference_min", 18: "policy_version_difference_mean", 19: "policy_version_difference_max"}
+SLOT_WIDTH = 24
 
 
 class Updater:
@@ -229,14 +233,23 @@ class PPO(nn.Module, Updater):
         rgb, depth = obs.get("rgb"), obs.get("depth")
         goal = obs.get("pointgoal_with_gps_compass")
         extra = {k: obs[k] for k in ("semantic", "objectgoal", "compass", "gps", "visual_features") if k in obs}
-        Bn, n = batch.T * batch.n, batch.n
+        ver = "policy_version" in Bf  # VERRolloutStorage: slots of a linear buffer, importance weights, staleness statistics
+        Bn, n = (batch.B, batch.n) if ver and hasattr(batch, "B") else (batch.T * batch.n, batch.n)
         w = self._work(Bn)
         eng.evaluate(rgb, depth, goal, batch.rows, Bf["recurrent_hidden_states"], Bf["masks"], Bf["actions"], batch.pack, Bn, n,
                      value=w["v"], log_prob=w["lp"], entropy=w["ent"], prev_actions=Bf["prev_actions"], extra=extra)
-        check(L.hab_ppo_loss(ptr(w["v"]), ptr(w["lp"]), ptr(w["ent"]), ptr(Bf["action_log_probs"]), ptr(batch.advantages_full),
-                             ptr(Bf["value_preds"]), ptr(Bf["returns"]), ptr(batch.rows), Bn, float(self.clip_param),
-                             float(self.value_loss_coef), float(self.entropy_coef), int(self.use_clipped_value_loss),
-                             ptr(w["dv"]), ptr(w["dlp"]), ptr(w["dent"]), ptr(slot), stream_ptr()), "hab_ppo_loss")
+        if ver:
+            check(L.hab_ppo_loss_ver(ptr(w["v"]), ptr(w["lp"]), ptr(w["ent"]), ptr(Bf["action_log_probs"]), ptr(batch.advantages_full),
+                                     ptr(Bf["value_preds"]), ptr(Bf["returns"]), ptr(batch.rows), Bn, float(self.clip_param),
+                                     float(self.value_loss_coef), float(self.entropy_coef), int(self.use_clipped_value_loss),
+                                     ptr(Bf.get("is_coeffs")), ptr(Bf["is_stale"]), ptr(Bf["policy_version"]),
+                                     int(st.cpu_current_policy_version[0, 0]), ptr(w["dv"]), ptr(w["dlp"]), ptr(w["dent"]), ptr(slot),
+                                     stream_ptr()), "hab_ppo_loss_ver")
+        else:
+            check(L.hab_ppo_loss(ptr(w["v"]), ptr(w["lp"]), ptr(w["ent"]), ptr(Bf["action_log_probs"]), ptr(batch.advantages_full),
+                                 ptr(Bf["value_preds"]), ptr(Bf["returns"]), ptr(batch.rows), Bn, float(self.clip_param),
+                                 float(self.value_loss_coef), float(self.entropy_coef), int(self.use_clipped_value_loss),
+                                 ptr(w["dv"]), ptr(w["dlp"]), ptr(w["dent"]), ptr(slot), stream_ptr()), "hab_ppo_loss")
         eng.backward(rgb, depth, goal, batch.rows, Bf["actions"], batch.pack, w["dv"], w["dlp"], w["dent"],
                      prev_actions=Bf["prev_actions"], extra=extra)
         self.before_step()
@@ -252,7 +265,7 @@ class PPO(nn.Module, Updater):
     def update(self, rollouts: RolloutStorage) -> Dict[str, float]:
         advantages = self.get_advantages(rollouts)
         nmb = self.ppo_epoch * self.num_mini_batch
-        slots = torch.zeros(nmb + 1, 16, device=self.device)
+        slots = torch.zeros(nmb + 1, SLOT_WIDTH, device=self.device)
         k = 0
         last_epoch_slots = []
         for epoch in range(self.ppo_epoch):
@@ -272,6 +285,11 @@ class PPO(nn.Module, Updater):
             rows = last_epoch_slots if name == "ppo_fraction_clipped" else list(range(k))
             out[name] = float(host[rows, i].mean())
         out["grad_norm"] = float(host[:, 12].mean())
+        if "policy_version" in rollouts.buffers:
+            for i, name in VER_METRIC_KEYS.items():
+                if name.startswith("ver_is_coeffs") and "is_coeffs" not in rollouts.buffers:
+                    continue
+                out[name] = float(host[:, i].mean())
         return out
 
     # ---- hooks kept for subclass compatibility (ppo.py:341-375) ---------------------------------------

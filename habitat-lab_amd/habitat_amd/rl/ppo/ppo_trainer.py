@@ -39,6 +39,7 @@ from habitat_amd.utils.timing import g_timer
 import habitat_amd.rl.ddppo  # noqa: F401  (registers DDPPO)
 import habitat_amd.rl.ppo  # noqa: F401  (registers policies / PPO)
 import habitat_amd.rl.ppo.single_agent_access_mgr  # noqa: F401
+import habitat_amd.rl.ver  # noqa: F401  (registers VERRolloutStorage)
 
 
 def batch_obs(observations, device):

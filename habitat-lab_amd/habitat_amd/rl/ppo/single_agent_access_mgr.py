@@ -92,17 +92,22 @@ class SingleAgentAccessMgr:
     def _create_storage(self, num_envs, env_spec, actor_critic, policy_action_space, config, device):
         cls = baseline_registry.get_storage(config.habitat_baselines.rollout_storage_name)
         ppo = config.habitat_baselines.rl.ppo
+        obs_space = self.rollout_obs_space(env_spec, actor_critic)
+        st = cls(numsteps=ppo.num_steps, num_envs=num_envs, observation_space=obs_space,
+                 action_space=policy_action_space, actor_critic=actor_critic, is_double_buffered=ppo.use_double_buffered_sampler)
+        st.to(device)
+        return st
+
+    def rollout_obs_space(self, env_spec, actor_critic):
+        """get_rollout_obs_space (single_agent_access_mgr.py:300-319): a frozen encoder's output is stored next to the sensors."""
         obs_space = env_spec.observation_space
-        if self._is_static_encoder:  # get_rollout_obs_space (single_agent_access_mgr.py:300-319)
+        if self._is_static_encoder:
             from habitat_amd.common import spaces
             from habitat_amd.rl.ppo.policy import VISUAL_FEATURES_KEY
             lim = float(np.finfo(np.float32).max)
             obs_space = spaces.Dict({VISUAL_FEATURES_KEY: spaces.Box(-lim, lim, tuple(actor_critic.visual_encoder.output_shape), np.float32),
                                      **obs_space.spaces})
-        st = cls(numsteps=ppo.num_steps, num_envs=num_envs, observation_space=obs_space,
-                 action_space=policy_action_space, actor_critic=actor_critic, is_double_buffered=ppo.use_double_buffered_sampler)
-        st.to(device)
-        return st
+        return obs_space
 
     def post_init(self, create_rollouts_fn: Optional[Callable] = None) -> None:
         create = create_rollouts_fn or self._create_storage

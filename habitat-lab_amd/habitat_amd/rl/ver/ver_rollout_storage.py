@@ -1,0 +1,330 @@
+"""VERRolloutStorage: rollout arena for Variable Experience Rollouts (habitat_baselines/rl/ver/ver_rollout_storage.py:122-620).
+
+With `variable_experience` the arena is ONE linear buffer of (num_steps + 1) * num_envs step slots (the reference flattens the
+(T+1, N) buffers, :233-238): a rollout collects a fixed NUMBER of steps, however they are spread over the environments, so fast
+environments contribute more steps than slow ones.  Every slot carries (environment id, episode id, step id, policy version);
+sequences are recovered from those ids, not from the slot position.
+
+What runs on the device here (the reference does all of it in numpy on the host after three device->host copies, :430-470):
+  * compute_returns: one launch of `hab_ver_compute_returns` -- one lane per sequence walks its steps backwards in float64, as the
+    numpy loop does (bit-identical returns);
+  * after_rollout: `hab_ver_is_coeffs` (per-environment step counts -> importance coefficients);
+  * minibatches are NOT gathered: `VERMiniBatch` carries the slot indices (`rows`) and the pack info built from the ids of those
+    slots (`DevicePackInfo.from_ids`), the policy engine gathers through `rows`.
+The index bookkeeping (which slot is written next, which slots survive an update, sequence structure) is host-side integer logic
+with the same definitions as the reference."""
+from __future__ import annotations
+
+from typing import Any, Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from habitat_amd import _lib
+from habitat_amd._lib import check, ptr, stream_ptr
+from habitat_amd.common.baseline_registry import baseline_registry
+from habitat_amd.common.rollout_storage import _LAZY, RolloutStorage
+from habitat_amd.common.tensor_dict import TensorDict
+from habitat_amd.engine import DevicePackInfo
+
+
+def unique_in_order_of_appearance(arr: np.ndarray) -> np.ndarray:
+    vals, first = np.unique(arr, return_index=True)
+    return vals[np.argsort(first)]
+
+
+def compute_movements_for_aliased_swaps(dst_locations: np.ndarray, src_locations: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """(dst, src) such that `t[dst] = t[src]` moves every src slot to its dst slot AND parks the displaced dst contents in the slots
+    that were vacated (ver_rollout_storage.py:31-63): dst = dst_locations followed by the src slots that are not destinations, src =
+    src_locations followed by the destination slots that are not sources."""
+    assert len(dst_locations) == len(src_locations)
+    swap_dst = unique_in_order_of_appearance(np.concatenate((dst_locations, src_locations)))
+    swap_src = unique_in_order_of_appearance(np.concatenate((src_locations, dst_locations)))
+    assert len(swap_dst) == len(swap_src)
+    return swap_dst, swap_src
+
+
+def partition_n_into_p(n: int, p: int) -> List[int]:
+    return [n // p + (1 if i < n % p else 0) for i in range(p)]
+
+
+def pack_info_from_ids_np(episode_ids: np.ndarray, environment_ids: np.ndarray, step_ids: np.ndarray) -> Dict[str, np.ndarray]:
+    """build_pack_info_from_episode_ids (rl/models/rnn_state_encoder.py:35-150) for the WHOLE buffer, in numpy with the reference's
+    own sort calls so that equal-length sequences come out in the same order (the minibatch composition depends on it)."""
+    ep = episode_ids * (environment_ids.max() + 1) + environment_ids  # globally unique episode key
+    order = np.argsort(ep * (step_ids.max() + 1) + step_ids)
+    keys, lengths = np.unique(ep[order], return_counts=True)
+    starts = np.cumsum(lengths) - lengths
+    by_len = np.argsort(-lengths)
+    lengths, starts = lengths[by_len], starts[by_len]
+    max_len = int(lengths[0])
+    num_seqs_at_step = (lengths[None, :] > np.arange(max_len)[:, None]).sum(1).astype(np.int64)
+    select = np.concatenate([starts[:num_seqs_at_step[s]] + s for s in range(max_len)])
+    select_inds = order[select]
+    sequence_starts = select_inds[:num_seqs_at_step[0]]
+    seq_env = environment_ids[sequence_starts]
+    seq_ep = ep[sequence_starts]
+    last = np.zeros(len(sequence_starts), dtype=bool)
+    for e in np.unique(seq_env):
+        m = seq_env == e
+        last[m] = seq_ep[m] == seq_ep[m].max()
+    return dict(select_inds=select_inds, num_seqs_at_step=num_seqs_at_step, sequence_lengths=lengths, sequence_starts=sequence_starts,
+                last_sequence_in_batch_mask=last)
+
+
+def generate_ver_mini_batches(num_mini_batch: int, sequence_lengths: np.ndarray, num_seqs_at_step: np.ndarray, select_inds: np.ndarray,
+                              last_sequence_in_batch_mask: np.ndarray, episode_ids: np.ndarray) -> Iterator[np.ndarray]:
+    """Sequences in random order, their steps concatenated and cut into `num_mini_batch` equal parts, parts yielded in random order
+    (ver_rollout_storage.py:71-119; two draws from numpy's global generator, in that order).  The bootstrap step of every
+    environment (last step of its last sequence) is not a training step."""
+    lengths = sequence_lengths.copy()
+    lengths[last_sequence_in_batch_mask] -= 1
+    step_offsets = np.cumsum(num_seqs_at_step, dtype=np.int64) - num_seqs_at_step
+    seq_order = np.random.permutation(len(lengths))
+    steps_of = [select_inds[i + step_offsets[:lengths[i]]] for i in range(len(lengths))]
+    all_steps = np.concatenate([steps_of[q] for q in seq_order])
+    sizes = np.array(partition_n_into_p(int(lengths.sum()), num_mini_batch), dtype=np.int64)
+    begins = np.cumsum(sizes) - sizes
+    for mb in np.random.permutation(num_mini_batch):
+        yield all_steps[begins[mb]:begins[mb] + sizes[mb]]
+
+
+class VERMiniBatch(dict):
+    """Slots `inds` of the linear buffer.  Zero-copy for the fused updater (`rows`, `pack`); dict-style access materialises
+    reference-style gathered tensors (`recurrent_hidden_states` = the hidden state of each environment's first step in the batch,
+    ver_rollout_storage.py:606-614)."""
+
+    def __init__(self, storage: "VERRolloutStorage", inds: np.ndarray, advantages: Optional[torch.Tensor]):
+        super().__init__()
+        self.storage, self.advantages_full = storage, advantages
+        self.inds_cpu = torch.from_numpy(np.ascontiguousarray(inds, dtype=np.int64))
+        self.rows = self.inds_cpu.to(torch.int32).to(storage.device, non_blocking=True)
+        self.B = len(inds)
+        self.pack = DevicePackInfo.from_ids(storage.episode_ids_cpu[inds], storage.environment_ids_cpu[inds], storage.step_ids_cpu[inds],
+                                            storage.device)
+        self.n = self.pack.N
+
+    def __missing__(self, key):
+        if key not in _LAZY + ("is_coeffs", "is_stale", "policy_version", "episode_ids", "environment_ids", "step_ids"):
+            raise KeyError(key)
+        b, idx = self.storage.buffers, self.inds_cpu.to(self.storage.device)
+        if key == "advantages":
+            v = self.advantages_full[idx]
+        elif key == "rnn_build_seq_info":
+            v = TensorDict()
+            for k, arr in self.pack.arrays.items():
+                t = torch.from_numpy(np.ascontiguousarray(arr))
+                dict.__setitem__(v, f"cpu_{k}", t)
+                dict.__setitem__(v, k, t.to(self.storage.device))
+        elif key == "recurrent_hidden_states":
+            first = torch.from_numpy(np.ascontiguousarray(self.pack.arrays["first_step_for_env"])).to(self.storage.device)
+            v = b[key][idx].index_select(0, first)
+        elif key == "observations":
+            v = b[key][idx]
+        else:
+            if key not in b:
+                raise KeyError(key)
+            v = b[key][idx]
+        dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in _LAZY or key in self.storage.buffers
+
+    def to_tree(self):
+        return self
+
+
+@baseline_registry.register_storage
+class VERRolloutStorage(RolloutStorage):
+    r"""Rollout storage for VER."""
+
+    def __init__(self, numsteps, num_envs, observation_space, action_space, actor_critic, variable_experience: bool,
+                 is_double_buffered: bool = False, device=None):
+        super().__init__(numsteps, num_envs, observation_space, action_space, actor_critic, is_double_buffered, device=device)
+        dev = self.device
+        B = self.buffers
+        self.use_is_coeffs = variable_experience
+        self.variable_experience = variable_experience
+        ret = B["returns"]
+        if self.use_is_coeffs:
+            dict.__setitem__(B, "is_coeffs", torch.ones_like(ret))
+        for k in ("policy_version", "environment_ids", "episode_ids", "step_ids"):
+            dict.__setitem__(B, k, torch.zeros_like(ret, dtype=torch.int64))
+        dict.__setitem__(B, "is_stale", torch.ones_like(ret, dtype=torch.bool))
+        self.buffer_size = (self.num_steps + 1) * self._num_envs
+        # device-side state the inference worker reads / writes (ver_rollout_storage.py:186-201)
+        self.next_hidden_states = B["recurrent_hidden_states"][0].clone()
+        self.next_prev_actions = B["prev_actions"][0].clone()
+        self.current_policy_version = torch.ones((1, 1), dtype=torch.int64, device=dev)
+        # host-side bookkeeping (:203-227)
+        self.cpu_current_policy_version = np.ones((1, 1), dtype=np.int64)
+        self.num_steps_collected = np.zeros((1,), dtype=np.int64)
+        self.rollout_done = np.zeros((1,), dtype=bool)
+        self.current_steps = np.zeros((num_envs,), dtype=np.int64)
+        self.actor_steps_collected = np.zeros((num_envs,), dtype=np.int64)
+        self.ptr = np.zeros((1,), dtype=np.int64)
+        self.prev_inds = np.full((num_envs,), -1, dtype=np.int64)
+        self._first_rollout = np.full((1,), True, dtype=bool)
+        self.will_replay_step = np.zeros((num_envs,), dtype=bool)
+        if self.variable_experience:
+            self.buffers.map_in_place(lambda t: t.flatten(0, 1))  # (T+1, N, ...) -> ((T+1)*N, ...): a linear buffer of step slots
+        self._counts = torch.zeros(num_envs, dtype=torch.int32, device=dev)
+        self._pack_dev = None
+
+    @property
+    def num_steps_to_collect(self) -> int:
+        return self.buffer_size if self._first_rollout else self._num_envs * self.num_steps
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.device:
+            return
+        super().to(device)
+        self.next_hidden_states = self.next_hidden_states.to(device)
+        self.next_prev_actions = self.next_prev_actions.to(device)
+        self.current_policy_version = self.current_policy_version.to(device)
+        self._counts = self._counts.to(device)
+
+    # ---- between rollouts (:278-365) -----------------------------------------------------------------------------------------
+    def after_update(self):
+        self.current_steps[:] = 1
+        self.current_steps[self.will_replay_step] -= 1
+        B = self.buffers
+        B["is_stale"].fill_(True)
+        if not self.variable_experience:
+            assert np.all(self.will_replay_step)
+            self.next_hidden_states[:] = B["recurrent_hidden_states"][-1]
+            self.next_prev_actions[:] = B["prev_actions"][-1]
+        else:
+            # Environments whose action is still in flight keep their previous step (its reward arrives during the next rollout):
+            # those slots move to the front, [0, n_in_flight).  Environments that will REPLAY their last step (re-run inference
+            # with the new policy) go right behind them, where the next rollout overwrites them first.
+            in_flight = np.logical_not(self.will_replay_step)
+            n_in_flight = int(np.count_nonzero(in_flight))
+            keep_first = np.concatenate((self.prev_inds[in_flight], self.prev_inds[np.logical_not(in_flight)]))
+            dst, src = compute_movements_for_aliased_swaps(np.arange(len(keep_first)), keep_first)
+            dst_t, src_t = (torch.from_numpy(a).to(self.device) for a in (dst, src))
+            self.buffers[dst_t] = self.buffers[src_t]
+            self.prev_inds[:] = -1
+            self.prev_inds[in_flight] = np.arange(n_in_flight, dtype=self.prev_inds.dtype)
+            self.will_replay_step[:] = False
+            self.ptr[:] = n_in_flight
+            # the remaining slots are ordered oldest policy version first (stable), so that the oldest experience is overwritten first
+            pv = B["policy_version"].view(-1)[self._num_envs:]
+            diff = self.current_policy_version.view(-1) - pv
+            m = diff.numel()
+            _, ordering = torch.sort(diff * m + torch.arange(m - 1, -1, -1, dtype=diff.dtype, device=diff.device), descending=True)
+            N = self._num_envs
+            self.buffers.map_in_place(lambda t: _reorder_tail(t, N, ordering))
+        self.num_steps_collected[:] = 0
+        self.rollout_done[:] = False
+        self._first_rollout[:] = False
+
+    def increment_policy_version(self):
+        self.current_policy_version += 1
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.cpu_current_policy_version += 1
+
+    def after_rollout(self):
+        B = self.buffers
+        B["is_stale"][:] = B["policy_version"] < self.current_policy_version
+        self.current_rollout_step_idxs[0] = self.num_steps + 1
+        if self.use_is_coeffs:
+            # importance weights against the biased sampling: uniform collection would give num_steps + 1 slots per environment
+            ids = B["environment_ids"].view(-1)
+            check(_lib.lib().hab_ver_is_coeffs(ptr(ids), ids.numel(), self._num_envs, self.num_steps, ptr(self._counts),
+                                               ptr(B["is_coeffs"]), stream_ptr()), "hab_ver_is_coeffs")
+
+    # ---- returns (:430-568) -----------------------------------------------------------------------------------------------------
+    def compute_returns(self, use_gae, gamma, tau):
+        if self.device.type != "cuda":
+            raise _lib.HabError("VERRolloutStorage.compute_returns needs the arena on a GPU (no CPU fallback)")
+        if not use_gae:
+            tau = 1.0
+        B = self.buffers
+        # the id columns are needed on the host (sequence structure, minibatch composition): one small device->host copy each
+        self.dones_cpu = torch.logical_not(B["masks"]).cpu().view(-1, self._num_envs).numpy()
+        self.episode_ids_cpu = B["episode_ids"].cpu().view(-1).numpy()
+        self.environment_ids_cpu = B["environment_ids"].cpu().view(-1).numpy()
+        self.step_ids_cpu = B["step_ids"].cpu().view(-1).numpy()
+        info = pack_info_from_ids_np(self.episode_ids_cpu, self.environment_ids_cpu, self.step_ids_cpu)
+        self.select_inds, self.num_seqs_at_step = info["select_inds"], info["num_seqs_at_step"]
+        self.sequence_lengths, self.sequence_starts = info["sequence_lengths"], info["sequence_starts"]
+        self.last_sequence_in_batch_mask = info["last_sequence_in_batch_mask"]
+        F = len(self.sequence_lengths)
+        offs = np.zeros(len(self.num_seqs_at_step) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum(self.num_seqs_at_step)
+        packed = np.concatenate([self.select_inds, offs, self.sequence_lengths]).astype(np.int32)
+        dev_i = torch.from_numpy(packed).to(self.device, non_blocking=True)
+        dev_m = torch.from_numpy(self.last_sequence_in_batch_mask.astype(np.uint8)).to(self.device, non_blocking=True)
+        self._pack_dev = (dev_i, dev_m)  # keep alive until the launch has run
+        P = len(self.select_inds)
+        base = dev_i.data_ptr()
+        check(_lib.lib().hab_ver_compute_returns(ptr(B["rewards"]), ptr(B["value_preds"]), ptr(B["is_stale"]), ptr(B["returns"]),
+                                                 base, base + 4 * P, base + 4 * (P + len(offs)), ptr(dev_m), F, float(gamma), float(tau),
+                                                 stream_ptr()), "hab_ver_compute_returns")
+        self.current_rollout_step_idxs[0] = self.num_steps
+
+    # ---- minibatches (:570-620) ---------------------------------------------------------------------------------------------------
+    def data_generator(self, advantages: Optional[torch.Tensor], num_mini_batch: int):
+        if not self.variable_experience:
+            yield from super().data_generator(advantages, num_mini_batch)
+            return
+        for mb_inds in generate_ver_mini_batches(num_mini_batch, self.sequence_lengths, self.num_seqs_at_step, self.select_inds,
+                                                 self.last_sequence_in_batch_mask, self.episode_ids_cpu):
+            yield VERMiniBatch(self, mb_inds, advantages)
+
+    # ---- what the inference worker does to the arena for one batch of requests (inference_worker.py:169-214,262-285,393-420) --------
+    def reserve_slots(self, n_requests: int, n_replay: int) -> Tuple[slice, int, bool]:
+        """Variable experience: claims the next slots for up to `n_requests` steps.  Returns (slots, number processed, final batch)."""
+        start = int(self.ptr[0])
+        n = int(min(int(self.num_steps_to_collect - self.num_steps_collected[0]), n_requests))
+        stop = start + n
+        assert stop <= self.buffer_size
+        self.ptr[:] = stop
+        self.num_steps_collected += n - n_replay
+        final = bool(self.num_steps_collected[0] == self.num_steps_to_collect)
+        if final:
+            self.rollout_done[:] = True
+        return slice(start, stop), n, final
+
+    def write_step(self, env_ids: List[int], slots: Optional[slice], current_step: Dict[str, Any], prev_rewards: torch.Tensor,
+                   current_steps: Optional[np.ndarray] = None) -> None:
+        """current_step: the step the policy just acted on (masks, observations, actions, log-probs, values, hidden state entering
+        the step, ids, policy version, returns = NaN); prev_rewards: the reward that the PREVIOUS action of each of these
+        environments earned, written to that environment's previous slot."""
+        B = self.buffers
+        if self.variable_experience:
+            prev = self._prev_inds_before[env_ids]
+            has = prev >= 0
+            if has.any():
+                dst = torch.from_numpy(prev[has]).to(self.device)
+                B["rewards"][dst] = prev_rewards[torch.from_numpy(np.nonzero(has)[0]).to(self.device)]
+            sub = TensorDict((k, B[k]) for k in current_step)
+            sub[slots] = current_step
+        else:
+            env_t = torch.as_tensor(env_ids, device=self.device)
+            steps = torch.from_numpy(current_steps[env_ids]).to(self.device)
+            okp = (steps - 1 >= 0) & (steps - 1 <= self.num_steps)
+            B["rewards"][(steps - 1)[okp], env_t[okp]] = prev_rewards[okp]
+            ok = (steps >= 0) & (steps <= self.num_steps)
+            sub = TensorDict((k, B[k]) for k in current_step)
+            sel = TensorDict.from_tree(current_step)[ok] if not bool(ok.all()) else current_step
+            sub[(steps[ok], env_t[ok])] = sel
+
+    def remember_slots(self, env_ids: List[int], slots: slice) -> None:
+        self._prev_inds_before = self.prev_inds.copy()
+        self.prev_inds[env_ids] = np.arange(slots.start, slots.stop, dtype=np.int64)
+
+
+def _reorder_tail(t: torch.Tensor, n_front: int, ordering: torch.Tensor) -> torch.Tensor:
+    t[n_front:].copy_(t[n_front:].index_select(0, ordering))
+    return t

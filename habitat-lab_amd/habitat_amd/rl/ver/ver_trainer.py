@@ -1,0 +1,205 @@
+"""VERTrainer (registered as "ver"): Variable Experience Rollouts, habitat_baselines/rl/ver/ver_trainer.py:66-580.
+
+A rollout collects a fixed number of STEPS (num_envs * num_steps; the first one fills the whole buffer) from whichever environments
+deliver them: the inference worker batches the environments whose step has arrived, so slow environments do not hold the policy
+(or the other environments) up.  The update is PPO on the linear step buffer with importance weights for the uneven per-environment
+sampling (VERRolloutStorage / `hab_ppo_loss_ver`), the learning-rate schedule is the reference's cosine decay.
+
+Arrangement: the inference worker runs in this process (`rl.ver.overlap_rollouts_and_learn=False`, one worker -- ver_trainer.py:269-337
+`main_is_iw`); environment workers are the process-per-environment VectorEnv workers (shared-memory observation plane) or, for the
+synthetic benchmark source, the device-resident generator."""
+from __future__ import annotations
+
+import contextlib
+import math
+import os
+import random
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from habitat_amd import _lib
+from habitat_amd.common.baseline_registry import baseline_registry
+from habitat_amd.common.env_factory import instantiate
+from habitat_amd.common.obs_transformers import apply_obs_transforms_obs_space, get_active_obs_transforms
+from habitat_amd.config.default import read_write
+from habitat_amd.rl.ddppo.ddp_utils import (EXIT, get_distrib_size, init_distrib_slurm, load_resume_state, rank0_only, requeue_job,
+                                            save_resume_state)
+from habitat_amd.rl.ppo.ppo_trainer import PPOTrainer
+from habitat_amd.rl.ppo.single_agent_access_mgr import EnvironmentSpec
+from habitat_amd.rl.ver.inference_worker import InferenceWorker
+from habitat_amd.rl.ver.report_worker import ReportWorker
+from habitat_amd.rl.ver.transport import DeviceEnvTransport, VectorEnvTransport
+from habitat_amd.rl.ver.ver_rollout_storage import VERRolloutStorage
+from habitat_amd.utils.logging import get_writer, logger
+from habitat_amd.utils.timing import Timing
+
+
+def cosine_decay(progress: float) -> float:
+    """ver_trainer.py:57-63."""
+    progress = min(max(progress, 0.0), 1.0)
+    return (1.0 + math.cos(progress * math.pi)) / 2.0
+
+
+@baseline_registry.register_trainer(name="ver")
+class VERTrainer(PPOTrainer):
+    def _create_agent(self, resume_state, **kwargs):
+        cls = baseline_registry.get_agent_access_mgr(self.config.habitat_baselines.rl.agent.type)
+        return cls(config=self.config, env_spec=self._env_spec, is_distrib=self._is_distributed, device=self.device,
+                   resume_state=resume_state, num_envs=self.config.habitat_baselines.num_environments,
+                   percent_done_fn=self.percent_done, **kwargs)
+
+    def _init_train(self, resume_state=None):
+        hb = self.config.habitat_baselines
+        if self._is_distributed:
+            local_rank, world_rank, _ = get_distrib_size()
+            with read_write(self.config):
+                hb.torch_gpu_id = local_rank % max(1, torch.cuda.device_count()) if torch.cuda.is_available() else local_rank
+                self.config.habitat.seed += world_rank * hb.num_environments  # ver_trainer.py:96-99
+        random.seed(self.config.habitat.seed)
+        np.random.seed(self.config.habitat.seed)
+        torch.manual_seed(self.config.habitat.seed)
+        if hb.rl.ddppo.force_distributed:
+            self._is_distributed = True
+        self._add_preemption_signal_handlers()
+        if self._is_distributed:
+            init_distrib_slurm(hb.rl.ddppo.distrib_backend)
+            if rank0_only():
+                logger.info("Initialized VER+DD-PPO with {} workers".format(torch.distributed.get_world_size()))
+        else:
+            logger.info("Initialized VER")
+        self.device = torch.device("cuda", hb.torch_gpu_id) if torch.cuda.is_available() else torch.device("cpu")
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        if self.device.type != "cuda":
+            raise _lib.HabError("the VER trainer needs a GPU (no CPU execution path)")
+        self._my_t_zero = time.perf_counter()
+        self._init_envs()  # environment workers (vector_env_factory) + observation-space bookkeeping of the parent
+        self.ver_config = hb.rl.ver
+        if self.ver_config.overlap_rollouts_and_learn or self.ver_config.num_inference_workers != 1:
+            raise _lib.HabError("habitat_amd's VER runs ONE inference worker inside the trainer process "
+                                "(rl.ver.num_inference_workers=1, rl.ver.overlap_rollouts_and_learn=False)")
+        if rank0_only() and not os.path.isdir(hb.checkpoint_folder):
+            os.makedirs(hb.checkpoint_folder, exist_ok=True)
+        self._agent = self._create_agent(resume_state, lr_schedule_fn=cosine_decay)
+        ppo_cfg = hb.rl.ppo
+        self._ppo_cfg = ppo_cfg
+
+        def create_ver_rollouts(num_envs, env_spec, actor_critic, policy_action_space, config, device):
+            return VERRolloutStorage(numsteps=ppo_cfg.num_steps, num_envs=num_envs,
+                                     observation_space=self._agent.rollout_obs_space(env_spec, actor_critic),
+                                     action_space=policy_action_space, actor_critic=actor_critic,
+                                     variable_experience=self.ver_config.variable_experience, device=device)
+
+        self._agent.post_init(create_ver_rollouts)
+        self.learning_rollouts = self._agent.rollouts
+        if self._is_distributed:
+            self._agent.init_distributed(find_unused_params=False)
+        has_report_state = resume_state is not None and "report_worker_state" in resume_state.get("requeue_stats", {})
+        self._writer_cm = get_writer(self.config, flush_secs=self.flush_secs) if rank0_only() else contextlib.nullcontext()
+        self._writer = self._writer_cm.__enter__()
+        self.report_worker = ReportWorker(self.config, self._my_t_zero, self.num_steps_done, writer=self._writer)
+        if has_report_state and resume_state["requeue_stats"]["report_worker_state"] is not None:
+            self.report_worker.load_state_dict(resume_state["requeue_stats"]["report_worker_state"])
+        if hasattr(self.envs, "step_into_obs"):  # device-resident synthetic source
+            speeds = getattr(self.config.habitat, "synthetic", {}).get("ver_speeds", None)
+            self.transport = DeviceEnvTransport(self.envs, self.report_worker, speeds=speeds, seed=self.config.habitat.seed)
+        else:
+            self.transport = VectorEnvTransport(self.envs, self.report_worker)
+        self.inference_worker = InferenceWorker(self.config, self._agent.actor_critic, self._agent.rollouts, self.transport,
+                                                self.device, self.obs_transforms, report=self.report_worker)
+        if self._is_distributed:
+            torch.distributed.barrier()
+        # every environment starts with its first observation on the table (environment_worker.py:148-160)
+        self.inference_worker.new_reqs += self.transport.start_experience_collection()
+        self.report_worker.start_collection()
+        self.timer = Timing()
+        self._learning_time = 0.0
+
+    # ---- learner (ver_trainer.py:377-428) ---------------------------------------------------------------------------------------------
+    def _update_agent(self):
+        ppo_cfg = self._ppo_cfg
+        with self.timer.avg_time("learn"):
+            t0 = time.perf_counter()
+            with self.timer.avg_time("compute returns"):
+                self.learning_rollouts.compute_returns(ppo_cfg.use_gae, ppo_cfg.gamma, ppo_cfg.tau)
+            t_returns = time.perf_counter() - t0
+            if self._is_distributed:
+                with self.timer.avg_time("synchronize"):
+                    torch.distributed.barrier()
+            t1 = time.perf_counter()
+            with self.timer.avg_time("update agent"):
+                self._agent.train()
+                losses = self._agent.updater.update(self.learning_rollouts)
+            with self.timer.avg_time("after update"):
+                self.learning_rollouts.after_update()
+                self._agent.rollouts.increment_policy_version()
+        self._learning_time = (time.perf_counter() - t1) + t_returns
+        self._agent.after_update()
+        return losses
+
+    def collect_rollout(self) -> int:
+        """One VER rollout: inference batches until the arena has its quota of steps."""
+        ro, iw = self._agent.rollouts, self.inference_worker
+        self._agent.eval()
+        with self.timer.avg_time("rollout"):
+            while not bool(ro.rollout_done):
+                iw.try_one_step()
+            iw.finish_rollout()
+            ro.after_rollout()
+        n = int(ro.num_steps_collected[0])
+        self.report_worker.num_steps_collected(n)
+        return n
+
+    def run_update_cycle(self) -> Dict[str, float]:
+        self._agent.pre_rollout()
+        n = self.collect_rollout()
+        self.local_steps_done = getattr(self, "local_steps_done", 0) + n
+        losses = self._update_agent()
+        self.report_worker.learner_timing(self.timer)
+        self.report_worker.learner_update(losses)
+        self.timer = Timing()
+        self.num_steps_done = int(self.report_worker.num_steps_done)
+        self.num_updates_done += 1
+        return losses
+
+    def train(self) -> None:
+        self.num_steps_done = 0
+        resume_state = load_resume_state(self.config)
+        if resume_state is not None:
+            if not self.config.habitat_baselines.load_resume_state_config:
+                raise FileExistsError("habitat_baselines.load_resume_state_config=False but a previous training run exists in "
+                                      f"{self.config.habitat_baselines.checkpoint_folder}")
+            self.config = self._get_resume_state_config_or_new_config(resume_state["config"])
+            rs = resume_state["requeue_stats"]
+            self.num_steps_done, self.num_updates_done = rs["num_steps_done"], rs["num_updates_done"]
+        self._init_train(resume_state)
+        count_checkpoints = 0
+        if resume_state is not None:
+            self._last_checkpoint_percent = resume_state["requeue_stats"]["_last_checkpoint_percent"]
+            count_checkpoints = resume_state["requeue_stats"]["count_checkpoints"]
+        try:
+            while not self.is_done():
+                if rank0_only() and self._should_save_resume_state():
+                    requeue_stats = dict(count_checkpoints=count_checkpoints, num_steps_done=self.num_steps_done,
+                                         num_updates_done=self.num_updates_done, _last_checkpoint_percent=self._last_checkpoint_percent,
+                                         report_worker_state=self.report_worker.state_dict())
+                    save_resume_state({**self._agent.get_resume_state(), "config": self.config.to_dict(), "requeue_stats": requeue_stats},
+                                      self.config)
+                if EXIT.is_set():
+                    self.envs.close()
+                    requeue_job()
+                    return
+                self.run_update_cycle()
+                if rank0_only() and self.should_checkpoint():
+                    self.save_checkpoint(f"ckpt.{count_checkpoints}.pth",
+                                         dict(step=self.num_steps_done, wall_time=self.report_worker.time_taken))
+                    count_checkpoints += 1
+            self.window_episode_stats = self.report_worker.get_window_episode_stats()
+        finally:
+            self.envs.close()
+            self._writer_cm.__exit__(None, None, None)
+            if self._is_distributed:
+                torch.distributed.barrier()

@@ -24,6 +24,7 @@ def execute_exp(config, run_type: str) -> None:
     if config.habitat_baselines.force_torch_single_threaded and torch.cuda.is_available():
         torch.set_num_threads(1)
     import habitat_amd.rl.ppo.ppo_trainer  # noqa: F401  (registers "ppo" / "ddppo")
+    import habitat_amd.rl.ver.ver_trainer  # noqa: F401  (registers "ver")
     trainer_init = baseline_registry.get_trainer(config.habitat_baselines.trainer_name)
     assert trainer_init is not None, f"{config.habitat_baselines.trainer_name} is not supported"
     trainer = trainer_init(config)

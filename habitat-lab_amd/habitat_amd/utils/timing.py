@@ -54,3 +54,5 @@ class Timer:
 
 
 g_timer = Timer()
+
+Timing = Timer  # the per-worker timers of rl/ver (habitat_baselines/utils/timing.py's class name)

@@ -106,6 +106,28 @@ int hab_ppo_loss(const float* values, const float* logp, const float* entropy, c
                  float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
                  float* d_value, float* d_logp, float* d_entropy, float* out12, hipStream_t stream);
 
+/* The same with VER's importance weights and learner statistics (rl/ppo/ppo.py:226-231,262-263,285-299): every per-frame loss term
+ * is multiplied by min(is_coeffs, 1) before the batch mean.  is_coeffs / is_stale / policy_version are storage buffers gathered
+ * through rows (each nullable).  out20 = out12 + {[12] reserved (grad norm), ver_is_coeffs min/mean/max, fraction_stale,
+ * policy_version_difference min/mean/max}. */
+int hab_ppo_loss_ver(const float* values, const float* logp, const float* entropy, const float* old_logp, const float* adv,
+                     const float* old_values, const float* returns, const int* rows, int B, float clip_param, float value_loss_coef,
+                     float entropy_coef, int use_clipped_value_loss, const float* is_coeffs, const uint8_t* is_stale,
+                     const int64_t* policy_version, int64_t current_policy_version, float* d_value, float* d_logp, float* d_entropy,
+                     float* out20, hipStream_t stream);
+
+/* VERRolloutStorage.compute_returns (rl/ver/ver_rollout_storage.py:430-568) on the linear step buffer: GAE per sequence (episode
+ * fragment) in float64 like the numpy loop, result rounded to float32; the last step of an environment's last sequence is the
+ * bootstrap step (return = NaN); stale steps keep a finite previous return.  select_inds / step_offsets ([max_len+1] prefix sums
+ * of num_seqs_at_step) / sequence_lengths / last_sequence_in_batch_mask: device copies of the buffer's pack info (F sequences). */
+int hab_ver_compute_returns(const float* rewards, const float* value_preds, const uint8_t* is_stale, float* returns,
+                            const int32_t* select_inds, const int32_t* step_offsets, const int32_t* sequence_lengths,
+                            const uint8_t* last_sequence_in_batch_mask, int F, double gamma, double tau, hipStream_t stream);
+/* VERRolloutStorage.after_rollout's importance coefficients (:399-428): is_coeffs[b] = (num_steps + 1) / #steps of
+ * environment_ids[b] in the buffer.  counts_scratch: num_envs int32. */
+int hab_ver_is_coeffs(const int64_t* environment_ids, int n, int num_envs, int num_steps, int32_t* counts_scratch, float* is_coeffs,
+                      hipStream_t stream);
+
 /* nn.utils.clip_grad_norm_ + optim.Adam(foreach).step (rl/ppo/ppo.py:347-371,112-137,257) over the
  * flat parameter arena.  grads are first multiplied by grad_scale (1/world_size after a sum
  * all-reduce).  scratch_partials: >= 1024 doubles.  step counts from 1.  All pointers 16-B aligned. */
@@ -224,6 +246,13 @@ int hab_build_pack_info(const uint8_t* dones, int T, int N, int64_t* select_inds
                         uint8_t* last_sequence_in_batch_mask, uint8_t* first_sequence_in_batch_mask,
                         int64_t* last_sequence_in_batch_inds, int64_t* first_episode_in_batch_inds,
                         int64_t* first_step_for_env, int32_t* num_fragments, int32_t* max_len);
+/* build_pack_info_from_episode_ids (rnn_state_encoder.py:35-150): P frames in any order tagged (episode, environment, step).
+ * Outputs as above; environments are renumbered 0..n-1 in increasing id order, first_step_for_env has n entries. */
+int hab_build_pack_info_from_ids(const int64_t* episode_ids, const int64_t* environment_ids, const int64_t* step_ids, int P,
+                                 int64_t* select_inds, int64_t* num_seqs_at_step, int64_t* sequence_starts, int64_t* sequence_lengths,
+                                 int64_t* rnn_state_batch_inds, uint8_t* last_sequence_in_batch_mask,
+                                 uint8_t* first_sequence_in_batch_mask, int64_t* first_step_for_env, int32_t* num_fragments,
+                                 int32_t* max_len, int32_t* num_envs);
 
 /* ---------------------------------------------------------------------------------------------
  * Policy engine: NetPolicy.act / get_value / evaluate_actions (rl/ppo/policy.py:324-402) and the
@@ -280,6 +309,9 @@ typedef struct hab_pack_info { /* int32 copies of hab_build_pack_info's arrays *
     const int32_t* step_offsets_host;     /* host  [max_len+1] */
     const int32_t* num_seqs_at_step_host; /* host  [max_len] */
     int32_t P, F, max_len;
+    /* VER minibatches (frames in any order, hab_build_pack_info_from_ids): device [n] first_step_for_env -- the frame whose arena
+     * row holds the hidden state of batch environment e.  NULL: frame e (the t = 0 row of a time-major T x n minibatch). */
+    const int32_t* env_first_frame;
 } hab_pack_info;
 
 typedef struct hab_policy hab_policy;

@@ -268,6 +268,48 @@ def load_reference():
     return ns
 
 
+def load_reference_ver():
+    """Adds the reference's VER pieces to the namespace: the real VERRolloutStorage (replacing the placeholder
+    class rl/ppo/ppo.py was given to import) and the real InferenceWorkerProcess, so that tests/golden/make_golden.py can drive the
+    reference's own `step()` / storage writes.  Stubbed: the batched queue (the reference's fallback class subclasses
+    torch.multiprocessing.Queue, which is a bound method in this torch) and the obs-transformer helpers (identity: none configured)."""
+    ns = load_reference()
+    if getattr(ns, "inference_worker", None) is not None:
+        return ns
+    for name in ("habitat_baselines.rl.ver.ver_rollout_storage",):
+        sys.modules.pop(name, None)
+    ns.ver_rollout_storage = _load("habitat_baselines.rl.ver.ver_rollout_storage", "rl/ver/ver_rollout_storage.py")
+    ns.ppo.VERRolloutStorage = ns.ver_rollout_storage.VERRolloutStorage  # the isinstance check of ppo.py:292
+
+    class BatchedQueue:
+        def __init__(self, *_a, **_k):
+            self.items = []
+
+        def put(self, x, *_a, **_k):
+            self.items.append(x)
+
+        def put_many(self, xs, *_a, **_k):
+            self.items.extend(xs)
+
+        def get_many(self, *_a, **_k):
+            out, self.items = self.items, []
+            if not out:
+                import queue
+                raise queue.Empty
+            return out
+
+        def empty(self):
+            return not self.items
+
+    _mod("habitat_baselines.rl.ver.queue", BatchedQueue=BatchedQueue)
+    _mod("habitat_baselines.common.obs_transformers", apply_obs_transforms_batch=lambda obs, _t: obs, get_active_obs_transforms=lambda _c: [])
+    ns.task_enums = _load("habitat_baselines.rl.ver.task_enums", "rl/ver/task_enums.py")
+    ns.worker_common = _load("habitat_baselines.rl.ver.worker_common", "rl/ver/worker_common.py")
+    ns.inference_worker = _load("habitat_baselines.rl.ver.inference_worker", "rl/ver/inference_worker.py")
+    ns.BatchedQueue = BatchedQueue
+    return ns
+
+
 def make_config(**ppo_overrides):
     """A plain attribute-tree carrying the config keys the hot path reads
     (default_structured_configs.py:288-316,343-363)."""

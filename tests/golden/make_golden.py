@@ -179,7 +179,174 @@ def c1_case(ns):
     run_case(ns, "c1_depth84_h512_4x32", pol, space, cfg, T=32, N=4, seed=41, H=84, W=84, rgb=False, sampled=True)
 
 
+VER_CASE = dict(H=44, W=44, N=4, T=6, hidden=64, seed=77, speeds=(0.9, 0.6, 0.35, 0.75), p_done=0.2,
+                cfg=dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.5, use_normalized_advantage=False,
+                         use_clipped_value_loss=True, entropy_coef=0.01, value_loss_coef=0.5, lr=2.5e-4, eps=1e-5))
+
+
+def ver_env_step(c, env, t):
+    """Synthetic env `env` at its own step counter t: (obs dict, reward, done).  done: a dedicated hash draw at rate p_done."""
+    H, W, seed = c["H"], c["W"], c["seed"]
+    obs = {"rgb": synth.rgb(seed, env, t, H, W), "depth": synth.depth(seed, env, t, H, W), GOAL: synth.goal(seed, env, t)}
+    done = bool(synth.words(seed, synth.SENSOR_DONE, env, t, 1)[0] < np.uint32(int(c["p_done"] * (1 << 32))))
+    return obs, float(synth.reward(seed, env, t)), done
+
+
+def ver_case():
+    """Variable Experience Rollouts, driven through the REFERENCE's own classes: VERRolloutStorage, the
+    InferenceWorkerProcess.step() that fills it (rl/ver/inference_worker.py:238-420), after_rollout / compute_returns, PPO.update
+    with the importance-weighted loss (rl/ppo/ppo.py:226-231), after_update, and a second rollout on top of the reordered buffer.
+    Environments finish their steps at different rates (a scripted scheduler with its own RandomState), so they contribute different
+    numbers of steps.  Stored: the request batches the scheduler handed to step() (the test replays them), the Exp(1) noise of every
+    sampling call, and snapshots of every buffer / bookkeeping array after each phase."""
+    from oracle.ref_loader import load_reference_ver
+    ns = load_reference_ver()
+    c = VER_CASE
+    N, T, H, W = c["N"], c["T"], c["H"], c["W"]
+    VS, IW = ns.ver_rollout_storage.VERRolloutStorage, ns.inference_worker.InferenceWorkerProcess
+    space = obs_space(ns, H, W)
+    aspace = ns.spaces.Discrete(4)
+    torch.manual_seed(0)
+    policy = ns.policy.PointNavBaselinePolicy(space, aspace, hidden_size=c["hidden"])
+    sd = policy.state_dict()
+    sd.update(det_params([(k, v.shape) for k, v in sd.items()], c["seed"]))
+    policy.load_state_dict(sd)
+    with torch.inference_mode():  # as ver_trainer.py:255-262 creates them
+        rollouts = VS(T, N, space, aspace, policy, variable_experience=True)
+        tb = VS(1, N, space, aspace, policy, variable_experience=True).buffers.slice_keys(
+            "rewards", "masks", "observations", "episode_ids", "environment_ids", "actions", "step_ids")[slice(0, N)]
+        tb["environment_ids"][:] = torch.arange(N).view(N, 1)
+    iw = object.__new__(IW)
+    iw.__dict__.update(new_reqs=[], replay_reqs=[], rollouts=rollouts, _current_policy_version=int(rollouts.cpu_current_policy_version),
+                       _overlapped=False, _variable_experience=True, num_inference_workers=1, _n_replay_steps=0,
+                       timer=ns.timing.Timing(), device=torch.device("cpu"), obs_transforms=[], _static_encoder=False,
+                       actor_critic=policy, visual_encoder=None, inference_worker_idx=0)
+    iw.transfer_buffers = tb.numpy()
+    iw.incoming_transfer_buffers = iw.transfer_buffers.slice_keys(set(iw.transfer_buffers.keys()) - {"actions"})
+    send = iw.transfer_buffers.slice_keys("observations", "rewards", "masks", "episode_ids", "step_ids")  # environment_worker.py:223-229
+    iw.queues = type("Q", (), {})()
+    iw.queues.environments = [ns.BatchedQueue() for _ in range(N)]
+    out = {}
+    sched = np.random.RandomState(c["seed"])
+    env_t = np.zeros(N, dtype=np.int64)
+    ep_id = np.zeros(N, dtype=np.int64)
+    step_id = np.zeros(N, dtype=np.int64)
+    stepping = np.zeros(N, dtype=bool)
+    policy.eval()
+    torch.manual_seed(c["seed"] + 5)
+
+    def snapshot(tag):
+        for k, v in rollouts.buffers.items():
+            if k == "observations":
+                continue
+            out[f"{tag}/buf/{k}"] = v.numpy().copy()
+        out[f"{tag}/buf/obs_depth_sum"] = rollouts.buffers["observations"]["depth"].flatten(1).sum(1).numpy().copy()
+        for k in ("ptr", "prev_inds", "num_steps_collected", "rollout_done", "current_steps", "actor_steps_collected",
+                  "will_replay_step", "_first_rollout", "cpu_current_policy_version"):
+            out[f"{tag}/aux/{k}"] = np.asarray(getattr(rollouts, k)).copy()
+        out[f"{tag}/aux/next_hidden_states"] = rollouts.next_hidden_states.numpy().copy()
+        out[f"{tag}/aux/next_prev_actions"] = rollouts.next_prev_actions.numpy().copy()
+
+    def collect(rollout_idx, ready):
+        batches, noises = [], []
+        while not bool(rollouts.rollout_done):
+            # environments with an outstanding step finish it with their own probability per scheduler tick
+            for e in range(N):
+                if stepping[e] and sched.random_sample() < c["speeds"][e]:
+                    env_t[e] += 1
+                    obs, rew, done = ver_env_step(c, e, int(env_t[e]))
+                    step_id[e] += 1
+                    if done:
+                        ep_id[e] += 1
+                        step_id[e] = 0
+                    send[e] = dict(observations=obs, rewards=rew, masks=not done, episode_ids=int(ep_id[e]),
+                                                           step_ids=int(step_id[e]))
+                    stepping[e] = False
+                    ready.append(e)
+            if not ready and not iw.new_reqs:
+                continue
+            # the worker picks up what has arrived so far (possibly not everything); replayed requests of the last rollout are waiting
+            k = int(sched.randint(0 if iw.new_reqs else 1, len(ready) + 1))
+            iw.new_reqs = iw.new_reqs + ready[:k]
+            del ready[:k]
+            reqs = list(iw.new_reqs)
+            n_proc = int(min(int(rollouts.num_steps_to_collect - rollouts.num_steps_collected), len(reqs)))  # inference_worker.py:262-270
+            state = torch.get_rng_state()
+            noises.append(torch.empty(n_proc, 4).exponential_(1).numpy())  # what multinomial is about to draw for the processed requests
+            torch.set_rng_state(state)
+            with torch.inference_mode():  # InferenceWorkerProcess.run is decorated with it
+                stepped, _ = iw.step()
+            assert stepped
+            iw._n_replay_steps = 0
+            batches.append(np.array(reqs, dtype=np.int64))
+            for e in range(N):
+                q = iw.queues.environments[e]
+                if q.items:
+                    q.items.clear()
+                    stepping[e] = True
+        # finish_rollout (inference_worker.py:422-456) for a single worker: outstanding + replay requests are replayed first
+        iw.new_reqs = iw.replay_reqs + iw.new_reqs + ready
+        del ready[:]
+        iw.replay_reqs = []
+        iw._n_replay_steps = len(iw.new_reqs)
+        rollouts.will_replay_step[iw.new_reqs] = True
+        out[f"r{rollout_idx}/num_batches"] = np.int64(len(batches))
+        for i, (b, q) in enumerate(zip(batches, noises)):
+            out[f"r{rollout_idx}/batch{i}"] = b
+            out[f"r{rollout_idx}/noise{i}"] = q
+        out[f"r{rollout_idx}/replay_after"] = np.array(iw.new_reqs, dtype=np.int64)
+        out[f"r{rollout_idx}/in_flight_after"] = stepping.copy()
+
+    # every env starts with its first observation on the table (start_experience_collection, environment_worker.py:148-160)
+    ready0 = []
+    for e in range(N):
+        obs, _, _ = ver_env_step(c, e, 0)
+        send.slice_keys("observations", "episode_ids", "step_ids")[e] = dict(observations=obs, episode_ids=0,
+                                                                                                    step_ids=0)
+        ready0.append(e)
+    cfg = make_config(num_steps=T, hidden_size=c["hidden"], **c["cfg"])
+    ppo = ns.ppo.PPO.from_config(policy, cfg)
+    for r in range(2):
+        collect(r, ready0 if r == 0 else [])
+        snapshot(f"r{r}/collected")
+        with torch.inference_mode():
+            rollouts.after_rollout()
+            rollouts.compute_returns(cfg.use_gae, cfg.gamma, cfg.tau)
+        snapshot(f"r{r}/returns")
+        for k in ("select_inds", "num_seqs_at_step", "sequence_lengths", "sequence_starts", "last_sequence_in_batch_mask"):
+            out[f"r{r}/pack/{k}"] = np.asarray(getattr(rollouts, k)).copy()
+        np.random.seed(c["seed"] + 10 + r)
+        st = np.random.get_state()
+        mbs = list(ns.ver_rollout_storage.generate_ver_mini_batches(cfg.num_mini_batch, rollouts.sequence_lengths, rollouts.num_seqs_at_step,
+                                                                   rollouts.select_inds, rollouts.last_sequence_in_batch_mask,
+                                                                   rollouts.episode_ids_cpu))
+        for i, mb in enumerate(mbs):
+            out[f"r{r}/mb{i}"] = mb
+            info = ns.rnn_state_encoder.build_pack_info_from_episode_ids(rollouts.episode_ids_cpu[mb], rollouts.environment_ids_cpu[mb],
+                                                                         rollouts.step_ids_cpu[mb])
+            out[f"r{r}/mb{i}_first_step_for_env"] = info["first_step_for_env"]
+            out[f"r{r}/mb{i}_sequence_lengths"] = info["sequence_lengths"]
+        np.random.set_state(st)
+        policy.train()
+        metrics = ppo.update(rollouts)
+        policy.eval()
+        for k, v in metrics.items():
+            out[f"r{r}/metric/{k}"] = np.float32(v)
+        for k, v in policy.state_dict().items():
+            out[f"r{r}/post/{k}"] = v.numpy().copy()
+        with torch.inference_mode():
+            rollouts.after_update()
+            rollouts.increment_policy_version()
+        iw._current_policy_version = int(rollouts.cpu_current_policy_version)
+        snapshot(f"r{r}/after_update")
+    np.savez_compressed(os.path.join(HERE, "ver_baseline_rgbd44.npz"), **out)
+    print("ver_baseline_rgbd44 ->", len(out), "arrays;", {k: float(v) for k, v in metrics.items()})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ver":
+        ver_case()
+        return
     ns = load_reference()
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
@@ -222,6 +389,7 @@ def main():
                        use_normalized_advantage=False, hidden_size=64, lr=2.5e-4, eps=1e-5)
     run_case(ns, "objectnav_resnet50_256", pol4, space4, cfg4, T=3, N=2, seed=33, H=256, W=256, sampled=True, task="objectnav",
              num_actions=6)
+    ver_case()
 
 
 if __name__ == "__main__":

@@ -266,3 +266,91 @@ def test_adam_resume_state_round_trip_through_live_reference():
     ppo2.optimizer.step()
     for (k, a), b in zip(pol.state_dict().items(), pol2.state_dict().values()):
         assert torch.equal(a, b), k
+
+
+def test_ver_pack_info_and_minibatches_vs_reference_golden():
+    """VER host-side index logic against the fixture the reference produced (tests/golden/ver_baseline_rgbd44.npz): sequence
+    structure of the whole buffer (same numpy sort calls -> same order of equal-length sequences), minibatch composition (same two
+    draws from numpy's global generator), and the C++ per-minibatch pack-info builder."""
+    import os
+    from habitat_amd.engine import DevicePackInfo
+    from habitat_amd.rl.ver.ver_rollout_storage import generate_ver_mini_batches, pack_info_from_ids_np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ver_baseline_rgbd44.npz"))
+    for r in range(2):
+        ep, env, st = (z[f"r{r}/returns/buf/{k}"].reshape(-1) for k in ("episode_ids", "environment_ids", "step_ids"))
+        info = pack_info_from_ids_np(ep, env, st)
+        for k in ("select_inds", "num_seqs_at_step", "sequence_lengths", "sequence_starts", "last_sequence_in_batch_mask"):
+            assert np.array_equal(info[k], z[f"r{r}/pack/{k}"]), (r, k)
+        np.random.seed(77 + 10 + r)
+        mbs = list(generate_ver_mini_batches(2, info["sequence_lengths"], info["num_seqs_at_step"], info["select_inds"],
+                                             info["last_sequence_in_batch_mask"], ep))
+        for i, mb in enumerate(mbs):
+            assert np.array_equal(mb, z[f"r{r}/mb{i}"]), (r, i)
+            pk = DevicePackInfo.from_ids(ep[mb], env[mb], st[mb])
+            assert np.array_equal(pk.arrays["first_step_for_env"], z[f"r{r}/mb{i}_first_step_for_env"])
+            assert np.array_equal(pk.arrays["sequence_lengths"], z[f"r{r}/mb{i}_sequence_lengths"])
+            # every frame exactly once, fragment q occupies slot q of every packed step it is alive in, steps in step-id order
+            sel, nseq = pk.arrays["select_inds"], pk.arrays["num_seqs_at_step"]
+            assert sorted(sel.tolist()) == list(range(len(mb)))
+            off = np.concatenate([[0], np.cumsum(nseq)])
+            for q, (s0, ln) in enumerate(zip(pk.arrays["sequence_starts"], pk.arrays["sequence_lengths"])):
+                frames = [sel[off[s] + q] for s in range(ln)]
+                assert frames[0] == s0
+                assert len({(ep[mb][f], env[mb][f]) for f in frames}) == 1
+                assert (np.diff(st[mb][frames]) > 0).all()
+
+
+def test_ver_aliased_swaps_and_partition():
+    from habitat_amd.rl.ver.ver_rollout_storage import compute_movements_for_aliased_swaps, partition_n_into_p
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        n = int(rng.integers(1, 9))
+        src = rng.choice(40, size=n, replace=False)
+        dst = np.arange(n)
+        t = rng.standard_normal(40)
+        d, s = compute_movements_for_aliased_swaps(dst, src)
+        t2 = t.copy()
+        t2[d] = t[s]
+        assert np.array_equal(t2[dst], t[src])                       # every source value sits at its destination
+        assert sorted(t2.tolist()) == sorted(t.tolist())             # nothing lost or duplicated
+        untouched = np.setdiff1d(np.arange(40), np.concatenate([d, s]))
+        assert np.array_equal(t2[untouched], t[untouched])
+    assert partition_n_into_p(10, 3) == [4, 3, 3] and sum(partition_n_into_p(23, 4)) == 23
+
+
+def test_ver_pack_info_from_ids_vs_live_reference():
+    from oracle import ref_loader
+    if not ref_loader.reference_available():
+        pytest.skip("needs /root/reference (live reference)")
+    from habitat_amd.engine import DevicePackInfo
+    from habitat_amd.rl.ver.ver_rollout_storage import pack_info_from_ids_np
+    from test_oracle_golden import canon_pack
+    ns = ref_loader.load_reference()
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        n_env, P = int(rng.integers(1, 7)), int(rng.integers(1, 60))
+        env = rng.integers(0, n_env, P)
+        ep, st = np.zeros(P, np.int64), np.zeros(P, np.int64)
+        cur_ep, cur_st = np.zeros(n_env, np.int64), np.zeros(n_env, np.int64)
+        for i in range(P):  # each env walks through episodes of random length
+            e = env[i]
+            ep[i], st[i] = cur_ep[e], cur_st[e]
+            cur_st[e] += 1
+            if rng.random() < 0.25:
+                cur_ep[e] += 1
+                cur_st[e] = 0
+        perm = rng.permutation(P)  # frames in arbitrary order
+        ep, env_p, st = ep[perm], env[perm].astype(np.int64), st[perm]
+        ref = ns.rnn_state_encoder.build_pack_info_from_episode_ids(ep, env_p, st)
+        mine = DevicePackInfo.from_ids(ep, env_p, st).arrays
+        N = 1  # canon_pack only uses N for nothing but signature parity here
+        assert canon_pack(ref, N) == canon_pack(mine, N)
+        assert np.array_equal(np.sort(mine["first_step_for_env"]), np.sort(ref["first_step_for_env"]))
+        assert np.array_equal(mine["first_step_for_env"], ref["first_step_for_env"])
+        # rnn_state_batch_inds: same environment numbering (np.unique order)
+        starts_r = dict(zip(np.asarray(ref["sequence_starts"]).tolist(), np.asarray(ref["rnn_state_batch_inds"]).tolist()))
+        starts_m = dict(zip(np.asarray(mine["sequence_starts"]).tolist(), np.asarray(mine["rnn_state_batch_inds"]).tolist()))
+        assert starts_r == starts_m
+        full = pack_info_from_ids_np(ep, env_p, st)
+        for k in ("select_inds", "num_seqs_at_step", "sequence_lengths", "sequence_starts", "last_sequence_in_batch_mask"):
+            assert np.array_equal(full[k], np.asarray(ref[k])), (trial, k)
