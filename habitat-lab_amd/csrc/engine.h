@@ -41,6 +41,9 @@ struct hab_policy {
     int fc_in = 0, rnn_in = 0, rnn_ld = 0, G_ = 3, L = 1;
     // param indices
     int i_c1w, i_c1b, i_c2w, i_c2b, i_c3w, i_c3b, i_fcw, i_fcb, i_aw, i_ab, i_cw, i_cb;
+    int i_astd = -1;   // Gaussian head: state-independent std parameter `action_distribution.std` (or -1)
+    int head_K = 0;    // Gaussian head: linear outputs (A or 2A)
+    int64_t w_gsaved = -1;  // Gaussian head: [B][16] mu / std / chain factors of the last evaluate
     std::vector<int> i_wih, i_whh, i_bih, i_bhh;
     // packed offsets
     int64_t pk_c1f, pk_c2f, pk_c2d, pk_c3f, pk_c3d, pk_fc;

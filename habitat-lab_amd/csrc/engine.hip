@@ -103,6 +103,8 @@ extern "C" int hab_policy_create(const hab_policy_desc* desc, hab_policy** out) 
     if (desc->hidden <= 0 || desc->hidden % 64 || desc->num_actions <= 0 || desc->num_actions > 8 || desc->max_frames <= 0 ||
         desc->max_envs <= 0 || desc->rnn_layers <= 0 || desc->H <= 0 || desc->W <= 0 || desc->goal_dim < 0)
         return HAB_ERR_ARG;
+    if (desc->action_dist != HAB_DIST_CATEGORICAL && (desc->action_dist != HAB_DIST_GAUSSIAN || desc->arch != HAB_ARCH_RESNET))
+        return HAB_ERR_UNSUPPORTED;  // PointNavBaselinePolicy never builds a Gaussian head (rl/ppo/policy.py:439-460)
     hab_policy* e = new hab_policy();
     e->d = *desc;
     int rc = HAB_ERR_UNSUPPORTED;
@@ -313,6 +315,20 @@ extern "C" int hab_policy_act(hab_policy* e, const hab_obs* obs, const float* hi
         x = hout;  // next layer's input / the heads' features, read with the same row stride
         ldx = hstride;
     }
+    if (e->d.action_dist == HAB_DIST_GAUSSIAN) {
+        GaussHeadsArgs ga;
+        ga.B = n; ga.H = H; ga.A = e->d.num_actions; ga.K = e->head_K; ga.flags = e->d.gauss_flags;
+        ga.min_std = e->d.gauss_min_std; ga.max_std = e->d.gauss_max_std;
+        ga.mode = actions ? (deterministic ? 2 : 1) : 2;
+        ga.feats = x; ga.feats_ld = ldx; ga.w = e->p(e->i_aw); ga.b = e->p(e->i_ab);
+        ga.std_param = e->i_astd >= 0 ? e->p(e->i_astd) : nullptr; ga.w_critic = e->p(e->i_cw); ga.b_critic = e->p(e->i_cb);
+        ga.actions_in = nullptr; ga.rows = nullptr; ga.noise = exp_noise;
+        ga.actions_out = actions ? reinterpret_cast<float*>(actions) : W + e->w_dzv;
+        ga.value = values; ga.logp = action_log_probs ? action_log_probs : W + e->w_logp; ga.entropy = nullptr; ga.saved = nullptr;
+        if (ga.mode == 1 && !exp_noise) return HAB_ERR_ARG;
+        if (probs_out) return HAB_ERR_ARG;
+        return gauss_heads_forward(ga, stream);
+    }
     HeadsArgs ha;
     ha.B = n; ha.H = H; ha.A = e->d.num_actions;
     ha.mode = actions ? (deterministic ? 2 : 1) : 2;
@@ -363,14 +379,26 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
         x = wk.out;
         ldx = H;
     }
+    if (e->d.action_dist == HAB_DIST_GAUSSIAN) {
+        GaussHeadsArgs ga;
+        ga.B = B; ga.H = H; ga.A = e->d.num_actions; ga.K = e->head_K; ga.flags = e->d.gauss_flags; ga.mode = 0;
+        ga.min_std = e->d.gauss_min_std; ga.max_std = e->d.gauss_max_std;
+        ga.feats = x; ga.feats_ld = ldx; ga.w = e->p(e->i_aw); ga.b = e->p(e->i_ab);
+        ga.std_param = e->i_astd >= 0 ? e->p(e->i_astd) : nullptr; ga.w_critic = e->p(e->i_cw); ga.b_critic = e->p(e->i_cb);
+        ga.actions_in = reinterpret_cast<const float*>(actions); ga.rows = rows; ga.noise = nullptr; ga.actions_out = nullptr;
+        ga.value = value ? value : W + e->w_value; ga.logp = log_prob ? log_prob : W + e->w_logp;
+        ga.entropy = entropy ? entropy : W + e->w_ent; ga.saved = W + e->w_gsaved;
+        HAB_TRY(gauss_heads_forward(ga, stream));
+    } else {
     HeadsArgs ha;
-    ha.B = B; ha.H = H; ha.A = e->d.num_actions; ha.mode = 0;
-    ha.feats = x; ha.feats_ld = ldx; ha.w_actor = e->p(e->i_aw); ha.b_actor = e->p(e->i_ab); ha.w_critic = e->p(e->i_cw); ha.b_critic = e->p(e->i_cb);
-    ha.actions_in = actions; ha.rows = rows; ha.noise = nullptr; ha.actions_out = nullptr;
-    ha.value = value ? value : W + e->w_value; ha.logp = log_prob ? log_prob : W + e->w_logp;
-    ha.entropy = entropy ? entropy : W + e->w_ent;
-    ha.probs = W + e->w_probs; ha.logits_n = W + e->w_logitsn;
-    HAB_TRY(heads_forward(ha, stream));
+        ha.B = B; ha.H = H; ha.A = e->d.num_actions; ha.mode = 0;
+        ha.feats = x; ha.feats_ld = ldx; ha.w_actor = e->p(e->i_aw); ha.b_actor = e->p(e->i_ab); ha.w_critic = e->p(e->i_cw); ha.b_critic = e->p(e->i_cb);
+        ha.actions_in = actions; ha.rows = rows; ha.noise = nullptr; ha.actions_out = nullptr;
+        ha.value = value ? value : W + e->w_value; ha.logp = log_prob ? log_prob : W + e->w_logp;
+        ha.entropy = entropy ? entropy : W + e->w_ent;
+        ha.probs = W + e->w_probs; ha.logits_n = W + e->w_logitsn;
+        HAB_TRY(heads_forward(ha, stream));
+    }
     e->last_B = B;
     e->last_n = pack->env_first_frame ? 0 : n;  // (no "last n frames = final step of every env" in a VER minibatch)
     e->last_masks = masks;
@@ -407,15 +435,29 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
     pk.frag_env = pack->frag_env; pk.frag_start = pack->frag_start; pk.P = pack->P; pk.F = pack->F; pk.max_len = pack->max_len;
     pk.n_envs = e->last_n;
     const float* feats = W + e->w_out[L - 1];
+    if (e->d.action_dist == HAB_DIST_GAUSSIAN) {
+        const int K = e->head_K;
+        GaussHeadsBwdArgs gb;
+        gb.B = B; gb.H = H; gb.A = A; gb.K = K; gb.d_value = d_value; gb.d_logp = d_log_prob; gb.d_entropy = d_entropy;
+        gb.actions = reinterpret_cast<const float*>(actions); gb.rows = rows; gb.saved = W + e->w_gsaved;
+        gb.w = e->p(e->i_aw); gb.w_critic = e->p(e->i_cw); gb.dfeat = W + e->w_dfeat; gb.dz = W + e->w_dzv; gb.dv_out = W + e->w_dv;
+        HAB_TRY(gauss_heads_backward(gb, stream));
+        HAB_TRY(linear_wgrad(W + e->w_dzv, 8, feats, H, e->g(e->i_aw), H, B, K, H, 0, 0, 0, ws, e->ws_floats, stream));
+        HAB_TRY(colsum(W + e->w_dzv, 8, B, K, e->g(e->i_ab), 0, ws, e->ws_floats, stream));
+        if (e->i_astd >= 0) HAB_TRY(colsum(W + e->w_dzv + A, 8, B, A, e->g(e->i_astd), 0, ws, e->ws_floats, stream));
+        HAB_TRY(linear_wgrad(W + e->w_dv, 1, feats, H, e->g(e->i_cw), H, B, 1, H, 0, 0, 0, ws, e->ws_floats, stream));
+        HAB_TRY(colsum(W + e->w_dv, 1, B, 1, e->g(e->i_cb), 0, ws, e->ws_floats, stream));
+    } else {
     HeadsBwdArgs hb;
-    hb.B = B; hb.H = H; hb.A = A; hb.d_value = d_value; hb.d_logp = d_log_prob; hb.d_entropy = d_entropy;
-    hb.actions = actions; hb.rows = rows; hb.probs = W + e->w_probs; hb.logits_n = W + e->w_logitsn;
-    hb.w_actor = e->p(e->i_aw); hb.w_critic = e->p(e->i_cw); hb.dfeat = W + e->w_dfeat; hb.dzv = W + e->w_dzv; hb.dv_out = W + e->w_dv;
-    HAB_TRY(heads_backward(hb, stream));
-    HAB_TRY(linear_wgrad(W + e->w_dzv, 8, feats, H, e->g(e->i_aw), H, B, A, H, 0, 0, 0, ws, e->ws_floats, stream));
-    HAB_TRY(linear_wgrad(W + e->w_dv, 1, feats, H, e->g(e->i_cw), H, B, 1, H, 0, 0, 0, ws, e->ws_floats, stream));
-    HAB_TRY(colsum(W + e->w_dzv, 8, B, A, e->g(e->i_ab), 0, ws, e->ws_floats, stream));
-    HAB_TRY(colsum(W + e->w_dv, 1, B, 1, e->g(e->i_cb), 0, ws, e->ws_floats, stream));
+        hb.B = B; hb.H = H; hb.A = A; hb.d_value = d_value; hb.d_logp = d_log_prob; hb.d_entropy = d_entropy;
+        hb.actions = actions; hb.rows = rows; hb.probs = W + e->w_probs; hb.logits_n = W + e->w_logitsn;
+        hb.w_actor = e->p(e->i_aw); hb.w_critic = e->p(e->i_cw); hb.dfeat = W + e->w_dfeat; hb.dzv = W + e->w_dzv; hb.dv_out = W + e->w_dv;
+        HAB_TRY(heads_backward(hb, stream));
+        HAB_TRY(linear_wgrad(W + e->w_dzv, 8, feats, H, e->g(e->i_aw), H, B, A, H, 0, 0, 0, ws, e->ws_floats, stream));
+        HAB_TRY(linear_wgrad(W + e->w_dv, 1, feats, H, e->g(e->i_cw), H, B, 1, H, 0, 0, 0, ws, e->ws_floats, stream));
+        HAB_TRY(colsum(W + e->w_dzv, 8, B, A, e->g(e->i_ab), 0, ws, e->ws_floats, stream));
+        HAB_TRY(colsum(W + e->w_dv, 1, B, 1, e->g(e->i_cb), 0, ws, e->ws_floats, stream));
+    }
     // recurrent layers, top down
     const float* dout = W + e->w_dfeat;
     for (int l = L - 1; l >= 0; --l) {

@@ -47,6 +47,7 @@ struct ResNetPlan {
     std::vector<RnConv> convs;
     std::vector<RnBlock> blocks;
     RnConv comp;
+    int i_embb = -1;
     int i_fcw = -1, i_fcb = -1, i_emb = -1, i_tgw = -1, i_tgb = -1, i_mean = -1, i_var = -1, i_count = -1;
     int i_objw = -1, i_gpsw = -1, i_gpsb = -1, i_cmpw = -1, i_cmpb = -1;
     int c_rgb = -1, c_depth = -1, c_sem = -1;  // first channel of each visual key in the concatenated encoder input
@@ -108,7 +109,14 @@ int build_resnet(hab_policy* e) {
     const int* layers = bottleneck ? L50 : L18;
 
     // ---- parameter table in the reference's state_dict order (resnet_policy.py:389-396,454-456 first) ----
-    r->i_emb = add_param(e, "net.prev_action_embedding.weight", {d.num_actions + 1, 32});
+    const bool gauss = d.action_dist == HAB_DIST_GAUSSIAN;
+    if (gauss && (d.num_actions > 4)) return HAB_ERR_UNSUPPORTED;
+    if (gauss) {  // nn.Linear(num_actions, 32) on masks * prev_actions (resnet_policy.py:424-428)
+        r->i_emb = add_param(e, "net.prev_action_embedding.weight", {32, d.num_actions});
+        r->i_embb = add_param(e, "net.prev_action_embedding.bias", {32});
+    } else {
+        r->i_emb = add_param(e, "net.prev_action_embedding.weight", {d.num_actions + 1, 32});
+    }
     r->nslots = 1;
     if (d.goal_dim == 2) {
         r->i_tgw = add_param(e, "net.tgt_embeding.weight", {32, 3});
@@ -194,8 +202,15 @@ int build_resnet(hab_policy* e) {
         e->i_bih.push_back(add_param(e, rn + "bias_ih" + sfx, {e->G_ * H}));
         e->i_bhh.push_back(add_param(e, rn + "bias_hh" + sfx, {e->G_ * H}));
     }
-    e->i_aw = add_param(e, "action_distribution.linear.weight", {d.num_actions, H});
-    e->i_ab = add_param(e, "action_distribution.linear.bias", {d.num_actions});
+    if (gauss) {  // GaussianNet (utils/common.py:124-149): the std parameter is registered before the linear layer
+        if (d.gauss_flags & HAB_GAUSS_USE_STD_PARAM) e->i_astd = add_param(e, "action_distribution.std", {d.num_actions});
+        e->head_K = (d.gauss_flags & HAB_GAUSS_USE_STD_PARAM) ? d.num_actions : 2 * d.num_actions;
+        e->i_aw = add_param(e, "action_distribution.mu_maybe_std.weight", {e->head_K, H});
+        e->i_ab = add_param(e, "action_distribution.mu_maybe_std.bias", {e->head_K});
+    } else {
+        e->i_aw = add_param(e, "action_distribution.linear.weight", {d.num_actions, H});
+        e->i_ab = add_param(e, "action_distribution.linear.bias", {d.num_actions});
+    }
     e->i_cw = add_param(e, "critic.fc.weight", {1, H});
     e->i_cb = add_param(e, "critic.fc.bias", {1});
 
@@ -261,6 +276,7 @@ int build_resnet(hab_policy* e) {
     e->w_probs = wk.take(B * 8); e->w_logitsn = wk.take(B * 8); e->w_dzv = wk.take(B * 8); e->w_dv = wk.take(B);
     e->w_dfeat = wk.take(B * H); e->w_scratch = wk.take(3 * F * H);
     e->w_value = wk.take(B); e->w_logp = wk.take(B); e->w_ent = wk.take(B);
+    if (gauss) e->w_gsaved = wk.take(B * 16);
     e->w_hmask = wk.take((int64_t)2 * d.rnn_layers * d.max_envs * H);
     e->w_gistep = wk.take((int64_t)d.max_envs * e->G_ * H);
     e->w_step_h = wk.take((int64_t)d.max_envs * H * 2);
@@ -307,7 +323,8 @@ static int fill_embed_slots(hab_policy* e, const hab_obs* obs, EmbedSlot* sl, bo
     if (d.num_object_categories > 0) ok &= add(EMB_TOKEN, obs->objectgoal, r->i_objw, -1, d.num_object_categories);
     if (d.has_compass) ok &= add(EMB_COSSIN, obs->compass, r->i_cmpw, r->i_cmpb, 0);
     if (d.has_gps) ok &= add(EMB_LIN2, obs->gps, r->i_gpsw, r->i_gpsb, 0);
-    ok &= add(EMB_PREV, obs->prev_actions, r->i_emb, -1, d.num_actions + 1);
+    if (d.action_dist == HAB_DIST_GAUSSIAN) ok &= add(EMB_PREVLIN, obs->prev_actions, r->i_emb, r->i_embb, d.num_actions);
+    else ok &= add(EMB_PREV, obs->prev_actions, r->i_emb, -1, d.num_actions + 1);
     return (ok && n == r->nslots) ? HAB_OK : HAB_ERR_ARG;
 }
 

@@ -116,6 +116,109 @@ int heads_backward(const HeadsBwdArgs& a, hipStream_t stream) {
     return HAB_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Gaussian action head.  One wavefront per frame: K + 1 dot products over the recurrent features, then per action dimension
+//   mu = tanh(z) | z;   raw = std_param | z[A + a];   raw = clamp(raw, min, max);   std = exp(raw) | raw;   std = softplus(std) | std
+//   x = mu + std * eps (rsample) | mu | given;   log_prob = sum_a -(x - mu)^2 / (2 std^2) - log std - log sqrt(2 pi)
+//   entropy = sum_a 0.5 + 0.5 log(2 pi) + log std            (torch.distributions.Normal, in its operation order)
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int GA = 4;  // max action dimensions of the Gaussian head
+
+__device__ inline float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // F.softplus (beta 1, threshold 20)
+
+__global__ void __launch_bounds__(256) gauss_heads_fwd_kernel(const GaussHeadsArgs a) {
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (f >= a.B) return;
+    const float* x = a.feats + (size_t)f * (a.feats_ld ? a.feats_ld : a.H);
+    float acc[2 * GA + 1];
+#pragma unroll
+    for (int k = 0; k <= 2 * GA; ++k) acc[k] = 0.f;
+    for (int j = lane; j < a.H; j += 64) {
+        const float xv = x[j];
+#pragma unroll
+        for (int k = 0; k < 2 * GA; ++k)
+            if (k < a.K) acc[k] += xv * a.w[(size_t)k * a.H + j];
+        acc[2 * GA] += xv * a.w_critic[j];
+    }
+#pragma unroll
+    for (int k = 0; k <= 2 * GA; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane != 0) return;
+    const float LOG_SQRT_2PI = 0.91893853320467267f;  // math.log(math.sqrt(2 * math.pi))
+    float logp = 0.f, ent = 0.f;
+    for (int d = 0; d < a.A; ++d) {
+        const float zmu = acc[d] + a.b[d];
+        const float mu = (a.flags & HAB_GAUSS_TANH_MU) ? tanhf(zmu) : zmu;
+        const float dmu = (a.flags & HAB_GAUSS_TANH_MU) ? 1.0f - mu * mu : 1.0f;
+        const float raw = a.std_param ? a.std_param[d] : acc[a.A + d] + a.b[a.A + d];
+        float sd = raw, dsd = 1.0f;
+        if (a.flags & HAB_GAUSS_CLAMP_STD) {
+            if (!(raw >= a.min_std && raw <= a.max_std)) dsd = 0.0f;  // torch.clamp passes the gradient inside [min, max]
+            sd = fminf(fmaxf(raw, a.min_std), a.max_std);
+        }
+        if (a.flags & HAB_GAUSS_USE_LOG_STD) { sd = expf(sd); dsd *= sd; }
+        if (a.flags & HAB_GAUSS_USE_SOFTPLUS) { dsd *= 1.0f / (1.0f + expf(-sd)); sd = softplusf_(sd); }
+        float xv;
+        if (a.mode == 0) xv = a.actions_in[(size_t)(a.rows ? a.rows[f] : f) * a.A + d];
+        else {
+            xv = a.mode == 1 ? mu + sd * a.noise[(size_t)f * a.A + d] : mu;
+            a.actions_out[(size_t)f * a.A + d] = xv;
+        }
+        const float var = sd * sd, diff = xv - mu;
+        logp += -(diff * diff) / (2.0f * var) - logf(sd) - LOG_SQRT_2PI;
+        ent += 0.5f + LOG_SQRT_2PI + logf(sd);
+        if (a.saved) {
+            float* sv = a.saved + (size_t)f * 16;
+            sv[d] = mu; sv[4 + d] = sd; sv[8 + d] = dmu; sv[12 + d] = dsd;
+        }
+    }
+    a.value[f] = acc[2 * GA] + a.b_critic[0];
+    a.logp[f] = logp;
+    if (a.entropy) a.entropy[f] = ent;
+}
+int gauss_heads_forward(const GaussHeadsArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.A <= 0 || a.A > GA || (a.K != a.A && a.K != 2 * a.A) || !a.feats || !a.value || !a.logp || !a.w || !a.b) return HAB_ERR_ARG;
+    if ((a.K == a.A) != (a.std_param != nullptr)) return HAB_ERR_ARG;
+    if (a.mode == 0 ? !a.actions_in : (!a.actions_out || (a.mode == 1 && !a.noise))) return HAB_ERR_ARG;
+    gauss_heads_fwd_kernel<<<cdiv(a.B, 4), 256, 0, stream>>>(a);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// dL/dmu = g_lp (x - mu) / std^2;  dL/dstd = g_lp ((x - mu)^2 / std^3 - 1 / std) + g_ent / std;  chained to the linear outputs
+__global__ void __launch_bounds__(256) gauss_heads_bwd_kernel(const GaussHeadsBwdArgs a) {
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (f >= a.B) return;
+    const float dlp = a.d_logp[f], den = a.d_entropy[f], dv = a.d_value[f];
+    const float* sv = a.saved + (size_t)f * 16;
+    float dz[2 * GA];
+#pragma unroll
+    for (int k = 0; k < 2 * GA; ++k) dz[k] = 0.f;
+    for (int d = 0; d < a.A; ++d) {
+        const float mu = sv[d], sd = sv[4 + d];
+        const float xv = a.actions[(size_t)(a.rows ? a.rows[f] : f) * a.A + d];
+        const float diff = xv - mu, var = sd * sd;
+        dz[d] = dlp * (diff / var) * sv[8 + d];
+        dz[a.A + d] = (dlp * (diff * diff / (var * sd) - 1.0f / sd) + den / sd) * sv[12 + d];
+    }
+    if (lane == 0) {
+        for (int k = 0; k < 8; ++k) a.dz[(size_t)f * 8 + k] = k < 2 * a.A ? dz[k] : 0.f;
+        a.dv_out[f] = dv;
+    }
+    for (int j = lane; j < a.H; j += 64) {
+        float s = dv * a.w_critic[j];
+        for (int k = 0; k < a.K; ++k) s += dz[k] * a.w[(size_t)k * a.H + j];
+        a.dfeat[(size_t)f * a.H + j] = s;
+    }
+}
+int gauss_heads_backward(const GaussHeadsBwdArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.A <= 0 || a.A > GA || !a.saved || !a.actions || !a.dz || !a.dfeat) return HAB_ERR_ARG;
+    gauss_heads_bwd_kernel<<<cdiv(a.B, 4), 256, 0, stream>>>(a);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
 // dst[f][col0 + c] = src[rows[f]][c]  (c < ncols), zero-fills pad columns [col0+ncols, col0+ncols+npad)
 __global__ void gather_cols_kernel(const float* __restrict__ src, int src_ld, const int* __restrict__ rows, float* __restrict__ dst,
                                    int dst_ld, int col0, int ncols, int npad, int B) {

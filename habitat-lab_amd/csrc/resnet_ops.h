@@ -30,7 +30,8 @@ enum { EMB_POLAR = 0,   // pointgoal_with_gps_compass (rho, phi) -> Linear(3,32)
        EMB_TOKEN = 1,   // objectgoal id -> Embedding(n_categories, 32)                                          :715-717
        EMB_COSSIN = 2,  // compass x -> Linear(2,32)([cos x, sin x])                                             :719-729
        EMB_LIN2 = 3,    // gps (x, y) -> Linear(2,32)                                                            :731-734
-       EMB_PREV = 4 };  // previous action -> Embedding(A+1, 32)(mask ? a + 1 : 0)                               :747-753
+       EMB_PREV = 4,    // previous action -> Embedding(A+1, 32)(mask ? a + 1 : 0)                               :747-753
+       EMB_PREVLIN = 5 };  // continuous previous action (A <= 4 floats) -> Linear(A, 32)(mask * a); ntok carries A      :754-757
 constexpr int EMB_MAX_SLOTS = 5;
 struct EmbedSlot {
     int kind;
@@ -40,7 +41,9 @@ struct EmbedSlot {
     float* dw; float* db;  // gradients (backward only)
     int ntok;
 };
-inline int emb_nfeat(int kind) { return kind == EMB_POLAR ? 3 : (kind == EMB_COSSIN || kind == EMB_LIN2) ? 2 : 0; }
+__host__ __device__ inline int emb_nfeat(const EmbedSlot& sl) {
+    return sl.kind == EMB_POLAR ? 3 : (sl.kind == EMB_COSSIN || sl.kind == EMB_LIN2) ? 2 : sl.kind == EMB_PREVLIN ? sl.ntok : 0;
+}
 struct EmbedArgs {
     EmbedSlot slot[EMB_MAX_SLOTS];
     int nslots;

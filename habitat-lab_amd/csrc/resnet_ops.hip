@@ -1009,6 +1009,11 @@ __device__ inline void emb_features(const EmbedSlot& sl, int r, int masked, floa
             v[0] = g[0]; v[1] = g[1];
             break;
         }
+        case EMB_PREVLIN: {
+            const float* g = reinterpret_cast<const float*>(sl.in) + (size_t)r * sl.ntok;
+            for (int d = 0; d < sl.ntok; ++d) v[d] = masked ? g[d] : 0.f;  // masks * prev_actions.float()
+            break;
+        }
         default: v[3] = masked ? (float)(reinterpret_cast<const int64_t*>(sl.in)[r] + 1) : 0.f; break;
     }
 }
@@ -1023,9 +1028,13 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(const EmbedArgs a) {
         const EmbedSlot& sl = a.slot[s];
         float v[4];
         emb_features(sl, r, m, v);
-        const int nf = sl.kind == EMB_POLAR ? 3 : (sl.kind == EMB_COSSIN || sl.kind == EMB_LIN2) ? 2 : 0;
+        const int nf = emb_nfeat(sl);
         float y;
-        if (nf == 3) y = (sl.w[j * 3] * v[0] + sl.w[j * 3 + 1] * v[1]) + sl.w[j * 3 + 2] * v[2] + sl.b[j];
+        if (sl.kind == EMB_PREVLIN) {
+            y = 0.f;
+            for (int d = 0; d < nf; ++d) y += sl.w[j * nf + d] * v[d];
+            y += sl.b[j];
+        } else if (nf == 3) y = (sl.w[j * 3] * v[0] + sl.w[j * 3 + 1] * v[1]) + sl.w[j * 3 + 2] * v[2] + sl.b[j];
         else if (nf == 2) y = sl.w[j * 2] * v[0] + sl.w[j * 2 + 1] * v[1] + sl.b[j];
         else y = sl.w[(size_t)(int)v[3] * 32 + j];
         o[s * 32 + j] = y;
@@ -1035,7 +1044,7 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(const EmbedArgs a) {
 int embed_forward(const EmbedArgs& a, hipStream_t s) {
     if (!a.out || a.B <= 0 || a.nslots <= 0 || a.nslots > EMB_MAX_SLOTS) return HAB_ERR_ARG;
     for (int i = 0; i < a.nslots; ++i)
-        if (!a.slot[i].in || !a.slot[i].w || (emb_nfeat(a.slot[i].kind) && !a.slot[i].b)) return HAB_ERR_ARG;
+        if (!a.slot[i].in || !a.slot[i].w || (emb_nfeat(a.slot[i]) && !a.slot[i].b)) return HAB_ERR_ARG;
     embed_fwd_kernel<<<cdiv(a.B, 8), 256, 0, s>>>(a);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
@@ -1048,7 +1057,7 @@ __global__ void __launch_bounds__(256) embed_bwd_stage1(const EmbedBwdArgs a, co
     __shared__ float sm[256];
     const int b = blockIdx.x, j = threadIdx.x & 31, fl = threadIdx.x >> 5;
     const int s = rm.slot[b], sub = rm.sub[b];
-    const int nf = a.slot[s].kind == EMB_POLAR ? 3 : (a.slot[s].kind == EMB_COSSIN || a.slot[s].kind == EMB_LIN2) ? 2 : 0;
+    const int nf = emb_nfeat(a.slot[s]);
     const int f0 = blockIdx.y * frames_per_chunk, f1 = min(a.B, f0 + frames_per_chunk);
     float acc = 0.f;
     for (int f = f0 + fl; f < f1; f += 8) {
@@ -1071,7 +1080,7 @@ __global__ void __launch_bounds__(32) embed_bwd_stage2(const EmbedBwdArgs a, con
     float acc = 0.f;
     for (int c = 0; c < chunks; ++c) acc += partial[((size_t)c * rm.n + b) * 32 + j];
     const EmbedSlot& sl = a.slot[rm.slot[b]];
-    const int nf = sl.kind == EMB_POLAR ? 3 : (sl.kind == EMB_COSSIN || sl.kind == EMB_LIN2) ? 2 : 0;
+    const int nf = emb_nfeat(sl);
     const int sub = rm.sub[b];
     if (nf == 0) sl.dw[(size_t)sub * 32 + j] = acc;
     else if (sub < nf) sl.dw[j * nf + sub] = acc;
@@ -1082,7 +1091,7 @@ int embed_backward(const EmbedBwdArgs& a, float* ws, size_t ws_floats, hipStream
     EmbRowMap rm;
     rm.n = 0;
     for (int i = 0; i < a.nslots; ++i) {
-        const int nf = emb_nfeat(a.slot[i].kind);
+        const int nf = emb_nfeat(a.slot[i]);
         const int rows = nf ? nf + 1 : a.slot[i].ntok;
         if (!a.slot[i].dw || (nf && !a.slot[i].db) || rows <= 0 || rm.n + rows > 64) return HAB_ERR_ARG;
         for (int q = 0; q < rows; ++q) { rm.slot[rm.n] = i; rm.sub[rm.n] = q; ++rm.n; }

@@ -354,7 +354,11 @@ __global__ void __launch_bounds__(1024) ppo_loss_kernel(const float* __restrict_
                                                         float* __restrict__ d_value, float* __restrict__ d_logp,
                                                         float* __restrict__ d_entropy, float* __restrict__ out,
                                                         const float* __restrict__ is_coeffs, const uint8_t* __restrict__ is_stale,
-                                                        const int64_t* __restrict__ policy_version, long long current_version) {
+                                                        const int64_t* __restrict__ policy_version, long long current_version,
+                                                        const float* __restrict__ log_alpha, float entropy_threshold) {
+    // adaptive entropy penalty (LagrangeInequalityCoefficient, utils/common.py:749-806, greater_than form): the coefficient is
+    // alpha = exp(log_alpha), a device scalar trained by its own Adam step; loss term alpha * (threshold - [ent]) - [alpha] * ent
+    if (log_alpha) entropy_coef = expf(log_alpha[0]);
     __shared__ float red[16][10];
     __shared__ float redmm[16][8];
     const int tid = threadIdx.x;
@@ -432,6 +436,11 @@ __global__ void __launch_bounds__(1024) ppo_loss_kernel(const float* __restrict_
         const float vl = t[0] * invB, al = t[1] * invB, en = t[2] * invB;
         out[0] = vl; out[1] = al; out[2] = en;
         out[3] = value_coef * vl + al - entropy_coef * en;
+        if (log_alpha) {
+            out[3] = value_coef * vl + al + (entropy_coef * (entropy_threshold - en) - entropy_coef * en);
+            out[20] = entropy_coef * (entropy_threshold - en);  // d loss / d log_alpha
+            out[21] = entropy_coef;                             // learner metric `entropy_coef`
+        }
         out[4] = mn_v; out[5] = t[3] * invB; out[6] = mx_v;
         out[7] = mn_r; out[8] = t[4] * invB; out[9] = mx_r;
         out[10] = t[5] * invB; out[11] = (float)B;
@@ -447,7 +456,7 @@ extern "C" int hab_ppo_loss(const float* values, const float* logp, const float*
         return HAB_ERR_ARG;
     ppo_loss_kernel<<<1, 1024, 0, stream>>>(values, logp, entropy, old_logp, adv, old_values, returns, rows, B, clip_param,
                                             value_loss_coef, entropy_coef, use_clipped_value_loss, d_value, d_logp,
-                                            d_entropy, out12, nullptr, nullptr, nullptr, 0);
+                                            d_entropy, out12, nullptr, nullptr, nullptr, 0, nullptr, 0.f);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -456,14 +465,42 @@ extern "C" int hab_ppo_loss_ver(const float* values, const float* logp, const fl
                                 const float* adv, const float* old_values, const float* returns, const int* rows, int B,
                                 float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
                                 const float* is_coeffs, const uint8_t* is_stale, const int64_t* policy_version,
-                                int64_t current_policy_version, float* d_value, float* d_logp, float* d_entropy, float* out20,
-                                hipStream_t stream) {
+                                int64_t current_policy_version, const float* log_alpha, float entropy_threshold, float* d_value,
+                                float* d_logp, float* d_entropy, float* out20, hipStream_t stream) {
     if (B <= 0 || !values || !logp || !entropy || !old_logp || !adv || !old_values || !returns || !d_value || !d_logp ||
         !d_entropy || !out20)
         return HAB_ERR_ARG;
     ppo_loss_kernel<<<1, 1024, 0, stream>>>(values, logp, entropy, old_logp, adv, old_values, returns, rows, B, clip_param,
                                             value_loss_coef, entropy_coef, use_clipped_value_loss, d_value, d_logp,
-                                            d_entropy, out20, is_coeffs, is_stale, policy_version, (long long)current_policy_version);
+                                            d_entropy, out20, is_coeffs, is_stale, policy_version, (long long)current_policy_version,
+                                            log_alpha, entropy_threshold);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// Adam step + projection of the adaptive entropy coefficient's log_alpha (one scalar; rl/ppo/ppo.py:112-137 puts it in the same
+// optimiser as the policy, :373-375 projects it into [log alpha_min, log alpha_max] after every step).  torch.optim.Adam arithmetic.
+__global__ void lagrange_adam_kernel(float* __restrict__ log_alpha, float* __restrict__ m, float* __restrict__ v,
+                                     const float* __restrict__ grad, float gscale, float lr, float b1, float b2, float eps, int step,
+                                     float lo, float hi, float* __restrict__ alpha_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float g = grad[0] * gscale;
+    const float mm = m[0] + (g - m[0]) * (1.0f - b1);
+    const float vv = v[0] * b2 + (1.0f - b2) * g * g;
+    m[0] = mm; v[0] = vv;
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    const float denom = sqrtf(vv) / sqrtf(bc2) + eps;
+    const float p = log_alpha[0] - (lr / bc1) * (mm / denom);
+    const float pc = fminf(fmaxf(p, lo), hi);
+    log_alpha[0] = pc;
+    if (alpha_out) alpha_out[0] = expf(pc);  // learner metric `entropy_coef`, read after the step (ppo.py:276-279)
+}
+extern "C" int hab_lagrange_adam_step(float* log_alpha, float* exp_avg, float* exp_avg_sq, const float* grad, float grad_scale, float lr,
+                                      float beta1, float beta2, float eps, int step, float log_alpha_min, float log_alpha_max,
+                                      float* alpha_out, hipStream_t stream) {
+    if (!log_alpha || !exp_avg || !exp_avg_sq || !grad || step <= 0) return HAB_ERR_ARG;
+    lagrange_adam_kernel<<<1, 64, 0, stream>>>(log_alpha, exp_avg, exp_avg_sq, grad, grad_scale, lr, beta1, beta2, eps, step, log_alpha_min,
+                                               log_alpha_max, alpha_out);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }

@@ -25,7 +25,11 @@ class PolicyDesc(C.Structure):
     _fields_ = [(n, c_int32) for n in (
         "arch", "backbone", "baseplanes", "normalize_visual_inputs", "rnn_type", "rnn_layers", "hidden", "num_actions",
         "H", "W", "has_rgb", "has_depth", "goal_dim", "max_frames", "max_envs", "visual_order", "has_semantic",
-        "num_object_categories", "has_compass", "has_gps")]
+        "num_object_categories", "has_compass", "has_gps", "action_dist", "gauss_flags")] + [("gauss_min_std", c_float),
+                                                                                                ("gauss_max_std", c_float)]
+
+
+GAUSS_TANH_MU, GAUSS_USE_LOG_STD, GAUSS_USE_SOFTPLUS, GAUSS_USE_STD_PARAM, GAUSS_CLAMP_STD = 1, 2, 4, 8, 16  # HAB_GAUSS_*
 
 
 class Obs(C.Structure):
@@ -54,8 +58,9 @@ SIGNATURES = {
     "hab_compute_returns": (c_int, [vp, vp, vp, vp, vp, c_int, c_int, c_float, c_float, c_int, c_int, vp]),
     "hab_advantages": (c_int, [vp, vp, vp, c_int, c_int, vp, vp, vp]),
     "hab_ppo_loss": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_float, c_float, c_float, c_int, vp, vp, vp, vp, vp]),
-    "hab_ppo_loss_ver": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_float, c_float, c_float, c_int, vp, vp, vp, c_int64, vp, vp, vp,
-                                 vp, vp]),
+    "hab_ppo_loss_ver": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_float, c_float, c_float, c_int, vp, vp, vp, c_int64, vp, c_float,
+                                 vp, vp, vp, vp, vp]),
+    "hab_lagrange_adam_step": (c_int, [vp, vp, vp, vp, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_float, vp, vp]),
     "hab_ver_compute_returns": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_double, c_double, vp]),
     "hab_ver_is_coeffs": (c_int, [vp, c_int, c_int, c_int, vp, vp, vp]),
     "hab_clip_adam_step": (c_int, [vp, vp, vp, vp, c_size_t, vp, c_int, c_float, c_float, c_float, c_float, c_float,

@@ -50,15 +50,29 @@ class Dict(Space):
     def __repr__(self): return f"Dict({dict(self.spaces)})"
 
 
+def is_continuous_action_space(action_space) -> bool:
+    """utils/common.py:679-697: a Box action space is continuous, Discrete is not."""
+    if hasattr(action_space, "n"):
+        return False
+    if getattr(action_space, "low", None) is not None and getattr(action_space, "shape", None) is not None:
+        return True
+    raise NotImplementedError(f"Unknown action space {action_space}. Is neither continuous nor discrete")
+
+
 def get_num_actions(action_space) -> int:
-    """utils/common.py:729-746 for the Discrete nav action spaces."""
+    """utils/common.py:729-746: Discrete(n) -> n, a 1-D Box -> its length."""
     if hasattr(action_space, "n"):
         return int(action_space.n)
+    if is_continuous_action_space(action_space):
+        assert len(action_space.shape) == 1, f"shape was {action_space.shape} but was expecting a 1D action"
+        return int(action_space.shape[0])
     raise NotImplementedError(f"unsupported action space {action_space}")
 
 
 def get_action_space_info(action_space):
-    """utils/common.py:701-726 -> (shape, is_discrete); Discrete pointnav -> ((1,), True)."""
+    """utils/common.py:701-726 -> (shape, is_discrete); Discrete pointnav -> ((1,), True), Box(A,) -> ((A,), False)."""
     if hasattr(action_space, "n"):
         return (1,), True
+    if is_continuous_action_space(action_space):
+        return (get_num_actions(action_space),), False
     raise NotImplementedError(f"unsupported action space {action_space}")

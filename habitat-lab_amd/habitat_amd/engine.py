@@ -111,13 +111,16 @@ class PolicyEngine:
     def __init__(self, *, arch="simple_cnn", backbone=18, baseplanes=32, normalize_visual_inputs=False, rnn_type="GRU",
                  rnn_layers=1, hidden=512, num_actions=4, H=256, W=256, has_rgb=True, has_depth=True, goal_dim=2,
                  max_frames=4096, max_envs=64, device="cuda", with_grads=True, visual_order=("rgb", "depth", "semantic"),
-                 has_semantic=False, num_object_categories=0, has_compass=False, has_gps=False):
+                 has_semantic=False, num_object_categories=0, has_compass=False, has_gps=False, action_dist="categorical",
+                 gauss_flags=0, gauss_min_std=0.0, gauss_max_std=0.0):
         L = _lib.lib()
         self.L = L
         d = PolicyDesc(ARCH[arch], backbone, baseplanes, int(normalize_visual_inputs), RNN[rnn_type.upper()], rnn_layers, hidden,
                        num_actions, H, W, int(has_rgb), int(has_depth), goal_dim, max_frames, max_envs,
                        sum({"rgb": 1, "depth": 2, "semantic": 3}[k] << (2 * i) for i, k in enumerate(visual_order)), int(has_semantic),
-                       int(num_object_categories), int(has_compass), int(has_gps))
+                       int(num_object_categories), int(has_compass), int(has_gps), {"categorical": 0, "gaussian": 1}[action_dist],
+                       int(gauss_flags), float(gauss_min_std), float(gauss_max_std))
+        self.action_dist = action_dist
         self.desc = d
         h = C.c_void_p()
         check(L.hab_policy_create(C.byref(d), C.byref(h)), "hab_policy_create")

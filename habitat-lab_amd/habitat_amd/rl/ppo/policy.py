@@ -147,6 +147,7 @@ class NetPolicy(nn.Module, Policy):
         nn.Module.__init__(self)
         self.dim_actions = get_num_actions(action_space)
         self._engine_kwargs = dict(engine_kwargs, num_actions=self.dim_actions)
+        self.action_distribution_type = engine_kwargs.get("action_dist", "categorical")
         self.engine: Optional[PolicyEngine] = None
         self.device = torch.device("cpu")
         self._hidden = engine_kwargs["hidden"]
@@ -294,8 +295,12 @@ class NetPolicy(nn.Module, Policy):
         return rgb, depth, goal, extra
 
     def draw_noise(self, n: int) -> torch.Tensor:
-        """Exp(1) noise from the CPU generator -- the draw torch.multinomial would make (utils/common.py:64-68)."""
-        q = torch.empty(n, self.dim_actions).exponential_(1)
+        """The draw the reference's sampling makes from the CPU generator: Exp(1) noise for torch.multinomial
+        (utils/common.py:64-68), N(0, 1) for CustomNormal.rsample (:99-103, torch.distributions.Normal.rsample)."""
+        if self.action_distribution_type == "gaussian":
+            q = torch.empty(n, self.dim_actions).normal_()
+        else:
+            q = torch.empty(n, self.dim_actions).exponential_(1)
         return q.pin_memory().to(self.device, non_blocking=True) if self.device.type == "cuda" else q
 
     # ---- reference API --------------------------------------------------------------------------
@@ -306,7 +311,9 @@ class NetPolicy(nn.Module, Policy):
         n = rnn_hidden_states.shape[0]
         dev = self.device
         if out is None:
-            out = dict(values=torch.empty(n, 1, device=dev), actions=torch.empty(n, 1, dtype=torch.long, device=dev),
+            acts = (torch.empty(n, self.dim_actions, device=dev) if self.action_distribution_type == "gaussian"
+                    else torch.empty(n, 1, dtype=torch.long, device=dev))
+            out = dict(values=torch.empty(n, 1, device=dev), actions=acts,
                        action_log_probs=torch.empty(n, 1, device=dev),
                        rnn_hidden_states=torch.empty(n, self.num_recurrent_layers, self._hidden, device=dev))
         if not deterministic and exp_noise is None:
@@ -446,14 +453,18 @@ class PointNavBaselinePolicy(NetPolicy):
 
 
 def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, baseplanes, H, W, normalize, has_goal=True, n_obj=0,
-                 has_gps=False, has_compass=False):
+                 has_gps=False, has_compass=False, gauss=None):
     """Parameter / buffer values exactly as PointNavResNetPolicy.__init__ produces them: the torch modules are created in
     the reference's order (resnet_policy.py:389-396 embedding, :454-456 tgt_embeding, :578-585 ResNetEncoder [default
     Conv2d / GroupNorm initialisers -- ResNetEncoder.layer_init is never called], :588-595 visual_fc, :597-602 state encoder
     with orthogonal / zero init rnn_state_encoder.py:288-293), then CategoricalNet and CriticHead (policy.py:273-291)."""
     out = {}
-    emb = nn.Embedding(num_actions + 1, 32)
-    out["net.prev_action_embedding.weight"] = emb.weight.detach()
+    if gauss is not None:  # continuous actions: nn.Linear(num_actions, 32) (resnet_policy.py:424-428)
+        emb = nn.Linear(num_actions, 32)
+        out["net.prev_action_embedding.weight"], out["net.prev_action_embedding.bias"] = emb.weight.detach(), emb.bias.detach()
+    else:
+        emb = nn.Embedding(num_actions + 1, 32)
+        out["net.prev_action_embedding.weight"] = emb.weight.detach()
     n_slots = 1
     if has_goal:  # module creation order of PointNavResNetNet.__init__ (resnet_policy.py:441-528)
         tgt = nn.Linear(3, 32)
@@ -525,15 +536,48 @@ def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, base
             nn.init.constant_(param, 0)
     for name, param in rnn.named_parameters():
         out[f"net.state_encoder.rnn.{name}"] = param.detach()
-    lin = nn.Linear(hidden, num_actions)
-    nn.init.orthogonal_(lin.weight, gain=0.01)
-    nn.init.constant_(lin.bias, 0)
-    out["action_distribution.linear.weight"], out["action_distribution.linear.bias"] = lin.weight.detach(), lin.bias.detach()
+    if gauss is not None:  # GaussianNet.__init__ (utils/common.py:112-149)
+        if gauss["use_std_param"]:
+            out["action_distribution.std"] = (torch.randn(num_actions) * 0.01 + gauss["std_init"]).detach()
+        k = num_actions if gauss["use_std_param"] else 2 * num_actions
+        lin = nn.Linear(hidden, k)
+        nn.init.orthogonal_(lin.weight, gain=0.01)
+        nn.init.constant_(lin.bias, 0)
+        if not gauss["use_std_param"]:
+            with torch.no_grad():
+                lin.bias[num_actions:].fill_(gauss["std_init"])
+        out["action_distribution.mu_maybe_std.weight"], out["action_distribution.mu_maybe_std.bias"] = lin.weight.detach(), lin.bias.detach()
+    else:
+        lin = nn.Linear(hidden, num_actions)
+        nn.init.orthogonal_(lin.weight, gain=0.01)
+        nn.init.constant_(lin.bias, 0)
+        out["action_distribution.linear.weight"], out["action_distribution.linear.bias"] = lin.weight.detach(), lin.bias.detach()
     fcv = nn.Linear(hidden, 1)
     nn.init.orthogonal_(fcv.weight)
     nn.init.constant_(fcv.bias, 0)
     out["critic.fc.weight"], out["critic.fc.bias"] = fcv.weight.detach(), fcv.bias.detach()
     return out
+
+
+def _gaussian_options(ad):
+    """ActionDistributionConfig (default_structured_configs.py:70-85) -> (init options, engine kwargs), GaussianNet.__init__'s
+    choices (utils/common.py:118-140): which raw quantity the linear layer / parameter produces and its clamp range."""
+    import math
+    g = lambda k, d: (ad.get(k, d) if isinstance(ad, dict) else getattr(ad, k, d))
+    use_log_std, use_softplus = bool(g("use_log_std", True)), bool(g("use_softplus", False))
+    use_std_param, clamp_std = bool(g("use_std_param", False)), bool(g("clamp_std", True))
+    if use_log_std:
+        lo, hi, std_init = float(g("min_log_std", -5)), float(g("max_log_std", 2)), float(g("log_std_init", 0.0))
+    elif use_softplus:
+        inv = lambda x: math.log(math.exp(x) - 1)
+        lo, hi, std_init = inv(float(g("min_std", 1e-6))), inv(float(g("max_std", 1))), inv(1.0)
+    else:
+        lo, hi, std_init = float(g("min_std", 1e-6)), float(g("max_std", 1)), 1.0
+    flags = ((_lib.GAUSS_TANH_MU if g("action_activation", "tanh") == "tanh" else 0) | (_lib.GAUSS_USE_LOG_STD if use_log_std else 0)
+             | (_lib.GAUSS_USE_SOFTPLUS if use_softplus else 0) | (_lib.GAUSS_USE_STD_PARAM if use_std_param else 0)
+             | (_lib.GAUSS_CLAMP_STD if clamp_std else 0))
+    return (dict(use_std_param=use_std_param, std_init=std_init),
+            dict(action_dist="gaussian", gauss_flags=flags, gauss_min_std=lo, gauss_max_std=hi))
 
 
 @baseline_registry.register_policy
@@ -551,8 +595,12 @@ class PointNavResNetPolicy(NetPolicy):
             raise _lib.HabError(f"backbone {backbone!r} is outside the accelerated path (resnet18 / resnet50)")
         if force_blind_policy or aux_loss_config:
             raise _lib.HabError("blind policies / auxiliary losses are outside the accelerated path")
-        if policy_config is not None and getattr(policy_config, "action_distribution_type", "categorical") != "categorical":
-            raise _lib.HabError("Gaussian action heads are outside the accelerated path")
+        gauss = gauss_kw = None
+        dist = getattr(policy_config, "action_distribution_type", "categorical") if policy_config is not None else "categorical"
+        if dist == "gaussian":
+            gauss, gauss_kw = _gaussian_options(policy_config.action_dist)
+        elif dist != "categorical":
+            raise ValueError(f"Action distribution {dist} not supported.")
         visual_keys = [k for k, v in sp.items() if len(v.shape) > 1]  # observation-space order (resnet_policy.py:178-182)
         known_1d = {GOAL_UUID, "objectgoal", "compass", "gps"}
         other = [k for k in sp.keys() if k not in visual_keys and k not in known_1d]
@@ -579,9 +627,9 @@ class PointNavResNetPolicy(NetPolicy):
                               rnn_layers=num_recurrent_layers, hidden=hidden_size, H=H, W=W, has_rgb=has_rgb, has_depth=has_depth,
                               goal_dim=2 if has_goal else 0, max_frames=max_frames, max_envs=max_envs,
                               visual_order=tuple(visual_keys), has_semantic=has_sem, num_object_categories=n_obj,
-                              has_compass=has_compass, has_gps=has_gps),
+                              has_compass=has_compass, has_gps=has_gps, **(gauss_kw or {})),
                          lambda: _resnet_init(n_in, hidden_size, na, rnn_type, num_recurrent_layers, backbone, resnet_baseplanes,
-                                              H, W, normalize_visual_inputs, has_goal, n_obj, has_gps, has_compass),
+                                              H, W, normalize_visual_inputs, has_goal, n_obj, has_gps, has_compass, gauss),
                          buffer_names=bufs)
 
     @classmethod
@@ -593,5 +641,6 @@ class PointNavResNetPolicy(NetPolicy):
                    rnn_type=dd.rnn_type, num_recurrent_layers=dd.num_recurrent_layers, backbone=dd.backbone,
                    normalize_visual_inputs="rgb" in observation_space.spaces,
                    force_blind_policy=getattr(hb, "force_blind_policy", False),
+                   policy_config=hb.rl.policy[kwargs.get("agent_name") or "main_agent"],
                    aux_loss_config=getattr(hb.rl, "auxiliary_losses", None),
                    max_frames=int(ppo.num_steps) * max(1, -(-n_envs // int(ppo.num_mini_batch))), max_envs=n_envs)

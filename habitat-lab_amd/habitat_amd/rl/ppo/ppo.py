@@ -54,6 +54,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(eng.params_flat)
         self.exp_avg_sq = torch.zeros_like(eng.params_flat)
         self.step_count = 0
+        self.extra: List[Any] = []  # non-policy scalars trained by the same optimiser (adaptive entropy coefficient), after the policy
         self._scratch = torch.zeros(1024, dtype=torch.float64, device=eng.params_flat.device)
 
     @torch.no_grad()
@@ -89,7 +90,14 @@ class FlatAdam(torch.optim.Optimizer):
         return out
 
     def state_dict(self):
-        return flat_to_adam_state_dict(self._slots(), self.step_count, self.exp_avg, self.exp_avg_sq, self.param_groups[0])
+        sd = flat_to_adam_state_dict(self._slots(), self.step_count, self.exp_avg, self.exp_avg_sq, self.param_groups[0])
+        for x in self.extra:  # the reference's optimiser lists them after the policy's parameters (PPO.parameters() order)
+            i = len(sd["param_groups"][0]["params"])
+            sd["param_groups"][0]["params"].append(i)
+            if self.step_count > 0:
+                sd["state"][i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": x.exp_avg.detach().cpu().clone(),
+                                  "exp_avg_sq": x.exp_avg_sq.detach().cpu().clone()}
+        return sd
 
     def load_state_dict(self, sd):
         if "state" not in sd:  # round-1 files of this package: {step, exp_avg, exp_avg_sq} flat arenas
@@ -98,7 +106,16 @@ class FlatAdam(torch.optim.Optimizer):
             self.exp_avg_sq.copy_(sd["exp_avg_sq"])
             groups = sd.get("param_groups", [])
         else:
-            self.step_count = adam_state_dict_to_flat(self._slots(), sd, self.exp_avg, self.exp_avg_sq)
+            n_pol = len(self._slots())
+            ids = sd["param_groups"][0]["params"]
+            for x, pid in zip(self.extra, ids[n_pol:]):
+                e = sd["state"].get(pid)
+                if e is not None:
+                    x.exp_avg.copy_(e["exp_avg"])
+                    x.exp_avg_sq.copy_(e["exp_avg_sq"])
+            pol_sd = {"state": {k: v for k, v in sd["state"].items() if k in ids[:n_pol]},
+                      "param_groups": [dict(sd["param_groups"][0], params=ids[:n_pol])]}
+            self.step_count = adam_state_dict_to_flat(self._slots(), pol_sd, self.exp_avg, self.exp_avg_sq)
             groups = sd["param_groups"]
         for g, s in zip(self.param_groups, groups):
             g.update({k: v for k, v in s.items() if k != "params"})
@@ -151,6 +168,44 @@ def adam_state_dict_to_flat(slots, sd: Dict[str, Any], exp_avg: torch.Tensor, ex
     return steps.pop() if steps else 0
 
 
+class LagrangeInequalityCoefficient(nn.Module):
+    """Learnable coefficient alpha = exp(log_alpha) of the constraint `x > threshold` (utils/common.py:749-806, the `greater_than`
+    form the adaptive entropy penalty uses): loss alpha * (threshold - [x]) - [alpha] * x, projected into [alpha_min, alpha_max]
+    after every optimiser step.  log_alpha is a device scalar; its loss term, gradient and Adam step run in the fused kernels
+    (`hab_ppo_loss_ver`, `hab_lagrange_adam_step`), so no value crosses to the host during an update."""
+
+    def __init__(self, threshold: float, init_alpha: float = 1.0, alpha_min: float = 1e-4, alpha_max: float = 1.0,
+                 greater_than: bool = False, device=None):
+        super().__init__()
+        import math
+        if not greater_than:
+            raise _lib.HabError("only the greater_than form (entropy > target) is on the accelerated path")
+        self.log_alpha = nn.Parameter(torch.full((), math.log(init_alpha), device=device))
+        self.threshold = float(threshold)
+        self.log_alpha_min, self.log_alpha_max = math.log(alpha_min), math.log(alpha_max)
+        self._greater_than = greater_than
+        self.exp_avg = torch.zeros((), device=device)
+        self.exp_avg_sq = torch.zeros((), device=device)
+
+    def forward(self):
+        return torch.exp(self.log_alpha)
+
+    def project_into_bounds(self):
+        with torch.no_grad():
+            self.log_alpha.data.clamp_(self.log_alpha_min, self.log_alpha_max)
+
+    def lagrangian_loss(self, x):
+        alpha = self()
+        return alpha * (self.threshold - x.detach()) - alpha.detach() * x
+
+    @torch.no_grad()
+    def adam_step(self, grad: torch.Tensor, grad_scale: float, group: Dict[str, Any], step: int, alpha_out=None) -> None:
+        check(_lib.lib().hab_lagrange_adam_step(ptr(self.log_alpha), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(grad), float(grad_scale),
+                                                float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
+                                                float(group["eps"]), int(step), float(self.log_alpha_min), float(self.log_alpha_max),
+                                                ptr(alpha_out), stream_ptr()), "hab_lagrange_adam_step")
+
+
 @baseline_registry.register_updater
 class PPO(nn.Module, Updater):
     @classmethod
@@ -169,8 +224,6 @@ class PPO(nn.Module, Updater):
                  use_normalized_advantage: bool = True, entropy_target_factor: float = 0.0,
                  use_adaptive_entropy_pen: bool = False) -> None:
         super().__init__()
-        if use_adaptive_entropy_pen:
-            raise _lib.HabError("adaptive entropy penalty (Gaussian policies) is outside the accelerated path")
         self.actor_critic = actor_critic
         self.clip_param = clip_param
         self.ppo_epoch = ppo_epoch
@@ -185,6 +238,13 @@ class PPO(nn.Module, Updater):
             raise _lib.HabError("move the policy to a GPU before building the updater (policy.to('cuda'))")
         self.optimizer = FlatAdam(actor_critic, lr, eps)
         self.non_ac_params: List[torch.Tensor] = []
+        if (use_adaptive_entropy_pen and hasattr(actor_critic, "num_actions")
+                and getattr(actor_critic, "action_distribution_type", None) == "gaussian"):  # ppo.py:85-103
+            self.entropy_coef = LagrangeInequalityCoefficient(-float(entropy_target_factor) * actor_critic.num_actions,
+                                                              init_alpha=entropy_coef, alpha_max=1.0, alpha_min=1e-4, greater_than=True,
+                                                              device=self.device)
+            self.non_ac_params = [self.entropy_coef.log_alpha]
+            self.optimizer.extra.append(self.entropy_coef)
         dev = self.device
         self._stats = torch.zeros(4, device=dev)
         self._adv: Optional[torch.Tensor] = None
@@ -238,13 +298,15 @@ class PPO(nn.Module, Updater):
         w = self._work(Bn)
         eng.evaluate(rgb, depth, goal, batch.rows, Bf["recurrent_hidden_states"], Bf["masks"], Bf["actions"], batch.pack, Bn, n,
                      value=w["v"], log_prob=w["lp"], entropy=w["ent"], prev_actions=Bf["prev_actions"], extra=extra)
-        if ver:
+        lag = self.entropy_coef if isinstance(self.entropy_coef, LagrangeInequalityCoefficient) else None
+        if ver or lag is not None:
             check(L.hab_ppo_loss_ver(ptr(w["v"]), ptr(w["lp"]), ptr(w["ent"]), ptr(Bf["action_log_probs"]), ptr(batch.advantages_full),
                                      ptr(Bf["value_preds"]), ptr(Bf["returns"]), ptr(batch.rows), Bn, float(self.clip_param),
-                                     float(self.value_loss_coef), float(self.entropy_coef), int(self.use_clipped_value_loss),
-                                     ptr(Bf.get("is_coeffs")), ptr(Bf["is_stale"]), ptr(Bf["policy_version"]),
-                                     int(st.cpu_current_policy_version[0, 0]), ptr(w["dv"]), ptr(w["dlp"]), ptr(w["dent"]), ptr(slot),
-                                     stream_ptr()), "hab_ppo_loss_ver")
+                                     float(self.value_loss_coef), 0.0 if lag is not None else float(self.entropy_coef),
+                                     int(self.use_clipped_value_loss), ptr(Bf.get("is_coeffs")), ptr(Bf.get("is_stale")),
+                                     ptr(Bf.get("policy_version")), int(st.cpu_current_policy_version[0, 0]) if ver else 0,
+                                     ptr(lag.log_alpha) if lag is not None else None, lag.threshold if lag is not None else 0.0,
+                                     ptr(w["dv"]), ptr(w["dlp"]), ptr(w["dent"]), ptr(slot), stream_ptr()), "hab_ppo_loss_ver")
         else:
             check(L.hab_ppo_loss(ptr(w["v"]), ptr(w["lp"]), ptr(w["ent"]), ptr(Bf["action_log_probs"]), ptr(batch.advantages_full),
                                  ptr(Bf["value_preds"]), ptr(Bf["returns"]), ptr(batch.rows), Bn, float(self.clip_param),
@@ -254,6 +316,11 @@ class PPO(nn.Module, Updater):
                      prev_actions=Bf["prev_actions"], extra=extra)
         self.before_step()
         self.optimizer.step(max_grad_norm=self.max_grad_norm, grad_scale=1.0 / self._world_size(), grad_norm_out=slot[12:13])
+        if lag is not None:  # same optimiser, not part of the clipped norm (ppo.py:361-364 clips policy_parameters() only)
+            if self._world_size() > 1:
+                self._all_reduce_scalar_stats(slot[20:21])
+            lag.adam_step(slot[20:21], 1.0 / self._world_size(), self.optimizer.param_groups[0], self.optimizer.step_count,
+                          alpha_out=slot[21:22])
         self.after_step()
 
     def _work(self, B):
@@ -285,6 +352,8 @@ class PPO(nn.Module, Updater):
             rows = last_epoch_slots if name == "ppo_fraction_clipped" else list(range(k))
             out[name] = float(host[rows, i].mean())
         out["grad_norm"] = float(host[:, 12].mean())
+        if isinstance(self.entropy_coef, LagrangeInequalityCoefficient):
+            out["entropy_coef"] = float(host[:, 21].mean())
         if "policy_version" in rollouts.buffers:
             for i, name in VER_METRIC_KEYS.items():
                 if name.startswith("ver_is_coeffs") and "is_coeffs" not in rollouts.buffers:

@@ -183,8 +183,12 @@ class PPOTrainer(BaseRLTrainer):
     # ---- rollout: device path ---------------------------------------------------------------------------------
     def _draw_rollout_noise(self, T: int):
         """T successive (N, A) Exp(1) draws from the CPU generator = the draws torch.multinomial would make."""
-        N, A = self.envs.num_envs, self._agent.actor_critic.dim_actions
-        q = torch.stack([torch.empty(N, A).exponential_(1) for _ in range(T)])
+        ac = self._agent.actor_critic
+        N, A = self.envs.num_envs, ac.dim_actions
+        if getattr(ac, "action_distribution_type", "categorical") == "gaussian":  # CustomNormal.rsample's N(0, 1) draws
+            q = torch.stack([torch.empty(N, A).normal_() for _ in range(T)])
+        else:
+            q = torch.stack([torch.empty(N, A).exponential_(1) for _ in range(T)])
         return q.pin_memory().to(self.device, non_blocking=True)
 
     def _device_rollout_step(self, t: int, noise: torch.Tensor):
@@ -204,10 +208,14 @@ class PPOTrainer(BaseRLTrainer):
         with g_timer.avg_time("trainer.update_stats"):
             # episode bookkeeping (ppo_trainer.py:417-446) and prev_actions[t+1] = actions[t], one launch
             acts = B["actions"][t]
+            discrete = acts.dtype == torch.int64
+            if not discrete:  # continuous actions (float rows): plain row copy
+                B["prev_actions"][t + 1].copy_(acts)
             _lib.check(_lib.lib().hab_rollout_step_stats(
                 _lib.ptr(B["rewards"][t]), _lib.ptr(B["masks"][t + 1]), _lib.ptr(self.current_episode_reward),
                 _lib.ptr(self.running_episode_stats["reward"]), _lib.ptr(self.running_episode_stats["count"]),
-                _lib.ptr(acts), _lib.ptr(B["prev_actions"][t + 1]), self.envs.num_envs, acts.shape[-1], _lib.stream_ptr()))
+                _lib.ptr(acts) if discrete else None, _lib.ptr(B["prev_actions"][t + 1]) if discrete else None, self.envs.num_envs,
+                acts.shape[-1], _lib.stream_ptr()))
         st.advance_rollout()
         return self.envs.num_envs
 

@@ -109,12 +109,20 @@ int hab_ppo_loss(const float* values, const float* logp, const float* entropy, c
 /* The same with VER's importance weights and learner statistics (rl/ppo/ppo.py:226-231,262-263,285-299): every per-frame loss term
  * is multiplied by min(is_coeffs, 1) before the batch mean.  is_coeffs / is_stale / policy_version are storage buffers gathered
  * through rows (each nullable).  out20 = out12 + {[12] reserved (grad norm), ver_is_coeffs min/mean/max, fraction_stale,
- * policy_version_difference min/mean/max}. */
+ * policy_version_difference min/mean/max}.
+ * log_alpha (nullable, device scalar): adaptive entropy penalty (LagrangeInequalityCoefficient, utils/common.py:749-806; ppo.py:85-96,
+ * 236-239): the entropy coefficient is exp(*log_alpha) instead of entropy_coef, the total loss carries alpha * (threshold - [ent]) -
+ * [alpha] * ent, and out[20] = d loss / d log_alpha, out[21] = alpha (out must then hold 24 floats). */
 int hab_ppo_loss_ver(const float* values, const float* logp, const float* entropy, const float* old_logp, const float* adv,
                      const float* old_values, const float* returns, const int* rows, int B, float clip_param, float value_loss_coef,
                      float entropy_coef, int use_clipped_value_loss, const float* is_coeffs, const uint8_t* is_stale,
-                     const int64_t* policy_version, int64_t current_policy_version, float* d_value, float* d_logp, float* d_entropy,
-                     float* out20, hipStream_t stream);
+                     const int64_t* policy_version, int64_t current_policy_version, const float* log_alpha, float entropy_threshold,
+                     float* d_value, float* d_logp, float* d_entropy, float* out20, hipStream_t stream);
+/* Adam step (torch.optim.Adam arithmetic, gradient first multiplied by grad_scale) + projection into [log_alpha_min, log_alpha_max] of
+ * the adaptive entropy coefficient (rl/ppo/ppo.py:112-137,373-375). */
+int hab_lagrange_adam_step(float* log_alpha, float* exp_avg, float* exp_avg_sq, const float* grad, float grad_scale, float lr, float beta1,
+                           float beta2, float eps, int step, float log_alpha_min, float log_alpha_max,
+                           float* alpha_out /* nullable: exp(log_alpha) after the step */, hipStream_t stream);
 
 /* VERRolloutStorage.compute_returns (rl/ver/ver_rollout_storage.py:430-568) on the linear step buffer: GAE per sequence (episode
  * fragment) in float64 like the numpy loop, result rounded to float32; the last step of an environment's last sequence is the
@@ -221,6 +229,7 @@ int hab_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, 
 #define HAB_EMB_COSSIN 2  /* compass x: Linear(2,32)([cos x, sin x]) */
 #define HAB_EMB_LIN2 3    /* gps (x, y): Linear(2,32) */
 #define HAB_EMB_PREV 4    /* previous action: Embedding(A+1, 32)(mask ? a+1 : 0) */
+#define HAB_EMB_PREVLIN 5 /* continuous previous action, float (rows, A <= 4): Linear(A, 32)(mask * a); num_tokens carries A */
 typedef struct hab_embed_slot {
     int32_t kind;
     const void* input;     /* sensor values in arena rows: f32[2] / i64[1] / f32[1] / f32[2] / i64[1] per row */
@@ -285,7 +294,21 @@ typedef struct hab_policy_desc {
     int32_t has_semantic;  /* int32 (H,W,1) semantic sensor */
     int32_t num_object_categories; /* > 0: objectgoal sensor (ObjectNav) with that many categories */
     int32_t has_compass, has_gps;  /* compass f32 (1,), gps f32 (2,) */
+    /* action distribution (rl/ppo/policy.py:266-286).  HAB_DIST_GAUSSIAN (arch 1): GaussianNet / CustomNormal (utils/common.py:99-175)
+     * over a Box action space of num_actions <= 4 dimensions: actions / prev_actions are FLOAT (rows, num_actions) buffers (passed
+     * through the int64 pointers of the entry points), the previous-action embedding is Linear(num_actions, 32) on
+     * masks * prev_actions (resnet_policy.py:424-428,754-757), exp_noise of hab_policy_act carries N(0,1) draws (rsample). */
+    int32_t action_dist;           /* HAB_DIST_* */
+    int32_t gauss_flags;           /* HAB_GAUSS_* bits (ActionDistributionConfig, default_structured_configs.py:70-85) */
+    float gauss_min_std, gauss_max_std;  /* clamp range of the RAW std output (min_log_std / max_log_std when USE_LOG_STD) */
 } hab_policy_desc;
+#define HAB_DIST_CATEGORICAL 0
+#define HAB_DIST_GAUSSIAN 1
+#define HAB_GAUSS_TANH_MU 1        /* action_activation == "tanh" */
+#define HAB_GAUSS_USE_LOG_STD 2    /* std = exp(raw) */
+#define HAB_GAUSS_USE_SOFTPLUS 4   /* std = softplus(std) */
+#define HAB_GAUSS_USE_STD_PARAM 8  /* state-independent std parameter `action_distribution.std` instead of 2*A linear outputs */
+#define HAB_GAUSS_CLAMP_STD 16
 
 typedef struct hab_obs {   /* arena base pointers; frame f lives at row rows[f] (or f) */
     const uint8_t* rgb;    /* (rows, H, W, 3) */

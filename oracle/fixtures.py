@@ -59,11 +59,14 @@ def synth_rollout_inputs(envs: synth.SyntheticEnvs, T):
 
 
 def resnet_param_shapes(n_in, H, W, hidden, num_actions=4, rnn_type="LSTM", layers=2, backbone="resnet18", baseplanes=32,
-                        normalize=True, with_buffers=False, has_goal=True, n_obj=0, has_gps=False, has_compass=False):
+                        normalize=True, with_buffers=False, has_goal=True, n_obj=0, has_gps=False, has_compass=False, gauss=None):
     """state_dict() names/shapes of PointNavResNetPolicy (rl/ddppo/policy/resnet_policy.py:50-162,391-602) in reference
     order.  Buffers (RunningMeanAndVar statistics) are listed only with with_buffers=True."""
     import math
-    shapes = [("net.prev_action_embedding.weight", (num_actions + 1, 32))]
+    if gauss is not None:  # continuous actions: Linear(A, 32) previous-action embedding, GaussianNet head (utils/common.py:112-149)
+        shapes = [("net.prev_action_embedding.weight", (32, num_actions)), ("net.prev_action_embedding.bias", (32,))]
+    else:
+        shapes = [("net.prev_action_embedding.weight", (num_actions + 1, 32))]
     slots = 1
     if has_goal:
         shapes += [("net.tgt_embeding.weight", (32, 3)), ("net.tgt_embeding.bias", (32,))]
@@ -115,6 +118,13 @@ def resnet_param_shapes(n_in, H, W, hidden, num_actions=4, rnn_type="LSTM", laye
         i = hidden + 32 * slots if l == 0 else hidden
         shapes += [(f"{rn}weight_ih_l{l}", (G * hidden, i)), (f"{rn}weight_hh_l{l}", (G * hidden, hidden)),
                    (f"{rn}bias_ih_l{l}", (G * hidden,)), (f"{rn}bias_hh_l{l}", (G * hidden,))]
+    if gauss is not None:
+        k = num_actions if gauss["use_std_param"] else 2 * num_actions
+        if gauss["use_std_param"]:
+            shapes += [("action_distribution.std", (num_actions,))]
+        shapes += [("action_distribution.mu_maybe_std.weight", (k, hidden)), ("action_distribution.mu_maybe_std.bias", (k,)),
+                   ("critic.fc.weight", (1, hidden)), ("critic.fc.bias", (1,))]
+        return shapes
     shapes += [("action_distribution.linear.weight", (num_actions, hidden)), ("action_distribution.linear.bias", (num_actions,)),
                ("critic.fc.weight", (1, hidden)), ("critic.fc.bias", (1,))]
     return shapes

@@ -251,7 +251,11 @@ class NetSpec:
     rl/ddppo/policy/resnet_policy.py:50-162)."""
 
     def __init__(self, kind="baseline", rnn_type="GRU", num_layers=1, backbone="resnet18", baseplanes=32,
-                 visual_keys=("rgb", "depth"), normalize=True, num_actions=4, hidden=512):
+                 visual_keys=("rgb", "depth"), normalize=True, num_actions=4, hidden=512, action_dist="categorical", gauss=None):
+        # gauss: GaussianNet options (utils/common.py:112-140): dict(tanh, use_log_std, use_softplus, use_std_param, clamp_std,
+        # min_std, max_std) with min/max already in the RAW domain (log / inverse-softplus) as GaussianNet stores them
+        self.action_dist = action_dist
+        self.gauss = gauss
         self.kind = kind
         self.rnn_type = rnn_type
         self.num_layers = num_layers
@@ -289,9 +293,13 @@ def net_forward(params: Params, spec: NetSpec, obs, hidden_bf, prev_actions, mas
             parts.append(F.linear(c.squeeze(dim=1), params["net.compass_embedding.weight"], params["net.compass_embedding.bias"]))
         if "gps" in obs:  # :731-734
             parts.append(F.linear(obs["gps"], params["net.gps_embedding.weight"], params["net.gps_embedding.bias"]))
-        pa = prev_actions.squeeze(-1)
-        pa = torch.where(masks.view(-1), pa + 1, torch.zeros_like(pa))  # :747-753
-        parts.append(F.embedding(pa, params["net.prev_action_embedding.weight"]))
+        if spec.action_dist == "gaussian":  # continuous actions: Linear(A, 32)(masks * prev_actions.float()), :754-757
+            parts.append(F.linear(masks * prev_actions.float(), params["net.prev_action_embedding.weight"],
+                                  params["net.prev_action_embedding.bias"]))
+        else:
+            pa = prev_actions.squeeze(-1)
+            pa = torch.where(masks.view(-1), pa + 1, torch.zeros_like(pa))  # :747-753
+            parts.append(F.embedding(pa, params["net.prev_action_embedding.weight"]))
         x = torch.cat(parts, dim=1)
         if taps is not None:
             taps["visual_fc"] = vis
@@ -313,6 +321,37 @@ def heads(params: Params, feats):
     return logits, probs, value
 
 
+def gaussian_head(params: Params, spec: NetSpec, feats):
+    """GaussianNet.forward utils/common.py:151-175 -> (mu, std) of CustomNormal, and the critic value."""
+    g = spec.gauss
+    out = F.linear(feats, params["action_distribution.mu_maybe_std.weight"], params["action_distribution.mu_maybe_std.bias"]).float()
+    if g["use_std_param"]:
+        mu, std = out, params["action_distribution.std"]
+    else:
+        mu, std = torch.chunk(out, 2, -1)
+    if g["tanh"]:
+        mu = torch.tanh(mu)
+    if g["clamp_std"]:
+        std = torch.clamp(std, g["min_std"], g["max_std"])
+    if g["use_log_std"]:
+        std = torch.exp(std)
+    if g["use_softplus"]:
+        std = F.softplus(std)
+    value = F.linear(feats, params["critic.fc.weight"], params["critic.fc.bias"])
+    return mu, std, value
+
+
+def normal_log_prob(mu, std, x):
+    """CustomNormal.log_probs (utils/common.py:105-106) = torch.distributions.Normal.log_prob summed over action dims."""
+    var = std ** 2
+    return (-((x - mu) ** 2) / (2 * var) - torch.log(std) - math.log(math.sqrt(2 * math.pi))).sum(-1, keepdim=True)
+
+
+def normal_entropy(mu, std):
+    """CustomNormal.entropy (:108-109); std broadcast to mu's shape as Normal does."""
+    return (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(std.expand_as(mu))).sum(-1, keepdim=True)
+
+
 def sample_actions(probs, exp_noise=None, generator=None):
     """CustomFixedCategorical.sample utils/common.py:64-68 -> torch.multinomial(probs, 1, True).
     For one draw torch's CPU multinomial is argmax(probs / Exp(1) noise); passing the pre-drawn
@@ -325,6 +364,11 @@ def sample_actions(probs, exp_noise=None, generator=None):
 def act(params, spec, obs, hidden_bf, prev_actions, masks, exp_noise=None, deterministic=False):
     """NetPolicy.act rl/ppo/policy.py:324-352."""
     feats, hidden = net_forward(params, spec, obs, hidden_bf, prev_actions, masks, training=False)
+    if spec.action_dist == "gaussian":
+        mu, std, value = gaussian_head(params, spec, feats)
+        # rsample: mu + std * eps, eps ~ N(0, 1) from the global CPU generator (exp_noise carries the pre-drawn eps)
+        action = mu if deterministic else mu + std * (exp_noise if exp_noise is not None else torch.empty_like(mu).normal_())
+        return dict(values=value, actions=action, action_log_probs=normal_log_prob(mu, std, action), rnn_hidden_states=hidden)
     logits, probs, value = heads(params, feats)
     if deterministic:
         action = probs.argmax(dim=-1, keepdim=True)
@@ -337,6 +381,9 @@ def act(params, spec, obs, hidden_bf, prev_actions, masks, exp_noise=None, deter
 def evaluate_actions(params, spec, obs, hidden_bf, prev_actions, masks, action, training=True, taps=None, rmv_out=None):
     """NetPolicy.evaluate_actions rl/ppo/policy.py:361-402 -> (value, log_prob, entropy, hidden)."""
     feats, hidden = net_forward(params, spec, obs, hidden_bf, prev_actions, masks, training, taps, rmv_out)
+    if spec.action_dist == "gaussian":
+        mu, std, value = gaussian_head(params, spec, feats)
+        return value, normal_log_prob(mu, std, action), normal_entropy(mu, std), hidden
     logits, probs, value = heads(params, feats)
     logp = logits.gather(-1, action)
     min_real = torch.finfo(logits.dtype).min
@@ -383,7 +430,9 @@ def get_advantages(returns, value_preds, use_normalized_advantage, world_size: i
 
 def ppo_loss(values, action_log_probs, dist_entropy, batch, clip_param, value_loss_coef, entropy_coef,
              use_clipped_value_loss=True):
-    """rl/ppo/ppo.py:195-250.  Returns (total, value_loss, action_loss, entropy, ratio)."""
+    """rl/ppo/ppo.py:195-250.  Returns (total, value_loss, action_loss, entropy, ratio).  `entropy_coef` is a float or a dict
+    {log_alpha (leaf tensor), threshold}: the adaptive penalty's LagrangeInequalityCoefficient in its greater_than form
+    (utils/common.py:797-806): alpha * (threshold - [ent]) - [alpha] * ent.  batch["is_coeffs"] (VER) weights the three means."""
     ratio = torch.exp(action_log_probs - batch["action_log_probs"])
     surr1 = batch["advantages"] * ratio
     surr2 = batch["advantages"] * torch.clamp(ratio, 1.0 - clip_param, 1.0 + clip_param)
@@ -394,8 +443,18 @@ def ppo_loss(values, action_log_probs, dist_entropy, batch, clip_param, value_lo
         clipped = batch["value_preds"] + delta.clamp(-clip_param, clip_param)
         values = torch.where(delta.abs() < clip_param, values, clipped)
     value_loss = 0.5 * F.mse_loss(values, batch["returns"], reduction="none")
-    action_loss, value_loss, ent = action_loss.mean(), value_loss.mean(), dist_entropy.mean()
-    total = torch.stack([value_loss_coef * value_loss, action_loss, -entropy_coef * ent]).sum()
+    if "is_coeffs" in batch:
+        w = batch["is_coeffs"].clamp(max=1.0)
+        mean_fn = lambda t: torch.mean(w * t)
+    else:
+        mean_fn = torch.mean
+    action_loss, value_loss, ent = mean_fn(action_loss), mean_fn(value_loss), mean_fn(dist_entropy)
+    if isinstance(entropy_coef, dict):
+        alpha = torch.exp(entropy_coef["log_alpha"])
+        ent_term = alpha * (entropy_coef["threshold"] - ent.detach()) - alpha.detach() * ent
+    else:
+        ent_term = -entropy_coef * ent
+    total = torch.stack([value_loss_coef * value_loss, action_loss, ent_term]).sum()
     return total, value_loss, action_loss, ent, ratio
 
 
@@ -507,6 +566,10 @@ def ppo_update(params: Params, spec: NetSpec, buffers: dict, num_steps: int, cfg
     averaged learner metrics like the reference does."""
     adv = get_advantages(buffers["returns"], buffers["value_preds"], cfg.use_normalized_advantage)
     metrics: Dict[str, list] = {}
+    # adaptive entropy penalty (ppo.py:85-103): alpha is one more Adam parameter (same lr / eps), not clipped (ppo.py:361-364),
+    # projected into [1e-4, 1] after the step (:373-375).  opt_state["lagrange"] = {log_alpha, m, v, threshold}
+    lag = opt_state.get("lagrange")
+    entropy_coef = dict(log_alpha=lag["log_alpha"], threshold=lag["threshold"]) if lag is not None else cfg.entropy_coef
 
     def rec(k, v):
         metrics.setdefault(k, []).append(torch.as_tensor(v, dtype=torch.float32).detach())
@@ -522,8 +585,10 @@ def ppo_update(params: Params, spec: NetSpec, buffers: dict, num_steps: int, cfg
             values, logp, ent, _ = evaluate_actions(
                 params, spec, batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"],
                 batch["masks"], batch["actions"], training=True, rmv_out=rmv)
+            if lag is not None:
+                lag["log_alpha"].grad = None
             total, vl, al, de, ratio = ppo_loss(values, logp, ent, batch, cfg.clip_param, cfg.value_loss_coef,
-                                                cfg.entropy_coef, cfg.use_clipped_value_loss)
+                                                entropy_coef, cfg.use_clipped_value_loss)
             total.backward()
             grads = [params[n].grad for n in trainable if params[n].grad is not None]
             gnorm = clip_grad_norm(grads, cfg.max_grad_norm)
@@ -534,6 +599,10 @@ def ppo_update(params: Params, spec: NetSpec, buffers: dict, num_steps: int, cfg
                         continue
                     adam_step(params[n], params[n].grad, opt_state["m"][n], opt_state["v"][n], opt_state["step"],
                               cfg.lr, cfg.eps)
+                if lag is not None:
+                    adam_step(lag["log_alpha"], lag["log_alpha"].grad, lag["m"], lag["v"], opt_state["step"], cfg.lr, cfg.eps)
+                    lag["log_alpha"].clamp_(math.log(1e-4), math.log(1.0))
+                    rec("entropy_coef", torch.exp(lag["log_alpha"]).detach())  # recorded after the step + projection (ppo.py:276-279)
                 if rmv:
                     pre = "net.visual_encoder.running_mean_and_var."
                     params[pre + "_mean"], params[pre + "_var"], params[pre + "_count"] = rmv["mean"], rmv["var"], rmv["count"]

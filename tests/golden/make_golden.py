@@ -44,14 +44,17 @@ def obs_space(ns, H, W, rgb=True, depth=True, task="pointnav"):
     return sp.Dict(d)
 
 
-def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=True, sampled=False, task="pointnav", num_actions=4):
-    """Reference rollout (policy.act through RolloutStorage) + compute_returns + PPO.update."""
+def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=True, sampled=False, task="pointnav", num_actions=4,
+             action_space=None):
+    """Reference rollout (policy.act through RolloutStorage) + compute_returns + PPO.update.  action_space: a Box for the Gaussian
+    head (the stored noise is then the N(0, 1) draw of CustomNormal.rsample instead of multinomial's Exp(1))."""
+    gaussian = action_space is not None
     sd = policy.state_dict()
     newp = det_params([(k, v.shape) for k, v in sd.items() if v.dtype == torch.float32 and "running_mean_and_var" not in k], seed)
     sd.update(newp)
     policy.load_state_dict(sd)
     RolloutStorage = ns.rollout_storage.RolloutStorage
-    rollouts = RolloutStorage(T, N, space, ns.spaces.Discrete(num_actions), policy)
+    rollouts = RolloutStorage(T, N, space, action_space if gaussian else ns.spaces.Discrete(num_actions), policy)
     envs = synth.SyntheticEnvs(N, H, W, seed=seed, use_rgb=rgb, use_depth=depth, task=task)
     obs, rew, done = synth_rollout_inputs(envs, T)
     to_t = lambda o: {k: torch.from_numpy(v) for k, v in o.items()}
@@ -64,7 +67,10 @@ def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=Tru
         step = rollouts.get_current_step(slice(0, N), 0)
         with torch.no_grad():
             rng_state = torch.get_rng_state()
-            noises.append(torch.empty(N, num_actions).exponential_(1))  # what multinomial is about to draw
+            if gaussian:  # torch.distributions.Normal.rsample -> _standard_normal(shape) = torch.normal(zeros, ones)
+                noises.append(torch.normal(torch.zeros(N, num_actions), torch.ones(N, num_actions)))
+            else:
+                noises.append(torch.empty(N, num_actions).exponential_(1))  # what multinomial is about to draw
             torch.set_rng_state(rng_state)
             ad = policy.act(step["observations"], step["recurrent_hidden_states"], step["prev_actions"], step["masks"])
         rollouts.insert(next_recurrent_hidden_states=ad.rnn_hidden_states, actions=ad.actions,
@@ -84,6 +90,7 @@ def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=Tru
 
     policy.train()
     ppo = ns.ppo.PPO.from_config(policy, cfg)
+    adaptive = isinstance(ppo.entropy_coef, torch.nn.Module)
     out["advantages"] = ppo.get_advantages(rollouts).numpy().copy()
     # first minibatch of a fixed permutation: evaluate_actions + grads (no optimiser step)
     torch.manual_seed(seed + 1)
@@ -101,8 +108,9 @@ def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=Tru
     vc = batch["value_preds"] + delta.clamp(-cfg.clip_param, cfg.clip_param)
     vv = torch.where(delta.abs() < cfg.clip_param, v, vc)
     vl = (0.5 * (vv - batch["returns"]) ** 2).mean()
-    total = cfg.value_loss_coef * vl + al - cfg.entropy_coef * ent.mean()
+    total = cfg.value_loss_coef * vl + al + (ppo.entropy_coef.lagrangian_loss(ent.mean()) if adaptive else -cfg.entropy_coef * ent.mean())
     policy.zero_grad()
+    ppo.zero_grad()
     total.backward()
     out["mb0_losses"] = np.array([vl.item(), al.item(), ent.mean().item(), total.item()], dtype=np.float32)
     keep = (lambda a: golden_sample(a).copy()) if sampled else (lambda a: a.copy())
@@ -111,7 +119,10 @@ def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=Tru
             out["grad/" + k] = keep(p_.grad.numpy())
             if sampled:
                 out["gradnorm/" + k] = np.float64(np.linalg.norm(p_.grad.numpy().astype(np.float64)))
+    if adaptive:
+        out["mb0_grad_log_alpha"] = ppo.entropy_coef.log_alpha.grad.numpy().copy()
     policy.zero_grad()
+    ppo.zero_grad()
     # the full update (fresh generator state so the permutations are reproducible: seed + 2)
     torch.manual_seed(seed + 2)
     perm_state = torch.get_rng_state()
@@ -123,6 +134,8 @@ def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=Tru
         out["metric/" + k] = np.float32(val)
     for k, p_ in policy.state_dict().items():
         out["post/" + k] = keep(p_.numpy())
+    if adaptive:
+        out["post_log_alpha"] = ppo.entropy_coef.log_alpha.detach().numpy().copy()
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "->", len(out), "arrays;", {k: float(v) for k, v in metrics.items()})
 
@@ -347,6 +360,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ver":
         ver_case()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "gaussian":
+        gaussian_case(load_reference())
+        return
     ns = load_reference()
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
@@ -390,6 +406,30 @@ def main():
     run_case(ns, "objectnav_resnet50_256", pol4, space4, cfg4, T=3, N=2, seed=33, H=256, W=256, sampled=True, task="objectnav",
              num_actions=6)
     ver_case()
+    gaussian_case(ns)
+
+
+GAUSS_CASE = dict(use_log_std=True, use_softplus=False, log_std_init=0.0, use_std_param=False, clamp_std=True, min_std=1e-6, max_std=1,
+                  min_log_std=-5, max_log_std=2, action_activation="tanh")
+
+
+def gaussian_case(ns):
+    """Gaussian action head (GaussianNet + CustomNormal, utils/common.py:99-175) on a Box(2) action space with the
+    ResNet policy's Linear previous-action embedding (resnet_policy.py:424-428,754-757) and the adaptive entropy penalty
+    (LagrangeInequalityCoefficient, ppo.py:85-103,236-239,373-375): ResNet18 + 1-layer GRU, 128x128 RGB-D."""
+    space = obs_space(ns, 128, 128)
+    aspace = ns.spaces.Box(-1.0, 1.0, (2,), np.float32)
+    pcfg = types.SimpleNamespace(action_distribution_type="gaussian", action_dist=types.SimpleNamespace(**GAUSS_CASE))
+    torch.manual_seed(0)
+    pol = ns.resnet_policy.PointNavResNetPolicy(space, aspace, hidden_size=64, num_recurrent_layers=1, rnn_type="GRU", backbone="resnet18",
+                                                normalize_visual_inputs=True, policy_config=pcfg)
+    # PPO only builds the adaptive coefficient for policies that expose `num_actions` (ppo.py:87-90; the hierarchical policies do,
+    # NetPolicy does not): expose it, so that the fixture pins the Lagrangian path too
+    pol.num_actions = pol.dim_actions
+    cfg = make_config(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2, num_steps=4, use_normalized_advantage=False,
+                      hidden_size=64, lr=2.5e-4, eps=1e-5, entropy_coef=0.01, use_adaptive_entropy_pen=True, entropy_target_factor=0.5)
+    run_case(ns, "gaussian_resnet18_rgbd128", pol, space, cfg, T=4, N=2, seed=55, H=128, W=128, sampled=True, num_actions=2,
+             action_space=aspace)
 
 
 if __name__ == "__main__":

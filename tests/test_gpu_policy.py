@@ -31,6 +31,8 @@ def space_for(c):
         d["gps"] = S.Box(-1e9, 1e9, (2,), np.float32)
     else:
         d[GOAL] = S.Box(-1e9, 1e9, (2,), np.float32)
+    if c.get("gauss"):
+        return S.Dict(d), S.Box(-1.0, 1.0, (c["num_actions"],), np.float32)
     return S.Dict(d), S.Discrete(c.get("num_actions", 4))
 
 
@@ -46,15 +48,32 @@ def build(case, z):
     params, spec, buf, next_value = oracle_rollout(case, z)
     osp, asp = space_for(c)
     if c.get("kind", "baseline") == "resnet":
-        pol = PointNavResNetPolicy(osp, asp, hidden_size=c["hidden"], num_recurrent_layers=2, rnn_type="LSTM",
+        rnn_type, rnn_layers = c.get("rnn", ("LSTM", 2))
+        pcfg = None
+        if c.get("gauss"):  # the ActionDistributionConfig the fixture was generated with (tests/golden/make_golden.py::GAUSS_CASE)
+            pcfg = types.SimpleNamespace(action_distribution_type="gaussian",
+                                         action_dist=dict(use_log_std=True, use_softplus=False, log_std_init=0.0, use_std_param=False,
+                                                          clamp_std=True, min_std=1e-6, max_std=1, min_log_std=-5, max_log_std=2,
+                                                          action_activation="tanh"))
+        pol = PointNavResNetPolicy(osp, asp, hidden_size=c["hidden"], num_recurrent_layers=rnn_layers, rnn_type=rnn_type,
                                    backbone=c.get("backbone", "resnet18"), normalize_visual_inputs=True, max_frames=c["T"] * c["N"],
-                                   max_envs=c["N"])
+                                   max_envs=c["N"], policy_config=pcfg)
+        if c.get("lagrange"):
+            pol.num_actions = pol.dim_actions  # what makes PPO build the adaptive coefficient (ppo.py:87-90), as in the fixture
     else:
         pol = PointNavBaselinePolicy(osp, asp, hidden_size=c["hidden"], max_frames=c["T"] * c["N"], max_envs=c["N"])
     pol.load_state_dict(params)
     pol.to("cuda")
     st = RolloutStorage(c["T"], c["N"], osp, asp, pol, device="cuda", gae_variant="exact")
     return c, params, spec, buf, next_value, pol, st
+
+
+def cfg_of(c):
+    kw = dict(c["cfg"])
+    if c.get("lagrange"):
+        kw.update(use_adaptive_entropy_pen=True, entropy_target_factor=-c["lagrange"]["threshold"] / c["num_actions"],
+                  entropy_coef=c["lagrange"]["init_alpha"])
+    return make_cfg(**kw)
 
 
 def rel_ok(got, ref, tol=1e-4, floor=1e-3):
@@ -84,8 +103,12 @@ def test_rollout_act_matches_reference_golden(case):
                   next_masks=buf["masks"][t + 1].to(dev))
         st.advance_rollout()
     B = st.buffers
-    assert np.array_equal(B["actions"].cpu().numpy(), z["roll_actions"]), "sampled actions differ from the reference"
-    assert np.array_equal(B["prev_actions"].cpu().numpy(), z["roll_prev_actions"])
+    if c.get("gauss"):  # continuous: mu + std * eps with the reference's own N(0, 1) draws
+        assert rel_ok(B["actions"].cpu().numpy(), z["roll_actions"], tol=1e-5)
+        assert rel_ok(B["prev_actions"].cpu().numpy(), z["roll_prev_actions"], tol=1e-5)
+    else:
+        assert np.array_equal(B["actions"].cpu().numpy(), z["roll_actions"]), "sampled actions differ from the reference"
+        assert np.array_equal(B["prev_actions"].cpu().numpy(), z["roll_prev_actions"])
     assert rel_ok(B["action_log_probs"].cpu().numpy()[:T], z["roll_action_log_probs"][:T])
     assert rel_ok(B["value_preds"].cpu().numpy()[:T], z["roll_value_preds"][:T])
     assert rel_ok(B["recurrent_hidden_states"].cpu().numpy(), z["roll_recurrent_hidden_states"])
@@ -115,7 +138,7 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
     from habitat_amd.rl.ppo import PPO
     z = np.load(os.path.join(G, case + ".npz"))
     c, params, spec, buf, next_value, pol, st = build(case, z)
-    cfg = make_cfg(**c["cfg"])
+    cfg = cfg_of(c)
     T, N = c["T"], c["N"]
     fill_storage(st, buf, z, T)
     pol.train()
@@ -144,11 +167,19 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
     from habitat_amd import _lib
     import ctypes as C
     dv, dlp, dent = (torch.zeros(Bn, device="cuda") for _ in range(3))
-    out = torch.zeros(16, device="cuda")
+    out = torch.zeros(24, device="cuda")
     P = lambda t: C.c_void_p(t.data_ptr())
-    _lib.check(_lib.lib().hab_ppo_loss(P(v), P(lp), P(ent), P(Bf["action_log_probs"]), P(adv), P(Bf["value_preds"]), P(Bf["returns"]),
-                                       P(batch.rows), Bn, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef,
-                                       int(cfg.use_clipped_value_loss), P(dv), P(dlp), P(dent), P(out), _lib.stream_ptr()))
+    if c.get("lagrange"):  # adaptive entropy penalty: the coefficient is the device scalar exp(log_alpha)
+        lag = ppo.entropy_coef
+        _lib.check(_lib.lib().hab_ppo_loss_ver(P(v), P(lp), P(ent), P(Bf["action_log_probs"]), P(adv), P(Bf["value_preds"]), P(Bf["returns"]),
+                                               P(batch.rows), Bn, cfg.clip_param, cfg.value_loss_coef, 0.0, int(cfg.use_clipped_value_loss),
+                                               None, None, None, 0, P(lag.log_alpha), lag.threshold, P(dv), P(dlp), P(dent), P(out),
+                                               _lib.stream_ptr()))
+        assert np.allclose(out[20].item(), z["mb0_grad_log_alpha"], rtol=1e-4)
+    else:
+        _lib.check(_lib.lib().hab_ppo_loss(P(v), P(lp), P(ent), P(Bf["action_log_probs"]), P(adv), P(Bf["value_preds"]), P(Bf["returns"]),
+                                           P(batch.rows), Bn, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef,
+                                           int(cfg.use_clipped_value_loss), P(dv), P(dlp), P(dent), P(out), _lib.stream_ptr()))
     assert np.allclose(out[:4].cpu().numpy(), z["mb0_losses"], rtol=1e-4, atol=1e-6)
     eng.backward(obs.get("rgb"), obs.get("depth"), obs.get(GOAL), batch.rows, Bf["actions"], batch.pack, dv, dlp, dent,
                  prev_actions=Bf["prev_actions"], extra=extra_of(obs))
@@ -176,6 +207,8 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
             nerr = abs(float(g.double().norm()) - nr) / max(1e-12, nr)
             downstream = ("compression" in k or "visual_fc" in k or "state_encoder" in k or "_embed" in k
                           or k.startswith("action_") or k.startswith("critic") or (case == "resnet18_rgbd256" and "layer4" in k))
+            if case.startswith("gaussian"):
+                downstream = "backbone" not in k
             lim = 2e-4 if downstream else 2e-2
             if err > lim or nerr > lim:
                 bad.append((k, err, nerr))
@@ -246,6 +279,7 @@ def test_resnet_golden_mask_flip_accounting(case):
         return worst, max(vs_golden.values())
 
     before, before_golden = backward_and_errors()
+    from oracle.parity import resnet_relu_taps
     eng_taps = resnet_relu_taps(eng, c.get("backbone", "resnet18"))
     assert len(eng_taps) == len(taps["relu"])
     flips = {}
@@ -292,7 +326,7 @@ def test_full_ppo_update_vs_reference_golden(case, monkeypatch):
     from habitat_amd.rl.ppo import PPO
     z = np.load(os.path.join(G, case + ".npz"))
     c, params, spec, buf, next_value, pol, st = build(case, z)
-    cfg = make_cfg(**c["cfg"])
+    cfg = cfg_of(c)
     T, N = c["T"], c["N"]
     fill_storage(st, buf, z, T)
     pol.train()
@@ -321,6 +355,9 @@ def test_full_ppo_update_vs_reference_golden(case, monkeypatch):
         # 4 steps x lr 2.5e-4 bounds the drift by 1e-3, observed < 3e-4
         tol = 5e-4 * max(1.0, np.abs(ref).max()) if (c.get("sampled") and not c.get("exact")) else 1e-4 * max(1e-2, np.abs(ref).max())
         assert np.abs(got - ref).max() <= tol, k
+    if c.get("lagrange"):
+        assert "entropy_coef" in metrics
+        assert abs(float(ppo.entropy_coef.log_alpha) - float(z["post_log_alpha"])) <= 1e-5
 
 
 def test_autograd_bridge_matches_fused_path():

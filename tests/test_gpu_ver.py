@@ -115,6 +115,12 @@ def test_ver_replay_of_reference_inference_worker_golden():
             assert stepped
             iw._n_replay_steps = 0
         assert bool(st.rollout_done)
+        # steps that had arrived but had not been picked up when the rollout filled (still in the inference queue of the reference)
+        for e in z[f"r{r}/replay_after"].tolist():
+            if e not in iw.replay_reqs and e not in iw.new_reqs:
+                assert tr.stepping[e]
+                tr.arrive(e)
+                iw.new_reqs.append(e)
         iw.finish_rollout()
         assert iw.new_reqs == z[f"r{r}/replay_after"].tolist()
         assert np.array_equal(tr.stepping, z[f"r{r}/in_flight_after"])

@@ -100,6 +100,13 @@ CASES = {
                                    depth=True, T=3, N=2, seed=33, hidden=64, sampled=True,
                                    cfg=dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2,
                                             use_normalized_advantage=False, use_clipped_value_loss=True)),
+    # Gaussian head on Box(2), Linear previous-action embedding, adaptive entropy penalty (ResNet18 + GRU, 128x128)
+    "gaussian_resnet18_rgbd128": dict(kind="resnet", H=128, W=128, rgb=True, depth=True, T=4, N=2, seed=55, hidden=64, sampled=True,
+                                      num_actions=2, rnn=("GRU", 1), lagrange=dict(threshold=-0.5 * 2, init_alpha=0.01),
+                                      gauss=dict(tanh=True, use_log_std=True, use_softplus=False, use_std_param=False, clamp_std=True,
+                                                 min_std=-5.0, max_std=2.0),
+                                      cfg=dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2,
+                                               use_normalized_advantage=False, use_clipped_value_loss=True)),
 }
 
 
@@ -112,15 +119,18 @@ def case_params_spec(c):
     objnav = c.get("task") == "objectnav"
     keys = ("rgb", "depth", "semantic") if objnav else ("rgb", "depth")
     cin += 1 if objnav else 0
-    shapes = resnet_param_shapes(cin, c["H"], c["W"], c["hidden"], num_actions=c.get("num_actions", 4),
-                                 backbone=c.get("backbone", "resnet18"), has_goal=not objnav,
-                                 n_obj=synth.NUM_OBJECT_CATEGORIES if objnav else 0, has_gps=objnav, has_compass=objnav)
+    rnn_type, rnn_layers = c.get("rnn", ("LSTM", 2))
+    shapes = resnet_param_shapes(cin, c["H"], c["W"], c["hidden"], num_actions=c.get("num_actions", 4), rnn_type=rnn_type,
+                                 layers=rnn_layers, backbone=c.get("backbone", "resnet18"), has_goal=not objnav,
+                                 n_obj=synth.NUM_OBJECT_CATEGORIES if objnav else 0, has_gps=objnav, has_compass=objnav,
+                                 gauss=c.get("gauss"))
     params = det_params(shapes, c["seed"])
     pre = "net.visual_encoder.running_mean_and_var."
     params[pre + "_mean"], params[pre + "_var"], params[pre + "_count"] = torch.zeros(1, cin, 1, 1), torch.zeros(1, cin, 1, 1), torch.zeros(())
-    spec = O.NetSpec(kind="resnet", rnn_type="LSTM", num_layers=2, backbone=c.get("backbone", "resnet18"), baseplanes=32,
-                     visual_keys=keys, normalize=True, hidden=c["hidden"], num_actions=c.get("num_actions", 4))
-    return params, spec, 4
+    spec = O.NetSpec(kind="resnet", rnn_type=rnn_type, num_layers=rnn_layers, backbone=c.get("backbone", "resnet18"), baseplanes=32,
+                     visual_keys=keys, normalize=True, hidden=c["hidden"], num_actions=c.get("num_actions", 4),
+                     action_dist="gaussian" if c.get("gauss") else "categorical", gauss=c.get("gauss"))
+    return params, spec, rnn_layers * (2 if rnn_type == "LSTM" else 1)
 
 
 def is_buffer(k):
@@ -148,8 +158,12 @@ def oracle_rollout(case, z):
     buf["masks"][1:] = torch.from_numpy(~done).unsqueeze(-1)
     for k in ("value_preds", "action_log_probs"):
         buf[k] = torch.zeros(T + 1, N, 1)
-    buf["actions"] = torch.zeros(T + 1, N, 1, dtype=torch.long)
-    buf["prev_actions"] = torch.zeros(T + 1, N, 1, dtype=torch.long)
+    if c.get("gauss"):
+        buf["actions"] = torch.zeros(T + 1, N, c["num_actions"])
+        buf["prev_actions"] = torch.zeros(T + 1, N, c["num_actions"])
+    else:
+        buf["actions"] = torch.zeros(T + 1, N, 1, dtype=torch.long)
+        buf["prev_actions"] = torch.zeros(T + 1, N, 1, dtype=torch.long)
     noise = torch.from_numpy(z["exp_noise"])
     with torch.no_grad():
         for t in range(T):
@@ -159,7 +173,7 @@ def oracle_rollout(case, z):
             buf["recurrent_hidden_states"][t + 1], buf["prev_actions"][t + 1] = r["rnn_hidden_states"], r["actions"]
         o_T = {k: v[T] for k, v in buf["observations"].items()}
         feats, _ = O.net_forward(params, spec, o_T, buf["recurrent_hidden_states"][T], buf["prev_actions"][T], buf["masks"][T])
-        next_value = O.heads(params, feats)[2]
+        next_value = torch.nn.functional.linear(feats, params["critic.fc.weight"], params["critic.fc.bias"])
     return params, spec, buf, next_value
 
 
@@ -170,8 +184,11 @@ def test_oracle_rollout_returns_update_vs_reference_golden(case):
     cfg = make_cfg(**c["cfg"])
     T, N = c["T"], c["N"]
     params, spec, buf, next_value = oracle_rollout(case, z)
-    # sampled actions are bit-identical, the float quantities agree to fp32 round-off
-    assert (buf["actions"].numpy() == z["roll_actions"]).all()
+    # sampled actions are bit-identical (continuous ones: mu + std * eps, to round-off), the float quantities agree to fp32 round-off
+    if c.get("gauss"):
+        assert np.abs(buf["actions"].numpy() - z["roll_actions"]).max() < 2e-6
+    else:
+        assert (buf["actions"].numpy() == z["roll_actions"]).all()
     assert (buf["masks"].numpy() == z["roll_masks"]).all()
     assert np.array_equal(buf["rewards"].numpy(), z["roll_rewards"])
     for k in ("action_log_probs", "value_preds", "recurrent_hidden_states"):
@@ -205,10 +222,17 @@ def test_oracle_rollout_returns_update_vs_reference_golden(case):
     assert np.abs(lp.detach().numpy() - z["mb0_logp"]).max() < 2e-5
     assert np.abs(ent.detach().numpy() - z["mb0_entropy"]).max() < 2e-5
     assert np.abs(hfin.detach().numpy() - z["mb0_hidden"]).max() < 2e-5
-    total, vl, al, de, _ = O.ppo_loss(v, lp, ent, batch, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)
+    import math
+    lag = None
+    if c.get("lagrange"):
+        lag = dict(log_alpha=torch.full((), math.log(c["lagrange"]["init_alpha"])).requires_grad_(True), threshold=c["lagrange"]["threshold"])
+    total, vl, al, de, _ = O.ppo_loss(v, lp, ent, batch, cfg.clip_param, cfg.value_loss_coef, lag if lag else cfg.entropy_coef,
+                                      cfg.use_clipped_value_loss)
     got = np.array([vl.item(), al.item(), de.item(), total.item()])
     assert np.allclose(got, z["mb0_losses"], rtol=1e-4, atol=1e-6)
     total.backward()
+    if lag:
+        assert np.allclose(lag["log_alpha"].grad.numpy(), z["mb0_grad_log_alpha"], rtol=1e-4)
     for k in trainable:
         g_ref = z["grad/" + k]
         g = p[k].grad.numpy()
@@ -222,10 +246,16 @@ def test_oracle_rollout_returns_update_vs_reference_golden(case):
     for k, val in rmv0.items():  # the reference module kept the RunningMeanAndVar statistics of the mb0 evaluate above
         p["net.visual_encoder.running_mean_and_var._" + k] = val.clone()
     opt = dict(step=0, m={k: torch.zeros_like(p[k]) for k in trainable}, v={k: torch.zeros_like(p[k]) for k in trainable})
+    if c.get("lagrange"):
+        opt["lagrange"] = dict(log_alpha=torch.full((), math.log(c["lagrange"]["init_alpha"])).requires_grad_(True),
+                               m=torch.zeros(()), v=torch.zeros(()), threshold=c["lagrange"]["threshold"])
     metrics = O.ppo_update(p, spec, buf, T, cfg, opt, trainable, perms=perms)
     for k, val in metrics.items():
         ref = float(z["metric/" + k])
         assert abs(val - ref) <= 1e-4 * max(1.0, abs(ref)), (k, val, ref)
+    if c.get("lagrange"):
+        assert "entropy_coef" in metrics
+        assert abs(float(opt["lagrange"]["log_alpha"]) - float(z["post_log_alpha"])) <= 1e-5
     for k in params:
         ref = z["post/" + k]
         got = samp(p[k].detach().numpy()).reshape(ref.shape)
