@@ -25,6 +25,7 @@ struct RnConv {
     int i_w = -1, i_gamma = -1, i_beta = -1;
     int64_t pk_f = -1, pk_d = -1;   // packed weights (pk_d < 0: no data gradient needed)
     int64_t w_raw = -1, w_mean = -1, w_rstd = -1, w_out = -1;
+    int cgroups = 1;             // ResNeXt: groups of the 3x3 convolution (weight parameter is (Cout, C / cgroups, 3, 3))
     int64_t out_floats() const { return (int64_t)cd.Ho() * cd.Wo() * cd.Cout; }
     int64_t in_floats() const { return (int64_t)cd.H * cd.W * cd.C; }
 };
@@ -34,6 +35,10 @@ struct RnBlock {
     int ds = -1;             // downsample conv or -1
     int64_t w_in = -1;       // block input (previous block's out / pool)
     int64_t w_out = -1;      // block output
+    // squeeze-and-excitation gate (SEBottleneck, resnet.py:155-187): out = relu(se(convs(x)) * convs(x) + identity)
+    int se_c = 0, se_r = 0;  // channels, reduced width (channels / 16); 0 = no SE
+    int i_se1w = -1, i_se1b = -1, i_se2w = -1, i_se2b = -1;
+    int64_t w_se_pool = -1, w_se_h = -1, w_se_gate = -1;   // [B][C], [B][C/16], [B][C] (the last conv's w_out holds the un-gated GN output)
 };
 
 }  // namespace
@@ -62,7 +67,11 @@ struct ResNetPlan {
     int64_t w_stats = -1;     // RunningMeanAndVar batch moments: mean[8], count, var[8] at +16 (+ padding)
     int64_t w_dscratch = -1;  // doubles for chan_moment partials
     int64_t w_embsave = -1;   // [B][4] goal features + previous-action token of the last forward
+    int64_t w_se_scr = -1;    // SE backward scratch: dgate / dz / dpool [B][Cmax] x 3 + dh [B][Cmax/16]
+    int64_t w_gdense = -1;    // dense OIHW weight gradient of the largest grouped convolution
+    int64_t gdense_floats = 0;
     int cmax = 0;
+    int nlayers[4] = {2, 2, 2, 2};
 };
 
 static int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
@@ -76,7 +85,9 @@ static int add_conv_gn(hab_policy* e, RnConv& c, const std::string& wname, const
 
 int build_resnet(hab_policy* e) {
     const hab_policy_desc& d = e->d;
-    if (d.backbone != 18 && d.backbone != 50) return HAB_ERR_UNSUPPORTED;
+    if (d.backbone != HAB_BACKBONE_RESNET18 && d.backbone != HAB_BACKBONE_RESNET50 && d.backbone != HAB_BACKBONE_RESNEXT50 &&
+        d.backbone != HAB_BACKBONE_SE_RESNET50 && d.backbone != HAB_BACKBONE_SE_RESNEXT50 && d.backbone != HAB_BACKBONE_SE_RESNEXT101)
+        return HAB_ERR_UNSUPPORTED;
     if (d.baseplanes <= 0 || d.baseplanes % 8) return HAB_ERR_UNSUPPORTED;
     if ((d.H & 1) || (d.W & 1)) return HAB_ERR_UNSUPPORTED;
     if (d.rnn_type != HAB_RNN_GRU && d.rnn_type != HAB_RNN_LSTM) return HAB_ERR_ARG;
@@ -103,10 +114,16 @@ int build_resnet(hab_policy* e) {
     }
     r->H2 = d.H / 2; r->W2 = d.W / 2;
     const int bp = d.baseplanes, ng = bp / 2;
-    const bool bottleneck = d.backbone == 50;
-    const int expansion = bottleneck ? 4 : 1;
-    static const int L18[4] = {2, 2, 2, 2}, L50[4] = {3, 4, 6, 3};
-    const int* layers = bottleneck ? L50 : L18;
+    // resnet.py:296-345: block type, stage depths, ResNeXt (expansion 2, base width x2, grouped 3x3 with cardinality
+    // base_planes / 2 -- in the FIRST block of every stage only, _make_layer :257-268 passes it to no other), SE gate
+    const bool bottleneck = d.backbone != HAB_BACKBONE_RESNET18;
+    const bool resnext = d.backbone == HAB_BACKBONE_RESNEXT50 || d.backbone == HAB_BACKBONE_SE_RESNEXT50 || d.backbone == HAB_BACKBONE_SE_RESNEXT101;
+    const bool se = d.backbone == HAB_BACKBONE_SE_RESNET50 || d.backbone == HAB_BACKBONE_SE_RESNEXT50 || d.backbone == HAB_BACKBONE_SE_RESNEXT101;
+    const int expansion = !bottleneck ? 1 : (resnext ? 2 : 4);
+    const int cardinality = resnext ? bp / 2 : 1;
+    static const int L18[4] = {2, 2, 2, 2}, L50[4] = {3, 4, 6, 3}, L101[4] = {3, 4, 23, 3};
+    const int* layers = !bottleneck ? L18 : (d.backbone == HAB_BACKBONE_SE_RESNEXT101 ? L101 : L50);
+    r->nlayers[0] = layers[0]; r->nlayers[1] = layers[1]; r->nlayers[2] = layers[2]; r->nlayers[3] = layers[3];
 
     // ---- parameter table in the reference's state_dict order (resnet_policy.py:389-396,454-456 first) ----
     const bool gauss = d.action_dist == HAB_DIST_GAUSSIAN;
@@ -150,17 +167,20 @@ int build_resnet(hab_policy* e) {
     r->poolH = conv_out(sh, 3, 2, 1); r->poolW = conv_out(sw, 3, 2, 1);
     int inplanes = bp, curH = r->poolH, curW = r->poolW;
     for (int li = 0; li < 4; ++li) {
-        const int planes = bp << li;
+        const int planes = (resnext ? 2 * bp : bp) << li;
         for (int bi = 0; bi < layers[li]; ++bi) {
             const int stride = (bi == 0 && li > 0) ? 2 : 1;
             const std::string bpfx = bb + "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
             const bool has_ds = bi == 0 && (stride != 1 || inplanes != planes * expansion);
             RnBlock blk;
-            auto push = [&](int cin, int cout, int k, int s, int p, int hh, int ww, const std::string& w, const std::string& g) {
+            auto push = [&](int cin, int cout, int k, int s, int p, int hh, int ww, const std::string& w, const std::string& g,
+                            int cgroups = 1) {
                 RnConv c;
                 c.cd = ConvDesc{0, hh, ww, cin, cout, k, k, s, p};
                 c.groups = ng;
-                add_conv_gn(e, c, w, g, cin);
+                c.cgroups = cgroups;
+                add_conv_gn(e, c, w, g, cin / cgroups);
+                if (cgroups > 1) r->gdense_floats = std::max<int64_t>(r->gdense_floats, (int64_t)cout * cin * k * k);
                 r->convs.push_back(c);
                 return (int)r->convs.size() - 1;
             };
@@ -170,10 +190,19 @@ int build_resnet(hab_policy* e) {
                 blk.convs.push_back(push(planes, planes, 3, 1, 1, oh, ow, bpfx + "convs.3", bpfx + "convs.4"));
             } else {
                 blk.convs.push_back(push(inplanes, planes, 1, 1, 0, curH, curW, bpfx + "convs.0", bpfx + "convs.1"));
-                blk.convs.push_back(push(planes, planes, 3, stride, 1, curH, curW, bpfx + "convs.3", bpfx + "convs.4"));
+                blk.convs.push_back(push(planes, planes, 3, stride, 1, curH, curW, bpfx + "convs.3", bpfx + "convs.4",
+                                         bi == 0 ? cardinality : 1));
                 blk.convs.push_back(push(planes, planes * expansion, 1, 1, 0, oh, ow, bpfx + "convs.6", bpfx + "convs.7"));
             }
             if (has_ds) blk.ds = push(inplanes, planes * expansion, 1, stride, 0, curH, curW, bpfx + "downsample.0", bpfx + "downsample.1");
+            if (se) {  // registered after convs / downsample (SEBottleneck.__init__, resnet.py:166-176)
+                blk.se_c = planes * expansion; blk.se_r = blk.se_c / 16;
+                if (blk.se_r < 4 || (blk.se_r & 3)) return HAB_ERR_UNSUPPORTED;
+                blk.i_se1w = add_param(e, bpfx + "se.excite.0.weight", {blk.se_r, blk.se_c});
+                blk.i_se1b = add_param(e, bpfx + "se.excite.0.bias", {blk.se_r});
+                blk.i_se2w = add_param(e, bpfx + "se.excite.2.weight", {blk.se_c, blk.se_r});
+                blk.i_se2b = add_param(e, bpfx + "se.excite.2.bias", {blk.se_c});
+            }
             r->blocks.push_back(blk);
             inplanes = planes * expansion;
             curH = oh; curW = ow;
@@ -253,6 +282,10 @@ int build_resnet(hab_policy* e) {
         }
         if (blk.ds >= 0) { place(r->convs[blk.ds], true); r->gbuf_floats = std::max(r->gbuf_floats, r->convs[blk.ds].out_floats()); }
         blk.w_out = r->convs[blk.convs.back()].w_out;
+        if (blk.se_c) {  // the gated block output needs its own buffer: the last conv's w_out keeps the un-gated GN output
+            blk.w_out = wk.take(B * r->convs[blk.convs.back()].out_floats());
+            blk.w_se_pool = wk.take(B * blk.se_c); blk.w_se_h = wk.take(B * blk.se_r); blk.w_se_gate = wk.take(B * blk.se_c);
+        }
         prev = blk.w_out;
     }
     place(r->comp, true);
@@ -263,6 +296,8 @@ int build_resnet(hab_policy* e) {
     r->w_stats = wk.take(64);
     r->w_dscratch = wk.take(2 * 1024 * 8);  // 1024 blocks x 8 channels of double
     r->w_embsave = wk.take(B * 4 * EMB_MAX_SLOTS);
+    if (se) r->w_se_scr = wk.take(B * ((int64_t)3 * r->cmax + r->cmax / 16 + 16));
+    if (r->gdense_floats) r->w_gdense = wk.take(r->gdense_floats);
     // shared tail (RNN, heads) -- same layout as the SimpleCNN engine
     e->w_rnnin = wk.take(B * e->rnn_ld); e->w_drnnin = wk.take(B * e->rnn_ld);
     e->w_hinit = wk.take((int64_t)d.rnn_layers * F * H); e->w_cinit = wk.take((int64_t)d.rnn_layers * F * H);
@@ -295,6 +330,9 @@ int resnet_repack(hab_policy* e, hipStream_t s) {
     ResNetPlan* r = e->rn;
     const int H = e->d.hidden;
     auto rp = [&](const RnConv& c, int cin_real) {
+        if (c.cgroups > 1)
+            return repack_conv_grouped(e->p(c.i_w), e->PK + c.pk_f, c.pk_d >= 0 ? e->PK + c.pk_d : nullptr, c.cd.Cout, c.cd.C, c.cgroups,
+                                       c.cd.KH, c.cd.KW, s);
         return repack_conv(e->p(c.i_w), e->PK + c.pk_f, c.pk_d >= 0 ? e->PK + c.pk_d : nullptr, c.cd.Cout, cin_real, c.cd.KH, c.cd.KW,
                            c.cd.C, s);
     };
@@ -447,8 +485,21 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
         for (size_t q = 0; q < blk.convs.size(); ++q) {
             const RnConv& c = r->convs[blk.convs[q]];
             const bool last = q + 1 == blk.convs.size();
-            HAB_TRY(conv_gn_forward(e, c, cur, last ? residual : nullptr, 1, B, s));
+            if (last && blk.se_c) HAB_TRY(conv_gn_forward(e, c, cur, nullptr, 0, B, s));  // un-gated: the SE gate comes next
+            else HAB_TRY(conv_gn_forward(e, c, cur, last ? residual : nullptr, 1, B, s));
             cur = W + c.w_out;
+        }
+        if (blk.se_c) {  // out = relu(sigmoid(W2 relu(W1 mean_hw(y) + b1) + b2) * y + identity)
+            const RnConv& c = r->convs[blk.convs.back()];
+            const int HW = c.cd.Ho() * c.cd.Wo(), C = blk.se_c, R = blk.se_r;
+            float* ws = W + e->w_ws;
+            HAB_TRY(se_pool(W + c.w_out, W + blk.w_se_pool, B, HW, C, s));
+            HAB_TRY(linear_fwd(W + blk.w_se_pool, C, e->p(blk.i_se1w), C, e->p(blk.i_se1b), W + blk.w_se_h, R, B, R, C, 1, 0, ws,
+                               e->ws_floats, s));
+            HAB_TRY(linear_fwd(W + blk.w_se_h, R, e->p(blk.i_se2w), R, e->p(blk.i_se2b), W + blk.w_se_gate, C, B, C, R, 0, 0, ws,
+                               e->ws_floats, s));
+            HAB_TRY(sigmoid_inplace(W + blk.w_se_gate, (long long)B * C, s));
+            HAB_TRY(se_apply_forward(W + c.w_out, W + blk.w_se_gate, residual, W + blk.w_out, B, HW, C, s));
         }
     }
     return conv_gn_forward(e, r->comp, W + r->blocks.back().w_out, nullptr, 1, B, s);
@@ -528,14 +579,42 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
         float* d_pre = gp.get();
         float* cur = gp.get();
         if (!d_pre || !cur) return HAB_ERR_ARG;
-        HAB_TRY(gn_backward(e, r->convs[blk.convs[n - 1]], d_out, out, cur, d_pre, B, s));
+        if (blk.se_c) {
+            // through the gate: dm = d_out * (out > 0) (= the identity branch's gradient), dgate = sum_hw dm * y, then the two tiny
+            // linears backwards, and dy = dm * gate + dpool / HW is what the last GroupNorm receives
+            const RnConv& c = r->convs[blk.convs[n - 1]];
+            const int HW = c.cd.Ho() * c.cd.Wo(), C = blk.se_c, R = blk.se_r;
+            float* scr = W + r->w_se_scr;
+            float* dgate = scr; float* dz = scr + (size_t)B * r->cmax; float* dpool = scr + (size_t)2 * B * r->cmax;
+            float* dh = scr + (size_t)3 * B * r->cmax;
+            HAB_TRY(se_backward_reduce(d_out, out, W + c.w_out, d_pre, dgate, B, HW, C, s));
+            HAB_TRY(sigmoid_grad(W + blk.w_se_gate, dgate, dz, (long long)B * C, s));
+            HAB_TRY(linear_wgrad(dz, C, W + blk.w_se_h, R, e->g(blk.i_se2w), R, B, C, R, 0, 0, 0, ws, e->ws_floats, s));
+            HAB_TRY(colsum(dz, C, B, C, e->g(blk.i_se2b), 0, ws, e->ws_floats, s));
+            HAB_TRY(linear_dgrad(dz, C, e->p(blk.i_se2w), R, W + blk.w_se_h, R, R, dh, R, B, R, C, 0, ws, e->ws_floats, s));
+            HAB_TRY(linear_wgrad(dh, R, W + blk.w_se_pool, C, e->g(blk.i_se1w), C, B, R, C, 0, 0, 0, ws, e->ws_floats, s));
+            HAB_TRY(colsum(dh, R, B, R, e->g(blk.i_se1b), 0, ws, e->ws_floats, s));
+            HAB_TRY(linear_dgrad(dh, R, e->p(blk.i_se1w), C, nullptr, 0, 0, dpool, C, B, C, R, 0, ws, e->ws_floats, s));
+            float* dy_gn = gp.get();
+            if (!dy_gn) return HAB_ERR_ARG;
+            HAB_TRY(se_backward_apply(d_pre, W + blk.w_se_gate, dpool, dy_gn, B, HW, C, s));
+            HAB_TRY(gn_backward(e, c, dy_gn, nullptr, cur, nullptr, B, s));
+            gp.put(dy_gn);
+        } else {
+            HAB_TRY(gn_backward(e, r->convs[blk.convs[n - 1]], d_out, out, cur, d_pre, B, s));
+        }
         gp.put(d_out);
         for (int q = n - 1; q >= 1; --q) {
             const RnConv& c = r->convs[blk.convs[q]];
             const RnConv& pc = r->convs[blk.convs[q - 1]];
             ConvDesc c2 = c.cd;
             c2.B = B;
-            HAB_TRY(conv_wgrad(c2, W + pc.w_out, cur, e->g(c.i_w), nullptr, ws, e->ws_floats, s));
+            if (c.cgroups > 1) {  // dense weight gradient into scratch, block diagonal gathered into the (Cout, C / groups, 3, 3) gradient
+                HAB_TRY(conv_wgrad(c2, W + pc.w_out, cur, W + r->w_gdense, nullptr, ws, e->ws_floats, s));
+                HAB_TRY(gather_grouped_wgrad(W + r->w_gdense, e->g(c.i_w), c.cd.Cout, c.cd.C, c.cgroups, c.cd.KH, c.cd.KW, s));
+            } else {
+                HAB_TRY(conv_wgrad(c2, W + pc.w_out, cur, e->g(c.i_w), nullptr, ws, e->ws_floats, s));
+            }
             float* tmp = gp.get();
             if (!tmp) return HAB_ERR_ARG;
             HAB_TRY(conv_dgrad(c2, cur, e->PK + c.pk_d, W + pc.w_out /* ReLU mask */, nullptr, tmp, ws, e->ws_floats, s));
@@ -605,8 +684,7 @@ int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats) {
     }
     if (which >= HAB_TAP_LAYER1 && which < HAB_TAP_LAYER1 + 4) {
         // last block of stage (which - HAB_TAP_LAYER1)
-        static const int L18[4] = {2, 2, 2, 2}, L50[4] = {3, 4, 6, 3};
-        const int* layers = e->d.backbone == 50 ? L50 : L18;
+        const int* layers = r->nlayers;
         int idx = -1;
         for (int li = 0; li <= which - HAB_TAP_LAYER1; ++li) idx += layers[li];
         const RnBlock& blk = r->blocks[idx];

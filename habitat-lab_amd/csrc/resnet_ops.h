@@ -69,6 +69,20 @@ int groupnorm_forward(const GnArgs& a, hipStream_t s);
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s);
 int maxpool_forward(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t s);
 int maxpool_backward(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t s);
+// Squeeze-and-excitation gate of SEBottleneck (resnet.py:92-113,155-187): pooled[b][c] = mean_hw x;  y = relu(gate[b][c] * x + residual);
+// backward pieces: dm = dy * (y > 0) (written out: it is also the residual branch's gradient), dgate[b][c] = sum_hw dm * x, and
+// dx = dm * gate[b][c] + dpool[b][c] / HW (the squeeze's gradient spread over the frame).
+int se_pool(const float* x, float* pooled, int B, int HW, int C, hipStream_t s);
+int se_apply_forward(const float* x, const float* gate, const float* residual, float* y, int B, int HW, int C, hipStream_t s);
+int se_backward_reduce(const float* dy, const float* y, const float* x, float* dm, float* dgate, int B, int HW, int C, hipStream_t s);
+int se_backward_apply(const float* dm, const float* gate, const float* dpool, float* dx, int B, int HW, int C, hipStream_t s);
+int sigmoid_inplace(float* z, long long n, hipStream_t s);
+int sigmoid_grad(const float* g, const float* dg, float* dz, long long n, hipStream_t s);
+// Grouped 3x3 convolution of the ResNeXt bottlenecks (resnet.py:72-89, groups = cardinality): the weight (Cout, Cin/groups, KH, KW)
+// is expanded to the dense block-diagonal kernel layouts (zeros off the diagonal) so that the dense contraction kernels serve it;
+// the dense weight gradient is computed into scratch and its block diagonal is gathered back.
+int repack_conv_grouped(const float* w, float* wf, float* wd, int Cout, int Cin, int groups, int KH, int KW, hipStream_t s);
+int gather_grouped_wgrad(const float* dense_oihw, float* dw, int Cout, int Cin, int groups, int KH, int KW, hipStream_t s);
 int embed_forward(const EmbedArgs& a, hipStream_t s);
 int embed_backward(const EmbedBwdArgs& a, float* ws, size_t ws_floats, hipStream_t s);
 

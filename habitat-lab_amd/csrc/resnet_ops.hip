@@ -1108,6 +1108,153 @@ int embed_backward(const EmbedBwdArgs& a, float* ws, size_t ws_floats, hipStream
     return HAB_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Squeeze-and-excitation (resnet.py:92-113): block per frame, thread per channel quad, fixed-order loops over the frame.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) se_pool_kernel(const float* __restrict__ x, float* __restrict__ pooled, int HW, int C) {
+    const int b = blockIdx.x, C4 = C >> 2;
+    const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * HW * C);
+    const float inv = 1.0f / (float)HW;
+    for (int c = threadIdx.x; c < C4; c += 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < HW; ++p) s += xb[(size_t)p * C4 + c];
+        *reinterpret_cast<f32x4*>(pooled + (size_t)b * C + c * 4) = s * inv;
+    }
+}
+int se_pool(const float* x, float* pooled, int B, int HW, int C, hipStream_t s) {
+    if (!x || !pooled || B <= 0 || HW <= 0 || (C & 3)) return HAB_ERR_ARG;
+    se_pool_kernel<<<B, 256, 0, s>>>(x, pooled, HW, C);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+__global__ void __launch_bounds__(256) se_apply_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                           const float* __restrict__ residual, float* __restrict__ y, long long total4,
+                                                           int HWC4, int C4) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        const int b = (int)(e / HWC4), c = (int)(e % C4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gate + ((size_t)b * C4 + c) * 4);
+        f32x4 v = g * reinterpret_cast<const f32x4*>(x)[e] + reinterpret_cast<const f32x4*>(residual)[e];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        reinterpret_cast<f32x4*>(y)[e] = v;
+    }
+}
+int se_apply_forward(const float* x, const float* gate, const float* residual, float* y, int B, int HW, int C, hipStream_t s) {
+    if (!x || !gate || !residual || !y || B <= 0 || (C & 3)) return HAB_ERR_ARG;
+    const long long total4 = (long long)B * HW * (C >> 2);
+    se_apply_fwd_kernel<<<(int)fmin(32768.0, (double)cdivl(total4, 256)), 256, 0, s>>>(x, gate, residual, y, total4, HW * (C >> 2), C >> 2);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+__global__ void __launch_bounds__(256) se_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ x, float* __restrict__ dm,
+                                                            float* __restrict__ dgate, int HW, int C) {
+    const int b = blockIdx.x, C4 = C >> 2;
+    const size_t fb = (size_t)b * HW * C4;
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy) + fb;
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y) + fb;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + fb;
+    f32x4* dm4 = reinterpret_cast<f32x4*>(dm) + fb;
+    for (int c = threadIdx.x; c < C4; c += 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < HW; ++p) {
+            const size_t i = (size_t)p * C4 + c;
+            f32x4 d = dy4[i];
+            const f32x4 yv = y4[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = yv[k] > 0.f ? d[k] : 0.f;
+            dm4[i] = d;
+            s += d * x4[i];
+        }
+        *reinterpret_cast<f32x4*>(dgate + (size_t)b * C + c * 4) = s;
+    }
+}
+int se_backward_reduce(const float* dy, const float* y, const float* x, float* dm, float* dgate, int B, int HW, int C, hipStream_t s) {
+    if (!dy || !y || !x || !dm || !dgate || B <= 0 || (C & 3)) return HAB_ERR_ARG;
+    se_bwd_reduce_kernel<<<B, 256, 0, s>>>(dy, y, x, dm, dgate, HW, C);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+__global__ void __launch_bounds__(256) se_bwd_apply_kernel(const float* __restrict__ dm, const float* __restrict__ gate,
+                                                           const float* __restrict__ dpool, float* __restrict__ dx, long long total4,
+                                                           int HWC4, int C4, float inv_hw) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        const int b = (int)(e / HWC4), c = (int)(e % C4);
+        const size_t o = ((size_t)b * C4 + c) * 4;
+        reinterpret_cast<f32x4*>(dx)[e] = reinterpret_cast<const f32x4*>(dm)[e] * *reinterpret_cast<const f32x4*>(gate + o) +
+                                          *reinterpret_cast<const f32x4*>(dpool + o) * inv_hw;
+    }
+}
+int se_backward_apply(const float* dm, const float* gate, const float* dpool, float* dx, int B, int HW, int C, hipStream_t s) {
+    if (!dm || !gate || !dpool || !dx || B <= 0 || (C & 3)) return HAB_ERR_ARG;
+    const long long total4 = (long long)B * HW * (C >> 2);
+    se_bwd_apply_kernel<<<(int)fmin(32768.0, (double)cdivl(total4, 256)), 256, 0, s>>>(dm, gate, dpool, dx, total4, HW * (C >> 2), C >> 2,
+                                                                                         1.0f / (float)HW);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+__global__ void sigmoid_kernel(float* __restrict__ z, long long n) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) z[e] = 1.0f / (1.0f + expf(-z[e]));
+}
+__global__ void sigmoid_grad_kernel(const float* __restrict__ g, const float* __restrict__ dg, float* __restrict__ dz, long long n) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) dz[e] = dg[e] * g[e] * (1.0f - g[e]);
+}
+int sigmoid_inplace(float* z, long long n, hipStream_t s) {
+    if (!z || n <= 0) return HAB_ERR_ARG;
+    sigmoid_kernel<<<(int)fmin(4096.0, (double)cdivl(n, 256)), 256, 0, s>>>(z, n);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+int sigmoid_grad(const float* g, const float* dg, float* dz, long long n, hipStream_t s) {
+    if (!g || !dg || !dz || n <= 0) return HAB_ERR_ARG;
+    sigmoid_grad_kernel<<<(int)fmin(4096.0, (double)cdivl(n, 256)), 256, 0, s>>>(g, dg, dz, n);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// Grouped-conv weight (Cout, Cin/groups, KH, KW) -> dense Wf [co][kh][kw][ci] / Wd [ci][kh][kw][co] with zeros off the block diagonal
+__global__ void repack_grouped_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd, int Cout, int Cin,
+                                      int groups, int KH, int KW) {
+    const int total = Cout * Cin * KH * KW, cig = Cin / groups, cog = Cout / groups;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int ci = e % Cin;
+        int t = e / Cin;
+        const int kw = t % KW; t /= KW;
+        const int kh = t % KH;
+        const int co = t / KH;
+        const int g = co / cog;
+        const int cl = ci - g * cig;
+        const float v = (cl >= 0 && cl < cig) ? w[(((size_t)co * cig + cl) * KH + kh) * KW + kw] : 0.f;
+        wf[e] = v;
+        if (wd) wd[(((size_t)ci * KH + kh) * KW + kw) * Cout + co] = v;
+    }
+}
+int repack_conv_grouped(const float* w, float* wf, float* wd, int Cout, int Cin, int groups, int KH, int KW, hipStream_t s) {
+    if (!w || !wf || groups <= 0 || Cout % groups || Cin % groups) return HAB_ERR_ARG;
+    const int total = Cout * Cin * KH * KW;
+    repack_grouped_kernel<<<min(2048, cdiv(total, 256)), 256, 0, s>>>(w, wf, wd, Cout, Cin, groups, KH, KW);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+__global__ void gather_grouped_kernel(const float* __restrict__ dense, float* __restrict__ dw, int Cout, int Cin, int groups, int KH, int KW) {
+    const int cig = Cin / groups, cog = Cout / groups, total = Cout * cig * KH * KW;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        int t = e / (KH * KW);
+        const int r = e % (KH * KW);
+        const int cl = t % cig;
+        const int co = t / cig;
+        const int ci = (co / cog) * cig + cl;
+        dw[e] = dense[((size_t)co * Cin + ci) * KH * KW + r];
+    }
+}
+int gather_grouped_wgrad(const float* dense_oihw, float* dw, int Cout, int Cin, int groups, int KH, int KW, hipStream_t s) {
+    if (!dense_oihw || !dw || groups <= 0 || Cout % groups || Cin % groups) return HAB_ERR_ARG;
+    const int total = Cout * (Cin / groups) * KH * KW;
+    gather_grouped_kernel<<<min(2048, cdiv(total, 256)), 256, 0, s>>>(dense_oihw, dw, Cout, Cin, groups, KH, KW);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
 }  // namespace hab
 
 // ------------------------------------------- C ABI -------------------------------------------

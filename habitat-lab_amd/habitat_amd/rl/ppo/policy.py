@@ -452,6 +452,12 @@ class PointNavBaselinePolicy(NetPolicy):
                    max_frames=int(ppo.num_steps) * max(1, -(-n_envs // int(ppo.num_mini_batch))), max_envs=n_envs)
 
 
+# rl/ddppo/policy/resnet.py:296-345 -> (HAB_BACKBONE_* code, block kind, stage depths, ResNeXt?, SE?)
+BACKBONES = {"resnet18": (18, "basic", [2, 2, 2, 2], False, False), "resnet50": (50, "bottleneck", [3, 4, 6, 3], False, False),
+             "resneXt50": (51, "bottleneck", [3, 4, 6, 3], True, False), "se_resnet50": (52, "bottleneck", [3, 4, 6, 3], False, True),
+             "se_resneXt50": (53, "bottleneck", [3, 4, 6, 3], True, True), "se_resneXt101": (101, "bottleneck", [3, 4, 23, 3], True, True)}
+
+
 def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, baseplanes, H, W, normalize, has_goal=True, n_obj=0,
                  has_gps=False, has_compass=False, gauss=None):
     """Parameter / buffer values exactly as PointNavResNetPolicy.__init__ produces them: the torch modules are created in
@@ -488,12 +494,13 @@ def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, base
         out[ve + "running_mean_and_var._var"] = torch.zeros(1, n_in, 1, 1)
         out[ve + "running_mean_and_var._count"] = torch.zeros(())
     ng = baseplanes // 2
-    bottleneck = backbone == "resnet50"
-    expansion = 4 if bottleneck else 1
-    layers = [3, 4, 6, 3] if bottleneck else [2, 2, 2, 2]
+    _, kind, layers, resnext, se = BACKBONES[backbone]
+    bottleneck = kind == "bottleneck"
+    expansion = (2 if resnext else 4) if bottleneck else 1
+    cardinality = baseplanes // 2 if resnext else 1
 
-    def conv_gn(prefix_w, prefix_g, cin, cout, k, groups):
-        conv = nn.Conv2d(cin, cout, kernel_size=k, bias=False)
+    def conv_gn(prefix_w, prefix_g, cin, cout, k, groups, conv_groups=1):
+        conv = nn.Conv2d(cin, cout, kernel_size=k, bias=False, groups=conv_groups)
         gn = nn.GroupNorm(groups, cout)
         out[prefix_w + ".weight"] = conv.weight.detach()
         out[prefix_g + ".weight"], out[prefix_g + ".bias"] = gn.weight.detach(), gn.bias.detach()
@@ -502,7 +509,7 @@ def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, base
     conv_gn(bb + "conv1.0", bb + "conv1.1", n_in, baseplanes, 7, ng)
     inplanes = baseplanes
     for li, nblocks in enumerate(layers):
-        planes = baseplanes * (2 ** li)
+        planes = (2 * baseplanes if resnext else baseplanes) * (2 ** li)  # resnet.py:223-225
         for bi in range(nblocks):
             stride = 2 if (bi == 0 and li > 0) else 1
             bp = f"{bb}layer{li + 1}.{bi}."
@@ -516,11 +523,19 @@ def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, base
                 conv_gn(bp + "convs.3", bp + "convs.4", planes, planes, 3, ng)
             else:
                 conv_gn(bp + "convs.0", bp + "convs.1", inplanes, planes, 1, ng)
-                conv_gn(bp + "convs.3", bp + "convs.4", planes, planes, 3, ng)
+                # only the first block of a stage receives the cardinality (resnet.py:257-268)
+                conv_gn(bp + "convs.3", bp + "convs.4", planes, planes, 3, ng, conv_groups=cardinality if bi == 0 else 1)
                 conv_gn(bp + "convs.6", bp + "convs.7", planes, planes * expansion, 1, ng)
+            se_mods = None
+            if se and bottleneck:  # SE is created after the block's convs (resnet.py:166-176), registered after downsample
+                c_se = planes * expansion
+                se_mods = (nn.Linear(c_se, int(c_se / 16)), nn.Linear(int(c_se / 16), c_se))
             if ds is not None:
                 out[bp + "downsample.0.weight"] = ds[0].weight.detach()
                 out[bp + "downsample.1.weight"], out[bp + "downsample.1.bias"] = ds[1].weight.detach(), ds[1].bias.detach()
+            if se_mods is not None:
+                out[bp + "se.excite.0.weight"], out[bp + "se.excite.0.bias"] = se_mods[0].weight.detach(), se_mods[0].bias.detach()
+                out[bp + "se.excite.2.weight"], out[bp + "se.excite.2.bias"] = se_mods[1].weight.detach(), se_mods[1].bias.detach()
             inplanes = planes * expansion
     fh, fw = int(np.ceil((H // 2) / 32.0)), int(np.ceil((W // 2) / 32.0))
     ncomp = int(round(2048 / (fh * fw)))
@@ -591,8 +606,8 @@ class PointNavResNetPolicy(NetPolicy):
                  normalize_visual_inputs: bool = False, force_blind_policy: bool = False, policy_config=None,
                  aux_loss_config=None, fuse_keys=None, max_frames: int = 4096, max_envs: int = 64, **kwargs):
         sp = observation_space.spaces
-        if backbone not in ("resnet18", "resnet50"):
-            raise _lib.HabError(f"backbone {backbone!r} is outside the accelerated path (resnet18 / resnet50)")
+        if backbone not in BACKBONES:
+            raise _lib.HabError(f"backbone {backbone!r} is not one of {sorted(BACKBONES)} (rl/ddppo/policy/resnet.py:296-345)")
         if force_blind_policy or aux_loss_config:
             raise _lib.HabError("blind policies / auxiliary losses are outside the accelerated path")
         gauss = gauss_kw = None
@@ -622,7 +637,7 @@ class PointNavResNetPolicy(NetPolicy):
             raise _lib.HabError("gps sensor must be 2-D")
         bufs = tuple("net.visual_encoder.running_mean_and_var." + k for k in ("_mean", "_var", "_count")) if normalize_visual_inputs else ()
         super().__init__(action_space,
-                         dict(arch="resnet", backbone=int(backbone[6:]), baseplanes=resnet_baseplanes,
+                         dict(arch="resnet", backbone=BACKBONES[backbone][0], baseplanes=resnet_baseplanes,
                               normalize_visual_inputs=bool(normalize_visual_inputs), rnn_type=rnn_type,
                               rnn_layers=num_recurrent_layers, hidden=hidden_size, H=H, W=W, has_rgb=has_rgb, has_depth=has_depth,
                               goal_dim=2 if has_goal else 0, max_frames=max_frames, max_envs=max_envs,

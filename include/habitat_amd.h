@@ -277,7 +277,7 @@ int hab_build_pack_info_from_ids(const int64_t* episode_ids, const int64_t* envi
 
 typedef struct hab_policy_desc {
     int32_t arch;          /* HAB_ARCH_* */
-    int32_t backbone;      /* 18 or 50 (arch 1) */
+    int32_t backbone;      /* HAB_BACKBONE_* (arch 1) */
     int32_t baseplanes;    /* 32 */
     int32_t normalize_visual_inputs;
     int32_t rnn_type;      /* HAB_RNN_* */
@@ -302,6 +302,13 @@ typedef struct hab_policy_desc {
     int32_t gauss_flags;           /* HAB_GAUSS_* bits (ActionDistributionConfig, default_structured_configs.py:70-85) */
     float gauss_min_std, gauss_max_std;  /* clamp range of the RAW std output (min_log_std / max_log_std when USE_LOG_STD) */
 } hab_policy_desc;
+/* rl/ddppo/policy/resnet.py:296-345 */
+#define HAB_BACKBONE_RESNET18 18
+#define HAB_BACKBONE_RESNET50 50
+#define HAB_BACKBONE_RESNEXT50 51      /* resneXt50: expansion 2, base width x2, grouped 3x3 (cardinality base_planes / 2) */
+#define HAB_BACKBONE_SE_RESNET50 52    /* se_resnet50: Bottleneck + squeeze-and-excitation gate */
+#define HAB_BACKBONE_SE_RESNEXT50 53   /* se_resneXt50 */
+#define HAB_BACKBONE_SE_RESNEXT101 101 /* se_resneXt101: stages 3, 4, 23, 3 */
 #define HAB_DIST_CATEGORICAL 0
 #define HAB_DIST_GAUSSIAN 1
 #define HAB_GAUSS_TANH_MU 1        /* action_activation == "tanh" */

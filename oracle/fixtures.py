@@ -84,18 +84,20 @@ def resnet_param_shapes(n_in, H, W, hidden, num_actions=4, rnn_type="LSTM", laye
     if normalize and with_buffers:
         shapes += [(ve + "running_mean_and_var._mean", (1, n_in, 1, 1)), (ve + "running_mean_and_var._var", (1, n_in, 1, 1)),
                    (ve + "running_mean_and_var._count", ())]
-    bottleneck = backbone == "resnet50"
-    exp = 4 if bottleneck else 1
-    nblocks = [3, 4, 6, 3] if bottleneck else [2, 2, 2, 2]
+    from .functional import RESNET_LAYERS
+    kind, nblocks, resnext, se = RESNET_LAYERS[backbone]
+    bottleneck = kind == "bottleneck"
+    exp = (2 if resnext else 4) if bottleneck else 1
+    card = baseplanes // 2 if resnext else 1
 
-    def cg(w, g, cin, cout, k):
-        return [(w + ".weight", (cout, cin, k, k)), (g + ".weight", (cout,)), (g + ".bias", (cout,))]
+    def cg(w, g, cin, cout, k, groups=1):
+        return [(w + ".weight", (cout, cin // groups, k, k)), (g + ".weight", (cout,)), (g + ".bias", (cout,))]
 
     bb = ve + "backbone."
     shapes += cg(bb + "conv1.0", bb + "conv1.1", n_in, baseplanes, 7)
     inplanes = baseplanes
     for li, nb in enumerate(nblocks):
-        planes = baseplanes * 2 ** li
+        planes = (2 * baseplanes if resnext else baseplanes) * 2 ** li
         for bi in range(nb):
             stride = 2 if (bi == 0 and li > 0) else 1
             bp = f"{bb}layer{li + 1}.{bi}."
@@ -103,10 +105,15 @@ def resnet_param_shapes(n_in, H, W, hidden, num_actions=4, rnn_type="LSTM", laye
             if not bottleneck:
                 shapes += cg(bp + "convs.0", bp + "convs.1", inplanes, planes, 3) + cg(bp + "convs.3", bp + "convs.4", planes, planes, 3)
             else:
-                shapes += (cg(bp + "convs.0", bp + "convs.1", inplanes, planes, 1) + cg(bp + "convs.3", bp + "convs.4", planes, planes, 3)
+                shapes += (cg(bp + "convs.0", bp + "convs.1", inplanes, planes, 1)
+                           + cg(bp + "convs.3", bp + "convs.4", planes, planes, 3, card if bi == 0 else 1)
                            + cg(bp + "convs.6", bp + "convs.7", planes, planes * exp, 1))
             if has_ds:
                 shapes += cg(bp + "downsample.0", bp + "downsample.1", inplanes, planes * exp, 1)
+            if se and bottleneck:
+                c_se = planes * exp
+                shapes += [(bp + "se.excite.0.weight", (c_se // 16, c_se)), (bp + "se.excite.0.bias", (c_se // 16,)),
+                           (bp + "se.excite.2.weight", (c_se, c_se // 16)), (bp + "se.excite.2.bias", (c_se,))]
             inplanes = planes * exp
     fh, fw = math.ceil((H // 2) / 32), math.ceil((W // 2) / 32)
     ncomp = int(round(2048 / (fh * fw)))

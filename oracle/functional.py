@@ -94,7 +94,10 @@ def running_mean_and_var(x, mean, var, count, training: bool, world_size: int = 
     return torch.addcmul(-mean * inv_stdev, x, inv_stdev), mean, var, count
 
 
-RESNET_LAYERS = {"resnet18": ("basic", [2, 2, 2, 2]), "resnet50": ("bottleneck", [3, 4, 6, 3])}
+# rl/ddppo/policy/resnet.py:296-345: (block kind, stage depths, ResNeXt?, SE?)
+RESNET_LAYERS = {"resnet18": ("basic", [2, 2, 2, 2], False, False), "resnet50": ("bottleneck", [3, 4, 6, 3], False, False),
+                 "resneXt50": ("bottleneck", [3, 4, 6, 3], True, False), "se_resnet50": ("bottleneck", [3, 4, 6, 3], False, True),
+                 "se_resneXt50": ("bottleneck", [3, 4, 6, 3], True, True), "se_resneXt101": ("bottleneck", [3, 4, 23, 3], True, True)}
 
 
 def _gn(x, params, key, groups):
@@ -104,7 +107,8 @@ def _gn(x, params, key, groups):
 def resnet_backbone(params: Params, pre: str, x, backbone: str, baseplanes: int, ngroups: int, taps=None):
     """rl/ddppo/policy/resnet.py:196-281.  bias-free convs, GroupNorm(ngroups), 7x7/2 stem,
     3x3/2 maxpool, 4 stages; BasicBlock :37-69, Bottleneck :116-152."""
-    kind, layers = RESNET_LAYERS[backbone]
+    kind, layers, resnext, se = RESNET_LAYERS[backbone]
+    cardinality = baseplanes // 2 if resnext else 1  # groups of the 3x3 conv, first block of each stage only (resnet.py:257-268)
     x = F.conv2d(x, params[pre + "conv1.0.weight"], None, stride=2, padding=3)
     x = F.relu(_gn(x, params, pre + "conv1.1", ngroups))
     relu_log = taps.setdefault("relu", []) if taps is not None else None  # every post-ReLU activation, in forward order
@@ -121,9 +125,9 @@ def resnet_backbone(params: Params, pre: str, x, backbone: str, baseplanes: int,
     if taps is not None:
         taps["pool"] = x
     inplanes = baseplanes
-    expansion = 1 if kind == "basic" else 4
+    expansion = 1 if kind == "basic" else (2 if resnext else 4)
     for li, nblocks in enumerate(layers):
-        planes = baseplanes * (2 ** li)
+        planes = (2 * baseplanes if resnext else baseplanes) * (2 ** li)
         for bi in range(nblocks):
             stride = 2 if (bi == 0 and li > 0) else 1
             bp = f"{pre}layer{li + 1}.{bi}."
@@ -137,10 +141,15 @@ def resnet_backbone(params: Params, pre: str, x, backbone: str, baseplanes: int,
             else:
                 out = F.conv2d(x, params[bp + "convs.0.weight"], None)
                 out = rl(bp + "convs.1", F.relu(_gn(out, params, bp + "convs.1", ngroups)))
-                out = F.conv2d(out, params[bp + "convs.3.weight"], None, stride=stride, padding=1)
+                out = F.conv2d(out, params[bp + "convs.3.weight"], None, stride=stride, padding=1, groups=cardinality if bi == 0 else 1)
                 out = rl(bp + "convs.4", F.relu(_gn(out, params, bp + "convs.4", ngroups)))
                 out = F.conv2d(out, params[bp + "convs.6.weight"], None)
                 out = _gn(out, params, bp + "convs.7", ngroups)
+                if se:  # SEBottleneck._impl resnet.py:178-187: squeeze (global mean), excite (Linear-ReLU-Linear-Sigmoid), scale
+                    g = out.mean(dim=(2, 3))
+                    g = F.relu(F.linear(g, params[bp + "se.excite.0.weight"], params[bp + "se.excite.0.bias"]))
+                    g = torch.sigmoid(F.linear(g, params[bp + "se.excite.2.weight"], params[bp + "se.excite.2.bias"]))
+                    out = g.view(g.size(0), -1, 1, 1) * out
             if has_ds:
                 residual = F.conv2d(x, params[bp + "downsample.0.weight"], None, stride=stride)
                 residual = _gn(residual, params, bp + "downsample.1", ngroups)

@@ -360,6 +360,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ver":
         ver_case()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "se":
+        se_resnext_case(load_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "gaussian":
         gaussian_case(load_reference())
         return
@@ -407,6 +410,19 @@ def main():
              num_actions=6)
     ver_case()
     gaussian_case(ns)
+    se_resnext_case(ns)
+
+
+def se_resnext_case(ns):
+    """se_resneXt50 backbone (resnet.py:92-113,155-193,317-328): grouped 3x3 convolutions (cardinality 16, first
+    block of every stage), expansion 2, squeeze-and-excitation gates; 1-layer GRU, 128x128 RGB-D."""
+    space = obs_space(ns, 128, 128)
+    torch.manual_seed(0)
+    pol = ns.resnet_policy.PointNavResNetPolicy(space, ns.spaces.Discrete(4), hidden_size=64, num_recurrent_layers=1, rnn_type="GRU",
+                                                backbone="se_resneXt50", normalize_visual_inputs=True)
+    cfg = make_config(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2, num_steps=3, use_normalized_advantage=False,
+                      hidden_size=64, lr=2.5e-4, eps=1e-5)
+    run_case(ns, "se_resnext50_rgbd128", pol, space, cfg, T=3, N=2, seed=61, H=128, W=128, sampled=True)
 
 
 GAUSS_CASE = dict(use_log_std=True, use_softplus=False, log_std_init=0.0, use_std_param=False, clamp_std=True, min_std=1e-6, max_std=1,

@@ -432,6 +432,11 @@ RESNET_VARIANTS = [  # backbone, rnn, layers, H, W, visual key order, normalize
     ("resnet18", "LSTM", 2, 64, 96, ("rgb", "depth"), False),
     ("resnet50", "LSTM", 1, 128, 128, ("rgb", "depth"), True),
     ("resnet18", "GRU", 1, 128, 128, ("depth",), False),
+    # SURVEY.md 8f N3 (resnet.py:296-345): grouped 3x3 convolutions (ResNeXt), squeeze-and-excitation gates, both, 23-block stage 3
+    ("resneXt50", "GRU", 1, 128, 128, ("rgb", "depth"), True),
+    ("se_resnet50", "GRU", 1, 128, 128, ("rgb", "depth"), False),
+    ("se_resneXt50", "LSTM", 1, 128, 128, ("rgb", "depth"), True),
+    ("se_resneXt101", "GRU", 1, 64, 64, ("rgb", "depth"), False),
 ]
 
 

@@ -122,7 +122,25 @@ def test_resnet_policy_names_shapes_and_init_identical_to_live_reference():
     sp = ns.spaces
     robs = sp.Dict({"rgb": sp.Box(0, 255, (128, 128, 3), np.uint8), "depth": sp.Box(0, 1, (128, 128, 1), np.float32),
                     "pointgoal_with_gps_compass": sp.Box(-1e9, 1e9, (2,), np.float32)})
-    for backbone, rnn, layers in (("resnet18", "LSTM", 2), ("resnet50", "GRU", 1)):
+    from types import SimpleNamespace
+    gauss = SimpleNamespace(action_distribution_type="gaussian",
+                            action_dist=SimpleNamespace(use_log_std=True, use_softplus=False, log_std_init=0.0, use_std_param=True, clamp_std=True,
+                                                        min_std=1e-6, max_std=1, min_log_std=-5, max_log_std=2, action_activation="tanh"))
+    from habitat_amd.common import spaces as S
+    for backbone, rnn, layers, pcfg in (("resnet18", "LSTM", 2, None), ("resnet50", "GRU", 1, None), ("resneXt50", "GRU", 1, None),
+                                        ("se_resnet50", "GRU", 1, None), ("se_resneXt50", "LSTM", 2, None), ("se_resneXt101", "GRU", 1, None),
+                                        ("resnet18", "GRU", 1, gauss)):
+        if pcfg is not None:  # continuous actions: Gaussian head with a std parameter, Linear previous-action embedding
+            torch.manual_seed(77)
+            a = PointNavResNetPolicy(osp, S.Box(-1.0, 1.0, (2,), np.float32), hidden_size=64, num_recurrent_layers=layers, rnn_type=rnn,
+                                     backbone=backbone, normalize_visual_inputs=True, policy_config=pcfg).state_dict()
+            torch.manual_seed(77)
+            b = ns.resnet_policy.PointNavResNetPolicy(robs, sp.Box(-1.0, 1.0, (2,), np.float32), hidden_size=64, num_recurrent_layers=layers,
+                                                      rnn_type=rnn, backbone=backbone, normalize_visual_inputs=True,
+                                                      policy_config=pcfg).state_dict()
+            assert list(a.keys()) == list(b.keys())
+            assert all(a[k].shape == b[k].shape and torch.equal(a[k], b[k]) for k in b), "gaussian"
+            continue
         torch.manual_seed(77)
         a = PointNavResNetPolicy(osp, asp, hidden_size=64, num_recurrent_layers=layers, rnn_type=rnn, backbone=backbone,
                                  normalize_visual_inputs=True).state_dict()
