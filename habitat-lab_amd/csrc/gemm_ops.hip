@@ -3,6 +3,7 @@
 #include "igemm.h"
 #include "igemm_dma.h"
 #include "igemm_dma_wgrad.h"
+#include "igemm_bf3.h"
 #include "wgrad3x3_patch.h"
 #include "prob_build.h"
 #include <stdlib.h>
@@ -17,6 +18,8 @@ namespace hab {
 static bool no_dma() { static const bool v = hab_env_flag("HAB_NO_DMA"); return v; }
 static bool no_merged_dgrad() { static const bool v = hab_env_flag("HAB_NO_MERGED_DGRAD"); return v; }
 static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); return v; }
+// split-bf16 matrix-pipe path (igemm_bf3.h) for the r-contiguous x r-contiguous contractions
+static int bf3_mode() { static const int v = hab_env_int("HAB_BF3", 0); return v; }
 
 template <class P>
 static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream, int target_blocks = 1024) {
@@ -28,6 +31,13 @@ static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream
     static const int wg_target = hab_env_int("HAB_TARGET_BLOCKS_WG", 0);
     if (wg_target > 0 && !P::A_RC && !P::B_RC) target_blocks = wg_target;
     constexpr bool WG = !P::A_RC && !P::B_RC && AKv<P>::value == 4;  // weight-gradient form
+    if constexpr (P::A_RC && P::B_RC) {
+        if (bf3_mode() && p.M > 64) {
+            if (p.N <= 32) return igemm_bf3_launch<P, 2, 1, 4, 1>(p, ws, ws_floats, target_blocks, stream);
+            if (p.N <= 64) return igemm_bf3_launch<P, 1, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
+            return igemm_bf3_launch<P, 2, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
+        }
+    }
     if constexpr (std::is_same_v<P, ConvFwdProb> || std::is_same_v<P, ConvDgradProb>) {
         if (p.dma_ok() && p.M > 64 && !no_dma()) {  // LDS-DMA staged variant (igemm_dma.h)
             if (p.N <= 32) return igemm_dma_launch<P, 2, 1, 4, 1, false>(p, ws, ws_floats, target_blocks, stream);

@@ -1,0 +1,256 @@
+// igemm_bf3.h -- the r-contiguous x r-contiguous contractions (convolution forward / data gradient, Linear forward) on the bf16
+// matrix pipe with fp32-equivalent arithmetic.
+//
+// gfx950 issues v_mfma_f32_32x32x2_f32 at the fp32 VECTOR rate (157 TFLOP/s chip peak) and -- measured in round 1
+// (tools/ubench/mfma_valu_overlap.hip) -- that instruction shares the SIMD's issue with every other instruction, so a kernel's time is
+// MFMA time + everything else.  v_mfma_f32_32x32x16_bf16 runs on the matrix pipe proper: 16x the rate, and VALU / LDS / address work
+// of other waves issues beside it.  An fp32 operand is split EXACTLY into three bf16 terms by truncation
+//      a1 = trunc16(a),  a2 = trunc16(a - a1),  a3 = a - a1 - a2      (8 significant bits each, 24 in total: a = a1 + a2 + a3)
+// and the product a*b is accumulated from the six partial products whose weight is >= 2^-16 relative
+//      a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2)
+// (each exact in the fp32 accumulator; the three dropped terms are <= 2^-24 relative, the size of one fp32 rounding).  Six bf16 MFMAs
+// of K = 16 replace eight fp32 MFMAs of K = 2: 6/16 of the matrix-pipe time, which no longer blocks the rest of the instruction
+// stream.  The split costs ~6 VALU instructions per staged element, paid once per element when the tile is written to LDS.
+//
+// LDS image: three planes per operand, [rows][BK + 8] bf16 (80-byte row pitch: the 16-byte fragment reads of 16 lanes fall on 16
+// distinct 4-bank windows).  Lane l of a wave supplies A[i = l & 31][k = 8 (l >> 5) .. +7] of a K = 16 step: one ds_read_b128 per
+// plane and operand tile.  The accumulator layout equals v_mfma_f32_32x32x2_f32's, so the problems' epilogues are shared with
+// igemm.h unchanged (incl. the transposed-accumulator vector epilogue).
+#pragma once
+#include "igemm.h"
+
+namespace hab {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BF3_BKP = IGEMM_BK + 8;  // bf16 elements per LDS row
+
+// x = t1 + t2 + t3 exactly, each term representable in bf16 (top 16 bits of an fp32 pattern); returns the three bit patterns
+__device__ __forceinline__ void bf3_split(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
+    const unsigned b1 = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(b1);  // exact: the low 16 mantissa bits of x
+    const unsigned b2 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(b2);  // exact: at most 8 significant bits remain
+    h1 = b1; h2 = b2; h3 = __float_as_uint(r2);
+}
+// packs the bf16 halves (upper 16 bits) of two fp32 patterns: low half = first element
+__device__ __forceinline__ unsigned bf3_pack(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// four consecutive-k fp32 values -> 8 bytes (4 bf16) in each of the three planes
+__device__ __forceinline__ void bf3_store4(const f32x4 v, unsigned short* p1, unsigned short* p2, unsigned short* p3) {
+    unsigned a1[4], a2[4], a3[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bf3_split(v[q], a1[q], a2[q], a3[q]);
+    u32x2 w1, w2, w3;
+    w1[0] = bf3_pack(a1[0], a1[1]); w1[1] = bf3_pack(a1[2], a1[3]);
+    w2[0] = bf3_pack(a2[0], a2[1]); w2[1] = bf3_pack(a2[2], a2[3]);
+    w3[0] = bf3_pack(a3[0], a3[1]); w3[1] = bf3_pack(a3[2], a3[3]);
+    *reinterpret_cast<u32x2*>(p1) = w1;
+    *reinterpret_cast<u32x2*>(p2) = w2;
+    *reinterpret_cast<u32x2*>(p3) = w3;
+}
+
+template <class P, int TM, int TN, int WM, int WN>
+struct IgemmBf3Cfg {
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = IGEMM_BK;
+    static constexpr int KV = AKv<P>::value;
+    static constexpr int A_PLANE = BM * BF3_BKP, B_PLANE = BN * BF3_BKP;  // bf16 elements
+    static constexpr int A_TOTAL = BM * BK / KV, B_TOTAL = BN * BK / 4;
+    static constexpr int A_UNITS = (A_TOTAL + NT - 1) / NT, B_UNITS = (B_TOTAL + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES = (size_t)3 * (A_PLANE + B_PLANE) * 2;
+    static_assert(P::A_RC && P::B_RC, "bf3 path: both operands r-contiguous");
+    static_assert(NT % (BK / KV) == 0 && NT % (BK / 4) == 0, "unit mapping");
+};
+
+template <class P, int TM, int TN, int WM, int WN>
+__global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const int k_per_split, float* __restrict__ partial) {
+    using Cfg = IgemmBf3Cfg<P, TM, TN, WM, WN>;
+    constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, KV = Cfg::KV;
+    constexpr int A_UNITS = Cfg::A_UNITS, B_UNITS = Cfg::B_UNITS, A_TOTAL = Cfg::A_TOTAL, B_TOTAL = Cfg::B_TOTAL;
+    constexpr int AKQ = BK / KV;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+    unsigned short* As = smem16;                        // planes 0..2: [BM][BF3_BKP]
+    unsigned short* Bs = smem16 + 3 * Cfg::A_PLANE;     // planes 0..2: [BN][BF3_BKP]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, hi = lane >> 5;
+
+    const int nt_m = cdiv(p.M, BM), nt_n = cdiv(p.N, BN);
+    const int ntiles = nt_m * nt_n;
+    int tile;
+    {
+        const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, idx = b >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = tile % nt_n, tile_m = tile / nt_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int kz = blockIdx.z;
+    const int k_begin = kz * k_per_split;
+    const int k_end = min(p.K, k_begin + k_per_split);
+    const int ntk = max(0, cdiv(k_end - k_begin, BK));
+
+    typename P::ACtx actx[A_UNITS];
+    typename P::BCtx bctx[B_UNITS];
+#pragma unroll
+    for (int j = 0; j < A_UNITS; ++j) actx[j] = p.a_ctx(m0 + (t + NT * j) / AKQ);
+#pragma unroll
+    for (int j = 0; j < B_UNITS; ++j) bctx[j] = p.b_ctx(n0 + ((t + NT * j) >> 3));
+
+    typename P::ARaw araw[A_UNITS];
+    typename P::BRaw braw[B_UNITS];
+    auto a_k = [&](int kt, int j) { return k_begin + kt * BK + ((t + NT * j) % AKQ) * KV; };
+    auto b_k = [&](int kt, int j) { return k_begin + kt * BK + ((t + NT * j) & 7) * 4; };
+    auto fetch = [&](int kt) {
+        const typename P::KCtx kc = p.k_ctx(k_begin + kt * BK, k_end);
+        const typename P::AKey ak = p.a_key(kc, a_k(kt, 0), k_end);
+#pragma unroll
+        for (int j = 0; j < A_UNITS; ++j)
+            if (A_TOTAL % NT == 0 || t + NT * j < A_TOTAL) araw[j] = p.a_fetch(actx[j], kc, ak);
+        const typename P::BKey bk = p.b_key(kc, b_k(kt, 0), k_end);
+#pragma unroll
+        for (int j = 0; j < B_UNITS; ++j)
+            if (B_TOTAL % NT == 0 || t + NT * j < B_TOTAL) braw[j] = p.b_fetch(bctx[j], kc, bk);
+    };
+    auto stage = [&](int kt) {  // registers -> split -> three bf16 planes
+#pragma unroll
+        for (int j = 0; j < A_UNITS; ++j) {
+            const int u = t + NT * j;
+            if (A_TOTAL % NT == 0 || u < A_TOTAL) {
+                f32x4 v[KV / 4];
+                p.a_cvt(actx[j], araw[j], a_k(kt, j), k_end, v);
+                unsigned short* dst = As + (u / AKQ) * BF3_BKP + (u % AKQ) * KV;
+#pragma unroll
+                for (int q = 0; q < KV / 4; ++q) bf3_store4(v[q], dst + 4 * q, dst + Cfg::A_PLANE + 4 * q, dst + 2 * Cfg::A_PLANE + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_UNITS; ++j) {
+            const int u = t + NT * j;
+            if (B_TOTAL % NT == 0 || u < B_TOTAL) {
+                const f32x4 v = p.b_cvt(braw[j]);
+                unsigned short* dst = Bs + (u >> 3) * BF3_BKP + (u & 7) * 4;
+                bf3_store4(v, dst, dst + Cfg::B_PLANE, dst + 2 * Cfg::B_PLANE);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.0f;
+
+    if (ntk > 0) fetch(0);
+    for (int kt = 0; kt < ntk; ++kt) {
+        stage(kt);
+        __syncthreads();
+        if (kt + 1 < ntk) fetch(kt + 1);
+#pragma unroll
+        for (int c = 0; c < BK / 16; ++c) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned short* src = As + ((wm * TM + i) * 32 + li) * BF3_BKP + c * 16 + hi * 8;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(src + pl * Cfg::A_PLANE);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned short* src = Bs + ((wn * TN + j) * 32 + li) * BF3_BKP + c * 16 + hi * 8;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(src + pl * Cfg::B_PLANE);
+            }
+            // six partial products, smallest weight first
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if constexpr (EpiV4<P>::value)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[q]], af[i][PA[q]], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[q]], bf[j][PB[q]], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: identical to igemm_kernel's (same accumulator layout) ----
+    const bool split = gridDim.z > 1;
+    const int MP = p.M;
+    if constexpr (EpiV4<P>::value) {
+        if (split)
+            igemm_partial_v4<P, TM, TN>(p, acc, partial + (size_t)kz * MP * p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, hi);
+        else
+            igemm_epilogue_v4<P, TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, li, hi);
+        return;
+    }
+    if (split) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = m0 + (wm * TM + i) * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
+                    if (row < p.M && col < p.N) partial[((size_t)kz * MP + row) * p.N + col] = acc[i][j][v];
+                }
+            }
+        return;
+    }
+    typename P::EpiCol ecol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) ecol[j] = p.epi_col(n0 + (wn * TN + j) * 32 + li);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            typename P::EpiRow erow[4];
+            typename P::EpiAux eaux[4][TN];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                erow[q] = p.epi_row(m0 + (wm * TM + i) * 32 + q + 8 * g + 4 * hi);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) eaux[q][j] = p.epi_fetch(erow[q], ecol[j]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) p.epi_store(erow[q], ecol[j], eaux[q][j], acc[i][j][g * 4 + q]);
+        }
+}
+
+template <class P, int TM, int TN, int WM, int WN>
+inline int igemm_bf3_launch(const P& p, float* ws, size_t ws_floats, int target_blocks, hipStream_t stream) {
+    using Cfg = IgemmBf3Cfg<P, TM, TN, WM, WN>;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return HAB_ERR_ARG;
+    const IgemmPlan pl = igemm_plan(Cfg::BM, Cfg::BN, p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
+    auto kern = igemm_bf3_kernel<P, TM, TN, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.M, Cfg::BM) * cdiv(p.N, Cfg::BN), 1, pl.splits);
+    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, pl.k_per_split, ws);
+    HAB_LAUNCH_CHECK();
+    if (pl.splits > 1) {
+        igemm_splitk_reduce<P>(p, ws, pl.splits, stream);
+        HAB_LAUNCH_CHECK();
+    }
+    return HAB_OK;
+}
+
+}  // namespace hab

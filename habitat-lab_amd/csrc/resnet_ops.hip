@@ -1114,11 +1114,15 @@ int embed_backward(const EmbedBwdArgs& a, float* ws, size_t ws_floats, hipStream
 __global__ void __launch_bounds__(256) se_pool_kernel(const float* __restrict__ x, float* __restrict__ pooled, int HW, int C) {
     const int b = blockIdx.x, C4 = C >> 2;
     const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * HW * C);
-    const float inv = 1.0f / (float)HW;
     for (int c = threadIdx.x; c < C4; c += 256) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int p = 0; p < HW; ++p) s += xb[(size_t)p * C4 + c];
-        *reinterpret_cast<f32x4*>(pooled + (size_t)b * C + c * 4) = s * inv;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // fp64 accumulation: the mean of a zero-centred GroupNorm output cancels heavily
+        for (int p = 0; p < HW; ++p) {
+            const f32x4 v = xb[(size_t)p * C4 + c];
+            s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
+        }
+        f32x4 o;
+        o[0] = (float)(s0 / HW); o[1] = (float)(s1 / HW); o[2] = (float)(s2 / HW); o[3] = (float)(s3 / HW);
+        *reinterpret_cast<f32x4*>(pooled + (size_t)b * C + c * 4) = o;
     }
 }
 int se_pool(const float* x, float* pooled, int B, int HW, int C, hipStream_t s) {
@@ -1156,17 +1160,18 @@ __global__ void __launch_bounds__(256) se_bwd_reduce_kernel(const float* __restr
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + fb;
     f32x4* dm4 = reinterpret_cast<f32x4*>(dm) + fb;
     for (int c = threadIdx.x; c < C4; c += 256) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
         for (int p = 0; p < HW; ++p) {
             const size_t i = (size_t)p * C4 + c;
             f32x4 d = dy4[i];
-            const f32x4 yv = y4[i];
+            const f32x4 yv = y4[i], xv = x4[i];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] = yv[k] > 0.f ? d[k] : 0.f;
+            for (int k = 0; k < 4; ++k) { d[k] = yv[k] > 0.f ? d[k] : 0.f; s[k] += (double)d[k] * (double)xv[k]; }
             dm4[i] = d;
-            s += d * x4[i];
         }
-        *reinterpret_cast<f32x4*>(dgate + (size_t)b * C + c * 4) = s;
+        f32x4 o;
+        o[0] = (float)s[0]; o[1] = (float)s[1]; o[2] = (float)s[2]; o[3] = (float)s[3];
+        *reinterpret_cast<f32x4*>(dgate + (size_t)b * C + c * 4) = o;
     }
 }
 int se_backward_reduce(const float* dy, const float* y, const float* x, float* dm, float* dgate, int B, int HW, int C, hipStream_t s) {
