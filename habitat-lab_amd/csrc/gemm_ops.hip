@@ -4,6 +4,7 @@
 #include "igemm_dma.h"
 #include "igemm_dma_wgrad.h"
 #include "igemm_bf3.h"
+#include "obs_conv_bf3.h"
 #include "wgrad3x3_patch.h"
 #include "prob_build.h"
 #include <stdlib.h>
@@ -19,7 +20,17 @@ static bool no_dma() { static const bool v = hab_env_flag("HAB_NO_DMA"); return 
 static bool no_merged_dgrad() { static const bool v = hab_env_flag("HAB_NO_MERGED_DGRAD"); return v; }
 static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); return v; }
 // split-bf16 matrix-pipe path (igemm_bf3.h) for the r-contiguous x r-contiguous contractions
-static int bf3_mode() { static const int v = hab_env_int("HAB_BF3", 0); return v; }
+// bit 0: generic r-contiguous x r-contiguous problems, bit 1: observation-ingest convolution (obs_conv_bf3.h)
+static int g_bf3_mode = -1;
+static int bf3_mode() {
+    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 0);
+    return g_bf3_mode;
+}
+extern "C" int hab_set_matrix_path(int mode) {
+    const int prev = bf3_mode();
+    if (mode >= 0) g_bf3_mode = mode;
+    return prev;
+}
 
 template <class P>
 static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream, int target_blocks = 1024) {
@@ -32,7 +43,7 @@ static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream
     if (wg_target > 0 && !P::A_RC && !P::B_RC) target_blocks = wg_target;
     constexpr bool WG = !P::A_RC && !P::B_RC && AKv<P>::value == 4;  // weight-gradient form
     if constexpr (P::A_RC && P::B_RC) {
-        if (bf3_mode() && p.M > 64) {
+        if ((bf3_mode() & 1) && p.M > 64) {
             if (p.N <= 32) return igemm_bf3_launch<P, 2, 1, 4, 1>(p, ws, ws_floats, target_blocks, stream);
             if (p.N <= 64) return igemm_bf3_launch<P, 1, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
             return igemm_bf3_launch<P, 2, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
@@ -75,6 +86,11 @@ int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const f
                  size_t ws_floats, hipStream_t stream) {
     ObsConvFwdProb p;
     HAB_TRY(build(p, d, obs, wf, bias, y, relu));
+    if ((bf3_mode() & 2) && p.quad && p.M > 64) {  // uint8 x split-bf16 weights on the matrix pipe (obs_conv_bf3.h)
+        static const int tm = hab_env_int("HAB_OBF_TM", 2);
+        const int rc = tm == 4 ? obs_conv_bf3_launch<4>(p, ws, ws_floats, stream) : obs_conv_bf3_launch<2>(p, ws, ws_floats, stream);
+        if (rc != 1) return rc;
+    }
     return run_igemm(p, ws, ws_floats, stream);
 }
 // dX pixels whose class has no taps (possible only when stride > kernel size) receive no contribution:

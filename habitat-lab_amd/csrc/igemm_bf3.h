@@ -4,13 +4,16 @@
 // gfx950 issues v_mfma_f32_32x32x2_f32 at the fp32 VECTOR rate (157 TFLOP/s chip peak) and -- measured in round 1
 // (tools/ubench/mfma_valu_overlap.hip) -- that instruction shares the SIMD's issue with every other instruction, so a kernel's time is
 // MFMA time + everything else.  v_mfma_f32_32x32x16_bf16 runs on the matrix pipe proper: 16x the rate, and VALU / LDS / address work
-// of other waves issues beside it.  An fp32 operand is split EXACTLY into three bf16 terms by truncation
-//      a1 = trunc16(a),  a2 = trunc16(a - a1),  a3 = a - a1 - a2      (8 significant bits each, 24 in total: a = a1 + a2 + a3)
-// and the product a*b is accumulated from the six partial products whose weight is >= 2^-16 relative
+// of other waves issues beside it.  An fp32 operand is split EXACTLY into three bf16 terms by rounding to nearest
+//      a1 = rn16(a),  a2 = rn16(a - a1),  a3 = a - a1 - a2      (|a2| <= 2^-9 |a|, |a3| <= 2^-17 |a|, a = a1 + a2 + a3 exactly)
+// and the product a*b is accumulated from the six partial products of weight >= 2^-18 relative
 //      a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2)
-// (each exact in the fp32 accumulator; the three dropped terms are <= 2^-24 relative, the size of one fp32 rounding).  Six bf16 MFMAs
-// of K = 16 replace eight fp32 MFMAs of K = 2: 6/16 of the matrix-pipe time, which no longer blocks the rest of the instruction
-// stream.  The split costs ~6 VALU instructions per staged element, paid once per element when the tile is written to LDS.
+// (each product exact in the fp32 accumulator; the three dropped terms a2 b3 + a3 b2 + a3 b3 are <= 2^-25 |a b| and of either sign --
+// below the rounding of the fp32 product itself.  Truncation instead of rounding would leave all dropped terms with the sign of a*b: a
+// bias that grows with K instead of averaging out; measured 12x the fp32 path's error on ResNet18 gradients at 4096 frames).  Six bf16
+// MFMAs of K = 16 replace eight fp32 MFMAs of K = 2: 6/16 of the matrix-pipe time, which no longer blocks the rest of the instruction
+// stream.  The split costs 4.5 VALU instructions per staged element (v_cvt_pk_bf16_f32 packs as it rounds), paid once per element when
+// the tile is written to LDS.
 //
 // LDS image: three planes per operand, [rows][BK + 8] bf16 (80-byte row pitch: the 16-byte fragment reads of 16 lanes fall on 16
 // distinct 4-bank windows).  Lane l of a wave supplies A[i = l & 31][k = 8 (l >> 5) .. +7] of a K = 16 step: one ds_read_b128 per
@@ -27,26 +30,38 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BF3_BKP = IGEMM_BK + 8;  // bf16 elements per LDS row
 
-// x = t1 + t2 + t3 exactly, each term representable in bf16 (top 16 bits of an fp32 pattern); returns the three bit patterns
-__device__ __forceinline__ void bf3_split(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
-    const unsigned b1 = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(b1);  // exact: the low 16 mantissa bits of x
-    const unsigned b2 = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(b2);  // exact: at most 8 significant bits remain
-    h1 = b1; h2 = b2; h3 = __float_as_uint(r2);
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1) = t1 + t2 + t3 exactly, element-wise, each term a bf16: t1 = rn(x), t2 = rn(x - t1), t3 = x - t1 - t2 (rn = v_cvt_pk_bf16_f32,
+// round to nearest even; both residuals are exact in fp32 and the last one has at most 8 significant bits).  Returns the three PACKED
+// pairs (low half = element 0).  4.5 VALU instructions per element, packing included.
+__device__ __forceinline__ void bf3_split2(float x0, float x1, unsigned& w1, unsigned& w2, unsigned& w3) {
+    f32x2 v; v[0] = x0; v[1] = x1;
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    f32x2 r;
+    r[0] = v[0] - __uint_as_float(w1 << 16); r[1] = v[1] - __uint_as_float(w1 & 0xffff0000u);
+    w2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    f32x2 q;
+    q[0] = r[0] - __uint_as_float(w2 << 16); q[1] = r[1] - __uint_as_float(w2 & 0xffff0000u);
+    w3 = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
 }
-// packs the bf16 halves (upper 16 bits) of two fp32 patterns: low half = first element
+// scalar form: the three bf16 bit patterns in the low 16 bits
+__device__ __forceinline__ void bf3_split(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
+    unsigned w1, w2, w3;
+    bf3_split2(x, 0.f, w1, w2, w3);
+    h1 = w1 & 0xffffu; h2 = w2 & 0xffffu; h3 = w3 & 0xffffu;
+}
+// packs the bf16 halves (upper 16 bits) of two fp32 patterns whose low halves are zero or ignorable: low half = first element
 __device__ __forceinline__ unsigned bf3_pack(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
 // four consecutive-k fp32 values -> 8 bytes (4 bf16) in each of the three planes
 __device__ __forceinline__ void bf3_store4(const f32x4 v, unsigned short* p1, unsigned short* p2, unsigned short* p3) {
-    unsigned a1[4], a2[4], a3[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bf3_split(v[q], a1[q], a2[q], a3[q]);
+    unsigned a1, a2, a3, b1, b2, b3;
+    bf3_split2(v[0], v[1], a1, a2, a3);
+    bf3_split2(v[2], v[3], b1, b2, b3);
     u32x2 w1, w2, w3;
-    w1[0] = bf3_pack(a1[0], a1[1]); w1[1] = bf3_pack(a1[2], a1[3]);
-    w2[0] = bf3_pack(a2[0], a2[1]); w2[1] = bf3_pack(a2[2], a2[3]);
-    w3[0] = bf3_pack(a3[0], a3[1]); w3[1] = bf3_pack(a3[2], a3[3]);
+    w1[0] = a1; w1[1] = b1; w2[0] = a2; w2[1] = b2; w3[0] = a3; w3[1] = b3;
     *reinterpret_cast<u32x2*>(p1) = w1;
     *reinterpret_cast<u32x2*>(p2) = w2;
     *reinterpret_cast<u32x2*>(p3) = w3;

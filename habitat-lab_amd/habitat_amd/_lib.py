@@ -66,6 +66,7 @@ SIGNATURES = {
     "hab_clip_adam_step": (c_int, [vp, vp, vp, vp, c_size_t, vp, c_int, c_float, c_float, c_float, c_float, c_float,
                                    c_float, c_int, vp, vp]),
     "hab_sample_actions": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
+    "hab_set_matrix_path": (c_int, [c_int]),
     "hab_conv2d_fwd": (c_int, [vp, vp, vp, vp] + [c_int] * 10 + [vp, c_size_t, vp]),
     "hab_obs_conv2d_fwd": (c_int, [vp, vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
     "hab_conv2d_dgrad": (c_int, [vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),

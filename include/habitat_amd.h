@@ -158,7 +158,15 @@ int hab_sample_actions(const float* probs, const float* exp_noise, int64_t* acti
  *                            rl/ddppo/policy/resnet.py:19-34,207-219)
  *   obs conv              <- the permute/.float()/255/cat ingest fused into conv1 (simple_cnn.py:139-156)
  *   linear fwd/dgrad/wgrad<- nn.Linear (simple_cnn.py:92, policy.py:416-424, rnn input projections)
+ *
+ * Matrix path.  The contractions are fp32 in, fp32 out, fp32-equivalent arithmetic on either of two instruction paths:
+ *   v_mfma_f32_32x32x2_f32 (igemm.h), or -- hab_set_matrix_path bits, env HAB_BF3 -- the exact three-term bf16 split of both
+ *   operands with the six partial products >= 2^-16 on v_mfma_f32_32x32x16_bf16 (igemm_bf3.h; dropped terms <= 2^-24 relative):
+ *     bit 0  r-contiguous x r-contiguous problems (conv fwd / dgrad, Linear fwd)
+ *     bit 1  observation-ingest convolution (uint8 rgb is exact in ONE bf16 plane; obs_conv_bf3.h)
+ *   hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one; mode < 0 only queries.
  * ------------------------------------------------------------------------------------------- */
+int hab_set_matrix_path(int mode);
 int hab_conv2d_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int H, int W, int C, int Cout,
                    int KH, int KW, int stride, int pad, int relu, float* ws, size_t ws_floats, hipStream_t stream);
 int hab_obs_conv2d_fwd(const uint8_t* rgb, const float* depth, const int* rows, const float* w_fwd, const float* bias,

@@ -1,0 +1,130 @@
+"""Split-bf16 matrix path (csrc/igemm_bf3.h, obs_conv_bf3.h) against a float64 reference: the path must be as accurate as the fp32
+MFMA path (its arithmetic is fp32-equivalent: exact 3-term operand split, six partial products, dropped terms <= 2^-24)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from habitat_amd import _lib  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def L():
+    return _lib.lib()
+
+
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def both_paths(L, fn, mask):
+    out = {}
+    prev = L.hab_set_matrix_path(-1)
+    try:
+        for mode in (0, mask):
+            L.hab_set_matrix_path(mode)
+            out[mode] = fn()
+    finally:
+        L.hab_set_matrix_path(prev)
+    return out[0], out[mask]
+
+
+def err_vs(ref64, y):
+    ref = ref64.double()
+    return ((y.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+
+
+def repack_fwd(L, w):  # OIHW -> [Cout][KH][KW][Cin]
+    return w.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+@pytest.mark.parametrize("B,H,W,Cc,Cout,K,s,p", [(8, 63, 63, 32, 64, 4, 2, 0), (16, 16, 16, 64, 64, 3, 1, 1), (64, 8, 8, 128, 128, 3, 1, 1),
+                                                  (3, 30, 30, 64, 32, 3, 1, 0)])
+def test_conv_fwd_bf3_as_accurate_as_fp32_path(L, B, H, W, Cc, Cout, K, s, p):
+    torch.manual_seed(0)
+    x = torch.randn(B, Cc, H, W) * torch.rand(B, Cc, H, W).pow(4) * 50  # wide dynamic range
+    w = torch.randn(Cout, Cc, K, K) / np.sqrt(Cc * K * K)
+    b = torch.randn(Cout)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p).permute(0, 2, 3, 1)
+    xd, wf, bd = x.permute(0, 2, 3, 1).contiguous().cuda(), repack_fwd(L, w), b.cuda()
+    ws = torch.zeros(1 << 22, device="cuda")
+
+    def run():
+        y = torch.zeros(ref.shape, device="cuda")
+        _lib.check(L.hab_conv2d_fwd(P(xd), P(wf), P(bd), P(y), B, H, W, Cc, Cout, K, K, s, p, 0, P(ws), ws.numel(), S()))
+        return y
+
+    y0, y1 = both_paths(L, run, 1)
+    e0, e1 = err_vs(ref, y0), err_vs(ref, y1)
+    assert e1 <= 2 * e0 + 2e-7, (e0, e1)
+    assert e1 < 3e-6
+
+
+def test_obs_conv_bf3_as_accurate_as_fp32_path(L):
+    torch.manual_seed(1)
+    B, H, W = 5, 256, 256
+    rgb = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8)
+    depth = torch.rand(B, H, W, 1)
+    x = torch.cat([rgb.double() / 255.0, depth.double()], -1).permute(0, 3, 1, 2)
+    w = torch.randn(32, 4, 8, 8) / 16
+    b = torch.randn(32)
+    ref = F.relu(F.conv2d(x, w.double(), b.double(), stride=4)).permute(0, 2, 3, 1)
+    wf, bd = repack_fwd(L, w), b.cuda()
+    rg, dp = rgb.cuda(), depth.cuda()
+    ws = torch.zeros(1 << 22, device="cuda")
+
+    def run():
+        y = torch.zeros(ref.shape, device="cuda")
+        _lib.check(L.hab_obs_conv2d_fwd(P(rg), P(dp), None, P(wf), P(bd), P(y), B, H, W, 32, 8, 8, 4, 0, 1, P(ws), ws.numel(), S()))
+        return y
+
+    y0, y1 = both_paths(L, run, 2)
+    e0, e1 = err_vs(ref, y0), err_vs(ref, y1)
+    assert e1 <= 2 * e0 + 2e-7, (e0, e1)
+    assert e1 < 3e-6
+
+
+def test_linear_fwd_bf3_as_accurate_as_fp32_path(L):
+    torch.manual_seed(2)
+    M, N, K = 300, 512, 25088
+    x = torch.randn(M, K) * torch.rand(M, K).pow(3) * 10
+    w = torch.randn(N, K) * 0.01
+    ref = x.double() @ w.double().t()
+    xd, wd = x.cuda(), w.cuda()
+    ws = torch.zeros(1 << 24, device="cuda")
+
+    def run():
+        y = torch.zeros(M, N, device="cuda")
+        _lib.check(L.hab_linear_fwd(P(xd), K, P(wd), K, None, P(y), N, M, N, K, 0, 0, P(ws), ws.numel(), S()))
+        return y
+
+    y0, y1 = both_paths(L, run, 1)
+    e0, e1 = err_vs(ref, y0), err_vs(ref, y1)
+    assert e1 <= 2 * e0 + 2e-7, (e0, e1)
+
+
+def test_bf3_has_no_systematic_bias_on_same_sign_products(L):
+    """All-positive operands: a truncating split would lose a same-signed 2^-24 fraction of EVERY product (error grows ~K); the
+    round-to-nearest split keeps the error of the fp32 path."""
+    torch.manual_seed(3)
+    M, N, K = 512, 256, 8192
+    x = torch.rand(M, K) + 0.5
+    w = torch.rand(N, K) + 0.5
+    ref = x.double() @ w.double().t()
+    xd, wd = x.cuda(), w.cuda()
+    ws = torch.zeros(1 << 24, device="cuda")
+
+    def run():
+        y = torch.zeros(M, N, device="cuda")
+        _lib.check(L.hab_linear_fwd(P(xd), K, P(wd), K, None, P(y), N, M, N, K, 0, 0, P(ws), ws.numel(), S()))
+        return y
+
+    y0, y1 = both_paths(L, run, 1)
+    e0, e1 = err_vs(ref, y0), err_vs(ref, y1)
+    mean1 = ((y1.double().cpu() - ref) / ref).mean().abs().item()
+    assert e1 <= 1.5 * e0 + 3e-8, (e0, e1)
+    assert mean1 < 3e-8, mean1
