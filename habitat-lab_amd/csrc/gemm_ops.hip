@@ -5,6 +5,7 @@
 #include "igemm_dma_wgrad.h"
 #include "igemm_bf3.h"
 #include "obs_conv_bf3.h"
+#include "obs_wgrad_bf3.h"
 #include "wgrad3x3_patch.h"
 #include "prob_build.h"
 #include <stdlib.h>
@@ -20,7 +21,8 @@ static bool no_dma() { static const bool v = hab_env_flag("HAB_NO_DMA"); return 
 static bool no_merged_dgrad() { static const bool v = hab_env_flag("HAB_NO_MERGED_DGRAD"); return v; }
 static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); return v; }
 // split-bf16 matrix-pipe path (igemm_bf3.h) for the r-contiguous x r-contiguous contractions
-// bit 0: generic r-contiguous x r-contiguous problems, bit 1: observation-ingest convolution (obs_conv_bf3.h)
+// bit 0: r-contiguous x r-contiguous problems, bit 1: observation-ingest convolution (obs_conv_bf3.h), bit 2: problems with an
+// i/j-contiguous operand (weight gradients, Linear data gradient)
 static int g_bf3_mode = -1;
 static int bf3_mode() {
     if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 0);
@@ -46,6 +48,24 @@ static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream
         if ((bf3_mode() & 1) && p.M > 64) {
             if (p.N <= 32) return igemm_bf3_launch<P, 2, 1, 4, 1>(p, ws, ws_floats, target_blocks, stream);
             if (p.N <= 64) return igemm_bf3_launch<P, 1, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
+            return igemm_bf3_launch<P, 2, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
+        }
+    } else if constexpr (AKv<P>::value == 4) {  // an i/j-contiguous operand: register-transposed staging (igemm_bf3.h)
+        if ((bf3_mode() & 4) && p.M > 64) {
+            if (p.N <= 32) {
+                if constexpr (WG) {
+                    if (p.M % 96 == 0 || cdiv(p.M, 96) * 96 < cdiv(p.M, 256) * 256)
+                        return igemm_bf3_launch<P, 1, 1, 3, 1>(p, ws, ws_floats, target_blocks, stream);
+                }
+                return igemm_bf3_launch<P, 2, 1, 4, 1>(p, ws, ws_floats, target_blocks, stream);
+            }
+            if (p.N <= 64) {
+                if constexpr (WG) {
+                    if (p.M % 96 == 0 || cdiv(p.M, 96) * 96 < cdiv(p.M, 128) * 128)
+                        return igemm_bf3_launch<P, 1, 2, 3, 1>(p, ws, ws_floats, target_blocks, stream);
+                }
+                return igemm_bf3_launch<P, 1, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
+            }
             return igemm_bf3_launch<P, 2, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
         }
     }
@@ -139,7 +159,7 @@ int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oih
                hipStream_t stream) {
     ConvWgradProb p;
     HAB_TRY(build(p, d, x, dy, dw_oihw, dbias));
-    if (ws && wgrad3x3_patch_ok(p) && !no_patch()) {  // 3x3/1/1 with W in {16, 32}: patch-resident kernel
+    if (ws && wgrad3x3_patch_ok(p) && !no_patch() && !(bf3_mode() & 8)) {  // 3x3/1/1 with W in {16, 32}: patch-resident kernel
         ConvWgradProb q = p;
         q.colsum = nullptr;
         if (dbias) HAB_TRY(colsum(dy, p.N, p.K, p.N, dbias, 0, ws, ws_floats, stream));
@@ -147,7 +167,7 @@ int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oih
     }
     // LDS-DMA staged variant (igemm_dma_wgrad.h): measured faster only for unpadded convolutions with Cout <= 32 (SimpleCNN conv3:
     // 51 -> 64 TFLOP/s); with padding the per-pixel scalar decode + border tests cost more than the VGPR staging they replace.
-    if (ws && d.pad == 0 && p.N <= 32 && !no_dma()) {
+    if (ws && d.pad == 0 && p.N <= 32 && !no_dma() && !(bf3_mode() & 8)) {
         ConvWgradProb q = p;
         q.colsum = nullptr;  // the DMA path never sees dY in registers: the bias gradient is a separate column sum
         if (wgrad_dma_ok(q)) {
@@ -162,6 +182,10 @@ int obs_conv_wgrad(const ConvDesc& d, const ObsView& obs, const float* dy, float
                    size_t ws_floats, hipStream_t stream) {
     ObsConvWgradProb p;
     HAB_TRY(build(p, d, obs, dy, dw_oihw, dbias));
+    if ((bf3_mode() & 2) && p.quad && p.K > 4096) {  // uint8 x split-bf16 dY on the matrix pipe (obs_wgrad_bf3.h)
+        const int rc = obs_wgrad_bf3_launch(p, ws, ws_floats, stream);
+        if (rc != 1) return rc;
+    }
     return run_igemm(p, ws, ws_floats, stream);
 }
 int linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N, int K,

@@ -67,25 +67,60 @@ __device__ __forceinline__ void bf3_store4(const f32x4 v, unsigned short* p1, un
     *reinterpret_cast<u32x2*>(p3) = w3;
 }
 
+// k-run of an i/j-contiguous operand: a staging unit is KV consecutive rows x R consecutive k, gathered as R row-vectors and
+// transposed in registers (the split pairs neighbours along k, so the packed bf16 pairs come out k-contiguous for free).
+constexpr int bf3_run(int rows, int kv, int bk, int nt) {
+    int r = bk * rows / (kv * nt);
+    int p = 2;
+    while (p * 2 <= r && p < 8) p *= 2;
+    return p;
+}
+
 template <class P, int TM, int TN, int WM, int WN>
 struct IgemmBf3Cfg {
     static constexpr int NT = WM * WN * 64;
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = IGEMM_BK;
     static constexpr int KV = AKv<P>::value;
     static constexpr int A_PLANE = BM * BF3_BKP, B_PLANE = BN * BF3_BKP;  // bf16 elements
-    static constexpr int A_TOTAL = BM * BK / KV, B_TOTAL = BN * BK / 4;
+    static constexpr int RA = bf3_run(BM, KV, BK, NT), RB = bf3_run(BN, 4, BK, NT);
+    static constexpr int AKQ = P::A_RC ? BK / KV : BK / RA;  // units per row (RC) / k-runs per k-tile (IC)
+    static constexpr int BKQ = P::B_RC ? BK / 4 : BK / RB;
+    static constexpr int A_TOTAL = P::A_RC ? BM * BK / KV : (BM / KV) * AKQ;
+    static constexpr int B_TOTAL = P::B_RC ? BN * BK / 4 : (BN / 4) * BKQ;
     static constexpr int A_UNITS = (A_TOTAL + NT - 1) / NT, B_UNITS = (B_TOTAL + NT - 1) / NT;
+    static constexpr int A_RAWS = P::A_RC ? 1 : RA, B_RAWS = P::B_RC ? 1 : RB;
     static constexpr size_t LDS_BYTES = (size_t)3 * (A_PLANE + B_PLANE) * 2;
-    static_assert(P::A_RC && P::B_RC, "bf3 path: both operands r-contiguous");
-    static_assert(NT % (BK / KV) == 0 && NT % (BK / 4) == 0, "unit mapping");
+    static_assert(!P::A_RC || NT % (BK / KV) == 0, "A unit mapping");
+    static_assert(!P::B_RC || NT % (BK / 4) == 0, "B unit mapping");
+    static_assert(BM % KV == 0, "A rows per unit");
 };
+
+template <int R>
+__device__ __forceinline__ void bf3_store_run(const float (&x)[R], unsigned short* p1, unsigned short* p2, unsigned short* p3) {
+    unsigned w1[R / 2], w2[R / 2], w3[R / 2];
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) bf3_split2(x[2 * q], x[2 * q + 1], w1[q], w2[q], w3[q]);
+    if constexpr (R == 2) {
+        *reinterpret_cast<unsigned*>(p1) = w1[0]; *reinterpret_cast<unsigned*>(p2) = w2[0]; *reinterpret_cast<unsigned*>(p3) = w3[0];
+    } else if constexpr (R == 4) {
+        u32x2 a, b, c;
+        a[0] = w1[0]; a[1] = w1[1]; b[0] = w2[0]; b[1] = w2[1]; c[0] = w3[0]; c[1] = w3[1];
+        *reinterpret_cast<u32x2*>(p1) = a; *reinterpret_cast<u32x2*>(p2) = b; *reinterpret_cast<u32x2*>(p3) = c;
+    } else {
+        static_assert(R == 8, "k-run");
+        u32x4 a, b, c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = w1[q]; b[q] = w2[q]; c[q] = w3[q]; }
+        *reinterpret_cast<u32x4*>(p1) = a; *reinterpret_cast<u32x4*>(p2) = b; *reinterpret_cast<u32x4*>(p3) = c;
+    }
+}
 
 template <class P, int TM, int TN, int WM, int WN>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const int k_per_split, float* __restrict__ partial) {
     using Cfg = IgemmBf3Cfg<P, TM, TN, WM, WN>;
     constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, KV = Cfg::KV;
     constexpr int A_UNITS = Cfg::A_UNITS, B_UNITS = Cfg::B_UNITS, A_TOTAL = Cfg::A_TOTAL, B_TOTAL = Cfg::B_TOTAL;
-    constexpr int AKQ = BK / KV;
+    constexpr int AKQ = Cfg::AKQ, BKQ = Cfg::BKQ, RA = Cfg::RA, RB = Cfg::RB;
 
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     unsigned short* As = smem16;                        // planes 0..2: [BM][BF3_BKP]
@@ -111,47 +146,120 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
     const int k_end = min(p.K, k_begin + k_per_split);
     const int ntk = max(0, cdiv(k_end - k_begin, BK));
 
+    // unit u = t + NT*j.   RC operand: row u / AKQ, k-offset (u % AKQ) * KV.   IC operand: k-run u % AKQ (fastest: the lanes of an
+    // LDS write group then cover whole rows of the image -> conflict-free), rows (u / AKQ) * KV .. +KV-1.
     typename P::ACtx actx[A_UNITS];
     typename P::BCtx bctx[B_UNITS];
 #pragma unroll
-    for (int j = 0; j < A_UNITS; ++j) actx[j] = p.a_ctx(m0 + (t + NT * j) / AKQ);
+    for (int j = 0; j < A_UNITS; ++j) {
+        const int u = t + NT * j;
+        actx[j] = P::A_RC ? p.a_ctx(m0 + u / AKQ) : p.a_ctx(m0 + (u / AKQ) * KV);
+    }
 #pragma unroll
-    for (int j = 0; j < B_UNITS; ++j) bctx[j] = p.b_ctx(n0 + ((t + NT * j) >> 3));
+    for (int j = 0; j < B_UNITS; ++j) {
+        const int u = t + NT * j;
+        bctx[j] = P::B_RC ? p.b_ctx(n0 + (u >> 3)) : p.b_ctx(n0 + (u / BKQ) * 4);
+    }
+    constexpr bool CS = ColsumB<P>::value;
+    bool has_cs = false;
+    if constexpr (CS) has_cs = (p.colsum != nullptr);
+    const bool do_cs = has_cs && (tile_m == 0);
+    const int MP = p.M + (has_cs ? 1 : 0);
+    f32x4 cs[B_UNITS];
+#pragma unroll
+    for (int j = 0; j < B_UNITS; ++j) cs[j] = zero4();
 
-    typename P::ARaw araw[A_UNITS];
-    typename P::BRaw braw[B_UNITS];
-    auto a_k = [&](int kt, int j) { return k_begin + kt * BK + ((t + NT * j) % AKQ) * KV; };
-    auto b_k = [&](int kt, int j) { return k_begin + kt * BK + ((t + NT * j) & 7) * 4; };
+    typename P::ARaw araw[A_UNITS][Cfg::A_RAWS];
+    typename P::BRaw braw[B_UNITS][Cfg::B_RAWS];
+    auto a_k = [&](int kt, int j, int r) {
+        const int u = t + NT * j;
+        return k_begin + kt * BK + (P::A_RC ? (u % AKQ) * KV : (u % AKQ) * RA + r);
+    };
+    auto b_k = [&](int kt, int j, int r) {
+        const int u = t + NT * j;
+        return k_begin + kt * BK + (P::B_RC ? (u & 7) * 4 : (u % BKQ) * RB + r);
+    };
     auto fetch = [&](int kt) {
         const typename P::KCtx kc = p.k_ctx(k_begin + kt * BK, k_end);
-        const typename P::AKey ak = p.a_key(kc, a_k(kt, 0), k_end);
+        if constexpr (P::A_RC) {
+            const typename P::AKey ak = p.a_key(kc, a_k(kt, 0, 0), k_end);
 #pragma unroll
-        for (int j = 0; j < A_UNITS; ++j)
-            if (A_TOTAL % NT == 0 || t + NT * j < A_TOTAL) araw[j] = p.a_fetch(actx[j], kc, ak);
-        const typename P::BKey bk = p.b_key(kc, b_k(kt, 0), k_end);
+            for (int j = 0; j < A_UNITS; ++j)
+                if (A_TOTAL % NT == 0 || t + NT * j < A_TOTAL) araw[j][0] = p.a_fetch(actx[j], kc, ak);
+        } else {
 #pragma unroll
-        for (int j = 0; j < B_UNITS; ++j)
-            if (B_TOTAL % NT == 0 || t + NT * j < B_TOTAL) braw[j] = p.b_fetch(bctx[j], kc, bk);
+            for (int r = 0; r < RA; ++r) {
+                // NT % AKQ == 0 is not required: the key depends on the unit
+#pragma unroll
+                for (int j = 0; j < A_UNITS; ++j)
+                    if (A_TOTAL % NT == 0 || t + NT * j < A_TOTAL) araw[j][r] = p.a_fetch(actx[j], kc, p.a_key(kc, a_k(kt, j, r), k_end));
+            }
+        }
+        if constexpr (P::B_RC) {
+            const typename P::BKey bk = p.b_key(kc, b_k(kt, 0, 0), k_end);
+#pragma unroll
+            for (int j = 0; j < B_UNITS; ++j)
+                if (B_TOTAL % NT == 0 || t + NT * j < B_TOTAL) braw[j][0] = p.b_fetch(bctx[j], kc, bk);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int j = 0; j < B_UNITS; ++j)
+                    if (B_TOTAL % NT == 0 || t + NT * j < B_TOTAL) braw[j][r] = p.b_fetch(bctx[j], kc, p.b_key(kc, b_k(kt, j, r), k_end));
+        }
     };
     auto stage = [&](int kt) {  // registers -> split -> three bf16 planes
 #pragma unroll
         for (int j = 0; j < A_UNITS; ++j) {
             const int u = t + NT * j;
             if (A_TOTAL % NT == 0 || u < A_TOTAL) {
-                f32x4 v[KV / 4];
-                p.a_cvt(actx[j], araw[j], a_k(kt, j), k_end, v);
-                unsigned short* dst = As + (u / AKQ) * BF3_BKP + (u % AKQ) * KV;
+                if constexpr (P::A_RC) {
+                    f32x4 v[KV / 4];
+                    p.a_cvt(actx[j], araw[j][0], a_k(kt, j, 0), k_end, v);
+                    unsigned short* dst = As + (u / AKQ) * BF3_BKP + (u % AKQ) * KV;
 #pragma unroll
-                for (int q = 0; q < KV / 4; ++q) bf3_store4(v[q], dst + 4 * q, dst + Cfg::A_PLANE + 4 * q, dst + 2 * Cfg::A_PLANE + 4 * q);
+                    for (int q = 0; q < KV / 4; ++q) bf3_store4(v[q], dst + 4 * q, dst + Cfg::A_PLANE + 4 * q, dst + 2 * Cfg::A_PLANE + 4 * q);
+                } else {
+                    f32x4 v[RA][KV / 4];
+#pragma unroll
+                    for (int r = 0; r < RA; ++r) p.a_cvt(actx[j], araw[j][r], a_k(kt, j, r), k_end, v[r]);
+                    unsigned short* dst = As + ((u / AKQ) * KV) * BF3_BKP + (u % AKQ) * RA;
+#pragma unroll
+                    for (int e = 0; e < KV; ++e) {
+                        float x[RA];
+#pragma unroll
+                        for (int r = 0; r < RA; ++r) x[r] = v[r][e >> 2][e & 3];
+                        bf3_store_run<RA>(x, dst + e * BF3_BKP, dst + Cfg::A_PLANE + e * BF3_BKP, dst + 2 * Cfg::A_PLANE + e * BF3_BKP);
+                    }
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < B_UNITS; ++j) {
             const int u = t + NT * j;
             if (B_TOTAL % NT == 0 || u < B_TOTAL) {
-                const f32x4 v = p.b_cvt(braw[j]);
-                unsigned short* dst = Bs + (u >> 3) * BF3_BKP + (u & 7) * 4;
-                bf3_store4(v, dst, dst + Cfg::B_PLANE, dst + 2 * Cfg::B_PLANE);
+                if constexpr (P::B_RC) {
+                    const f32x4 v = p.b_cvt(braw[j][0]);
+                    unsigned short* dst = Bs + (u >> 3) * BF3_BKP + (u & 7) * 4;
+                    bf3_store4(v, dst, dst + Cfg::B_PLANE, dst + 2 * Cfg::B_PLANE);
+                } else {
+                    f32x4 v[RB];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        v[r] = p.b_cvt(braw[j][r]);
+                        if constexpr (CS) {
+                            if (do_cs) cs[j] += v[r];
+                        }
+                    }
+                    unsigned short* dst = Bs + ((u / BKQ) * 4) * BF3_BKP + (u % BKQ) * RB;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x[RB];
+#pragma unroll
+                        for (int r = 0; r < RB; ++r) x[r] = v[r][e];
+                        bf3_store_run<RB>(x, dst + e * BF3_BKP, dst + Cfg::B_PLANE + e * BF3_BKP, dst + 2 * Cfg::B_PLANE + e * BF3_BKP);
+                    }
+                }
             }
         }
     };
@@ -202,7 +310,23 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
 
     // ---- epilogue: identical to igemm_kernel's (same accumulator layout) ----
     const bool split = gridDim.z > 1;
-    const int MP = p.M;
+    if constexpr (CS) {
+        if (do_cs) {  // block-uniform: column c = the BKQ units of column quad c >> 2, summed in unit order through LDS
+            float* red = reinterpret_cast<float*>(smem16);
+#pragma unroll
+            for (int j = 0; j < B_UNITS; ++j)
+                if (B_TOTAL % NT == 0 || t + NT * j < B_TOTAL) *reinterpret_cast<f32x4*>(red + (size_t)(t + NT * j) * 4) = cs[j];
+            __syncthreads();
+            if (t < BN && n0 + t < p.N) {
+                float s_ = 0.f;
+                for (int q = 0; q < BKQ; ++q) s_ += red[((t >> 2) * BKQ + q) * 4 + (t & 3)];
+                if (split)
+                    partial[((size_t)kz * MP + p.M) * p.N + n0 + t] = s_;
+                else
+                    p.store_colsum(n0 + t, s_);
+            }
+        }
+    }
     if constexpr (EpiV4<P>::value) {
         if (split)
             igemm_partial_v4<P, TM, TN>(p, acc, partial + (size_t)kz * MP * p.N, m0 + wm * TM * 32, n0 + wn * TN * 32, li, hi);

@@ -128,3 +128,78 @@ def test_bf3_has_no_systematic_bias_on_same_sign_products(L):
     mean1 = ((y1.double().cpu() - ref) / ref).mean().abs().item()
     assert e1 <= 1.5 * e0 + 3e-8, (e0, e1)
     assert mean1 < 3e-8, mean1
+
+
+def test_obs_wgrad_bf3_as_accurate_as_fp32_path(L):
+    torch.manual_seed(4)
+    B, H, W = 6, 256, 256
+    rgb = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8)
+    depth = torch.rand(B, H, W, 1)
+    x = torch.cat([rgb.double() / 255.0, depth.double()], -1).permute(0, 3, 1, 2)
+    dy = torch.randn(B, 63, 63, 32) * torch.rand(B, 63, 63, 32).pow(3)
+    w = torch.zeros(32, 4, 8, 8, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, None, stride=4).backward(dy.double().permute(0, 3, 1, 2))
+    ref, ref_b = w.grad, dy.double().sum((0, 1, 2))
+    rg, dp, dyd = rgb.cuda(), depth.cuda(), dy.cuda()
+    ws = torch.zeros(1 << 24, device="cuda")
+
+    def run():
+        dw = torch.zeros(32, 4, 8, 8, device="cuda")
+        db = torch.zeros(32, device="cuda")
+        _lib.check(L.hab_obs_conv2d_wgrad(P(rg), P(dp), None, P(dyd), P(dw), P(db), B, H, W, 32, 8, 8, 4, 0, P(ws), ws.numel(), S()))
+        return torch.cat([dw.flatten(), db])
+
+    y0, y1 = both_paths(L, run, 2)
+    full = torch.cat([ref.flatten(), ref_b])
+    e0, e1 = err_vs(full, y0), err_vs(full, y1)
+    assert e1 <= 2 * e0 + 2e-7, (e0, e1)
+    assert e1 < 3e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cc,Cout,K,s,p", [(8, 63, 63, 32, 64, 4, 2, 0), (16, 16, 16, 64, 64, 3, 1, 1), (64, 8, 8, 128, 128, 3, 1, 1),
+                                                  (3, 30, 30, 64, 32, 3, 1, 0)])
+def test_conv_wgrad_bf3_as_accurate_as_fp32_path(L, B, H, W, Cc, Cout, K, s, p):
+    torch.manual_seed(5)
+    x = torch.randn(B, Cc, H, W) * torch.rand(B, Cc, H, W).pow(4) * 50
+    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    dy = torch.randn(B, Cout, Ho, Wo)
+    w = torch.zeros(Cout, Cc, K, K, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, stride=s, padding=p).backward(dy.double())
+    ref = torch.cat([w.grad.flatten(), dy.double().sum((0, 2, 3))])
+    xd, dyd = x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda()
+    ws = torch.zeros(1 << 24, device="cuda")
+
+    def run():
+        dw = torch.zeros(Cout, Cc, K, K, device="cuda")
+        db = torch.zeros(Cout, device="cuda")
+        _lib.check(L.hab_conv2d_wgrad(P(xd), P(dyd), P(dw), P(db), B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S()))
+        return torch.cat([dw.flatten(), db])
+
+    y0, y1 = both_paths(L, run, 4 | 8)
+    e0, e1 = err_vs(ref, y0), err_vs(ref, y1)
+    assert e1 <= 2 * e0 + 2e-7, (e0, e1)
+    assert e1 < 3e-6
+
+
+def test_linear_dgrad_wgrad_bf3_as_accurate_as_fp32_path(L):
+    torch.manual_seed(6)
+    M, N, K = 700, 512, 3136  # rows, out features, in features
+    x = torch.randn(M, K) * torch.rand(M, K).pow(3) * 10
+    w = torch.randn(N, K) * 0.02
+    dy = torch.randn(M, N)
+    ref_dx = dy.double() @ w.double()
+    ref_dw = dy.double().t() @ x.double()
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    ws = torch.zeros(1 << 24, device="cuda")
+
+    def run():
+        dx = torch.zeros(M, K, device="cuda")
+        dw = torch.zeros(N, K, device="cuda")
+        _lib.check(L.hab_linear_dgrad(P(dyd), N, P(wd), K, None, 0, P(dx), K, M, K, N, 0, P(ws), ws.numel(), S()))
+        _lib.check(L.hab_linear_wgrad(P(dyd), N, P(xd), K, P(dw), K, M, N, K, 0, 0, 0, P(ws), ws.numel(), S()))
+        return dx, dw
+
+    (dx0, dw0), (dx1, dw1) = both_paths(L, run, 4)
+    for ref, y0, y1 in ((ref_dx, dx0, dx1), (ref_dw, dw0, dw1)):
+        e0, e1 = err_vs(ref, y0), err_vs(ref, y1)
+        assert e1 <= 2 * e0 + 2e-7, (e0, e1)
