@@ -41,6 +41,8 @@ sys.path.insert(0, os.path.join(ROOT, "habitat-lab_amd"))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E
 NUM_ENVS, NUM_STEPS, OBS = 64, 128, 256
 
 WORKLOADS = {
@@ -74,9 +76,45 @@ PROBES = {
 C2_TABLE = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_wgrad", "fc_dgrad", "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad",
             "conv1_wgrad", "rnn_fwd", "rnn_bwd"]
 # kernel launched by a probed call site (rocprofv3 names), for the HBM-traffic lookup in the committed --pmc passes
-PROBE_KERNELS = {"conv2_dgrad": "igemm_dma_kernel<ConvDgradMergedProb", "conv1_fwd": "igemm_kernel<ObsConvFwdProb",
-                 "conv1_wgrad": "igemm_kernel<ObsConvWgradProb", "conv2_wgrad": "igemm_kernel<ConvWgradProb",
-                 "conv3_wgrad": "igemm_dma_wgrad_kernel", "conv2_fwd": "igemm_dma_kernel<ConvFwdProb"}
+PROBE_KERNELS = {"conv2_dgrad": "igemm_bf3_kernel<ConvDgradMergedProb", "conv1_fwd": "obs_conv_bf3_kernel",
+                 "conv1_wgrad": "obs_wgrad_bf3_kernel", "conv2_wgrad": "igemm_bf3_kernel<ConvWgradProb, 1, 2",
+                 "conv3_wgrad": "igemm_bf3_kernel<ConvWgradProb, 1, 1", "conv2_fwd": "igemm_bf3_kernel<ConvFwdProb, 1, 2",
+                 "conv3_fwd": "igemm_bf3_kernel<ConvFwdProb, 2, 1", "conv3_dgrad": "igemm_bf3_kernel<ConvDgradProb",
+                 "fc_fwd": "igemm_bf3_kernel<LinearFwdProb, 2, 2", "fc_dgrad": "igemm_bf3_kernel<LinearDgradProb",
+                 "fc_wgrad": "igemm_bf3_kernel<LinearWgradProb"}
+# Roofline model of a contraction call site on the split-bf16 matrix path (csrc/igemm_bf3.h): (algorithmic HBM bytes per frame:
+# every operand read once, the result written once; bf16 MFMA flops issued per useful fp32 flop).  The fp32-equivalent MFMA ceiling
+# of a site is PEAK_BF16 / factor: 6 partial products in general; the observation-ingest convolutions need 3 for the uint8 rgb
+# operand (exact in one bf16 plane) and 6 for depth = 3.75 on the 3:1 channel mix (csrc/obs_conv_bf3.h, obs_wgrad_bf3.h).
+_A0, _A1, _A2, _A3 = 256 * 256 * 7, 63 * 63 * 32 * 4, 30 * 30 * 64 * 4, 28 * 28 * 32 * 4  # obs (u8 rgb + f32 depth), conv1..3 outputs
+SITE_MODEL = {
+    "conv1_fwd": (_A0 + _A1, 3.75), "conv1_wgrad": (_A0 + _A1, 3.75),
+    "conv2_fwd": (_A1 + _A2, 6.0), "conv2_wgrad": (_A1 + _A2, 6.0), "conv2_dgrad": (_A2 + 2 * _A1, 6.0),  # dgrad reads the ReLU mask
+    "conv3_fwd": (_A2 + _A3, 6.0), "conv3_wgrad": (_A2 + _A3, 6.0), "conv3_dgrad": (_A3 + 2 * _A2, 6.0),
+    "fc_fwd": (_A3 + 2048, 6.0), "fc_wgrad": (_A3 + 2048, 6.0), "fc_dgrad": (_A3 + 2048 + _A3, 6.0),
+}
+
+
+def site_roofline(site, flops_per_frame, frames, ms):
+    """Which roofline bounds the call site (time per frame at the HBM peak vs at the split-bf16 MFMA ceiling) and where it is."""
+    tfl = flops_per_frame * frames / (ms * 1e-3) / 1e12
+    if site not in SITE_MODEL:
+        return {"bound": "mfma", "achieved": round(tfl, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / PEAK_FP32_MFMA_TFLOPS, 4)}
+    bytes_pf, factor = SITE_MODEL[site]
+    peak_eq = PEAK_BF16_MFMA_TFLOPS / factor
+    gbs = bytes_pf * frames / (ms * 1e-3) / 1e9
+    t_hbm, t_mfma = bytes_pf / (PEAK_HBM_GBS * 1e9), flops_per_frame / (peak_eq * 1e12)
+    r = {"bound": "hbm" if t_hbm >= t_mfma else "mfma"}
+    if r["bound"] == "hbm":
+        r.update(achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
+    else:
+        r.update(achieved=round(tfl, 2), peak=round(peak_eq, 1), unit="TFLOP/s", frac=round(tfl / peak_eq, 4))
+    r["fp32_equiv_tflops"] = round(tfl, 2)
+    r["algorithmic_gbs"] = round(gbs, 1)
+    r["mfma_ceiling_fp32_equiv_tflops"] = round(peak_eq, 1)
+    r["frac_of_fp32_mfma_peak"] = round(tfl / PEAK_FP32_MFMA_TFLOPS, 4)  # the round-1 yardstick (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s)
+    r["roofline_floor_ms_per_kframe"] = round(max(t_hbm, t_mfma) * 1e6, 4)
+    return r
 
 
 def make_trainer(workload: str, total_updates: int):
@@ -252,6 +290,8 @@ def encoder_record(frames=4096, calls=2):
            "fwd_bwd_tflops": round(tf(f_fwd + f_bwd, fwd + bwd), 1), "peak_tflops": PEAK_FP32_MFMA_TFLOPS,
            "forward_frac": round(tf(f_fwd, fwd) / PEAK_FP32_MFMA_TFLOPS, 4), "backward_frac": round(tf(f_bwd, bwd) / PEAK_FP32_MFMA_TFLOPS, 4),
            "fwd_bwd_frac": round(tf(f_fwd + f_bwd, fwd + bwd) / PEAK_FP32_MFMA_TFLOPS, 4),
+           "split_bf16_ceiling_tflops": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
+           "fwd_bwd_frac_of_split_bf16_ceiling": round(tf(f_fwd + f_bwd, fwd + bwd) / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
            "what": "ResNet18 GroupNorm encoder (ingest, RunningMeanAndVar, 17 convs + GroupNorms, compression, visual_fc), fp32, 256x256 RGB-D; "
                    "every non-contraction kernel (GroupNorm, pooling, ingest) is inside the times"}
     del eng
@@ -392,7 +432,7 @@ def main():
         kname = f"{a.probe}: {PROBE_KERNELS[a.probe]}...>"
     else:
         kname = f"contraction at call site {a.probe}"
-    ach = flops_per_frame * frames / (probe_ms * 1e-3) / 1e12 if probe_ms > 0 else None
+    rl = site_roofline(a.probe, flops_per_frame, frames, probe_ms) if probe_ms > 0 else {"bound": "mfma", "achieved": None, "peak": None, "frac": None}
     traffic, traffic_src = hbm_traffic(a.workload, a.probe)
     out = {
         "metric": "env-steps/sec (SPS) PointNav RGB-D 256x256, 64 envs x 128 rollout" if a.workload != "c5" else
@@ -401,11 +441,12 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOADS[a.workload]["name"], "envs_per_gpu": n_envs, "rollout_steps": n_steps,
-                   "ppo_epoch": ppo.ppo_epoch, "num_mini_batch": ppo.num_mini_batch, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2) if ach else None,
-                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4) if ach else None,
-                     "traffic": traffic, "traffic_source": traffic_src, "launches": probe_cnt,
-                     "avg_launch_ms": round(probe_ms / max(probe_cnt, 1), 4), "share_of_step": round(probe_ms / (dt * 1e3), 4)},
+                   "ppo_epoch": ppo.ppo_epoch, "num_mini_batch": ppo.num_mini_batch, "parallelism": f"dp{world}",
+                   "matrix_path": "fp32 in / fp32 out; exact 3-term bf16 operand split, 6 (uint8 operand: 3) partial products on "
+                                  "v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/igemm_bf3.h); HAB_BF3=0 selects v_mfma_f32_32x32x2_f32"},
+        "roofline": dict(rl, kernel=kname, traffic=traffic, traffic_source=traffic_src, launches=probe_cnt,
+                         avg_launch_ms=round(probe_ms / max(probe_cnt, 1), 4), share_of_step=round(probe_ms / (dt * 1e3), 4),
+                         frames_per_launch=round(frames / max(probe_cnt, 1), 1)),
     }
     if a.workload in ("c2", "c3"):
         f_step = 2.365e9 if a.workload == "c2" else 2.442e9  # algorithmic FLOPs per env-step
@@ -424,9 +465,10 @@ def main():
         for k, (t_, fl) in tags.items():
             ms, cnt = eng.probe_read_tag(t_)
             if cnt:
-                tfl = fl * frames_seen(k, ls, 1) / (ms * 1e-3) / 1e12
-                table.append({"site": k, "ms": round(ms, 2), "calls": cnt, "share": round(ms / cyc_ms, 4), "tflops": round(tfl, 1),
-                              "frac": round(tfl / PEAK_FP32_MFMA_TFLOPS, 4)})
+                sr = site_roofline(k, fl, frames_seen(k, ls, 1), ms)
+                table.append({"site": k, "ms": round(ms, 2), "calls": cnt, "share": round(ms / cyc_ms, 4),
+                              "tflops": sr.get("fp32_equiv_tflops", sr["achieved"]), "bound": sr["bound"], "achieved": sr["achieved"],
+                              "peak": sr["peak"], "unit": sr["unit"], "frac": sr["frac"]})
         eng.probe_read()
         eng.probe_enable(-1)
         out["roofline"]["kernels"] = sorted(table, key=lambda r: -r["ms"])

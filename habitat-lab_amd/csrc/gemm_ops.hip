@@ -25,7 +25,7 @@ static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); ret
 // i/j-contiguous operand (weight gradients, Linear data gradient)
 static int g_bf3_mode = -1;
 static int bf3_mode() {
-    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 0);
+    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 15);
     return g_bf3_mode;
 }
 extern "C" int hab_set_matrix_path(int mode) {
@@ -131,6 +131,11 @@ int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float*
         if (ConvDgradMergedProb::applicable(q.g)) {
             q.dy = dy; q.w = wd; q.mask = mask; q.add = add; q.dx = dx;
             q.finish();
+            if ((bf3_mode() & 1) && q.M > 64) {  // split-bf16 matrix path, register-staged (igemm_bf3.h)
+                if (q.N <= 32) return igemm_bf3_launch<ConvDgradMergedProb, 2, 1, 4, 1>(q, ws, ws_floats, 256, stream);
+                if (q.N <= 64) return igemm_bf3_launch<ConvDgradMergedProb, 1, 2, 4, 1>(q, ws, ws_floats, 256, stream);
+                return igemm_bf3_launch<ConvDgradMergedProb, 2, 2, 2, 2>(q, ws, ws_floats, 256, stream);
+            }
             if (q.dma_ok()) {
                 if (q.N <= 32) return igemm_dma_launch<ConvDgradMergedProb, 2, 1, 4, 1, false>(q, ws, ws_floats, 1024, stream);
                 if (q.N <= 64) return igemm_dma_launch<ConvDgradMergedProb, 1, 2, 4, 1, false>(q, ws, ws_floats, 1024, stream);

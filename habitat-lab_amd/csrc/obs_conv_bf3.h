@@ -25,15 +25,20 @@ namespace hab {
 constexpr int OBF_BK = 64, OBF_RGB = 48, OBF_DEP = 16;
 constexpr int OBF_RGBP = 56, OBF_DEPP = 24;  // LDS row pitches in bf16 elements
 
-// weight planes (bf16 bit patterns) in the workspace:  rgb [3][KT][NP][48], then dep [3][KT][NP][16]
-__global__ void obs_conv_bf3_split_weights(const float* __restrict__ w, int N, int K, int NP, unsigned short* __restrict__ planes) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= NP * K) return;
+// weight planes (bf16 bit patterns) in the workspace:  rgb [3][KT][NP][48], then dep [3][KT][NP][16]; a second set of the same size
+// holds the planes of -w (sign schedule of igemm_bf3.h: odd output tiles accumulate the negated sum)
+__global__ void obs_conv_bf3_split_weights(const float* __restrict__ w, int N, int K, int NP, unsigned short* __restrict__ planes_both) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * NP * K) return;
+    const bool negset = e >= NP * K;
+    if (negset) e -= NP * K;
+    unsigned short* planes = planes_both + (negset ? (size_t)3 * NP * K : 0);
     const int n = e / K, k = e - n * K;
     const int kt = k >> 6, kk = k & 63, u = kk >> 4, q = (kk >> 2) & 3, c = kk & 3;
     const int KT = K >> 6;
     float v = n < N ? w[(size_t)n * K + k] : 0.f;
     if (c < 3) v *= HAB_RCP255;
+    if (negset) v = -v;
     unsigned h1, h2, h3;
     bf3_split(v, h1, h2, h3);
     const size_t rgb_plane = (size_t)KT * NP * OBF_RGB, dep_plane = (size_t)KT * NP * OBF_DEP;
@@ -123,7 +128,9 @@ __global__ void __launch_bounds__(256) obs_conv_bf3_kernel(const ObsConvFwdProb 
             dep_ptr[j] = p.obs.depth + pix;
         }
     };
-    auto fetch = [&](int kt, int n0) {
+    // sign schedule (igemm_bf3.h, short reduction): odd output tiles accumulate the negated sum (planes of -w), negated before the epilogue
+    const size_t neg_set = (size_t)3 * NP * p.K;
+    auto fetch = [&](int kt, int n0, bool neg) {
         int kh, kw;
         p.g.dKW.divmod(kt * 16 + (t & 3) * 4, kh, kw);  // first of the unit's four taps
         const int off = kh * p.g.W + kw;
@@ -132,7 +139,7 @@ __global__ void __launch_bounds__(256) obs_conv_bf3_kernel(const ObsConvFwdProb 
             a_rgb[j] = *reinterpret_cast<const Rgb12*>(rgb_ptr[j] + off * 3);
             a_dep[j] = ld4(dep_ptr[j] + off);
         }
-        const unsigned short* src = b_src0 + (size_t)n0 * b_row_elems + kt * b_tile_stride;
+        const unsigned short* src = b_src0 + (size_t)n0 * b_row_elems + kt * b_tile_stride + (neg ? neg_set : 0);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) braw[pl] = *reinterpret_cast<const u32x4*>(src + pl * b_plane_stride);
     };
@@ -163,7 +170,8 @@ __global__ void __launch_bounds__(256) obs_conv_bf3_kernel(const ObsConvFwdProb 
     if (vb >= vgrid) return;
     int m0, n0;
     setup(tile_of(vb), m0, n0);
-    fetch(0, n0);
+    bool neg = ((tile_of(vb) / nt_n + tile_of(vb) % nt_n) & 1) != 0;
+    fetch(0, n0, neg);
     for (;;) {
         f32x16 acc[TM][1];
 #pragma unroll
@@ -171,18 +179,20 @@ __global__ void __launch_bounds__(256) obs_conv_bf3_kernel(const ObsConvFwdProb 
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][0][v] = 0.0f;
         const int m0_cur = m0, n0_cur = n0;
+        const bool neg_cur = neg;
         bool more = false;
         for (int kt = 0; kt < KT; ++kt) {
             stage();
             __syncthreads();
             if (kt + 1 < KT) {
-                fetch(kt + 1, n0_cur);
+                fetch(kt + 1, n0_cur, neg_cur);
             } else {
                 vb += gridDim.x;
                 more = vb < vgrid;
                 if (more) {
                     setup(tile_of(vb), m0, n0);
-                    fetch(0, n0);
+                    neg = ((tile_of(vb) / nt_n + tile_of(vb) % nt_n) & 1) != 0;
+                    fetch(0, n0, neg);
                 }
             }
             // rgb: three k-groups, A exact in one plane
@@ -217,6 +227,12 @@ __global__ void __launch_bounds__(256) obs_conv_bf3_kernel(const ObsConvFwdProb 
             }
             __syncthreads();
         }
+        if (neg_cur) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][0][v] = -acc[i][0][v];
+        }
         igemm_epilogue_v4<P, TM, 1>(p, acc, m0_cur + wm * TM * 32, n0_cur, li, hi);
         if (!more) break;
     }
@@ -228,10 +244,10 @@ inline int obs_conv_bf3_launch(const ObsConvFwdProb& p, float* ws, size_t ws_flo
     using Cfg = ObsBf3Cfg<TM>;
     if (!p.quad || (p.K & 63) || p.M <= 0 || p.N <= 0) return 1;
     const int KT = p.K >> 6, NP = cdiv(p.N, 32) * 32;
-    const size_t plane_bytes = (size_t)3 * KT * NP * OBF_BK * 2;
+    const size_t plane_bytes = (size_t)2 * 3 * KT * NP * OBF_BK * 2;  // +w and -w sets
     if (!ws || ws_floats * 4 < plane_bytes || (reinterpret_cast<uintptr_t>(ws) & 15)) return 1;
     unsigned short* planes = reinterpret_cast<unsigned short*>(ws);
-    obs_conv_bf3_split_weights<<<cdiv(NP * p.K, 256), 256, 0, stream>>>(p.w, p.N, p.K, NP, planes);
+    obs_conv_bf3_split_weights<<<cdiv(2 * NP * p.K, 256), 256, 0, stream>>>(p.w, p.N, p.K, NP, planes);
     HAB_LAUNCH_CHECK();
     auto kern = obs_conv_bf3_kernel<TM>;
     static bool attr_set = false;

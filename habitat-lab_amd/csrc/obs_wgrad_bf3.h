@@ -129,6 +129,12 @@ __global__ void __launch_bounds__(256, 2) obs_wgrad_bf3_kernel(const ObsConvWgra
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
 
+    // Sign schedule (igemm_bf3.h): the bf16 MFMA truncates towards -infinity below its alignment window, a coherent ~0.0025 ulp per
+    // instruction.  Waves 0, 1 accumulate +sum, waves 2, 3 the NEGATED sum (dY fragments sign-flipped as they are read); the final
+    // cross-wave reduction subtracts, and the truncation biases of the two pairs cancel.
+    const unsigned sf = wave >= 2 ? 0x80008000u : 0u;
+    u32x4 sign_flip;
+    sign_flip[0] = sf; sign_flip[1] = sf; sign_flip[2] = sf; sign_flip[3] = sf;
     if (tile_begin < tile_end) fetch(tile_begin);
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         stage();
@@ -137,7 +143,11 @@ __global__ void __launch_bounds__(256, 2) obs_wgrad_bf3_kernel(const ObsConvWgra
         const int koff = wave * 16 + hi * 8;
         bf16x8 b[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * BP + li * OWG_P + koff);
+        for (int pl = 0; pl < 3; ++pl) {
+            u32x4 raw = *reinterpret_cast<const u32x4*>(Bs + pl * BP + li * OWG_P + koff);
+            raw ^= sign_flip;  // waves 2, 3: -dY (sign schedule, see below)
+            b[pl] = __builtin_bit_cast(bf16x8, raw);
+        }
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(Argb + (mt * 32 + li) * OWG_P + koff);
@@ -166,7 +176,7 @@ __global__ void __launch_bounds__(256, 2) obs_wgrad_bf3_kernel(const ObsConvWgra
                 for (int v = 0; v < 16; ++v) {
                     const int rrow = mt * 32 + (v & 3) + 8 * (v >> 2) + 4 * hi;
                     float* dst = red + rrow * 32 + li;
-                    *dst = (w == 0 ? 0.f : *dst) + acc[mt][v];
+                    *dst = (w == 0 ? 0.f : *dst) + (w >= 2 ? -acc[mt][v] : acc[mt][v]);
                 }
         }
         __syncthreads();

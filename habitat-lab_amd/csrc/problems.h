@@ -620,6 +620,64 @@ struct ConvDgradMergedProb {
         M = g.B * Hq * Wq; N = s * s * g.C; K = KHs * KWs * g.Cout;
         dHqWq = FastDiv(Hq * Wq); dWq = FastDiv(Wq); dKWs = FastDiv(KWs);
     }
+    // ---- register-staged interface (igemm_bf3.h): both operands r-contiguous (Cout % 32 == 0: a k-quad is 4 channels of one tap) ----
+    static constexpr bool A_RC = true, B_RC = true;
+    HAB_NO_KCTX
+    struct ACtx { const float* base; int hq, wq; };   // base = dY of the row's image
+    struct AKey { int a, b, co, ok; };
+    using BCtx = WRowCtx;
+    struct BKey { int koff, ok; };
+    using ARaw = Raw4;
+    using BRaw = Raw4;
+    HAB_HD ACtx a_ctx(int m) const {
+        ACtx c;
+        if (m >= M) { c.base = dy; c.hq = HAB_FAR; c.wq = 0; return c; }
+        int img, rem;
+        dHqWq.divmod(m, img, rem);
+        dWq.divmod(rem, c.hq, c.wq);
+        c.base = dy + (size_t)img * g.Ho * g.Wo * g.Cout;
+        return c;
+    }
+    HAB_HD AKey a_key(const KCtx&, int k, int k_end) const {
+        AKey q;
+        int tap;
+        g.dCout.divmod(k, tap, q.co);
+        dKWs.divmod(tap, q.a, q.b);
+        q.ok = k < k_end;
+        return q;
+    }
+    HAB_HD ARaw a_fetch(const ACtx& c, const KCtx&, const AKey& q) const {
+        const int h = c.hq - q.a, w_ = c.wq - q.b;
+        ARaw r;
+        r.ok = q.ok & ((unsigned)h < (unsigned)g.Ho) & ((unsigned)w_ < (unsigned)g.Wo);
+        r.v = ld4(c.base + (((h * g.Wo + w_) * g.Cout + q.co) & -r.ok));
+        return r;
+    }
+    HAB_HD BCtx b_ctx(int n) const {
+        BCtx c;
+        c.ok = n < N;
+        int pp, ci;
+        g.dC.divmod(c.ok ? n : 0, pp, ci);
+        const int ph = pp / g.stride, pw = pp - ph * g.stride;
+        c.row = w + (size_t)ci * Kfull + (ph * g.KW + pw) * g.Cout;
+        return c;
+    }
+    HAB_HD BKey b_key(const KCtx&, int k, int k_end) const {
+        BKey q;
+        int tap, co, a, b;
+        g.dCout.divmod(k, tap, co);
+        dKWs.divmod(tap, a, b);
+        q.koff = (g.stride * a * g.KW + g.stride * b) * g.Cout + co;
+        q.ok = k < k_end;
+        return q;
+    }
+    HAB_HD BRaw b_fetch(const BCtx& c, const KCtx&, const BKey& q) const {
+        BRaw r;
+        r.ok = c.ok & q.ok;
+        r.v = ld4(c.row + (q.koff & -r.ok));
+        return r;
+    }
+    HAB_PLAIN_CVT
     HAB_HD bool dma_ok() const { return (KHs * KWs <= 32) && (KWs < 32) && ((size_t)g.Ho * g.Wo * g.Cout * 4 * 64 < 0x7fffffffull); }
     HAB_HD DmaTile dma_a_tile(int m0) const {
         DmaTile t;

@@ -68,7 +68,10 @@ def test_full_minibatch_at_benchmark_shape_vs_oracle(workload, frames):
         assert rep["rmv_max_rel"] <= 1e-5, rep["rmv_max_rel"]
     bad = []
     for k, (elem, normw) in per.items():
-        deep = workload == "c3" and ("visual_encoder" in k)  # upstream of at least one of the ~1.5e9 ReLU decisions
+        # upstream of a ReLU / max-pool decision: the visual encoder and visual_fc (C3: ~1.5e9 sign bits, C2: ~3e8).  Which
+        # near-zero activations flip depends on the arithmetic path (fp32 MFMA / split-bf16 MFMA / the CPU's own blocking), a
+        # handful always do; their effect is accounted for below, where the oracle's decisions are injected
+        deep = ("visual_encoder" in k) or ("visual_fc" in k)
         if normw > (3e-2 if deep else 1e-4):
             bad.append((k, elem, normw))
     assert not bad, bad
