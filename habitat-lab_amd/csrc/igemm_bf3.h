@@ -116,7 +116,7 @@ __device__ __forceinline__ void bf3_store_run(const float (&x)[R], unsigned shor
 }
 
 template <class P, int TM, int TN, int WM, int WN>
-__global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const int k_per_split, float* __restrict__ partial, const int sign_schedule) {
+__global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const int k_per_split, float* __restrict__ partial, const int sign_schedule, const int nsplit) {
     using Cfg = IgemmBf3Cfg<P, TM, TN, WM, WN>;
     constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, KV = Cfg::KV;
     constexpr int A_UNITS = Cfg::A_UNITS, B_UNITS = Cfg::B_UNITS, A_TOTAL = Cfg::A_TOTAL, B_TOTAL = Cfg::B_TOTAL;
@@ -133,15 +133,30 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
 
     const int nt_m = cdiv(p.M, BM), nt_n = cdiv(p.N, BN);
     const int ntiles = nt_m * nt_n;
-    int tile;
-    {
+    int tile, kz;
+    if (nsplit == 1) {  // XCD-contiguous runs of M-tiles (igemm.h)
         const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, idx = b >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        kz = 0;
+    } else {
+        // Split-K (weight gradients: a handful of output tiles, hundreds of K slices).  All output tiles of ONE K slice read the same
+        // rows of both operands (the taps of a filter are shifted views of the same pixels), so they are placed on the same XCD, in
+        // consecutive dispatch slots: workgroups are dealt round-robin over the 8 XCDs, hence slice kz -> XCD kz % 8.  With the
+        // slices of a tile spread over all XCDs instead, every private L2 fetched the operands again: 2.5-5.6x the algorithmic HBM
+        // bytes, at ~4 TB/s -- the weight gradients were HBM-bound on re-reads (profiles/r02_c2_hbm_traffic_before_xcd_slices.txt).
+        if (nsplit >= 16) {
+            const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+            tile = slot % ntiles;
+            kz = (slot / ntiles) * 8 + xcd;
+            if (kz >= nsplit) return;
+        } else {  // few slices: grouping would leave XCDs idle
+            tile = blockIdx.x % ntiles;
+            kz = blockIdx.x / ntiles;
+        }
     }
     const int tile_n = tile % nt_n, tile_m = tile / nt_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int kz = blockIdx.z;
     const int k_begin = kz * k_per_split;
     const int k_end = min(p.K, k_begin + k_per_split);
     const int ntk = max(0, cdiv(k_end - k_begin, BK));
@@ -332,7 +347,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
     if (flip_all) negate_acc();
 
     // ---- epilogue: identical to igemm_kernel's (same accumulator layout) ----
-    const bool split = gridDim.z > 1;
+    const bool split = nsplit > 1;
     if constexpr (CS) {
         if (do_cs) {  // block-uniform: column c = the BKQ units of column quad c >> 2, summed in unit order through LDS
             float* red = reinterpret_cast<float*>(smem16);
@@ -405,9 +420,10 @@ inline int igemm_bf3_launch(const P& p, float* ws, size_t ws_floats, int target_
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid(cdiv(p.M, Cfg::BM) * cdiv(p.N, Cfg::BN), 1, pl.splits);
+    const int ntiles = cdiv(p.M, Cfg::BM) * cdiv(p.N, Cfg::BN);
+    const int grid = pl.splits >= 16 ? ntiles * ((pl.splits + 7) / 8 * 8) : ntiles * pl.splits;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");  // development: measure the cost of the sign schedule
-    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, pl.k_per_split, ws, sign_schedule);
+    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, pl.k_per_split, ws, sign_schedule, pl.splits);
     HAB_LAUNCH_CHECK();
     if (pl.splits > 1) {
         igemm_splitk_reduce<P>(p, ws, pl.splits, stream);
