@@ -651,6 +651,11 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
         gp.put(cur);
         gp.put(add_ptr);
         d_out = d_in;
+        // DD-PPO buckets: the stages finish last-to-first and layer4 + compression hold ~3/4 of the convolution stack's bytes, so the
+        // arena tail is extended when layer4 and when layer3 are done; their all-reduces overlap the backward of the earlier stages
+        // (large activations, few parameters).  layer2, layer1 and the stem go with the final message.
+        if (bi == r->nlayers[0] + r->nlayers[1] + r->nlayers[2] || bi == r->nlayers[0] + r->nlayers[1])
+            grad_tail_ready(e, r->convs[blk.convs[0]].i_w);
     }
     // maxpool + stem
     float* d_n0 = W + r->w_gstem[0];

@@ -2,10 +2,12 @@
 
 The reference wraps `evaluate_actions` in DistributedDataParallel so that backward all-reduces ~60-170
 parameter tensors in 25 MiB buckets, overlapped with the rest of backward.  Here every gradient already lives in
-ONE flat fp32 arena and the overlap needs exactly two messages: the engine reports (`hab_policy_set_grad_ready`)
-when the TAIL of the arena -- visual fc, recurrent encoder, heads: 99.5 % of the SimpleCNN policy's bytes, 63 % of
-ResNet18's -- is final, which is BEFORE the convolution stack's backward starts; that range is all-reduced
-asynchronously on RCCL's stream while the convolutions run, and the small head of the arena follows after backward.
+ONE flat fp32 arena, backward fills it from the end, and the overlap needs two to four messages: the engine reports
+(`hab_policy_set_grad_ready`) each time a longer TAIL of the arena is final -- first visual fc + recurrent encoder + heads
+(99.5 % of the SimpleCNN policy's bytes, 63 % of ResNet18's), BEFORE the convolution stack's backward starts; for the ResNets
+again when layer4 (+ compression: 28 % of ResNet18) and when layer3 (7 %) are done.  Each new segment is all-reduced
+asynchronously on RCCL's stream while the earlier stages' backward runs, and the small head of the arena (layer2, layer1,
+stem: 2 %) follows after backward.
 The 1/world_size is folded into the fused clip+Adam kernel (`grad_scale`); the initial weight broadcast (DDP ctor)
 is one broadcast of the parameter arena.  HAB_NO_GRAD_OVERLAP=1 restores the single blocking all-reduce."""
 from __future__ import annotations
@@ -40,13 +42,17 @@ class DecentralizedDistributedMixin:
                     view.mul_(scale)
 
             eng.set_allreduce(_avg, world)
-        self._grad_work = None  # (work handle, first) of the early all-reduce of grads_flat[first:]
+        self._grad_works = []      # handles of the early all-reduces of this backward
+        self._grad_first = None    # grads_flat[_grad_first:] is covered by them
         overlap = (world > 1 and os.environ.get("HAB_NO_GRAD_OVERLAP") is None) or os.environ.get("HAB_FORCE_GRAD_OVERLAP") is not None
         if overlap and hasattr(eng, "set_grad_ready"):
             def _tail_ready(first: int, count: int) -> None:
                 g = eng.grads_flat
                 assert first + count == g.numel()
-                self._grad_work = (distrib.all_reduce(g[first:], async_op=True), first)
+                end = g.numel() if self._grad_first is None else self._grad_first
+                assert first < end, "the engine reports growing tails"
+                self._grad_works.append(distrib.all_reduce(g[first:end], async_op=True))
+                self._grad_first = first
 
             eng.set_grad_ready(_tail_ready)
         self._distributed = True
@@ -55,15 +61,16 @@ class DecentralizedDistributedMixin:
         if not distrib.is_initialized():
             return
         g = self.actor_critic.engine.grads_flat
-        pending, self._grad_work = getattr(self, "_grad_work", None), None
-        if pending is None:
+        works, first = getattr(self, "_grad_works", []), getattr(self, "_grad_first", None)
+        self._grad_works, self._grad_first = [], None
+        if first is None:
             if distrib.get_world_size() > 1:
                 distrib.all_reduce(g)
             return
-        work, first = pending
         if first > 0:
-            distrib.all_reduce(g[:first])  # the convolution stack's gradients, produced after the tail
-        work.wait()                        # the current stream now waits for the early all-reduce
+            distrib.all_reduce(g[:first])  # the head of the arena, produced after the last reported tail
+        for w in works:
+            w.wait()                       # the current stream now waits for the early all-reduces
 
     def _all_reduce_scalar_stats(self, t: torch.Tensor) -> None:
         if distrib.is_initialized() and distrib.get_world_size() > 1:

@@ -58,11 +58,14 @@ def _worker(rank, world, port, q):
     upd.actor_critic.engine.allreduce(stats, 1.0 / world)
     assert torch.allclose(stats, torch.full((8,), (world + 1) / 2.0)) and upd.actor_critic.engine.world == world
     g_first = upd.actor_critic.engine.grads_flat
-    # early exchange: the engine reports the tail [700, 1000) mid-backward, the head follows in _all_reduce_grads
+    # early exchange: the engine reports growing tails mid-backward -- [700, 1000), then [400, 1000) (a ResNet stage finished) --
+    # each new segment is all-reduced at once; the head [0, 400) follows in _all_reduce_grads
     upd.actor_critic.engine.grad_ready(700, 300)
-    assert upd._grad_work is not None and upd._grad_work[1] == 700
+    assert len(upd._grad_works) == 1 and upd._grad_first == 700
+    upd.actor_critic.engine.grad_ready(400, 600)
+    assert len(upd._grad_works) == 2 and upd._grad_first == 400
     DecentralizedDistributedMixin._all_reduce_grads(upd)
-    assert upd._grad_work is None
+    assert upd._grad_works == [] and upd._grad_first is None
     g_reduced = g_first.clone()
     # a backward that never reports (e.g. a policy without the hook) falls back to the single all-reduce
     g2 = torch.full((1000,), float(rank + 1))
