@@ -6,6 +6,7 @@
 #include "igemm_bf3.h"
 #include "obs_conv_bf3.h"
 #include "obs_wgrad_bf3.h"
+#include "conv_patch_bf3.h"
 #include "wgrad3x3_patch.h"
 #include "prob_build.h"
 #include <stdlib.h>
@@ -22,10 +23,11 @@ static bool no_merged_dgrad() { static const bool v = hab_env_flag("HAB_NO_MERGE
 static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); return v; }
 // split-bf16 matrix-pipe path (igemm_bf3.h) for the r-contiguous x r-contiguous contractions
 // bit 0: r-contiguous x r-contiguous problems, bit 1: observation-ingest convolution (obs_conv_bf3.h), bit 2: problems with an
-// i/j-contiguous operand (weight gradients, Linear data gradient)
+// i/j-contiguous operand (weight gradients, Linear data gradient), bit 3: prefer it over the fp32 patch / DMA weight-gradient kernels,
+// bit 4: input-patch-resident stride-1 3x3 convolutions (conv_patch_bf3.h)
 static int g_bf3_mode = -1;
 static int bf3_mode() {
-    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 15);
+    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 31);
     return g_bf3_mode;
 }
 extern "C" int hab_set_matrix_path(int mode) {
@@ -100,6 +102,13 @@ int conv_fwd(const ConvDesc& d, const float* x, const float* wf, const float* bi
              size_t ws_floats, hipStream_t stream) {
     ConvFwdProb p;
     HAB_TRY(build(p, d, x, wf, bias, y, relu));
+    if ((bf3_mode() & 16) && d.stride == 1 && d.KH == 3 && d.KW == 3 && p.M > 64) {  // input patch resident in LDS (conv_patch_bf3.h)
+        PatchGeom gq{};
+        gq.in = x; gq.Hi = d.H; gq.Wi = d.W; gq.Ci = d.C; gq.Ho = p.g.Ho; gq.Wo = p.g.Wo; gq.KH = 3; gq.KW = 3;
+        gq.off_h = -d.pad; gq.off_w = -d.pad; gq.flip = 0;
+        const int rc = conv_patch_bf3_dispatch(p, gq, ws, ws_floats, stream);
+        if (rc != 1) return rc;
+    }
     return run_igemm(p, ws, ws_floats, stream);
 }
 int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const float* bias, float* y, int relu, float* ws,
@@ -150,6 +159,14 @@ int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float*
             ConvDgradProb p;
             HAB_TRY(build(p, d, dy, wd, mask, add, dx, ph, pw));
             if (p.Hc <= 0 || p.Wc <= 0) continue;
+            if ((bf3_mode() & 16) && d.stride == 1 && d.KH == 3 && d.KW == 3 && p.M > 64 && p.K > 0) {  // conv_patch_bf3.h, taps flipped
+                PatchGeom gq{};
+                gq.in = dy; gq.Hi = p.g.Ho; gq.Wi = p.g.Wo; gq.Ci = d.Cout; gq.Ho = d.H; gq.Wo = d.W; gq.KH = 3; gq.KW = 3;
+                gq.off_h = d.pad - 2; gq.off_w = d.pad - 2; gq.flip = 1;
+                const int rc = conv_patch_bf3_dispatch(p, gq, ws, ws_floats, stream);
+                if (rc == HAB_OK) continue;
+                if (rc != 1) return rc;
+            }
             if (p.K <= 0) {
                 p.M = d.B * p.Hc * p.Wc;
                 dgrad_empty_class_kernel<<<1024, 256, 0, stream>>>(p);
