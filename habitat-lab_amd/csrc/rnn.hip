@@ -73,6 +73,26 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
     const float keep = (a.row_mask && !a.row_mask[q]) ? 0.f : 1.f;  // h * mask (rnn_state_encoder.py:308-311), applied to the operand
     const int kq = H / NW;  // per-wave K range (multiple of 16)
     const int kb = wave * kq;
+    // Gate-phase operands of this thread's (row, unit) element -- frame index, input projection, previous state, bias: they do not
+    // depend on the mat-vec, so their two dependent L2 round trips (index, then data) run underneath it instead of after it.
+    const int r_ = t >> 4, u_ = t & 15, qq_ = row0 + r_;
+    const bool gate_thread = (t < 256) & (qq_ < a.R);
+    int f_pre = 0;
+    float hp_pre = 0.f, cp_pre = 0.f, gi_pre[G], bhh_pre[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { gi_pre[g] = 0.f; bhh_pre[g] = 0.f; }
+    if (gate_thread) {
+        f_pre = a.out_idx ? a.out_idx[qq_] : qq_;
+        const bool kept_ = !(a.row_mask && !a.row_mask[qq_]);
+        const size_t prow_ = (size_t)(a.hp_idx ? a.hp_idx[qq_] : qq_);
+        hp_pre = kept_ ? a.hp_base[prow_ * a.hp_stride + u0 + u_] : 0.f;
+        if constexpr (G == 4) cp_pre = kept_ ? a.cp_base[(size_t)(a.cp_idx ? a.cp_idx[qq_] : qq_) * a.cp_stride + u0 + u_] : 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            gi_pre[g] = a.gi[(size_t)f_pre * G * H + g * H + u0 + u_];
+            bhh_pre[g] = a.b_hh[g * H + u0 + u_];
+        }
+    }
     f32x4 acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) { acc[g][0] = 0.f; acc[g][1] = 0.f; acc[g][2] = 0.f; acc[g][3] = 0.f; }
@@ -123,17 +143,15 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; w += 4) sum += (red[w][g][t] + red[w + 1][g][t]) + (red[w + 2][g][t] + red[w + 3][g][t]);
-        gh[g] = sum + a.b_hh[g * H + u0 + u];
+        gh[g] = sum + bhh_pre[g];
     }
-    const int f = a.out_idx ? a.out_idx[qq] : qq;
+    const int f = f_pre;
     const int uu = u0 + u;
-    const bool kept = !(a.row_mask && !a.row_mask[qq]);
-    const float hp = kept ? a.hp_base[(size_t)(a.hp_idx ? a.hp_idx[qq] : qq) * a.hp_stride + uu] : 0.f;
-    const float* gi = a.gi + (size_t)f * G * H;
+    const float hp = hp_pre;
     if constexpr (G == 3) {
-        const float rg = sigmoidf_(gi[uu] + gh[0]);
-        const float zg = sigmoidf_(gi[H + uu] + gh[1]);
-        const float ng = tanhf(gi[2 * H + uu] + rg * gh[2]);
+        const float rg = sigmoidf_(gi_pre[0] + gh[0]);
+        const float zg = sigmoidf_(gi_pre[1] + gh[1]);
+        const float ng = tanhf(gi_pre[2] + rg * gh[2]);
         const float hnew = (1.0f - zg) * ng + zg * hp;
         a.out[(size_t)f * a.out_stride + uu] = hnew;
         if (a.gates) {
@@ -143,11 +161,11 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
             a.hprev[(size_t)f * H + uu] = hp;
         }
     } else {
-        const float cp = kept ? a.cp_base[(size_t)(a.cp_idx ? a.cp_idx[qq] : qq) * a.cp_stride + uu] : 0.f;
-        const float ig = sigmoidf_(gi[uu] + gh[0]);
-        const float fg = sigmoidf_(gi[H + uu] + gh[1]);
-        const float gg = tanhf(gi[2 * H + uu] + gh[2]);
-        const float og = sigmoidf_(gi[3 * H + uu] + gh[3]);
+        const float cp = cp_pre;
+        const float ig = sigmoidf_(gi_pre[0] + gh[0]);
+        const float fg = sigmoidf_(gi_pre[1] + gh[1]);
+        const float gg = tanhf(gi_pre[2] + gh[2]);
+        const float og = sigmoidf_(gi_pre[3] + gh[3]);
         const float cn = fg * cp + ig * gg;
         const float hnew = og * tanhf(cn);
         a.out[(size_t)f * a.out_stride + uu] = hnew;
@@ -248,6 +266,26 @@ __global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs
     const int row0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
     const int H = a.H;
     const bool has_carry = row0 < a.R_next;  // workgroup-uniform
+    // gate-phase operands of this thread's (row, unit) element, fetched underneath the carry mat-vec (see rnn_step_kernel)
+    const int r_ = t >> 4, uu_ = u0 + (t & 15), q_ = row0 + r_;
+    const bool gate_thread = (t < 256) & (q_ < a.R);
+    int f_pre = 0;
+    float dout_pre = 0.f, dhd_pre = 0.f, dcc_pre = 0.f, gs_pre[G], hp_pre = 0.f, hn_pre = 0.f, cn_pre = 0.f, cp_pre = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) gs_pre[g] = 0.f;
+    if (gate_thread) {
+        f_pre = a.idx[q_];
+        const size_t qo_ = (size_t)q_ * H + uu_, fo_ = (size_t)f_pre * H + uu_;
+        dout_pre = a.dout[fo_];
+        if (q_ < a.R_next) {
+            if constexpr (G == 3) dhd_pre = a.dh_direct[qo_];
+            else dcc_pre = a.dc_carry[qo_];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) gs_pre[g] = a.gates[(size_t)f_pre * G * H + g * H + uu_];
+        if constexpr (G == 3) { hp_pre = a.hprev[fo_]; hn_pre = a.hn[fo_]; }
+        else { cn_pre = a.c[fo_]; cp_pre = a.cprev[fo_]; }
+    }
     if (has_carry) {
         const int i = lane & 15, kg = lane >> 4;
         const int q = min(row0 + i, a.R_next - 1);
@@ -284,20 +322,19 @@ __global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs
     if (t >= 256) return;
     const int r = t >> 4, uu = u0 + (t & 15), q = row0 + r;
     if (q >= a.R) return;
-    const int f = a.idx[q];
-    const size_t qo = (size_t)q * H + uu, fo = (size_t)f * H + uu;
-    float dh = a.dout[fo];
+    const int f = f_pre;
+    const size_t qo = (size_t)q * H + uu;
+    float dh = dout_pre;
     if (q < a.R_next) {
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; w += 4) sum += (red[w][t] + red[w + 1][t]) + (red[w + 2][t] + red[w + 3][t]);
         dh += sum;
-        if constexpr (G == 3) dh += a.dh_direct[qo];
+        if constexpr (G == 3) dh += dhd_pre;
     }
     if constexpr (G == 3) {
-        const float* gs = a.gates + (size_t)f * 3 * H;
-        const float rg = gs[uu], z = gs[H + uu], n = gs[2 * H + uu];
-        const float hp = a.hprev[fo], hn = a.hn[fo];
+        const float rg = gs_pre[0], z = gs_pre[1], n = gs_pre[2];
+        const float hp = hp_pre, hn = hn_pre;
         const float dn = dh * (1.0f - z);
         const float dz = dh * (hp - n);
         const float dn_pre = dn * (1.0f - n * n);
@@ -310,12 +347,11 @@ __global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs
         gh[uu] = dr_pre; gh[H + uu] = dz_pre; gh[2 * H + uu] = dn_pre * rg;
         a.dh_direct[qo] = dh * z;
     } else {
-        const float* gs = a.gates + (size_t)f * 4 * H;
-        const float ig = gs[uu], fg = gs[H + uu], gg = gs[2 * H + uu], og = gs[3 * H + uu];
-        const float cn = a.c[fo], cp = a.cprev[fo];
+        const float ig = gs_pre[0], fg = gs_pre[1], gg = gs_pre[2], og = gs_pre[3];
+        const float cn = cn_pre, cp = cp_pre;
         const float tc = tanhf(cn);
         float dc = dh * og * (1.0f - tc * tc);
-        if (q < a.R_next) dc += a.dc_carry[qo];
+        if (q < a.R_next) dc += dcc_pre;
         const float d_o = dh * tc;
         const float di = dc * gg, dg = dc * ig, df = dc * cp;
         float* gi = a.dgi + (size_t)f * 4 * H;
