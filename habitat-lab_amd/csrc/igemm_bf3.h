@@ -89,7 +89,14 @@ struct IgemmBf3Cfg {
     static constexpr int B_TOTAL = P::B_RC ? BN * BK / 4 : (BN / 4) * BKQ;
     static constexpr int A_UNITS = (A_TOTAL + NT - 1) / NT, B_UNITS = (B_TOTAL + NT - 1) / NT;
     static constexpr int A_RAWS = P::A_RC ? 1 : RA, B_RAWS = P::B_RC ? 1 : RB;
-    static constexpr size_t LDS_BYTES = (size_t)3 * (A_PLANE + B_PLANE) * 2;
+    // both operands i/j-contiguous (weight gradients): the per-k gather keys (pixel decode: two divisions + 64-bit offsets, ~30 VALU
+    // each) are the same for every row unit, so each k-tile's BK keys are computed ONCE per workgroup into LDS (two buffers) instead
+    // of R times per thread
+    // (measured: +5..13 % on the N >= 64 weight gradients; the 32-column tiles lose 6 % to the extra LDS traffic and stay as they were)
+    static constexpr bool KSH = !P::A_RC && !P::B_RC && (TN * WN >= 2);
+    static constexpr size_t PLANES_BYTES = (size_t)3 * (A_PLANE + B_PLANE) * 2;
+    static constexpr size_t KEYS_BYTES = KSH ? (size_t)2 * BK * (sizeof(typename P::AKey) + sizeof(typename P::BKey)) : 0;
+    static constexpr size_t LDS_BYTES = PLANES_BYTES + KEYS_BYTES;
     static_assert(!P::A_RC || NT % (BK / KV) == 0, "A unit mapping");
     static_assert(!P::B_RC || NT % (BK / 4) == 0, "B unit mapping");
     static_assert(BM % KV == 0, "A rows per unit");
@@ -125,6 +132,9 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     unsigned short* As = smem16;                        // planes 0..2: [BM][BF3_BKP]
     unsigned short* Bs = smem16 + 3 * Cfg::A_PLANE;     // planes 0..2: [BN][BF3_BKP]
+
+    typename P::AKey* akeys = reinterpret_cast<typename P::AKey*>(reinterpret_cast<char*>(smem16) + Cfg::PLANES_BYTES);  // [2][BK]
+    typename P::BKey* bkeys = reinterpret_cast<typename P::BKey*>(akeys + 2 * BK);                                       // [2][BK]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -194,6 +204,15 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
         const int u = t + NT * j;
         return k_begin + kt * BK + (P::B_RC ? (u & 7) * 4 : (u % BKQ) * RB + r);
     };
+    auto make_keys = [&](int kt) {  // Cfg::KSH: keys of k-tile kt into key buffer kt & 1 (visible after the next barrier)
+        if constexpr (Cfg::KSH) {
+            if (t < BK) {
+                const typename P::KCtx kc = p.k_ctx(k_begin + kt * BK, k_end);
+                akeys[(kt & 1) * BK + t] = p.a_key(kc, k_begin + kt * BK + t, k_end);
+                bkeys[(kt & 1) * BK + t] = p.b_key(kc, k_begin + kt * BK + t, k_end);
+            }
+        }
+    };
     auto fetch = [&](int kt) {
         const typename P::KCtx kc = p.k_ctx(k_begin + kt * BK, k_end);
         if constexpr (P::A_RC) {
@@ -207,7 +226,10 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
                 // NT % AKQ == 0 is not required: the key depends on the unit
 #pragma unroll
                 for (int j = 0; j < A_UNITS; ++j)
-                    if (A_TOTAL % NT == 0 || t + NT * j < A_TOTAL) araw[j][r] = p.a_fetch(actx[j], kc, p.a_key(kc, a_k(kt, j, r), k_end));
+                    if (A_TOTAL % NT == 0 || t + NT * j < A_TOTAL) {
+                        if constexpr (Cfg::KSH) araw[j][r] = p.a_fetch(actx[j], kc, akeys[(kt & 1) * BK + ((t + NT * j) % AKQ) * RA + r]);
+                        else araw[j][r] = p.a_fetch(actx[j], kc, p.a_key(kc, a_k(kt, j, r), k_end));
+                    }
             }
         }
         if constexpr (P::B_RC) {
@@ -220,7 +242,10 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
             for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int j = 0; j < B_UNITS; ++j)
-                    if (B_TOTAL % NT == 0 || t + NT * j < B_TOTAL) braw[j][r] = p.b_fetch(bctx[j], kc, p.b_key(kc, b_k(kt, j, r), k_end));
+                    if (B_TOTAL % NT == 0 || t + NT * j < B_TOTAL) {
+                        if constexpr (Cfg::KSH) braw[j][r] = p.b_fetch(bctx[j], kc, bkeys[(kt & 1) * BK + ((t + NT * j) % BKQ) * RB + r]);
+                        else braw[j][r] = p.b_fetch(bctx[j], kc, p.b_key(kc, b_k(kt, j, r), k_end));
+                    }
         }
     };
     auto stage = [&](int kt, const unsigned sgn) {  // registers -> split -> three bf16 planes; sgn = 0x80000000: B enters negated
@@ -308,8 +333,12 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = -acc[i][j][v];
     };
-    if (ntk > 0) fetch(0);
+    if (ntk > 0) {
+        if constexpr (Cfg::KSH) { make_keys(0); __syncthreads(); }
+        fetch(0);
+    }
     for (int kt = 0; kt < ntk; ++kt) {
+        if (kt + 1 < ntk) make_keys(kt + 1);  // other key buffer: read by fetch(kt + 1) behind the barrier below
         stage(kt, sgn);
         __syncthreads();
         if (kt + 1 < ntk) fetch(kt + 1);
