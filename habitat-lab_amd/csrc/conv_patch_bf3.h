@@ -209,11 +209,11 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_patch_bf3_kernel(const P p, 
         const int vb_next = vb + gridDim.x;
         const bool more = vb_next < ntiles;
 
-        f32x16 acc[TN];
+        f32x16 acc[TN], acc2[TN], tot[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[j][v] = 0.0f;
+            for (int v = 0; v < 16; ++v) { acc[j][v] = 0.0f; acc2[j][v] = 0.0f; tot[j][v] = 0.0f; }
 
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             fetch_b(n0, chunk, 0, flip_all);
@@ -243,26 +243,39 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_patch_bf3_kernel(const P p, 
                         for (int pl = 0; pl < 3; ++pl) bf[buf][j][pl] = *reinterpret_cast<const bf16x8*>(src + pl * Cfg::B_PLANE);
                     }
                 };
-                load_group(0, 0);
+                // Two accumulators, alternating MFMA by MFMA (groups g, g + 1 side by side).  Every MFMA rounds its accumulator to fp32;
+                // six back-to-back updates of ONE accumulator per k-group measured 2.7x the rounding noise of the im2col kernel,
+                // which interleaves two output tiles -- so this kernel interleaves two k-groups.  Summed before the epilogue.
+                static_assert(NG % 2 == 0, "pairs of k-groups");
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g + 1 < NG) load_group(g + 1, (g + 1) & 1);
+                for (int g = 0; g < NG; g += 2) {
+                    load_group(g, 0);
+                    load_group(g + 1, 1);
                     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
                     for (int q = 0; q < 6; ++q)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g & 1][j][PB[q]], af[g & 1][PA[q]], acc[j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) {
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0][j][PB[q]], af[0][PA[q]], acc[j], 0, 0, 0);
+                            acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1][j][PB[q]], af[1][PA[q]], acc2[j], 0, 0, 0);
+                        }
                 }
                 __syncthreads();
             }
-        }
-        if (flip_all) {
+            // per 32-channel chunk the two MFMA chains (54 instructions each) are folded into the running total with one fp32 add
+            // each: the chains stay short whatever Cin is
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[j][v] = -acc[j][v];
+                for (int v = 0; v < 16; ++v) {
+                    tot[j][v] += acc[j][v] + acc2[j][v];
+                    acc[j][v] = 0.0f; acc2[j][v] = 0.0f;
+                }
         }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][v] = flip_all ? -tot[j][v] : tot[j][v];
         // ---- epilogue of the problem (transposed accumulator: lane = output pixel, register quad = 4 consecutive channels) ----
         {
             const int img = tile_m / gq.tiles_per_img, ho = (tile_m - img * gq.tiles_per_img) * TH + ty;
@@ -309,8 +322,9 @@ inline int conv_patch_bf3_launch(const P& p, PatchGeom gq, float* ws, size_t ws_
     int grid = 256 * (occ > 0 ? occ : 1);
     if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
     // weights as bf16 planes once per call when the launch is large enough to pay for the extra kernel
+    static const int pre_min = hab_env_int("HAB_CPB_PRE_MIN", 131072);
     const size_t wn_elems = cpb_w_elems(p);
-    const bool pre = ws && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0) && ws_floats * 4 >= wn_elems * 12 && p.M >= 131072 && (wn_elems % 4 == 0);
+    const bool pre = ws && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0) && ws_floats * 4 >= wn_elems * 12 && p.M >= pre_min && (wn_elems % 4 == 0);
     hipError_t e = hipSuccess;
     if (pre) {
         auto kern = conv_patch_bf3_kernel<P, TW, WM, WN, TN, BT, true>;

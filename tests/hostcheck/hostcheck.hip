@@ -159,6 +159,10 @@ extern "C" int hc_conv2d_dgrad_dma(const float* dy, const float* wd, const float
         if (!ConvDgradMergedProb::applicable(q.g)) return -2;
         q.dy = dy; q.w = wd; q.mask = mask; q.add = add; q.dx = dx;
         q.finish();
+        if (merged == 2) {  // register-staged interface of the merged problem (the split-bf16 kernel's gathers)
+            host_igemm(q);
+            return 0;
+        }
         if (!q.dma_ok()) return -1;
         host_dma_igemm(q, 128, 128);
         return 0;

@@ -203,3 +203,39 @@ def test_linear_dgrad_wgrad_bf3_as_accurate_as_fp32_path(L):
     for ref, y0, y1 in ((ref_dx, dx0, dx1), (ref_dw, dw0, dw1)):
         e0, e1 = err_vs(ref, y0), err_vs(ref, y1)
         assert e1 <= 2 * e0 + 2e-7, (e0, e1)
+
+
+@pytest.mark.parametrize("B,H,W,Cc,Cout,p", [(5, 32, 32, 32, 32, 1), (3, 30, 30, 64, 32, 0), (7, 16, 16, 32, 32, 1), (2, 21, 19, 32, 32, 1),
+                                            (130, 32, 32, 32, 32, 1)])
+def test_patch_resident_conv_fwd_dgrad_as_accurate_as_fp32_path(L, B, H, W, Cc, Cout, p):
+    """conv_patch_bf3.h (stride-1 3x3, N = 32): forward with bias + ReLU and data gradient with residual add + ReLU mask against
+    float64, incl. tiles that run over the image's last rows (H % 4 != 0), idle columns (W < 32) and > 131072 rows (pre-split weights)."""
+    torch.manual_seed(8)
+    x = torch.randn(B, Cc, H, W) * torch.rand(B, Cc, H, W).pow(3) * 20
+    w = torch.randn(Cout, Cc, 3, 3) / np.sqrt(Cc * 9)
+    b = torch.randn(Cout)
+    xd64 = x.double().requires_grad_()
+    pre = F.conv2d(xd64, w.double(), b.double(), stride=1, padding=p)
+    ref_y = F.relu(pre).permute(0, 2, 3, 1)
+    Ho, Wo = pre.shape[2:]
+    dy = torch.randn(B, Cout, Ho, Wo)
+    pre.backward(dy.double())
+    mask, add = torch.randn(B, H, W, Cc), torch.randn(B, H, W, Cc)
+    ref_dx = (xd64.grad.permute(0, 2, 3, 1) + add.double()) * (mask > 0)
+    xn, dyn = x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda()
+    wf, wdg, bd = w.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(1, 2, 3, 0).contiguous().cuda(), b.cuda()
+    md, ad = mask.cuda(), add.cuda()
+    ws = torch.zeros(1 << 22, device="cuda")
+
+    def run():
+        y = torch.zeros(B, Ho, Wo, Cout, device="cuda")
+        dx = torch.full((B, H, W, Cc), 7.0, device="cuda")
+        _lib.check(L.hab_conv2d_fwd(P(xn), P(wf), P(bd), P(y), B, H, W, Cc, Cout, 3, 3, 1, p, 1, P(ws), ws.numel(), S()))
+        _lib.check(L.hab_conv2d_dgrad(P(dyn), P(wdg), P(md), P(ad), P(dx), B, H, W, Cc, Cout, 3, 3, 1, p, P(ws), ws.numel(), S()))
+        return y, dx
+
+    (y0, dx0), (y1, dx1) = both_paths(L, run, 16)
+    for ref, a0, a1 in ((ref_y, y0, y1), (ref_dx, dx0, dx1)):
+        e0, e1 = err_vs(ref, a0), err_vs(ref, a1)
+        assert e1 <= 2 * e0 + 2e-7, (e0, e1)
+        assert e1 < 3e-6

@@ -208,7 +208,7 @@ def test_dma_staged_functors_on_host(hc, B, H, W, Cc, Cout, K, s, p):
     dy_pre = nhwc(gy * (y_ref > 0))
     m, add = torch.randn(B, H, W, Cc), torch.randn(B, H, W, Cc)
     ref = (nhwc(x.grad) + add) * (m > 0)
-    for merged in (0, 1):
+    for merged in (0, 1, 2):  # 2: the merged problem through its register-staged functors (igemm_bf3.h path)
         dx = torch.full((B, H, W, Cc), 7.0)  # every element must be written
         rc = hc.hc_conv2d_dgrad_dma(P(dy_pre), P(wd), P(m), P(add), P(dx), B, H, W, Cc, Cout, K, K, s, p, merged)
         if merged and (K % s != 0 or s == 1):
