@@ -79,7 +79,7 @@ C2_TABLE = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_wgrad", "fc_dgr
 PROBE_KERNELS = {"conv2_dgrad": "igemm_bf3_kernel<ConvDgradMergedProb", "conv1_fwd": "obs_conv_bf3_kernel",
                  "conv1_wgrad": "obs_wgrad_bf3_kernel", "conv2_wgrad": "igemm_bf3_kernel<ConvWgradProb, 1, 2",
                  "conv3_wgrad": "igemm_bf3_kernel<ConvWgradProb, 1, 1", "conv2_fwd": "igemm_bf3_kernel<ConvFwdProb, 1, 2",
-                 "conv3_fwd": "igemm_bf3_kernel<ConvFwdProb, 2, 1", "conv3_dgrad": "igemm_bf3_kernel<ConvDgradProb",
+                 "conv3_fwd": "conv_patch_bf3_kernel<ConvFwdProb", "conv3_dgrad": "igemm_bf3_kernel<ConvDgradProb",
                  "fc_fwd": "igemm_bf3_kernel<LinearFwdProb, 2, 2", "fc_dgrad": "igemm_bf3_kernel<LinearDgradProb",
                  "fc_wgrad": "igemm_bf3_kernel<LinearWgradProb"}
 # Roofline model of a contraction call site on the split-bf16 matrix path (csrc/igemm_bf3.h): (algorithmic HBM bytes per frame:

@@ -5,6 +5,7 @@
 #   * --pmc passes, counters only, each in its own run (MI355X_MICROARCH.md):
 #       FETCH_SIZE, WRITE_SIZE (C2 and C3)            -> tools/pmc_traffic.py -> HBM bytes per launch
 #       SQ busy / MFMA-busy / wait / instruction mix  -> tools/pmc_sq.py      -> per-kernel matrix-pipe utilisation (C2)
+# Every profiler pass runs under `timeout`: a rocprofv3 --pmc pass of the C3 command once hung until gpurun's limit.
 # usage: tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>_*   (copy what is to be judged into profiles/)
 set -u
 TAG=${1:-r02}
@@ -18,7 +19,7 @@ python bench.py --workload c5 --steps 3 --warmup 1 > $O/${TAG}_c5_bench.json 2> 
 cd /tmp
 for W in c2 c3 c5; do
   rm -rf /tmp/prof_${TAG}_$W
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_$W -o $W -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_${TAG}_$W.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_$W -o $W -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_${TAG}_$W.log 2>&1
   DB=$(ls /tmp/prof_${TAG}_$W/*results.db /tmp/prof_${TAG}_$W/*/*results.db 2>/dev/null | head -1)
   python $R/tools/rocprof_summary.py $DB $O/${TAG}_${W}_kernel_stats.txt > /dev/null
   python $R/tools/trace_phases.py $DB $O/${TAG}_${W}_phases.txt > /dev/null
@@ -28,7 +29,7 @@ done
 for W in c2 c3; do
   rm -rf /tmp/pmc_${TAG}_$W
   for PM in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $PM --kernel-trace -d /tmp/pmc_${TAG}_$W -o $PM --output-format csv -- python $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+    timeout 300 rocprofv3 --pmc $PM --kernel-trace -d /tmp/pmc_${TAG}_$W -o $PM --output-format csv -- python $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   done
   python $R/tools/pmc_traffic.py /tmp/pmc_${TAG}_$W $O/${TAG}_${W}_hbm_traffic.json $O/${TAG}_${W}_hbm_traffic.txt
   rm -rf /tmp/pmc_${TAG}_$W
