@@ -123,9 +123,6 @@ HAB_HD f32x4 splat4(float x) { f32x4 z; z[0] = x; z[1] = x; z[2] = x; z[3] = x; 
 // ----------------------------------------------------------------------------------------------
 // Convolution forward: Y[(img,ho,wo)][co] = sum_{kh,kw,ci} X[img, ho*s-p+kh, wo*s-p+kw, ci] * Wf[co][(kh,kw,ci)]
 // Epilogue: + bias[co], optional ReLU.   (simple_cnn.py:68-93, resnet.py:19-34,207-219)
-// Optional loader-side affine + ReLU per (image, channel): x' = relu?(x * ss[img][ci][0] + ss[img][ci][1]) -- the
-// GroupNorm-apply of the producing layer fused into this conv's gather (resnet.py:51-57); zero padding
-// stays zero (it is applied to in-bounds taps only).
 // ----------------------------------------------------------------------------------------------
 struct ConvFwdProb {
     static constexpr bool A_RC = true, B_RC = true;

@@ -162,9 +162,14 @@ int hab_sample_actions(const float* probs, const float* exp_noise, int64_t* acti
  * Matrix path.  The contractions are fp32 in, fp32 out, fp32-equivalent arithmetic on either of two instruction paths:
  *   v_mfma_f32_32x32x2_f32 (igemm.h), or -- hab_set_matrix_path bits, env HAB_BF3 -- the exact three-term bf16 split of both
  *   operands with the six partial products >= 2^-16 on v_mfma_f32_32x32x16_bf16 (igemm_bf3.h; dropped terms <= 2^-24 relative):
- *     bit 0  r-contiguous x r-contiguous problems (conv fwd / dgrad, Linear fwd)
- *     bit 1  observation-ingest convolution (uint8 rgb is exact in ONE bf16 plane; obs_conv_bf3.h)
- *   hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one; mode < 0 only queries.
+ *     bit 0  r-contiguous x r-contiguous problems (conv fwd / dgrad incl. the merged stride-2 dgrad, Linear fwd)
+ *     bit 1  observation-ingest convolution, forward and weight gradient (uint8 rgb is exact in ONE bf16 plane; obs_conv_bf3.h,
+ *            obs_wgrad_bf3.h)
+ *     bit 2  problems with an i/j-contiguous operand (weight gradients, Linear dgrad): register-transposed staging
+ *     bit 3  prefer bit 2's kernel over the fp32 patch / LDS-DMA weight-gradient kernels
+ *     bit 4  stride-1 3x3 convolutions with N = 32 (fwd + dgrad): input patch resident in LDS (conv_patch_bf3.h)
+ *   Default 31 (all), env HAB_BF3 overrides.  hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one;
+ *   mode < 0 only queries.  Results are fp32-equivalent on either path (tests/test_gpu_bf3.py: error vs float64 of both).
  * ------------------------------------------------------------------------------------------- */
 int hab_set_matrix_path(int mode);
 int hab_conv2d_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int H, int W, int C, int Cout,
