@@ -317,7 +317,8 @@ def run_cycles(workload, steps, warmup):
     trainer.envs.close()
     rec = {"workload": WORKLOADS[workload]["name"], "value": round(n / dt, 1), "unit": "env-steps/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(dt / steps * 1e3, 2),
-           "frac_of_mfma_roofline": round(n / dt * 2.442e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if workload == "c3" else None}
+           "frac_of_mfma_roofline": round(n / dt * 2.2632e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if workload == "c3" else None,
+           "frac_basis": "executed contraction FLOPs (2.263 GFLOP per env-step: the stem's data gradient is not computed) / fp32 MFMA peak 157.3"}
     del trainer
     torch.cuda.empty_cache()
     return rec
@@ -449,8 +450,16 @@ def main():
                          frames_per_launch=round(frames / max(probe_cnt, 1), 1)),
     }
     if a.workload in ("c2", "c3"):
-        f_step = 2.365e9 if a.workload == "c2" else 2.442e9  # algorithmic FLOPs per env-step
-        out["roofline"]["whole_cycle_frac"] = round(steps_total / world / dt * f_step / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)
+        # FLOPs per env-step of the contractions that are EXECUTED: F = 2 MAC_fwd (1 + 1/T) + E (2 (3 MAC_fwd - MAC_first_dgrad)) -- the data
+        # gradient of the first convolution (wrt the observation) is never computed.  SURVEY.md 8(d)'s formula counts it (C2 2.365,
+        # C3 2.442 GFLOP); both are reported, priced against the fp32 MFMA peak (the round-1 yardstick) for comparability.
+        mac_fwd, mac_first, f_survey = (89.3e6, 32.5e6, 2.365e9) if a.workload == "c2" else (168.82e6, 25.69e6, 2.442e9)
+        f_exec = 2.0 * (mac_fwd * (1.0 + 1.0 / n_steps) + ppo.ppo_epoch * (3.0 * mac_fwd - mac_first))
+        rate = steps_total / world / dt
+        out["roofline"]["whole_cycle_frac"] = round(rate * f_exec / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)
+        out["roofline"]["whole_cycle"] = {"executed_gflop_per_env_step": round(f_exec / 1e9, 4), "tflops": round(rate * f_exec / 1e12, 2),
+                                          "frac_of_fp32_mfma_peak": out["roofline"]["whole_cycle_frac"],
+                                          "frac_with_survey_formula": round(rate * f_survey / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)}
     if a.workload == "c2":
         # per-call-site table from ONE extra cycle with every probe on (outside the timed region: ~1400 event records per cycle)
         tags = {k: PROBES[k] for k in C2_TABLE}
