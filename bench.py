@@ -460,8 +460,10 @@ def main():
         out["roofline"]["whole_cycle"] = {"executed_gflop_per_env_step": round(f_exec / 1e9, 4), "tflops": round(rate * f_exec / 1e12, 2),
                                           "frac_of_fp32_mfma_peak": out["roofline"]["whole_cycle_frac"],
                                           "frac_with_survey_formula": round(rate * f_survey / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)}
-    if a.workload == "c2":
-        # per-call-site table from ONE extra cycle with every probe on (outside the timed region: ~1400 event records per cycle)
+    if a.workload == "c2" and world == 1:
+        # per-call-site table from ONE extra cycle with every probe on (outside the timed region: ~1400 event records per cycle).
+        # Single-rank runs only: the other ranks of a multi-rank run have left by now and an extra cycle would wait on their
+        # collectives forever.
         tags = {k: PROBES[k] for k in C2_TABLE}
         eng.probe_enable_mask([t for t, _ in tags.values()])
         l0 = trainer.local_steps_done
