@@ -337,3 +337,39 @@ def test_minibatch_chunked_equals_whole(case):
         for k in ("mean", "var", "count"):
             assert np.allclose(own["rmv"][k].numpy(), rmv0[k].numpy(), rtol=1e-6, atol=1e-7)
         assert np.abs(own["value"].numpy() - v.detach().numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("rnn_type", ["GRU", "LSTM"])
+def test_rnn_state_encoder_known_answer_grid_of_the_reference(rnn_type):
+    """The reference's only numeric known-answer test on the path (test/test_rnn_state_encoder.py:19-94): the packed-sequence forward
+    equals a per-step RNN with the hidden state zeroed at episode starts, over T in {1..64, 3, 13, 31} x N in {1..8, 3, 5}, L2
+    distance < 1e-3.  Here, on the same grid: (a) the LIVE reference's packed path (build_rnn_state_encoder + build_pack_info_from_dones)
+    against the oracle's restatement with the reference module's own weights, (b) the oracle's sequence form against its single-step
+    form applied step by step -- the property the reference pins."""
+    from oracle.ref_loader import load_reference, reference_available
+    if not reference_available():
+        pytest.skip("/root/reference is not present on this machine")
+    ns = load_reference()
+    R = ns.rnn_state_encoder
+    torch.manual_seed(11)
+    enc = R.build_rnn_state_encoder(32, 32, rnn_type=rnn_type, num_layers=2)
+    params = {"rnn." + k: v.detach().clone() for k, v in enc.rnn.state_dict().items()}
+    Lh = enc.num_recurrent_layers
+    with torch.no_grad():
+        for T in [1, 2, 4, 8, 16, 32, 64, 3, 13, 31]:
+            for N in [1, 2, 4, 8, 3, 5]:
+                not_done = torch.rand((T, N, 1)) > (1.0 / 25.0)
+                seq_info = None if T == 1 else R.build_rnn_build_seq_info(
+                    torch.device("cpu"), build_fn_result=R.build_pack_info_from_dones(torch.logical_not(not_done).view(T, N).numpy()))
+                x = torch.randn(T, N, 32)
+                h0 = torch.randn(N, Lh, 32)
+                ref_out, ref_h = enc(x.flatten(0, 1), h0, not_done.flatten(0, 1), seq_info)
+                out, h = O.rnn_forward(params, "rnn.", rnn_type, 2, x.flatten(0, 1), h0, not_done.flatten(0, 1))
+                assert torch.linalg.norm(ref_out - out) < 1e-3 and torch.linalg.norm(ref_h - h) < 1e-3, (T, N)
+                assert (ref_out - out).abs().max() < 5e-6 and (ref_h - h).abs().max() < 5e-6, (T, N)
+                # (b) sequence form == single-step form applied T times
+                hs, outs = h0, []
+                for t in range(T):
+                    o_t, hs = O.rnn_forward(params, "rnn.", rnn_type, 2, x[t], hs, not_done[t])
+                    outs.append(o_t)
+                assert torch.linalg.norm(torch.cat(outs, 0) - out) < 1e-3 and torch.linalg.norm(hs - h) < 1e-3, (T, N)
