@@ -1,6 +1,7 @@
 """Split-bf16 matrix path (csrc/igemm_bf3.h, obs_conv_bf3.h) against a float64 reference: the path must be as accurate as the fp32
 MFMA path (its arithmetic is fp32-equivalent: exact 3-term operand split, six partial products, dropped terms <= 2^-24)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -24,9 +25,10 @@ S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def both_paths(L, fn, mask):
     out = {}
     prev = L.hab_set_matrix_path(-1)
+    extra = int(os.environ.get("HAB_TEST_EXTRA_PATH_BITS", "0"))  # tools/experiments: further matrix-path bits of a patched library
     try:
         for mode in (0, mask):
-            L.hab_set_matrix_path(mode)
+            L.hab_set_matrix_path(mode | extra if mode else 0)
             out[mode] = fn()
     finally:
         L.hab_set_matrix_path(prev)

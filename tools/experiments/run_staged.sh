@@ -15,7 +15,7 @@ R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
 case $NAME in
-  ws)    PATCH=tools/experiments/bf3_wave_specialised.patch;   VARIANTS=("HAB_BF3=63" "HAB_BF3=63 HAB_BF3_WS_TALL=0" "HAB_BF3=63 HAB_BF3_WS_PW=8");;
+  ws)    PATCH=tools/experiments/bf3_wave_specialised.patch;   VARIANTS=("HAB_BF3=63 HAB_TEST_EXTRA_PATH_BITS=32" "HAB_BF3=63 HAB_TEST_EXTRA_PATH_BITS=32 HAB_BF3_WS_TALL=0" "HAB_BF3=63 HAB_TEST_EXTRA_PATH_BITS=32 HAB_BF3_WS_PW=8");;
   pipe2) PATCH=tools/experiments/bf3_interleaved_schedule.patch; VARIANTS=("HAB_BF3_PIPE2=1" "HAB_BF3_PIPE2=2");;
   *) echo "unknown experiment $NAME"; exit 2;;
 esac
