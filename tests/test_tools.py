@@ -71,3 +71,16 @@ def test_pmc_sq_table(tmp_path):
     assert "0.300" in out  # MFMA busy = 1.2e6 / 1.0e6 / 4
     assert "SQ_WAIT_ANY / SQ_WAVE_CYCLES" in out and "0.250" in out
     assert "SQ_INSTS_VALU per wave" in out and "2000.0" in out
+
+
+def test_staged_wave_specialised_schedule_model():
+    """tools/experiments: the barrier schedule of the staged producer / consumer kernels (not part of the product) is replayed on the
+    CPU for every k-tile count: equal barrier counts in both roles, no image written while read, register sets / key buffers hold
+    what their readers expect."""
+    import runpy
+    mod = runpy.run_path(os.path.join(ROOT, "tools", "experiments", "ws_schedule_model.py"))
+    for ksh in (False, True):
+        for ntk in range(0, 24):
+            mod["check"](ntk, ksh)
+    for n in range(1, 8):
+        mod["check_obs"](n)
