@@ -3,10 +3,12 @@
 preemption signal flags :141-179).  One process per GPU; backend "nccl" is RCCL over xGMI on ROCm."""
 from __future__ import annotations
 
+import contextlib
 import functools
 import os
 import signal
 import threading
+import time
 from typing import Any, Callable, Optional, Tuple
 
 import torch
@@ -133,3 +135,58 @@ def rank0_only(fn: Optional[Callable] = None):
         return None
 
     return _wrapper
+
+
+class StoreCounterPoller:
+    """Cached view of an integer key of the rendezvous store, refreshed by a daemon thread while `polling()` is active.
+
+    The reference reads the `num_done` counter with one blocking `store.get` per rollout step (ppo_trainer.py:641-653); its steps
+    take milliseconds of simulator time.  Here a rollout step is ~200 us of GPU work enqueued by the host slightly ahead of the
+    device, and a TCP round trip per step (tens of microseconds, 75 % of the steps, every rank against rank 0's server) would put the
+    host on the critical path of multi-rank rollouts.  While `polling()` is active the trainer reads the cached value instead:
+    at most `interval_s` (0.5 ms, ~2 rollout steps) older than a direct query.  Outside `polling()` every read is a direct query."""
+
+    def __init__(self, store, key: str, interval_s: float = 0.0005):
+        self._store, self._key, self._interval = store, key, interval_s
+        self._active = threading.Event()
+        self._fresh = threading.Event()   # set once the cached value was read after the current activation
+        self._value = 0
+        self._gen = 0
+        self._error: Optional[BaseException] = None
+        self._thread: Optional[threading.Thread] = None
+
+    def _run(self) -> None:
+        while True:
+            self._active.wait()
+            try:
+                gen = self._gen
+                value = int(self._store.get(self._key))
+                if gen == self._gen:  # a query that straddles a new activation does not count as fresh for it
+                    self._value = value
+                    self._fresh.set()
+            except BaseException as e:  # store gone (teardown) or transport error: fall back to direct queries
+                self._error = e
+                self._active.clear()
+                self._fresh.set()
+                return
+            time.sleep(self._interval)
+
+    def read(self) -> int:
+        if self._active.is_set() and self._error is None:
+            self._fresh.wait()
+            if self._error is None:
+                return self._value
+        return int(self._store.get(self._key))
+
+    @contextlib.contextmanager
+    def polling(self):
+        if self._error is None and (self._thread is None or not self._thread.is_alive()):
+            self._thread = threading.Thread(target=self._run, name="num_done_poller", daemon=True)
+            self._thread.start()
+        self._gen += 1
+        self._fresh.clear()
+        self._active.set()
+        try:
+            yield self
+        finally:
+            self._active.clear()

@@ -29,7 +29,7 @@ from habitat_amd.common.env_factory import instantiate
 from habitat_amd.common.obs_transformers import (apply_obs_transforms_batch, apply_obs_transforms_obs_space,
                                                  get_active_obs_transforms)
 from habitat_amd.config.default import read_write
-from habitat_amd.rl.ddppo.ddp_utils import (EXIT, get_distrib_size, init_distrib_slurm, load_resume_state, rank0_only,
+from habitat_amd.rl.ddppo.ddp_utils import (EXIT, StoreCounterPoller, get_distrib_size, init_distrib_slurm, load_resume_state, rank0_only,
                                             requeue_job, save_resume_state)
 from habitat_amd.rl.ppo.policy import VISUAL_FEATURES_KEY
 from habitat_amd.rl.ppo.single_agent_access_mgr import EnvironmentSpec
@@ -337,9 +337,11 @@ class PPOTrainer(BaseRLTrainer):
         """DD-PPO preemptive synchronisation of stragglers (ppo_trainer.py:641-653)."""
         if not self._is_distributed:
             return False
-        return (rollout_step >= self.config.habitat_baselines.rl.ppo.num_steps * self.SHORT_ROLLOUT_THRESHOLD) and int(
-            self.num_rollouts_done_store.get("num_done")) >= (
-                self.config.habitat_baselines.rl.ddppo.sync_frac * torch.distributed.get_world_size())
+        if rollout_step < self.config.habitat_baselines.rl.ppo.num_steps * self.SHORT_ROLLOUT_THRESHOLD:
+            return False
+        poller = getattr(self, "_num_done_poller", None)  # active inside device-path rollouts only (ddp_utils.StoreCounterPoller)
+        num_done = poller.read() if poller is not None else int(self.num_rollouts_done_store.get("num_done"))
+        return num_done >= self.config.habitat_baselines.rl.ddppo.sync_frac * torch.distributed.get_world_size()
 
     # ---- main loop (ppo_trainer.py:656-801) ----------------------------------------------------------------------------
     def train(self) -> None:
@@ -396,12 +398,20 @@ class PPOTrainer(BaseRLTrainer):
         with g_timer.avg_time("trainer.rollout_collect"):
             if self._device_envs:
                 noise = self._draw_rollout_noise(T)
-                for step in range(T):
-                    count += self._device_rollout_step(step, noise)
-                    if self._straggler_delay_s:
-                        time.sleep(self._straggler_delay_s)
-                    if self.should_end_early(step + 1):
-                        break
+                # a rollout step is ~200 us of GPU work: the straggler counter is read through a cached poller, not one TCP round
+                # trip per step (at most 0.5 ms older than the reference's per-step query)
+                polling = contextlib.nullcontext()
+                if self._is_distributed:
+                    if getattr(self, "_num_done_poller", None) is None:
+                        self._num_done_poller = StoreCounterPoller(self.num_rollouts_done_store, "num_done")
+                    polling = self._num_done_poller.polling()
+                with polling:
+                    for step in range(T):
+                        count += self._device_rollout_step(step, noise)
+                        if self._straggler_delay_s:
+                            time.sleep(self._straggler_delay_s)
+                        if self.should_end_early(step + 1):
+                            break
             else:
                 nb = self._agent.nbuffers
                 for b in range(nb):

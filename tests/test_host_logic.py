@@ -618,3 +618,35 @@ def test_ver_bookkeeping_replay_of_reference_golden_on_cpu():
         st.after_update()
         st.increment_policy_version()
         cmp(f"r{r}/after_update", with_stale=True)
+
+
+def test_store_counter_poller_cached_inside_polling_direct_outside():
+    """ddp_utils.StoreCounterPoller: the DD-PPO straggler counter as the device-path rollout reads it -- a cached value refreshed every
+    0.5 ms while a rollout is collected, the reference's direct store query everywhere else."""
+    import time
+    import torch.distributed as dist
+    from habitat_amd.rl.ddppo.ddp_utils import StoreCounterPoller
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    store = dist.PrefixStore("rollout_tracker", dist.TCPStore("127.0.0.1", port, 1, True))
+    store.set("num_done", "0")
+    p = StoreCounterPoller(store, "num_done")
+    assert p.read() == 0                      # not polling: direct
+    store.add("num_done", 1)
+    assert p.read() == 1
+    for cycle in range(3):
+        with p.polling():
+            assert p.read() == 1 + 2 * cycle  # the first read of an activation waits for a query made after it
+            store.add("num_done", 2)
+            t0 = time.time()
+            while p.read() != 3 + 2 * cycle:  # picked up within a few poll intervals
+                assert time.time() - t0 < 2.0
+                time.sleep(0.0002)
+            n, t0 = 0, time.time()
+            while time.time() - t0 < 0.02:
+                p.read(); n += 1
+            assert n > 2000                   # cached reads do not go to the store (a TCP round trip each would manage ~500)
+        store.add("num_done", 0)
+    assert p.read() == 7                      # direct again
