@@ -8,7 +8,8 @@
 #      mismatch between the two roles would hang the workgroup)
 #   3. per-layer timings of the variant                   -> gpurun_out/staged_<name>_layers_*.txt
 #   4. whole-cycle bench lines (C2, C3) of the variant    -> gpurun_out/staged_<name>_c{2,3}.json
-# Nothing is timed after a failed step 2.
+# Nothing is timed after a failed step 2.  Both experiments in one call: `tools/experiments/run_staged.sh ws; tools/experiments/run_staged.sh pipe2`
+# (~25 min of box time together).
 set -u
 NAME=${1:-ws}
 R=$PWD
@@ -35,3 +36,6 @@ for V in "${VARIANTS[@]}"; do
   grep -o '"value": [0-9.]*' $O/staged_${NAME}_c2_$i.json $O/staged_${NAME}_c3_$i.json
   i=$((i+1))
 done
+# leave the snapshot as it was (a second experiment may follow in the same gpurun call): unapply and rebuild the product library
+patch -R -p1 < $PATCH > /dev/null 2>&1
+make -C habitat-lab_amd/csrc -j8 > /dev/null 2>&1 || echo "rebuild of the product library failed"
