@@ -650,3 +650,46 @@ def test_store_counter_poller_cached_inside_polling_direct_outside():
             assert n > 2000                   # cached reads do not go to the store (a TCP round trip each would manage ~500)
         store.add("num_done", 0)
     assert p.read() == 7                      # direct again
+
+
+def test_device_path_rollout_reads_straggler_counter_through_the_poller():
+    """collect_rollout (device path, distributed): the rollout ends early once >= sync_frac * world ranks are done and >= 25 % of the
+    steps are collected -- with the counter read through the cached poller (stand-in step function, real store)."""
+    import socket
+    import time
+    import types
+    import torch.distributed as dist
+    import habitat_amd.rl.ppo.ppo_trainer as tr
+    from habitat_amd.config.default import get_config
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    store = dist.PrefixStore("rollout_tracker", dist.TCPStore("127.0.0.1", port, 1, True))
+    store.set("num_done", "0")
+    cfg = get_config("pointnav/ddppo_pointnav.yaml", ["habitat_baselines.rl.ppo.num_steps=64"])
+    t = tr.PPOTrainer.__new__(tr.PPOTrainer)
+    t.config, t._ppo_cfg = cfg, cfg.habitat_baselines.rl.ppo
+    t._is_distributed, t._device_envs, t._straggler_delay_s = True, True, 0.0
+    t.num_rollouts_done_store = store
+    t._draw_rollout_noise = lambda T: None
+    steps, others_finish = [], [True]
+
+    def step(self, s, noise):
+        steps.append(s)
+        if s == 40 and others_finish[0]:
+            store.add("num_done", 5)   # the other ranks finish while this one is at step 40
+            time.sleep(0.01)            # > poll interval: the next query sees it
+        return 4
+    t._device_rollout_step = types.MethodType(step, t)
+    real_ws = dist.get_world_size
+    dist.get_world_size = lambda *a, **k: 8  # sync_frac 0.6 * 8 = 4.8
+    try:
+        n = t.collect_rollout()
+        assert steps == list(range(41)) and n == 41 * 4     # ended right after the step at which 5 >= 4.8 became visible
+        assert t._num_done_poller.read() == 5               # outside the rollout: direct query
+        store.set("num_done", "0")
+        steps.clear()
+        others_finish[0] = False
+        assert t.collect_rollout() == 64 * 4 and len(steps) == 64  # nobody done: full rollout
+    finally:
+        dist.get_world_size = real_ws
