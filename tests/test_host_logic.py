@@ -693,3 +693,29 @@ def test_device_path_rollout_reads_straggler_counter_through_the_poller():
         assert t.collect_rollout() == 64 * 4 and len(steps) == 64  # nobody done: full rollout
     finally:
         dist.get_world_size = real_ws
+
+
+@pytest.mark.parametrize("H,W", [(62, 30), (63, 84), (64, 128), (65, 30), (66, 64), (100, 180), (256, 256)])
+def test_resnet_encoder_geometry_rule_matches_live_reference(H, W):
+    """The observation geometries of the reference's test/test_baseline_resnet.py (odd, non-square) + the benchmark's: spatial halving,
+    final feature map and the round() rule for the compression channels (resnet_policy.py:199-216) give the same parameter table and
+    the same initial values as the reference's constructor, for BasicBlock and Bottleneck backbones."""
+    from oracle.ref_loader import load_reference, reference_available
+    if not reference_available():
+        pytest.skip("reference checkout not present")
+    from habitat_amd.common import spaces as S
+    from habitat_amd.rl.ddppo.policy import PointNavResNetPolicy
+    ns = load_reference()
+    sp = ns.spaces
+    mk = lambda m: m.Dict({"rgb": m.Box(0, 255, (H, W, 3), np.uint8), "depth": m.Box(0, 1, (H, W, 1), np.float32),
+                           "pointgoal_with_gps_compass": m.Box(-1e9, 1e9, (2,), np.float32)})
+    for backbone in ("resnet18", "resnet50"):
+        torch.manual_seed(3)
+        a = PointNavResNetPolicy(mk(S), S.Discrete(4), hidden_size=64, num_recurrent_layers=1, rnn_type="GRU", backbone=backbone,
+                                 normalize_visual_inputs=True)
+        torch.manual_seed(3)
+        b = ns.resnet_policy.PointNavResNetPolicy(mk(sp), sp.Discrete(4), hidden_size=64, num_recurrent_layers=1, rnn_type="GRU",
+                                                  backbone=backbone, normalize_visual_inputs=True)
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert all(sa[k].shape == sb[k].shape and torch.equal(sa[k], sb[k]) for k in sb), (backbone, H, W)
