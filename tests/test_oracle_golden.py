@@ -373,3 +373,42 @@ def test_rnn_state_encoder_known_answer_grid_of_the_reference(rnn_type):
                     o_t, hs = O.rnn_forward(params, "rnn.", rnn_type, 2, x[t], hs, not_done[t])
                     outs.append(o_t)
                 assert torch.linalg.norm(torch.cat(outs, 0) - out) < 1e-3 and torch.linalg.norm(hs - h) < 1e-3, (T, N)
+
+
+@pytest.mark.parametrize("H,W,backbone", [(62, 30, "resnet18"), (65, 30, "resnet50"), (63, 84, "resnet18"), (100, 180, "resnet18"),
+                                          (66, 64, "se_resneXt50")])
+def test_oracle_forward_on_odd_geometries_vs_live_reference(H, W, backbone):
+    """The oracle's network forward (features, value, log-probs, next hidden state) against the LIVE reference policy on the odd /
+    non-square observation sizes of the reference's test_baseline_resnet.py -- floor rules of the 2x average pool, strided
+    convolutions, max-pool and the compression stage -- with the reference's own initial parameters."""
+    from oracle.ref_loader import load_reference, reference_available
+    if not reference_available():
+        pytest.skip("reference checkout not present")
+    ns = load_reference()
+    sp = ns.spaces
+    robs = sp.Dict({"rgb": sp.Box(0, 255, (H, W, 3), np.uint8), "depth": sp.Box(0, 1, (H, W, 1), np.float32),
+                    "pointgoal_with_gps_compass": sp.Box(-1e9, 1e9, (2,), np.float32)})
+    torch.manual_seed(11)
+    ref = ns.resnet_policy.PointNavResNetPolicy(robs, sp.Discrete(4), hidden_size=64, num_recurrent_layers=1, rnn_type="GRU",
+                                                backbone=backbone, normalize_visual_inputs=True)
+    ref.eval()
+    params = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    spec = O.NetSpec(kind="resnet", rnn_type="GRU", num_layers=1, backbone=backbone, baseplanes=32, visual_keys=("rgb", "depth"),
+                     normalize=True, hidden=64, num_actions=4)
+    n = 3
+    g = torch.Generator().manual_seed(5)
+    obs = {"rgb": torch.randint(0, 256, (n, H, W, 3), generator=g, dtype=torch.uint8), "depth": torch.rand(n, H, W, 1, generator=g),
+           "pointgoal_with_gps_compass": torch.randn(n, 2, generator=g)}
+    hidden = torch.randn(n, 1, 64, generator=g)
+    prev = torch.randint(0, 4, (n, 1), generator=g)
+    masks = torch.tensor([[True], [False], [True]])
+    with torch.no_grad():
+        feats_ref, hid_ref, _ = ref.net(obs, hidden, prev, masks)
+        value_ref = ref.critic(feats_ref)
+        logits_ref = ref.action_distribution(feats_ref).logits
+        feats, hid = O.net_forward(params, spec, obs, hidden, prev, masks)
+        logits, _, value = O.heads(params, feats)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    assert feats.shape == feats_ref.shape and rel(feats, feats_ref) < 1e-5, rel(feats, feats_ref)
+    assert rel(hid, hid_ref) < 1e-5
+    assert rel(value, value_ref) < 1e-5 and float((logits - logits_ref).abs().max()) < 1e-5
