@@ -32,6 +32,14 @@ for V in "${VARIANTS[@]}"; do
   env $V timeout 120 python tools/bench_layers.py 1024 > $O/staged_${NAME}_layers_$i.txt 2>&1
   env $V timeout 300 python bench.py --no-extras > $O/staged_${NAME}_c2_$i.json 2> $O/staged_${NAME}_c2_$i.err
   env $V timeout 300 python bench.py --workload c3 --steps 3 --warmup 1 --no-extras > $O/staged_${NAME}_c3_$i.json 2> $O/staged_${NAME}_c3_$i.err
+  if [ $i -eq 0 ]; then  # per-kernel durations + matrix-pipe busy of the first variant (counters in their own pass, under timeout)
+    (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/staged_prof && env $V timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/staged_prof -o layers -- python $R/tools/bench_layers.py 1024 > /dev/null 2>&1)
+    DB=$(ls /tmp/staged_prof/*results.db /tmp/staged_prof/*/*results.db 2>/dev/null | head -1)
+    [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/staged_${NAME}_kernel_stats.txt > /dev/null
+    env $V tools/pmc_run.sh /tmp/staged_pmc python $R/tools/bench_layers.py 256 > /dev/null 2>&1
+    python tools/pmc_sq.py /tmp/staged_pmc $O/staged_${NAME}_sq_counters.txt > /dev/null 2>&1
+    rm -rf /tmp/staged_prof /tmp/staged_pmc
+  fi
   echo "== $V"; paste -d'|' <(cut -c1-70 $O/staged_${NAME}_layers_base.txt) <(cut -c29-70 $O/staged_${NAME}_layers_$i.txt) | head -60
   grep -o '"value": [0-9.]*' $O/staged_${NAME}_c2_$i.json $O/staged_${NAME}_c3_$i.json
   i=$((i+1))
