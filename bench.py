@@ -411,6 +411,7 @@ def main():
     if os.environ.get("HAB_BENCH_CHECKSUM"):  # development: parameters must not depend on how the gradient exchange is scheduled
         pf = eng.params_flat.double()
         print(f"[rank {rank}] params checksum {pf.sum().item():.12e} {pf.abs().sum().item():.12e}", flush=True)
+    trainer.shutdown()  # joins the straggler-counter poller before the store goes away
     if rank != 0:
         torch.distributed.destroy_process_group()
         return
@@ -441,6 +442,9 @@ def main():
         "value": round(steps_total / dt, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        # ranks that took part, read from the process group after init (1 without one): a launcher that silently started fewer
+        # ranks than --gpus would show here
+        "ranks_seen": torch.distributed.get_world_size() if dist else 1,
         "config": {"workload": WORKLOADS[a.workload]["name"], "envs_per_gpu": n_envs, "rollout_steps": n_steps,
                    "ppo_epoch": ppo.ppo_epoch, "num_mini_batch": ppo.num_mini_batch, "parallelism": f"dp{world}",
                    "matrix_path": "fp32 in / fp32 out; exact 3-term bf16 operand split, 6 (uint8 operand: 3) partial products on "
@@ -494,6 +498,9 @@ def main():
         if not a.no_extras:
             out["c3"] = run_cycles("c3", 3, 1)
             out["encoder_r18_b8192"] = encoder_record()
+    if world > 1:
+        out["note"] = ("n_gpus > 1: `cpu_baseline`, `parity`, the per-site `kernels` table and the c3 / encoder sub-records are reported by the "
+                       "N = 1 run only (rank 0 would have to run them while the other ranks have left)")
     print(json.dumps(out), flush=True)
     if dist:
         torch.distributed.destroy_process_group()

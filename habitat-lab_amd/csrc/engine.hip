@@ -105,6 +105,8 @@ extern "C" int hab_policy_create(const hab_policy_desc* desc, hab_policy** out) 
         return HAB_ERR_ARG;
     if (desc->action_dist != HAB_DIST_CATEGORICAL && (desc->action_dist != HAB_DIST_GAUSSIAN || desc->arch != HAB_ARCH_RESNET))
         return HAB_ERR_UNSUPPORTED;  // PointNavBaselinePolicy never builds a Gaussian head (rl/ppo/policy.py:439-460)
+    // the Gaussian head kernels (heads.hip: saved[f][16], dz stride 8, std column sums at dz + A) hold 2A <= 8 values per frame
+    if (desc->action_dist == HAB_DIST_GAUSSIAN && desc->num_actions > 4) return HAB_ERR_UNSUPPORTED;
     hab_policy* e = new hab_policy();
     e->d = *desc;
     int rc = HAB_ERR_UNSUPPORTED;

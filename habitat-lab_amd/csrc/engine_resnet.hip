@@ -89,7 +89,7 @@ int build_resnet(hab_policy* e) {
         d.backbone != HAB_BACKBONE_SE_RESNET50 && d.backbone != HAB_BACKBONE_SE_RESNEXT50 && d.backbone != HAB_BACKBONE_SE_RESNEXT101)
         return HAB_ERR_UNSUPPORTED;
     if (d.baseplanes <= 0 || d.baseplanes % 8) return HAB_ERR_UNSUPPORTED;
-    if ((d.H & 1) || (d.W & 1)) return HAB_ERR_UNSUPPORTED;
+    if (d.H < 2 || d.W < 2) return HAB_ERR_UNSUPPORTED;  // odd sizes: avg_pool2d(2) floors, the last row / column is dropped (F.avg_pool2d)
     if (d.rnn_type != HAB_RNN_GRU && d.rnn_type != HAB_RNN_LSTM) return HAB_ERR_ARG;
     if (d.goal_dim != 0 && d.goal_dim != 2) return HAB_ERR_UNSUPPORTED;  // 2-D polar pointgoal (resnet_policy.py:662-672)
     ResNetPlan* r = new ResNetPlan();

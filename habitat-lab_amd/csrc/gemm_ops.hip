@@ -4,7 +4,9 @@
 #include "igemm_dma.h"
 #include "igemm_dma_wgrad.h"
 #include "igemm_bf3.h"
+#include "igemm_bf3_ws.h"
 #include "obs_conv_bf3.h"
+#include "obs_conv_bf3_ws.h"
 #include "obs_wgrad_bf3.h"
 #include "conv_patch_bf3.h"
 #include "wgrad3x3_patch.h"
@@ -24,16 +26,34 @@ static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); ret
 // split-bf16 matrix-pipe path (igemm_bf3.h) for the r-contiguous x r-contiguous contractions
 // bit 0: r-contiguous x r-contiguous problems, bit 1: observation-ingest convolution (obs_conv_bf3.h), bit 2: problems with an
 // i/j-contiguous operand (weight gradients, Linear data gradient), bit 3: prefer it over the fp32 patch / DMA weight-gradient kernels,
-// bit 4: input-patch-resident stride-1 3x3 convolutions (conv_patch_bf3.h)
+// bit 4: input-patch-resident stride-1 3x3 convolutions (conv_patch_bf3.h), bit 5: producer / consumer waves where they won
+// (igemm_bf3_ws.h: long-K 128 x 128 forward-form tiles; obs_conv_bf3_ws.h: the observation-ingest convolution)
 static int g_bf3_mode = -1;
 static int bf3_mode() {
-    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 31);
+    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 63);
     return g_bf3_mode;
 }
 extern "C" int hab_set_matrix_path(int mode) {
     const int prev = bf3_mode();
     if (mode >= 0) g_bf3_mode = mode;
     return prev;
+}
+
+
+// Producer / consumer waves (igemm_bf3_ws.h, matrix-path bit 5, on by default).  Measured on the MI355X against igemm_bf3_kernel, same
+// arithmetic and bit-identical results (profiles/r03_ws_vs_base_layers.txt): the 128 x 128 forward-form tiles with a long reduction gain
+// (3x3 256->256 at 4x4: 128 -> 163 TFLOP/s-eq forward and data gradient, fc 25088->512 forward 132 -> 150), every other shape loses
+// (32- / 64-column tiles -10..-45 %, i/j-contiguous operands -30 %, K = 256 merged data gradient -18 %: the longer prologue and the
+// halved MFMA wave count are not paid back).  It is therefore selected only where it won; HAB_BF3_WS_ALL=1 forces it everywhere
+// the plain kernel runs (development: reproduces the comparison).
+template <class P, int TM, int TN, int WM, int WN>
+static int bf3_launch(const P& p, float* ws, size_t ws_floats, int target_blocks, hipStream_t stream) {
+    constexpr bool WS_SHAPE = P::A_RC && P::B_RC && TM == 2 && TN == 2 && WM == 2 && WN == 2;
+    if constexpr (WS_SHAPE) {
+        static const int ws_min_k = hab_env_int("HAB_BF3_WS_MIN_K", 2048);
+        if ((bf3_mode() & 32) && p.K >= ws_min_k) return igemm_bf3_ws_launch<P, TM, TN, WM, WN, 4>(p, ws, ws_floats, target_blocks, stream);
+    }
+    return igemm_bf3_launch<P, TM, TN, WM, WN>(p, ws, ws_floats, target_blocks, stream);
 }
 
 template <class P>
@@ -48,27 +68,27 @@ static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream
     constexpr bool WG = !P::A_RC && !P::B_RC && AKv<P>::value == 4;  // weight-gradient form
     if constexpr (P::A_RC && P::B_RC) {
         if ((bf3_mode() & 1) && p.M > 64) {
-            if (p.N <= 32) return igemm_bf3_launch<P, 2, 1, 4, 1>(p, ws, ws_floats, target_blocks, stream);
-            if (p.N <= 64) return igemm_bf3_launch<P, 1, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
-            return igemm_bf3_launch<P, 2, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
+            if (p.N <= 32) return bf3_launch<P, 2, 1, 4, 1>(p, ws, ws_floats, target_blocks, stream);
+            if (p.N <= 64) return bf3_launch<P, 1, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
+            return bf3_launch<P, 2, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
         }
     } else if constexpr (AKv<P>::value == 4) {  // an i/j-contiguous operand: register-transposed staging (igemm_bf3.h)
         if ((bf3_mode() & 4) && p.M > 64) {
             if (p.N <= 32) {
                 if constexpr (WG) {
                     if (p.M % 96 == 0 || cdiv(p.M, 96) * 96 < cdiv(p.M, 256) * 256)
-                        return igemm_bf3_launch<P, 1, 1, 3, 1>(p, ws, ws_floats, target_blocks, stream);
+                        return bf3_launch<P, 1, 1, 3, 1>(p, ws, ws_floats, target_blocks, stream);
                 }
-                return igemm_bf3_launch<P, 2, 1, 4, 1>(p, ws, ws_floats, target_blocks, stream);
+                return bf3_launch<P, 2, 1, 4, 1>(p, ws, ws_floats, target_blocks, stream);
             }
             if (p.N <= 64) {
                 if constexpr (WG) {
                     if (p.M % 96 == 0 || cdiv(p.M, 96) * 96 < cdiv(p.M, 128) * 128)
-                        return igemm_bf3_launch<P, 1, 2, 3, 1>(p, ws, ws_floats, target_blocks, stream);
+                        return bf3_launch<P, 1, 2, 3, 1>(p, ws, ws_floats, target_blocks, stream);
                 }
-                return igemm_bf3_launch<P, 1, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
+                return bf3_launch<P, 1, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
             }
-            return igemm_bf3_launch<P, 2, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
+            return bf3_launch<P, 2, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
         }
     }
     if constexpr (std::is_same_v<P, ConvFwdProb> || std::is_same_v<P, ConvDgradProb>) {
@@ -115,6 +135,10 @@ int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const f
                  size_t ws_floats, hipStream_t stream) {
     ObsConvFwdProb p;
     HAB_TRY(build(p, d, obs, wf, bias, y, relu));
+    if ((bf3_mode() & 32) && (bf3_mode() & 2) && p.quad && p.M > 64) {  // producer / consumer waves (obs_conv_bf3_ws.h): 133 -> 148-152 TFLOP/s-eq at 1024 frames
+        const int rc = obs_conv_bf3_ws_launch(p, ws, ws_floats, stream);
+        if (rc != 1) return rc;
+    }
     if ((bf3_mode() & 2) && p.quad && p.M > 64) {  // uint8 x split-bf16 weights on the matrix pipe (obs_conv_bf3.h)
         static const int tm = hab_env_int("HAB_OBF_TM", 2);
         const int rc = tm == 4 ? obs_conv_bf3_launch<4>(p, ws, ws_floats, stream) : obs_conv_bf3_launch<2>(p, ws, ws_floats, stream);
@@ -141,9 +165,9 @@ int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float*
             q.dy = dy; q.w = wd; q.mask = mask; q.add = add; q.dx = dx;
             q.finish();
             if ((bf3_mode() & 1) && q.M > 64) {  // split-bf16 matrix path, register-staged (igemm_bf3.h)
-                if (q.N <= 32) return igemm_bf3_launch<ConvDgradMergedProb, 2, 1, 4, 1>(q, ws, ws_floats, 256, stream);
-                if (q.N <= 64) return igemm_bf3_launch<ConvDgradMergedProb, 1, 2, 4, 1>(q, ws, ws_floats, 256, stream);
-                return igemm_bf3_launch<ConvDgradMergedProb, 2, 2, 2, 2>(q, ws, ws_floats, 256, stream);
+                if (q.N <= 32) return bf3_launch<ConvDgradMergedProb, 2, 1, 4, 1>(q, ws, ws_floats, 256, stream);
+                if (q.N <= 64) return bf3_launch<ConvDgradMergedProb, 1, 2, 4, 1>(q, ws, ws_floats, 256, stream);
+                return bf3_launch<ConvDgradMergedProb, 2, 2, 2, 2>(q, ws, ws_floats, 256, stream);
             }
             if (q.dma_ok()) {
                 if (q.N <= 32) return igemm_dma_launch<ConvDgradMergedProb, 2, 1, 4, 1, false>(q, ws, ws_floats, 1024, stream);

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restr
 
 int ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic, const int* rows, float* y, int B, int H, int W, int cpad,
                 int c_rgb, int c_depth, int c_sem, hipStream_t s) {
-    if ((!rgb && !depth && !semantic) || !y || B <= 0 || (H & 1) || (W & 1) || (cpad != 4 && cpad != 8)) return HAB_ERR_ARG;
+    if ((!rgb && !depth && !semantic) || !y || B <= 0 || H < 2 || W < 2 || (cpad != 4 && cpad != 8)) return HAB_ERR_ARG;
     const int n = (rgb ? 3 : 0) + (depth ? 1 : 0) + (semantic ? 1 : 0);
     if (n > cpad || (rgb && (c_rgb < 0 || c_rgb + 3 > n)) || (depth && (c_depth < 0 || c_depth >= n)) || (semantic && (c_sem < 0 || c_sem >= n)))
         return HAB_ERR_ARG;

@@ -150,26 +150,42 @@ class StoreCounterPoller:
         self._store, self._key, self._interval = store, key, interval_s
         self._active = threading.Event()
         self._fresh = threading.Event()   # set once the cached value was read after the current activation
+        self._stop = threading.Event()    # stop(): the thread leaves its loop and is joined (teardown before the store goes away)
+        self._lock = threading.Lock()     # guards (_gen, _fresh, _value): an activation and a straddling query never interleave
         self._value = 0
         self._gen = 0
         self._error: Optional[BaseException] = None
         self._thread: Optional[threading.Thread] = None
 
     def _run(self) -> None:
-        while True:
+        while not self._stop.is_set():
             self._active.wait()
+            if self._stop.is_set():
+                return
             try:
-                gen = self._gen
+                with self._lock:
+                    gen = self._gen
                 value = int(self._store.get(self._key))
-                if gen == self._gen:  # a query that straddles a new activation does not count as fresh for it
-                    self._value = value
-                    self._fresh.set()
+                with self._lock:
+                    if gen == self._gen:  # a query that straddles a new activation does not count as fresh for it
+                        self._value = value
+                        self._fresh.set()
             except BaseException as e:  # store gone (teardown) or transport error: fall back to direct queries
                 self._error = e
                 self._active.clear()
                 self._fresh.set()
                 return
-            time.sleep(self._interval)
+            self._stop.wait(self._interval)
+
+    def stop(self, timeout_s: float = 2.0) -> None:
+        """Ends the polling thread and joins it.  Call before the process group / store is destroyed: a daemon thread left inside a
+        blocking TCPStore call at interpreter shutdown can hang or crash the teardown."""
+        self._stop.set()
+        self._active.set()  # wake the thread if it is parked between activations
+        t = self._thread
+        if t is not None and t.is_alive() and t is not threading.current_thread():
+            t.join(timeout_s)
+        self._active.clear()
 
     def read(self) -> int:
         if self._active.is_set() and self._error is None:
@@ -180,11 +196,15 @@ class StoreCounterPoller:
 
     @contextlib.contextmanager
     def polling(self):
-        if self._error is None and (self._thread is None or not self._thread.is_alive()):
+        if self._error is None and not self._stop.is_set() and (self._thread is None or not self._thread.is_alive()):
             self._thread = threading.Thread(target=self._run, name="num_done_poller", daemon=True)
             self._thread.start()
-        self._gen += 1
-        self._fresh.clear()
+        if self._stop.is_set():  # stopped pollers answer every read with a direct query
+            yield self
+            return
+        with self._lock:
+            self._gen += 1
+            self._fresh.clear()
         self._active.set()
         try:
             yield self

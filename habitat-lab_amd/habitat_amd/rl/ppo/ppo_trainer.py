@@ -378,6 +378,15 @@ class PPOTrainer(BaseRLTrainer):
                                          dict(step=self.num_steps_done, wall_time=(time.time() - self.t_start) + prev_time))
                     count_checkpoints += 1
             self.envs.close()
+            self.shutdown()
+
+    def shutdown(self) -> None:
+        """Teardown of what the trainer started besides the envs: the straggler-counter polling thread must be joined BEFORE the
+        process group / rendezvous store is destroyed (it may sit inside a blocking TCPStore call)."""
+        poller = getattr(self, "_num_done_poller", None)
+        if poller is not None:
+            poller.stop()
+            self._num_done_poller = None
 
     def run_update_cycle(self) -> Dict[str, float]:
         """One full cycle of the hot path: rollout collection -> GAE -> PPO update -> statistics reduction."""

@@ -44,8 +44,32 @@ def obs_space(ns, H, W, rgb=True, depth=True, task="pointnav"):
     return sp.Dict(d)
 
 
+class ReluMargin:
+    """Smallest |pre-ReLU| value seen while active (nn.ReLU.forward -> F.relu): a ReLU input inside fp32 round-off of zero (~1e-6
+    after 20 GroupNorm layers) lands on either side in two correct implementations -- or in two runs of THIS script at different
+    thread counts -- and flips a mask bit of the backward.  Fixtures of deep encoders record the margin of the minibatch whose
+    gradients they store."""
+
+    def __init__(self):
+        self.min = float("inf")
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._F, self._orig = F, F.relu
+
+        def probe(x, inplace=False):
+            self.min = min(self.min, float(x.detach().abs().min()))
+            return self._orig(x, inplace=inplace)
+
+        F.relu = probe
+        return self
+
+    def __exit__(self, *a):
+        self._F.relu = self._orig
+
+
 def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=True, sampled=False, task="pointnav", num_actions=4,
-             action_space=None):
+             action_space=None, margin_only=False):
     """Reference rollout (policy.act through RolloutStorage) + compute_returns + PPO.update.  action_space: a Box for the Gaussian
     head (the stored noise is then the N(0, 1) draw of CustomNormal.rsample instead of multinomial's Exp(1))."""
     gaussian = action_space is not None
@@ -96,8 +120,12 @@ def run_case(ns, name, policy, space, cfg, T, N, seed, H, W, rgb=True, depth=Tru
     torch.manual_seed(seed + 1)
     gen = rollouts.data_generator(ppo.get_advantages(rollouts), cfg.num_mini_batch)
     batch = next(gen)
-    v, lp, ent, hfin, _ = policy.evaluate_actions(batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"],
-                                                  batch["masks"], batch["actions"], batch["rnn_build_seq_info"])
+    with ReluMargin() as rm:
+        v, lp, ent, hfin, _ = policy.evaluate_actions(batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"],
+                                                      batch["masks"], batch["actions"], batch["rnn_build_seq_info"])
+    out["mb0_relu_margin"] = np.float64(rm.min)
+    if margin_only:
+        return rm.min
     out["mb0_value"], out["mb0_logp"], out["mb0_entropy"], out["mb0_hidden"] = (
         v.detach().numpy(), lp.detach().numpy(), ent.detach().numpy(), hfin.detach().numpy())
     ratio = torch.exp(lp - batch["action_log_probs"])
@@ -357,6 +385,12 @@ def ver_case():
 
 
 def main():
+    torch.set_num_threads(4)  # EVERY branch: the fixtures must not depend on how the script was invoked (summation order of ATen's CPU kernels)
+    if len(sys.argv) > 1 and sys.argv[1] == "se-seeds":  # margin scan used to choose SE_SEED below
+        ns = load_reference()
+        for seed in range(int(sys.argv[2]), int(sys.argv[3])):
+            print(seed, se_resnext_case(ns, seed=seed, margin_only=True), flush=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "ver":
         ver_case()
         return
@@ -367,7 +401,6 @@ def main():
         gaussian_case(load_reference())
         return
     ns = load_reference()
-    torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
         c1_case(ns)
         return
@@ -413,7 +446,10 @@ def main():
     se_resnext_case(ns)
 
 
-def se_resnext_case(ns):
+SE_SEED = 61
+
+
+def se_resnext_case(ns, seed=None, margin_only=False):
     """se_resneXt50 backbone (resnet.py:92-113,155-193,317-328): grouped 3x3 convolutions (cardinality 16, first
     block of every stage), expansion 2, squeeze-and-excitation gates; 1-layer GRU, 128x128 RGB-D."""
     space = obs_space(ns, 128, 128)
@@ -422,7 +458,8 @@ def se_resnext_case(ns):
                                                 backbone="se_resneXt50", normalize_visual_inputs=True)
     cfg = make_config(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2, num_steps=3, use_normalized_advantage=False,
                       hidden_size=64, lr=2.5e-4, eps=1e-5)
-    run_case(ns, "se_resnext50_rgbd128", pol, space, cfg, T=3, N=2, seed=61, H=128, W=128, sampled=True)
+    return run_case(ns, "se_resnext50_rgbd128", pol, space, cfg, T=3, N=2, seed=SE_SEED if seed is None else seed, H=128, W=128, sampled=True,
+                    margin_only=margin_only)
 
 
 GAUSS_CASE = dict(use_log_std=True, use_softplus=False, log_std_init=0.0, use_std_param=False, clamp_std=True, min_std=1e-6, max_std=1,

@@ -25,7 +25,7 @@ S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def both_paths(L, fn, mask):
     out = {}
     prev = L.hab_set_matrix_path(-1)
-    extra = int(os.environ.get("HAB_TEST_EXTRA_PATH_BITS", "0"))  # tools/experiments: further matrix-path bits of a patched library
+    extra = int(os.environ.get("HAB_TEST_EXTRA_PATH_BITS", "0"))  # development: further matrix-path bits on top of the mode under test
     try:
         for mode in (0, mask):
             L.hab_set_matrix_path(mode | extra if mode else 0)
@@ -241,3 +241,62 @@ def test_patch_resident_conv_fwd_dgrad_as_accurate_as_fp32_path(L, B, H, W, Cc, 
         e0, e1 = err_vs(ref, a0), err_vs(ref, a1)
         assert e1 <= 2 * e0 + 2e-7, (e0, e1)
         assert e1 < 3e-6
+
+
+def _with_path(L, mode, fn):
+    prev = L.hab_set_matrix_path(-1)
+    try:
+        L.hab_set_matrix_path(mode)
+        return fn()
+    finally:
+        L.hab_set_matrix_path(prev)
+
+
+def test_producer_consumer_kernels_match_the_plain_split_kernels(L):
+    """Matrix-path bit 5 (igemm_bf3_ws.h / obs_conv_bf3_ws.h, on by default where it measured faster): same split, same operand order,
+    same sign schedule and split-K plan as igemm_bf3_kernel -- the long-K 128 x 128 forward-form tiles must come out BIT-identical with
+    and without it; the observation-ingest convolution (different tile loop) must be as accurate against float64."""
+    torch.manual_seed(5)
+    # fc 25088 -> 512 forward (LinearFwdProb, K >= 2048): M = 300 rows, partial last tile
+    M, N, K = 300, 512, 25088
+    x = (torch.randn(M, K) * torch.rand(M, K).pow(3) * 10).cuda()
+    w = (torch.randn(N, K) * 0.01).cuda()
+    ws = torch.zeros(1 << 24, device="cuda")
+
+    def lin():
+        y = torch.zeros(M, N, device="cuda")
+        _lib.check(L.hab_linear_fwd(P(x), K, P(w), K, None, P(y), N, M, N, K, 0, 0, P(ws), ws.numel(), S()))
+        return y
+
+    assert torch.equal(_with_path(L, 31, lin), _with_path(L, 63, lin))
+    # 3x3 256 -> 256 at 4x4 (ResNet18 layer4), forward and data gradient: K = 2304
+    B, Cc = 70, 256
+    xc = torch.randn(B, 4, 4, Cc, device="cuda")
+    wf = (torch.randn(Cc, 3, 3, Cc, device="cuda") / 48)
+    bias = torch.randn(Cc, device="cuda")
+
+    def conv():
+        y = torch.zeros(B, 4, 4, Cc, device="cuda")
+        dx = torch.zeros(B, 4, 4, Cc, device="cuda")
+        _lib.check(L.hab_conv2d_fwd(P(xc), P(wf), P(bias), P(y), B, 4, 4, Cc, Cc, 3, 3, 1, 1, 1, P(ws), ws.numel(), S()))
+        _lib.check(L.hab_conv2d_dgrad(P(xc), P(wf), None, None, P(dx), B, 4, 4, Cc, Cc, 3, 3, 1, 1, P(ws), ws.numel(), S()))
+        return torch.cat([y.view(-1), dx.view(-1)])
+
+    assert torch.equal(_with_path(L, 31, conv), _with_path(L, 63, conv))
+    # observation-ingest convolution at the benchmark geometry, odd frame count
+    Bo, H, W = 7, 256, 256
+    rgb = torch.randint(0, 256, (Bo, H, W, 3), dtype=torch.uint8)
+    depth = torch.rand(Bo, H, W, 1)
+    xo = torch.cat([rgb.double() / 255.0, depth.double()], -1).permute(0, 3, 1, 2)
+    wo = torch.randn(32, 4, 8, 8) / 16
+    bo = torch.randn(32)
+    ref = F.relu(F.conv2d(xo, wo.double(), bo.double(), stride=4)).permute(0, 2, 3, 1)
+    wfo, bd, rg, dp = repack_fwd(L, wo), bo.cuda(), rgb.cuda(), depth.cuda()
+
+    def obs():
+        y = torch.zeros(ref.shape, device="cuda")
+        _lib.check(L.hab_obs_conv2d_fwd(P(rg), P(dp), None, P(wfo), P(bd), P(y), Bo, H, W, 32, 8, 8, 4, 0, 1, P(ws), ws.numel(), S()))
+        return y
+
+    e_plain, e_ws = err_vs(ref, _with_path(L, 31, obs)), err_vs(ref, _with_path(L, 63, obs))
+    assert e_ws <= 2 * e_plain + 2e-7 and e_ws < 3e-6, (e_plain, e_ws)

@@ -220,3 +220,26 @@ def test_ddppo_running_mean_var_with_uneven_frame_counts():
     assert a["rmv_err"] <= 1e-5 and b["rmv_err"] <= 1e-5, (a["rmv_err"], b["rmv_err"])
     assert torch.equal(a["rmv_state"], b["rmv_state"])
     assert torch.equal(a["p_final"], b["p_final"])
+
+
+def test_bench_py_launches_two_ranks_and_reports_whole_job_rate():
+    """The driver's multi-GPU scaling run is the first time RCCL sees more than one rank; everything around the transport must not be
+    able to fail there.  `bench.py --gpus 2` (the self-launching form: torchrun with --master-addr 127.0.0.1) on ONE GPU with the gloo
+    transport (HAB_BENCH_DISTRIB_BACKEND=GLOO; both ranks wrap onto device 0): exactly one JSON line, n_gpus = ranks_seen = 2,
+    parallelism dp2, all 2 x 64 x 128 x K env-steps counted, value = env-steps / max-over-ranks time."""
+    import json
+    import subprocess
+    env = dict(os.environ, HAB_BENCH_DISTRIB_BACKEND="GLOO", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak"
+    assert out["steps"] == 2 and out["warmup"] == 1
+    steps = 2 * 64 * 128 * 2
+    assert abs(out["value"] * out["ms_per_step"] * 2 / 1e3 - steps) <= 0.01 * steps  # whole-job aggregate over both ranks
+    assert "cpu_baseline" not in out and "note" in out

@@ -1,6 +1,7 @@
-"""GPU parity AT THE BENCHMARK SHAPES (BASELINE.json configs[1] / configs[2]): the trainer built from the YAML entrypoint collects a
+"""GPU parity AT THE BENCHMARK SHAPES (BASELINE.json configs[1] / configs[2] / configs[4] per GPU): the trainer built from the YAML entrypoint collects a
 full 64 envs x 128 steps rollout of 256x256 RGB-D on the device, then ONE full-size PPO minibatch -- 2048 frames for SimpleCNN+GRU
-(M=4), 4096 frames for ResNet18 + 2-layer LSTM (M=2), hidden 512 -- is evaluated by the HIP engine (forward, fused loss, backward)
+(M=4), 4096 frames for ResNet18 + 2-layer LSTM (M=2), 1024 frames (32 envs x 64 steps, M=2) of rgb + depth + semantic for the ObjectNav
+ResNet50, hidden 512 -- is evaluated by the HIP engine (forward, fused loss, backward)
 and by the CPU oracle on the same arena columns (oracle.parity / oracle.functional.minibatch_chunked, bounded memory).  These are the
 code paths the golden fixtures (T <= 32, N <= 4) never reach: tile selection and split-K plans at M = 1.8e6 ... 1.7e7 rows,
 per-tile buffer re-basing of > 2 GB tensors, the patch-resident weight gradients at 4096 frames, chunked GroupNorm at full batch.
@@ -31,7 +32,7 @@ def _report(name, rep):
         json.dump({k: v for k, v in rep.items() if not k.startswith("_")}, f, indent=1)
 
 
-@pytest.mark.parametrize("workload,frames", [("c2", 2048), ("c3", 4096)])
+@pytest.mark.parametrize("workload,frames", [("c2", 2048), ("c3", 4096), ("c5", 1024)])
 def test_full_minibatch_at_benchmark_shape_vs_oracle(workload, frames):
     import bench
     from oracle import parity
@@ -41,9 +42,10 @@ def test_full_minibatch_at_benchmark_shape_vs_oracle(workload, frames):
     ppo_cfg = cfg.habitat_baselines.rl.ppo
     agent = trainer._agent
     st = agent.rollouts
-    assert (trainer.envs.num_envs, ppo_cfg.num_steps, ppo_cfg.hidden_size) == (64, 128, 512)
+    N, T = (32, 64) if workload == "c5" else (64, 128)  # C5 = BASELINE.json configs[4] per GPU: ObjectNav ResNet50, 5 visual channels
+    assert (trainer.envs.num_envs, ppo_cfg.num_steps, ppo_cfg.hidden_size) == (N, T, 512)
     agent.eval()
-    assert trainer.collect_rollout() == 64 * 128
+    assert trainer.collect_rollout() == N * T
     last = st.get_last_step()
     nv = agent.actor_critic.get_value({k: v.contiguous() for k, v in last["observations"].items()}, last["recurrent_hidden_states"],
                                       last["prev_actions"], last["masks"])

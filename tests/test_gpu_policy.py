@@ -1,6 +1,7 @@
 """GPU parity of the policy engine / Python plugin layer against (a) the golden fixtures produced by the
 real reference and (b) the CPU oracle, on the same deterministic inputs.  Tolerances: 1e-4 relative on
 values / losses / gradients / updated parameters (BASELINE.json), bit-exact sampled actions."""
+import json
 import os
 import types
 
@@ -76,9 +77,24 @@ def cfg_of(c):
     return make_cfg(**kw)
 
 
+MARGINS = {}  # test id -> largest (error / tolerance) any rel_ok check of that test saw; written to gpurun_out/parity_margins.json
+
+
 def rel_ok(got, ref, tol=1e-4, floor=1e-3):
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
-    return np.abs(got - ref).max() <= tol * max(floor, np.abs(ref).max())
+    err = np.abs(got - ref).max() / max(floor, np.abs(ref).max())
+    tid = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    MARGINS[tid] = max(MARGINS.get(tid, 0.0), float(err / tol))
+    return err <= tol
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_margins():
+    yield
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "parity_margins.json"), "w") as f:
+        json.dump({"what": "largest observed error / tolerance per test (1.0 = at the limit)", "tests": MARGINS}, f, indent=1)
 
 
 @pytest.mark.parametrize("case", list(CASES))
@@ -209,10 +225,10 @@ def test_minibatch_forward_loss_backward_vs_reference_golden(case):
                           or k.startswith("action_") or k.startswith("critic") or (case == "resnet18_rgbd256" and "layer4" in k))
             if case.startswith("gaussian"):
                 downstream = "backbone" not in k
-            lim = 2e-4 if downstream else 2e-2
+            lim = 1e-4 if downstream else 2e-2
             if err > lim or nerr > lim:
                 bad.append((k, err, nerr))
-        elif not rel_ok(got, ref, tol=2e-4, floor=1e-4):
+        elif not rel_ok(got, ref, tol=1e-4, floor=1e-4):
             bad.append((k, float(np.abs(got - ref).max()), float(np.abs(ref).max())))
     assert not bad, f"gradient mismatch: {bad}"
 
@@ -346,7 +362,9 @@ def test_full_ppo_update_vs_reference_golden(case, monkeypatch):
         # losses: 1e-4 (BASELINE.json).  In the deep-encoder fixture the remaining learner statistics are taken after Adam
         # steps driven by gradients that contain legitimate ReLU-boundary flips (see the minibatch test): 1e-3 there.
         tol = 1e-4 if (not c.get("sampled") or c.get("exact") or k in ("value_loss", "action_loss", "dist_entropy")) else 1e-3
-        assert abs(val - ref) <= tol * max(1.0, abs(ref)), (k, val, ref)
+        # true relative error, with an absolute floor of 1e-6 for statistics that are themselves ~0 (e.g. ppo_fraction_clipped = 0)
+        MARGINS[os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0] + ":" + k] = abs(val - ref) / max(tol * abs(ref), 1e-6)
+        assert abs(val - ref) <= max(tol * abs(ref), 1e-6), (k, val, ref)
     samp = golden_sample if c.get("sampled") else (lambda a: a)
     for k, v in pol.state_dict().items():
         ref = z["post/" + k]
@@ -382,7 +400,7 @@ def test_autograd_bridge_matches_fused_path():
     assert np.allclose(np.array([vl.item(), al.item(), de.item(), total.item()]), z["mb0_losses"], rtol=1e-4, atol=1e-6)
     for k, p_ in pol.named_parameters():
         ref = z["grad/" + k]
-        assert rel_ok(p_.grad.cpu().numpy(), ref, tol=2e-4, floor=1e-4), k
+        assert rel_ok(p_.grad.cpu().numpy(), ref, tol=1e-4, floor=1e-4), k
 
 
 @pytest.mark.parametrize("rnn_type,layers,hidden", [("LSTM", 2, 64), ("GRU", 2, 64), ("GRU", 1, 512), ("LSTM", 1, 256)])
@@ -423,7 +441,7 @@ def test_engine_lstm_gru_multilayer_vs_oracle(rnn_type, layers, hidden):
     assert rel_ok(hf.cpu().numpy(), hfin.detach().numpy())
     eng.backward(rgb.cuda(), depth.cuda(), goal.cuda(), None, actions.cuda(), pack, gv.view(-1).cuda(), glp.view(-1).cuda(), gent.view(-1).cuda())
     bad = [(k, float((g.cpu() - p[k].grad).abs().max()), float(p[k].grad.abs().max())) for k, g in eng.grad_views.items()
-           if not rel_ok(g.cpu().numpy(), p[k].grad.numpy(), tol=2e-4, floor=1e-4)]
+           if not rel_ok(g.cpu().numpy(), p[k].grad.numpy(), tol=1e-4, floor=1e-4)]
     assert not bad, bad
 
 
@@ -437,6 +455,13 @@ RESNET_VARIANTS = [  # backbone, rnn, layers, H, W, visual key order, normalize
     ("se_resnet50", "GRU", 1, 128, 128, ("rgb", "depth"), False),
     ("se_resneXt50", "LSTM", 1, 128, 128, ("rgb", "depth"), True),
     ("se_resneXt101", "GRU", 1, 64, 64, ("rgb", "depth"), False),
+    # odd / non-square observation sizes of the reference's test/test_baseline_resnet.py:22-73 (the 2x2 average pool floors,
+    # the stem's padded 4-channel input, conv_patch_bf3's TW selection with Wo < 32, chunked GroupNorm at odd extents)
+    ("resnet18", "GRU", 1, 62, 30, ("rgb", "depth"), True),
+    ("resnet18", "LSTM", 2, 63, 84, ("rgb", "depth"), False),
+    ("resnet50", "GRU", 1, 65, 30, ("rgb", "depth"), True),
+    ("resnet18", "GRU", 1, 66, 64, ("depth",), False),
+    ("resnet18", "GRU", 1, 100, 180, ("rgb", "depth"), True),
 ]
 
 
@@ -527,14 +552,14 @@ def test_resnet_engine_vs_oracle(backbone, rnn_type, layers, H, W, keys, normali
     for tap_id, name in ((6, "stem"), (7, "pool"), (9, "layer1"), (10, "layer2"), (11, "layer3"), (12, "layer4"), (8, "compression")):
         ref = nhwc(taps[name])
         got = eng.tap(tap_id).cpu().numpy().reshape(ref.shape)
-        assert rel_ok(got, ref, tol=2e-4), name
-    assert rel_ok(eng.tap(3).cpu().numpy().reshape(B, -1)[:, :hidden + 64], taps["rnn_in"].detach().numpy(), tol=2e-4), "rnn_in"
-    assert rel_ok(dv.cpu().numpy(), v.detach().numpy().reshape(-1), tol=2e-4)
-    assert rel_ok(dl.cpu().numpy(), lp.detach().numpy().reshape(-1), tol=2e-4)
-    assert rel_ok(de.cpu().numpy(), ent.detach().numpy().reshape(-1), tol=2e-4)
+        assert rel_ok(got, ref, tol=1e-4), name
+    assert rel_ok(eng.tap(3).cpu().numpy().reshape(B, -1)[:, :hidden + 64], taps["rnn_in"].detach().numpy(), tol=1e-4), "rnn_in"
+    assert rel_ok(dv.cpu().numpy(), v.detach().numpy().reshape(-1), tol=1e-4)
+    assert rel_ok(dl.cpu().numpy(), lp.detach().numpy().reshape(-1), tol=1e-4)
+    assert rel_ok(de.cpu().numpy(), ent.detach().numpy().reshape(-1), tol=1e-4)
     hf = torch.zeros(n, Lh, hidden, device="cuda")
     eng.final_hidden(hf)
-    assert rel_ok(hf.cpu().numpy(), hfin.detach().numpy(), tol=2e-4)
+    assert rel_ok(hf.cpu().numpy(), hfin.detach().numpy(), tol=1e-4)
     if normalize:
         sd = pol.state_dict()
         for k in ("mean", "var", "count"):
@@ -542,7 +567,7 @@ def test_resnet_engine_vs_oracle(backbone, rnn_type, layers, H, W, keys, normali
     eng.backward(cu(obs.get("rgb")), cu(obs.get("depth")), obs[GOAL].cuda(), None, actions.cuda(), pack, gv.view(-1).cuda(),
                  glp.view(-1).cuda(), gent.view(-1).cuda(), prev_actions=prev_actions.cuda())
     bad = [(k, float((g.cpu() - p[k].grad).abs().max()), float(p[k].grad.abs().max())) for k, g in eng.grad_views.items()
-           if not is_buffer(k) and not rel_ok(g.cpu().numpy(), p[k].grad.numpy(), tol=3e-4, floor=1e-4)]
+           if not is_buffer(k) and not rel_ok(g.cpu().numpy(), p[k].grad.numpy(), tol=1e-4, floor=1e-4)]
     assert not bad, bad
     # eval mode: statistics frozen, act() on n envs equals the oracle
     pol.eval()
@@ -555,8 +580,8 @@ def test_resnet_engine_vs_oracle(backbone, rnn_type, layers, H, W, keys, normali
     with torch.no_grad():
         ref = O.act(pp, spec, {k: v[:n] for k, v in obs.items()}, h0, prev_actions[:n], masks[:n], exp_noise=noise)
     assert torch.equal(ad.actions.cpu(), ref["actions"])
-    assert rel_ok(ad.values.cpu().numpy(), ref["values"].numpy(), tol=2e-4)
-    assert rel_ok(ad.rnn_hidden_states.cpu().numpy(), ref["rnn_hidden_states"].numpy(), tol=2e-4)
+    assert rel_ok(ad.values.cpu().numpy(), ref["values"].numpy(), tol=1e-4)
+    assert rel_ok(ad.rnn_hidden_states.cpu().numpy(), ref["rnn_hidden_states"].numpy(), tol=1e-4)
     for k, v0 in before.items():
         assert torch.equal(pol.state_dict()[k], v0), "RunningMeanAndVar must not change in eval mode"
 
@@ -748,7 +773,7 @@ def test_frozen_encoder_visual_features_vs_oracle(backbone, rnn_type, layers):
     assert tuple(pol.visual_encoder.output_shape) == tuple(ref_feats.shape[1:])
     buf0 = {k: v.clone() for k, v in pol.state_dict().items() if is_buffer(k)}
     feats = pol.visual_encoder({k: v.cuda() for k, v in obs.items()})
-    assert rel_ok(feats.cpu().numpy(), ref_feats.numpy(), tol=2e-4)
+    assert rel_ok(feats.cpu().numpy(), ref_feats.numpy(), tol=1e-4)
     for k, v0 in buf0.items():
         assert torch.equal(pol.state_dict()[k], v0)
     # (2) training step on stored features: the oracle consumes the SAME features, so everything downstream is comparable at 1e-4

@@ -74,11 +74,11 @@ def test_pmc_sq_table(tmp_path):
 
 
 def test_staged_wave_specialised_schedule_model():
-    """tools/experiments: the barrier schedule of the staged producer / consumer kernels (not part of the product) is replayed on the
+    """tools/ws_schedule_model.py: the barrier schedule of the producer / consumer kernels (csrc/igemm_bf3_ws.h, obs_conv_bf3_ws.h) is replayed on the
     CPU for every k-tile count: equal barrier counts in both roles, no image written while read, register sets / key buffers hold
     what their readers expect."""
     import runpy
-    mod = runpy.run_path(os.path.join(ROOT, "tools", "experiments", "ws_schedule_model.py"))
+    mod = runpy.run_path(os.path.join(ROOT, "tools", "ws_schedule_model.py"))
     for ksh in (False, True):
         for ntk in range(0, 24):
             mod["check"](ntk, ksh)

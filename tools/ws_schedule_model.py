@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Model of the barrier schedule of igemm_bf3_ws.h (tools/experiments/bf3_wave_specialised.patch): replays the producer and the consumer
+"""Model of the barrier schedule of igemm_bf3_ws.h (habitat-lab_amd/csrc/igemm_bf3_ws.h): replays the producer and the consumer
 program of one workgroup as two instruction lists cut at their barriers, executes them phase by phase (everything between barrier n and
 barrier n + 1 of BOTH roles is concurrent) and checks, for every ntk:
   * both roles execute the same number of barriers;
@@ -7,7 +7,7 @@ barrier n + 1 of BOTH roles is concurrent) and checks, for every ntk:
   * a gather of register set s is never issued while set s still holds a k-tile that has not been staged, and stage(kt) finds kt in its set;
   * shared gather keys: fetch(kt) reads key buffer kt % 3 holding keys(kt), written in an EARLIER phase; no write to a buffer that is
     read in the same phase.
-usage: python tools/experiments/ws_schedule_model.py   (prints OK)"""
+usage: python tools/ws_schedule_model.py   (prints OK)"""
 
 
 def producer(ntk, ksh):
