@@ -385,7 +385,7 @@ def ver_case():
 
 
 def main():
-    torch.set_num_threads(4)  # EVERY branch: the fixtures must not depend on how the script was invoked (summation order of ATen's CPU kernels)
+    torch.set_num_threads(int(os.environ.get("HAB_GOLDEN_THREADS", "4")))  # EVERY branch: the fixtures must not depend on how the script was invoked (summation order of ATen's CPU kernels)
     if len(sys.argv) > 1 and sys.argv[1] == "se-seeds":  # margin scan used to choose SE_SEED below
         ns = load_reference()
         for seed in range(int(sys.argv[2]), int(sys.argv[3])):
@@ -446,7 +446,7 @@ def main():
     se_resnext_case(ns)
 
 
-SE_SEED = 61
+SE_SEED = 124  # of seeds 0..699 the one whose smallest |pre-ReLU| over the stored minibatch is largest (3.9e-6; `make_golden.py se-seeds`)
 
 
 def se_resnext_case(ns, seed=None, margin_only=False):

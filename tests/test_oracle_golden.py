@@ -101,7 +101,7 @@ CASES = {
                                    cfg=dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2,
                                             use_normalized_advantage=False, use_clipped_value_loss=True)),
     # se_resneXt50 (grouped 3x3 convolutions + squeeze-and-excitation gates), 1-layer GRU, 128x128 RGB-D
-    "se_resnext50_rgbd128": dict(kind="resnet", backbone="se_resneXt50", H=128, W=128, rgb=True, depth=True, T=3, N=2, seed=61, hidden=64,
+    "se_resnext50_rgbd128": dict(kind="resnet", backbone="se_resneXt50", H=128, W=128, rgb=True, depth=True, T=3, N=2, seed=124, hidden=64,
                                  sampled=True, rnn=("GRU", 1),
                                  cfg=dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.2,
                                           use_normalized_advantage=False, use_clipped_value_loss=True)),
