@@ -256,7 +256,10 @@ __global__ void __launch_bounds__(512) obs_conv_bf3_ws_kernel(const ObsConvFwdPr
                 v[0] = acc[0][0][4 * g]; v[1] = acc[0][0][4 * g + 1]; v[2] = acc[0][0][4 * g + 2]; v[3] = acc[0][0][4 * g + 3];
                 v += *reinterpret_cast<const f32x4*>(biasL + n);
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                if (erow.ok && n + 3 < p.N) *reinterpret_cast<f32x4*>(p.y + erow.base + n) = v;
+                if (erow.ok && n + 3 < p.N) {
+                    if (p.y) *reinterpret_cast<f32x4*>(p.y + erow.base + n) = v;
+                    if (p.ypl) pl_store4(p.ypl, erow.base + n, v);
+                }
             }
         }
 #pragma unroll

@@ -68,6 +68,10 @@ SIGNATURES = {
     "hab_sample_actions": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
     "hab_set_matrix_path": (c_int, [c_int]),
     "hab_conv2d_fwd": (c_int, [vp, vp, vp, vp] + [c_int] * 10 + [vp, c_size_t, vp]),
+    "hab_pl_split": (c_int, [vp, c_int64, c_int, c_int, vp, vp]),
+    "hab_pl_merge": (c_int, [vp, c_int64, vp, vp]),
+    "hab_conv2d_fwd_pl": (c_int, [vp, vp, vp, vp, c_int, vp] + [c_int] * 10 + [vp, c_size_t, vp]),
+    "hab_conv2d_dgrad_pl": (c_int, [vp, vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
     "hab_obs_conv2d_fwd": (c_int, [vp, vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
     "hab_conv2d_dgrad": (c_int, [vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
     "hab_conv2d_wgrad": (c_int, [vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),

@@ -168,10 +168,36 @@ int hab_sample_actions(const float* probs, const float* exp_noise, int64_t* acti
  *     bit 2  problems with an i/j-contiguous operand (weight gradients, Linear dgrad): register-transposed staging
  *     bit 3  prefer bit 2's kernel over the fp32 patch / LDS-DMA weight-gradient kernels
  *     bit 4  stride-1 3x3 convolutions with N = 32 (fwd + dgrad): input patch resident in LDS (conv_patch_bf3.h)
- *   Default 31 (all), env HAB_BF3 overrides.  hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one;
+ *     bit 5  producer / consumer waves where they measured faster (igemm_bf3_ws.h: 128 x 128 forward-form tiles with K >= 2048;
+ *            obs_conv_bf3_ws.h: the observation-ingest convolution); bit-identical results
+ *   Default 63 (all), env HAB_BF3 overrides.  hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one;
  *   mode < 0 only queries.  Results are fp32-equivalent on either path (tests/test_gpu_bf3.py: error vs float64 of both).
  * ------------------------------------------------------------------------------------------- */
 int hab_set_matrix_path(int mode);
+
+/* -------------------------------------------------------------------------------------------
+ * pl32 operand planes (csrc/bf3_planes.h, igemm_pl.h) -- the producer-side form of the split-bf16 matrix path.
+ *   A tensor that is going to be a contraction operand (an NHWC activation with C % 32 == 0, a packed weight matrix with K % 32 == 0)
+ *   is stored ONCE as its three bf16 terms: every group of 32 consecutive logical elements becomes 192 bytes
+ *   [rn16(x) x 32 | rn16(x - p0) x 32 | (x - p0 - p1) x 32] (x = p0 + p1 + p2 exactly), and the consuming contraction copies the planes
+ *   global -> LDS by `buffer_load_dwordx4 ... lds` with no register or VALU work.  Same six partial products, same order, same sign
+ *   schedule and split-K plan as the consumer-side split (igemm_bf3.h): bit-identical results for one tile shape.
+ *   Replaces the same op chains as hab_conv2d_fwd / hab_conv2d_dgrad / hab_linear_fwd / hab_linear_dgrad below
+ *   (rl/models/simple_cnn.py:68-93,139-158 and their autograd): a Linear layer is the 1x1 convolution of a 1x1 image.
+ *     hab_pl_split   fp32 [rows][cols] (row stride ld, cols % 32 == 0) -> planes of the compact logical array; planes: 3*rows*cols uint16
+ *     hab_pl_merge   planes of n elements -> fp32 (exact)
+ *     hab_conv2d_fwd_pl    x planes (NHWC, C % 32 == 0), w_fwd planes ([Cout][KH*KW*C]); outputs: fp32 y (row stride ldy floats, 0 = Cout;
+ *                          may be null) and / or planes ypl (Cout % 32 == 0; may be null); bias, ReLU as hab_conv2d_fwd
+ *     hab_conv2d_dgrad_pl  dy planes, w_dgrad planes ([C][KH*KW*Cout]); ReLU mask from fp32 `relu_mask` or from the planes of the
+ *                          masking tensor `relu_mask_pl` (sign / zero of plane 0); outputs fp32 dx and / or planes dxpl (C % 32 == 0)
+ * ------------------------------------------------------------------------------------------- */
+int hab_pl_split(const float* x, int64_t rows, int cols, int ld, uint16_t* planes, hipStream_t stream);
+int hab_pl_merge(const uint16_t* planes, int64_t n, float* out, hipStream_t stream);
+int hab_conv2d_fwd_pl(const uint16_t* xpl, const uint16_t* w_fwd_pl, const float* bias, float* y, int ldy, uint16_t* ypl, int B, int H, int W,
+                      int C, int Cout, int KH, int KW, int stride, int pad, int relu, float* ws, size_t ws_floats, hipStream_t stream);
+int hab_conv2d_dgrad_pl(const uint16_t* dypl, const uint16_t* w_dgrad_pl, const float* relu_mask, const uint16_t* relu_mask_pl, float* dx,
+                        uint16_t* dxpl, int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                        size_t ws_floats, hipStream_t stream);
 int hab_conv2d_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int H, int W, int C, int Cout,
                    int KH, int KW, int stride, int pad, int relu, float* ws, size_t ws_floats, hipStream_t stream);
 int hab_obs_conv2d_fwd(const uint8_t* rgb, const float* depth, const int* rows, const float* w_fwd, const float* bias,

@@ -1,0 +1,208 @@
+"""pl32 operand planes (csrc/bf3_planes.h) and the DMA-staged contractions that consume them (csrc/igemm_pl.h), through the C ABI.
+
+* hab_pl_split / hab_pl_merge: the three planes are exactly rn16(x), rn16(x - p0), x - p0 - p1 (torch.bfloat16 rounds to nearest even
+  like v_cvt_pk_bf16_f32), their sum is x bit for bit, the layout is 32-element groups of [p0 | p1 | p2];
+* hab_conv2d_fwd_pl / hab_conv2d_dgrad_pl against float64 (same bound as the consumer-side split kernels, tests/test_gpu_bf3.py) and --
+  where the tile shape and split-K plan coincide -- BIT-identical to igemm_bf3_kernel (same products, same order, same sign schedule);
+* outputs as planes: merging them gives the fp32 output bit for bit; the ReLU mask read from planes equals the fp32 mask;
+* Linear as the 1x1 convolution of a 1x1 image, with an output row stride."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from habitat_amd import _lib
+
+pytestmark = pytest.mark.gpu
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.fixture(scope="module")
+def L():
+    return _lib.lib()
+
+
+def split(L, x2d):
+    """fp32 (rows, cols) cuda tensor -> int16 planes tensor (3 * rows * cols)"""
+    rows, cols = x2d.shape
+    out = torch.zeros(3 * rows * cols, dtype=torch.int16, device="cuda")
+    _lib.check(L.hab_pl_split(P(x2d), rows, cols, x2d.stride(0), P(out), S()))
+    return out
+
+
+def merge(L, planes, n):
+    out = torch.zeros(n, device="cuda")
+    _lib.check(L.hab_pl_merge(P(planes), n, P(out), S()))
+    return out
+
+
+def with_path(L, mode, fn):
+    prev = L.hab_set_matrix_path(-1)
+    try:
+        L.hab_set_matrix_path(mode)
+        return fn()
+    finally:
+        L.hab_set_matrix_path(prev)
+
+
+def err_vs(ref64, y):
+    ref = ref64.double()
+    return ((y.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+
+
+def test_split_is_the_exact_three_term_rounding_and_merge_restores_it(L):
+    torch.manual_seed(0)
+    rows, cols, ld = 37, 96, 100
+    x = (torch.randn(rows, ld) * torch.rand(rows, ld).pow(4) * 1e3).cuda()
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e-39, 65504.0, 1e-30, -7.5e20])  # zero, subnormal, large
+    xv = x[:, :cols]
+    pl = split(L, xv)
+    p0 = xv.bfloat16()
+    r1 = xv - p0.float()
+    p1 = r1.bfloat16()
+    p2 = (r1 - p1.float())
+    ok = ((xv.abs() > 1e-30) | (xv == 0))  # the terms of near-subnormal inputs fall into the subnormal range, where flushing is allowed to differ
+    assert torch.equal(p2[ok], p2.bfloat16().float()[ok]), "third term must be a bf16 exactly"
+    want = torch.stack([p0.view(torch.int16).view(rows * cols // 32, 32), p1.view(torch.int16).view(-1, 32),
+                        p2.bfloat16().view(torch.int16).view(-1, 32)], 1)  # (groups, 3, 32)
+    got = pl.view(-1, 3, 32)
+    normal = (xv.abs() > 1e-30).view(-1, 32).unsqueeze(1).expand_as(got) | (xv == 0).view(-1, 32).unsqueeze(1).expand_as(got)
+    assert torch.equal(got[normal], want[normal])
+    back = merge(L, pl, rows * cols).view(rows, cols)
+    assert torch.equal(back[ok], xv[ok])
+
+
+def conv_weights(Cout, Cin, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / np.sqrt(Cin * K * K)
+    wf = w.permute(0, 2, 3, 1).contiguous().cuda()   # [Cout][KH][KW][Cin]
+    wd = w.permute(1, 2, 3, 0).contiguous().cuda()   # [Cin][KH][KW][Cout]
+    return w, wf, wd
+
+
+FWD_CASES = [  # B, H, W, Cin, Cout, K, stride, pad, bit-identical to igemm_bf3 expected (same tile shape / split-K plan)
+    (8, 63, 63, 32, 64, 4, 2, 0, True),      # SimpleCNN conv2
+    (3, 30, 30, 64, 32, 3, 1, 0, False),     # SimpleCNN conv3 (N = 32: 128-row tile here, 256-row there)
+    (16, 16, 16, 64, 64, 3, 1, 1, True),     # ResNet layer2 3x3, zero padding through the buffer range check
+    (70, 4, 4, 256, 256, 3, 1, 1, True),     # ResNet layer4, 128 x 128 tiles
+    (5, 9, 7, 32, 96, 3, 2, 1, False),       # odd extents, stride 2 with padding, N = 96 (partial last column tile)
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cc,Cout,K,s,p,exact", FWD_CASES)
+def test_conv_fwd_on_planes(L, B, H, W, Cc, Cout, K, s, p, exact):
+    torch.manual_seed(1)
+    x = torch.randn(B, H, W, Cc) * torch.rand(B, H, W, Cc).pow(4) * 50
+    w, wf, _ = conv_weights(Cout, Cc, K, 2)
+    b = torch.randn(Cout)
+    ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=s, padding=p)).permute(0, 2, 3, 1)
+    xd, bd = x.cuda(), b.cuda()
+    ws = torch.zeros(1 << 22, device="cuda")
+    xpl, wpl = split(L, xd.view(-1, Cc)), split(L, wf.view(Cout, -1))
+    Ho, Wo = ref.shape[1:3]
+    y = torch.zeros(B, Ho, Wo, Cout, device="cuda")
+    ypl = torch.zeros(3 * y.numel(), dtype=torch.int16, device="cuda") if Cout % 32 == 0 else None
+    _lib.check(L.hab_conv2d_fwd_pl(P(xpl), P(wpl), P(bd), P(y), 0, P(ypl), B, H, W, Cc, Cout, K, K, s, p, 1, P(ws), ws.numel(), S()))
+
+    def old():
+        y0 = torch.zeros_like(y)
+        _lib.check(L.hab_conv2d_fwd(P(xd), P(wf), P(bd), P(y0), B, H, W, Cc, Cout, K, K, s, p, 1, P(ws), ws.numel(), S()))
+        return y0
+
+    y_bf3, y_f32 = with_path(L, 7, old), with_path(L, 0, old)  # igemm_bf3_kernel / fp32 MFMA
+    e_pl, e_f32 = err_vs(ref, y), err_vs(ref, y_f32)
+    assert e_pl <= 2 * e_f32 + 2e-7 and e_pl < 3e-6, (e_pl, e_f32)
+    if exact:
+        assert torch.equal(y, y_bf3)
+    if ypl is not None:
+        assert torch.equal(merge(L, ypl, y.numel()).view_as(y), y), "planes output must be the split of the fp32 output"
+
+
+def test_conv_fwd_planes_only_output_and_chaining(L):
+    """conv2 -> conv3 of SimpleCNN with NO fp32 activation in between: conv2 writes planes only, conv3 reads them."""
+    torch.manual_seed(3)
+    B = 4
+    x = torch.randn(B, 63, 63, 32).abs().cuda()
+    w2, wf2, _ = conv_weights(64, 32, 4, 5)
+    w3, wf3, _ = conv_weights(32, 64, 3, 6)
+    b2, b3 = torch.randn(64).cuda(), torch.randn(32).cuda()
+    ws = torch.zeros(1 << 22, device="cuda")
+    a2pl = torch.zeros(3 * B * 30 * 30 * 64, dtype=torch.int16, device="cuda")
+    _lib.check(L.hab_conv2d_fwd_pl(P(split(L, x.view(-1, 32))), P(split(L, wf2.view(64, -1))), P(b2), None, 0, P(a2pl), B, 63, 63, 32, 64, 4, 4,
+                                   2, 0, 1, P(ws), ws.numel(), S()))
+    y3 = torch.zeros(B, 28, 28, 32, device="cuda")
+    _lib.check(L.hab_conv2d_fwd_pl(P(a2pl), P(split(L, wf3.view(32, -1))), P(b3), P(y3), 0, None, B, 30, 30, 64, 32, 3, 3, 1, 0, 0, P(ws),
+                                   ws.numel(), S()))
+    a2 = F.relu(F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), w2.double(), b2.cpu().double(), stride=2))
+    ref = F.conv2d(a2, w3.double(), b3.cpu().double()).permute(0, 2, 3, 1)
+    assert err_vs(ref, y3) < 3e-6
+
+
+def test_linear_as_1x1_convolution_with_row_stride(L):
+    """fc 25088 -> 512 forward into a concat buffer (ldy = 516) and its data gradient (weights transposed at repack) on planes."""
+    torch.manual_seed(4)
+    M, N, K, ldy = 300, 512, 25088, 516
+    x = (torch.randn(M, K) * torch.rand(M, K).pow(3) * 10)
+    w = torch.randn(N, K) * 0.01
+    b = torch.randn(N)
+    ref = F.relu(x.double() @ w.double().t() + b.double())
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    ws = torch.zeros(1 << 24, device="cuda")
+    y = torch.full((M, ldy), 7.0, device="cuda")
+    _lib.check(L.hab_conv2d_fwd_pl(P(split(L, xd)), P(split(L, wd)), P(bd), P(y), ldy, None, M, 1, 1, K, N, 1, 1, 1, 0, 1, P(ws), ws.numel(), S()))
+    assert err_vs(ref, y[:, :N]) < 3e-6
+    assert torch.all(y[:, N:] == 7.0), "columns beyond N are not touched"
+
+    def old():
+        y0 = torch.zeros(M, N, device="cuda")
+        _lib.check(L.hab_linear_fwd(P(xd), K, P(wd), K, P(bd), P(y0), N, M, N, K, 1, 0, P(ws), ws.numel(), S()))
+        return y0
+
+    assert torch.equal(y[:, :N].contiguous(), with_path(L, 31, old)), "same tile, same split-K plan as igemm_bf3_kernel: same bits"
+    # data gradient: dx[m][k] = sum_n dy[m][n] W[n][k] = forward form with the transposed weight, planes out
+    dy = torch.randn(M, N).cuda()
+    wt = wd.t().contiguous()
+    dxpl = torch.zeros(3 * M * K, dtype=torch.int16, device="cuda")
+    _lib.check(L.hab_conv2d_fwd_pl(P(split(L, dy)), P(split(L, wt)), None, None, 0, P(dxpl), M, 1, 1, N, K, 1, 1, 1, 0, 0, P(ws), ws.numel(), S()))
+    assert err_vs(dy.cpu().double() @ w.double(), merge(L, dxpl, M * K).view(M, K)) < 3e-6
+
+
+DGRAD_CASES = [  # B, H, W, Cin, Cout, K, stride, pad
+    (8, 63, 63, 32, 64, 4, 2, 0),    # SimpleCNN conv2: merged stride classes, N = 128, depth-to-space epilogue
+    (3, 30, 30, 64, 32, 3, 1, 0),    # SimpleCNN conv3
+    (16, 16, 16, 64, 64, 3, 1, 1),
+    (6, 17, 15, 32, 64, 3, 2, 1),    # stride classes that are NOT merged (3 % 2 != 0): per-class launches
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cc,Cout,K,s,p", DGRAD_CASES)
+def test_conv_dgrad_on_planes_with_mask_from_planes(L, B, H, W, Cc, Cout, K, s, p):
+    torch.manual_seed(7)
+    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    dy = torch.randn(B, Ho, Wo, Cout) * torch.rand(B, Ho, Wo, Cout).pow(3) * 10
+    w, _, wd = conv_weights(Cout, Cc, K, 8)
+    xin = F.relu(torch.randn(B, H, W, Cc))  # the layer's (post-ReLU) input: ~half the mask is zero
+    ref = torch.nn.grad.conv2d_input((B, Cc, H, W), w.double(), dy.permute(0, 3, 1, 2).double(), stride=s, padding=p).permute(0, 2, 3, 1)
+    ref = ref * (xin > 0).double()
+    dyd, xd = dy.cuda(), xin.cuda()
+    ws = torch.zeros(1 << 22, device="cuda")
+    dypl, wdpl, mpl = split(L, dyd.view(-1, Cout)), split(L, wd.view(Cc, -1)), split(L, xd.view(-1, Cc))
+    dx = torch.zeros(B, H, W, Cc, device="cuda")
+    dxpl = torch.zeros(3 * dx.numel(), dtype=torch.int16, device="cuda")
+    _lib.check(L.hab_conv2d_dgrad_pl(P(dypl), P(wdpl), None, P(mpl), P(dx), P(dxpl), B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S()))
+
+    def old():
+        d0 = torch.zeros_like(dx)
+        _lib.check(L.hab_conv2d_dgrad(P(dyd), P(wd), P(xd), None, P(d0), B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S()))
+        return d0
+
+    e_pl, e_f32 = err_vs(ref, dx), err_vs(ref, with_path(L, 0, old))
+    assert e_pl <= 2 * e_f32 + 2e-7 and e_pl < 3e-6, (e_pl, e_f32)
+    assert torch.equal(merge(L, dxpl, dx.numel()).view_as(dx), dx)
+    # the fp32 mask and the planes mask select the same elements
+    dx2 = torch.zeros_like(dx)
+    _lib.check(L.hab_conv2d_dgrad_pl(P(dypl), P(wdpl), P(xd), None, P(dx2), None, B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S()))
+    assert torch.equal(dx, dx2)
