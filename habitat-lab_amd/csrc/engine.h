@@ -55,6 +55,11 @@ struct hab_policy {
     int64_t ws_floats = 0;
     int last_B = 0, last_n = 0;
     const uint8_t* last_masks = nullptr;
+    // time-major chunked recurrence (rnn.hip, engine.hip): second stream, its events and its private scratch
+    hipStream_t s2 = nullptr;
+    std::vector<hipEvent_t> evs;
+    int64_t w_ws2 = -1, ws2_floats = 0, w_fmask = -1, w_iota = -1;
+    int last_tm = 0;  // the last evaluate ran the time-major form with this many chunks (0: packed form)
     // ResNet policy (engine_resnet.hip)
     struct ResNetPlan* rn = nullptr;
     int training = 1;                                   // nn.Module.train()/eval(): RunningMeanAndVar updates only in training

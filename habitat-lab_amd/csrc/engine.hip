@@ -93,6 +93,11 @@ static int build_baseline(hab_policy* e) {
     // split-K / column-sum scratch: big enough for 64 slabs of the largest weight-gradient (fc) or 1024 colsum rows
     e->ws_floats = std::max<int64_t>((int64_t)16 << 20, (int64_t)8 * H * e->fc_in / 4);
     e->w_ws = wk.take(e->ws_floats);
+    // second stream of the time-major chunked recurrence: its own split-K scratch, the dense per-frame episode-start mask, an iota
+    e->ws2_floats = e->ws_floats;  // same cap as the first stream's: the split-K plans (hence the bits) must not depend on the stream
+    e->w_ws2 = wk.take(e->ws2_floats);
+    e->w_fmask = wk.take((B + 3) / 4 + 64);
+    e->w_iota = wk.take(B + 64);
     e->work_floats = wk.used;
     return HAB_OK;
 }
@@ -119,6 +124,8 @@ extern "C" int hab_policy_create(const hab_policy_desc* desc, hab_policy** out) 
 extern "C" void hab_policy_destroy(hab_policy* e) {
     if (!e) return;
     for (auto& ev : e->probe_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : e->evs) (void)hipEventDestroy(ev);
+    if (e->s2) (void)hipStreamDestroy(e->s2);
     destroy_resnet(e);
     delete e;
 }
@@ -230,29 +237,60 @@ extern "C" int hab_policy_probe_read_tag(hab_policy* e, int tag, double* total_m
 // ------------------------------------------------------------------------------------------
 // Encoder forward on B frames (shared by act / evaluate): obs -> rnn_in[B][rnn_ld]
 // ------------------------------------------------------------------------------------------
-static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s) {
+// f0 / nB: frames [f0, f0 + nB) of the minibatch only (the time-major chunked evaluate); rows may be null (dense frames: act)
+static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s, int f0 = 0, int nB = -1) {
     if (e->rn) { Probe pr(e, HAB_PROBE_ENC_FWD, s); return resnet_encoder_forward(e, obs, masks, rows, B, s); }
+    if (nB < 0) nB = B;
     float* W = e->WK;
     float* ws = W + e->w_ws;
     const int H = e->d.hidden;
+    const int64_t m1 = (int64_t)e->c1.Ho() * e->c1.Wo() * 32, m2 = (int64_t)e->c2.Ho() * e->c2.Wo() * 64, m3 = e->fc_in;
+    float *a1 = W + e->w_a1 + f0 * m1, *a2 = W + e->w_a2 + f0 * m2, *a3 = W + e->w_a3 + f0 * m3, *rin = W + e->w_rnnin + (int64_t)f0 * e->rnn_ld;
+    const int* rws = rows ? rows + f0 : nullptr;
+    if (!rows && f0) return HAB_ERR_ARG;
     ObsView ov;
-    ov.rgb = e->d.has_rgb ? obs->rgb : nullptr; ov.depth = e->d.has_depth ? obs->depth : nullptr; ov.rows = rows;
+    ov.rgb = e->d.has_rgb ? obs->rgb : nullptr; ov.depth = e->d.has_depth ? obs->depth : nullptr; ov.rows = rws;
     ov.H = e->d.H; ov.W = e->d.W; ov.C = e->Cin;
     ConvDesc c1 = e->c1, c2 = e->c2, c3 = e->c3;
-    c1.B = c2.B = c3.B = B;
+    c1.B = c2.B = c3.B = nB;
     { Probe pr(e, HAB_PROBE_CONV1_FWD, s);
-      HAB_TRY(obs_conv_fwd(c1, ov, e->PK + e->pk_c1f, e->p(e->i_c1b), W + e->w_a1, 1, ws, e->ws_floats, s)); }
+      HAB_TRY(obs_conv_fwd(c1, ov, e->PK + e->pk_c1f, e->p(e->i_c1b), a1, 1, ws, e->ws_floats, s)); }
     { Probe pr(e, HAB_PROBE_CONV2_FWD, s);
-      HAB_TRY(conv_fwd(c2, W + e->w_a1, e->PK + e->pk_c2f, e->p(e->i_c2b), W + e->w_a2, 1, ws, e->ws_floats, s)); }
+      HAB_TRY(conv_fwd(c2, a1, e->PK + e->pk_c2f, e->p(e->i_c2b), a2, 1, ws, e->ws_floats, s)); }
     { Probe pr(e, HAB_PROBE_CONV3_FWD, s);
-      HAB_TRY(conv_fwd(c3, W + e->w_a2, e->PK + e->pk_c3f, e->p(e->i_c3b), W + e->w_a3, 0, ws, e->ws_floats, s)); }
+      HAB_TRY(conv_fwd(c3, a2, e->PK + e->pk_c3f, e->p(e->i_c3b), a3, 0, ws, e->ws_floats, s)); }
     { Probe pr(e, HAB_PROBE_FC_FWD, s);
-      HAB_TRY(linear_fwd(W + e->w_a3, e->fc_in, e->PK + e->pk_fc, e->fc_in, e->p(e->i_fcb), W + e->w_rnnin, e->rnn_ld, B, H,
-                         e->fc_in, 1, 0, ws, e->ws_floats, s)); }
+      HAB_TRY(linear_fwd(a3, e->fc_in, e->PK + e->pk_fc, e->fc_in, e->p(e->i_fcb), rin, e->rnn_ld, nB, H, e->fc_in, 1, 0, ws, e->ws_floats, s)); }
     if (e->d.goal_dim > 0)
-        HAB_TRY(gather_cols(obs->goal, e->d.goal_dim, rows, W + e->w_rnnin, e->rnn_ld, H, e->d.goal_dim,
-                            e->rnn_ld - e->rnn_in, B, s));
+        HAB_TRY(gather_cols(obs->goal, e->d.goal_dim, rws, rin, e->rnn_ld, H, e->d.goal_dim, e->rnn_ld - e->rnn_in, nB, s));
     return HAB_OK;
+}
+
+// ---- time-major chunked recurrence: second stream + events ----
+static int tm_chunks_cfg() { static const int v = hab_env_int("HAB_RNN_CHUNKS", 4); return v; }
+static int tm_setup(hab_policy* e, int nev) {
+    if (!e->s2) {
+        // highest priority: the recurrence is a chain of ~7 us launches; each must be dispatched ahead of the queued waves of the large
+        // contraction running beside it, or the chain inherits that kernel's tail
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        hipError_t err = hipStreamCreateWithPriority(&e->s2, hipStreamNonBlocking, hi);
+        if (err != hipSuccess) return (int)err;
+    }
+    while ((int)e->evs.size() < nev) {
+        hipEvent_t ev;
+        hipError_t err = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (err != hipSuccess) return (int)err;
+        e->evs.push_back(ev);
+    }
+    return HAB_OK;
+}
+// everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
+static int tm_order(hab_policy* e, int ev, hipStream_t from, hipStream_t to) {
+    hipError_t err = hipEventRecord(e->evs[ev], from);
+    if (err != hipSuccess) return (int)err;
+    err = hipStreamWaitEvent(to, e->evs[ev], 0);
+    return err == hipSuccess ? HAB_OK : (int)err;
 }
 
 static RnnLayerParams layer_params(hab_policy* e, int l) {
@@ -358,13 +396,54 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
     if (pack->P != B || pack->F <= 0 || pack->F > B || pack->max_len <= 0) return HAB_ERR_ARG;
     float* W = e->WK;
     const int H = e->d.hidden, L = e->L;
+    // Time-major chunked form (rnn.hip): a regular T x n minibatch of the SimpleCNN policy is cut into time chunks; the encoder of
+    // chunk c + 1 runs on `stream` while the recurrence walks chunk c on the engine's second stream.  Bit-identical to the packed form.
+    const int T = B / n;
+    int NC = (!e->rn && rows && !pack->env_first_frame && (B % n) == 0 && T >= 2 && e->w_ws2 >= 0 && (int64_t)L * 2 * n <= 3 * (int64_t)e->d.max_frames)
+                 ? tm_chunks_cfg() : 0;
+    if (NC > T) NC = T;
+    const float* x = W + e->w_rnnin;
+    int ldx = e->rnn_ld;
+    if (NC > 0) {
+        HAB_TRY(tm_setup(e, 2 * NC + 4));
+        hipStream_t sB = e->s2;
+        uint8_t* fmask = reinterpret_cast<uint8_t*>(W + e->w_fmask);
+        int* iota = reinterpret_cast<int*>(W + e->w_iota);
+        HAB_TRY(rnn_tm_prepare(masks, rows, B, fmask, iota, stream));
+        for (int l = 0; l < L; ++l) {  // state entering t = 0: env j of the minibatch is frame j; its arena row is rows[j]
+            HAB_TRY(rnn_frag_init(hidden0 + (size_t)l * H, rows, hidden_env_stride, masks, rows, nullptr, nullptr, n, H,
+                                  W + e->w_hinit + (size_t)l * n * H, stream, nullptr));
+            if (e->d.rnn_type == HAB_RNN_LSTM)
+                HAB_TRY(rnn_frag_init(hidden0 + (size_t)(L + l) * H, rows, hidden_env_stride, masks, rows, nullptr, nullptr, n, H,
+                                      W + e->w_cinit + (size_t)l * n * H, stream, nullptr));
+        }
+        const int Tc = (T + NC - 1) / NC;
+        for (int c = 0; c < NC; ++c) {
+            const int t0 = c * Tc, t1 = std::min(T, t0 + Tc);
+            if (t0 >= t1) break;
+            HAB_TRY(encoder_forward(e, obs, masks, rows, B, stream, t0 * n, (t1 - t0) * n));
+            HAB_TRY(tm_order(e, c, stream, sB));  // also orders everything before this evaluate (parameters, pack info) ahead of stream B
+            const float* xl = W + e->w_rnnin;
+            int ldl = e->rnn_ld;
+            for (int l = 0; l < L; ++l) {
+                RnnLayerParams lp = layer_params(e, l);
+                RnnWork wk = layer_work(e, l);
+                Probe pr(e, HAB_PROBE_RNN_FWD, sB);
+                HAB_TRY(rnn_tm_layer_forward(e->d.rnn_type, H, lp, wk, xl, ldl, W + e->w_hinit + (size_t)l * n * H,
+                                             W + e->w_cinit + (size_t)l * n * H, fmask, n, t0, t1, W + e->w_ws2, e->ws2_floats, sB));
+                xl = wk.out;
+                ldl = H;
+            }
+        }
+        HAB_TRY(tm_order(e, NC, sB, stream));  // the heads (and everything after this evaluate) wait for the recurrence
+        x = W + e->w_out[L - 1];
+        ldx = H;
+    } else {
     HAB_TRY(encoder_forward(e, obs, masks, rows, B, stream));
     PackInfo pk;
     pk.select_inds = pack->select_inds; pk.step_offsets = pack->step_offsets_host; pk.num_seqs_at_step = pack->num_seqs_at_step_host;
     pk.frag_env = pack->frag_env; pk.frag_start = pack->frag_start; pk.P = pack->P; pk.F = pack->F; pk.max_len = pack->max_len;
     pk.n_envs = n;
-    const float* x = W + e->w_rnnin;
-    int ldx = e->rnn_ld;
     for (int l = 0; l < L; ++l) {
         float* hinit = W + e->w_hinit + (size_t)l * pk.F * H;
         float* cinit = W + e->w_cinit + (size_t)l * pk.F * H;
@@ -381,6 +460,8 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
         x = wk.out;
         ldx = H;
     }
+    }
+    e->last_tm = NC;
     if (e->d.action_dist == HAB_DIST_GAUSSIAN) {
         GaussHeadsArgs ga;
         ga.B = B; ga.H = H; ga.A = e->d.num_actions; ga.K = e->head_K; ga.flags = e->d.gauss_flags; ga.mode = 0;
@@ -460,6 +541,62 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
         HAB_TRY(colsum(W + e->w_dzv, 8, B, A, e->g(e->i_ab), 0, ws, e->ws_floats, stream));
         HAB_TRY(colsum(W + e->w_dv, 1, B, 1, e->g(e->i_cb), 0, ws, e->ws_floats, stream));
     }
+    ConvDesc c1 = e->c1, c2 = e->c2, c3 = e->c3;
+    c1.B = c2.B = c3.B = B;
+    const float* dfc = W + e->w_drnnin;
+    if (e->last_tm > 0 && !e->rn) {
+        // Time-major chunked backward: BPTT walks the chunks from the last to the first on the second stream; behind each chunk the
+        // DATA-gradient chain of its frames (fc, conv3, conv2 -- per-frame work) runs on `stream`; the weight gradients, which reduce over
+        // all frames, follow once at the end (the recurrent ones on the second stream, beside the encoder's).
+        const int n = e->last_n, T = B / n, NC = e->last_tm, Tc = (T + NC - 1) / NC;
+        hipStream_t sB = e->s2;
+        const uint8_t* fmask = reinterpret_cast<const uint8_t*>(W + e->w_fmask);
+        const int* iota = reinterpret_cast<const int*>(W + e->w_iota);
+        float* ws2 = W + e->w_ws2;
+        const int64_t m1 = (int64_t)e->c1.Ho() * e->c1.Wo() * 32, m2 = (int64_t)e->c2.Ho() * e->c2.Wo() * 64, m3 = e->fc_in;
+        HAB_TRY(tm_order(e, NC + 1, stream, sB));  // the head gradients are in place
+        for (int c = NC - 1; c >= 0; --c) {
+            const int t0 = c * Tc, t1 = std::min(T, t0 + Tc);
+            if (t0 >= t1) continue;
+            const int64_t f0 = (int64_t)t0 * n;
+            const int nB = (t1 - t0) * n;
+            for (int l = L - 1; l >= 0; --l) {
+                RnnLayerParams lp = layer_params(e, l);
+                RnnWork wk = layer_work(e, l);
+                const float* dout = l == L - 1 ? W + e->w_dfeat : W + e->w_dlayer[l + 1];
+                const float* xin = l == 0 ? W + e->w_rnnin : W + e->w_out[l - 1];
+                const int ldx = l == 0 ? e->rnn_ld : H;
+                float* dx = l == 0 ? W + e->w_drnnin : W + e->w_dlayer[l];
+                Probe pr(e, HAB_PROBE_RNN_BWD, sB);
+                HAB_TRY(rnn_tm_layer_backward(e->d.rnn_type, H, lp, wk, dout, dx, ldx, l == 0 ? xin : nullptr, ldx, H, fmask, iota, n, T, t0, t1,
+                                              W + e->w_scratch + (size_t)l * 2 * n * H, ws2, e->ws2_floats, sB));
+            }
+            HAB_TRY(tm_order(e, NC + 2 + c, sB, stream));  // d_rnnin of the chunk's frames is final
+            ConvDesc k2 = c2, k3 = c3;
+            k2.B = k3.B = nB;
+            { Probe pr(e, HAB_PROBE_FC_DGRAD, stream);
+              HAB_TRY(linear_dgrad(dfc + f0 * e->rnn_ld, e->rnn_ld, e->PK + e->pk_fc, e->fc_in, nullptr, 0, 0, W + e->w_da3 + f0 * m3, e->fc_in, nB,
+                                   e->fc_in, H, 0, ws, e->ws_floats, stream)); }
+            { Probe pr(e, HAB_PROBE_CONV3_DGRAD, stream);
+              HAB_TRY(conv_dgrad(k3, W + e->w_da3 + f0 * m3, e->PK + e->pk_c3d, W + e->w_a2 + f0 * m2, nullptr, W + e->w_da2 + f0 * m2, ws,
+                                 e->ws_floats, stream)); }
+            { Probe pr(e, HAB_PROBE_CONV2_DGRAD, stream);
+              HAB_TRY(conv_dgrad(k2, W + e->w_da2 + f0 * m2, e->PK + e->pk_c2d, W + e->w_a1 + f0 * m1, nullptr, W + e->w_da1 + f0 * m1, ws,
+                                 e->ws_floats, stream)); }
+        }
+        for (int l = L - 1; l >= 0; --l) {  // recurrent weight gradients over all frames: second stream, beside the encoder's below
+            RnnLayerParams lp = layer_params(e, l);
+            RnnWork wk = layer_work(e, l);
+            HAB_TRY(rnn_tm_layer_param_grads(e->d.rnn_type, H, lp, wk, l == 0 ? W + e->w_rnnin : W + e->w_out[l - 1], l == 0 ? e->rnn_ld : H, B, ws2,
+                                             e->ws2_floats, sB));
+        }
+        { Probe pr(e, HAB_PROBE_FC_WGRAD, stream);
+          HAB_TRY(linear_wgrad(dfc, e->rnn_ld, W + e->w_a3, e->fc_in, e->g(e->i_fcw), e->fc_in, B, H, e->fc_in, 32, e->fc_in / 32, 0,
+                               ws, e->ws_floats, stream)); }
+        HAB_TRY(colsum(dfc, e->rnn_ld, B, H, e->g(e->i_fcb), 0, ws, e->ws_floats, stream));
+        HAB_TRY(tm_order(e, 2 * NC + 3, sB, stream));  // recurrent gradients final before the tail of the arena is announced
+        grad_tail_ready(e, e->i_fcw);
+    } else {
     // recurrent layers, top down
     const float* dout = W + e->w_dfeat;
     for (int l = L - 1; l >= 0; --l) {
@@ -477,9 +614,6 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
     }
     if (e->rn) { Probe pr(e, HAB_PROBE_ENC_BWD, stream); return resnet_encoder_backward(e, obs, e->last_masks, rows, B, stream); }
     // fc (Flatten -> Linear -> ReLU): d_rnnin[:, :H] already carries the ReLU mask
-    const float* dfc = W + e->w_drnnin;
-    ConvDesc c1 = e->c1, c2 = e->c2, c3 = e->c3;
-    c1.B = c2.B = c3.B = B;
     { Probe pr(e, HAB_PROBE_FC_WGRAD, stream);
       HAB_TRY(linear_wgrad(dfc, e->rnn_ld, W + e->w_a3, e->fc_in, e->g(e->i_fcw), e->fc_in, B, H, e->fc_in, 32, e->fc_in / 32, 0,
                            ws, e->ws_floats, stream)); }
@@ -488,15 +622,16 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
     { Probe pr(e, HAB_PROBE_FC_DGRAD, stream);
       HAB_TRY(linear_dgrad(dfc, e->rnn_ld, e->PK + e->pk_fc, e->fc_in, nullptr, 0, 0, W + e->w_da3, e->fc_in, B, e->fc_in, H, 0,
                            ws, e->ws_floats, stream)); }
+    { Probe pr(e, HAB_PROBE_CONV3_DGRAD, stream);
+      HAB_TRY(conv_dgrad(c3, W + e->w_da3, e->PK + e->pk_c3d, W + e->w_a2, nullptr, W + e->w_da2, ws, e->ws_floats, stream)); }
+    { Probe pr(e, HAB_PROBE_CONV2_DGRAD, stream);
+      HAB_TRY(conv_dgrad(c2, W + e->w_da2, e->PK + e->pk_c2d, W + e->w_a1, nullptr, W + e->w_da1, ws, e->ws_floats, stream)); }
+    }
     // conv3 (no ReLU after it; its input a2 is post-ReLU -> mask on the data gradient)
     { Probe pr(e, HAB_PROBE_CONV3_WGRAD, stream);
       HAB_TRY(conv_wgrad(c3, W + e->w_a2, W + e->w_da3, e->g(e->i_c3w), e->g(e->i_c3b), ws, e->ws_floats, stream)); }
-    { Probe pr(e, HAB_PROBE_CONV3_DGRAD, stream);
-      HAB_TRY(conv_dgrad(c3, W + e->w_da3, e->PK + e->pk_c3d, W + e->w_a2, nullptr, W + e->w_da2, ws, e->ws_floats, stream)); }
     { Probe pr(e, HAB_PROBE_CONV2_WGRAD, stream);
       HAB_TRY(conv_wgrad(c2, W + e->w_a1, W + e->w_da2, e->g(e->i_c2w), e->g(e->i_c2b), ws, e->ws_floats, stream)); }
-    { Probe pr(e, HAB_PROBE_CONV2_DGRAD, stream);
-      HAB_TRY(conv_dgrad(c2, W + e->w_da2, e->PK + e->pk_c2d, W + e->w_a1, nullptr, W + e->w_da1, ws, e->ws_floats, stream)); }
     ObsView ov;
     ov.rgb = e->d.has_rgb ? obs->rgb : nullptr; ov.depth = e->d.has_depth ? obs->depth : nullptr; ov.rows = rows;
     ov.H = e->d.H; ov.W = e->d.W; ov.C = e->Cin;

@@ -37,7 +37,7 @@ struct IgemmPlCfg {
 
 template <class P, int TM, int TN, int WM, int WN, bool DB>
 __global__ void __launch_bounds__(WM* WN * 64) igemm_pl_kernel(const P p, const pl16* __restrict__ apl, const pl16* __restrict__ bpl, const int k_per_split,
-                                                               float* __restrict__ partial, const int sign_schedule, const int nsplit) {
+                                                               float* __restrict__ partial, const int sign_schedule, const int nsplit, const int ablate) {
     using Cfg = IgemmPlCfg<P, TM, TN, WM, WN, DB>;
     constexpr int NW = Cfg::NW, BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
     constexpr int A_UNITS = Cfg::A_UNITS, B_UNITS = Cfg::B_UNITS, A_CHUNKS = Cfg::A_CHUNKS, B_CHUNKS = Cfg::B_CHUNKS;
@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_pl_kernel(const P p, const 
         for (int s = 0; s < 2; ++s) boff[j][s] = ((wn * TN + j) * 32 + li) * 32 + (((2 * s + hi) ^ pl_swz(li)) * 8);
 
     auto issue = [&](int kt, int buf) {
+        if (ablate & 1) return;  // development (HAB_PL_ABLATE): no operand traffic
         const int k0 = k_begin + kt * BK;
         int tap;
         uint32_t sa, sb;
@@ -151,6 +152,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_pl_kernel(const P p, const 
     const unsigned sgn = flip_all ? 0x80008000u : 0u;
 
     auto compute = [&](const pl16* a, const pl16* b) {
+        if (ablate & 2) return;  // development: no fragment reads, no MFMAs
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 af[TM][3], bf[TN][3];
@@ -219,6 +221,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_pl_kernel(const P p, const 
     }
 
     // ---- epilogue: the problem's own (same accumulator layout as igemm_kernel / igemm_bf3_kernel) ----
+    if ((ablate & 4) && acc[0][0][0] != 12345.f) return;  // development: no output traffic
     const bool split = nsplit > 1;
     if constexpr (EpiV4<P>::value) {
         if (split)
@@ -278,7 +281,8 @@ inline int igemm_pl_launch(const P& p, const pl16* apl, const pl16* bpl, float* 
     const int ntiles = cdiv(p.M, Cfg::BM) * cdiv(p.N, Cfg::BN);
     const int grid = pl.splits >= 16 ? ntiles * ((pl.splits + 7) / 8 * 8) : ntiles * pl.splits;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");
-    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, apl, bpl, pl.k_per_split, ws, sign_schedule, pl.splits);
+    static const int ablate = hab_env_int("HAB_PL_ABLATE", 0);
+    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, apl, bpl, pl.k_per_split, ws, sign_schedule, pl.splits, ablate);
     HAB_LAUNCH_CHECK();
     if (pl.splits > 1) {
         igemm_splitk_reduce<P>(p, ws, pl.splits, stream);

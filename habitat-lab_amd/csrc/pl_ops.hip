@@ -81,6 +81,8 @@ int conv_fwd_pl(const ConvDesc& d, const pl16* xpl, const pl16* wfpl, const floa
     if (y && ldy > 0 && (ldy < p.N || (ldy & 3))) return HAB_ERR_ARG;
     p.ypl = ypl;
     p.ldy = ldy;
+    static const int tap_cm = hab_env_int("HAB_PL_TAPCM", 0);  // EXPERIMENT: timing only (the weights are not repacked to match yet)
+    p.tap_cm = tap_cm && d.stride > 1 && d.KH % d.stride == 0 && d.KW % d.stride == 0;
     return run_pl(p, xpl, wfpl, ws, ws_floats, stream);
 }
 

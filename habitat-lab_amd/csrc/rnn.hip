@@ -250,6 +250,8 @@ struct BwdStepArgs {
     int R, H, K, R_next;
     const int* idx;        // row q -> frame at step s
     const int* idx_next;   // row q -> frame at step s+1
+    const uint8_t* next_keep;  // time-major form: [R_next] episode-start mask of the frames at step s+1 (0: that frame starts from the zero
+                               // state, nothing flows back into row q); null in the packed form, where such a row is simply absent
     const float* dout;     // [frames][H] gradient wrt the layer output
     const float* w_hh_t;   // [H][K]
     float* dh_direct;      // [F][H] in: direct part of dh from step s+1 (GRU dh*z); out: the same for step s-1
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs
         f_pre = a.idx[q_];
         const size_t qo_ = (size_t)q_ * H + uu_, fo_ = (size_t)f_pre * H + uu_;
         dout_pre = a.dout[fo_];
-        if (q_ < a.R_next) {
+        if (q_ < a.R_next && (!a.next_keep || a.next_keep[q_])) {
             if constexpr (G == 3) dhd_pre = a.dh_direct[qo_];
             else dcc_pre = a.dc_carry[qo_];
         }
@@ -325,7 +327,8 @@ __global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs
     const int f = f_pre;
     const size_t qo = (size_t)q * H + uu;
     float dh = dout_pre;
-    if (q < a.R_next) {
+    const bool carried = (q < a.R_next) && (!a.next_keep || a.next_keep[q]);
+    if (carried) {
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; w += 4) sum += (red[w][t] + red[w + 1][t]) + (red[w + 2][t] + red[w + 3][t]);
@@ -351,7 +354,7 @@ __global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs
         const float cn = cn_pre, cp = cp_pre;
         const float tc = tanhf(cn);
         float dc = dh * og * (1.0f - tc * tc);
-        if (q < a.R_next) dc += dcc_pre;
+        if (carried) dc += dcc_pre;
         const float d_o = dh * tc;
         const float di = dc * gg, dg = dc * ig, df = dc * cp;
         float* gi = a.dgi + (size_t)f * 4 * H;
@@ -379,6 +382,7 @@ int rnn_seq_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const 
         g.R_next = (s + 1 < pk.max_len) ? pk.num_seqs_at_step[s + 1] : 0;
         g.idx = pk.select_inds + pk.step_offsets[s];
         g.idx_next = g.R_next ? pk.select_inds + pk.step_offsets[s + 1] : g.idx;
+        g.next_keep = nullptr;
         g.dout = dout; g.w_hh_t = lp.w_hh_t; g.dh_direct = dh_direct; g.dc_carry = dc_carry;
         g.gates = wk.gates; g.hn = wk.hn; g.hprev = wk.hprev; g.cprev = wk.cprev; g.c = wk.c;
         g.dgi = wk.dgi; g.dgh = dgh;
@@ -398,6 +402,109 @@ int rnn_seq_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const 
     HAB_TRY(colsum(wk.dgi, G * H, pk.P, G * H, lp.db_ih, 0, ws, ws_floats, stream));
     HAB_TRY(colsum(dgh, G * H, pk.P, G * H, lp.db_hh, 0, ws, ws_floats, stream));
     if (dx) HAB_TRY(linear_dgrad(wk.dgi, G * H, lp.w_ih, lp.in_dim, dx_mask, ldmask, mask_cols, dx, lddx, pk.P, lp.in_dim, G * H, 0, ws, ws_floats, stream));
+    return HAB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// TIME-MAJOR form of the same recurrence, for a regular T x n minibatch (frame f = t * n + j; RolloutStorage.data_generator's layout,
+// rollout_storage.py:246).  Step t processes the n environments of time t; an episode start (masks == 0) zeroes the state OPERAND
+// (h * masks, rnn_state_encoder.py:308-311) instead of opening a new packed fragment.  Per environment the chain of operations is the
+// packed form's, operand for operand -- the two forms are bit-identical (tests/test_gpu_policy.py) -- but step t only needs the frames of
+// times <= t, so the minibatch can be cut into time chunks and the recurrence of chunk c runs on a second stream BESIDE the encoder of
+// chunk c + 1 (forward) / the data-gradient chain of chunk c + 1 (backward): the 2 x T dependent ~7 us launches of a minibatch
+// (12.8 % of the C2 cycle, profiles/r02_c2_kernel_stats.txt) leave the critical path.
+// ------------------------------------------------------------------------------------------------------
+__global__ void gather_u8_kernel(const uint8_t* __restrict__ src, const int* __restrict__ rows, int n, uint8_t* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[rows ? rows[i] : i];
+}
+__global__ void iota_kernel(int* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = i;
+}
+int rnn_tm_prepare(const uint8_t* masks, const int* rows, int B, uint8_t* frame_mask, int* iota, hipStream_t stream) {
+    if (!masks || !frame_mask || !iota || B <= 0) return HAB_ERR_ARG;
+    gather_u8_kernel<<<cdiv(B, 256), 256, 0, stream>>>(masks, rows, B, frame_mask);
+    iota_kernel<<<cdiv(B, 256), 256, 0, stream>>>(iota, B);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// steps t0 .. t1-1 of one layer: input projection of the chunk's frames, then the recurrence.  hinit / cinit: [n][H] state entering t = 0
+// (episode-start mask already applied, rnn_frag_init).  ws: split-K scratch private to the calling stream.
+int rnn_tm_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx, const float* hinit,
+                         const float* cinit, const uint8_t* frame_mask, int n, int t0, int t1, float* ws, size_t ws_floats, hipStream_t stream) {
+    const int G = rnn_type == RNN_GRU ? 3 : 4;
+    const size_t f0 = (size_t)t0 * n;
+    HAB_TRY(linear_fwd(x + f0 * ldx, ldx, lp.w_ih, lp.in_dim, lp.b_ih, wk.gi + f0 * G * H, G * H, (t1 - t0) * n, G * H, lp.in_dim, 0, 0, ws,
+                       ws_floats, stream));
+    for (int t = t0; t < t1; ++t) {
+        const size_t f = (size_t)t * n, fp = (size_t)(t - 1) * n;
+        StepArgs a;
+        a.R = n; a.H = H;
+        if (t == 0) {
+            a.hp_base = hinit; a.cp_base = cinit; a.row_mask = nullptr;
+        } else {
+            a.hp_base = wk.out + fp * H; a.cp_base = wk.c + fp * H; a.row_mask = frame_mask + f;
+        }
+        a.hp_idx = nullptr; a.hp_stride = H; a.cp_idx = nullptr; a.cp_stride = H;
+        a.out_idx = nullptr;  // row q = frame f + q: every per-frame array is passed at the step's first frame
+        a.gi = wk.gi + f * G * H; a.w_hh = lp.w_hh; a.b_hh = lp.b_hh;
+        a.gates = wk.gates + f * G * H; a.hn = wk.hn ? wk.hn + f * H : nullptr; a.hprev = wk.hprev + f * H;
+        a.cprev = wk.cprev ? wk.cprev + f * H : nullptr; a.c = wk.c ? wk.c + f * H : nullptr;
+        a.out = wk.out + f * H; a.out_stride = H; a.c_out = nullptr; a.c_out_stride = 0;
+        HAB_TRY(launch_step(rnn_type, a, stream));
+    }
+    return HAB_OK;
+}
+
+// BPTT steps t1-1 .. t0 of one layer (chunks must be walked from the last to the first), then the chunk's gradient wrt the layer input.
+// scratch: [2][n][H] carries, kept between the chunk calls of one backward.
+int rnn_tm_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* dout, float* dx, int lddx,
+                          const float* dx_mask, int ldmask, int mask_cols, const uint8_t* frame_mask, const int* iota, int n, int T, int t0,
+                          int t1, float* scratch, float* ws, size_t ws_floats, hipStream_t stream) {
+    const int G = rnn_type == RNN_GRU ? 3 : 4;
+    if (H % 64) return HAB_ERR_UNSUPPORTED;
+    float* dh_direct = scratch;
+    float* dc_carry = scratch + (size_t)n * H;
+    float* dgh = (rnn_type == RNN_GRU) ? wk.dgh : wk.dgi;
+    const int K = G * H;
+    const bool wide = K % 128 == 0;
+    for (int t = t1 - 1; t >= t0; --t) {
+        BwdStepArgs g;
+        g.R = n; g.H = H; g.K = K;
+        g.R_next = (t + 1 < T) ? n : 0;
+        g.idx = iota + (size_t)t * n;
+        g.idx_next = g.R_next ? iota + (size_t)(t + 1) * n : g.idx;
+        g.next_keep = g.R_next ? frame_mask + (size_t)(t + 1) * n : nullptr;
+        g.dout = dout; g.w_hh_t = lp.w_hh_t; g.dh_direct = dh_direct; g.dc_carry = dc_carry;
+        g.gates = wk.gates; g.hn = wk.hn; g.hprev = wk.hprev; g.cprev = wk.cprev; g.c = wk.c;
+        g.dgi = wk.dgi; g.dgh = dgh;
+        const dim3 grid(cdiv(g.R, 16), H / 16);
+        if (rnn_type == RNN_GRU) {
+            if (wide) rnn_bwd_step_kernel<3, 8><<<grid, 512, 0, stream>>>(g);
+            else rnn_bwd_step_kernel<3, 4><<<grid, 256, 0, stream>>>(g);
+        } else {
+            if (wide) rnn_bwd_step_kernel<4, 8><<<grid, 512, 0, stream>>>(g);
+            else rnn_bwd_step_kernel<4, 4><<<grid, 256, 0, stream>>>(g);
+        }
+        HAB_LAUNCH_CHECK();
+    }
+    const size_t f0 = (size_t)t0 * n;
+    if (dx) HAB_TRY(linear_dgrad(wk.dgi + f0 * G * H, G * H, lp.w_ih, lp.in_dim, dx_mask ? dx_mask + f0 * ldmask : nullptr, ldmask, mask_cols,
+                                 dx + f0 * lddx, lddx, (t1 - t0) * n, lp.in_dim, G * H, 0, ws, ws_floats, stream));
+    return HAB_OK;
+}
+
+// parameter gradients of one layer over ALL frames (after the last chunk of rnn_tm_layer_backward)
+int rnn_tm_layer_param_grads(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx, int P, float* ws,
+                             size_t ws_floats, hipStream_t stream) {
+    const int G = rnn_type == RNN_GRU ? 3 : 4;
+    float* dgh = (rnn_type == RNN_GRU) ? wk.dgh : wk.dgi;
+    HAB_TRY(linear_wgrad(wk.dgi, G * H, x, ldx, lp.dw_ih, lp.in_dim, P, G * H, lp.in_dim, 0, 0, 0, ws, ws_floats, stream));
+    HAB_TRY(linear_wgrad(dgh, G * H, wk.hprev, H, lp.dw_hh, H, P, G * H, H, 0, 0, 0, ws, ws_floats, stream));
+    HAB_TRY(colsum(wk.dgi, G * H, P, G * H, lp.db_ih, 0, ws, ws_floats, stream));
+    HAB_TRY(colsum(dgh, G * H, P, G * H, lp.db_hh, 0, ws, ws_floats, stream));
     return HAB_OK;
 }
 

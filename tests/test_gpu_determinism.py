@@ -58,3 +58,31 @@ def test_update_cycles_are_bitwise_reproducible(workload, cycles):
     line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1]
     fresh = json.loads(line[len("DIGEST"):])
     assert fresh == first, "a fresh process gives different bits"
+
+
+def _digest_in_subprocess(workload, cycles, extra_env):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "habitat-lab_amd"), os.path.join(ROOT, "tests")]), **extra_env)
+    out = subprocess.run([sys.executable, "-c",
+                          f"import json, test_gpu_determinism as t; print('DIGEST' + json.dumps(t.run_cycles({workload!r}, {cycles})))"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1][len("DIGEST"):])
+
+
+def test_time_major_chunked_recurrence_vs_the_packed_form():
+    """csrc/rnn.hip: the recurrent encoder of a regular T x n minibatch runs time-major, cut into time chunks that overlap the encoder
+    (forward) / the data-gradient chain (backward) on a second stream.  Per environment the time-major recurrence is the packed form's
+    chain of operations, operand for operand: ONE chunk (the whole sequence time-major) gives bit-identical parameters after a full C2
+    update cycle to HAB_RNN_CHUNKS=0 (packed sequences, rl/models/rnn_state_encoder.py:187-277).  With several chunks the chunk-sized
+    contractions choose other split-K plans / sign-schedule phases (fp32 summation order): same rollout (bit-identical actions -- the
+    rollout does not use the form), losses within 1e-5, and bitwise reproducible for a given chunk count (the default is part of
+    test_update_cycles_are_bitwise_reproducible)."""
+    packed = _digest_in_subprocess("c2", 1, {"HAB_RNN_CHUNKS": "0"})
+    assert _digest_in_subprocess("c2", 1, {"HAB_RNN_CHUNKS": "1"}) == packed
+    for chunks in ("4", "7"):
+        d = _digest_in_subprocess("c2", 1, {"HAB_RNN_CHUNKS": chunks})
+        assert d["actions"] == packed["actions"]
+        for k, v in d["losses"][0].items():
+            a, b = float.fromhex(v), float.fromhex(packed["losses"][0][k])
+            assert abs(a - b) <= 1e-5 * max(abs(b), 1e-3), (chunks, k, a, b)
+        assert d == _digest_in_subprocess("c2", 1, {"HAB_RNN_CHUNKS": chunks}), "not reproducible"
