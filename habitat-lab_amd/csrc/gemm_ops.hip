@@ -7,6 +7,7 @@
 #include "igemm_bf3_ws.h"
 #include "obs_conv_bf3.h"
 #include "obs_conv_bf3_ws.h"
+#include "obs_conv_patch.h"
 #include "obs_wgrad_bf3.h"
 #include "conv_patch_bf3.h"
 #include "wgrad3x3_patch.h"
@@ -27,10 +28,11 @@ static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); ret
 // bit 0: r-contiguous x r-contiguous problems, bit 1: observation-ingest convolution (obs_conv_bf3.h), bit 2: problems with an
 // i/j-contiguous operand (weight gradients, Linear data gradient), bit 3: prefer it over the fp32 patch / DMA weight-gradient kernels,
 // bit 4: input-patch-resident stride-1 3x3 convolutions (conv_patch_bf3.h), bit 5: producer / consumer waves where they won
-// (igemm_bf3_ws.h: long-K 128 x 128 forward-form tiles; obs_conv_bf3_ws.h: the observation-ingest convolution)
+// (igemm_bf3_ws.h: long-K 128 x 128 forward-form tiles; obs_conv_bf3_ws.h: the observation-ingest convolution), bit 6: the
+// observation-ingest convolution with the input patch resident in LDS (obs_conv_patch.h)
 static int g_bf3_mode = -1;
 static int bf3_mode() {
-    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 63);
+    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 127);
     return g_bf3_mode;
 }
 extern "C" int hab_set_matrix_path(int mode) {
@@ -135,6 +137,14 @@ int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const f
                  size_t ws_floats, hipStream_t stream) {
     ObsConvFwdProb p;
     HAB_TRY(build(p, d, obs, wf, bias, y, relu));
+    if ((bf3_mode() & 64) && (bf3_mode() & 2) && p.quad) {  // observation patch resident in LDS (obs_conv_patch.h): 8x8 / 4 RGB-D -> 32 only
+        const int rc = obs_conv_patch_launch(p, ws, ws_floats, stream);
+        if (rc != 1) return rc;
+    }
+    if ((bf3_mode() & 64) && (bf3_mode() & 2) && p.quad) {  // observation patch resident in LDS (obs_conv_patch.h): 8x8 / 4 RGB-D -> 32 only
+        const int rc = obs_conv_patch_launch(p, ws, ws_floats, stream);
+        if (rc != 1) return rc;
+    }
     if ((bf3_mode() & 32) && (bf3_mode() & 2) && p.quad && p.M > 64) {  // producer / consumer waves (obs_conv_bf3_ws.h): 133 -> 148-152 TFLOP/s-eq at 1024 frames
         const int rc = obs_conv_bf3_ws_launch(p, ws, ws_floats, stream);
         if (rc != 1) return rc;

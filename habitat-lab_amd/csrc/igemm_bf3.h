@@ -107,7 +107,7 @@ __device__ __forceinline__ void bf3_store_run(const float (&x)[R], unsigned shor
 }
 
 template <class P, int TM, int TN, int WM, int WN>
-__global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const int k_per_split, float* __restrict__ partial, const int sign_schedule, const int nsplit) {
+__global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const int k_per_split, float* __restrict__ partial, const int sign_schedule, const int nsplit, const int ablate) {
     using Cfg = IgemmBf3Cfg<P, TM, TN, WM, WN>;
     constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, KV = Cfg::KV;
     constexpr int A_UNITS = Cfg::A_UNITS, B_UNITS = Cfg::B_UNITS, A_TOTAL = Cfg::A_TOTAL, B_TOTAL = Cfg::B_TOTAL;
@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
         }
     };
     auto fetch = [&](int kt) {
+        if (ablate & 1) return;  // development (HAB_BF3_ABLATE, tools/ablate_layers.sh): no operand gathers
         const typename P::KCtx kc = p.k_ctx(k_begin + kt * BK, k_end);
         if constexpr (P::A_RC) {
             const typename P::AKey ak = p.a_key(kc, a_k(kt, 0, 0), k_end);
@@ -233,6 +234,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
         }
     };
     auto stage = [&](int kt, const unsigned sgn) {  // registers -> split -> three bf16 planes; sgn = 0x80000000: B enters negated
+        if (ablate & 8) return;  // development: no split, no LDS writes
 #pragma unroll
         for (int j = 0; j < A_UNITS; ++j) {
             const int u = t + NT * j;
@@ -317,6 +319,11 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = -acc[i][j][v];
     };
+    if (ablate & 0xff00) {  // EXPERIMENT (HAB_BF3_ABLATE bits 8..15 = max start skew in units of 1024 cycles): de-phase co-resident workgroups
+        const unsigned hsh = (blockIdx.x * 2654435761u) >> 24;  // 0 .. 255
+        const int steps = (int)((hsh * (unsigned)((ablate >> 8) & 0xff)) >> 8) * 16;
+        for (int q = 0; q < steps; ++q) __builtin_amdgcn_s_sleep(1);
+    }
     if (ntk > 0) {
         if constexpr (Cfg::KSH) { make_keys(0); __syncthreads(); }
         fetch(0);
@@ -326,6 +333,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
         stage(kt, sgn);
         __syncthreads();
         if (kt + 1 < ntk) fetch(kt + 1);
+        if (!(ablate & 2))  // development: no fragment reads, no MFMAs
 #pragma unroll
         for (int c = 0; c < BK / 16; ++c) {
             bf16x8 af[TM][3], bf[TN][3];
@@ -358,6 +366,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
     }
 
     if (flip_all) negate_acc();
+    if ((ablate & 4) && acc[0][0][0] != 12345.f) return;  // development: no output traffic
 
     // ---- epilogue: identical to igemm_kernel's (same accumulator layout) ----
     const bool split = nsplit > 1;
@@ -436,7 +445,8 @@ inline int igemm_bf3_launch(const P& p, float* ws, size_t ws_floats, int target_
     const int ntiles = cdiv(p.M, Cfg::BM) * cdiv(p.N, Cfg::BN);
     const int grid = pl.splits >= 16 ? ntiles * ((pl.splits + 7) / 8 * 8) : ntiles * pl.splits;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");  // development: measure the cost of the sign schedule
-    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, pl.k_per_split, ws, sign_schedule, pl.splits);
+    static const int ablate = hab_env_int("HAB_BF3_ABLATE", 0);
+    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, pl.k_per_split, ws, sign_schedule, pl.splits, ablate);
     HAB_LAUNCH_CHECK();
     if (pl.splits > 1) {
         igemm_splitk_reduce<P>(p, ws, pl.splits, stream);

@@ -300,3 +300,39 @@ def test_producer_consumer_kernels_match_the_plain_split_kernels(L):
 
     e_plain, e_ws = err_vs(ref, _with_path(L, 31, obs)), err_vs(ref, _with_path(L, 63, obs))
     assert e_ws <= 2 * e_plain + 2e-7 and e_ws < 3e-6, (e_plain, e_ws)
+
+
+@pytest.mark.parametrize("B,H,W", [(5, 256, 256), (3, 96, 128), (2, 256, 64), (67, 44, 44)])
+def test_obs_conv_patch_resident_as_accurate_as_fp32_path(L, B, H, W):
+    """Matrix-path bit 6 (obs_conv_patch.h): the first convolution with the observation patch resident in LDS -- same six partial
+    products as obs_conv_bf3.h in another grouping -- against float64, next to the fp32 MFMA path: full benchmark geometry (Ho = Wo =
+    63: partial last tile, one idle lane), a narrow image (second 32-pixel half empty), one with fewer rows than a tile, and the
+    golden fixtures' 44 x 44 with a frame count that is not a multiple of anything."""
+    torch.manual_seed(11)
+    rgb = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8)
+    depth = torch.rand(B, H, W, 1) * torch.rand(B, H, W, 1).pow(3)
+    x = torch.cat([rgb.double() / 255.0, depth.double()], -1).permute(0, 3, 1, 2)
+    w = torch.randn(32, 4, 8, 8) / 16
+    b = torch.randn(32)
+    ref = F.relu(F.conv2d(x, w.double(), b.double(), stride=4)).permute(0, 2, 3, 1)
+    wf, bd, rg, dp = repack_fwd(L, w), b.cuda(), rgb.cuda(), depth.cuda()
+    ws = torch.zeros(1 << 22, device="cuda")
+
+    def run():
+        y = torch.full(ref.shape, -7.0, device="cuda")
+        _lib.check(L.hab_obs_conv2d_fwd(P(rg), P(dp), None, P(wf), P(bd), P(y), B, H, W, 32, 8, 8, 4, 0, 1, P(ws), ws.numel(), S()))
+        return y
+
+    e_f32, e_patch = err_vs(ref, _with_path(L, 0, run)), err_vs(ref, _with_path(L, 2 | 64, run))
+    assert e_patch <= 2 * e_f32 + 2e-7 and e_patch < 3e-6, (e_f32, e_patch)
+    # gathered through rows[] (the minibatch indirection of the update) and bit-reproducible
+    rows = torch.randperm(B).int().cuda()
+    y_rows = torch.zeros(ref.shape, device="cuda")
+
+    def run_rows():
+        _lib.check(L.hab_obs_conv2d_fwd(P(rg), P(dp), P(rows), P(wf), P(bd), P(y_rows), B, H, W, 32, 8, 8, 4, 0, 1, P(ws), ws.numel(), S()))
+        return y_rows.clone()
+
+    a = _with_path(L, 2 | 64, run_rows)
+    assert torch.equal(a, _with_path(L, 2 | 64, run_rows))
+    assert err_vs(ref[rows.cpu().long()], a) < 3e-6
