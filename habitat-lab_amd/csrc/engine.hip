@@ -22,29 +22,34 @@ static int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1
 static int build_baseline(hab_policy* e) {
     const hab_policy_desc& d = e->d;
     e->Cin = (d.has_rgb ? 3 : 0) + (d.has_depth ? 1 : 0);
-    if (e->Cin == 0) return HAB_ERR_UNSUPPORTED;  // blind policies are not on the benchmarked path
+    const bool blind = e->Cin == 0;  // SimpleCNN.is_blind (simple_cnn.py:54,95-97): no visual sensor -> the net is goal -> GRU -> heads
+    if (blind && d.goal_dim <= 0) return HAB_ERR_ARG;
     if (d.rnn_type != HAB_RNN_GRU && d.rnn_type != HAB_RNN_LSTM) return HAB_ERR_ARG;
     const int H = d.hidden;
     e->G_ = d.rnn_type == HAB_RNN_GRU ? 3 : 4;
     e->L = d.rnn_layers;
     // SimpleCNN (rl/models/simple_cnn.py:68-93)
-    e->c1 = ConvDesc{0, d.H, d.W, e->Cin, 32, 8, 8, 4, 0};
+    e->c1 = ConvDesc{0, d.H, d.W, blind ? 4 : e->Cin, 32, 8, 8, 4, 0};
     e->c2 = ConvDesc{0, conv_out(d.H, 8, 4, 0), conv_out(d.W, 8, 4, 0), 32, 64, 4, 4, 2, 0};
     e->c3 = ConvDesc{0, e->c2.Ho(), e->c2.Wo(), 64, 32, 3, 3, 1, 0};
     const int h3 = e->c3.Ho(), w3 = e->c3.Wo();
-    if (h3 <= 0 || w3 <= 0) return HAB_ERR_ARG;
-    e->fc_in = 32 * h3 * w3;
-    e->rnn_in = H + d.goal_dim;
+    if (!blind && (h3 <= 0 || w3 <= 0)) return HAB_ERR_ARG;
+    e->fc_in = blind ? 0 : 32 * h3 * w3;
+    e->rnn_in = (blind ? 0 : H) + d.goal_dim;  // policy.py:532-535
     e->rnn_ld = (e->rnn_in + 3) & ~3;
     const std::string ve = "net.visual_encoder.cnn.";
-    e->i_c1w = add_param(e, ve + "0.weight", {32, e->Cin, 8, 8});
-    e->i_c1b = add_param(e, ve + "0.bias", {32});
-    e->i_c2w = add_param(e, ve + "2.weight", {64, 32, 4, 4});
-    e->i_c2b = add_param(e, ve + "2.bias", {64});
-    e->i_c3w = add_param(e, ve + "4.weight", {32, 64, 3, 3});
-    e->i_c3b = add_param(e, ve + "4.bias", {32});
-    e->i_fcw = add_param(e, ve + "6.weight", {H, e->fc_in});
-    e->i_fcb = add_param(e, ve + "6.bias", {H});
+    if (!blind) {
+        e->i_c1w = add_param(e, ve + "0.weight", {32, e->Cin, 8, 8});
+        e->i_c1b = add_param(e, ve + "0.bias", {32});
+        e->i_c2w = add_param(e, ve + "2.weight", {64, 32, 4, 4});
+        e->i_c2b = add_param(e, ve + "2.bias", {64});
+        e->i_c3w = add_param(e, ve + "4.weight", {32, 64, 3, 3});
+        e->i_c3b = add_param(e, ve + "4.bias", {32});
+        e->i_fcw = add_param(e, ve + "6.weight", {H, e->fc_in});
+        e->i_fcb = add_param(e, ve + "6.bias", {H});
+    } else {
+        e->i_c1w = e->i_c1b = e->i_c2w = e->i_c2b = e->i_c3w = e->i_c3b = e->i_fcw = e->i_fcb = -1;
+    }
     const std::string rn = "net.state_encoder.rnn.";
     for (int l = 0; l < d.rnn_layers; ++l) {
         const int in = l == 0 ? e->rnn_in : H;
@@ -60,19 +65,19 @@ static int build_baseline(hab_policy* e) {
     e->i_cb = add_param(e, "critic.fc.bias", {1});
 
     Arena pk;
-    e->pk_c1f = pk.take(32 * 64 * e->Cin);
+    e->pk_c1f = pk.take(32 * 64 * (blind ? 4 : e->Cin));
     e->pk_c2f = pk.take(64 * 16 * 32);
     e->pk_c2d = pk.take(64 * 16 * 32);
     e->pk_c3f = pk.take(32 * 9 * 64);
     e->pk_c3d = pk.take(32 * 9 * 64);
-    e->pk_fc = pk.take((int64_t)H * e->fc_in);
+    e->pk_fc = pk.take((int64_t)H * std::max(e->fc_in, 4));
     for (int l = 0; l < d.rnn_layers; ++l) e->pk_whht.push_back(pk.take((int64_t)e->G_ * H * H));
     e->packed_floats = pk.used;
 
     Arena wk;
     const int64_t B = d.max_frames;
     const int64_t F = d.max_frames;  // worst case: every frame its own fragment
-    const int64_t m1 = (int64_t)e->c1.Ho() * e->c1.Wo() * 32, m2 = (int64_t)e->c2.Ho() * e->c2.Wo() * 64, m3 = e->fc_in;
+    const int64_t m1 = blind ? 0 : (int64_t)e->c1.Ho() * e->c1.Wo() * 32, m2 = blind ? 0 : (int64_t)e->c2.Ho() * e->c2.Wo() * 64, m3 = e->fc_in;
     e->w_a1 = wk.take(B * m1); e->w_a2 = wk.take(B * m2); e->w_a3 = wk.take(B * m3);
     e->w_da1 = wk.take(B * m1); e->w_da2 = wk.take(B * m2); e->w_da3 = wk.take(B * m3);
     e->w_rnnin = wk.take(B * e->rnn_ld); e->w_drnnin = wk.take(B * e->rnn_ld);
@@ -106,7 +111,8 @@ static int build_baseline(hab_policy* e) {
 extern "C" int hab_policy_create(const hab_policy_desc* desc, hab_policy** out) {
     if (!desc || !out) return HAB_ERR_ARG;
     if (desc->hidden <= 0 || desc->hidden % 64 || desc->num_actions <= 0 || desc->num_actions > 8 || desc->max_frames <= 0 ||
-        desc->max_envs <= 0 || desc->rnn_layers <= 0 || desc->H <= 0 || desc->W <= 0 || desc->goal_dim < 0)
+        desc->max_envs <= 0 || desc->rnn_layers <= 0 || desc->goal_dim < 0 ||
+        ((desc->has_rgb || desc->has_depth || desc->arch != HAB_ARCH_SIMPLE_CNN) && (desc->H <= 0 || desc->W <= 0)))
         return HAB_ERR_ARG;
     if (desc->action_dist != HAB_DIST_CATEGORICAL && (desc->action_dist != HAB_DIST_GAUSSIAN || desc->arch != HAB_ARCH_RESNET))
         return HAB_ERR_UNSUPPORTED;  // PointNavBaselinePolicy never builds a Gaussian head (rl/ppo/policy.py:439-460)
@@ -184,6 +190,10 @@ extern "C" int hab_policy_repack(hab_policy* e, hipStream_t stream) {
     if (!e || !e->P) return HAB_ERR_ARG;
     if (e->rn) return resnet_repack(e, stream);
     const int H = e->d.hidden;
+    if (e->Cin == 0) {  // blind baseline policy: only the recurrent weights have a kernel-layout copy
+        for (int l = 0; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_whh[l]), e->PK + e->pk_whht[l], e->G_ * H, H, stream));
+        return HAB_OK;
+    }
     HAB_TRY(repack_conv(e->p(e->i_c1w), e->PK + e->pk_c1f, nullptr, 32, e->Cin, 8, 8, e->Cin, stream));
     HAB_TRY(repack_conv(e->p(e->i_c2w), e->PK + e->pk_c2f, e->PK + e->pk_c2d, 64, 32, 4, 4, 32, stream));
     HAB_TRY(repack_conv(e->p(e->i_c3w), e->PK + e->pk_c3f, e->PK + e->pk_c3d, 32, 64, 3, 3, 64, stream));
@@ -244,6 +254,11 @@ static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
     float* W = e->WK;
     float* ws = W + e->w_ws;
     const int H = e->d.hidden;
+    if (e->Cin == 0) {  // blind: rnn_in = the goal vector alone (policy.py:572-582)
+        if (!rows && f0) return HAB_ERR_ARG;
+        return gather_cols(obs->goal, e->d.goal_dim, rows ? rows + f0 : nullptr, W + e->w_rnnin + (int64_t)f0 * e->rnn_ld, e->rnn_ld, 0, e->d.goal_dim,
+                           e->rnn_ld - e->rnn_in, nB, s);
+    }
     const int64_t m1 = (int64_t)e->c1.Ho() * e->c1.Wo() * 32, m2 = (int64_t)e->c2.Ho() * e->c2.Wo() * 64, m3 = e->fc_in;
     float *a1 = W + e->w_a1 + f0 * m1, *a2 = W + e->w_a2 + f0 * m2, *a3 = W + e->w_a3 + f0 * m3, *rin = W + e->w_rnnin + (int64_t)f0 * e->rnn_ld;
     const int* rws = rows ? rows + f0 : nullptr;
@@ -399,7 +414,7 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
     // Time-major chunked form (rnn.hip): a regular T x n minibatch of the SimpleCNN policy is cut into time chunks; the encoder of
     // chunk c + 1 runs on `stream` while the recurrence walks chunk c on the engine's second stream.  Bit-identical to the packed form.
     const int T = B / n;
-    int NC = (!e->rn && rows && !pack->env_first_frame && (B % n) == 0 && T >= 2 && e->w_ws2 >= 0 && (int64_t)L * 2 * n <= 3 * (int64_t)e->d.max_frames)
+    int NC = (!e->rn && e->Cin > 0 && rows && !pack->env_first_frame && (B % n) == 0 && T >= 2 && e->w_ws2 >= 0 && (int64_t)L * 2 * n <= 3 * (int64_t)e->d.max_frames)
                  ? tm_chunks_cfg() : 0;
     if (NC > T) NC = T;
     const float* x = W + e->w_rnnin;
@@ -606,11 +621,17 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
         const int ldx = l == 0 ? e->rnn_ld : H;
         float* dx = l == 0 ? W + e->w_drnnin : W + e->w_dlayer[l];
         const int lddx = l == 0 ? e->rnn_ld : H;
-        // layer 0: the first H columns of rnn_in are ReLU(fc) -> mask them here (fused ReLU backward)
+        // layer 0: the first H columns of rnn_in are ReLU(fc) -> mask them here (fused ReLU backward); a blind policy's rnn_in is the
+        // goal vector alone: no mask, and no gradient is wanted for it
+        const bool blind0 = !e->rn && e->Cin == 0 && l == 0;
         Probe pr(e, HAB_PROBE_RNN_BWD, stream);
-        HAB_TRY(rnn_seq_layer_backward(e->d.rnn_type, H, lp, wk, x, ldx, dout, dx, lddx, l == 0 ? x : nullptr, ldx, H, pk,
-                                       W + e->w_scratch, ws, e->ws_floats, stream));
+        HAB_TRY(rnn_seq_layer_backward(e->d.rnn_type, H, lp, wk, x, ldx, dout, blind0 ? nullptr : dx, lddx, (l == 0 && !blind0) ? x : nullptr, ldx,
+                                       blind0 ? 0 : H, pk, W + e->w_scratch, ws, e->ws_floats, stream));
         dout = dx;
+    }
+    if (!e->rn && e->Cin == 0) {  // blind baseline policy: the recurrent encoder and the heads are all there is
+        grad_tail_ready(e, e->i_wih[0]);
+        return HAB_OK;
     }
     if (e->rn) { Probe pr(e, HAB_PROBE_ENC_BWD, stream); return resnet_encoder_backward(e, obs, e->last_masks, rows, B, stream); }
     // fc (Flatten -> Linear -> ReLU): d_rnnin[:, :H] already carries the ReLU mask
@@ -646,6 +667,7 @@ extern "C" int hab_policy_tap(hab_policy* e, int which, const float** ptr, int64
     const int64_t B = e->last_B;
     float* W = e->WK;
     if (e->rn && which != HAB_TAP_RNN_IN && which != HAB_TAP_RNN_OUT) return resnet_tap(e, which, ptr, floats);
+    if (!e->rn && e->Cin == 0 && (which == HAB_TAP_CONV1 || which == HAB_TAP_CONV2 || which == HAB_TAP_CONV3)) return HAB_ERR_ARG;
     switch (which) {
         case HAB_TAP_CONV1: *ptr = W + e->w_a1; *floats = B * e->c1.Ho() * e->c1.Wo() * 32; break;
         case HAB_TAP_CONV2: *ptr = W + e->w_a2; *floats = B * e->c2.Ho() * e->c2.Wo() * 64; break;

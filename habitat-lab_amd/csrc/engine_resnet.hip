@@ -54,7 +54,7 @@ struct ResNetPlan {
     RnConv comp;
     int i_embb = -1;
     int i_fcw = -1, i_fcb = -1, i_emb = -1, i_tgw = -1, i_tgb = -1, i_mean = -1, i_var = -1, i_count = -1;
-    int i_objw = -1, i_gpsw = -1, i_gpsb = -1, i_cmpw = -1, i_cmpb = -1;
+    int i_objw = -1, i_gpsw = -1, i_gpsb = -1, i_cmpw = -1, i_cmpb = -1, i_pgw = -1, i_pgb = -1, i_pxw = -1, i_pxb = -1;
     int c_rgb = -1, c_depth = -1, c_sem = -1;  // first channel of each visual key in the concatenated encoder input
     int nslots = 0;
     int64_t pk_fc = -1;
@@ -144,6 +144,18 @@ int build_resnet(hab_policy* e) {
     if (d.has_gps) {
         r->i_gpsw = add_param(e, "net.gps_embedding.weight", {32, 2});
         r->i_gpsb = add_param(e, "net.gps_embedding.bias", {32});
+        ++r->nslots;
+    }
+    // (resnet_policy.py:489-515: pointgoal_embedding, [heading_embedding], proximity_embedding sit between gps and compass)
+    if (d.pointgoal_dim < 0 || d.pointgoal_dim > 4 || d.proximity_dim < 0 || d.proximity_dim > 4) return HAB_ERR_UNSUPPORTED;
+    if (d.pointgoal_dim > 0) {
+        r->i_pgw = add_param(e, "net.pointgoal_embedding.weight", {32, d.pointgoal_dim});
+        r->i_pgb = add_param(e, "net.pointgoal_embedding.bias", {32});
+        ++r->nslots;
+    }
+    if (d.proximity_dim > 0) {
+        r->i_pxw = add_param(e, "net.proximity_embedding.weight", {32, d.proximity_dim});
+        r->i_pxb = add_param(e, "net.proximity_embedding.bias", {32});
         ++r->nslots;
     }
     if (d.has_compass) {
@@ -345,7 +357,7 @@ int resnet_repack(hab_policy* e, hipStream_t s) {
 }
 
 // Embedding slots in the order PointNavResNetNet.forward concatenates them (resnet_policy.py:662-755):
-// pointgoal_with_gps_compass, objectgoal, compass, gps, previous action.
+// pointgoal_with_gps_compass, pointgoal, proximity, objectgoal, compass, gps, previous action.
 static int fill_embed_slots(hab_policy* e, const hab_obs* obs, EmbedSlot* sl, bool grads) {
     ResNetPlan* r = e->rn;
     const hab_policy_desc& d = e->d;
@@ -358,6 +370,8 @@ static int fill_embed_slots(hab_policy* e, const hab_obs* obs, EmbedSlot* sl, bo
     };
     bool ok = true;
     if (d.goal_dim == 2) ok &= add(EMB_POLAR, obs->goal, r->i_tgw, r->i_tgb, 0);
+    if (d.pointgoal_dim > 0) ok &= add(EMB_LINN, obs->pointgoal, r->i_pgw, r->i_pgb, d.pointgoal_dim);
+    if (d.proximity_dim > 0) ok &= add(EMB_LINN, obs->proximity, r->i_pxw, r->i_pxb, d.proximity_dim);
     if (d.num_object_categories > 0) ok &= add(EMB_TOKEN, obs->objectgoal, r->i_objw, -1, d.num_object_categories);
     if (d.has_compass) ok &= add(EMB_COSSIN, obs->compass, r->i_cmpw, r->i_cmpb, 0);
     if (d.has_gps) ok &= add(EMB_LIN2, obs->gps, r->i_gpsw, r->i_gpsb, 0);

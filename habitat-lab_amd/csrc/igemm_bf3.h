@@ -319,11 +319,6 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = -acc[i][j][v];
     };
-    if (ablate & 0xff00) {  // EXPERIMENT (HAB_BF3_ABLATE bits 8..15 = max start skew in units of 1024 cycles): de-phase co-resident workgroups
-        const unsigned hsh = (blockIdx.x * 2654435761u) >> 24;  // 0 .. 255
-        const int steps = (int)((hsh * (unsigned)((ablate >> 8) & 0xff)) >> 8) * 16;
-        for (int q = 0; q < steps; ++q) __builtin_amdgcn_s_sleep(1);
-    }
     if (ntk > 0) {
         if constexpr (Cfg::KSH) { make_keys(0); __syncthreads(); }
         fetch(0);

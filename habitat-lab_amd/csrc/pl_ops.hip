@@ -61,9 +61,6 @@ static int run_pl(const P& p, const pl16* apl, const pl16* bpl, float* ws, size_
                        : igemm_pl_launch<P, 1, 1, 4, 1, false>(p, apl, bpl, ws, ws_floats, target, stream);
     }
     if (p.N <= 64) {
-        static const int cfg = hab_env_int("HAB_PL_CFG", 0);  // EXPERIMENT: 8-wave workgroups (2 waves / SIMD inside one workgroup)
-        if (cfg == 1) return igemm_pl_launch<P, 1, 2, 8, 1, true>(p, apl, bpl, ws, ws_floats, target, stream);   // 256 x 64, 120 KB, 1 WG / CU
-        if (cfg == 2) return igemm_pl_launch<P, 1, 2, 8, 1, false>(p, apl, bpl, ws, ws_floats, target, stream);  // 256 x 64, 60 KB, 2 WG / CU
         if (tall) return pl_db() ? igemm_pl_launch<P, 2, 2, 4, 1, true>(p, apl, bpl, ws, ws_floats, target, stream)
                                  : igemm_pl_launch<P, 2, 2, 4, 1, false>(p, apl, bpl, ws, ws_floats, target, stream);
         return pl_db() ? igemm_pl_launch<P, 1, 2, 4, 1, true>(p, apl, bpl, ws, ws_floats, target, stream)
@@ -84,8 +81,6 @@ int conv_fwd_pl(const ConvDesc& d, const pl16* xpl, const pl16* wfpl, const floa
     if (y && ldy > 0 && (ldy < p.N || (ldy & 3))) return HAB_ERR_ARG;
     p.ypl = ypl;
     p.ldy = ldy;
-    static const int tap_cm = hab_env_int("HAB_PL_TAPCM", 0);  // EXPERIMENT: timing only (the weights are not repacked to match yet)
-    p.tap_cm = tap_cm && d.stride > 1 && d.KH % d.stride == 0 && d.KW % d.stride == 0;
     return run_pl(p, xpl, wfpl, ws, ws_floats, stream);
 }
 

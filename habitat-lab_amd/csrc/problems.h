@@ -163,7 +163,6 @@ struct ConvFwdProb {
     int relu;
     pl16* ypl = nullptr;  // optional second output: the same values as pl32 operand planes (bf3_planes.h; needs N % 32 == 0, ldy == 0)
     int ldy = 0;          // row stride of y in floats (0: N) -- a Linear layer is the 1x1 convolution of a 1x1 image (igemm_pl.h)
-    int tap_cm = 0;       // DMA path: reduction blocks (and the packed weights) in stride-class-major tap order, see dma_tap
     HAB_HD const float* dma_a_origin() const { return x; }
     HAB_HD const float* dma_b_origin() const { return w; }
     HAB_NO_KCTX
@@ -233,18 +232,7 @@ struct ConvFwdProb {
     HAB_HD void dma_tap(int k0, int& tap, uint32_t& sa, uint32_t& sb) const {
         int c0, kh, kw;
         g.dC.divmod(k0, tap, c0);
-        if (tap_cm) {
-            // class-major tap order (weights repacked to match): the KH/s x KW/s taps of one stride class (kh % s, kw % s) read the SAME
-            // input pixels shifted by whole output pixels, so visiting them back to back turns the s*s-fold im2col re-read of every
-            // input element into L2 hits one k-tile apart instead of re-fetches half a k-loop apart
-            const int s = g.stride, khs = g.KH / s, kws = g.KW / s;
-            const int cls = tap / (khs * kws), r = tap - cls * (khs * kws);
-            const int ph = cls / s, pw = cls - ph * s, a = r / kws, b = r - a * kws;
-            kh = a * s + ph; kw = b * s + pw;
-            tap = kh * g.KW + kw;  // the validity masks are indexed row-major
-        } else {
-            g.dKW.divmod(tap, kh, kw);
-        }
+        g.dKW.divmod(tap, kh, kw);
         sa = (uint32_t)((kh * g.W + kw) * g.C + c0) * 4u;
         sb = (uint32_t)k0 * 4u;
     }

@@ -31,8 +31,9 @@ enum { EMB_POLAR = 0,   // pointgoal_with_gps_compass (rho, phi) -> Linear(3,32)
        EMB_COSSIN = 2,  // compass x -> Linear(2,32)([cos x, sin x])                                             :719-729
        EMB_LIN2 = 3,    // gps (x, y) -> Linear(2,32)                                                            :731-734
        EMB_PREV = 4,    // previous action -> Embedding(A+1, 32)(mask ? a + 1 : 0)                               :747-753
-       EMB_PREVLIN = 5 };  // continuous previous action (A <= 4 floats) -> Linear(A, 32)(mask * a); ntok carries A      :754-757
-constexpr int EMB_MAX_SLOTS = 5;
+       EMB_PREVLIN = 5,  // continuous previous action (A <= 4 floats) -> Linear(A, 32)(mask * a); ntok carries A      :754-757
+       EMB_LINN = 6 };   // pointgoal (PointGoalSensor) / proximity: Linear(d, 32) on the raw d <= 4 floats; ntok carries d :694-700
+constexpr int EMB_MAX_SLOTS = 7;
 struct EmbedSlot {
     int kind;
     const void* in;      // sensor buffer (arena rows): f32 [rows][2] / int64 [rows][1] / f32 [rows][1] / f32 [rows][2] / int64 [rows][1]
@@ -42,7 +43,7 @@ struct EmbedSlot {
     int ntok;
 };
 __host__ __device__ inline int emb_nfeat(const EmbedSlot& sl) {
-    return sl.kind == EMB_POLAR ? 3 : (sl.kind == EMB_COSSIN || sl.kind == EMB_LIN2) ? 2 : sl.kind == EMB_PREVLIN ? sl.ntok : 0;
+    return sl.kind == EMB_POLAR ? 3 : (sl.kind == EMB_COSSIN || sl.kind == EMB_LIN2) ? 2 : (sl.kind == EMB_PREVLIN || sl.kind == EMB_LINN) ? sl.ntok : 0;
 }
 struct EmbedArgs {
     EmbedSlot slot[EMB_MAX_SLOTS];

@@ -1014,6 +1014,11 @@ __device__ inline void emb_features(const EmbedSlot& sl, int r, int masked, floa
             for (int d = 0; d < sl.ntok; ++d) v[d] = masked ? g[d] : 0.f;  // masks * prev_actions.float()
             break;
         }
+        case EMB_LINN: {
+            const float* g = reinterpret_cast<const float*>(sl.in) + (size_t)r * sl.ntok;
+            for (int d = 0; d < sl.ntok; ++d) v[d] = g[d];
+            break;
+        }
         default: v[3] = masked ? (float)(reinterpret_cast<const int64_t*>(sl.in)[r] + 1) : 0.f; break;
     }
 }
@@ -1030,7 +1035,7 @@ __global__ void __launch_bounds__(256) embed_fwd_kernel(const EmbedArgs a) {
         emb_features(sl, r, m, v);
         const int nf = emb_nfeat(sl);
         float y;
-        if (sl.kind == EMB_PREVLIN) {
+        if (sl.kind == EMB_PREVLIN || sl.kind == EMB_LINN) {
             y = 0.f;
             for (int d = 0; d < nf; ++d) y += sl.w[j * nf + d] * v[d];
             y += sl.b[j];

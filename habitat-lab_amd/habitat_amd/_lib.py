@@ -26,7 +26,9 @@ class PolicyDesc(C.Structure):
         "arch", "backbone", "baseplanes", "normalize_visual_inputs", "rnn_type", "rnn_layers", "hidden", "num_actions",
         "H", "W", "has_rgb", "has_depth", "goal_dim", "max_frames", "max_envs", "visual_order", "has_semantic",
         "num_object_categories", "has_compass", "has_gps", "action_dist", "gauss_flags")] + [("gauss_min_std", c_float),
-                                                                                                ("gauss_max_std", c_float)]
+                                                                                                ("gauss_max_std", c_float),
+                                                                                                ("pointgoal_dim", c_int32),
+                                                                                                ("proximity_dim", c_int32)]
 
 
 GAUSS_TANH_MU, GAUSS_USE_LOG_STD, GAUSS_USE_SOFTPLUS, GAUSS_USE_STD_PARAM, GAUSS_CLAMP_STD = 1, 2, 4, 8, 16  # HAB_GAUSS_*
@@ -34,7 +36,7 @@ GAUSS_TANH_MU, GAUSS_USE_LOG_STD, GAUSS_USE_SOFTPLUS, GAUSS_USE_STD_PARAM, GAUSS
 
 class Obs(C.Structure):
     _fields_ = [("rgb", vp), ("depth", vp), ("goal", vp), ("prev_actions", vp), ("semantic", vp), ("objectgoal", vp), ("compass", vp),
-                ("gps", vp), ("visual_features", vp)]
+                ("gps", vp), ("visual_features", vp), ("pointgoal", vp), ("proximity", vp)]
 
 
 class EmbedSlot(C.Structure):

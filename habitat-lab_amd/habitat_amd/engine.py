@@ -112,14 +112,14 @@ class PolicyEngine:
                  rnn_layers=1, hidden=512, num_actions=4, H=256, W=256, has_rgb=True, has_depth=True, goal_dim=2,
                  max_frames=4096, max_envs=64, device="cuda", with_grads=True, visual_order=("rgb", "depth", "semantic"),
                  has_semantic=False, num_object_categories=0, has_compass=False, has_gps=False, action_dist="categorical",
-                 gauss_flags=0, gauss_min_std=0.0, gauss_max_std=0.0):
+                 gauss_flags=0, gauss_min_std=0.0, gauss_max_std=0.0, pointgoal_dim=0, proximity_dim=0):
         L = _lib.lib()
         self.L = L
         d = PolicyDesc(ARCH[arch], backbone, baseplanes, int(normalize_visual_inputs), RNN[rnn_type.upper()], rnn_layers, hidden,
                        num_actions, H, W, int(has_rgb), int(has_depth), goal_dim, max_frames, max_envs,
                        sum({"rgb": 1, "depth": 2, "semantic": 3}[k] << (2 * i) for i, k in enumerate(visual_order)), int(has_semantic),
                        int(num_object_categories), int(has_compass), int(has_gps), {"categorical": 0, "gaussian": 1}[action_dist],
-                       int(gauss_flags), float(gauss_min_std), float(gauss_max_std))
+                       int(gauss_flags), float(gauss_min_std), float(gauss_max_std), int(pointgoal_dim), int(proximity_dim))
         self.action_dist = action_dist
         self.desc = d
         h = C.c_void_p()
@@ -234,11 +234,12 @@ class PolicyEngine:
     # ---- calls ------------------------------------------------------------------------------
     @staticmethod
     def _obs(rgb, depth, goal, prev_actions=None, extra=None):
-        """extra: optional dict with the ObjectNav sensors `semantic` (int32), `objectgoal` (int64), `compass`, `gps`."""
+        """extra: optional dict with the ObjectNav sensors `semantic` (int32), `objectgoal` (int64), `compass`, `gps`, and the further
+        1-D goal sensors `pointgoal`, `proximity` (float)."""
         dp = lambda t: t.data_ptr() if t is not None else None
         e = extra or {}
         return Obs(dp(rgb), dp(depth), dp(goal), dp(prev_actions), dp(e.get("semantic")), dp(e.get("objectgoal")), dp(e.get("compass")),
-                   dp(e.get("gps")), dp(e.get("visual_features")))
+                   dp(e.get("gps")), dp(e.get("visual_features")), dp(e.get("pointgoal")), dp(e.get("proximity")))
 
     def visual_feature_shape(self):
         """(C, Hf, Wf) = ResNetEncoder.output_shape (resnet_policy.py:235-253)."""

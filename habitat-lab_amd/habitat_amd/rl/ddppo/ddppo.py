@@ -55,6 +55,13 @@ class DecentralizedDistributedMixin:
                 self._grad_first = first
 
             eng.set_grad_ready(_tail_ready)
+
+        def _dense_sync() -> None:  # autograd bridge (PPO._evaluate_actions + loss.backward()): average, as DDP does in backward
+            self._all_reduce_grads()
+            if world > 1:
+                eng.grads_flat.div_(world)
+
+        self.actor_critic._dense_grad_sync = _dense_sync
         self._distributed = True
 
     def _all_reduce_grads(self) -> None:

@@ -25,6 +25,7 @@ from habitat_amd.engine import DevicePackInfo, PolicyEngine
 
 VISUAL_FEATURES_KEY = "visual_features"  # PointNavResNetNet.PRETRAINED_VISUAL_FEATURES_KEY (resnet_policy.py:399)
 GOAL_UUID = "pointgoal_with_gps_compass"  # IntegratedPointGoalGPSAndCompassSensor.cls_uuid (tasks/nav/nav.py:309)
+POINTGOAL_UUID = "pointgoal"            # PointGoalSensor.cls_uuid (tasks/nav/nav.py:127)
 
 
 @dataclass
@@ -133,6 +134,8 @@ class _EvaluateFn(torch.autograd.Function):
     def backward(ctx, dv, dlp, dent):
         pol, call = ctx.policy, ctx.call
         pol._backward_dense(call, dv.contiguous().view(-1), dlp.contiguous().view(-1), dent.contiguous().view(-1))
+        if pol._dense_grad_sync is not None:  # DD-PPO: what DistributedDataParallel does inside backward (ddppo.py:110-157)
+            pol._dense_grad_sync()
         grads = tuple(g.clone() for k, g in pol.engine.grad_views.items() if k not in pol.engine.buffer_names)
         return (None, None) + grads
 
@@ -149,6 +152,7 @@ class NetPolicy(nn.Module, Policy):
         self._engine_kwargs = dict(engine_kwargs, num_actions=self.dim_actions)
         self.action_distribution_type = engine_kwargs.get("action_dist", "categorical")
         self.engine: Optional[PolicyEngine] = None
+        self._dense_grad_sync = None  # set by the DD-PPO updater: averages the gradient arena over ranks (autograd bridge only)
         self.device = torch.device("cpu")
         self._hidden = engine_kwargs["hidden"]
         self._rnn_type = engine_kwargs["rnn_type"].upper()
@@ -202,10 +206,16 @@ class NetPolicy(nn.Module, Policy):
             raise _lib.HabError("habitat_amd policies cannot be moved off the GPU (no CPU execution path)")
         if self.engine is not None and self.device == device:
             return self
-        state = {k: v.detach() for k, v in self.state_dict().items()}
         with torch.cuda.device(device):
             eng = PolicyEngine(device=device, **self._engine_kwargs)
         names = [s[0] for s in eng.specs]
+        # modules a caller hung on the policy afterwards (test_ddppo_reduce.py:60-61 `actor_critic.unused = nn.Linear(64, 64)`) are not
+        # the engine's: they move like any nn.Module and stay outside the arena, the fused optimiser and the gradient exchange
+        own = set(names)
+        state = {k: v.detach() for k, v in self.state_dict().items() if k in own}
+        for nm, m in self._modules.items():
+            if nm not in ("net", "critic", "action_distribution") and m is not None:
+                m.to(device)
         assert names == list(state.keys()), "engine parameter table does not match the module's parameters"
         for nm, shp, _ in eng.specs:
             assert tuple(state[nm].shape) == shp, (nm, state[nm].shape, shp)
@@ -271,7 +281,7 @@ class NetPolicy(nn.Module, Policy):
         kw = self._engine_kwargs
         rgb = observations["rgb"] if kw["has_rgb"] else None
         depth = observations["depth"] if kw["has_depth"] else None
-        goal = observations[GOAL_UUID] if kw.get("goal_dim", 2) > 0 else None
+        goal = observations[getattr(self, "goal_key", GOAL_UUID)] if kw.get("goal_dim", 2) > 0 else None
         extra = {}
         if kw.get("has_semantic"):
             extra["semantic"] = observations["semantic"]
@@ -281,10 +291,15 @@ class NetPolicy(nn.Module, Policy):
             extra["compass"] = observations["compass"]
         if kw.get("has_gps"):
             extra["gps"] = observations["gps"]
+        if kw.get("arch") == "resnet" and kw.get("pointgoal_dim", 0) > 0:
+            extra["pointgoal"] = observations[POINTGOAL_UUID]
+        if kw.get("proximity_dim", 0) > 0:
+            extra["proximity"] = observations["proximity"]
         if VISUAL_FEATURES_KEY in observations:  # frozen encoder: the rollout holds its output (resnet_policy.py:636-646)
             extra["visual_features"] = observations[VISUAL_FEATURES_KEY]
         want = {"rgb": torch.uint8, "depth": torch.float32, "goal": torch.float32, "semantic": torch.int32, "objectgoal": torch.int64,
-                "compass": torch.float32, "gps": torch.float32, "visual_features": torch.float32}
+                "compass": torch.float32, "gps": torch.float32, "visual_features": torch.float32, "pointgoal": torch.float32,
+                "proximity": torch.float32}
         for name, t in dict(rgb=rgb, depth=depth, goal=goal, **extra).items():
             if t is None:
                 continue
@@ -344,7 +359,8 @@ class NetPolicy(nn.Module, Policy):
         call = dict(rgb=rgb, depth=depth, goal=goal, extra=extra, hidden0=rnn_hidden_states.contiguous(), masks=masks.contiguous(),
                     actions=action.contiguous(), prev_actions=prev_actions, pack=pack, B=B, n=n)
         if torch.is_grad_enabled():
-            v, lp, ent = _EvaluateFn.apply(self, call, *self.parameters())
+            own = self.engine.grad_views
+            v, lp, ent = _EvaluateFn.apply(self, call, *(p_ for k, p_ in self.named_parameters() if k in own))
         else:
             v, lp, ent = self._evaluate_dense(call)
         hidden = torch.empty(n, self.num_recurrent_layers, self._hidden, device=self.device)
@@ -390,15 +406,16 @@ def _baseline_init(cin, H, W, hidden, num_actions, goal_dim):
     h, w = co(co(co(H, 8, 4), 4, 2), 3, 1), co(co(co(W, 8, 4), 4, 2), 3, 1)
     out = {}
     # PointNavBaselineNet.__init__ builds SimpleCNN first (policy.py:530), then the RNN (:532-535)
-    layers = [("0", nn.Conv2d(cin, 32, 8, 4)), ("2", nn.Conv2d(32, 64, 4, 2)), ("4", nn.Conv2d(64, 32, 3, 1)),
-              ("6", nn.Linear(32 * h * w, hidden))]
+    # (blind -- no visual sensor -- : SimpleCNN.cnn is an empty nn.Sequential, simple_cnn.py:95-97: no parameters, no RNG consumed)
+    layers = [] if cin == 0 else [("0", nn.Conv2d(cin, 32, 8, 4)), ("2", nn.Conv2d(32, 64, 4, 2)), ("4", nn.Conv2d(64, 32, 3, 1)),
+                                  ("6", nn.Linear(32 * h * w, hidden))]
     for _, layer in layers:
         nn.init.kaiming_normal_(layer.weight, nn.init.calculate_gain("relu"))
         nn.init.constant_(layer.bias, val=0)
     for idx, layer in layers:
         out[f"net.visual_encoder.cnn.{idx}.weight"] = layer.weight.detach()
         out[f"net.visual_encoder.cnn.{idx}.bias"] = layer.bias.detach()
-    rnn = nn.GRU(input_size=hidden + goal_dim, hidden_size=hidden, num_layers=1)
+    rnn = nn.GRU(input_size=(hidden if cin else 0) + goal_dim, hidden_size=hidden, num_layers=1)  # policy.py:532-535
     for name, param in rnn.named_parameters():
         if "weight" in name:
             nn.init.orthogonal_(param)
@@ -426,21 +443,26 @@ class PointNavBaselinePolicy(NetPolicy):
                  max_envs: int = 64, **kwargs):
         sp = observation_space.spaces
         has_rgb, has_depth = "rgb" in sp, "depth" in sp
-        if not (has_rgb or has_depth):
-            raise _lib.HabError("blind PointNavBaselinePolicy is outside the accelerated path")
-        if GOAL_UUID not in sp:
-            raise _lib.HabError(f"PointNavBaselinePolicy on habitat_amd needs the '{GOAL_UUID}' sensor")
+        # goal sensor: IntegratedPointGoalGPSAndCompassSensor first, then PointGoalSensor (policy.py:504-514); the ImageGoalSensor variant
+        # builds a second SimpleCNN for the goal image (:515-522) and is outside the accelerated path
+        goal_key = GOAL_UUID if GOAL_UUID in sp else (POINTGOAL_UUID if POINTGOAL_UUID in sp else None)
+        if goal_key is None:
+            raise _lib.HabError(f"PointNavBaselinePolicy on habitat_amd needs the '{GOAL_UUID}' or the '{POINTGOAL_UUID}' sensor"
+                                + (" (an 'imagegoal' goal encoder is outside the accelerated path)" if "imagegoal" in sp else ""))
         if aux_loss_config:
             raise _lib.HabError("auxiliary losses are outside the accelerated path")
-        vis = sp["rgb"] if has_rgb else sp["depth"]
-        H, W = int(vis.shape[0]), int(vis.shape[1])
+        # blind (no rgb / depth, SimpleCNN.is_blind simple_cnn.py:54): the net is goal -> GRU -> heads -- the configuration of the
+        # reference's own DD-PPO test (test/test_ddppo_reduce.py:43-56)
+        vis = sp["rgb"] if has_rgb else (sp["depth"] if has_depth else None)
+        H, W = (int(vis.shape[0]), int(vis.shape[1])) if vis is not None else (0, 0)
         cin = (3 if has_rgb else 0) + (1 if has_depth else 0)
-        goal_dim = int(sp[GOAL_UUID].shape[0])
+        goal_dim = int(sp[goal_key].shape[0])
         na = get_num_actions(action_space)
         super().__init__(action_space,
                          dict(arch="simple_cnn", rnn_type="GRU", rnn_layers=1, hidden=hidden_size, H=H, W=W, has_rgb=has_rgb,
                               has_depth=has_depth, goal_dim=goal_dim, max_frames=max_frames, max_envs=max_envs),
                          lambda: _baseline_init(cin, H, W, hidden_size, na, goal_dim))
+        self.goal_key = goal_key
 
     @classmethod
     def from_config(cls, config, observation_space, action_space, **kwargs):
@@ -459,7 +481,7 @@ BACKBONES = {"resnet18": (18, "basic", [2, 2, 2, 2], False, False), "resnet50": 
 
 
 def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, baseplanes, H, W, normalize, has_goal=True, n_obj=0,
-                 has_gps=False, has_compass=False, gauss=None):
+                 has_gps=False, has_compass=False, gauss=None, pointgoal_dim=0, proximity_dim=0):
     """Parameter / buffer values exactly as PointNavResNetPolicy.__init__ produces them: the torch modules are created in
     the reference's order (resnet_policy.py:389-396 embedding, :454-456 tgt_embeding, :578-585 ResNetEncoder [default
     Conv2d / GroupNorm initialisers -- ResNetEncoder.layer_init is never called], :588-595 visual_fc, :597-602 state encoder
@@ -483,6 +505,14 @@ def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, base
     if has_gps:
         gps = nn.Linear(2, 32)
         out["net.gps_embedding.weight"], out["net.gps_embedding.bias"] = gps.weight.detach(), gps.bias.detach()
+        n_slots += 1
+    if pointgoal_dim > 0:  # resnet_policy.py:489-494
+        pg = nn.Linear(pointgoal_dim, 32)
+        out["net.pointgoal_embedding.weight"], out["net.pointgoal_embedding.bias"] = pg.weight.detach(), pg.bias.detach()
+        n_slots += 1
+    if proximity_dim > 0:  # :510-515
+        px = nn.Linear(proximity_dim, 32)
+        out["net.proximity_embedding.weight"], out["net.proximity_embedding.bias"] = px.weight.detach(), px.bias.detach()
         n_slots += 1
     if has_compass:
         cmp_ = nn.Linear(2, 32)
@@ -617,11 +647,14 @@ class PointNavResNetPolicy(NetPolicy):
         elif dist != "categorical":
             raise ValueError(f"Action distribution {dist} not supported.")
         visual_keys = [k for k, v in sp.items() if len(v.shape) > 1]  # observation-space order (resnet_policy.py:178-182)
-        known_1d = {GOAL_UUID, "objectgoal", "compass", "gps"}
+        # 1-D sensors with an embedding on the accelerated path (resnet_policy.py:454-515,662-734).  `heading` is refused: the reference's
+        # forward embeds sensor_observations[0] -- the FIRST ROW of the batch (:705-713) -- which only type-checks for one environment;
+        # `imagegoal` / `instance_imagegoal` build a second ResNetEncoder for the goal image (:517-545)
+        known_1d = {GOAL_UUID, POINTGOAL_UUID, "proximity", "objectgoal", "compass", "gps"}
         other = [k for k in sp.keys() if k not in visual_keys and k not in known_1d]
         if any(k not in ("rgb", "depth", "semantic") for k in visual_keys) or not visual_keys or other:
             raise _lib.HabError("PointNavResNetPolicy on habitat_amd supports the rgb / depth / semantic visual sensors and the "
-                                f"pointgoal_with_gps_compass, objectgoal, compass, gps 1-D sensors (got {list(sp.keys())})")
+                                f"pointgoal_with_gps_compass, pointgoal, proximity, objectgoal, compass, gps 1-D sensors (got {list(sp.keys())})")
         has_rgb, has_depth, has_sem = "rgb" in visual_keys, "depth" in visual_keys, "semantic" in visual_keys
         vis = sp[visual_keys[0]]
         H, W = int(vis.shape[0]), int(vis.shape[1])
@@ -635,6 +668,10 @@ class PointNavResNetPolicy(NetPolicy):
         has_gps, has_compass = "gps" in sp, "compass" in sp
         if has_gps and int(sp["gps"].shape[0]) != 2:
             raise _lib.HabError("gps sensor must be 2-D")
+        pg_dim = int(sp[POINTGOAL_UUID].shape[0]) if POINTGOAL_UUID in sp else 0
+        px_dim = int(sp["proximity"].shape[0]) if "proximity" in sp else 0
+        if pg_dim > 4 or px_dim > 4:
+            raise _lib.HabError("pointgoal / proximity sensors of more than 4 dimensions are outside the accelerated path")
         bufs = tuple("net.visual_encoder.running_mean_and_var." + k for k in ("_mean", "_var", "_count")) if normalize_visual_inputs else ()
         super().__init__(action_space,
                          dict(arch="resnet", backbone=BACKBONES[backbone][0], baseplanes=resnet_baseplanes,
@@ -642,9 +679,10 @@ class PointNavResNetPolicy(NetPolicy):
                               rnn_layers=num_recurrent_layers, hidden=hidden_size, H=H, W=W, has_rgb=has_rgb, has_depth=has_depth,
                               goal_dim=2 if has_goal else 0, max_frames=max_frames, max_envs=max_envs,
                               visual_order=tuple(visual_keys), has_semantic=has_sem, num_object_categories=n_obj,
-                              has_compass=has_compass, has_gps=has_gps, **(gauss_kw or {})),
+                              has_compass=has_compass, has_gps=has_gps, pointgoal_dim=pg_dim, proximity_dim=px_dim, **(gauss_kw or {})),
                          lambda: _resnet_init(n_in, hidden_size, na, rnn_type, num_recurrent_layers, backbone, resnet_baseplanes,
-                                              H, W, normalize_visual_inputs, has_goal, n_obj, has_gps, has_compass, gauss),
+                                              H, W, normalize_visual_inputs, has_goal, n_obj, has_gps, has_compass, gauss,
+                                              pointgoal_dim=pg_dim, proximity_dim=px_dim),
                          buffer_names=bufs)
 
     @classmethod

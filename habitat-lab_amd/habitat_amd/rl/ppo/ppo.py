@@ -49,8 +49,10 @@ class FlatAdam(torch.optim.Optimizer):
 
     def __init__(self, policy, lr, eps, betas=(0.9, 0.999)):
         self.policy = policy
-        super().__init__([p for p in policy.parameters() if p.requires_grad], dict(lr=lr, eps=eps, betas=betas))
         eng = policy.engine
+        own = {nm for nm, _, _ in eng.specs}  # parameters of foreign modules hung on the policy are not in the arena (never trained:
+        # in the reference they receive no gradient, test_ddppo_reduce.py:60-61)
+        super().__init__([p for nm, p in policy.named_parameters() if p.requires_grad and nm in own], dict(lr=lr, eps=eps, betas=betas))
         self.exp_avg = torch.zeros_like(eng.params_flat)
         self.exp_avg_sq = torch.zeros_like(eng.params_flat)
         self.step_count = 0
@@ -80,7 +82,7 @@ class FlatAdam(torch.optim.Optimizer):
         spec = {nm: (off, shp) for nm, shp, off in eng.specs}
         out = []
         for nm, par in self.policy.named_parameters():
-            if not par.requires_grad:
+            if not par.requires_grad or nm not in spec:
                 continue
             off, shp = spec[nm]
             n = 1
@@ -290,9 +292,7 @@ class PPO(nn.Module, Updater):
         st: RolloutStorage = batch.storage
         Bf = st.buffers
         obs = Bf["observations"]
-        rgb, depth = obs.get("rgb"), obs.get("depth")
-        goal = obs.get("pointgoal_with_gps_compass")
-        extra = {k: obs[k] for k in ("semantic", "objectgoal", "compass", "gps", "visual_features") if k in obs}
+        rgb, depth, goal, extra = self.actor_critic._obs_ptrs(obs)
         ver = "policy_version" in Bf  # VERRolloutStorage: slots of a linear buffer, importance weights, staleness statistics
         Bn, n = (batch.B, batch.n) if ver and hasattr(batch, "B") else (batch.T * batch.n, batch.n)
         w = self._work(Bn)
@@ -360,6 +360,11 @@ class PPO(nn.Module, Updater):
                     continue
                 out[name] = float(host[:, i].mean())
         return out
+
+    def _evaluate_actions(self, *args, **kwargs):
+        """Reference-style entry (ppo.py:155-162): dense tensors in, autograd out; under DD-PPO the gradients that reach
+        `param.grad` are already averaged over ranks, as with the reference's DistributedDataParallel wrapper (ddppo.py:142-157)."""
+        return self.actor_critic.evaluate_actions(*args, **kwargs)
 
     # ---- hooks kept for subclass compatibility (ppo.py:341-375) ---------------------------------------
     def before_backward(self, loss): return loss

@@ -270,6 +270,7 @@ int hab_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, 
 #define HAB_EMB_LIN2 3    /* gps (x, y): Linear(2,32) */
 #define HAB_EMB_PREV 4    /* previous action: Embedding(A+1, 32)(mask ? a+1 : 0) */
 #define HAB_EMB_PREVLIN 5 /* continuous previous action, float (rows, A <= 4): Linear(A, 32)(mask * a); num_tokens carries A */
+#define HAB_EMB_LINN 6    /* pointgoal (PointGoalSensor) / proximity, float (rows, d <= 4): Linear(d, 32) on the raw values; num_tokens carries d */
 typedef struct hab_embed_slot {
     int32_t kind;
     const void* input;     /* sensor values in arena rows: f32[2] / i64[1] / f32[1] / f32[2] / i64[1] per row */
@@ -341,6 +342,9 @@ typedef struct hab_policy_desc {
     int32_t action_dist;           /* HAB_DIST_* */
     int32_t gauss_flags;           /* HAB_GAUSS_* bits (ActionDistributionConfig, default_structured_configs.py:70-85) */
     float gauss_min_std, gauss_max_std;  /* clamp range of the RAW std output (min_log_std / max_log_std when USE_LOG_STD) */
+    /* further 1-D goal sensors (resnet_policy.py:489-494,510-515,694-700): dims of the PointGoalSensor / ProximitySensor vectors, 0 = absent.
+     * arch 0 (PointNavBaselinePolicy): a `pointgoal` sensor is passed as `goal` (policy.py:509-514), these stay 0. */
+    int32_t pointgoal_dim, proximity_dim;
 } hab_policy_desc;
 /* rl/ddppo/policy/resnet.py:296-345 */
 #define HAB_BACKBONE_RESNET18 18
@@ -370,6 +374,8 @@ typedef struct hab_obs {   /* arena base pointers; frame f lives at row rows[f] 
                                     (PointNavResNetNet.PRETRAINED_VISUAL_FEATURES_KEY, resnet_policy.py:399,636-646: frozen-encoder
                                     training, rl.ddppo.train_encoder=False).  When non-NULL, act / evaluate use it instead of running
                                     the encoder and backward stops at visual_fc (no encoder gradients are written). */
+    const float* pointgoal;      /* (rows, pointgoal_dim)  PointGoalSensor, arch 1 */
+    const float* proximity;      /* (rows, proximity_dim)  ProximitySensor, arch 1 */
 } hab_obs;
 
 typedef struct hab_pack_info { /* int32 copies of hab_build_pack_info's arrays */

@@ -281,8 +281,13 @@ def net_forward(params: Params, spec: NetSpec, obs, hidden_bf, prev_actions, mas
     """PointNavBaselineNet.forward rl/ppo/policy.py:557-589 / PointNavResNetNet.forward
     rl/ddppo/policy/resnet_policy.py:625-767 (PointNav subset: visual + goal + prev-action)."""
     if spec.kind == "baseline":
-        vis = simple_cnn(params, "net.visual_encoder.cnn.", obs, taps)
-        x = torch.cat([vis, obs[GOAL_UUID]], dim=1)
+        # rl/ppo/policy.py:572-582: goal = pointgoal_with_gps_compass, else pointgoal; a blind net (no visual sensor) is the goal alone
+        goal = obs[GOAL_UUID] if GOAL_UUID in obs else obs["pointgoal"]
+        if "rgb" in obs or "depth" in obs:
+            vis = simple_cnn(params, "net.visual_encoder.cnn.", obs, taps)
+            x = torch.cat([vis, goal], dim=1)
+        else:
+            x = goal
     else:
         if "visual_features" in obs:  # frozen encoder: PRETRAINED_VISUAL_FEATURES_KEY, resnet_policy.py:636-646
             feats = obs["visual_features"]
@@ -295,6 +300,10 @@ def net_forward(params: Params, spec: NetSpec, obs, hidden_bf, prev_actions, mas
             g = obs[GOAL_UUID]
             g = torch.stack([g[:, 0], torch.cos(-g[:, 1]), torch.sin(-g[:, 1])], -1)  # :662-672
             parts.append(F.linear(g, params["net.tgt_embeding.weight"], params["net.tgt_embeding.bias"]))
+        if "pointgoal" in obs:  # :694-696 (raw vector, no polar transform)
+            parts.append(F.linear(obs["pointgoal"], params["net.pointgoal_embedding.weight"], params["net.pointgoal_embedding.bias"]))
+        if "proximity" in obs:  # :698-700
+            parts.append(F.linear(obs["proximity"], params["net.proximity_embedding.weight"], params["net.proximity_embedding.bias"]))
         if "objectgoal" in obs:  # :715-717
             parts.append(F.embedding(obs["objectgoal"].long(), params["net.obj_categories_embedding.weight"]).squeeze(dim=1))
         if "compass" in obs:  # :719-729

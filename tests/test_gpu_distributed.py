@@ -243,3 +243,88 @@ def test_bench_py_launches_two_ranks_and_reports_whole_job_rate():
     steps = 2 * 64 * 128 * 2
     assert abs(out["value"] * out["ms_per_step"] * 2 / 1e3 - steps) <= 0.01 * steps  # whole-job aggregate over both ranks
     assert "cpu_baseline" not in out and "note" in out
+
+
+def _reduce_worker(rank, world, port, unused_params, q):
+    """The body of the reference's own worker, test/test_ddppo_reduce.py:28-121, on this package's classes: blind
+    PointNavBaselinePolicy (only `pointgoal_with_gps_compass`, Discrete(1)), DDPPO, RolloutStorage, one batch through the
+    updater's `_evaluate_actions`, autograd backward, gradients compared across ranks."""
+    for p in (ROOT, os.path.join(ROOT, "habitat-lab_amd")):
+        sys.path.insert(0, p)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import torch.distributed as distrib
+    from torch import nn
+    from habitat_amd.common import spaces as S
+    from habitat_amd.common.rollout_storage import RolloutStorage
+    from habitat_amd.config.default import get_config
+    from habitat_amd.rl.ddppo.ddppo import DDPPO
+    from habitat_amd.rl.ppo import PointNavBaselinePolicy
+    device = torch.device("cuda")
+    store = distrib.TCPStore("127.0.0.1", port, world, rank == 0)
+    distrib.init_process_group("gloo", store=store, rank=rank, world_size=world)
+    config = get_config("pointnav/ppo_pointnav_example.yaml", ["habitat_baselines.rl.ppo.num_mini_batch=1", "habitat_baselines.rl.ppo.num_steps=16",
+                                                               "habitat_baselines.rl.ppo.ppo_epoch=4", "habitat_baselines.rl.ppo.clip_param=0.1"])
+    obs_space = S.Dict({"pointgoal_with_gps_compass": S.Box(np.finfo(np.float32).min, np.finfo(np.float32).max, (2,), np.float32)})
+    action_space = S.Discrete(1)
+    torch.manual_seed(100 + rank)  # different initial weights per rank: init_distributed must make them rank 0's
+    actor_critic = PointNavBaselinePolicy.from_config(config, obs_space, action_space)
+    if unused_params:
+        actor_critic.unused = nn.Linear(64, 64)
+    actor_critic.to(device=device)
+    ppo_cfg = config.habitat_baselines.rl.ppo
+    agent = DDPPO(actor_critic=actor_critic, clip_param=ppo_cfg.clip_param, ppo_epoch=ppo_cfg.ppo_epoch, num_mini_batch=ppo_cfg.num_mini_batch,
+                  value_loss_coef=ppo_cfg.value_loss_coef, entropy_coef=ppo_cfg.entropy_coef, lr=ppo_cfg.lr, eps=ppo_cfg.eps,
+                  max_grad_norm=ppo_cfg.max_grad_norm, use_normalized_advantage=ppo_cfg.use_normalized_advantage)
+    agent.init_distributed(find_unused_params=unused_params)
+    rollouts = RolloutStorage(ppo_cfg.num_steps, 2, obs_space, action_space, actor_critic, is_double_buffered=False)
+    rollouts.to(device)
+    torch.manual_seed(7 + rank)  # the ranks see different observations
+    for k, v in rollouts.buffers["observations"].items():
+        rollouts.buffers["observations"][k] = torch.randn_like(v)
+    rollouts.advance_rollout()
+    rollouts.advance_rollout()
+    batch = next(rollouts.data_generator(rollouts.buffers["returns"], 1))
+    value, action_log_probs, dist_entropy, _, _ = agent._evaluate_actions(batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"],
+                                                                          batch["masks"], batch["actions"], batch["rnn_build_seq_info"])
+    (value.mean() + action_log_probs.mean() + dist_entropy.mean()).backward()
+    n_checked, local_norm = 0, 0.0
+    for name, param in actor_critic.named_parameters():
+        if param.grad is not None:
+            mine = param.grad.detach().cpu().clone()
+            grads = [torch.empty_like(mine) for _ in range(world)]
+            distrib.all_gather(grads, mine)
+            for i in range(world):
+                assert torch.isclose(grads[i], grads[rank]).all(), name
+            n_checked += 1
+            local_norm += float(mine.abs().sum())
+        else:
+            assert name.startswith("unused."), name
+    assert n_checked == 4 + 4 + 2  # GRU (4) + the two heads (2 x 2): a blind policy has no visual encoder
+    assert local_norm > 0
+    # the full fused update on the same storage: parameters stay identical across ranks, foreign parameters untouched
+    before = actor_critic.unused.weight.detach().clone() if unused_params else None
+    agent.update(rollouts)
+    flat = actor_critic.engine.params_flat.detach().cpu()
+    both = [torch.empty_like(flat) for _ in range(world)]
+    distrib.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])
+    if unused_params:
+        assert torch.equal(before, actor_critic.unused.weight) and actor_critic.unused.weight.is_cuda
+    q.put(rank)
+    distrib.barrier()
+    distrib.destroy_process_group()
+
+
+@pytest.mark.parametrize("unused_params", [True, False])
+def test_ddppo_reduce_reference_configuration(unused_params):
+    """test/test_ddppo_reduce.py:43-56,123-132 as the reference runs it."""
+    world, port = 2, find_free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, world, port, unused_params, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [0, 1]

@@ -451,6 +451,100 @@ def test_engine_lstm_gru_multilayer_vs_oracle(rnn_type, layers, hidden):
     assert not bad, bad
 
 
+def test_blind_baseline_policy_vs_oracle():
+    """PointNavBaselinePolicy without a visual sensor (SimpleCNN.is_blind: goal -> GRU -> heads; the reference's own DD-PPO test builds
+    exactly this, test/test_ddppo_reduce.py:43-56, with Discrete(1)): act, evaluate, every gradient against the oracle."""
+    from habitat_amd.common import spaces as S
+    from habitat_amd.engine import DevicePackInfo
+    from habitat_amd.rl.ppo import PointNavBaselinePolicy
+    hidden, T, n = 64, 9, 3
+    B = T * n
+    for goal_key, n_act in ((GOAL, 1), ("pointgoal", 4)):
+        torch.manual_seed(21)
+        pol = PointNavBaselinePolicy(S.Dict({goal_key: S.Box(-1e9, 1e9, (2,), np.float32)}), S.Discrete(n_act), hidden_size=hidden,
+                                     max_frames=B, max_envs=n)
+        params = {k: v.detach().clone() for k, v in pol.state_dict().items()}
+        assert not any("visual_encoder" in k for k in params)
+        pol.to("cuda")
+        pol.train()
+        rng = np.random.default_rng(4)
+        goal = torch.from_numpy(rng.standard_normal((B, 2)).astype(np.float32))
+        masks = torch.from_numpy(rng.random((B, 1)) > 0.25)
+        actions = torch.from_numpy(rng.integers(0, n_act, (B, 1)))
+        h0 = torch.from_numpy(rng.standard_normal((n, 1, hidden)).astype(np.float32))
+        spec = O.NetSpec(kind="baseline", hidden=hidden, num_actions=n_act)
+        p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        v, lp, ent, hfin = O.evaluate_actions(p, spec, {goal_key: goal}, h0, torch.zeros(B, 1, dtype=torch.long), masks, actions)
+        gv, glp, gent = (torch.from_numpy(rng.standard_normal((B, 1)).astype(np.float32)) for _ in range(3))
+        ((v * gv).sum() + (lp * glp).sum() + (ent * gent).sum()).backward()
+        eng = pol.engine
+        pack = DevicePackInfo(np.logical_not(masks.view(T, n).numpy()), "cuda")
+        dv, dl, de = (torch.zeros(B, device="cuda") for _ in range(3))
+        eng.evaluate(None, None, goal.cuda(), None, h0.cuda(), masks.cuda(), actions.cuda(), pack, B, n, value=dv, log_prob=dl, entropy=de)
+        assert rel_ok(dv.cpu().numpy(), v.detach().numpy().reshape(-1))
+        assert rel_ok(dl.cpu().numpy(), lp.detach().numpy().reshape(-1), floor=1e-6)
+        assert rel_ok(de.cpu().numpy(), ent.detach().numpy().reshape(-1), floor=1e-6)
+        eng.backward(None, None, goal.cuda(), None, actions.cuda(), pack, gv.view(-1).cuda(), glp.view(-1).cuda(), gent.view(-1).cuda())
+        bad = [(k, float((g.cpu() - p[k].grad).abs().max()), float(p[k].grad.abs().max())) for k, g in eng.grad_views.items()
+               if not rel_ok(g.cpu().numpy(), p[k].grad.numpy(), tol=1e-4, floor=1e-4)]
+        assert not bad, bad
+        # act on n envs through the plugin surface: same sampled actions as the oracle given the same Exp(1) noise
+        pol.eval()
+        noise = torch.from_numpy(rng.exponential(1.0, (n, n_act)).astype(np.float32))
+        ad = pol.act({goal_key: goal[:n].cuda()}, h0.cuda(), torch.zeros(n, 1, dtype=torch.long, device="cuda"), masks[:n].cuda(),
+                     exp_noise=noise.cuda())
+        with torch.no_grad():
+            ref = O.act({k: v.detach() for k, v in p.items()}, spec, {goal_key: goal[:n]}, h0, torch.zeros(n, 1, dtype=torch.long), masks[:n],
+                        exp_noise=noise)
+        assert torch.equal(ad.actions.cpu(), ref["actions"])
+        assert rel_ok(ad.values.cpu().numpy(), ref["values"].numpy())
+
+
+def test_resnet_policy_pointgoal_and_proximity_embeddings_vs_oracle():
+    """PointNavResNetNet's PointGoalSensor / ProximitySensor inputs (resnet_policy.py:489-515,694-700) beside the polar goal, gps and
+    compass: values / log-probs and the gradients of all six embeddings against the oracle."""
+    from habitat_amd.common import spaces as S
+    from habitat_amd.engine import DevicePackInfo
+    from habitat_amd.rl.ppo import PointNavResNetPolicy
+    hidden, T, n, H, W = 64, 3, 2, 64, 64
+    B = T * n
+    box = lambda d: S.Box(-1e9, 1e9, (d,), np.float32)
+    osp = S.Dict({"depth": S.Box(0.0, 1.0, (H, W, 1), np.float32), GOAL: box(2), "pointgoal": box(2), "proximity": box(1), "gps": box(2),
+                  "compass": box(1)})
+    torch.manual_seed(8)
+    pol = PointNavResNetPolicy(osp, S.Discrete(4), hidden_size=hidden, backbone="resnet18", max_frames=B, max_envs=n)
+    params = {k: v.detach().clone() for k, v in pol.state_dict().items()}
+    pol.to("cuda")
+    pol.train()
+    rng = np.random.default_rng(5)
+    f32 = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    obs = {"depth": torch.from_numpy(rng.random((B, H, W, 1), dtype=np.float32)), GOAL: f32(B, 2).abs(), "pointgoal": f32(B, 2),
+           "proximity": f32(B, 1).abs(), "gps": f32(B, 2), "compass": f32(B, 1)}
+    masks = torch.from_numpy(rng.random((B, 1)) > 0.3)
+    actions = torch.from_numpy(rng.integers(0, 4, (B, 1)))
+    prev_actions = torch.from_numpy(rng.integers(0, 4, (B, 1)))
+    h0 = f32(n, 1, hidden)
+    spec = O.NetSpec(kind="resnet", rnn_type="GRU", num_layers=1, backbone="resnet18", baseplanes=32, visual_keys=("depth",), normalize=False,
+                     hidden=hidden)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    v, lp, ent, _ = O.evaluate_actions(p, spec, obs, h0, prev_actions, masks, actions, training=True)
+    gv, glp, gent = (f32(B, 1) for _ in range(3))
+    ((v * gv).sum() + (lp * glp).sum() + (ent * gent).sum()).backward()
+    eng = pol.engine
+    pack = DevicePackInfo(np.logical_not(masks.view(T, n).numpy()), "cuda")
+    dv, dl, de = (torch.zeros(B, device="cuda") for _ in range(3))
+    extra = {k: obs[k].cuda() for k in ("pointgoal", "proximity", "gps", "compass")}
+    eng.evaluate(None, obs["depth"].cuda(), obs[GOAL].cuda(), None, h0.cuda(), masks.cuda(), actions.cuda(), pack, B, n, value=dv, log_prob=dl,
+                 entropy=de, prev_actions=prev_actions.cuda(), extra=extra)
+    assert rel_ok(dv.cpu().numpy(), v.detach().numpy().reshape(-1))
+    assert rel_ok(dl.cpu().numpy(), lp.detach().numpy().reshape(-1))
+    eng.backward(None, obs["depth"].cuda(), obs[GOAL].cuda(), None, actions.cuda(), pack, gv.view(-1).cuda(), glp.view(-1).cuda(),
+                 gent.view(-1).cuda(), prev_actions=prev_actions.cuda(), extra=extra)
+    for k, g in eng.grad_views.items():
+        if "_embed" in k:
+            assert rel_ok(g.cpu().numpy(), p[k].grad.numpy(), tol=1e-4, floor=1e-5), k
+
+
 RESNET_VARIANTS = [  # backbone, rnn, layers, H, W, visual key order, normalize
     ("resnet18", "GRU", 1, 128, 128, ("depth", "rgb"), True),
     ("resnet18", "LSTM", 2, 64, 96, ("rgb", "depth"), False),

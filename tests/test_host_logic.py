@@ -719,3 +719,64 @@ def test_resnet_encoder_geometry_rule_matches_live_reference(H, W):
         sa, sb = a.state_dict(), b.state_dict()
         assert list(sa.keys()) == list(sb.keys())
         assert all(sa[k].shape == sb[k].shape and torch.equal(sa[k], sb[k]) for k in sb), (backbone, H, W)
+
+
+def test_blind_baseline_policy_and_pointgoal_sensor_identical_to_live_reference():
+    """PointNavBaselinePolicy without a visual sensor (SimpleCNN.is_blind, simple_cnn.py:54,95-97: the configuration of the reference's
+    own DD-PPO test, test/test_ddppo_reduce.py:43-56) and with the PointGoalSensor goal (policy.py:509-514): parameter names, shapes and
+    seeded values equal the live reference's."""
+    from habitat_amd.common import spaces as S
+    from habitat_amd.rl.ppo import PointNavBaselinePolicy
+    from habitat_amd._lib import HabError
+    goal = S.Box(-1e9, 1e9, (2,), np.float32)
+    blind = PointNavBaselinePolicy(S.Dict({"pointgoal_with_gps_compass": goal}), S.Discrete(1), hidden_size=64)
+    assert [k for k in blind.state_dict()] == ["net.state_encoder.rnn.weight_ih_l0", "net.state_encoder.rnn.weight_hh_l0",
+                                               "net.state_encoder.rnn.bias_ih_l0", "net.state_encoder.rnn.bias_hh_l0",
+                                               "action_distribution.linear.weight", "action_distribution.linear.bias", "critic.fc.weight",
+                                               "critic.fc.bias"]
+    assert blind.state_dict()["net.state_encoder.rnn.weight_ih_l0"].shape == (3 * 64, 2)
+    with pytest.raises(HabError, match="imagegoal"):
+        PointNavBaselinePolicy(S.Dict({"imagegoal": S.Box(0, 255, (8, 8, 3), np.uint8)}), S.Discrete(4), hidden_size=64)
+    from oracle.ref_loader import load_reference, reference_available
+    if not reference_available():
+        return
+    ns = load_reference()
+    sp = ns.spaces
+    rgoal = sp.Box(-1e9, 1e9, (2,), np.float32)
+    for mine_space, ref_space, asp_n in (
+            (S.Dict({"pointgoal_with_gps_compass": goal}), sp.Dict({"pointgoal_with_gps_compass": rgoal}), 1),
+            (S.Dict({"depth": S.Box(0, 1, (44, 44, 1), np.float32), "pointgoal": goal}),
+             sp.Dict({"depth": sp.Box(0, 1, (44, 44, 1), np.float32), "pointgoal": rgoal}), 4)):
+        torch.manual_seed(9)
+        a = PointNavBaselinePolicy(mine_space, S.Discrete(asp_n), hidden_size=64).state_dict()
+        torch.manual_seed(9)
+        b = ns.policy.PointNavBaselinePolicy(ref_space, sp.Discrete(asp_n), hidden_size=64).state_dict()
+        assert list(a.keys()) == list(b.keys())
+        assert all(a[k].shape == b[k].shape and torch.equal(a[k], b[k]) for k in b)
+
+
+def test_resnet_policy_pointgoal_and_proximity_sensors_identical_to_live_reference():
+    """PointNavResNetNet's further 1-D goal sensors (resnet_policy.py:489-515,694-700): pointgoal_embedding / proximity_embedding are created
+    between gps_embedding and compass_embedding; `heading` is refused (the reference embeds row 0 of the batch)."""
+    from habitat_amd.common import spaces as S
+    from habitat_amd._lib import HabError
+    from habitat_amd.rl.ddppo.policy import PointNavResNetPolicy
+    mk = lambda M, extra: M.Dict(dict({"depth": M.Box(0, 1, (64, 64, 1), np.float32), "pointgoal_with_gps_compass": M.Box(-1e9, 1e9, (2,), np.float32),
+                                       "pointgoal": M.Box(-1e9, 1e9, (2,), np.float32), "proximity": M.Box(0, 10, (1,), np.float32),
+                                       "gps": M.Box(-1e9, 1e9, (2,), np.float32), "compass": M.Box(-4, 4, (1,), np.float32)}, **extra))
+    torch.manual_seed(3)
+    mine = PointNavResNetPolicy(mk(S, {}), S.Discrete(4), hidden_size=64, backbone="resnet18").state_dict()
+    keys = list(mine.keys())
+    assert keys.index("net.gps_embedding.bias") < keys.index("net.pointgoal_embedding.weight") < keys.index("net.proximity_embedding.weight") \
+        < keys.index("net.compass_embedding.weight")
+    assert mine["net.proximity_embedding.weight"].shape == (32, 1) and mine["net.state_encoder.rnn.weight_ih_l0"].shape[1] == 64 + 32 * 6
+    with pytest.raises(HabError):
+        PointNavResNetPolicy(mk(S, {"heading": S.Box(-4, 4, (1,), np.float32)}), S.Discrete(4), hidden_size=64, backbone="resnet18")
+    from oracle.ref_loader import load_reference, reference_available
+    if not reference_available():
+        return
+    ns = load_reference()
+    torch.manual_seed(3)
+    ref = ns.resnet_policy.PointNavResNetPolicy(mk(ns.spaces, {}), ns.spaces.Discrete(4), hidden_size=64, backbone="resnet18").state_dict()
+    assert list(mine.keys()) == list(ref.keys())
+    assert all(mine[k].shape == ref[k].shape and torch.equal(mine[k], ref[k]) for k in ref)
