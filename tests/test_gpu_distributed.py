@@ -299,7 +299,7 @@ def _reduce_worker(rank, world, port, unused_params, q):
             local_norm += float(mine.abs().sum())
         else:
             assert name.startswith("unused."), name
-    assert n_checked == 4 + 4 + 2  # GRU (4) + the two heads (2 x 2): a blind policy has no visual encoder
+    assert n_checked == 4 + 2 * 2, n_checked  # GRU (4) + the two heads (2 x 2): a blind policy has no visual encoder
     assert local_norm > 0
     # the full fused update on the same storage: parameters stay identical across ranks, foreign parameters untouched
     before = actor_critic.unused.weight.detach().clone() if unused_params else None
