@@ -76,7 +76,7 @@ PROBES = {
 C2_TABLE = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_wgrad", "fc_dgrad", "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad",
             "conv1_wgrad", "rnn_fwd", "rnn_bwd"]
 # kernel launched by a probed call site (rocprofv3 names), for the HBM-traffic lookup in the committed --pmc passes
-PROBE_KERNELS = {"conv2_dgrad": "igemm_bf3_kernel<ConvDgradMergedProb", "conv1_fwd": "obs_conv_bf3_kernel",
+PROBE_KERNELS = {"conv2_dgrad": "igemm_bf3_kernel<ConvDgradMergedProb", "conv1_fwd": "obs_conv_patch_kernel",
                  "conv1_wgrad": "obs_wgrad_bf3_kernel", "conv2_wgrad": "igemm_bf3_kernel<ConvWgradProb, 1, 2",
                  "conv3_wgrad": "igemm_bf3_kernel<ConvWgradProb, 1, 1", "conv2_fwd": "igemm_bf3_kernel<ConvFwdProb, 1, 2",
                  "conv3_fwd": "conv_patch_bf3_kernel<ConvFwdProb", "conv3_dgrad": "igemm_bf3_kernel<ConvDgradProb",
@@ -110,11 +110,20 @@ def site_roofline(site, flops_per_frame, frames, ms):
     else:
         r.update(achieved=round(tfl, 2), peak=round(peak_eq, 1), unit="TFLOP/s", frac=round(tfl / peak_eq, 4))
     r["fp32_equiv_tflops"] = round(tfl, 2)
+    r["frac_of_split_ceiling"] = round(tfl / peak_eq, 4)  # against the matrix pipe in use, whichever roofline bounds the site
+    r["algorithmic_bytes_per_frame"] = bytes_pf
     r["algorithmic_gbs"] = round(gbs, 1)
     r["mfma_ceiling_fp32_equiv_tflops"] = round(peak_eq, 1)
     r["frac_of_fp32_mfma_peak"] = round(tfl / PEAK_FP32_MFMA_TFLOPS, 4)  # the round-1 yardstick (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s)
     r["roofline_floor_ms_per_kframe"] = round(max(t_hbm, t_mfma) * 1e6, 4)
     return r
+
+
+def site_chunks(site):
+    """Launches of a call site per minibatch: the time-major chunked recurrence (csrc/engine.hip, HAB_RNN_CHUNKS, default 4) runs the
+    forward sites and the data-gradient chain (fc / conv3 / conv2 dgrad) once per time chunk; weight gradients once per minibatch."""
+    chunks = int(os.environ.get("HAB_RNN_CHUNKS", "4")) or 1
+    return chunks if (site.endswith("_fwd") or site.endswith("_dgrad")) else 1
 
 
 def make_trainer(workload: str, total_updates: int):
@@ -138,7 +147,7 @@ def make_trainer(workload: str, total_updates: int):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # CPU leg + parity leg (rank 0, N = 1)
 # ---------------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_and_parity(trainer, cfg, sample_envs=NUM_ENVS, sample_steps=NUM_STEPS, parity=True):
+def cpu_baseline_and_parity(trainer, cfg, sample_envs=NUM_ENVS, sample_steps=NUM_STEPS, parity=True, cpu_threads=0):
     """(a) `cpu_baseline`: the oracle (oracle/functional.py: CPU restatement of the reference PPOTrainer path, pinned to the live
     reference by tests/golden) runs ONE full update cycle of the workload -- rollout of 64 envs x 128 steps with policy.act per step,
     GAE, PPO update E=4 x M=4 -- on the host cores and is timed.  (b) `parity`: the rollout the oracle produced (observations,
@@ -151,7 +160,9 @@ def cpu_baseline_and_parity(trainer, cfg, sample_envs=NUM_ENVS, sample_steps=NUM
     from oracle import functional as O
     from oracle import synth
     from oracle.fixtures import synth_rollout_inputs
-    threads = min(16, os.cpu_count() or 1)  # more threads than this slow the small-batch CPU convolutions down
+    # default 16 threads: more slow the small-batch CPU convolutions of the rollout down (both settings were timed:
+    # profiles/r03_cpu_leg_threads.json, --cpu-threads)
+    threads = cpu_threads if cpu_threads > 0 else min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     N, T, hidden = sample_envs, sample_steps, 512
     pol = trainer._agent.actor_critic
@@ -318,7 +329,9 @@ def run_cycles(workload, steps, warmup):
     rec = {"workload": WORKLOADS[workload]["name"], "value": round(n / dt, 1), "unit": "env-steps/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(dt / steps * 1e3, 2),
            "frac_of_mfma_roofline": round(n / dt * 2.2632e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if workload == "c3" else None,
-           "frac_basis": "executed contraction FLOPs (2.263 GFLOP per env-step: the stem's data gradient is not computed) / fp32 MFMA peak 157.3"}
+           "frac_of_split_ceiling": round(n / dt * 2.2632e9 / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12), 4) if workload == "c3" else None,
+           "frac_basis": "executed contraction FLOPs (2.263 GFLOP per env-step: the stem's data gradient is not computed) / fp32 MFMA peak 157.3; "
+                         "frac_of_split_ceiling = the same FLOPs / (bf16 MFMA peak / 6 partial products = 416.7)"}
     del trainer
     torch.cuda.empty_cache()
     return rec
@@ -331,7 +344,7 @@ def hbm_traffic(workload, probe):
     same command (the newest committed round); null when the probed call site has no entry."""
     if workload != "c2" or probe not in PROBE_KERNELS:
         return None, None
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_c2_hbm_traffic.json")
         if not os.path.exists(path):
             continue
@@ -365,6 +378,7 @@ def main():
     ap.add_argument("--probe", default=None, choices=list(PROBES))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg, the parity leg and the sub-records (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the c3 / encoder sub-records only")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU leg (default min(16, host cores); -1 = every host core)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -453,6 +467,10 @@ def main():
                          avg_launch_ms=round(probe_ms / max(probe_cnt, 1), 4), share_of_step=round(probe_ms / (dt * 1e3), 4),
                          frames_per_launch=round(frames / max(probe_cnt, 1), 1)),
     }
+    if traffic is not None and a.probe in SITE_MODEL and probe_cnt:
+        upd_frames = n_envs * n_steps // ppo.num_mini_batch // site_chunks(a.probe)
+        out["roofline"]["traffic_ratio"] = round(traffic / (SITE_MODEL[a.probe][0] * upd_frames), 3)
+        out["roofline"]["traffic_basis"] = f"update-sized launch of {upd_frames} frames; algorithmic bytes {SITE_MODEL[a.probe][0]} per frame"
     if a.workload in ("c2", "c3"):
         # FLOPs per env-step of the contractions that are EXECUTED: F = 2 MAC_fwd (1 + 1/T) + E (2 (3 MAC_fwd - MAC_first_dgrad)) -- the data
         # gradient of the first convolution (wrt the observation) is never computed.  SURVEY.md 8(d)'s formula counts it (C2 2.365,
@@ -463,7 +481,10 @@ def main():
         out["roofline"]["whole_cycle_frac"] = round(rate * f_exec / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)
         out["roofline"]["whole_cycle"] = {"executed_gflop_per_env_step": round(f_exec / 1e9, 4), "tflops": round(rate * f_exec / 1e12, 2),
                                           "frac_of_fp32_mfma_peak": out["roofline"]["whole_cycle_frac"],
-                                          "frac_with_survey_formula": round(rate * f_survey / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)}
+                                          "frac_with_survey_formula": round(rate * f_survey / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                                          # against the pipe in use: bf16 MFMA peak / 6 partial products (conv1: 3.75, priced at 6 here)
+                                          "frac_of_split_ceiling": round(rate * f_exec / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12), 4),
+                                          "split_ceiling_tflops": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)}
     if a.workload == "c2" and world == 1:
         # per-call-site table from ONE extra cycle with every probe on (outside the timed region: ~1400 event records per cycle).
         # Single-rank runs only: the other ranks of a multi-rank run have left by now and an extra cycle would wait on their
@@ -480,15 +501,28 @@ def main():
         for k, (t_, fl) in tags.items():
             ms, cnt = eng.probe_read_tag(t_)
             if cnt:
-                sr = site_roofline(k, fl, frames_seen(k, ls, 1), ms)
-                table.append({"site": k, "ms": round(ms, 2), "calls": cnt, "share": round(ms / cyc_ms, 4),
-                              "tflops": sr.get("fp32_equiv_tflops", sr["achieved"]), "bound": sr["bound"], "achieved": sr["achieved"],
-                              "peak": sr["peak"], "unit": sr["unit"], "frac": sr["frac"]})
+                fs = frames_seen(k, ls, 1)
+                sr = site_roofline(k, fl, fs, ms)
+                row = {"site": k, "ms": round(ms, 2), "calls": cnt, "share": round(ms / cyc_ms, 4),
+                       "tflops": sr.get("fp32_equiv_tflops", sr["achieved"]), "bound": sr["bound"], "achieved": sr["achieved"],
+                       "peak": sr["peak"], "unit": sr["unit"], "frac": sr["frac"]}
+                if "frac_of_split_ceiling" in sr:
+                    row["frac_of_split_ceiling"] = sr["frac_of_split_ceiling"]
+                # HBM bytes of the update-sized launch (committed --pmc passes of this command) over its algorithmic bytes
+                tr, _ = hbm_traffic(a.workload, k)
+                if tr is not None and k in SITE_MODEL:
+                    upd_frames = n_envs * n_steps // ppo.num_mini_batch // site_chunks(k)
+                    row["traffic"] = tr
+                    row["traffic_ratio"] = round(tr / (SITE_MODEL[k][0] * upd_frames), 3)
+                table.append(row)
         eng.probe_read()
         eng.probe_enable(-1)
         out["roofline"]["kernels"] = sorted(table, key=lambda r: -r["ms"])
     if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
-        base, par = cpu_baseline_and_parity(trainer, cfg)
+        base, par = cpu_baseline_and_parity(trainer, cfg, cpu_threads=(os.cpu_count() or 1) if a.cpu_threads < 0 else a.cpu_threads)
+        other = os.path.join(ROOT, "profiles", "r03_cpu_leg_threads.json")
+        if os.path.exists(other):  # the same leg timed once at every thread setting on the GPU box's host (committed measurement)
+            base["thread_settings_measured"] = json.load(open(other))
         out["cpu_baseline"] = base
         if par:
             out["parity"] = par

@@ -4,7 +4,9 @@
 #   * rocprofv3 --kernel-trace summaries (C2, C3, C5) + the rollout / learner phase split of the same traces (tools/trace_phases.py)
 #   * --pmc passes, counters only, each in its own run (MI355X_MICROARCH.md):
 #       FETCH_SIZE, WRITE_SIZE (C2 and C3)            -> tools/pmc_traffic.py -> HBM bytes per launch
-#       SQ busy / MFMA-busy / wait / instruction mix  -> tools/pmc_sq.py      -> per-kernel matrix-pipe utilisation (C2)
+#       SQ busy / MFMA-busy / wait / instruction mix  -> tools/pmc_sq.py      -> per-kernel matrix-pipe utilisation (C2: all three
+#                                                        counter groups; C3, C5: the busy / MFMA-busy group)
+#   * the CPU leg of bench.py once more with every host core (the default line uses 16 threads) -> <tag>_cpu_leg_threads.json
 # Every profiler pass runs under `timeout`: a rocprofv3 --pmc pass of the C3 command once hung until gpurun's limit.
 # usage: tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>_*   (copy what is to be judged into profiles/)
 set -u
@@ -26,7 +28,7 @@ for W in c2 c3 c5; do
   grep '^{' $O/prof_${TAG}_$W.log | tail -1 > $O/${TAG}_${W}_profiled_bench.json
   rm -rf /tmp/prof_${TAG}_$W $O/prof_${TAG}_$W.log
 done
-for W in c2 c3; do
+for W in c2 c3 c5; do
   rm -rf /tmp/pmc_${TAG}_$W
   for PM in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $PM --kernel-trace -d /tmp/pmc_${TAG}_$W -o $PM --output-format csv -- python $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
@@ -38,4 +40,22 @@ cd $R
 tools/pmc_run.sh /tmp/pmcsq_${TAG} python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline
 python tools/pmc_sq.py /tmp/pmcsq_${TAG} $O/${TAG}_c2_sq_counters.txt > /dev/null
 rm -rf /tmp/pmcsq_${TAG}
+for W in c3 c5; do
+  PMC_GROUPS=1 tools/pmc_run.sh /tmp/pmcsq_${TAG}_$W python $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline
+  python tools/pmc_sq.py /tmp/pmcsq_${TAG}_$W $O/${TAG}_${W}_sq_counters.txt > /dev/null
+  rm -rf /tmp/pmcsq_${TAG}_$W
+done
+timeout 400 python bench.py --steps 1 --warmup 1 --no-extras --cpu-threads -1 > $O/${TAG}_c2_cpu_allcores.json 2> $O/${TAG}_c2_cpu_allcores.err
+python - <<PY
+import json
+rows = []
+for f in ("$O/${TAG}_c2_bench.json", "$O/${TAG}_c2_cpu_allcores.json"):
+    try:
+        c = json.loads(open(f).read().strip().splitlines()[-1])["cpu_baseline"]
+        rows.append({"threads": c["cores"], "env_steps_per_s": c["value"]})
+    except Exception as e:
+        print("cpu leg missing in", f, e)
+json.dump(rows, open("$O/${TAG}_cpu_leg_threads.json", "w"))
+print(rows)
+PY
 ls -la $O | grep ${TAG}_

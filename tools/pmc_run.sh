@@ -11,6 +11,7 @@ P3="SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ
 i=0
 for PM in "$P1" "$P2" "$P3"; do
   i=$((i+1))
+  if [ $i -gt ${PMC_GROUPS:-3} ]; then break; fi
   ( cd /tmp && timeout 300 rocprofv3 --pmc $PM --kernel-trace -d $OUT/p$i -o p$i --output-format csv -- "$@" > $OUT/p$i.log 2>&1 )
   find $OUT/p$i -name "*kernel_trace.csv" -delete
 done

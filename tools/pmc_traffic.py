@@ -16,7 +16,10 @@ def load(path, name):
         for r in csv.DictReader(f):
             if r["Counter_Name"] != name:
                 continue
-            a = agg[re.sub(r"\bhab::", "", r["Kernel_Name"])]
+            # one row per (kernel, grid): a kernel that serves the rollout (64 frames) and the update (512 .. 2048 frames) is not averaged
+            # over the two
+            grid = r.get("Grid_Size") or r.get("Grid_Size_X") or ""
+            a = agg[re.sub(r"\bhab::", "", r["Kernel_Name"]) + (f" [grid {grid}]" if grid else "")]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
     return agg
