@@ -158,15 +158,16 @@ class SyntheticVectorEnv:
             raise _lib.HabError(f"env {index_env}: async_step_at called twice without wait_step_at")
         self._pending.add(int(index_env))
 
-    def _advance_pending(self):
-        """Advances exactly the envs whose step was requested.  All envs (the usual case): one generator launch into the env's
-        own tensors.  A subset (the double-buffered sampler steps the two halves out of phase, ppo_trainer.py:743-768): the
-        generator runs on scratch copies of the per-env clocks / tensors and only the requested rows are taken over."""
+    def advance_on_device(self) -> List[int]:
+        """Advances exactly the envs whose step was requested, entirely on the device (no host copy of any observation): their new
+        observations / rewards / not-done bytes are in the env's own tensors afterwards.  All envs (the usual case): one generator
+        launch into the env's own tensors.  A subset (VER batches, the double-buffered sampler's halves, ppo_trainer.py:743-768): the
+        generator runs on scratch copies of the per-env clocks / tensors and only the requested rows are taken over.  Returns the ids."""
         ids = sorted(self._pending)
         self._pending.clear()
         if len(ids) == self.num_envs:
             self.step_into_obs(self._own_obs(), self._rew, self._nd)
-        else:
+        elif ids:
             own = self._own_obs()
             if self._tmp is None:
                 self._tmp = ({k: torch.empty_like(v) for k, v in own.items()}, torch.empty_like(self._rew), torch.empty_like(self._nd))
@@ -180,7 +181,18 @@ class SyntheticVectorEnv:
             for k, v in own.items():
                 v[sel] = tobs[k][sel]
             self._rew[sel], self._nd[sel] = trew[sel], tnd[sel]
-        obs, rew, nd = self._host_obs(), self._rew.cpu().numpy(), self._nd.cpu().numpy()
+        return ids
+
+    def step_results_host(self):
+        """(rewards (N,), not-done (N,)) of the last steps as host arrays: the two small per-env vectors the host-side episode
+        accounting needs (one device->host copy each; observations stay in HBM)."""
+        return self._rew.cpu().numpy(), self._nd.cpu().numpy()
+
+    def _advance_pending(self):
+        """Host path (VectorEnv.wait_step_at): device advance + the host copies of the observations the caller asked for."""
+        ids = self.advance_on_device()
+        obs = self._host_obs()
+        rew, nd = self.step_results_host()
         if self._host_cache is None or len(ids) == self.num_envs:
             self._host_cache = (obs, rew.copy(), nd.copy())
         else:

@@ -1,10 +1,17 @@
 """VER inference worker (habitat_baselines/rl/ver/inference_worker.py:52-520): batches the environments whose step has arrived,
 runs ONE policy forward for them on the HIP engine, hands the actions back, and writes the step into the VER arena.
 
-This implementation runs in the trainer's process (the reference's `main_is_iw` arrangement, ver_trainer.py:269-337, i.e.
-`rl.ver.overlap_rollouts_and_learn=False`, one inference worker): the policy lives in device memory once, the arena is written by
-device-side index copies, and the only host<->device traffic per batch is the observation upload (from the environment workers'
-shared-memory slabs) and the sampled actions coming back.
+Inference workers are THREADS of the trainer's process, each with its own HIP stream over the one device arena (the reference
+starts processes that share CUDA tensors through IPC handles; a thread shares the address space, so the arena, the transfer records
+and the request queue need no serialisation at all).  Worker 0 of a non-overlapped run is the trainer's own thread and uses the
+learner's engine (the reference's `main_is_iw` arrangement, ver_trainer.py:262,326-337); every other worker owns a private policy
+engine (its own activation workspace -- two engines never share scratch memory) whose parameter arena is refreshed from the
+learner's PUBLISHED parameters whenever the policy version has moved (inference_worker.py:224-232 `_update_actor_critic`).
+Host-side integer state that several workers touch (slot pointer, step counters, the request queue) is guarded by
+`InferenceWorkerSync.lock` exactly where the reference takes it (`lock_and_sync`, inference_worker.py:206-217,244-263,281-292); the
+end-of-rollout hand-over (two barrier waits, replay requests to the last worker, `rollout_done`) is inference_worker.py:422-456.
+The only host<->device traffic per batch is the observation upload (from the environment workers' shared-memory slabs; none for
+the device-resident source) and the sampled actions coming back.
 
 `EnvironmentTransport` is what the worker needs from the environment side: per-environment transfer records (reward, not-done
 mask, episode id, step id written by the environment after each step: environment_worker.py:186-203), the observations of a list of
@@ -12,6 +19,8 @@ environments as device tensors, and a way to send an action.  `core.vector_env.V
 tests use an in-process transport."""
 from __future__ import annotations
 
+import contextlib
+import threading
 import time
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -44,10 +53,86 @@ class EnvironmentTransport:
         raise NotImplementedError
 
 
+class InferenceWorkerSync:
+    """worker_common.py:51-68 with threading primitives."""
+
+    def __init__(self, n_inference_workers: int):
+        self.lock = threading.Lock()
+        self.all_workers = threading.Barrier(n_inference_workers)
+        self.should_start_next = threading.Event()
+        self.should_start_next.set()
+        self.rollout_done = threading.Event()
+        # Not in the reference: the worker that holds the replay requests of the previous rollout acts on them before any other
+        # worker claims a slot.  The reference lets the workers race; if the others fill the step quota first, its own accounting
+        # (`num_steps_collected += num_to_process - _n_replay_steps`, inference_worker.py:262-264) goes negative by the number of
+        # replay steps and the buffer keeps their stale slots -- rare with 128-step rollouts, certain with short ones.
+        self.replays_done = threading.Event()
+        self.replays_done.set()
+
+
+class RequestQueue:
+    """`queues.inference` (worker_common.py:24-38): environments whose step has arrived, taken by whichever worker asks first.  The
+    transport's `poll` is the producer side; `put_many` / `drain` carry the end-of-rollout hand-over."""
+
+    def __init__(self, transport: EnvironmentTransport):
+        self.transport = transport
+        self._lock = threading.Lock()
+        self._back: List[int] = []
+
+    def get_many(self, timeout: float, max_messages: int) -> List[int]:
+        with self._lock:
+            if self._back:
+                out, self._back = self._back[:max_messages], self._back[max_messages:]
+                return out
+            return self.transport.poll(timeout, max_messages)
+
+    def put_many(self, reqs: List[int]) -> None:
+        with self._lock:
+            self._back += list(reqs)
+
+    def drain(self) -> List[int]:
+        with self._lock:
+            out, self._back = self._back, []
+            return out
+
+
+class PublishedWeights:
+    """What the reference keeps in shared memory as `_transfer_policy_tensors` (ver_trainer.py:318-320,402-410): the parameter arena
+    (weights and registered buffers) of the last COMPLETED policy version.  The learner publishes after an update, workers with a
+    private engine copy from here when `cpu_current_policy_version` has moved; both sides hold the lock and drain their stream inside
+    it, so a worker never reads a half-written arena."""
+
+    def __init__(self, engine):
+        self.flat = engine.params_flat.detach().clone()
+        self.lock = threading.Lock()
+
+    def _drain(self) -> None:
+        if self.flat.is_cuda:
+            torch.cuda.current_stream(self.flat.device).synchronize()
+
+    def publish(self, engine) -> None:
+        with self.lock:
+            self.flat.copy_(engine.params_flat)
+            self._drain()
+
+    def load_into(self, engine) -> None:
+        with self.lock:
+            engine.params_flat.copy_(self.flat)
+            self._drain()
+        engine.repack()
+
+
 class InferenceWorker:
     def __init__(self, config, actor_critic, rollouts: VERRolloutStorage, transport: EnvironmentTransport, device, obs_transforms=(),
-                 num_inference_workers: int = 1, report=None):
+                 num_inference_workers: int = 1, report=None, worker_idx: int = 0, iw_sync: Optional[InferenceWorkerSync] = None,
+                 queue: Optional[RequestQueue] = None, published: Optional[PublishedWeights] = None, stream=None):
         self.config, self.actor_critic, self.rollouts, self.transport = config, actor_critic, rollouts, transport
+        self.worker_idx, self.num_inference_workers = worker_idx, num_inference_workers
+        self.iw_sync = iw_sync if iw_sync is not None else InferenceWorkerSync(1)
+        self.queue = queue if queue is not None else RequestQueue(transport)
+        self.published = published   # None: this worker runs on the learner's own engine
+        self.stream = stream         # None: the thread's current stream
+        self.error: Optional[BaseException] = None
         self.device = torch.device(device)
         self.obs_transforms = list(obs_transforms)
         self.report = report
@@ -72,24 +157,30 @@ class InferenceWorker:
         if not self.new_reqs:
             return False, steps_finished
         ro, tr = self.rollouts, self.transport
-        self._current_policy_version = int(ro.cpu_current_policy_version[0, 0])
+        version = int(ro.cpu_current_policy_version[0, 0])
+        if version != self._current_policy_version:
+            self._current_policy_version = version
+            if self.published is not None:  # private engine: take over the parameters of the version that was just completed
+                self.published.load_into(self.actor_critic.engine)
         current_steps = ro.current_steps.copy()
         final_batch = False
         slots = None
         if self._variable_experience:
             # environments that have contributed the fewest steps go first: they are the ones cut off when the rollout fills up
             self.new_reqs.sort(key=lambda a: (ro.actor_steps_collected[a], a))
-            slots, n_proc, final_batch = ro.reserve_slots(len(self.new_reqs), self._n_replay_steps)
+            with self.lock_and_sync():
+                slots, n_proc, final_batch = ro.reserve_slots(len(self.new_reqs), self._n_replay_steps)
             self.replay_reqs += self.new_reqs[n_proc:]
             self.new_reqs = self.new_reqs[:n_proc]
         else:
             for r in self.new_reqs:
                 if current_steps[r] > ro.num_steps:
                     raise RuntimeError(f"Got a step from actor {r} after collecting {current_steps[r]} steps. This shouldn't be possible.")
-            ro.num_steps_collected += len(self.new_reqs) - self._n_replay_steps
-            if ro.num_steps_collected[0] == ro.num_steps_to_collect:
-                final_batch = True
-                ro.rollout_done[:] = True
+            with self.lock_and_sync():
+                ro.num_steps_collected += len(self.new_reqs) - self._n_replay_steps
+                if ro.num_steps_collected[0] == ro.num_steps_to_collect:
+                    final_batch = True
+                    ro.rollout_done[:] = True
         if not self.new_reqs:
             return False, steps_finished
         if self._n_replay_steps > 0 and self.replay_reqs:
@@ -110,8 +201,7 @@ class InferenceWorker:
         if not final_batch:
             ro.next_hidden_states.index_copy_(0, env_ids, action_data.rnn_hidden_states)
             ro.next_prev_actions.index_copy_(0, env_ids, action_data.actions)
-        if self._variable_experience:
-            ro.remember_slots(reqs, slots)
+        prev_slots = ro.remember_slots(reqs, slots) if self._variable_experience else None
         cpu_actions = action_data.env_actions.cpu().numpy()  # the one device->host read of the batch
         for i, env_idx in enumerate(reqs):
             steps_finished.append((int(ro.current_steps[env_idx]), int(env_idx)))
@@ -130,23 +220,75 @@ class InferenceWorker:
                             policy_version=ro.current_policy_version.expand(n, 1), episode_ids=episode_ids,
                             environment_ids=env_ids.view(-1, 1), step_ids=step_ids, value_preds=action_data.values,
                             returns=torch.full((n, 1), float("nan"), device=dev))
-        ro.write_step(reqs, slots, current_step, rewards, current_steps)
+        ro.write_step(reqs, slots, current_step, rewards, current_steps, prev_slots=prev_slots)
         self.new_reqs = []
         return True, steps_finished
 
-    # ---- end of a rollout (inference_worker.py:422-456, single worker) -----------------------------------------------------------------
+    @contextlib.contextmanager
+    def lock_and_sync(self):
+        """inference_worker.py:205-217: the shared counters change under the lock, and this worker's device work is drained before
+        the lock is released, so that whoever sees `rollout_done` also sees every slot that was claimed before it."""
+        if self.num_inference_workers == 1:
+            yield
+            return
+        with self.iw_sync.lock:
+            yield
+            self._sync_device()
+
+    def _sync_device(self) -> None:
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+
+    # ---- end of a rollout (inference_worker.py:422-456) -----------------------------------------------------------------------------
     def finish_rollout(self) -> None:
         """Requests that arrived but were not processed, and the requests of the final batch, are replayed first in the next
-        rollout; environments with an action still in flight are not (their step lands in the next rollout)."""
-        self.new_reqs = self.replay_reqs + self.new_reqs
-        self.replay_reqs = []
-        self._n_replay_steps = len(self.new_reqs)
-        self.rollouts.will_replay_step[self.new_reqs] = True
+        rollout; environments with an action still in flight are not (their step lands in the next rollout).  With several workers
+        everything goes back into the request queue between two barrier waits and the LAST worker takes it all (it is never the
+        trainer's own thread when there is more than one worker) and announces the end of the rollout."""
+        self._sync_device()
+        sync = self.iw_sync
+        sync.all_workers.wait()   # nobody puts outstanding / replay requests back before everyone is done stepping
+        self.queue.put_many(self.replay_reqs + self.new_reqs)
+        self.replay_reqs, self.new_reqs = [], []
+        sync.should_start_next.clear()
+        sync.all_workers.wait()   # nobody reads the queue before everyone has put theirs in
+        if self.worker_idx == self.num_inference_workers - 1:
+            self.new_reqs = self.queue.drain()
+            self._n_replay_steps = len(self.new_reqs)
+            self.rollouts.will_replay_step[self.new_reqs] = True
+            if self._n_replay_steps > 0 and self.num_inference_workers > 1:
+                sync.replays_done.clear()
+            sync.rollout_done.set()
+
+    # ---- worker thread (inference_worker.py:507-532) --------------------------------------------------------------------------------
+    def run(self, done_event: threading.Event) -> None:
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        ctx = torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+        try:
+            with ctx:
+                self.actor_critic.eval()
+                while not done_event.is_set():
+                    if not self.iw_sync.should_start_next.is_set():
+                        self.iw_sync.should_start_next.wait(timeout=0.05)
+                        continue
+                    self.try_one_step()
+                    if bool(self.rollouts.rollout_done):
+                        self.finish_rollout()
+        except threading.BrokenBarrierError:
+            pass  # the trainer is shutting the workers down
+        except BaseException as e:  # surfaced by the trainer (VERTrainer._check_workers)
+            self.error = e
+            self.iw_sync.all_workers.abort()
+            self.iw_sync.rollout_done.set()
 
     # ---- request batching (inference_worker.py:458-505) ------------------------------------------------------------------------------
     def try_one_step(self) -> bool:
+        if self._n_replay_steps == 0 and not self.iw_sync.replays_done.is_set():
+            self.iw_sync.replays_done.wait(0.005)  # the holder of the replay requests goes first (InferenceWorkerSync)
+            return False
         if len(self.new_reqs) < self.max_reqs:
-            self.new_reqs += self.transport.poll(0.005, self.max_reqs - len(self.new_reqs))
+            self.new_reqs += self.queue.get_many(0.005, self.max_reqs - len(self.new_reqs))
         should = len(self.new_reqs) > 0 and (len(self.new_reqs) >= self.min_reqs
                                             or (time.perf_counter() - self.last_step_time) > self.min_wait_time)
         if not should:
@@ -158,7 +300,61 @@ class InferenceWorker:
             self._avg_step_time.add(t1 - t0)
             self.last_step_time = t1
             self.min_wait_time = self._avg_step_time.mean / 2
-            self._n_replay_steps = 0
+            if self._n_replay_steps > 0:
+                self._n_replay_steps = 0
+                self.iw_sync.replays_done.set()
             if self.report is not None:
                 self.report.policy_step(steps_finished, t1)
         return stepped
+
+
+class InferenceWorkerPool:
+    """The trainer's side of the worker protocol (ver_trainer.py:326-349,493-530): starts the worker threads, runs worker 0 on the
+    calling thread when the trainer itself is an inference worker, waits for the end of a rollout, lets the next one start."""
+
+    def __init__(self, workers: List[InferenceWorker], iw_sync: InferenceWorkerSync, queue: RequestQueue, main_is_iw: bool):
+        self.workers, self.sync, self.queue, self.main_is_iw = workers, iw_sync, queue, main_is_iw
+        self.done = threading.Event()
+        self.threads: List[threading.Thread] = []
+
+    def start(self) -> None:
+        for iw in self.workers[(1 if self.main_is_iw else 0):]:
+            t = threading.Thread(target=iw.run, args=(self.done,), name=f"habitat_amd-iw{iw.worker_idx}", daemon=True)
+            t.start()
+            self.threads.append(t)
+
+    def check(self) -> None:
+        for iw in self.workers:
+            if iw.error is not None:
+                raise RuntimeError(f"inference worker {iw.worker_idx} failed") from iw.error
+
+    def collect(self, rollouts: VERRolloutStorage) -> None:
+        """Returns when the rollout is complete and every worker has handed its outstanding requests over."""
+        if self.main_is_iw:
+            iw = self.workers[0]
+            while not bool(rollouts.rollout_done):
+                iw.try_one_step()
+                self.check()
+            iw.finish_rollout()
+        while not self.sync.rollout_done.wait(timeout=0.5):
+            self.check()
+        self.check()
+        self.sync.rollout_done.clear()
+        if self.sync.all_workers.n_waiting > 0:
+            raise RuntimeError(f"{self.sync.all_workers.n_waiting} inference worker(s) still waiting on the worker barrier")
+
+    def start_next(self, device=None) -> None:
+        """`should_start_next.set()` after the caller's device work on the arena (buffer reordering) has drained."""
+        if device is not None and torch.device(device).type == "cuda":
+            torch.cuda.current_stream(device).synchronize()
+        self.sync.should_start_next.set()
+
+    def shutdown(self) -> None:
+        if self.done.is_set():
+            return
+        self.done.set()
+        self.sync.all_workers.abort()
+        self.sync.should_start_next.set()
+        self.sync.replays_done.set()
+        for t in self.threads:
+            t.join(10.0)

@@ -99,8 +99,8 @@ class DeviceEnvTransport(_Records):
             return []
         for e in arrived:
             self.envs.async_step_at(e, 0)
-        self.envs._advance_pending()
-        rew, nd = self.envs._rew.cpu().numpy(), self.envs._nd.cpu().numpy()
+        self.envs.advance_on_device()               # observations are generated in HBM and stay there
+        rew, nd = self.envs.step_results_host()     # two N-element vectors for the host-side episode accounting
         for e in arrived:
             self._outstanding[e] = False
             self._record(e, float(rew[e]), not bool(nd[e]), {})

@@ -287,6 +287,8 @@ class VERRolloutStorage(RolloutStorage):
         """Variable experience: claims the next slots for up to `n_requests` steps.  Returns (slots, number processed, final batch)."""
         start = int(self.ptr[0])
         n = int(min(int(self.num_steps_to_collect - self.num_steps_collected[0]), n_requests))
+        if n < n_replay:
+            raise RuntimeError(f"{n_replay} replay steps of the previous rollout cannot be processed: only {n} steps are left in this one")
         stop = start + n
         assert stop <= self.buffer_size
         self.ptr[:] = stop
@@ -297,13 +299,13 @@ class VERRolloutStorage(RolloutStorage):
         return slice(start, stop), n, final
 
     def write_step(self, env_ids: List[int], slots: Optional[slice], current_step: Dict[str, Any], prev_rewards: torch.Tensor,
-                   current_steps: Optional[np.ndarray] = None) -> None:
+                   current_steps: Optional[np.ndarray] = None, prev_slots: Optional[np.ndarray] = None) -> None:
         """current_step: the step the policy just acted on (masks, observations, actions, log-probs, values, hidden state entering
         the step, ids, policy version, returns = NaN); prev_rewards: the reward that the PREVIOUS action of each of these
         environments earned, written to that environment's previous slot."""
         B = self.buffers
         if self.variable_experience:
-            prev = self._prev_inds_before[env_ids]
+            prev = prev_slots if prev_slots is not None else self._prev_inds_before[env_ids]
             has = prev >= 0
             if has.any():
                 dst = torch.from_numpy(prev[has]).to(self.device)
@@ -320,9 +322,32 @@ class VERRolloutStorage(RolloutStorage):
             sel = TensorDict.from_tree(current_step)[ok] if not bool(ok.all()) else current_step
             sub[(steps[ok], env_t[ok])] = sel
 
-    def remember_slots(self, env_ids: List[int], slots: slice) -> None:
+    def remember_slots(self, env_ids: List[int], slots: slice) -> np.ndarray:
+        """Records the slot each of these environments has just been given; returns the slots they held before (-1: none) -- where
+        `write_step` puts the reward their previous action earned.  Per-environment state: two workers never hold the same
+        environment, so no lock is needed."""
+        before = self.prev_inds[env_ids].copy()
         self._prev_inds_before = self.prev_inds.copy()
         self.prev_inds[env_ids] = np.arange(slots.start, slots.stop, dtype=np.int64)
+        return before
+
+    _HOST_STATE = ("cpu_current_policy_version", "num_steps_collected", "rollout_done", "current_steps", "actor_steps_collected", "ptr",
+                   "prev_inds", "_first_rollout", "will_replay_step")
+
+    def copy(self, other: "VERRolloutStorage") -> None:
+        """ver_rollout_storage.py:283-285: the learner's private arena takes over a finished rollout (overlapped collection)."""
+        for k, t in self.buffers.items():
+            if isinstance(t, dict):
+                for kk, tt in t.items():
+                    tt.copy_(other.buffers[k][kk])
+            else:
+                t.copy_(other.buffers[k])
+        self.next_hidden_states.copy_(other.next_hidden_states)
+        self.next_prev_actions.copy_(other.next_prev_actions)
+        self.current_policy_version.copy_(other.current_policy_version)
+        for k in self._HOST_STATE:
+            getattr(self, k)[...] = getattr(other, k)
+        self.current_rollout_step_idxs = list(other.current_rollout_step_idxs)
 
 
 def _reorder_tail(t: torch.Tensor, n_front: int, ordering: torch.Tensor) -> torch.Tensor:

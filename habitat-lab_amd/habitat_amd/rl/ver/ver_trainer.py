@@ -5,9 +5,18 @@ deliver them: the inference worker batches the environments whose step has arriv
 (or the other environments) up.  The update is PPO on the linear step buffer with importance weights for the uneven per-environment
 sampling (VERRolloutStorage / `hab_ppo_loss_ver`), the learning-rate schedule is the reference's cosine decay.
 
-Arrangement: the inference worker runs in this process (`rl.ver.overlap_rollouts_and_learn=False`, one worker -- ver_trainer.py:269-337
-`main_is_iw`); environment workers are the process-per-environment VectorEnv workers (shared-memory observation plane) or, for the
-synthetic benchmark source, the device-resident generator."""
+Arrangement (ver_trainer.py:261-337): `rl.ver.num_inference_workers` inference workers batch the arrived environment steps.  They
+are threads of this process with their own HIP stream over the one device arena (rl/ver/inference_worker.py); without
+`overlap_rollouts_and_learn` worker 0 is the trainer's own thread (`main_is_iw`) and the learner updates in place between rollouts.
+With `overlap_rollouts_and_learn=True` every worker is a thread, the finished rollout is copied into the learner's private arena
+(`learning_rollouts`) and the workers start on the next rollout while the learner works on the previous one (ver_trainer.py:504-530);
+the workers act with the parameters of the last COMPLETED policy version, which the learner publishes after every update.
+Environment workers are the process-per-environment VectorEnv workers (shared-memory observation plane) or, for the synthetic
+benchmark source, the device-resident generator.
+
+Not implemented: the preemption decider (ver_trainer.py:224-233, preemption_decider.py): a rollout always collects its full step
+quota, so under VER + DD-PPO every rank waits at the barrier of `_update_agent` for the slowest rank's quota (no effect on results:
+every rank contributes the same number of steps either way)."""
 from __future__ import annotations
 
 import contextlib
@@ -29,7 +38,8 @@ from habitat_amd.rl.ddppo.ddp_utils import (EXIT, get_distrib_size, init_distrib
                                             save_resume_state)
 from habitat_amd.rl.ppo.ppo_trainer import PPOTrainer
 from habitat_amd.rl.ppo.single_agent_access_mgr import EnvironmentSpec
-from habitat_amd.rl.ver.inference_worker import InferenceWorker
+from habitat_amd.rl.ver.inference_worker import (InferenceWorker, InferenceWorkerPool, InferenceWorkerSync, PublishedWeights,
+                                                 RequestQueue)
 from habitat_amd.rl.ver.report_worker import ReportWorker
 from habitat_amd.rl.ver.transport import DeviceEnvTransport, VectorEnvTransport
 from habitat_amd.rl.ver.ver_rollout_storage import VERRolloutStorage
@@ -78,9 +88,10 @@ class VERTrainer(PPOTrainer):
         self._my_t_zero = time.perf_counter()
         self._init_envs()  # environment workers (vector_env_factory) + observation-space bookkeeping of the parent
         self.ver_config = hb.rl.ver
-        if self.ver_config.overlap_rollouts_and_learn or self.ver_config.num_inference_workers != 1:
-            raise _lib.HabError("habitat_amd's VER runs ONE inference worker inside the trainer process "
-                                "(rl.ver.num_inference_workers=1, rl.ver.overlap_rollouts_and_learn=False)")
+        n_iw = int(self.ver_config.num_inference_workers)
+        overlap = bool(self.ver_config.overlap_rollouts_and_learn)
+        if n_iw < 1:
+            raise _lib.HabError("rl.ver.num_inference_workers must be >= 1")
         if rank0_only() and not os.path.isdir(hb.checkpoint_folder):
             os.makedirs(hb.checkpoint_folder, exist_ok=True)
         self._agent = self._create_agent(resume_state, lr_schedule_fn=cosine_decay)
@@ -94,7 +105,10 @@ class VERTrainer(PPOTrainer):
                                      variable_experience=self.ver_config.variable_experience, device=device)
 
         self._agent.post_init(create_ver_rollouts)
-        self.learning_rollouts = self._agent.rollouts
+        # overlapped collection: the learner works on its own copy of the finished rollout (ver_trainer.py:265-269)
+        self.learning_rollouts = (create_ver_rollouts(hb.num_environments, self._env_spec, self._agent.actor_critic,
+                                                      self._agent.policy_action_space, self.config, self.device)
+                                  if overlap else self._agent.rollouts)
         if self._is_distributed:
             self._agent.init_distributed(find_unused_params=False)
         has_report_state = resume_state is not None and "report_worker_state" in resume_state.get("requeue_stats", {})
@@ -108,15 +122,56 @@ class VERTrainer(PPOTrainer):
             self.transport = DeviceEnvTransport(self.envs, self.report_worker, speeds=speeds, seed=self.config.habitat.seed)
         else:
             self.transport = VectorEnvTransport(self.envs, self.report_worker)
-        self.inference_worker = InferenceWorker(self.config, self._agent.actor_critic, self._agent.rollouts, self.transport,
-                                                self.device, self.obs_transforms, report=self.report_worker)
+        # ---- inference workers (ver_trainer.py:261-349) ---------------------------------------------------------------------------
+        main_is_iw = not overlap
+        self._overlap, self._main_is_iw = overlap, main_is_iw
+        self._iw_sync = InferenceWorkerSync(n_iw)
+        self._iw_queue = RequestQueue(self.transport)
+        self._published = PublishedWeights(self._agent.actor_critic.engine) if (n_iw > 1 or overlap) else None
+        self.inference_workers = []
+        for i in range(n_iw):
+            own_thread = not (main_is_iw and i == 0)
+            pol, stream = self._agent.actor_critic, None
+            if own_thread:
+                pol, stream = self._private_policy(n_iw), torch.cuda.Stream(device=self.device)
+            self.inference_workers.append(InferenceWorker(self.config, pol, self._agent.rollouts, self.transport, self.device,
+                                                          self.obs_transforms, num_inference_workers=n_iw, report=self.report_worker,
+                                                          worker_idx=i, iw_sync=self._iw_sync, queue=self._iw_queue,
+                                                          published=self._published if own_thread else None, stream=stream))
+        self.inference_worker = self.inference_workers[0]
         if self._is_distributed:
             torch.distributed.barrier()
-        # every environment starts with its first observation on the table (environment_worker.py:148-160)
-        self.inference_worker.new_reqs += self.transport.start_experience_collection()
+        # every environment starts with its first observation on the table (environment_worker.py:148-160): the requests go into
+        # the shared queue, from which the workers take them
+        self._iw_queue.put_many(self.transport.start_experience_collection())
+        torch.cuda.current_stream().synchronize()  # first observations are in HBM before any worker stream reads them
         self.report_worker.start_collection()
+        self._iw_pool = InferenceWorkerPool(self.inference_workers, self._iw_sync, self._iw_queue, main_is_iw)
+        self._iw_pool.start()
         self.timer = Timing()
         self._learning_time = 0.0
+
+    def _private_policy(self, n_iw: int):
+        """A policy object of the same class and configuration on its own engine (own activation workspace, sized for inference
+        batches only), holding the learner's current parameters (inference_worker.py:90-101)."""
+        hb = self.config.habitat_baselines
+        cls = baseline_registry.get_policy(hb.rl.policy[self._agent.agent_name].name)
+        with torch.random.fork_rng(devices=[]):  # the initialisers' draws (overwritten below) must not move the trainer's generator
+            pol = cls.from_config(self.config, self._env_spec.observation_space, self._env_spec.action_space,
+                                  orig_action_space=self._env_spec.orig_action_space, agent_name=self._agent.agent_name)
+        kw = pol._engine_kwargs
+        kw["max_frames"] = max(int(kw.get("max_envs", 1)), 2)  # act() only: no minibatch-sized workspace
+        pol.aux_loss_modules.clear()
+        pol.to(self.device)
+        pol.eval()
+        self._published.load_into(pol.engine)
+        return pol
+
+    def shutdown(self) -> None:
+        """Stops the inference-worker threads (idempotent)."""
+        if getattr(self, "_iw_pool", None) is not None:
+            self._iw_pool.shutdown()
+        super().shutdown()
 
     # ---- learner (ver_trainer.py:377-428) ---------------------------------------------------------------------------------------------
     def _update_agent(self):
@@ -134,7 +189,11 @@ class VERTrainer(PPOTrainer):
                 self._agent.train()
                 losses = self._agent.updater.update(self.learning_rollouts)
             with self.timer.avg_time("after update"):
-                self.learning_rollouts.after_update()
+                if self._published is not None:  # ver_trainer.py:402-410: the new weights become visible to the other workers
+                    self._published.publish(self._agent.actor_critic.engine)
+                if not self._overlap:
+                    self.learning_rollouts.after_update()
+                    self._iw_pool.start_next(self.device)  # after the buffer reordering has drained: worker streams write slots next
                 self._agent.rollouts.increment_policy_version()
         self._learning_time = (time.perf_counter() - t1) + t_returns
         self._agent.after_update()
@@ -142,15 +201,21 @@ class VERTrainer(PPOTrainer):
 
     def collect_rollout(self) -> int:
         """One VER rollout: inference batches until the arena has its quota of steps."""
-        ro, iw = self._agent.rollouts, self.inference_worker
-        self._agent.eval()
+        ro = self._agent.rollouts
+        if self._main_is_iw:
+            self._agent.eval()
         with self.timer.avg_time("rollout"):
-            while not bool(ro.rollout_done):
-                iw.try_one_step()
-            iw.finish_rollout()
+            self._iw_pool.collect(ro)
             ro.after_rollout()
+            if self._overlap:
+                with self.timer.avg_time("overlap_transfers"):
+                    self.learning_rollouts.copy(ro)
         n = int(ro.num_steps_collected[0])
         self.report_worker.num_steps_collected(n)
+        if self._overlap:  # ver_trainer.py:524-530: the workers go on with the next rollout while the learner works on this one
+            with self.timer.avg_time("overlap_transfers"):
+                ro.after_update()
+                self._iw_pool.start_next(self.device)
         return n
 
     def run_update_cycle(self) -> Dict[str, float]:
@@ -199,6 +264,7 @@ class VERTrainer(PPOTrainer):
                     count_checkpoints += 1
             self.window_episode_stats = self.report_worker.get_window_episode_stats()
         finally:
+            self.shutdown()
             self.envs.close()
             self._writer_cm.__exit__(None, None, None)
             if self._is_distributed:

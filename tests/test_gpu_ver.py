@@ -166,11 +166,14 @@ def test_ver_replay_of_reference_inference_worker_golden():
         _cmp_snapshot(z, f"r{r}/after_update", st)
 
 
-@pytest.mark.parametrize("env_source", ["device", "process"])
-def test_ver_trainer_update_cycles(env_source, tmp_path):
+@pytest.mark.parametrize("env_source,n_iw,overlap", [("device", 1, False), ("process", 1, False), ("device", 3, False), ("device", 2, True),
+                                                      ("process", 2, True)])
+def test_ver_trainer_update_cycles(env_source, n_iw, overlap, tmp_path):
     """The registered "ver" trainer from its YAML entrypoint: rollouts of a fixed number of steps collected from environments that
     finish at different rates (device-resident synthetic source with per-environment arrival rates / worker processes), PPO on the
-    linear buffer with importance weights, policy versions advancing, finite losses, parameters moving, step accounting."""
+    linear buffer with importance weights, policy versions advancing, finite losses, parameters moving, step accounting.  With one
+    inference worker inside the trainer's thread (the reference's default VER configuration), with several worker threads on their
+    own streams and private engines, and with collection overlapped with learning (ver_trainer.py:261-337,493-530)."""
     from habitat_amd.config.default import get_config
     from habitat_amd.common.baseline_registry import baseline_registry
     import habitat_amd.rl.ver.ver_trainer  # noqa: F401
@@ -178,7 +181,8 @@ def test_ver_trainer_update_cycles(env_source, tmp_path):
     ov = [f"habitat_baselines.num_environments={N}", f"habitat_baselines.rl.ppo.num_steps={T}", "habitat_baselines.num_updates=3",
           "habitat_baselines.total_num_steps=-1", "habitat_baselines.num_checkpoints=-1", "habitat_baselines.checkpoint_interval=1000000",
           "habitat_baselines.rl.ppo.hidden_size=64", f"habitat_baselines.checkpoint_folder={tmp_path}", "habitat_baselines.log_interval=1",
-          "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000", "habitat_baselines.rl.ddppo.backbone=resnet18"]
+          "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000", "habitat_baselines.rl.ddppo.backbone=resnet18",
+          f"habitat_baselines.rl.ver.num_inference_workers={n_iw}", f"habitat_baselines.rl.ver.overlap_rollouts_and_learn={overlap}"]
     for s in ("rgb", "depth"):
         ov += [f"habitat.simulator.sensors.{s}.height={size}", f"habitat.simulator.sensors.{s}.width={size}"]
     if env_source == "process":
@@ -189,7 +193,9 @@ def test_ver_trainer_update_cycles(env_source, tmp_path):
         cfg.habitat.synthetic["ver_speeds"] = [1.0, 0.7, 0.3, 0.9]
     trainer = baseline_registry.get_trainer("ver")(cfg)
     trainer._init_train()
-    st = trainer._agent.rollouts
+    assert len(trainer.inference_workers) == n_iw and len(trainer._iw_pool.threads) == (n_iw if overlap else n_iw - 1)
+    assert (trainer.learning_rollouts is not trainer._agent.rollouts) == overlap
+    st = trainer.learning_rollouts
     pol = trainer._agent.actor_critic
     before = pol.engine.params_flat.clone()
     collected = []
@@ -197,13 +203,79 @@ def test_ver_trainer_update_cycles(env_source, tmp_path):
         losses = trainer.run_update_cycle()
         assert all(np.isfinite(v) for v in losses.values()), losses
         collected.append(trainer.num_steps_done)
-        assert int(st.cpu_current_policy_version[0, 0]) == u + 2
+        assert int(trainer._agent.rollouts.cpu_current_policy_version[0, 0]) == u + 2
+        # every slot of the learner's arena holds a step: ids consistent with the observations' source, no slot left from an
+        # earlier layout (each (environment, episode, step) triple at most once)
+        ids = torch.stack([st.buffers[k].view(-1) for k in ("environment_ids", "episode_ids", "step_ids")], 1).cpu().numpy()
+        assert len({tuple(r) for r in ids}) == len(ids)
+        assert torch.isfinite(st.buffers["value_preds"]).all() and torch.isfinite(st.buffers["action_log_probs"]).all()
     # the first rollout fills the whole buffer, the following ones collect num_envs * num_steps
     assert collected == [(T + 1) * N, (T + 1) * N + N * T, (T + 1) * N + 2 * N * T], collected
     assert {"value_loss", "action_loss", "dist_entropy", "grad_norm", "ver_is_coeffs_mean", "fraction_stale",
             "policy_version_difference_mean"} <= set(losses)
     assert float((pol.engine.params_flat - before).abs().max()) > 0
-    if env_source == "device":  # uneven arrival rates -> uneven contributions -> importance coefficients away from 1
+    if env_source == "device" and n_iw == 1:  # uneven arrival rates -> uneven contributions -> importance coefficients away from 1
         counts = torch.bincount(st.buffers["environment_ids"].view(-1), minlength=N).cpu().numpy()
         assert counts.max() > counts.min(), counts
+    if n_iw > 1 or overlap:  # the private engines follow the learner: after the last update every worker that acted since holds
+        for iw in trainer.inference_workers:  # the published parameters
+            if iw.published is not None and iw._current_policy_version == 4:
+                assert torch.equal(iw.actor_critic.engine.params_flat, trainer._published.flat)
+        assert torch.equal(trainer._published.flat, pol.engine.params_flat)
+    trainer.shutdown()
+    assert all(not t.is_alive() for t in trainer._iw_pool.threads)
     trainer.envs.close()
+
+
+def test_ver_overlapped_run_hands_the_learner_the_same_rollouts_as_the_sequential_run(tmp_path):
+    """Fixed arrival order (device source, every step arrives at the next poll, one inference worker) and a learning rate of zero
+    (the acting parameters are the same whichever policy version an engine holds): the overlapped run (worker thread on its own
+    stream with a private engine, learner on its copy of the arena) must hand the learner bit-identical rollouts to the sequential
+    run -- observations, actions, log-probs, values, rewards, masks, ids, hidden states -- cycle after cycle; only the policy-version
+    stamps differ (a rollout of the overlapped run starts before the previous update has finished)."""
+    from habitat_amd.config.default import get_config
+    from habitat_amd.common.baseline_registry import baseline_registry
+    import habitat_amd.rl.ver.ver_trainer  # noqa: F401
+    N, T, size = 4, 8, 64
+    snaps = {}
+    for overlap in (False, True):
+        ov = [f"habitat_baselines.num_environments={N}", f"habitat_baselines.rl.ppo.num_steps={T}", "habitat_baselines.num_updates=4",
+              "habitat_baselines.total_num_steps=-1", "habitat_baselines.num_checkpoints=-1", "habitat_baselines.checkpoint_interval=1000000",
+              "habitat_baselines.rl.ppo.hidden_size=64", f"habitat_baselines.checkpoint_folder={tmp_path}", "habitat_baselines.log_interval=100",
+              "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000", "habitat_baselines.rl.ddppo.backbone=resnet18",
+              "habitat_baselines.rl.ppo.lr=0.0", f"habitat_baselines.rl.ver.overlap_rollouts_and_learn={overlap}"]
+        for s_ in ("rgb", "depth"):
+            ov += [f"habitat.simulator.sensors.{s_}.height={size}", f"habitat.simulator.sensors.{s_}.width={size}"]
+        cfg = get_config("pointnav/ver_pointnav.yaml", ov)
+        cfg.habitat.simulator.sensors.pop("semantic", None)
+        torch.manual_seed(3)
+        np.random.seed(3)
+        trainer = baseline_registry.get_trainer("ver")(cfg)
+        trainer._init_train()
+        out = []
+        orig = trainer._update_agent
+
+        def snap_then_update():
+            st = trainer.learning_rollouts
+            torch.cuda.synchronize()
+            rec = {}
+            for k, v in st.buffers.items():
+                rec[k] = {kk: vv.cpu().clone() for kk, vv in v.items()} if isinstance(v, dict) else v.cpu().clone()
+            out.append(rec)
+            return orig()
+        trainer._update_agent = snap_then_update
+        for _ in range(3):
+            trainer.run_update_cycle()
+        trainer.shutdown()
+        trainer.envs.close()
+        snaps[overlap] = out
+    for k, (a, b) in enumerate(zip(snaps[False], snaps[True])):
+        for key in a:
+            if key in ("policy_version", "is_stale", "returns", "is_coeffs"):
+                continue
+            if isinstance(a[key], dict):
+                for kk in a[key]:
+                    assert torch.equal(a[key][kk], b[key][kk]), (k, key, kk)
+            else:
+                assert torch.equal(a[key], b[key]), (k, key)
+        assert torch.equal(a["is_coeffs"], b["is_coeffs"]), k

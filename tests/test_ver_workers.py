@@ -1,0 +1,268 @@
+"""CPU: the VER inference-worker protocol with several workers and with overlapped collection / learning (VERDICT r02 item 7;
+reference: rl/ver/ver_trainer.py:261-337,493-530, rl/ver/inference_worker.py:205-217,244-292,422-456,507-532).
+
+The worker threads, the request queue, the slot reservation under the lock, the two-barrier hand-over at the end of a rollout, the
+copy into the learner's arena and the release of the next rollout are the production classes (rl/ver/inference_worker.py,
+rl/ver/ver_rollout_storage.py on the CPU device); only the policy (a deterministic function of the observation) and the environments
+(in-process clocks) are stand-ins, so that every slot's expected content is known in closed form."""
+import os
+import sys
+import threading
+import time
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "habitat-lab_amd"))
+
+from habitat_amd.common import spaces as S  # noqa: E402
+from habitat_amd.rl.ppo.policy import PolicyActionData  # noqa: E402
+from habitat_amd.rl.ver.inference_worker import (InferenceWorker, InferenceWorkerPool, InferenceWorkerSync, PublishedWeights,  # noqa: E402
+                                                 RequestQueue)
+from habitat_amd.rl.ver.transport import _Records  # noqa: E402
+from habitat_amd.rl.ver.ver_rollout_storage import VERRolloutStorage  # noqa: E402
+
+HID = 4
+
+
+def reward_of(e, t):   # reward earned by the action taken at env-time t - 1, delivered with observation t
+    return float((e * 131 + t * 7) % 13) / 4.0 - 1.0
+
+
+def done_at(e, t):     # observation t of environment e starts a new episode
+    return t > 0 and t % (5 + e % 3) == 0
+
+
+class ClockEnvs(_Records):
+    """Environment e delivers observation t = (e, t); an outstanding step arrives 1 / speeds[e] milliseconds after its action was sent
+    (speeds of 1000 and more: at the next poll)."""
+
+    def __init__(self, n, speeds, seed):
+        super().__init__(n, None)
+        self.t = np.zeros(n, np.int64)
+        self.outstanding = np.zeros(n, bool)
+        self.delay = 1e-3 / np.asarray(speeds, float)
+        self.due = np.zeros(n, float)
+        self.busy = np.zeros(n, np.int64)  # guards against one environment being held by two workers
+        self.sent = 0
+
+    def start_experience_collection(self):
+        return list(range(self.num_envs))
+
+    def observations(self, env_ids, device):
+        return {"x": torch.tensor([[float(e), float(self.t[e])] for e in env_ids], dtype=torch.float32)}
+
+    def send_action(self, env_idx, action):
+        assert not self.outstanding[env_idx], "action sent twice"
+        assert int(np.asarray(action).reshape(-1)[0]) == (env_idx + int(self.t[env_idx])) % 4  # the action of THIS observation
+        self.sent += 1
+        self.due[env_idx] = time.perf_counter() + self.delay[env_idx]
+        self.outstanding[env_idx] = True
+
+    def poll(self, timeout, max_messages):
+        now = time.perf_counter()
+        arrived = [int(e) for e in np.nonzero(self.outstanding)[0] if self.delay[e] < 2e-6 or now >= self.due[e]][:max_messages]
+        for e in arrived:
+            self.outstanding[e] = False
+            self.t[e] += 1
+            self._record(e, reward_of(e, int(self.t[e])), done_at(e, int(self.t[e])), {})
+        return arrived
+
+
+class FakeEngine:
+    def __init__(self):
+        self.params_flat = torch.zeros(4)
+        self.repacked = 0
+
+    def repack(self):
+        self.repacked += 1
+
+
+class ClockPolicy:
+    """act() is a closed-form function of the observation and of the engine's parameter arena (so a stale worker engine shows)."""
+    num_recurrent_layers, recurrent_hidden_size = 1, HID
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.engine = FakeEngine()
+        self.calls = 0
+
+    def eval(self):
+        return self
+
+    def act(self, obs, hidden, prev_actions, masks, exp_noise=None):
+        x = obs["x"]
+        self.calls += 1
+        e, t = x[:, 0:1], x[:, 1:2]
+        w = self.engine.params_flat[0]
+        return PolicyActionData(rnn_hidden_states=hidden * masks.view(-1, 1, 1) + 1.0, actions=((e + t) % 4).long(),
+                                values=e * 1000.0 + t + w * 1e6, action_log_probs=-(t + 1.0))
+
+
+def make_config(train_encoder=True):
+    return types.SimpleNamespace(habitat_baselines=types.SimpleNamespace(rl=types.SimpleNamespace(ddppo=types.SimpleNamespace(train_encoder=train_encoder))))
+
+
+class Harness:
+    """What VERTrainer does around the pool, minus the device-only pieces (returns / importance weights / the PPO update)."""
+
+    def __init__(self, n_envs, n_steps, n_workers, overlap, speeds, seed=0, variable_experience=True):
+        self.N, self.T, self.overlap = n_envs, n_steps, overlap
+        osp = S.Dict({"x": S.Box(-1e9, 1e9, (2,), np.float32)})
+        self.learner_policy = ClockPolicy()
+        mk = lambda: VERRolloutStorage(n_steps, n_envs, osp, S.Discrete(4), self.learner_policy, variable_experience, device="cpu")
+        self.ro = mk()
+        self.learning = mk() if overlap else self.ro
+        self.envs = ClockEnvs(n_envs, speeds, seed)
+        self.sync, self.queue = InferenceWorkerSync(n_workers), RequestQueue(self.envs)
+        self.published = PublishedWeights(self.learner_policy.engine) if (n_workers > 1 or overlap) else None
+        main_is_iw = not overlap
+        self.workers = []
+        for i in range(n_workers):
+            own = not (main_is_iw and i == 0)
+            pol = ClockPolicy() if own else self.learner_policy
+            self.workers.append(InferenceWorker(make_config(), pol, self.ro, self.envs, "cpu", (), num_inference_workers=n_workers,
+                                                worker_idx=i, iw_sync=self.sync, queue=self.queue,
+                                                published=self.published if own else None))
+        self.pool = InferenceWorkerPool(self.workers, self.sync, self.queue, main_is_iw)
+        self.queue.put_many(self.envs.start_experience_collection())
+        self.pool.start()
+
+    def after_rollout(self):  # VERRolloutStorage.after_rollout without the importance-weight kernel
+        B = self.ro.buffers
+        B["is_stale"][:] = B["policy_version"] < self.ro.current_policy_version
+        self.ro.current_rollout_step_idxs[0] = self.ro.num_steps + 1
+
+    def cycle(self, learn):
+        """One iteration of VERTrainer.train's loop; `learn(storage)` stands for compute_returns + update."""
+        self.pool.collect(self.ro)
+        self.after_rollout()
+        if self.overlap:
+            self.learning.copy(self.ro)
+            self.ro.after_update()
+            self.pool.start_next()
+        out = learn(self.learning)
+        self.learner_policy.engine.params_flat += 1.0  # "the update"
+        if self.published is not None:
+            self.published.publish(self.learner_policy.engine)
+        if not self.overlap:
+            self.learning.after_update()
+            self.pool.start_next()
+        self.ro.cpu_current_policy_version += 1
+        self.ro.current_policy_version += 1
+        return out
+
+
+def check_rollout(st, N, T, first):
+    """Invariants of a finished rollout in the learner's arena."""
+    B = st.buffers
+    env, ep, step = (B[k].view(-1).numpy() for k in ("environment_ids", "episode_ids", "step_ids"))
+    x = B["observations"]["x"].numpy()
+    size = (T + 1) * N
+    assert int(st.num_steps_collected[0]) == (size if first else N * T)
+    assert int(st.ptr[0]) == size  # the linear buffer is full: in-flight + replayed + new steps
+    assert np.array_equal(x[:, 0].astype(np.int64), env)
+    t = x[:, 1].astype(np.int64)
+    # every (environment, env-time) pair at most once; per environment the times form one contiguous run
+    assert len({(a, b) for a, b in zip(env, t)}) == size
+    for e in range(N):
+        te = np.sort(t[env == e])
+        assert len(te) >= 1 and np.array_equal(te, np.arange(te[0], te[0] + len(te))), (e, te)
+    # closed-form contents: actions, log-probs, masks, the hidden state entering the step is the (mask-reset) count of steps before
+    assert np.array_equal(B["actions"].view(-1).numpy(), (env + t) % 4)
+    assert np.array_equal(B["action_log_probs"].view(-1).numpy(), -(t + 1.0).astype(np.float32))
+    assert np.array_equal(B["masks"].view(-1).numpy(), np.array([not done_at(a, b) and b > 0 for a, b in zip(env, t)]))
+    # the reward of step t arrived with observation t + 1: present wherever the environment's next step is in the buffer too
+    rew = B["rewards"].view(-1).numpy()
+    have = {(a, b): i for i, (a, b) in enumerate(zip(env, t))}
+    n_checked = 0
+    for (a, b), i in have.items():
+        if (a, b + 1) in have:
+            assert rew[i] == np.float32(reward_of(a, b + 1)), (a, b)
+            n_checked += 1
+    assert n_checked >= size - 2 * N
+    # ids written by the environment side
+    for i in range(size):
+        a, b = int(env[i]), int(t[i])
+        n_done = sum(1 for q in range(1, b + 1) if done_at(a, q))
+        assert ep[i] == n_done
+    return {(int(a), int(b)) for a, b in zip(env, t)}
+
+
+@pytest.mark.parametrize("n_workers,overlap", [(1, False), (3, False), (1, True), (2, True), (4, True)])
+def test_worker_protocol_fills_every_rollout_exactly(n_workers, overlap):
+    N, T = 6, 5
+    speeds = [20.0, 10.0, 2.0, 20.0, 4.0, 0.25]  # step times 0.05 .. 4 ms
+    h = Harness(N, T, n_workers, overlap, speeds, seed=n_workers)
+    try:
+        seen = []
+        for k in range(5):
+            pairs = h.cycle(lambda st: check_rollout(st, N, T, first=(k == 0)))
+            seen.append(pairs)
+        # variable experience: fast environments contributed more steps than slow ones
+        t = h.envs.t
+        assert t[0] > t[5] and t[3] > t[5], t
+        # nothing is lost between rollouts: per environment the union of the rollouts is one contiguous run of env-times from 0
+        for e in range(N):
+            te = sorted({b for s in seen for (a, b) in s if a == e})
+            assert te == list(range(0, len(te))), (e, te)
+        # a private engine holds (at least) the parameters of the policy version its worker last acted under: version v <-> arena v - 1
+        for iw in h.workers:
+            if iw.published is not None and iw._current_policy_version > 1:
+                assert iw.actor_critic.engine.repacked >= 1
+                assert float(iw.actor_critic.engine.params_flat[0]) >= iw._current_policy_version - 1
+        assert max(iw._current_policy_version for iw in h.workers) >= 4
+    finally:
+        h.pool.shutdown()
+    assert all(not t.is_alive() for t in h.pool.threads)
+
+
+def test_overlapped_collection_gives_the_learner_the_same_rollouts_as_the_sequential_run():
+    """Fixed arrival order (every step arrives at the next poll, one worker): overlapped and non-overlapped runs hand the learner
+    identical arenas, rollout after rollout, up to the policy-version stamps (in the overlapped run a rollout starts before the
+    update of the previous one has finished, so its first steps carry the older version; ver_trainer.py:524-530).  The stand-in
+    policy's value head shows the parameter version it ran with: the sequential run acts with version k in rollout k, the overlapped
+    run with the last COMPLETED version."""
+    N, T = 4, 6
+    snaps = {}
+    for overlap in (False, True):
+        h = Harness(N, T, 1, overlap, [1e9] * N)
+        try:
+            out = []
+            for _ in range(4):
+                out.append(h.cycle(lambda st: {k: (v.clone() if torch.is_tensor(v) else {kk: vv.clone() for kk, vv in v.items()})
+                                               for k, v in st.buffers.items()}))
+            snaps[overlap] = out
+        finally:
+            h.pool.shutdown()
+    for k, (a, b) in enumerate(zip(snaps[False], snaps[True])):
+        for key in a:
+            if key in ("policy_version", "is_stale", "value_preds", "returns"):  # returns: NaN until compute_returns
+                continue
+            if key == "observations":
+                assert torch.equal(a[key]["x"], b[key]["x"]), (k, key)
+            else:
+                assert torch.equal(a[key], b[key]), (k, key)
+        # value = e * 1000 + t + 1e6 * (parameter version the acting engine held)
+        ver = lambda s: torch.div(s["value_preds"].view(-1), 1e6, rounding_mode="floor")
+        assert torch.all(ver(a)[N:] == float(k))           # sequential: rollout k entirely with version k
+        assert torch.all(ver(b) <= float(k)) and torch.all(ver(b)[N:] >= float(max(k - 1, 0)))  # overlapped: last completed version
+
+
+def test_a_failing_worker_surfaces_in_the_trainer_thread():
+    h = Harness(4, 3, 2, True, [1e9] * 4)
+    try:
+        boom = RuntimeError("boom")
+
+        def bad_act(*a, **k):
+            raise boom
+        h.workers[1].actor_critic.act = bad_act
+        h.workers[0].actor_critic.act = bad_act
+        with pytest.raises(RuntimeError, match="inference worker"):
+            for _ in range(3):
+                h.cycle(lambda st: None)
+    finally:
+        h.pool.shutdown()
