@@ -78,9 +78,9 @@ def _defaults() -> dict:
         rl=dict(agent=dict(type="SingleAgentAccessMgr"), preemption=dict(append_slurm_job_id=False, save_resume_state_interval=100,
                                                                        save_state_batch_only=False),
                 policy=dict(main_agent=policy), ppo=ppo, ddppo=ddppo, auxiliary_losses={},
-                # VERConfig (default_structured_configs.py:318-324).  This implementation runs the inference worker in the trainer's
-                # process (the reference's arrangement for overlap_rollouts_and_learn=False with one worker)
-                ver=dict(variable_experience=True, num_inference_workers=1, overlap_rollouts_and_learn=False)),
+                # VERConfig with the reference's defaults (default_structured_configs.py:318-324): two inference workers (worker 0 is
+                # the trainer's own thread), learning between rollouts
+                ver=dict(variable_experience=True, num_inference_workers=2, overlap_rollouts_and_learn=False)),
     )
     habitat = dict(
         seed=100,  # HL/config/default_structured_configs.py:1918
