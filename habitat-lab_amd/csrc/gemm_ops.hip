@@ -8,6 +8,7 @@
 #include "obs_conv_bf3.h"
 #include "obs_conv_bf3_ws.h"
 #include "obs_conv_patch.h"
+#include "wgrad3x3_bf3.h"
 #include "obs_wgrad_bf3.h"
 #include "conv_patch_bf3.h"
 #include "wgrad3x3_patch.h"
@@ -32,7 +33,7 @@ static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); ret
 // observation-ingest convolution with the input patch resident in LDS (obs_conv_patch.h)
 static int g_bf3_mode = -1;
 static int bf3_mode() {
-    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 127);
+    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 255);
     return g_bf3_mode;
 }
 extern "C" int hab_set_matrix_path(int mode) {
@@ -215,6 +216,9 @@ int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oih
                hipStream_t stream) {
     ConvWgradProb p;
     HAB_TRY(build(p, d, x, dy, dw_oihw, dbias));
+    if (ws && (bf3_mode() & 8) && (bf3_mode() & 128) && wgrad3x3_bf3_shape(p)) {  // strip-resident, transpose reads (wgrad3x3_bf3.h)
+        return wgrad3x3_bf3(p, ws, ws_floats, stream);
+    }
     if (ws && wgrad3x3_patch_ok(p) && !no_patch() && !(bf3_mode() & 8)) {  // 3x3/1/1 with W in {16, 32}: patch-resident kernel
         ConvWgradProb q = p;
         q.colsum = nullptr;

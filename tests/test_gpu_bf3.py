@@ -336,3 +336,39 @@ def test_obs_conv_patch_resident_as_accurate_as_fp32_path(L, B, H, W):
     a = _with_path(L, 2 | 64, run_rows)
     assert torch.equal(a, _with_path(L, 2 | 64, run_rows))
     assert err_vs(ref[rows.cpu().long()], a) < 3e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cc,Cout,p", [(3, 30, 30, 64, 32, 0), (37, 30, 30, 64, 32, 0), (5, 32, 32, 32, 32, 1), (67, 32, 32, 32, 32, 1),
+                                             (4, 16, 16, 64, 64, 1), (131, 16, 16, 64, 64, 1), (1, 32, 32, 32, 32, 1)])
+def test_wgrad3x3_strip_resident_as_accurate_as_fp32_path(L, B, H, W, Cc, Cout, p):
+    """Matrix-path bit 7 (wgrad3x3_bf3.h): the 3x3 / stride-1 weight gradient with the strip resident in LDS and fragments built by LDS
+    transpose reads, against float64 -- every weight (a transposed / shifted tap or a swapped channel half shows as an O(1) error), the
+    bias gradient, frame counts that do not divide into the workgroups' strip ranges, one frame (most workgroups idle), padded
+    borders (first / last strip of an image), and bit-for-bit reproducibility.  As accurate as the fp32 MFMA path."""
+    torch.manual_seed(11)
+    x = torch.randn(B, Cc, H, W) * torch.rand(B, Cc, H, W).pow(4) * 50
+    Ho, Wo = H + 2 * p - 2, W + 2 * p - 2
+    dy = torch.randn(B, Cout, Ho, Wo)
+    w = torch.zeros(Cout, Cc, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, stride=1, padding=p).backward(dy.double())
+    ref = torch.cat([w.grad.flatten(), dy.double().sum((0, 2, 3))])
+    xd, dyd = x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda()
+    ws = torch.zeros(1 << 24, device="cuda")
+
+    def run():
+        ws.normal_()  # stale slab contents must not matter
+        dw = torch.zeros(Cout, Cc, 3, 3, device="cuda")
+        db = torch.zeros(Cout, device="cuda")
+        _lib.check(L.hab_conv2d_wgrad(P(xd), P(dyd), P(dw), P(db), B, H, W, Cc, Cout, 3, 3, 1, p, P(ws), ws.numel(), S()))
+        return torch.cat([dw.flatten(), db])
+
+    y_fp32 = _with_path(L, 0, run)
+    y_igemm = _with_path(L, 4 | 8, run)
+    y_strip = _with_path(L, 4 | 8 | 128, run)
+    assert not torch.equal(y_strip, y_igemm), "bit 7 did not select another kernel"
+    e0, e1, e2 = err_vs(ref, y_fp32), err_vs(ref, y_igemm), err_vs(ref, y_strip)
+    assert e2 <= 2 * e0 + 2e-7 and e2 < 3e-6, (e0, e1, e2)
+    # per-element check in units of the weight's own magnitude scale (max-norm alone would hide one wrong small tap)
+    d = (y_strip.double().cpu() - ref).abs()
+    assert float(d.max()) <= 3e-6 * float(ref.abs().max())
+    assert torch.equal(y_strip, _with_path(L, 4 | 8 | 128, run)), "not reproducible"
