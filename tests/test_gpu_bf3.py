@@ -18,7 +18,18 @@ def L():
     return _lib.lib()
 
 
-P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+_KEEP = []
+
+
+def P(t):
+    """Device pointer of a tensor for a ctypes call.  The tensor is kept alive for the next few dozen calls: a temporary that only lived
+    inside P(...) would be freed -- and its block handed to the next allocation -- before the launch that reads it."""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    if len(_KEEP) > 96:
+        del _KEEP[:48]
+    return C.c_void_p(t.data_ptr())
 S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

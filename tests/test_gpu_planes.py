@@ -16,7 +16,18 @@ import torch.nn.functional as F
 from habitat_amd import _lib
 
 pytestmark = pytest.mark.gpu
-P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+_KEEP = []
+
+
+def P(t):
+    """Device pointer of a tensor for a ctypes call.  The tensor is kept alive for the next few dozen calls: a temporary that only lived
+    inside P(...) would be freed -- and its block handed to the next allocation -- before the launch that reads it."""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    if len(_KEEP) > 96:
+        del _KEEP[:48]
+    return C.c_void_p(t.data_ptr())
 S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -131,10 +142,13 @@ def test_conv_fwd_planes_only_output_and_chaining(L):
     b2, b3 = torch.randn(64).cuda(), torch.randn(32).cuda()
     ws = torch.zeros(1 << 22, device="cuda")
     a2pl = torch.zeros(3 * B * 30 * 30 * 64, dtype=torch.int16, device="cuda")
-    _lib.check(L.hab_conv2d_fwd_pl(P(split(L, x.view(-1, 32))), P(split(L, wf2.view(64, -1))), P(b2), None, 0, P(a2pl), B, 63, 63, 32, 64, 4, 4,
+    # (operand planes are named: a tensor that only lives inside P(...) is freed -- and its block handed to the NEXT allocation --
+    # before the launch that reads it)
+    xpl_, w2pl_, w3pl_ = split(L, x.view(-1, 32)), split(L, wf2.view(64, -1)), split(L, wf3.view(32, -1))
+    _lib.check(L.hab_conv2d_fwd_pl(P(xpl_), P(w2pl_), P(b2), None, 0, P(a2pl), B, 63, 63, 32, 64, 4, 4,
                                    2, 0, 1, P(ws), ws.numel(), S()))
     y3 = torch.zeros(B, 28, 28, 32, device="cuda")
-    _lib.check(L.hab_conv2d_fwd_pl(P(a2pl), P(split(L, wf3.view(32, -1))), P(b3), P(y3), 0, None, B, 30, 30, 64, 32, 3, 3, 1, 0, 0, P(ws),
+    _lib.check(L.hab_conv2d_fwd_pl(P(a2pl), P(w3pl_), P(b3), P(y3), 0, None, B, 30, 30, 64, 32, 3, 3, 1, 0, 0, P(ws),
                                    ws.numel(), S()))
     a2 = F.relu(F.conv2d(x.cpu().permute(0, 3, 1, 2).double(), w2.double(), b2.cpu().double(), stride=2))
     ref = F.conv2d(a2, w3.double(), b3.cpu().double()).permute(0, 2, 3, 1)
@@ -152,7 +166,8 @@ def test_linear_as_1x1_convolution_with_row_stride(L):
     xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
     ws = torch.zeros(1 << 24, device="cuda")
     y = torch.full((M, ldy), 7.0, device="cuda")
-    _lib.check(L.hab_conv2d_fwd_pl(P(split(L, xd)), P(split(L, wd)), P(bd), P(y), ldy, None, M, 1, 1, K, N, 1, 1, 1, 0, 1, P(ws), ws.numel(), S()))
+    xpl_, wpl_ = split(L, xd), split(L, wd)  # named: see above
+    _lib.check(L.hab_conv2d_fwd_pl(P(xpl_), P(wpl_), P(bd), P(y), ldy, None, M, 1, 1, K, N, 1, 1, 1, 0, 1, P(ws), ws.numel(), S()))
     assert err_vs(ref, y[:, :N]) < 3e-6
     assert torch.all(y[:, N:] == 7.0), "columns beyond N are not touched"
 
@@ -166,7 +181,8 @@ def test_linear_as_1x1_convolution_with_row_stride(L):
     dy = torch.randn(M, N).cuda()
     wt = wd.t().contiguous()
     dxpl = torch.zeros(3 * M * K, dtype=torch.int16, device="cuda")
-    _lib.check(L.hab_conv2d_fwd_pl(P(split(L, dy)), P(split(L, wt)), None, None, 0, P(dxpl), M, 1, 1, N, K, 1, 1, 1, 0, 0, P(ws), ws.numel(), S()))
+    dypl_, wtpl_ = split(L, dy), split(L, wt)
+    _lib.check(L.hab_conv2d_fwd_pl(P(dypl_), P(wtpl_), None, None, 0, P(dxpl), M, 1, 1, N, K, 1, 1, 1, 0, 0, P(ws), ws.numel(), S()))
     assert err_vs(dy.cpu().double() @ w.double(), merge(L, dxpl, M * K).view(M, K)) < 3e-6
 
 
