@@ -78,9 +78,9 @@ C2_TABLE = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_wgrad", "fc_dgr
 # kernel launched by a probed call site (rocprofv3 names), for the HBM-traffic lookup in the committed --pmc passes
 PROBE_KERNELS = {"conv2_dgrad": "igemm_bf3_kernel<ConvDgradMergedProb", "conv1_fwd": "obs_conv_patch_kernel",
                  "conv1_wgrad": "obs_wgrad_bf3_kernel", "conv2_wgrad": "igemm_bf3_kernel<ConvWgradProb, 1, 2",
-                 "conv3_wgrad": "igemm_bf3_kernel<ConvWgradProb, 1, 1", "conv2_fwd": "igemm_bf3_kernel<ConvFwdProb, 1, 2",
+                 "conv3_wgrad": "wgrad3x3_bf3_kernel<2, 1, 30", "conv2_fwd": "igemm_bf3_kernel<ConvFwdProb, 1, 2",
                  "conv3_fwd": "conv_patch_bf3_kernel<ConvFwdProb", "conv3_dgrad": "igemm_bf3_kernel<ConvDgradProb",
-                 "fc_fwd": "igemm_bf3_kernel<LinearFwdProb, 2, 2", "fc_dgrad": "igemm_bf3_kernel<LinearDgradProb",
+                 "fc_fwd": "igemm_bf3_ws_kernel<LinearFwdProb", "fc_dgrad": "igemm_bf3_kernel<LinearDgradProb",
                  "fc_wgrad": "igemm_bf3_kernel<LinearWgradProb"}
 # Roofline model of a contraction call site on the split-bf16 matrix path (csrc/igemm_bf3.h): (algorithmic HBM bytes per frame:
 # every operand read once, the result written once; bf16 MFMA flops issued per useful fp32 flop).  The fp32-equivalent MFMA ceiling
@@ -117,6 +117,12 @@ def site_roofline(site, flops_per_frame, frames, ms):
     r["frac_of_fp32_mfma_peak"] = round(tfl / PEAK_FP32_MFMA_TFLOPS, 4)  # the round-1 yardstick (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s)
     r["roofline_floor_ms_per_kframe"] = round(max(t_hbm, t_mfma) * 1e6, 4)
     return r
+
+
+# call sites whose kernel runs a FIXED (persistent) grid: the counter passes cannot tell its rollout-sized launches from the update-sized
+# ones (tools/pmc_traffic.py keys by kernel and grid), so their traffic figure is the mean over all launches and is compared with the
+# algorithmic bytes of the mean launch
+PERSISTENT_GRID_SITES = {"conv1_fwd"}
 
 
 def site_chunks(site):
@@ -468,9 +474,11 @@ def main():
                          frames_per_launch=round(frames / max(probe_cnt, 1), 1)),
     }
     if traffic is not None and a.probe in SITE_MODEL and probe_cnt:
-        upd_frames = n_envs * n_steps // ppo.num_mini_batch // site_chunks(a.probe)
+        upd_frames = (frames / probe_cnt if a.probe in PERSISTENT_GRID_SITES else
+                      n_envs * n_steps // ppo.num_mini_batch // site_chunks(a.probe))
         out["roofline"]["traffic_ratio"] = round(traffic / (SITE_MODEL[a.probe][0] * upd_frames), 3)
-        out["roofline"]["traffic_basis"] = f"update-sized launch of {upd_frames} frames; algorithmic bytes {SITE_MODEL[a.probe][0]} per frame"
+        out["roofline"]["traffic_basis"] = (f"{'mean' if a.probe in PERSISTENT_GRID_SITES else 'update-sized'} launch of {upd_frames:.1f} frames; "
+                                            f"algorithmic bytes {SITE_MODEL[a.probe][0]} per frame")
     if a.workload in ("c2", "c3"):
         # FLOPs per env-step of the contractions that are EXECUTED: F = 2 MAC_fwd (1 + 1/T) + E (2 (3 MAC_fwd - MAC_first_dgrad)) -- the data
         # gradient of the first convolution (wrt the observation) is never computed.  SURVEY.md 8(d)'s formula counts it (C2 2.365,
@@ -511,7 +519,7 @@ def main():
                 # HBM bytes of the update-sized launch (committed --pmc passes of this command) over its algorithmic bytes
                 tr, _ = hbm_traffic(a.workload, k)
                 if tr is not None and k in SITE_MODEL:
-                    upd_frames = n_envs * n_steps // ppo.num_mini_batch // site_chunks(k)
+                    upd_frames = fs / cnt if k in PERSISTENT_GRID_SITES else n_envs * n_steps // ppo.num_mini_batch // site_chunks(k)
                     row["traffic"] = tr
                     row["traffic_ratio"] = round(tr / (SITE_MODEL[k][0] * upd_frames), 3)
                 table.append(row)
