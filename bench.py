@@ -77,7 +77,7 @@ C2_TABLE = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_wgrad", "fc_dgr
             "conv1_wgrad", "rnn_fwd", "rnn_bwd"]
 # kernel launched by a probed call site (rocprofv3 names), for the HBM-traffic lookup in the committed --pmc passes
 PROBE_KERNELS = {"conv2_dgrad": "igemm_bf3_kernel<ConvDgradMergedProb", "conv1_fwd": "obs_conv_patch_kernel",
-                 "conv1_wgrad": "obs_wgrad_bf3_kernel", "conv2_wgrad": "igemm_bf3_kernel<ConvWgradProb, 1, 2",
+                 "conv1_wgrad": "obs_wgrad_bf3_kernel", "conv2_wgrad": "wgrad3x3_bf3_kernel<1, 2, 63",
                  "conv3_wgrad": "wgrad3x3_bf3_kernel<2, 1, 30", "conv2_fwd": "igemm_bf3_kernel<ConvFwdProb, 1, 2",
                  "conv3_fwd": "conv_patch_bf3_kernel<ConvFwdProb", "conv3_dgrad": "igemm_bf3_kernel<ConvDgradProb",
                  "fc_fwd": "igemm_bf3_ws_kernel<LinearFwdProb", "fc_dgrad": "igemm_bf3_kernel<LinearDgradProb",
@@ -126,9 +126,9 @@ PERSISTENT_GRID_SITES = {"conv1_fwd"}
 
 
 def site_chunks(site):
-    """Launches of a call site per minibatch: the time-major chunked recurrence (csrc/engine.hip, HAB_RNN_CHUNKS, default 4) runs the
+    """Launches of a call site per minibatch: the time-major chunked recurrence (csrc/engine.hip, HAB_RNN_CHUNKS, default 8) runs the
     forward sites and the data-gradient chain (fc / conv3 / conv2 dgrad) once per time chunk; weight gradients once per minibatch."""
-    chunks = int(os.environ.get("HAB_RNN_CHUNKS", "4")) or 1
+    chunks = int(os.environ.get("HAB_RNN_CHUNKS", "8")) or 1
     return chunks if (site.endswith("_fwd") or site.endswith("_dgrad")) else 1
 
 

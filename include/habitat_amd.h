@@ -171,7 +171,7 @@ int hab_sample_actions(const float* probs, const float* exp_noise, int64_t* acti
  *     bit 5  producer / consumer waves where they measured faster (igemm_bf3_ws.h: 128 x 128 forward-form tiles with K >= 2048;
  *            obs_conv_bf3_ws.h: the observation-ingest convolution); bit-identical results
  *     bit 6  the observation-ingest convolution (8x8 / 4, RGB-D -> 32) with the input patch resident in LDS (obs_conv_patch.h)
- *     bit 7  (with bit 3) weight gradient of 3x3 / stride-1 convolutions with 32 / 64 channels -- SimpleCNN conv3, ResNet layer1 and
+ *     bit 7  (with bit 3) weight gradient of the small-channel convolutions -- SimpleCNN conv2 (4x4 / 2) and conv3, ResNet layer1 and
  *            layer2 at 128^2 -- with the strip resident in LDS in pixel-major layout, fragments by LDS transpose reads
  *            (wgrad3x3_bf3.h)
  *   Default 255 (all), env HAB_BF3 overrides.  hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one;

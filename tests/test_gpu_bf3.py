@@ -349,28 +349,29 @@ def test_obs_conv_patch_resident_as_accurate_as_fp32_path(L, B, H, W):
     assert err_vs(ref[rows.cpu().long()], a) < 3e-6
 
 
-@pytest.mark.parametrize("B,H,W,Cc,Cout,p", [(3, 30, 30, 64, 32, 0), (37, 30, 30, 64, 32, 0), (5, 32, 32, 32, 32, 1), (67, 32, 32, 32, 32, 1),
-                                             (4, 16, 16, 64, 64, 1), (131, 16, 16, 64, 64, 1), (1, 32, 32, 32, 32, 1)])
-def test_wgrad3x3_strip_resident_as_accurate_as_fp32_path(L, B, H, W, Cc, Cout, p):
-    """Matrix-path bit 7 (wgrad3x3_bf3.h): the 3x3 / stride-1 weight gradient with the strip resident in LDS and fragments built by LDS
-    transpose reads, against float64 -- every weight (a transposed / shifted tap or a swapped channel half shows as an O(1) error), the
+@pytest.mark.parametrize("B,H,W,Cc,Cout,p,K,st", [(3, 30, 30, 64, 32, 0, 3, 1), (37, 30, 30, 64, 32, 0, 3, 1), (5, 32, 32, 32, 32, 1, 3, 1),
+                                                  (67, 32, 32, 32, 32, 1, 3, 1), (4, 16, 16, 64, 64, 1, 3, 1), (131, 16, 16, 64, 64, 1, 3, 1),
+                                                  (1, 32, 32, 32, 32, 1, 3, 1), (3, 63, 63, 32, 64, 0, 4, 2), (41, 63, 63, 32, 64, 0, 4, 2)])
+def test_wgrad3x3_strip_resident_as_accurate_as_fp32_path(L, B, H, W, Cc, Cout, p, K, st):
+    """Matrix-path bit 7 (wgrad3x3_bf3.h): the 3x3 / stride-1 (and SimpleCNN conv2's 4x4 / stride-2: k-slot groups that cross output rows,
+    strided taps) weight gradient with the strip resident in LDS and fragments built by LDS transpose reads, against float64 -- every weight (a transposed / shifted tap or a swapped channel half shows as an O(1) error), the
     bias gradient, frame counts that do not divide into the workgroups' strip ranges, one frame (most workgroups idle), padded
     borders (first / last strip of an image), and bit-for-bit reproducibility.  As accurate as the fp32 MFMA path."""
     torch.manual_seed(11)
     x = torch.randn(B, Cc, H, W) * torch.rand(B, Cc, H, W).pow(4) * 50
-    Ho, Wo = H + 2 * p - 2, W + 2 * p - 2
+    Ho, Wo = (H + 2 * p - K) // st + 1, (W + 2 * p - K) // st + 1
     dy = torch.randn(B, Cout, Ho, Wo)
-    w = torch.zeros(Cout, Cc, 3, 3, dtype=torch.float64, requires_grad=True)
-    F.conv2d(x.double(), w, None, stride=1, padding=p).backward(dy.double())
+    w = torch.zeros(Cout, Cc, K, K, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, stride=st, padding=p).backward(dy.double())
     ref = torch.cat([w.grad.flatten(), dy.double().sum((0, 2, 3))])
     xd, dyd = x.permute(0, 2, 3, 1).contiguous().cuda(), dy.permute(0, 2, 3, 1).contiguous().cuda()
     ws = torch.zeros(1 << 24, device="cuda")
 
     def run():
         ws.normal_()  # stale slab contents must not matter
-        dw = torch.zeros(Cout, Cc, 3, 3, device="cuda")
+        dw = torch.zeros(Cout, Cc, K, K, device="cuda")
         db = torch.zeros(Cout, device="cuda")
-        _lib.check(L.hab_conv2d_wgrad(P(xd), P(dyd), P(dw), P(db), B, H, W, Cc, Cout, 3, 3, 1, p, P(ws), ws.numel(), S()))
+        _lib.check(L.hab_conv2d_wgrad(P(xd), P(dyd), P(dw), P(db), B, H, W, Cc, Cout, K, K, st, p, P(ws), ws.numel(), S()))
         return torch.cat([dw.flatten(), db])
 
     y_fp32 = _with_path(L, 0, run)
