@@ -126,9 +126,9 @@ PERSISTENT_GRID_SITES = {"conv1_fwd"}
 
 
 def site_chunks(site):
-    """Launches of a call site per minibatch: the time-major chunked recurrence (csrc/engine.hip, HAB_RNN_CHUNKS, default 8) runs the
+    """Launches of a call site per minibatch: the time-major chunked recurrence (csrc/engine.hip, HAB_RNN_CHUNKS, default 4) runs the
     forward sites and the data-gradient chain (fc / conv3 / conv2 dgrad) once per time chunk; weight gradients once per minibatch."""
-    chunks = int(os.environ.get("HAB_RNN_CHUNKS", "8")) or 1
+    chunks = int(os.environ.get("HAB_RNN_CHUNKS", "4")) or 1
     return chunks if (site.endswith("_fwd") or site.endswith("_dgrad")) else 1
 
 

@@ -282,7 +282,7 @@ static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
 }
 
 // ---- time-major chunked recurrence: second stream + events ----
-static int tm_chunks_cfg() { static const int v = hab_env_int("HAB_RNN_CHUNKS", 8); return v; }
+static int tm_chunks_cfg() { static const int v = hab_env_int("HAB_RNN_CHUNKS", 4); return v; }
 static int tm_setup(hab_policy* e, int nev) {
     if (!e->s2) {
         // highest priority: the recurrence is a chain of ~7 us launches; each must be dispatched ahead of the queued waves of the large
