@@ -217,7 +217,8 @@ int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oih
     ConvWgradProb p;
     HAB_TRY(build(p, d, x, dy, dw_oihw, dbias));
     if (ws && (bf3_mode() & 8) && (bf3_mode() & 128) && wgrad3x3_bf3_shape(p)) {  // strip-resident, transpose reads (wgrad3x3_bf3.h)
-        return wgrad3x3_bf3(p, ws, ws_floats, stream);
+        const int rc = wgrad3x3_bf3(p, ws, ws_floats, stream);
+        if (rc != 1) return rc;
     }
     if (ws && wgrad3x3_patch_ok(p) && !no_patch() && !(bf3_mode() & 8)) {  // 3x3/1/1 with W in {16, 32}: patch-resident kernel
         ConvWgradProb q = p;

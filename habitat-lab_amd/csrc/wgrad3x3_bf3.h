@@ -263,7 +263,7 @@ inline int wgrad3x3_bf3_run(const ConvWgradProb& p, float* ws, size_t ws_floats,
     const int per_cu = (int)std::min<size_t>(Cfg::NT <= 192 ? 4 : 2, (160 * 1024) / Cfg::LDS_BYTES);
     int grid = 256 * std::max(per_cu, 1);
     while (grid > 8 && (grid > a.items || (size_t)grid * KS * MN > ws_floats)) grid -= 8;
-    if ((size_t)grid * KS * MN > ws_floats) return HAB_ERR_ARG;
+    if ((size_t)grid * KS * MN > ws_floats || (grid < 128 && a.items >= 1024)) return 1;  // workspace too small for a chip-filling launch
     kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(a);
     HAB_LAUNCH_CHECK();
     igemm_splitk_reduce<ConvWgradProb>(p, ws, grid * KS, stream);
@@ -284,6 +284,7 @@ inline int wgrad3x3_bf3_shape(const ConvWgradProb& p) {
     return 0;
 }
 // p.colsum (bias gradient) is produced by the same pass: dY goes through the workgroups' registers anyway.
+// Returns 1 when the workspace cannot hold the slabs of a chip-filling launch (the caller falls back to the implicit-GEMM form).
 inline int wgrad3x3_bf3(const ConvWgradProb& p, float* ws, size_t ws_floats, hipStream_t stream) {
     if (!ws) return HAB_ERR_ARG;
     // Instances (measured at 2048 frames, kernel + slab reduction; implicit-GEMM weight gradient before):
