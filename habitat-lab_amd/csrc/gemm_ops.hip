@@ -142,10 +142,6 @@ int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const f
         const int rc = obs_conv_patch_launch(p, ws, ws_floats, stream);
         if (rc != 1) return rc;
     }
-    if ((bf3_mode() & 64) && (bf3_mode() & 2) && p.quad) {  // observation patch resident in LDS (obs_conv_patch.h): 8x8 / 4 RGB-D -> 32 only
-        const int rc = obs_conv_patch_launch(p, ws, ws_floats, stream);
-        if (rc != 1) return rc;
-    }
     if ((bf3_mode() & 32) && (bf3_mode() & 2) && p.quad && p.M > 64) {  // producer / consumer waves (obs_conv_bf3_ws.h): 133 -> 148-152 TFLOP/s-eq at 1024 frames
         const int rc = obs_conv_bf3_ws_launch(p, ws, ws_floats, stream);
         if (rc != 1) return rc;
