@@ -78,7 +78,7 @@ C2_TABLE = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_wgrad", "fc_dgr
 # kernel launched by a probed call site (rocprofv3 names), for the HBM-traffic lookup in the committed --pmc passes
 PROBE_KERNELS = {"conv2_dgrad": "igemm_bf3_kernel<ConvDgradMergedProb", "conv1_fwd": "obs_conv_patch_kernel",
                  "conv1_wgrad": "obs_wgrad_bf3_kernel", "conv2_wgrad": "wgrad3x3_bf3_kernel<1, 2, 63",
-                 "conv3_wgrad": "wgrad3x3_bf3_kernel<2, 1, 30", "conv2_fwd": "igemm_bf3_kernel<ConvFwdProb, 1, 2",
+                 "conv3_wgrad": "wgrad3x3_bf3_kernel<2, 1, 30", "conv2_fwd": "conv2_fwd_strip_kernel",
                  "conv3_fwd": "conv_patch_bf3_kernel<ConvFwdProb", "conv3_dgrad": "igemm_bf3_kernel<ConvDgradProb",
                  "fc_fwd": "igemm_bf3_ws_kernel<LinearFwdProb", "fc_dgrad": "igemm_bf3_kernel<LinearDgradProb",
                  "fc_wgrad": "igemm_bf3_kernel<LinearWgradProb"}
@@ -122,7 +122,7 @@ def site_roofline(site, flops_per_frame, frames, ms):
 # call sites whose kernel runs a FIXED (persistent) grid: the counter passes cannot tell its rollout-sized launches from the update-sized
 # ones (tools/pmc_traffic.py keys by kernel and grid), so their traffic figure is the mean over all launches and is compared with the
 # algorithmic bytes of the mean launch
-PERSISTENT_GRID_SITES = {"conv1_fwd"}
+PERSISTENT_GRID_SITES = {"conv1_fwd", "conv2_fwd"}
 
 
 def site_chunks(site):

@@ -9,6 +9,7 @@
 #include "obs_conv_bf3_ws.h"
 #include "obs_conv_patch.h"
 #include "wgrad3x3_bf3.h"
+#include "conv2_fwd_strip.h"
 #include "obs_wgrad_bf3.h"
 #include "conv_patch_bf3.h"
 #include "wgrad3x3_patch.h"
@@ -33,7 +34,7 @@ static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); ret
 // observation-ingest convolution with the input patch resident in LDS (obs_conv_patch.h)
 static int g_bf3_mode = -1;
 static int bf3_mode() {
-    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 255);
+    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 511);
     return g_bf3_mode;
 }
 extern "C" int hab_set_matrix_path(int mode) {
@@ -131,6 +132,10 @@ int conv_fwd(const ConvDesc& d, const float* x, const float* wf, const float* bi
              size_t ws_floats, hipStream_t stream) {
     ConvFwdProb p;
     HAB_TRY(build(p, d, x, wf, bias, y, relu));
+    if ((bf3_mode() & 256) && (bf3_mode() & 1)) {  // SimpleCNN conv2: input strip in LDS, filter slices in registers (conv2_fwd_strip.h)
+        const int rc = conv2_fwd_strip(p, ws, ws_floats, stream);
+        if (rc != 1) return rc;
+    }
     if ((bf3_mode() & 16) && d.stride == 1 && d.KH == 3 && d.KW == 3 && p.M > 64) {  // input patch resident in LDS (conv_patch_bf3.h)
         PatchGeom gq{};
         gq.in = x; gq.Hi = d.H; gq.Wi = d.W; gq.Ci = d.C; gq.Ho = p.g.Ho; gq.Wo = p.g.Wo; gq.KH = 3; gq.KW = 3;

@@ -384,3 +384,38 @@ def test_wgrad3x3_strip_resident_as_accurate_as_fp32_path(L, B, H, W, Cc, Cout, 
     d = (y_strip.double().cpu() - ref).abs()
     assert float(d.max()) <= 3e-6 * float(ref.abs().max())
     assert torch.equal(y_strip, _with_path(L, 4 | 8 | 128, run)), "not reproducible"
+
+
+@pytest.mark.parametrize("B,relu,with_bias", [(16, 1, True), (37, 0, True), (64, 1, False), (131, 1, True)])
+def test_conv2_strip_resident_forward_as_accurate_as_fp32_path(L, B, relu, with_bias):
+    """Matrix-path bit 8 (conv2_fwd_strip.h): SimpleCNN conv2's forward with the input strip in LDS and the filter slices in the waves'
+    registers, partial sums of the eight waves folded in LDS: every output against float64 (a wrong tap, column class, swizzle slot,
+    channel block or wave order shows as an O(1) error), bias / no bias, ReLU / none, frame counts that leave workgroups with ragged
+    strip ranges, bit-for-bit reproducibility; as accurate as the fp32 MFMA path, and NOT the implicit-GEMM kernel's bits (so the new
+    kernel really ran)."""
+    torch.manual_seed(12)
+    H = W = 63
+    x = torch.randn(B, 32, H, W) * torch.rand(B, 32, H, W).pow(4) * 50
+    w = torch.randn(64, 32, 4, 4) / np.sqrt(32 * 16)
+    b = torch.randn(64) if with_bias else None
+    ref = F.conv2d(x.double(), w.double(), b.double() if with_bias else None, stride=2).permute(0, 2, 3, 1)
+    if relu:
+        ref = F.relu(ref)
+    xd, wf = x.permute(0, 2, 3, 1).contiguous().cuda(), repack_fwd(L, w)
+    bd = b.cuda() if with_bias else None
+    ws = torch.zeros(1 << 22, device="cuda")
+
+    def run():
+        y = torch.full(ref.shape, 7.0, device="cuda")
+        _lib.check(L.hab_conv2d_fwd(P(xd), P(wf), P(bd), P(y), B, H, W, 32, 64, 4, 4, 2, 0, relu, P(ws), ws.numel(), S()))
+        return y
+
+    y_fp32 = _with_path(L, 0, run)
+    y_igemm = _with_path(L, 1, run)
+    y_strip = _with_path(L, 1 | 256, run)
+    assert not torch.equal(y_strip, y_igemm), "bit 8 did not select another kernel"
+    e0, e2 = err_vs(ref, y_fp32), err_vs(ref, y_strip)
+    assert e2 <= 2 * e0 + 2e-7 and e2 < 3e-6, (e0, e2)
+    d = (y_strip.double().cpu() - ref).abs()
+    assert float(d.max()) <= 3e-6 * float(ref.abs().max())
+    assert torch.equal(y_strip, _with_path(L, 1 | 256, run)), "not reproducible"
