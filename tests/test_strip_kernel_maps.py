@@ -1,0 +1,251 @@
+"""CPU: the index maps of the strip-resident kernels (csrc/wgrad3x3_bf3.h, csrc/conv2_fwd_strip.h) replayed in numpy.
+
+Everything that decides WHICH numbers meet in an MFMA is index arithmetic: the LDS image a strip is staged into (pixel-major rows,
+channel halves, even / odd column order, XOR-swizzled chunks), the per-lane addresses of the fragment reads (incl. the LDS transpose
+read, whose data movement tools/ubench/tr_read_probe.hip pins on the hardware: every 16-lane group reads a [4 rows][16 columns] block,
+lane i supplies the address of 8-byte chunk i -- row i // 4, chunk i % 4 -- and receives column i of the four rows), the MFMA operand /
+accumulator lane layouts, the wave decomposition, the slab / partial-tile addresses of the epilogues.  This file restates those maps
+from the headers (same formulas, same constants) and runs them on small integer-valued tensors, where float64 arithmetic is exact:
+the result must equal the convolution's weight gradient / forward output element for element.  The operand split into three bf16
+planes is exact arithmetic and orthogonal to the maps, so one "plane" holds the whole value here.  The GPU parity tests
+(tests/test_gpu_bf3.py) check the kernels themselves; this test makes the design reviewable without a GPU."""
+import numpy as np
+import pytest
+
+
+# ---- hardware models -------------------------------------------------------------------------------------------------------------
+def tr_read_b64(lds, addr):
+    """ds_read_b64_tr_b16: `addr[64]` element offsets (multiples of 4); returns [64][4]: lane i of a 16-lane group receives element
+    (i % 16) of the group's 16-element rows, from the four rows whose chunks the lanes 4 r .. 4 r + 3 of the group addressed."""
+    out = np.zeros((64, 4), lds.dtype)
+    for g in range(4):
+        lanes = np.arange(16) + 16 * g
+        rows = [np.concatenate([lds[addr[lanes[4 * r + c]]: addr[lanes[4 * r + c]] + 4] for c in range(4)]) for r in range(4)]
+        for i in range(16):
+            out[lanes[i]] = [rows[r][i] for r in range(4)]
+    return out
+
+
+def mfma_32x32x16(a_frag, b_frag, acc):
+    """a_frag / b_frag: [64][8] (lane l: row / column l % 32, k = 8 (l // 32) .. +7); acc: [64][16] (lane l: column l % 32, rows
+    (v & 3) + 8 (v >> 2) + 4 (l // 32))."""
+    A = np.zeros((32, 16)); B = np.zeros((16, 32))
+    for l in range(64):
+        A[l % 32, 8 * (l // 32): 8 * (l // 32) + 8] = a_frag[l]
+        B[8 * (l // 32): 8 * (l // 32) + 8, l % 32] = b_frag[l]
+    D = A @ B
+    for l in range(64):
+        for v in range(16):
+            acc[l, v] += D[(v & 3) + 8 * (v >> 2) + 4 * (l // 32), l % 32]
+    return acc
+
+
+# ---- wgrad3x3_bf3.h ---------------------------------------------------------------------------------------------------------------
+def wgrad_strip_model(x, dy, C32, N32, W, PAD, KHW, S, R, KS, NS, strips=None):
+    """x [B][H][W][C], dy [B][Ho][Wo][N] -> dW [N][KHW][KHW][C] through the kernel's maps (strips: the strips to run; the others must
+    hold zero dY -- they contribute exactly zero and only cost time)."""
+    Bn, H = x.shape[0], x.shape[1]
+    C, N, WP = 32 * C32, 32 * N32, W + 2 * PAD
+    Wo = (WP - KHW) // S + 1
+    Ho = dy.shape[1]
+    NW = N32 // NS
+    XRS = (R - 1) * S + KHW
+    XROWS, NPIX = XRS * WP, R * Wo
+    NQ = (NPIX + 3) // 4
+    NSTEPS = (NQ + 3) // 4
+    YROWS = NSTEPS * 16
+    X_HALF, Y_HALF = XROWS * 32, YROWS * 32
+    WH = (WP + 1) // 2
+    xcol = (lambda w: (w & 1) * WH + (w >> 1)) if S == 2 else (lambda w: w)
+    tap_col = (lambda kw: (kw & 1) * WH + (kw >> 1)) if S == 2 else (lambda kw: kw)
+    nwaves = KHW * KS * NS
+    slabs = np.zeros((KS, KHW * KHW * C, N))
+    assert Ho % R == 0
+    for img in range(Bn):
+        for strip in (range(Ho // R) if strips is None else strips):
+            ho0 = strip * R
+            xs = np.zeros(C32 * X_HALF); ys = np.zeros(N32 * Y_HALF)
+            # stage(): unit u = 4 channels of one pixel
+            for u in range(XRS * W * C // 4):
+                c4, pix = u % (C // 4), u // (C // 4)
+                w, hh = pix % W, pix // W
+                h = ho0 * S - PAD + hh
+                v = x[img, h, w, 4 * c4: 4 * c4 + 4] if 0 <= h < H else np.zeros(4)
+                dst = (c4 >> 3) * X_HALF + (hh * WP + xcol(w + PAD)) * 32 + (c4 & 7) * 4
+                xs[dst: dst + 4] = v
+            for u in range(R * Wo * N // 4):
+                c4, pix = u % (N // 4), u // (N // 4)
+                dst = (c4 >> 3) * Y_HALF + pix * 32 + (c4 & 7) * 4
+                ys[dst: dst + 4] = dy[img, ho0 + pix // Wo, pix % Wo, 4 * c4: 4 * c4 + 4]
+            for wave in range(nwaves):
+                kh, ns, ks = wave % KHW, (wave // KHW) % NS, wave // (KHW * NS)
+                acc = np.zeros((KHW, C32, NW, 64, 16))
+                for s in range(ks, NSTEPS, KS):
+                    yoff = np.zeros((2, 64), int); xoff = np.zeros((2, 64), int)
+                    for lane in range(64):
+                        i16, kblk = lane & 15, lane >> 5
+                        chunk_off = ((lane >> 4) & 1) * 16 + (i16 & 3) * 4
+                        for r in range(2):
+                            pix = 4 * (4 * s + 2 * kblk + r) + (i16 >> 2)
+                            yoff[r, lane] = pix * 32 + chunk_off
+                            pc = pix if pix < NPIX else 0
+                            hol, wo = pc // Wo, pc % Wo
+                            xoff[r, lane] = ((hol * S + kh) * WP + (wo if S == 2 else wo * S)) * 32 + chunk_off
+                    bfr = [np.concatenate([tr_read_b64(ys, (ns * NW + hn) * Y_HALF + yoff[0]),
+                                           tr_read_b64(ys, (ns * NW + hn) * Y_HALF + yoff[1])], 1) for hn in range(NW)]
+                    for kw in range(KHW):
+                        for hc in range(C32):
+                            base = hc * X_HALF + tap_col(kw) * 32
+                            afr = np.concatenate([tr_read_b64(xs, base + xoff[0]), tr_read_b64(xs, base + xoff[1])], 1)
+                            for hn in range(NW):
+                                mfma_32x32x16(afr, bfr[hn], acc[kw, hc, hn])
+                for kw in range(KHW):
+                    for hc in range(C32):
+                        for hn in range(NW):
+                            for lane in range(64):
+                                li, hi = lane & 31, lane >> 5
+                                for v in range(16):
+                                    ci = (v & 3) + 8 * (v >> 2) + 4 * hi
+                                    slabs[ks, (kh * KHW + kw) * C + hc * 32 + ci, (ns * NW + hn) * 32 + li] += acc[kw, hc, hn, lane, v]
+    dw = slabs.sum(0).reshape(KHW, KHW, C, N)  # row i = (kh*KHW + kw)*C + ci
+    return dw.transpose(3, 0, 1, 2)
+
+
+def wgrad_reference(x, dy, PAD, KHW, S):
+    Bn, H, W, C = x.shape
+    _, Ho, Wo, N = dy.shape
+    xp = np.zeros((Bn, H + 2 * PAD, W + 2 * PAD, C)); xp[:, PAD: PAD + H, PAD: PAD + W] = x
+    dw = np.zeros((N, KHW, KHW, C))
+    for kh in range(KHW):
+        for kw in range(KHW):
+            patch = xp[:, kh: kh + S * (Ho - 1) + 1: S, kw: kw + S * (Wo - 1) + 1: S]  # [B][Ho][Wo][C]
+            dw[:, kh, kw] = np.einsum("bhwn,bhwc->nc", dy, patch)
+    return dw
+
+
+@pytest.mark.parametrize("cfg", [dict(C32=2, N32=1, W=30, PAD=0, KHW=3, S=1, R=2, KS=2, NS=1, H=30),    # SimpleCNN conv3
+                                 dict(C32=1, N32=1, W=32, PAD=1, KHW=3, S=1, R=2, KS=1, NS=1, H=32),    # ResNet layer1
+                                 dict(C32=2, N32=2, W=16, PAD=1, KHW=3, S=1, R=4, KS=1, NS=2, H=16),    # ResNet layer2
+                                 dict(C32=1, N32=2, W=63, PAD=0, KHW=4, S=2, R=2, KS=2, NS=1, H=63)])   # SimpleCNN conv2
+def test_weight_gradient_strip_maps(cfg):
+    rng = np.random.default_rng(0)
+    H, W, PAD, KHW, S = cfg["H"], cfg["W"], cfg["PAD"], cfg["KHW"], cfg["S"]
+    C, N = 32 * cfg["C32"], 32 * cfg["N32"]
+    Ho = (H + 2 * PAD - KHW) // S + 1
+    Wo = (W + 2 * PAD - KHW) // S + 1
+    R = cfg["R"]
+    # two strips of one image are enough to exercise every map (first strip: top border / padding row; the other: interior or bottom)
+    x = rng.integers(-3, 4, (1, H, W, C)).astype(np.float64)
+    dy = np.zeros((1, Ho, Wo, N))
+    rows = list(range(0, R)) + list(range(Ho - R, Ho))
+    dy[:, rows] = rng.integers(-3, 4, (1, len(rows), Wo, N))
+    kw = {k: v for k, v in cfg.items() if k != "H"}
+    got = wgrad_strip_model(x, dy, strips=(0, Ho // R - 1), **kw)
+    ref = wgrad_reference(x, dy, PAD, KHW, S)
+    assert np.array_equal(got, ref)
+
+
+# ---- conv2_fwd_strip.h ------------------------------------------------------------------------------------------------------------
+def conv2_fwd_strip_model(x, wf, bias, relu, R=2, strips=None):
+    """x [B][63][63][32], wf [64][4][4][32] -> y [B][30][30][64] through the kernel's maps (strips: subset of strip indices)."""
+    Bn = x.shape[0]
+    W, Wo, Ho, WH = 63, 30, 30, 32
+    XRS = 2 * (R - 1) + 4
+    XROWS, NPIX = XRS * W, R * Wo
+    NPT = (NPIX + 31) // 32
+    RED_LD = 68
+    xcol = lambda w: (w & 1) * WH + (w >> 1)
+    y = np.full((Bn, Ho, Wo, 64), np.nan)
+    for img in range(Bn):
+        for strip in (range(Ho // R) if strips is None else strips):
+            ho0 = strip * R
+            xs = np.zeros(XROWS * 32)
+            for u in range(XRS * W * 8):
+                c4, pix = u & 7, u >> 3
+                w, hh = pix % W, pix // W
+                row = hh * W + xcol(w)
+                dst = row * 32 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 3) + (c4 & 1) * 4
+                xs[dst: dst + 4] = x[img, ho0 * 2 + hh, w, 4 * c4: 4 * c4 + 4]
+            for pt in range(NPT):
+                red = np.zeros(8 * 32 * RED_LD)
+                for wave in range(8):
+                    kh, kwp = wave >> 1, wave & 1
+                    acc = np.zeros((2, 64, 16))
+                    for j in range(4):
+                        kw = 2 * kwp + (j >> 1)
+                        af = np.zeros((64, 8)); bw = np.zeros((2, 64, 8))
+                        for lane in range(64):
+                            li, hi = lane & 31, lane >> 5
+                            p = pt * 32 + li
+                            pc = p if p < NPIX else 0
+                            hol, wo = pc // Wo, pc % Wo
+                            row = (hol * 2 + kh) * W + wo + (kw & 1) * WH + (kw >> 1)
+                            chunk = (j & 1) * 2 + hi
+                            src = row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3)
+                            af[lane] = xs[src: src + 8]
+                            for ct in range(2):
+                                ci = (j & 1) * 16 + hi * 8
+                                bw[ct, lane] = wf[ct * 32 + li, kh, kw, ci: ci + 8]
+                        for ct in range(2):  # operands swapped: A = filter (rows = output channels), B = input (columns = pixels)
+                            mfma_32x32x16(bw[ct], af, acc[ct])
+                    for lane in range(64):
+                        li, hi = lane & 31, lane >> 5
+                        mine = (wave * 32 + li) * RED_LD
+                        for ct in range(2):
+                            for g in range(4):
+                                red[mine + ct * 32 + 8 * g + 4 * hi: mine + ct * 32 + 8 * g + 4 * hi + 4] = acc[ct, lane, 4 * g: 4 * g + 4]
+                for t in range(512):
+                    rpix, rco = t >> 4, (t & 15) * 4
+                    s = sum(red[(w8 * 32 + rpix) * RED_LD + rco: (w8 * 32 + rpix) * RED_LD + rco + 4] for w8 in range(8))
+                    if bias is not None:
+                        s = s + bias[rco: rco + 4]
+                    if relu:
+                        s = np.maximum(s, 0)
+                    op = pt * 32 + rpix
+                    if op < NPIX:
+                        y[img, ho0 + op // Wo, op % Wo, rco: rco + 4] = s
+    return y
+
+
+def test_conv2_forward_strip_maps():
+    rng = np.random.default_rng(1)
+    x = rng.integers(-3, 4, (1, 63, 63, 32)).astype(np.float64)
+    wf = rng.integers(-2, 3, (64, 4, 4, 32)).astype(np.float64)
+    bias = rng.integers(-5, 6, 64).astype(np.float64)
+    strips = (0, 7, 14)
+    y = conv2_fwd_strip_model(x, wf, bias, relu=True, strips=strips)
+    ref = np.zeros((30, 30, 64))
+    for kh in range(4):
+        for kw in range(4):
+            ref += np.einsum("hwc,nc->hwn", x[0, kh: kh + 59: 2, kw: kw + 59: 2], wf[:, kh, kw])
+    ref = np.maximum(ref + bias, 0)
+    for s in strips:
+        assert np.array_equal(y[0, 2 * s: 2 * s + 2], ref[2 * s: 2 * s + 2]), s
+    assert np.isnan(y[0, 2]).all()  # strips that were not run stay untouched
+
+
+def test_lds_read_patterns_are_conflict_free():
+    """Bank model: 64 banks x 4 bytes.  (a) conv2_fwd_strip's ds_read_b128 fragment reads: a phase = 16 lanes x 16 bytes must cover all
+    64 banks once; (b) wgrad3x3's transpose reads at 64-byte pixel rows: the two 16-lane groups of a 32-lane half (same 4 pixel rows,
+    both channel halves) cover 256 contiguous bytes."""
+    W, WH, Wo = 63, 32, 30
+    for kh in range(4):
+        for kw in range(4):
+            for chunk in range(4):
+                for p0 in range(0, 60 - 15):  # 16 consecutive pixels of the strip, any alignment, incl. an output-row crossing
+                    banks = []
+                    for li in range(16):
+                        p = p0 + li
+                        hol, wo = p // Wo, p % Wo
+                        row = (hol * 2 + kh) * W + wo + (kw & 1) * WH + (kw >> 1)
+                        byte = row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4)
+                        banks += [((byte >> 2) + q) & 63 for q in range(4)]
+                    if p0 // Wo == (p0 + 15) // Wo:  # inside one output row: consecutive LDS rows -> every bank exactly once
+                        assert sorted(banks) == list(range(64)), (kh, kw, chunk, p0)
+    for base_row in range(0, 40):
+        banks = []
+        for lane in range(32):
+            i16 = lane & 15
+            byte = (base_row + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8
+            banks += [((byte >> 2) + q) & 63 for q in range(2)]
+        assert sorted(banks) == list(range(64)), base_row
