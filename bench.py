@@ -76,7 +76,7 @@ PROBES = {
 C2_TABLE = ["conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_wgrad", "fc_dgrad", "conv3_wgrad", "conv3_dgrad", "conv2_wgrad", "conv2_dgrad",
             "conv1_wgrad", "rnn_fwd", "rnn_bwd"]
 # kernel launched by a probed call site (rocprofv3 names), for the HBM-traffic lookup in the committed --pmc passes
-PROBE_KERNELS = {"conv2_dgrad": "igemm_bf3_kernel<ConvDgradMergedProb", "conv1_fwd": "obs_conv_patch_kernel",
+PROBE_KERNELS = {"conv2_dgrad": "conv2_dgrad_strip_kernel", "conv1_fwd": "obs_conv_patch_kernel",
                  "conv1_wgrad": "obs_wgrad_bf3_kernel", "conv2_wgrad": "wgrad3x3_bf3_kernel<1, 2, 63",
                  "conv3_wgrad": "wgrad3x3_bf3_kernel<2, 1, 30", "conv2_fwd": "conv2_fwd_strip_kernel",
                  "conv3_fwd": "conv_patch_bf3_kernel<ConvFwdProb", "conv3_dgrad": "igemm_bf3_kernel<ConvDgradProb",

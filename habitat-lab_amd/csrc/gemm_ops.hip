@@ -10,6 +10,7 @@
 #include "obs_conv_patch.h"
 #include "wgrad3x3_bf3.h"
 #include "conv2_fwd_strip.h"
+#include "conv2_dgrad_strip.h"
 #include "obs_wgrad_bf3.h"
 #include "conv_patch_bf3.h"
 #include "wgrad3x3_patch.h"
@@ -34,7 +35,7 @@ static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); ret
 // observation-ingest convolution with the input patch resident in LDS (obs_conv_patch.h)
 static int g_bf3_mode = -1;
 static int bf3_mode() {
-    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 511);
+    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 1023);
     return g_bf3_mode;
 }
 extern "C" int hab_set_matrix_path(int mode) {
@@ -174,6 +175,10 @@ __global__ void dgrad_empty_class_kernel(ConvDgradProb p) {
 
 int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add, float* dx,
                float* ws, size_t ws_floats, hipStream_t stream) {
+    if ((bf3_mode() & 512) && (bf3_mode() & 1)) {  // SimpleCNN conv2: dY strip in LDS, filter slices in registers (conv2_dgrad_strip.h)
+        const int rc = conv2_dgrad_strip(d, dy, wd, mask, add, dx, stream);
+        if (rc != 1) return rc;
+    }
     if (d.stride > 1 && !no_dma() && !no_merged_dgrad()) {
         // kernel size a multiple of the stride: the stride classes share their dY gather -> one contraction with N = s*s*Cin
         ConvDgradMergedProb q;

@@ -176,7 +176,9 @@ int hab_sample_actions(const float* probs, const float* exp_noise, int64_t* acti
  *            (wgrad3x3_bf3.h)
  *     bit 8  (with bit 0) SimpleCNN conv2's forward (4x4 / 2, 32 -> 64 at 63 x 63, >= 16 frames) with the input strip resident in LDS and
  *            the filter slices resident in the waves' registers (conv2_fwd_strip.h)
- *   Default 511 (all), env HAB_BF3 overrides.  hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one;
+ *     bit 9  (with bit 0) SimpleCNN conv2's data gradient on the same scheme: dY strip in LDS, filter slices in registers, the four taps
+ *            of a row class folded in LDS, ReLU mask fused (conv2_dgrad_strip.h)
+ *   Default 1023 (all), env HAB_BF3 overrides.  hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one;
  *   mode < 0 only queries.  Results are fp32-equivalent on either path (tests/test_gpu_bf3.py: error vs float64 of both).
  * ------------------------------------------------------------------------------------------- */
 int hab_set_matrix_path(int mode);

@@ -419,3 +419,39 @@ def test_conv2_strip_resident_forward_as_accurate_as_fp32_path(L, B, relu, with_
     d = (y_strip.double().cpu() - ref).abs()
     assert float(d.max()) <= 3e-6 * float(ref.abs().max())
     assert torch.equal(y_strip, _with_path(L, 1 | 256, run)), "not reproducible"
+
+
+@pytest.mark.parametrize("B,with_mask", [(16, True), (37, True), (64, False)])
+def test_conv2_strip_resident_data_gradient_as_accurate_as_fp32_path(L, B, with_mask):
+    """Matrix-path bit 9 (conv2_dgrad_strip.h): SimpleCNN conv2's data gradient with the dY strip in LDS and the filter slices in the
+    waves' registers (four taps of a row class folded in LDS): every element of dX against float64 -- border cells that read dY outside
+    the image, the half-empty last cell row / column (h = w = 62 has no odd neighbour), the ReLU mask, no mask, ragged frame counts,
+    bit-for-bit reproducibility; as accurate as the fp32 MFMA path and not the implicit-GEMM kernel's bits."""
+    torch.manual_seed(13)
+    H = W = 63
+    w = torch.randn(64, 32, 4, 4) / np.sqrt(32 * 16)
+    dy = torch.randn(B, 64, 30, 30) * torch.rand(B, 64, 30, 30).pow(3) * 20
+    x64 = torch.zeros(B, 32, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x64, w.double(), None, stride=2).backward(dy.double())
+    ref = x64.grad.permute(0, 2, 3, 1)
+    mask = torch.randn(B, H, W, 32)
+    if with_mask:
+        ref = ref * (mask > 0)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    wdg = w.permute(1, 2, 3, 0).contiguous().cuda()  # [ci][kh][kw][co]
+    md = mask.cuda() if with_mask else None
+    ws = torch.zeros(1 << 22, device="cuda")
+
+    def run():
+        dx = torch.full((B, H, W, 32), 7.0, device="cuda")
+        _lib.check(L.hab_conv2d_dgrad(P(dyn), P(wdg), P(md), None, P(dx), B, H, W, 32, 64, 4, 4, 2, 0, P(ws), ws.numel(), S()))
+        return dx
+
+    d_fp32 = _with_path(L, 0, run)
+    d_igemm = _with_path(L, 1, run)
+    d_strip = _with_path(L, 1 | 512, run)
+    assert not torch.equal(d_strip, d_igemm), "bit 9 did not select another kernel"
+    e0, e2 = err_vs(ref, d_fp32), err_vs(ref, d_strip)
+    assert e2 <= 2 * e0 + 2e-7 and e2 < 3e-6, (e0, e2)
+    assert float((d_strip.double().cpu() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    assert torch.equal(d_strip, _with_path(L, 1 | 512, run)), "not reproducible"

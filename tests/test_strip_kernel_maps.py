@@ -249,3 +249,90 @@ def test_lds_read_patterns_are_conflict_free():
             byte = (base_row + (i16 >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (i16 & 3) * 8
             banks += [((byte >> 2) + q) & 63 for q in range(2)]
         assert sorted(banks) == list(range(64)), base_row
+
+
+# ---- conv2_dgrad_strip.h ----------------------------------------------------------------------------------------------------------
+def conv2_dgrad_strip_model(dy, wd, mask, R2=2, strips=None):
+    """dy [B][30][30][64], wd [32 ci][4][4][64 co], mask [B][63][63][32] or None -> dx [B][63][63][32] through the kernel's maps."""
+    Bn = dy.shape[0]
+    H, Ho, Wo, YCOLS, RED_LD = 63, 30, 30, 33, 68
+    YRS = R2 + 1
+    dx = np.full((Bn, H, H, 32), np.nan)
+    for img in range(Bn):
+        for strip in (range(32 // R2) if strips is None else strips):
+            h20 = strip * R2
+            ys = np.zeros(YRS * YCOLS * 64)
+            for u in range(YRS * Wo * 16):
+                r = u // (Wo * 16)
+                rem = u - r * (Wo * 16)
+                w, c4 = rem >> 4, rem & 15
+                pixidx = r * YCOLS + w + 1
+                dst = pixidx * 64 + (((c4 >> 1) ^ ((pixidx >> 1) & 7)) << 3) + (c4 & 1) * 4
+                row = h20 - 1 + r
+                ys[dst: dst + 4] = dy[img, row, w, 4 * c4: 4 * c4 + 4] if 0 <= row < Ho else 0.0
+            for tr in range(R2):
+                red = np.zeros(8 * 32 * RED_LD)
+                for wave in range(8):
+                    tap, ph = wave >> 1, wave & 1
+                    ta, tb = tap >> 1, tap & 1
+                    acc = np.zeros((2, 64, 16))
+                    for j in range(4):
+                        yf = np.zeros((64, 8)); bw = np.zeros((2, 64, 8))
+                        for lane in range(64):
+                            li, hi = lane & 31, lane >> 5
+                            pixidx = (tr + 1 - ta) * YCOLS + li + 1 - tb
+                            src = pixidx * 64 + (((2 * j + hi) ^ ((pixidx >> 1) & 7)) << 3)
+                            yf[lane] = ys[src: src + 8]
+                            for pw in range(2):
+                                kh, kw, co = ph + 2 * ta, pw + 2 * tb, j * 16 + hi * 8
+                                bw[pw, lane] = wd[li, kh, kw, co: co + 8]
+                        for pw in range(2):
+                            mfma_32x32x16(bw[pw], yf, acc[pw])
+                    for lane in range(64):
+                        li, hi = lane & 31, lane >> 5
+                        mine = (wave * 32 + li) * RED_LD
+                        for pw in range(2):
+                            for g in range(4):
+                                red[mine + pw * 32 + 8 * g + 4 * hi: mine + pw * 32 + 8 * g + 4 * hi + 4] = acc[pw, lane, 4 * g: 4 * g + 4]
+                h2 = h20 + tr
+                for t in range(512):
+                    for q in range(2):
+                        idx = t + q * 512
+                        rph, cell, cq = idx >> 9, (idx >> 4) & 31, idx & 15
+                        s = sum(red[((2 * t4 + rph) * 32 + cell) * RED_LD + cq * 4: ((2 * t4 + rph) * 32 + cell) * RED_LD + cq * 4 + 4]
+                                for t4 in range(4))
+                        h, w = 2 * h2 + rph, 2 * cell + (cq >> 3)
+                        if h < H and w < H:
+                            c0 = (cq & 7) * 4
+                            if mask is not None:
+                                s = np.where(mask[img, h, w, c0: c0 + 4] > 0, s, 0.0)
+                            dx[img, h, w, c0: c0 + 4] = s
+    return dx
+
+
+def test_conv2_data_gradient_strip_maps():
+    rng = np.random.default_rng(2)
+    dy = rng.integers(-3, 4, (1, 30, 30, 64)).astype(np.float64)
+    w = rng.integers(-2, 3, (64, 32, 4, 4)).astype(np.float64)  # OIHW
+    wd = np.ascontiguousarray(w.transpose(1, 2, 3, 0))          # [ci][kh][kw][co]
+    mask = rng.integers(-1, 2, (1, 63, 63, 32)).astype(np.float64)
+    strips = (0, 9, 14, 15)  # top border, interior, the rows that read dY rows 28 / 29 / outside, the half-empty last cell row
+    dx = conv2_dgrad_strip_model(dy, wd, mask, strips=strips)
+    ref = np.zeros((63, 63, 32))
+    for kh in range(4):
+        for kw in range(4):
+            ref[kh: kh + 59: 2, kw: kw + 59: 2] += np.einsum("hwn,nc->hwc", dy[0], w[:, :, kh, kw])
+    ref = np.where(mask[0] > 0, ref, 0.0)
+    for s in strips:
+        rows = slice(4 * s, min(4 * s + 4, 63))
+        assert np.array_equal(dx[0, rows], ref[rows]), s
+    assert np.isnan(dx[0, 4]).all()
+    # bank pattern of the fragment reads: 16 consecutive cells, any tap / chunk -> every bank once
+    for base in range(0, 3 * 33 - 17):
+        for chunk in range(8):
+            banks = []
+            for i in range(16):
+                pixidx = base + i
+                byte = pixidx * 128 + ((chunk ^ ((pixidx >> 1) & 7)) << 4)
+                banks += [((byte >> 2) + q) & 63 for q in range(4)]
+            assert sorted(banks) == list(range(64)), (base, chunk)

@@ -31,12 +31,12 @@ def test_site_roofline_picks_the_bound_that_takes_longer():
 
 def test_committed_traffic_lookup_matches_the_probed_kernels():
     import bench
-    for site in ("conv1_wgrad", "conv2_dgrad", "conv3_fwd", "conv3_dgrad", "fc_wgrad"):
+    for site in ("conv1_wgrad", "conv3_fwd", "conv3_dgrad", "fc_wgrad"):
         traffic, src = bench.hbm_traffic("c2", site)
         assert traffic and src.startswith("profiles/r0"), (site, traffic, src)
     # kernels that first appeared in round 3 (conv1 forward patch kernel, strip-resident weight gradients): only a counter pass that
     # ran them can describe them -- never an older file's entry for the kernel they replaced
-    for site in ("conv1_fwd", "conv2_fwd", "conv2_wgrad", "conv3_wgrad"):
+    for site in ("conv1_fwd", "conv2_fwd", "conv2_dgrad", "conv2_wgrad", "conv3_wgrad"):
         traffic, src = bench.hbm_traffic("c2", site)
         assert traffic is None or not src.startswith(("profiles/r02_", "profiles/r01_")), (site, traffic, src)
     assert bench.hbm_traffic("c3", "conv1_fwd") == (None, None)
