@@ -125,13 +125,14 @@ class PublishedWeights:
 class InferenceWorker:
     def __init__(self, config, actor_critic, rollouts: VERRolloutStorage, transport: EnvironmentTransport, device, obs_transforms=(),
                  num_inference_workers: int = 1, report=None, worker_idx: int = 0, iw_sync: Optional[InferenceWorkerSync] = None,
-                 queue: Optional[RequestQueue] = None, published: Optional[PublishedWeights] = None, stream=None):
+                 queue: Optional[RequestQueue] = None, published: Optional[PublishedWeights] = None, stream=None, decider=None):
         self.config, self.actor_critic, self.rollouts, self.transport = config, actor_critic, rollouts, transport
         self.worker_idx, self.num_inference_workers = worker_idx, num_inference_workers
         self.iw_sync = iw_sync if iw_sync is not None else InferenceWorkerSync(1)
         self.queue = queue if queue is not None else RequestQueue(transport)
         self.published = published   # None: this worker runs on the learner's own engine
         self.stream = stream         # None: the thread's current stream
+        self.decider = decider       # optional rl/ver/preemption_decider.PreemptionDecider: step-time reports out, rollout deadline in
         self.error: Optional[BaseException] = None
         self.device = torch.device(device)
         self.obs_transforms = list(obs_transforms)
@@ -273,6 +274,7 @@ class InferenceWorker:
                         self.iw_sync.should_start_next.wait(timeout=0.05)
                         continue
                     self.try_one_step()
+                    self.update_should_end_early()
                     if bool(self.rollouts.rollout_done):
                         self.finish_rollout()
         except threading.BrokenBarrierError:
@@ -305,7 +307,20 @@ class InferenceWorker:
                 self.iw_sync.replays_done.set()
             if self.report is not None:
                 self.report.policy_step(steps_finished, t1)
+            if self.decider is not None:
+                self.decider.policy_step(steps_finished, t1)
         return stepped
+
+    def update_should_end_early(self) -> None:
+        """inference_worker.py:533-555: past the deadline the preemption decider set for this rollout, the rollout is over with the
+        steps collected so far (variable experience only: a fixed-experience rollout needs every environment's full quota)."""
+        if self.decider is None or not self._variable_experience:
+            return
+        deadline = self.decider.rollout_ends.time
+        if deadline < 0.0 or deadline > time.perf_counter():
+            return
+        with self.iw_sync.lock:
+            self.rollouts.rollout_done[:] = True
 
 
 class InferenceWorkerPool:
@@ -334,6 +349,7 @@ class InferenceWorkerPool:
             iw = self.workers[0]
             while not bool(rollouts.rollout_done):
                 iw.try_one_step()
+                iw.update_should_end_early()
                 self.check()
             iw.finish_rollout()
         while not self.sync.rollout_done.wait(timeout=0.5):

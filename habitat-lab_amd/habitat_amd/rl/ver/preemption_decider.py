@@ -1,0 +1,174 @@
+"""Straggler preemption for VER (+ DD-PPO): when does a rollout stop early?  (habitat_baselines/rl/ver/preemption_decider.py:37-330)
+
+Given the learner time LT and Time(S), the time to collect S steps, the reference approximates argmax_S S / (Time(S) + LT): every
+environment's average step time (windowed over 5 rollouts) predicts when its 1st, 2nd, ... step of the next rollout arrives; the arrival
+times of all environments of all ranks are binned (5 ms), every bin edge is a candidate rollout length, candidates that would collect
+more than the step quota (in total, or per rank more than that rank can store) are dropped, and the candidate with the best
+steps / (length + LT + error) wins.  Its length becomes the wall-clock deadline of the next rollout on every rank
+(`RolloutEarlyEnds.time`): inference workers end the rollout when it passes (inference_worker.py:533-555).
+
+The reference runs this as a process per rank with its own gloo group; here it is a plain object owned by the trainer thread (the
+arithmetic is a few numpy operations per rollout), the collectives go through `torch.distributed` on the group handed in (or the
+default group).  `_compute_time` is checked against the reference's own function on the CPU (tests/test_host_logic.py)."""
+from __future__ import annotations
+
+import threading
+import time
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from habitat_amd.common.windowed_running_mean import WindowedRunningMean
+
+
+class RolloutEarlyEnds:
+    """worker_common.py:42-48: written by the decider, read by the inference workers (same process: plain attributes)."""
+
+    def __init__(self) -> None:
+        self.steps = -1.0
+        self.time = -1.0
+
+
+class PreemptionDecider:
+    def __init__(self, config, my_t_zero: float, world_rank: int = 0, world_size: int = 1, group=None, report=None):
+        hb = config.habitat_baselines
+        self.config = config
+        self.num_steps = int(hb.rl.ppo.num_steps)
+        self.num_envs = int(hb.num_environments)
+        self.overlap = bool(hb.rl.ver.overlap_rollouts_and_learn)
+        self.my_t_zero, self.world_rank, self.world_size, self.group, self.report = my_t_zero, world_rank, world_size, group, report
+        self.rollout_ends = RolloutEarlyEnds()
+        self.opt_rollout_time_avg = WindowedRunningMean(1)
+        self.preemption_error_time_avg = WindowedRunningMean(16)
+        self.learner_time_avg = WindowedRunningMean(5)
+        self.step_averages: List[WindowedRunningMean] = [WindowedRunningMean(5 * self.num_steps) for _ in range(self.num_envs)]
+        self.last_step_times = np.zeros((self.num_envs,), dtype=np.float64)
+        self.my_opt_rollout_steps = 0.0
+        self.start_time = 0.0
+        self.expected_steps_collected = 0
+        self.real_steps_collected = 0
+        self.n_rollouts_started = 0
+        self.started = False
+        self._bin_size = 5.0e-3
+        self._ver_extra_steps_scaling = 1.0
+        self._lock = threading.Lock()  # policy_step arrives from every inference-worker thread
+
+    # ---- collectives (:82-131) ------------------------------------------------------------------------------------------------
+    def _gather(self, arr: np.ndarray) -> Optional[np.ndarray]:
+        if self.world_size == 1:
+            return arr[np.newaxis]
+        all_arr = np.empty((self.world_size, *arr.shape), dtype=arr.dtype) if self.world_rank == 0 else None
+        torch.distributed.gather(torch.from_numpy(arr), gather_list=list(torch.from_numpy(all_arr).unbind(0)) if self.world_rank == 0 else None,
+                                 dst=0, group=self.group)
+        return all_arr
+
+    def _all_reduce(self, val: float, op=torch.distributed.ReduceOp.SUM) -> float:
+        if self.world_size == 1:
+            return val
+        t = torch.as_tensor(val, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=op, group=self.group)
+        return type(val)(t)
+
+    def _reduce_mean(self, val: float) -> float:
+        if self.world_size == 1:
+            return val
+        t = torch.as_tensor(val, dtype=torch.float64)
+        torch.distributed.reduce(t, dst=0, group=self.group)
+        t.div_(self.world_size)
+        return float(t)
+
+    def _bcast(self, vals: List[float]) -> List[float]:
+        if self.world_size == 1:
+            return vals
+        t = torch.as_tensor(vals, dtype=torch.float64)
+        torch.distributed.broadcast(t, 0, group=self.group)
+        return [float(v) for v in t]
+
+    # ---- the schedule (:133-222) -----------------------------------------------------------------------------------------------
+    def _compute_time(self, all_num_next_steps: np.ndarray, all_step_averages: np.ndarray, lt: float):
+        """all_num_next_steps (W, 1): steps each rank can store in its next rollout; all_step_averages (W, N): seconds per step of
+        every environment; lt: learner time.  Returns (rollout length in seconds, horizon in steps per environment)."""
+        max_possible_steps = (self.num_steps + 1) * (self._ver_extra_steps_scaling * np.max(all_step_averages) / np.min(all_step_averages))
+        # (W, N, T): when environment n of rank w delivers its t-th step
+        rollout_lengths = all_step_averages[..., np.newaxis] * np.arange(1, max_possible_steps + 1, dtype=np.float64)
+        candidate_lengths, counts = np.unique(np.ceil(rollout_lengths / self._bin_size) * self._bin_size, return_counts=True)
+        candidate_length_steps = np.cumsum(counts)
+        valids = candidate_length_steps <= self.num_steps * self.num_envs * self.world_size  # not more than the step quota in total
+        candidate_lengths, candidate_length_steps = candidate_lengths[valids], candidate_length_steps[valids]
+        valids = np.all(np.count_nonzero(rollout_lengths[..., np.newaxis] <= candidate_lengths, axis=(1, 2)) <= all_num_next_steps, 0)
+        candidate_lengths, candidate_length_steps = candidate_lengths[valids], candidate_length_steps[valids]
+        if candidate_lengths.size == 0:
+            # (not in the reference, whose argmax raises here and takes the decider process down) environments faster than the 5 ms
+            # bin deliver more than the step quota inside the first bin: no admissible deadline -> this rollout is not preempted
+            return -1.0, float(max_possible_steps)
+        err = max(float(self.preemption_error_time_avg.mean) if self.preemption_error_time_avg.count else 0.0, 0.0)
+        if not self.overlap:
+            total_time = candidate_lengths + lt + err
+        else:
+            total_time = candidate_lengths + err
+            if lt > np.max(total_time):
+                total_time = lt
+        candidate_sps = candidate_length_steps / total_time
+        best = int(np.argmax(candidate_sps))
+        target_length_time = candidate_lengths[best]
+        if np.any(rollout_lengths[..., -1] <= target_length_time):
+            self._ver_extra_steps_scaling *= 1.2  # the horizon was too short for the fastest environment: widen it next time
+        self.expected_steps_collected = int(candidate_length_steps[best])
+        return float(target_length_time), float(max_possible_steps)
+
+    def _ready(self) -> bool:
+        return (self.learner_time_avg.count == self.learner_time_avg.window_size
+                and self.opt_rollout_time_avg.count == self.opt_rollout_time_avg.window_size)
+
+    def update(self, num_next_steps: int) -> None:
+        all_num_next_steps = self._gather(np.array([num_next_steps], dtype=np.int64))
+        my_step_averages = np.array([v.mean if v.count else 0.0 for v in self.step_averages], dtype=np.float64)
+        all_step_averages = self._gather(my_step_averages)
+        lt = max(self._reduce_mean(float(self.learner_time_avg.mean) if self.learner_time_avg.count else 0.0), 0.01)
+        target_length_time, max_possible_steps = -1.0, 0.0
+        if self.world_rank == 0 and np.all(all_step_averages > 0):  # every environment has an estimate (else: keep collecting full quotas)
+            target_length_time, max_possible_steps = self._compute_time(all_num_next_steps, all_step_averages, lt)
+        target_length_time, max_possible_steps = self._bcast([float(target_length_time), float(max_possible_steps)])
+        if target_length_time > 0.0:
+            self.opt_rollout_time_avg += target_length_time
+            step_times = my_step_averages[:, np.newaxis] * np.arange(1, max_possible_steps + 1, dtype=np.float64)
+            self.my_opt_rollout_steps = float(np.count_nonzero(step_times <= self.opt_rollout_time_avg.mean))
+        self.rollout_ends.steps = float(self.my_opt_rollout_steps) if self._ready() else -1.0
+
+    # ---- events (:286-329) ---------------------------------------------------------------------------------------------------------
+    def policy_step(self, steps_finished, t_stamp: float) -> None:
+        """An inference batch has been written: (step index, environment) pairs and the time stamp of the batch."""
+        with self._lock:
+            for _, env_idx in steps_finished:
+                if self.last_step_times[env_idx] > 0:
+                    self.step_averages[env_idx] += t_stamp - self.last_step_times[env_idx]
+                self.last_step_times[env_idx] = t_stamp
+            self.real_steps_collected += len(steps_finished)
+
+    def start_rollout(self, start_time: Optional[float] = None) -> None:
+        start_time = time.perf_counter() if start_time is None else start_time
+        self.start_time = self._all_reduce(start_time - self.my_t_zero, op=torch.distributed.ReduceOp.MIN)
+        self.n_rollouts_started += 1
+        self.last_step_times[:] = -1.0
+        self.started = True
+        self.rollout_ends.time = self.my_t_zero + self.start_time + self.opt_rollout_time_avg.mean if self._ready() else -1.0
+
+    def end_rollout(self, num_next_steps: int, end_steps_time: Optional[float] = None) -> None:
+        end_steps_time = time.perf_counter() if end_steps_time is None else end_steps_time
+        end_steps_time = self._all_reduce(end_steps_time - self.my_t_zero, op=torch.distributed.ReduceOp.MAX)
+        if self.report is not None and hasattr(self.report, "preemption_decider"):
+            self.report.preemption_decider(dict(real_steps_collected=self.real_steps_collected,
+                                                expected_steps_collected=self.expected_steps_collected,
+                                                real_rollout_time=(end_steps_time - self.start_time) * 1e3,
+                                                expected_rollout_time=self.opt_rollout_time_avg.mean * 1e3))
+        if self.rollout_ends.time > 0:
+            self.preemption_error_time_avg += (end_steps_time - self.start_time) - self.opt_rollout_time_avg.mean
+        self.started = False
+        self.rollout_ends.time = -1.0
+        self.rollout_ends.steps = -1.0
+        self.update(num_next_steps)
+        self.real_steps_collected = 0
+
+    def learner_time(self, learner_time: float) -> None:
+        self.learner_time_avg += learner_time

@@ -14,9 +14,10 @@ the workers act with the parameters of the last COMPLETED policy version, which 
 Environment workers are the process-per-environment VectorEnv workers (shared-memory observation plane) or, for the synthetic
 benchmark source, the device-resident generator.
 
-Not implemented: the preemption decider (ver_trainer.py:224-233, preemption_decider.py): a rollout always collects its full step
-quota, so under VER + DD-PPO every rank waits at the barrier of `_update_agent` for the slowest rank's quota (no effect on results:
-every rank contributes the same number of steps either way)."""
+Straggler preemption (ver_trainer.py:224-233, rl/ver/preemption_decider.py): the schedule and the early-end mechanics are built and
+checked on the CPU (arithmetic against the reference's own function, the worker protocol with deadlines, the collectives at world size 2)
+but have not run on a multi-GPU node yet, so they are OFF unless HAB_VER_PREEMPTION=1: by default a rollout collects its full step
+quota, and under VER + DD-PPO every rank waits at the barrier of `_update_agent` for the slowest rank's quota (no effect on results)."""
 from __future__ import annotations
 
 import contextlib
@@ -40,6 +41,7 @@ from habitat_amd.rl.ppo.ppo_trainer import PPOTrainer
 from habitat_amd.rl.ppo.single_agent_access_mgr import EnvironmentSpec
 from habitat_amd.rl.ver.inference_worker import (InferenceWorker, InferenceWorkerPool, InferenceWorkerSync, PublishedWeights,
                                                  RequestQueue)
+from habitat_amd.rl.ver.preemption_decider import PreemptionDecider
 from habitat_amd.rl.ver.report_worker import ReportWorker
 from habitat_amd.rl.ver.transport import DeviceEnvTransport, VectorEnvTransport
 from habitat_amd.rl.ver.ver_rollout_storage import VERRolloutStorage
@@ -128,6 +130,13 @@ class VERTrainer(PPOTrainer):
         self._iw_sync = InferenceWorkerSync(n_iw)
         self._iw_queue = RequestQueue(self.transport)
         self._published = PublishedWeights(self._agent.actor_critic.engine) if (n_iw > 1 or overlap) else None
+        self._decider = None
+        if os.environ.get("HAB_VER_PREEMPTION") == "1" and self.ver_config.variable_experience:
+            world = torch.distributed.get_world_size() if self._is_distributed else 1
+            rank = torch.distributed.get_rank() if self._is_distributed else 0
+            # host-side numpy arrays travel: a gloo group next to the RCCL one (the reference's decider opens its own, :331-334)
+            group = torch.distributed.new_group(backend="gloo") if world > 1 else None
+            self._decider = PreemptionDecider(self.config, self._my_t_zero, rank, world, group=group, report=self.report_worker)
         self.inference_workers = []
         for i in range(n_iw):
             own_thread = not (main_is_iw and i == 0)
@@ -137,7 +146,8 @@ class VERTrainer(PPOTrainer):
             self.inference_workers.append(InferenceWorker(self.config, pol, self._agent.rollouts, self.transport, self.device,
                                                           self.obs_transforms, num_inference_workers=n_iw, report=self.report_worker,
                                                           worker_idx=i, iw_sync=self._iw_sync, queue=self._iw_queue,
-                                                          published=self._published if own_thread else None, stream=stream))
+                                                          published=self._published if own_thread else None, stream=stream,
+                                                          decider=self._decider))
         self.inference_worker = self.inference_workers[0]
         if self._is_distributed:
             torch.distributed.barrier()
@@ -147,6 +157,8 @@ class VERTrainer(PPOTrainer):
         torch.cuda.current_stream().synchronize()  # first observations are in HBM before any worker stream reads them
         self.report_worker.start_collection()
         self._iw_pool = InferenceWorkerPool(self.inference_workers, self._iw_sync, self._iw_queue, main_is_iw)
+        if self._decider is not None and overlap:
+            self._decider.start_rollout()
         self._iw_pool.start()
         self.timer = Timing()
         self._learning_time = 0.0
@@ -197,6 +209,8 @@ class VERTrainer(PPOTrainer):
                 self._agent.rollouts.increment_policy_version()
         self._learning_time = (time.perf_counter() - t1) + t_returns
         self._agent.after_update()
+        if self._decider is not None:
+            self._decider.learner_time(self._learning_time)
         return losses
 
     def collect_rollout(self) -> int:
@@ -204,6 +218,8 @@ class VERTrainer(PPOTrainer):
         ro = self._agent.rollouts
         if self._main_is_iw:
             self._agent.eval()
+        if self._decider is not None and not self._overlap:
+            self._decider.start_rollout()
         with self.timer.avg_time("rollout"):
             self._iw_pool.collect(ro)
             ro.after_rollout()
@@ -211,11 +227,15 @@ class VERTrainer(PPOTrainer):
                 with self.timer.avg_time("overlap_transfers"):
                     self.learning_rollouts.copy(ro)
         n = int(ro.num_steps_collected[0])
+        if self._decider is not None:
+            self._decider.end_rollout(int(ro.num_steps_to_collect))
         self.report_worker.num_steps_collected(n)
         if self._overlap:  # ver_trainer.py:524-530: the workers go on with the next rollout while the learner works on this one
             with self.timer.avg_time("overlap_transfers"):
                 ro.after_update()
                 self._iw_pool.start_next(self.device)
+                if self._decider is not None:
+                    self._decider.start_rollout()
         return n
 
     def run_update_cycle(self) -> Dict[str, float]:

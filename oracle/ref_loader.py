@@ -307,6 +307,10 @@ def load_reference_ver():
     ns.worker_common = _load("habitat_baselines.rl.ver.worker_common", "rl/ver/worker_common.py")
     ns.inference_worker = _load("habitat_baselines.rl.ver.inference_worker", "rl/ver/inference_worker.py")
     ns.BatchedQueue = BatchedQueue
+    # the straggler-preemption schedule (its arithmetic is plain numpy; the process / rendezvous machinery around it is not used)
+    if "habitat_baselines.rl.ddppo.ddp_utils" not in sys.modules:
+        _mod("habitat_baselines.rl.ddppo.ddp_utils", init_distrib_slurm=lambda *a, **k: None, rank0_only=lambda: True)
+    ns.preemption_decider = _load("habitat_baselines.rl.ver.preemption_decider", "rl/ver/preemption_decider.py")
     return ns
 
 

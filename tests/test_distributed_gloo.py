@@ -147,3 +147,58 @@ def test_ddppo_host_logic_world2_gloo():
     assert a["steps"] == b["steps"] == 64 * 3
     assert torch.equal(a["win_count"], torch.full((3, 1), 3.0))
     assert a["early"] == b["early"] == (False, False, False, True)
+
+
+def _preemption_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "habitat-lab_amd")):
+        sys.path.insert(0, p)
+    import numpy as np
+    from habitat_amd.rl.ver.preemption_decider import PreemptionDecider
+    store = dist.TCPStore("127.0.0.1", port, world, rank == 0)
+    dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
+    group = dist.new_group(backend="gloo")  # what VERTrainer does next to the device group
+    N, T = 4, 8
+    cfg = types.SimpleNamespace(habitat_baselines=types.SimpleNamespace(
+        num_environments=N, rl=types.SimpleNamespace(ppo=types.SimpleNamespace(num_steps=T),
+                                                     ver=types.SimpleNamespace(overlap_rollouts_and_learn=False))))
+    d = PreemptionDecider(cfg, my_t_zero=0.0, world_rank=rank, world_size=world, group=group)
+    speed = np.array([0.010, 0.012, 0.011, 0.013]) * (1.0 if rank == 0 else 3.0)  # rank 1 is the straggler: 3x slower environments
+    now, deadlines = 1.0 + 0.001 * rank, []
+    for rollout in range(8):
+        d.start_rollout(now)
+        deadlines.append(d.rollout_ends.time)
+        next_t = now + speed
+        for _ in range(N * T):
+            e = int(np.argmin(next_t))
+            d.policy_step([(0, e)], float(next_t[e]))
+            next_t[e] += speed[e]
+        now = float(next_t.min())
+        d.end_rollout(N * T, now)
+        d.learner_time(0.05)
+        now += 0.05
+    q.put((rank, dict(deadlines=deadlines, opt_time=d.opt_rollout_time_avg.mean, my_steps=d.my_opt_rollout_steps,
+                      start_time=d.start_time)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ver_preemption_decider_world2_gloo():
+    """rl/ver/preemption_decider.py at world size 2 (its gather / reduce / broadcast on a gloo group): both ranks arrive at the SAME
+    rollout length, the deadline (common start + length) is identical on both, and within it the rank with 3x slower environments is
+    scheduled for about a third of the steps of the fast rank -- it is the one the deadline cuts off."""
+    world, port = 2, find_free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_preemption_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    assert a["opt_time"] == b["opt_time"] and a["opt_time"] > 0
+    assert a["start_time"] == b["start_time"]                      # MIN over ranks of the rollout starts
+    active = [i for i, t in enumerate(a["deadlines"]) if t > 0]
+    assert len(active) >= 2 and all(a["deadlines"][i] == b["deadlines"][i] for i in range(len(a["deadlines"])))
+    assert a["my_steps"] > 2.5 * b["my_steps"] > 0, (a["my_steps"], b["my_steps"])

@@ -780,3 +780,68 @@ def test_resnet_policy_pointgoal_and_proximity_sensors_identical_to_live_referen
     ref = ns.resnet_policy.PointNavResNetPolicy(mk(ns.spaces, {}), ns.spaces.Discrete(4), hidden_size=64, backbone="resnet18").state_dict()
     assert list(mine.keys()) == list(ref.keys())
     assert all(mine[k].shape == ref[k].shape and torch.equal(mine[k], ref[k]) for k in ref)
+
+
+def test_ver_preemption_schedule_identical_to_live_reference():
+    """rl/ver/preemption_decider.py: the straggler-preemption schedule (candidate rollout lengths from the environments' step-time
+    estimates, argmax of steps / (length + learner time + error), the horizon scaling, the windows that gate it) against the
+    reference's own PreemptionDeciderProcess fed the same event sequence -- policy steps with uneven environment speeds, rollout starts /
+    ends, learner times -- for both the sequential and the overlapped arrangement (world size 1: the collectives are identities)."""
+    import types
+    from oracle.ref_loader import load_reference_ver, reference_available
+    if not reference_available():
+        pytest.skip("/root/reference not present")
+    ns = load_reference_ver()
+    from habitat_amd.rl.ver.preemption_decider import PreemptionDecider
+    for overlap in (False, True):
+        N, T = 6, 8
+        cfg = types.SimpleNamespace(habitat_baselines=types.SimpleNamespace(
+            num_environments=N, rl=types.SimpleNamespace(ppo=types.SimpleNamespace(num_steps=T),
+                                                         ver=types.SimpleNamespace(overlap_rollouts_and_learn=overlap))))
+        mine = PreemptionDecider(cfg, my_t_zero=100.0)
+        ref = object.__new__(ns.preemption_decider.PreemptionDeciderProcess)
+        RW = ns.windowed_running_mean.WindowedRunningMean
+        ref.config, ref.world_size, ref.world_rank, ref.my_t_zero = cfg, 1, 0, 100.0
+        ref.rollout_ends = types.SimpleNamespace(steps=types.SimpleNamespace(value=-1.0), time=types.SimpleNamespace(value=-1.0))
+        ref.queues = types.SimpleNamespace(report=types.SimpleNamespace(put=lambda *_a, **_k: None))
+        ref.opt_rollout_time_avg, ref.preemption_error_time_avg, ref.learner_time_avg = RW(1), RW(16), RW(5)
+        ref.my_opt_rollout_steps, ref.start_time, ref.expected_steps_collected = 0.0, 0.0, 0
+        ref._bin_size, ref._ver_extra_steps_scaling, ref.real_steps_collected, ref.n_rollouts_started = 5.0e-3, 1.0, 0, 0
+        ref.step_averages = [RW(5 * T) for _ in range(N)]
+        ref.last_step_times = np.zeros((N,), dtype=np.float64)
+        ref.started = False
+        rng = np.random.default_rng(7)
+        speed = np.array([0.004, 0.005, 0.008, 0.004, 0.010, 0.012])  # seconds per step and environment (every one gets >= 2 steps per rollout)
+        now = 100.0
+        active = 0
+        for rollout in range(9):
+            mine.start_rollout(now)
+            ref.start_rollout(now)
+            assert mine.rollout_ends.time == pytest.approx(ref.rollout_ends.time.value, abs=1e-12), (overlap, rollout)
+            active += mine.rollout_ends.time > 0
+            next_t = now + speed * (1 + 0.1 * rng.random(N))
+            collected, step_of = 0, np.zeros(N, int)
+            while collected < N * T:
+                e = int(np.argmin(next_t))
+                t_stamp = float(next_t[e])
+                batch = [(int(step_of[e]), e)]
+                mine.policy_step(batch, t_stamp)
+                ref.policy_step(dict(steps_finished=batch, t_stamp=t_stamp))
+                step_of[e] += 1
+                collected += 1
+                next_t[e] += speed[e] * (1 + 0.1 * rng.random())
+            now = float(next_t.min())
+            mine.end_rollout(N * T, now)
+            ref.end_rollout(now, N * T)
+            lt = 0.03 + 0.002 * rollout
+            mine.learner_time(lt)
+            ref.learner_time(lt)
+            now += lt
+            assert mine.rollout_ends.steps == ref.rollout_ends.steps.value
+            assert mine.expected_steps_collected == ref.expected_steps_collected
+            assert mine._ver_extra_steps_scaling == ref._ver_extra_steps_scaling
+            assert mine.opt_rollout_time_avg.mean == pytest.approx(float(ref.opt_rollout_time_avg), abs=1e-12)
+            assert mine.preemption_error_time_avg.mean == pytest.approx(float(ref.preemption_error_time_avg), abs=1e-12)
+        assert active >= 3, "the schedule never became active"
+        # the deadline cuts the slow environments off: fewer steps than the quota are expected once it is active
+        assert 0 < mine.expected_steps_collected <= N * T

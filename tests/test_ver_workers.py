@@ -102,15 +102,21 @@ class ClockPolicy:
                                 values=e * 1000.0 + t + w * 1e6, action_log_probs=-(t + 1.0))
 
 
-def make_config(train_encoder=True):
-    return types.SimpleNamespace(habitat_baselines=types.SimpleNamespace(rl=types.SimpleNamespace(ddppo=types.SimpleNamespace(train_encoder=train_encoder))))
+def make_config(train_encoder=True, n_envs=1, n_steps=1, overlap=False):
+    return types.SimpleNamespace(habitat_baselines=types.SimpleNamespace(
+        num_environments=n_envs,
+        rl=types.SimpleNamespace(ddppo=types.SimpleNamespace(train_encoder=train_encoder), ppo=types.SimpleNamespace(num_steps=n_steps),
+                                 ver=types.SimpleNamespace(overlap_rollouts_and_learn=overlap))))
 
 
 class Harness:
     """What VERTrainer does around the pool, minus the device-only pieces (returns / importance weights / the PPO update)."""
 
-    def __init__(self, n_envs, n_steps, n_workers, overlap, speeds, seed=0, variable_experience=True):
+    def __init__(self, n_envs, n_steps, n_workers, overlap, speeds, seed=0, variable_experience=True, preemption=False):
         self.N, self.T, self.overlap = n_envs, n_steps, overlap
+        from habitat_amd.rl.ver.preemption_decider import PreemptionDecider
+        cfg = make_config(n_envs=n_envs, n_steps=n_steps, overlap=overlap)
+        self.decider = PreemptionDecider(cfg, time.perf_counter()) if preemption else None
         osp = S.Dict({"x": S.Box(-1e9, 1e9, (2,), np.float32)})
         self.learner_policy = ClockPolicy()
         mk = lambda: VERRolloutStorage(n_steps, n_envs, osp, S.Discrete(4), self.learner_policy, variable_experience, device="cpu")
@@ -126,9 +132,11 @@ class Harness:
             pol = ClockPolicy() if own else self.learner_policy
             self.workers.append(InferenceWorker(make_config(), pol, self.ro, self.envs, "cpu", (), num_inference_workers=n_workers,
                                                 worker_idx=i, iw_sync=self.sync, queue=self.queue,
-                                                published=self.published if own else None))
+                                                published=self.published if own else None, decider=self.decider))
         self.pool = InferenceWorkerPool(self.workers, self.sync, self.queue, main_is_iw)
         self.queue.put_many(self.envs.start_experience_collection())
+        if self.decider is not None and overlap:
+            self.decider.start_rollout()
         self.pool.start()
 
     def after_rollout(self):  # VERRolloutStorage.after_rollout without the importance-weight kernel
@@ -138,13 +146,23 @@ class Harness:
 
     def cycle(self, learn):
         """One iteration of VERTrainer.train's loop; `learn(storage)` stands for compute_returns + update."""
+        if self.decider is not None and not self.overlap:
+            self.decider.start_rollout()
         self.pool.collect(self.ro)
         self.after_rollout()
         if self.overlap:
             self.learning.copy(self.ro)
+        if self.decider is not None:
+            self.decider.end_rollout(int(self.ro.num_steps_to_collect))
+        if self.overlap:
             self.ro.after_update()
             self.pool.start_next()
+            if self.decider is not None:
+                self.decider.start_rollout()
+        t_learn = time.perf_counter()
         out = learn(self.learning)
+        if self.decider is not None:
+            self.decider.learner_time(time.perf_counter() - t_learn)
         self.learner_policy.engine.params_flat += 1.0  # "the update"
         if self.published is not None:
             self.published.publish(self.learner_policy.engine)
@@ -264,5 +282,67 @@ def test_a_failing_worker_surfaces_in_the_trainer_thread():
         with pytest.raises(RuntimeError, match="inference worker"):
             for _ in range(3):
                 h.cycle(lambda st: None)
+    finally:
+        h.pool.shutdown()
+
+
+class DeadlineDecider:
+    """The deadline side of rl/ver/preemption_decider.py with a scripted schedule: from the third rollout on, every rollout must end
+    `budget` seconds after it started (the real schedule's arithmetic is checked against the reference in tests/test_host_logic.py; on one
+    rank with variable experience it never cuts a rollout short by itself -- fast environments fill the quota -- so the early-end
+    mechanics are driven directly here)."""
+
+    def __init__(self, budget):
+        from habitat_amd.rl.ver.preemption_decider import RolloutEarlyEnds
+        self.rollout_ends, self.budget, self.n, self.steps_seen = RolloutEarlyEnds(), budget, 0, 0
+        self._lock = threading.Lock()
+
+    def policy_step(self, steps_finished, t_stamp):
+        with self._lock:
+            self.steps_seen += len(steps_finished)
+
+    def start_rollout(self, start_time=None):
+        self.n += 1
+        self.rollout_ends.time = time.perf_counter() + self.budget if self.n >= 3 else -1.0
+
+    def end_rollout(self, num_next_steps, end_steps_time=None):
+        self.rollout_ends.time = -1.0
+
+    def learner_time(self, lt):
+        pass
+
+
+@pytest.mark.parametrize("n_workers,overlap", [(1, False), (3, False), (2, True)])
+def test_rollouts_that_end_at_the_preemption_deadline_lose_nothing(n_workers, overlap):
+    """inference_worker.py:533-555 (`update_should_end_early`): past the decider's deadline a rollout is over with the steps collected
+    so far.  Rollouts need ~16 ms here and get 5 ms from the third one on: they end with FEWER steps than the quota, and the protocol
+    still loses nothing -- every environment's steps reach the learner in order, a buffer never holds a step twice, the rollout after
+    an early end picks up exactly where it stopped (replay requests, in-flight actions, slot reuse)."""
+    N, T = 6, 6
+    speeds = [0.5, 0.4, 0.5, 0.45, 0.5, 0.25]  # ms^-1: 2 - 4 ms per step
+    h = Harness(N, T, n_workers, overlap, speeds, preemption=True)
+    h.decider = DeadlineDecider(0.005)
+    for iw in h.workers:
+        iw.decider = h.decider
+    if overlap:
+        h.decider.start_rollout()
+    try:
+        collected, seen_pairs = [], set()
+        for k in range(10):
+            def learn(st):
+                env = st.buffers["environment_ids"].view(-1).numpy().copy()
+                t = st.buffers["observations"]["x"].numpy()[:, 1].astype(np.int64)
+                return int(st.num_steps_collected[0]), {(int(a), int(b)) for a, b in zip(env, t)}
+            n, pairs = h.cycle(learn)
+            collected.append(n)
+            assert len(pairs) == (T + 1) * N, k  # a buffer never holds a step twice
+            seen_pairs |= pairs
+        quota = N * T
+        assert collected[0] == (T + 1) * N and all(c <= quota for c in collected[1:])
+        assert sum(c < quota for c in collected[3:]) >= 3, collected  # the deadline cut rollouts short ...
+        assert h.decider.steps_seen > 0
+        for e in range(N):                                  # ... and no step of any environment went missing
+            te = sorted(b for a, b in seen_pairs if a == e)
+            assert te == list(range(len(te))), (e, te)
     finally:
         h.pool.shutdown()
