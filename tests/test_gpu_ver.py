@@ -293,3 +293,39 @@ def test_ver_overlapped_run_hands_the_learner_the_same_rollouts_as_the_sequentia
             else:
                 assert torch.equal(a[key], b[key]), (k, key)
         assert torch.equal(a["is_coeffs"], b["is_coeffs"]), k
+
+
+def test_ver_trainer_with_the_preemption_decider_enabled(tmp_path, monkeypatch):
+    """HAB_VER_PREEMPTION=1 on one rank: the decider is fed by the workers' step reports, becomes ready after five learner times, sets
+    deadlines, and the trainer keeps producing finite updates with rollouts of at most the step quota (on one rank with variable
+    experience the optimum is normally the full quota: fast environments fill it)."""
+    from habitat_amd.config.default import get_config
+    from habitat_amd.common.baseline_registry import baseline_registry
+    import habitat_amd.rl.ver.ver_trainer  # noqa: F401
+    monkeypatch.setenv("HAB_VER_PREEMPTION", "1")
+    N, T, size = 4, 8, 64
+    ov = [f"habitat_baselines.num_environments={N}", f"habitat_baselines.rl.ppo.num_steps={T}", "habitat_baselines.num_updates=8",
+          "habitat_baselines.total_num_steps=-1", "habitat_baselines.num_checkpoints=-1", "habitat_baselines.checkpoint_interval=1000000",
+          "habitat_baselines.rl.ppo.hidden_size=64", f"habitat_baselines.checkpoint_folder={tmp_path}", "habitat_baselines.log_interval=100",
+          "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000",
+          "habitat_baselines.rl.policy.main_agent.name=PointNavBaselinePolicy", "habitat_baselines.rl.ver.num_inference_workers=2"]
+    for s in ("rgb", "depth"):
+        ov += [f"habitat.simulator.sensors.{s}.height={size}", f"habitat.simulator.sensors.{s}.width={size}"]
+    cfg = get_config("pointnav/ver_pointnav.yaml", ov)
+    cfg.habitat.simulator.sensors.pop("semantic", None)
+    cfg.habitat.synthetic["ver_speeds"] = [1.0, 0.8, 0.5, 0.9]
+    trainer = baseline_registry.get_trainer("ver")(cfg)
+    trainer._init_train()
+    d = trainer._decider
+    assert d is not None and all(iw.decider is d for iw in trainer.inference_workers)
+    steps = []
+    for u in range(8):
+        before = trainer.num_steps_done
+        losses = trainer.run_update_cycle()
+        assert all(np.isfinite(v) for v in losses.values()), losses
+        steps.append(trainer.num_steps_done - before)
+    assert steps[0] == (T + 1) * N and all(0 < s <= N * T for s in steps[1:]), steps
+    assert d.learner_time_avg.count == 5 and d.n_rollouts_started == 8 and d.real_steps_collected == 0
+    assert sum(v.count for v in d.step_averages) > 0  # the workers' step reports arrived
+    trainer.shutdown()
+    trainer.envs.close()
