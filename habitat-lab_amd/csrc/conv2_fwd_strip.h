@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(512) conv2_fwd_strip_kernel(const C2fArgs a) {
 inline int conv2_fwd_strip(const ConvFwdProb& p, float* /*ws*/, size_t /*ws_floats*/, hipStream_t stream) {
     const ConvGeom& g = p.g;
     if (!(g.KH == 4 && g.KW == 4 && g.stride == 2 && g.pad == 0 && g.C == 32 && g.Cout == 64 && g.H == 63 && g.W == 63)) return 1;
-    if (p.ypl || (p.ldy != 0 && p.ldy != 64) || g.B < 16) return 1;
+    if ((p.ldy != 0 && p.ldy != 64) || g.B < 16) return 1;
     if ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.w) | reinterpret_cast<uintptr_t>(p.y) | reinterpret_cast<uintptr_t>(p.bias)) & 15) return 1;
     constexpr int R = 2;
     using Cfg = C2fCfg<R>;

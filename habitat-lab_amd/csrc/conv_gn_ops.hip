@@ -1,0 +1,42 @@
+// conv_gn_ops.hip -- launchers / C ABI of the fused convolution + GroupNorm kernel of the small-batch ResNet passes (conv_gn_slab.h).
+#include "conv_gn_slab.h"
+#include "resnet_ops.h"
+#include "../../include/habitat_amd.h"
+
+namespace hab {
+
+int conv_gn_fused_ok(int C, int Cout, int H, int W, int KH, int KW, int stride, int pad, int groups) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    return Ho > 0 && Wo > 0 && conv_gn_slab_shape(C, Cout, Ho * Wo, groups);
+}
+
+int weight_planes(const float* w, long long n, unsigned short* planes, hipStream_t s) { return split_weight_planes(w, n, planes, s); }
+
+int conv_gn_fused(const ConvGnArgs& q, hipStream_t s) {
+    CgsArgs a{};
+    a.x = q.x; a.wp = q.w_planes; a.gamma = q.gamma; a.beta = q.beta; a.residual = q.residual; a.y = q.y;
+    a.raw = q.raw; a.mean = q.mean; a.rstd = q.rstd;
+    a.B = q.B; a.H = q.H; a.W = q.W; a.C = q.C; a.Cout = q.Cout; a.KH = q.KH; a.KW = q.KW; a.stride = q.stride; a.pad = q.pad;
+    a.groups = q.groups; a.relu = q.relu; a.eps = q.eps;
+    return conv_gn_slab(a, s);
+}
+
+}  // namespace hab
+
+using namespace hab;
+
+extern "C" int hab_split_weight_planes(const float* w_fwd, int64_t n, uint16_t* planes, hipStream_t stream) {
+    return weight_planes(w_fwd, n, planes, stream);
+}
+
+extern "C" int hab_conv_gn_fwd(const float* x, const uint16_t* w_planes, const float* gamma, const float* beta, const float* residual,
+                               float* y, float* raw, float* mean, float* rstd, int B, int H, int W, int C, int Cout, int KH, int KW,
+                               int stride, int pad, int groups, int relu, float eps, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return HAB_ERR_ARG;
+    ConvGnArgs q;
+    q.x = x; q.w_planes = w_planes; q.gamma = gamma; q.beta = beta; q.residual = residual; q.y = y; q.raw = raw; q.mean = mean; q.rstd = rstd;
+    q.B = B; q.H = H; q.W = W; q.C = C; q.Cout = Cout; q.KH = KH; q.KW = KW; q.stride = stride; q.pad = pad; q.groups = groups;
+    q.relu = relu; q.eps = eps;
+    const int rc = conv_gn_fused(q, stream);
+    return rc == 1 ? HAB_ERR_UNSUPPORTED : rc;
+}

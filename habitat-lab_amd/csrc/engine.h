@@ -62,6 +62,7 @@ struct hab_policy {
     int last_tm = 0;  // the last evaluate ran the time-major form with this many chunks (0: packed form)
     // ResNet policy (engine_resnet.hip)
     struct ResNetPlan* rn = nullptr;
+    int save_acts = 1;                                  // 0 inside act / encode: no backward follows, the fused kernels skip the saved copies
     int training = 1;                                   // nn.Module.train()/eval(): RunningMeanAndVar updates only in training
     hab_allreduce_fn allreduce_cb = nullptr;            // optional in-place all-reduce of a small device buffer (DD-PPO RMV stats)
     void* allreduce_ctx = nullptr;

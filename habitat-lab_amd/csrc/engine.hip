@@ -330,7 +330,10 @@ extern "C" int hab_policy_encode(hab_policy* e, const hab_obs* obs, int n, float
     if (!e || !e->P || !obs || !out || n <= 0 || n > e->d.max_frames) return HAB_ERR_ARG;
     if (!e->rn) return HAB_ERR_UNSUPPORTED;  // the baseline net has no visual_features input (rl/ppo/policy.py:557-589)
     Probe pr(e, HAB_PROBE_ENC_FWD, stream);
-    return resnet_encode(e, obs, n, out, stream);
+    e->save_acts = 0;
+    const int rc = resnet_encode(e, obs, n, out, stream);
+    e->save_acts = 1;
+    return rc;
 }
 extern "C" int hab_policy_visual_feature_shape(const hab_policy* e, int* c, int* hf, int* wf) {
     if (!e || !c || !hf || !wf) return HAB_ERR_ARG;
@@ -349,7 +352,10 @@ extern "C" int hab_policy_act(hab_policy* e, const hab_obs* obs, const float* hi
     float* W = e->WK;
     const int H = e->d.hidden, L = e->L;
     const int Lh = e->d.rnn_type == HAB_RNN_LSTM ? 2 * L : L;
-    HAB_TRY(encoder_forward(e, obs, masks, nullptr, n, stream));
+    e->save_acts = 0;  // no backward follows an act: fused kernels skip the copies kept for it
+    const int enc_rc = encoder_forward(e, obs, masks, nullptr, n, stream);
+    e->save_acts = 1;
+    HAB_TRY(enc_rc);
     const float* x = W + e->w_rnnin;
     int ldx = e->rnn_ld;
     // The episode-start mask (h * masks, rnn_state_encoder.py:308-311) is applied to the state operand inside the step kernel and

@@ -24,6 +24,7 @@ struct RnConv {
     int groups = 0;
     int i_w = -1, i_gamma = -1, i_beta = -1;
     int64_t pk_f = -1, pk_d = -1;   // packed weights (pk_d < 0: no data gradient needed)
+    int64_t pk_p = -1;              // forward weights as three bf16 planes for the fused small-batch kernel (conv_gn_slab.h), or -1
     int64_t w_raw = -1, w_mean = -1, w_rstd = -1, w_out = -1;
     int cgroups = 1;             // ResNeXt: groups of the 3x3 convolution (weight parameter is (Cout, C / cgroups, 3, 3))
     int64_t out_floats() const { return (int64_t)cd.Ho() * cd.Wo() * cd.Cout; }
@@ -261,6 +262,8 @@ int build_resnet(hab_policy* e) {
         const int64_t n = (int64_t)c.cd.Cout * c.cd.KH * c.cd.KW * c.cd.C;
         c.pk_f = pk.take(n);
         if (need_d) c.pk_d = pk.take(n);
+        if (conv_gn_fused_ok(c.cd.C, c.cd.Cout, c.cd.H, c.cd.W, c.cd.KH, c.cd.KW, c.cd.stride, c.cd.pad, c.groups))
+            c.pk_p = pk.take((3 * n + 1) / 2);  // 3 planes x 2 bytes per weight
     };
     pack_conv(r->stem, false);
     for (auto& c : r->convs) pack_conv(c, true);
@@ -348,9 +351,14 @@ int resnet_repack(hab_policy* e, hipStream_t s) {
         return repack_conv(e->p(c.i_w), e->PK + c.pk_f, c.pk_d >= 0 ? e->PK + c.pk_d : nullptr, c.cd.Cout, cin_real, c.cd.KH, c.cd.KW,
                            c.cd.C, s);
     };
+    auto planes = [&](const RnConv& c) {
+        if (c.pk_p < 0) return (int)HAB_OK;
+        return weight_planes(e->PK + c.pk_f, (long long)c.cd.Cout * c.cd.KH * c.cd.KW * c.cd.C, reinterpret_cast<unsigned short*>(e->PK + c.pk_p), s);
+    };
     HAB_TRY(rp(r->stem, r->creal));
-    for (const auto& c : r->convs) HAB_TRY(rp(c, c.cd.C));
+    for (const auto& c : r->convs) { HAB_TRY(rp(c, c.cd.C)); HAB_TRY(planes(c)); }
     HAB_TRY(rp(r->comp, r->comp.cd.C));
+    HAB_TRY(planes(r->comp));
     HAB_TRY(repack_flatten(e->p(r->i_fcw), e->PK + r->pk_fc, H, r->comp_c, r->comp_hw, s));
     for (int l = 0; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_whh[l]), e->PK + e->pk_whht[l], e->G_ * H, H, s));
     return HAB_OK;
@@ -385,6 +393,18 @@ static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, cons
     float* W = e->WK;
     ConvDesc cd = c.cd;
     cd.B = B;
+    // small batches (the rollout's act, encode, small minibatches): convolution + GroupNorm in one launch (conv_gn_slab.h)
+    static const int cgs_max_b = hab_env_int("HAB_CGS_MAX_B", 256);
+    if (c.pk_p >= 0 && B <= cgs_max_b) {
+        ConvGnArgs q;
+        q.x = in; q.w_planes = reinterpret_cast<const unsigned short*>(e->PK + c.pk_p); q.gamma = e->p(c.i_gamma); q.beta = e->p(c.i_beta);
+        q.residual = residual; q.y = W + c.w_out;
+        if (e->save_acts) { q.raw = W + c.w_raw; q.mean = W + c.w_mean; q.rstd = W + c.w_rstd; }
+        q.B = B; q.H = cd.H; q.W = cd.W; q.C = cd.C; q.Cout = cd.Cout; q.KH = cd.KH; q.KW = cd.KW; q.stride = cd.stride; q.pad = cd.pad;
+        q.groups = c.groups; q.relu = relu; q.eps = 1e-5f;
+        const int rc = conv_gn_fused(q, s);
+        if (rc != 1) return rc;
+    }
     HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, W + c.w_raw, 0, W + e->w_ws, e->ws_floats, s));
     GnArgs g;
     g.x = W + c.w_raw; g.y = W + c.w_out; g.gamma = e->p(c.i_gamma); g.beta = e->p(c.i_beta); g.residual = residual;

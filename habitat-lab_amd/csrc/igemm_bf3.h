@@ -21,7 +21,7 @@
 // igemm.h unchanged (incl. the transposed-accumulator vector epilogue).
 #pragma once
 #include "igemm.h"
-#include "bf3_planes.h"
+#include "bf3_split.h"
 
 namespace hab {
 
@@ -29,7 +29,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BF3_BKP = IGEMM_BK + 8;  // bf16 elements per LDS row
 
-// the exact 3-term split (bf3_split2) lives in bf3_planes.h: producers that write the pl32 operand format use it too
+// the exact 3-term split (bf3_split2) lives in bf3_split.h
 // scalar form: the three bf16 bit patterns in the low 16 bits
 __device__ __forceinline__ void bf3_split(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
     unsigned w1, w2, w3;

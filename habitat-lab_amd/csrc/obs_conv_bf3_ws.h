@@ -258,7 +258,6 @@ __global__ void __launch_bounds__(512) obs_conv_bf3_ws_kernel(const ObsConvFwdPr
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                 if (erow.ok && n + 3 < p.N) {
                     if (p.y) *reinterpret_cast<f32x4*>(p.y + erow.base + n) = v;
-                    if (p.ypl) pl_store4(p.ypl, erow.base + n, v);
                 }
             }
         }

@@ -8,7 +8,7 @@
 // image: it reads the 4 TH + 4 = 20 input rows they need as whole rows (768 B of rgb + 1 KB of depth each: fully coalesced, each
 // byte fetched once per tile -- 1.25x over all tiles), converts every element ONCE, and keeps the patch in LDS as bf16 images:
 //      P0 [20][W][4]   (r, g, b, d0)   uint8 values are exact in bf16; d0 = rn16(depth)
-//      P1 [20][W], P2 [20][W]          the two residual terms of the exact depth split (bf3_planes.h)
+//      P1 [20][W], P2 [20][W]          the two residual terms of the exact depth split (bf3_split.h)
 // With k = (kw, c) inside a filter row, the A fragment of output pixel (ho, wo) and filter row kh is 64 CONTIGUOUS bytes of P0 at pixel
 // (4 ho + kh, 4 wo): no im2col image exists anywhere.  The weights (32 x 256, three bf16 planes, 1/255 folded into the rgb columns; 59 KB)
 // are LDS-resident for the life of the persistent workgroup.  The six partial products of the split scheme (igemm_bf3.h):
@@ -283,7 +283,6 @@ __global__ void __launch_bounds__(512) obs_conv_patch_kernel(const ObsConvFwdPro
                 v += *reinterpret_cast<const f32x4*>(biasL + n);
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                 if (p.y) *reinterpret_cast<f32x4*>(p.y + base + n) = v;
-                if (p.ypl) pl_store4(p.ypl, base + n, v);
             }
         }
     };

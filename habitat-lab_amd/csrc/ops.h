@@ -30,14 +30,6 @@ int linear_dgrad(const float* dy, int lddy, const float* w, int ldw, const float
 int linear_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int lddw, int Mrows, int Nout, int Kin,
                  int perm_c, int perm_hw, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
 int colsum(const float* a, int lda, int M, int N, float* out, int accumulate, float* ws, size_t ws_floats, hipStream_t stream);
-// pl_ops.hip -- pl32 operand planes (bf3_planes.h): conversion + the DMA-staged contractions that consume planes (igemm_pl.h)
-typedef unsigned short pl16;
-int split_planes(const float* x, long long rows, int cols, int ld, pl16* out, hipStream_t stream);
-int merge_planes(const pl16* in, long long n, float* out, hipStream_t stream);
-int conv_fwd_pl(const ConvDesc& d, const pl16* xpl, const pl16* wfpl, const float* bias, float* y, int ldy, pl16* ypl, int relu, float* ws,
-                size_t ws_floats, hipStream_t stream);
-int conv_dgrad_pl(const ConvDesc& d, const pl16* dypl, const pl16* wdpl, const float* mask, const pl16* maskpl, float* dx, pl16* dxpl,
-                  float* ws, size_t ws_floats, hipStream_t stream);
 int repack_conv(const float* w_oihw, float* wf, float* wd, int Cout, int Cin, int KH, int KW, int cpad, hipStream_t stream);
 int repack_flatten(const float* w, float* wp, int N, int C, int HW, hipStream_t stream);
 int transpose2d(const float* w, float* wt, int R, int C, hipStream_t stream);

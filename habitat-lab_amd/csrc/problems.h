@@ -21,7 +21,7 @@
 #include <math.h>
 
 #include "hab_common.h"
-#include "bf3_planes.h"
+#include "bf3_split.h"
 
 namespace hab {
 
@@ -33,32 +33,6 @@ HAB_HD f32x4 zero4() {
     return z;
 }
 HAB_HD f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-// pl32 operand format (bf3_planes.h): one element -> its three bf16 terms (software round-to-nearest-even; tails and the split-K
-// second pass only -- the vector epilogue uses pl_store4)
-HAB_HD void pl_store1(pl16* base, size_t idx, float x) {
-    pl16* dst = base + pl_index(idx, 0);
-    for (int p = 0; p < 3; ++p) {
-        unsigned bits;
-        __builtin_memcpy(&bits, &x, 4);
-        const unsigned r = (bits + 0x7fffu + ((bits >> 16) & 1u)) >> 16;
-        dst[p * 32] = (pl16)r;
-        const unsigned back = r << 16;
-        float t;
-        __builtin_memcpy(&t, &back, 4);
-        x -= t;
-    }
-}
-HAB_HD float pl_positive1(const pl16* base, size_t idx) {
-    const unsigned h = base[pl_index(idx, 0)];
-    return ((h & 0x8000u) == 0 && (h & 0x7fffu) != 0) ? 1.f : 0.f;
-}
-HAB_HD f32x4 pl_mask4(const pl16* base, size_t idx) {
-    bool pos[4];
-    pl_positive4(base, idx, pos);
-    f32x4 m;
-    m[0] = pos[0] ? 1.f : 0.f; m[1] = pos[1] ? 1.f : 0.f; m[2] = pos[2] ? 1.f : 0.f; m[3] = pos[3] ? 1.f : 0.f;
-    return m;
-}
 
 struct Raw4 { f32x4 v; int ok; };
 struct KKey { int k, ok; };  // plain reduction coordinate + in-range flag
@@ -139,7 +113,6 @@ HAB_HD f32x4 splat4(float x) { f32x4 z; z[0] = x; z[1] = x; z[2] = x; z[3] = x; 
             v += c.bias;                                                                                         \
             if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); } \
             if (y) *reinterpret_cast<f32x4*>(y + r.base + c.n) = v;                                              \
-            if (ypl) pl_store4(ypl, r.base + c.n, v);                                                            \
         } else if (c.tail) {                                                                                     \
             for (int e = 0; e < 4; ++e) {                                                                        \
                 const EpiCol ce = epi_col(c.n + e);                                                              \
@@ -159,10 +132,9 @@ struct ConvFwdProb {
     const float* x;
     const float* w;
     const float* bias;
-    float* y;           // fp32 NHWC output, or null when only the operand planes are wanted
+    float* y;           // fp32 NHWC output
     int relu;
-    pl16* ypl = nullptr;  // optional second output: the same values as pl32 operand planes (bf3_planes.h; needs N % 32 == 0, ldy == 0)
-    int ldy = 0;          // row stride of y in floats (0: N) -- a Linear layer is the 1x1 convolution of a 1x1 image (igemm_pl.h)
+    int ldy = 0;          // row stride of y in floats (0: N)
     HAB_HD const float* dma_a_origin() const { return x; }
     HAB_HD const float* dma_b_origin() const { return w; }
     HAB_NO_KCTX
@@ -256,7 +228,6 @@ struct ConvFwdProb {
         v += c.bias;
         if (relu) v = v > 0.f ? v : 0.f;
         if (y) y[r.base + c.n] = v;
-        if (ypl) pl_store1(ypl, r.base + c.n, v);
     }
     HAB_BIAS_RELU_VEC4
     HAB_GENERIC_STORE
@@ -346,9 +317,8 @@ struct ObsConvFwdProb {
     ObsView obs;
     const float* w;
     const float* bias;
-    float* y;             // fp32 NHWC output, or null when only the operand planes are wanted
+    float* y;             // fp32 NHWC output
     int relu;
-    pl16* ypl = nullptr;  // optional: the output as pl32 operand planes for the next layer (bf3_planes.h; N % 32 == 0)
     int quad;
     HAB_NO_KCTX
     struct ACtx { int srow, h0, w0; };
@@ -430,7 +400,6 @@ struct ObsConvFwdProb {
         v += c.bias;
         if (relu) v = v > 0.f ? v : 0.f;
         if (y) y[r.base + c.n] = v;
-        if (ypl) pl_store1(ypl, r.base + c.n, v);
     }
     HAB_BIAS_RELU_VEC4
     HAB_GENERIC_STORE
@@ -458,9 +427,7 @@ struct ConvDgradProb {
     const float* w;     // Wd packed [Cin][Kfull]
     const float* mask;  // same shape as dx, or null: dx *= (mask > 0)
     const float* add;   // same shape as dx, or null: dx += add   (applied before the mask)
-    float* dx;          // fp32 output, or null when only the operand planes are wanted
-    const pl16* maskpl = nullptr;  // the mask tensor as pl32 planes (bf3_planes.h): dx *= (plane 0 > 0); replaces `mask`
-    pl16* dxpl = nullptr;          // optional second output: dx as pl32 operand planes (N % 32 == 0)
+    float* dx;          // fp32 output
     HAB_HD const float* dma_a_origin() const { return dy; }
     HAB_HD const float* dma_b_origin() const { return w; }
     void set_class(int ph_, int pw_) {
@@ -584,7 +551,7 @@ struct ConvDgradProb {
         EpiAux a;
         const size_t i = (r.ok & c.ok) ? r.base + c.n : 0;
         a.add = add ? add[i] : 0.f;
-        a.mask = maskpl ? pl_positive1(maskpl, i) : (mask ? mask[i] : 1.f);
+        a.mask = mask ? mask[i] : 1.f;
         return a;
     }
     HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux& a, float v) const {
@@ -592,7 +559,6 @@ struct ConvDgradProb {
         v += a.add;
         if (!(a.mask > 0.f)) v = 0.f;
         if (dx) dx[r.base + c.n] = v;
-        if (dxpl) pl_store1(dxpl, r.base + c.n, v);
     }
     static constexpr bool EPI_VEC4 = true;
     struct EpiCol4 { int n, ok, tail; };
@@ -602,7 +568,7 @@ struct ConvDgradProb {
         EpiAux4 a;
         const size_t i = (r.ok & c.ok) ? r.base + c.n : 0;
         a.add = add ? ld4(add + i) : zero4();
-        a.mask = maskpl ? pl_mask4(maskpl, i) : (mask ? ld4(mask + i) : splat4(1.f));
+        a.mask = mask ? ld4(mask + i) : splat4(1.f);
         return a;
     }
     HAB_HD void epi_store4(const EpiRow& r, const EpiCol4& c, const EpiAux4& a, f32x4 v) const {
@@ -613,7 +579,6 @@ struct ConvDgradProb {
             for (int e = 0; e < 4; ++e)
                 if (!(a.mask[e] > 0.f)) v[e] = 0.f;
             if (dx) *reinterpret_cast<f32x4*>(dx + r.base + c.n) = v;
-            if (dxpl) pl_store4(dxpl, r.base + c.n, v);
         } else if (c.tail) {
             for (int e = 0; e < 4; ++e) {
                 const EpiCol ce = epi_col(c.n + e);
@@ -645,9 +610,7 @@ struct ConvDgradMergedProb {
     const float* w;     // Wd packed [Cin][Kfull = KH*KW*Cout]
     const float* mask;  // same shape as dx, or null: dx *= (mask > 0)
     const float* add;   // same shape as dx, or null: dx += add   (applied before the mask)
-    float* dx;          // fp32 output, or null when only the operand planes are wanted
-    const pl16* maskpl = nullptr;  // the mask tensor as pl32 planes (bf3_planes.h): dx *= (plane 0 > 0); replaces `mask`
-    pl16* dxpl = nullptr;          // optional second output: dx as pl32 operand planes (Cin % 32 == 0)
+    float* dx;          // fp32 output
     HAB_HD const float* dma_a_origin() const { return dy; }
     HAB_HD const float* dma_b_origin() const { return w; }
     static bool applicable(const ConvGeom& g) {
@@ -789,7 +752,7 @@ struct ConvDgradMergedProb {
         EpiAux a;
         const long long i = epi_ok(r, c) ? r.base + c.off : 0;
         a.add = add ? add[i] : 0.f;
-        a.mask = maskpl ? pl_positive1(maskpl, (size_t)i) : (mask ? mask[i] : 1.f);
+        a.mask = mask ? mask[i] : 1.f;
         return a;
     }
     HAB_HD void epi_store(const EpiRow& r, const EpiCol& c, const EpiAux& a, float v) const {
@@ -797,7 +760,6 @@ struct ConvDgradMergedProb {
         v += a.add;
         if (!(a.mask > 0.f)) v = 0.f;
         if (dx) dx[r.base + c.off] = v;
-        if (dxpl) pl_store1(dxpl, (size_t)(r.base + c.off), v);
     }
     static constexpr bool EPI_VEC4 = true;  // Cin % 8 == 0: a quad of columns is 4 channels of one (ph, pw) class
     using EpiCol4 = EpiCol;
@@ -807,7 +769,7 @@ struct ConvDgradMergedProb {
         EpiAux4 a;
         const long long i = epi_ok(r, c) ? r.base + c.off : 0;
         a.add = add ? ld4(add + i) : zero4();
-        a.mask = maskpl ? pl_mask4(maskpl, (size_t)i) : (mask ? ld4(mask + i) : splat4(1.f));
+        a.mask = mask ? ld4(mask + i) : splat4(1.f);
         return a;
     }
     HAB_HD void epi_store4(const EpiRow& r, const EpiCol4& c, const EpiAux4& a, f32x4 v) const {
@@ -817,7 +779,6 @@ struct ConvDgradMergedProb {
         for (int e = 0; e < 4; ++e)
             if (!(a.mask[e] > 0.f)) v[e] = 0.f;
         if (dx) *reinterpret_cast<f32x4*>(dx + r.base + c.off) = v;
-        if (dxpl) pl_store4(dxpl, (size_t)(r.base + c.off), v);
     }
     HAB_GENERIC_STORE
 };

@@ -66,6 +66,19 @@ int chan_moment(const float* x, long long npix, int cpad, int mode, const float*
 int rmv_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C, hipStream_t s,
                const float* n_dev = nullptr, float div = 1.f);
 int rmv_normalize(float* x, long long npix, int cpad, int C, const float* mean, const float* var, hipStream_t s);
+// conv_gn_ops.hip -- convolution (bias-free) + GroupNorm (+ residual, + ReLU) in one launch for the small-batch passes (conv_gn_slab.h)
+struct ConvGnArgs {
+    const float* x;                 // [B][H][W][C]
+    const unsigned short* w_planes; // forward-packed weight [Cout][KH*KW*C] as three bf16 planes (weight_planes)
+    const float* gamma; const float* beta; const float* residual;
+    float* y;
+    float* raw = nullptr; float* mean = nullptr; float* rstd = nullptr;  // kept for a backward pass when given
+    int B, H, W, C, Cout, KH, KW, stride, pad, groups, relu;
+    float eps;
+};
+int conv_gn_fused_ok(int C, int Cout, int H, int W, int KH, int KW, int stride, int pad, int groups);
+int weight_planes(const float* w, long long n, unsigned short* planes, hipStream_t s);
+int conv_gn_fused(const ConvGnArgs& a, hipStream_t s);  // 1: geometry not covered
 int groupnorm_forward(const GnArgs& a, hipStream_t s);
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s);
 int maxpool_forward(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t s);

@@ -70,10 +70,6 @@ SIGNATURES = {
     "hab_sample_actions": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
     "hab_set_matrix_path": (c_int, [c_int]),
     "hab_conv2d_fwd": (c_int, [vp, vp, vp, vp] + [c_int] * 10 + [vp, c_size_t, vp]),
-    "hab_pl_split": (c_int, [vp, c_int64, c_int, c_int, vp, vp]),
-    "hab_pl_merge": (c_int, [vp, c_int64, vp, vp]),
-    "hab_conv2d_fwd_pl": (c_int, [vp, vp, vp, vp, c_int, vp] + [c_int] * 10 + [vp, c_size_t, vp]),
-    "hab_conv2d_dgrad_pl": (c_int, [vp, vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
     "hab_obs_conv2d_fwd": (c_int, [vp, vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
     "hab_conv2d_dgrad": (c_int, [vp, vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
     "hab_conv2d_wgrad": (c_int, [vp, vp, vp, vp] + [c_int] * 9 + [vp, c_size_t, vp]),
@@ -91,6 +87,8 @@ SIGNATURES = {
     "hab_running_mean_var_normalize": (c_int, [vp, c_int64, c_int, c_int, vp, vp, vp]),
     "hab_groupnorm_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_float, vp, c_int64, vp]),
     "hab_groupnorm_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, c_int64, vp]),
+    "hab_split_weight_planes": (c_int, [vp, c_int64, vp, vp]),
+    "hab_conv_gn_fwd": (c_int, [vp] * 9 + [c_int] * 11 + [c_float, vp]),
     "hab_maxpool3x3s2_fwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
     "hab_maxpool3x3s2_bwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
     "hab_nav_embed_fwd": (c_int, [POINTER(EmbedSlot), c_int, vp, vp, vp, c_int, c_int, c_int, vp, vp]),

@@ -183,29 +183,6 @@ int hab_sample_actions(const float* probs, const float* exp_noise, int64_t* acti
  * ------------------------------------------------------------------------------------------- */
 int hab_set_matrix_path(int mode);
 
-/* -------------------------------------------------------------------------------------------
- * pl32 operand planes (csrc/bf3_planes.h, igemm_pl.h) -- the producer-side form of the split-bf16 matrix path.
- *   A tensor that is going to be a contraction operand (an NHWC activation with C % 32 == 0, a packed weight matrix with K % 32 == 0)
- *   is stored ONCE as its three bf16 terms: every group of 32 consecutive logical elements becomes 192 bytes
- *   [rn16(x) x 32 | rn16(x - p0) x 32 | (x - p0 - p1) x 32] (x = p0 + p1 + p2 exactly), and the consuming contraction copies the planes
- *   global -> LDS by `buffer_load_dwordx4 ... lds` with no register or VALU work.  Same six partial products, same order, same sign
- *   schedule and split-K plan as the consumer-side split (igemm_bf3.h): bit-identical results for one tile shape.
- *   Replaces the same op chains as hab_conv2d_fwd / hab_conv2d_dgrad / hab_linear_fwd / hab_linear_dgrad below
- *   (rl/models/simple_cnn.py:68-93,139-158 and their autograd): a Linear layer is the 1x1 convolution of a 1x1 image.
- *     hab_pl_split   fp32 [rows][cols] (row stride ld, cols % 32 == 0) -> planes of the compact logical array; planes: 3*rows*cols uint16
- *     hab_pl_merge   planes of n elements -> fp32 (exact)
- *     hab_conv2d_fwd_pl    x planes (NHWC, C % 32 == 0), w_fwd planes ([Cout][KH*KW*C]); outputs: fp32 y (row stride ldy floats, 0 = Cout;
- *                          may be null) and / or planes ypl (Cout % 32 == 0; may be null); bias, ReLU as hab_conv2d_fwd
- *     hab_conv2d_dgrad_pl  dy planes, w_dgrad planes ([C][KH*KW*Cout]); ReLU mask from fp32 `relu_mask` or from the planes of the
- *                          masking tensor `relu_mask_pl` (sign / zero of plane 0); outputs fp32 dx and / or planes dxpl (C % 32 == 0)
- * ------------------------------------------------------------------------------------------- */
-int hab_pl_split(const float* x, int64_t rows, int cols, int ld, uint16_t* planes, hipStream_t stream);
-int hab_pl_merge(const uint16_t* planes, int64_t n, float* out, hipStream_t stream);
-int hab_conv2d_fwd_pl(const uint16_t* xpl, const uint16_t* w_fwd_pl, const float* bias, float* y, int ldy, uint16_t* ypl, int B, int H, int W,
-                      int C, int Cout, int KH, int KW, int stride, int pad, int relu, float* ws, size_t ws_floats, hipStream_t stream);
-int hab_conv2d_dgrad_pl(const uint16_t* dypl, const uint16_t* w_dgrad_pl, const float* relu_mask, const uint16_t* relu_mask_pl, float* dx,
-                        uint16_t* dxpl, int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad, float* ws,
-                        size_t ws_floats, hipStream_t stream);
 int hab_conv2d_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int H, int W, int C, int Cout,
                    int KH, int KW, int stride, int pad, int relu, float* ws, size_t ws_floats, hipStream_t stream);
 int hab_obs_conv2d_fwd(const uint8_t* rgb, const float* depth, const int* rows, const float* w_fwd, const float* bias,
@@ -266,6 +243,22 @@ int hab_groupnorm_fwd(const float* x, float* y, const float* gamma, const float*
 int hab_groupnorm_bwd(const float* x, const float* dy, const float* relu_out, float* dx, float* dy_masked, const float* gamma,
                       const float* mean, const float* rstd, float* chan_sums, int B, int HW, int C, int groups, float* ws,
                       int64_t ws_floats, hipStream_t stream);
+/* Convolution (bias-free) + GroupNorm [+ residual] [+ ReLU] of one ResNet layer in ONE launch, for small batches: the rollout's
+ * 64-frame `act`, hab_policy_encode, small minibatches (csrc/conv_gn_slab.h).  Replaces nn.Conv2d -> nn.GroupNorm -> (+ identity) ->
+ * ReLU of BasicBlock / Bottleneck / downsample / compression (rl/ddppo/policy/resnet.py:19-34,51-69,129-152,207-219;
+ * resnet_policy.py:213-234) as PPOTrainer._compute_actions_and_step_envs reaches them once per environment step
+ * (rl/ppo/ppo_trainer.py:343-399).
+ *   hab_split_weight_planes: forward-packed weight w_fwd [Cout][KH*KW*C] (n = its element count, even) -> its exact three-term bf16
+ *       split as planes [3][n] uint16 (x = p0 + p1 + p2); done once per optimiser step, shared by every step of a rollout.
+ *   hab_conv_gn_fwd: x NHWC [B][H][W][C] (C % 16 == 0), w_planes from above; y [B][Ho*Wo][Cout]; residual (nullable) same shape as y;
+ *       raw / mean / rstd (nullable, mean and rstd together): convolution output before the normalisation and the statistics
+ *       [B][groups], kept for hab_groupnorm_bwd.  Covered: Ho*Wo <= 256, Cout % 32 == 0, group size Cout / groups in {4 .. 128}
+ *       (> 32 only for Ho*Wo <= 32); anything else returns HAB_ERR_UNSUPPORTED and the caller runs hab_conv2d_fwd + hab_groupnorm_fwd.
+ *   fp32 in / out, fp32-equivalent arithmetic (csrc/igemm_bf3.h), exact two-pass statistics; deterministic. */
+int hab_split_weight_planes(const float* w_fwd, int64_t n, uint16_t* planes, hipStream_t stream);
+int hab_conv_gn_fwd(const float* x, const uint16_t* w_planes, const float* gamma, const float* beta, const float* residual, float* y,
+                    float* raw, float* mean, float* rstd, int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad,
+                    int groups, int relu, float eps, hipStream_t stream);
 /* nn.MaxPool2d(3, stride 2, padding 1) (resnet.py:220); idx = window offset of the first maximum (1 byte per output). */
 int hab_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t stream);
 int hab_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t stream);

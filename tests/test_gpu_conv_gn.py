@@ -1,0 +1,126 @@
+"""Fused convolution + GroupNorm (+ residual, + ReLU) of the small-batch ResNet passes (csrc/conv_gn_slab.h) against a float64
+evaluation of the reference's op chain (nn.Conv2d(bias=False) -> nn.GroupNorm -> + identity -> ReLU; rl/ddppo/policy/resnet.py:51-69)
+and against the unfused kernels of this library."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from habitat_amd import _lib  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def L():
+    return _lib.lib()
+
+
+_KEEP = []
+
+
+def P(t):
+    if t is None:
+        return None
+    _KEEP.append(t)
+    if len(_KEEP) > 96:
+        del _KEEP[:48]
+    return C.c_void_p(t.data_ptr())
+
+
+S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+# (B, H, W, C, Cout, K, stride, pad, groups): ResNet18 / ResNet50 layers behind layer1 at 256^2 observations, the 1x1 downsample
+# and bottleneck convolutions, the compression layer (one group), odd geometries, frame counts that do not fill the last workgroup
+CASES = [
+    (64, 32, 32, 32, 64, 3, 2, 1, 16),    # layer2.0 conv0: 256 pixels per frame, groups of 4
+    (5, 32, 32, 32, 64, 1, 2, 0, 16),     # layer2.0 downsample (K = 32: most waves idle)
+    (9, 16, 16, 64, 64, 3, 1, 1, 16),     # layer2
+    (64, 16, 16, 64, 128, 3, 2, 1, 16),   # layer3.0 conv0
+    (33, 8, 8, 128, 128, 3, 1, 1, 16),    # layer3
+    (64, 8, 8, 128, 256, 3, 2, 1, 16),    # layer4.0 conv0: 16 pixels per frame, 2 frames per workgroup
+    (7, 4, 4, 256, 256, 3, 1, 1, 16),     # layer4, odd frame count
+    (64, 4, 4, 256, 128, 3, 1, 1, 1),     # compression: one group over all 128 channels
+    (6, 4, 4, 256, 1024, 1, 1, 0, 16),    # ResNet50 layer4 expansion: groups of 64
+    (6, 8, 8, 128, 512, 1, 1, 0, 16),     # ResNet50 layer3 expansion: groups of 32
+    (3, 15, 8, 64, 64, 3, 1, 1, 16),      # 120 pixels per frame (128-row tile, 8 idle rows)
+    (10, 5, 3, 48, 96, 3, 1, 1, 12),      # 15 pixels, 2 frames per tile, C not a power of two, groups of 8
+    (4, 2, 2, 256, 256, 3, 1, 1, 16),     # 4 pixels per frame: 8 frames per tile
+]
+
+
+def reference(x, w, gamma, beta, res, groups, s, p, relu):
+    raw = F.conv2d(x.double(), w.double(), None, stride=s, padding=p)
+    y = F.group_norm(raw, groups, gamma.double(), beta.double(), 1e-5)
+    B = x.shape[0]
+    rg = raw.reshape(B, groups, -1)
+    mean, var = rg.mean(-1), rg.var(-1, unbiased=False)
+    if res is not None:
+        y = y + res.double()
+    if relu:
+        y = y.clamp_min(0)
+    return raw.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1), mean, (var + 1e-5).rsqrt()
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("with_res,relu,save", [(True, 1, True), (False, 0, False)])
+def test_conv_gn_fused_vs_float64(L, case, with_res, relu, save):
+    B, H, W, Cc, Cout, K, s, p, groups = case
+    torch.manual_seed(B * 131 + Cout)
+    x = torch.randn(B, Cc, H, W) * torch.rand(B, Cc, H, W).pow(2) * 4
+    w = torch.randn(Cout, Cc, K, K) / np.sqrt(Cc * K * K)
+    gamma, beta = torch.rand(Cout) + 0.5, torch.randn(Cout) * 0.3
+    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    res = torch.randn(B, Cout, Ho, Wo) if with_res else None
+    raw64, y64, mean64, rstd64 = reference(x, w, gamma, beta, res, groups, s, p, relu)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wf = w.permute(0, 2, 3, 1).contiguous().cuda()
+    n = wf.numel()
+    planes = torch.zeros(3 * n, dtype=torch.int16, device="cuda")
+    _lib.check(L.hab_split_weight_planes(P(wf), n, P(planes), S()))
+    # the planes are the exact split: p0 + p1 + p2 == w
+    pl = planes.view(3, n).cpu().numpy().view(np.uint16).astype(np.uint32) << 16
+    back = pl.view(np.float32).astype(np.float64).sum(0)
+    assert np.array_equal(back.astype(np.float32), wf.cpu().numpy().reshape(-1))
+    resd = res.permute(0, 2, 3, 1).contiguous().cuda() if with_res else None
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda")
+    raw = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda") if save else None
+    mean = torch.full((B, groups), float("nan"), device="cuda") if save else None
+    rstd = torch.full((B, groups), float("nan"), device="cuda") if save else None
+    g, b = gamma.cuda(), beta.cuda()
+    _lib.check(L.hab_conv_gn_fwd(P(xd), P(planes), P(g), P(b), P(resd), P(y), P(raw), P(mean), P(rstd), B, H, W, Cc, Cout, K, K, s, p,
+                                 groups, relu, 1e-5, S()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    scale = y64.abs().max().item()
+    assert (y.double().cpu() - y64).abs().max().item() <= 2e-5 * scale
+    if save:
+        assert (raw.double().cpu() - raw64).abs().max().item() <= 3e-6 * raw64.abs().max().item()
+        assert (mean.double().cpu() - mean64).abs().max().item() <= 1e-5 * max(1.0, mean64.abs().max().item())
+        assert ((rstd.double().cpu() - rstd64).abs() / rstd64).max().item() <= 1e-5
+    # the unfused kernels of this library on the same inputs
+    ws = torch.zeros(1 << 22, device="cuda")
+    raw2 = torch.zeros(B, Ho, Wo, Cout, device="cuda")
+    y2 = torch.zeros(B, Ho, Wo, Cout, device="cuda")
+    m2, r2 = torch.zeros(B, groups, device="cuda"), torch.zeros(B, groups, device="cuda")
+    _lib.check(L.hab_conv2d_fwd(P(xd), P(wf), None, P(raw2), B, H, W, Cc, Cout, K, K, s, p, 0, P(ws), ws.numel(), S()))
+    _lib.check(L.hab_groupnorm_fwd(P(raw2), P(y2), P(g), P(b), P(resd), P(m2), P(r2), B, Ho * Wo, Cout, groups, relu, 1e-5, P(ws), ws.numel(), S()))
+    assert (y - y2).abs().max().item() <= 2e-5 * scale
+    # deterministic: a second launch gives the same bits
+    y3 = torch.zeros_like(y)
+    _lib.check(L.hab_conv_gn_fwd(P(xd), P(planes), P(g), P(b), P(resd), P(y3), None, None, None, B, H, W, Cc, Cout, K, K, s, p, groups,
+                                 relu, 1e-5, S()))
+    assert torch.equal(y, y3)
+
+
+def test_conv_gn_fused_refuses_uncovered_geometries(L):
+    x = torch.zeros(2, 32, 32, 32, device="cuda")
+    pl = torch.zeros(3 * 32 * 288, dtype=torch.int16, device="cuda")
+    g = torch.ones(32, device="cuda")
+    y = torch.zeros(2, 32, 32, 32, device="cuda")
+    # 1024 pixels per frame (ResNet layer1): not covered -> the caller runs the unfused pair
+    assert L.hab_conv_gn_fwd(P(x), P(pl), P(g), P(g), None, P(y), None, None, None, 2, 32, 32, 32, 32, 3, 3, 1, 1, 16, 1, 1e-5, S()) == -2
+    # mean without rstd
+    assert L.hab_conv_gn_fwd(P(x), P(pl), P(g), P(g), None, P(y), None, P(y), None, 2, 8, 8, 32, 32, 3, 3, 1, 1, 8, 1, 1e-5, S()) == -1

@@ -51,63 +51,8 @@ def conv_case(name, B, H, W, Cc, Cout, K, s, p, ws):
     print(f"{name:28s} wgrad {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s")
 
 
-def split(x2d):
-    rows, cols = x2d.shape
-    out = torch.empty(3 * rows * cols, dtype=torch.int16, device="cuda")
-    _lib.check(L.hab_pl_split(P(x2d), rows, cols, x2d.stride(0), P(out), S()))
-    return out
-
-
-def conv_case_pl(name, B, H, W, Cc, Cout, K, s, p, ws):
-    """the same layers on pl32 operand planes (igemm_pl.h): planes in, planes out (what the engine's plane path runs)"""
-    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
-    x = torch.randn(B, H, W, Cc, device="cuda").relu_()
-    wf = torch.randn(Cout, K, K, Cc, device="cuda") * 0.05
-    wd = torch.randn(Cc, K, K, Cout, device="cuda") * 0.05
-    b = torch.zeros(Cout, device="cuda")
-    dy = torch.randn(B, Ho, Wo, Cout, device="cuda")
-    xpl, wfpl, wdpl, dypl = split(x.view(-1, Cc)), split(wf.view(Cout, -1)), split(wd.view(Cc, -1)), split(dy.view(-1, Cout))
-    ypl = torch.empty(3 * B * Ho * Wo * Cout, dtype=torch.int16, device="cuda")
-    dxpl = torch.empty(3 * B * H * W * Cc, dtype=torch.int16, device="cuda")
-    y = torch.empty(B, Ho, Wo, Cout, device="cuda")
-    fl = 2.0 * B * Ho * Wo * Cout * K * K * Cc
-    t = timeit(lambda: _lib.check(L.hab_conv2d_fwd_pl(P(xpl), P(wfpl), P(b), None, 0, P(ypl), B, H, W, Cc, Cout, K, K, s, p, 1, P(ws), ws.numel(), S())))
-    print(f"{name:28s} fwd   {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s  PLANES in -> planes out")
-    t = timeit(lambda: _lib.check(L.hab_conv2d_fwd_pl(P(xpl), P(wfpl), P(b), P(y), 0, None, B, H, W, Cc, Cout, K, K, s, p, 1, P(ws), ws.numel(), S())))
-    print(f"{name:28s} fwd   {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s  PLANES in -> fp32 out")
-    t = timeit(lambda: _lib.check(L.hab_conv2d_dgrad_pl(P(dypl), P(wdpl), None, P(xpl), None, P(dxpl), B, H, W, Cc, Cout, K, K, s, p, P(ws), ws.numel(), S())))
-    print(f"{name:28s} dgrad {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s  PLANES in, mask from planes -> planes out")
-
-
-def main_pl(B):
-    ws = torch.empty(1 << 26, device="cuda")
-    conv_case_pl("simplecnn conv2 4x4s2 32>64", B, 63, 63, 32, 64, 4, 2, 0, ws)
-    conv_case_pl("simplecnn conv3 3x3s1 64>32", B, 30, 30, 64, 32, 3, 1, 0, ws)
-    conv_case_pl("resnet l1 3x3 32>32 @32", B, 32, 32, 32, 32, 3, 1, 1, ws)
-    conv_case_pl("resnet l2 3x3 64>64 @16", B, 16, 16, 64, 64, 3, 1, 1, ws)
-    conv_case_pl("resnet l3 3x3 128>128 @8", B, 8, 8, 128, 128, 3, 1, 1, ws)
-    conv_case_pl("resnet l4 3x3 256>256 @4", B, 4, 4, 256, 256, 3, 1, 1, ws)
-    M, N, K = B, 512, 25088
-    x = torch.randn(M, K, device="cuda")
-    w = torch.randn(N, K, device="cuda") * 0.01
-    yy = torch.empty(M, 516, device="cuda")
-    xpl, wpl, wtpl = split(x), split(w), split(w.t().contiguous())
-    fl = 2.0 * M * N * K
-    t = timeit(lambda: _lib.check(L.hab_conv2d_fwd_pl(P(xpl), P(wpl), None, P(yy), 516, None, M, 1, 1, K, N, 1, 1, 1, 0, 1, P(ws), ws.numel(), S())))
-    print(f"{'fc 25088>512':28s} fwd   {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s  PLANES in -> fp32 out")
-    dy = torch.randn(M, N, device="cuda")
-    dypl = split(dy)
-    dxpl = torch.empty(3 * M * K, dtype=torch.int16, device="cuda")
-    t = timeit(lambda: _lib.check(L.hab_conv2d_fwd_pl(P(dypl), P(wtpl), None, None, 0, P(dxpl), M, 1, 1, N, K, 1, 1, 1, 0, 0, P(ws), ws.numel(), S())))
-    print(f"{'fc 25088>512':28s} dgrad {t:8.3f} ms  {fl / t / 1e9:7.1f} TF/s  PLANES in -> planes out")
-    t = timeit(lambda: split(x))
-    print(f"{'split fp32 -> planes':28s}       {t:8.3f} ms  {M * K * 10 / t / 1e6:7.1f} GB/s (4 B read + 6 B written per element)")
-
-
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    if len(sys.argv) > 2 and sys.argv[2] == "pl":
-        return main_pl(B)
     ws = torch.empty(1 << 26, device="cuda")
     H = W = 256
     rgb = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device="cuda")
