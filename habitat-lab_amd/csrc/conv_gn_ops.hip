@@ -6,15 +6,14 @@
 namespace hab {
 
 int conv_gn_fused_ok(int C, int Cout, int H, int W, int KH, int KW, int stride, int pad, int groups) {
-    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    return Ho > 0 && Wo > 0 && conv_gn_slab_shape(C, Cout, Ho * Wo, groups);
+    return conv_gn_slab_covers(C, Cout, H, W, KH, KW, stride, pad, groups);
 }
 
-int weight_planes(const float* w, long long n, unsigned short* planes, hipStream_t s) { return split_weight_planes(w, n, planes, s); }
+int weight_planes(const float* w, int Cout, int K, unsigned short* planes, hipStream_t s) { return cgs_split_weights(w, Cout, K, planes, s); }
 
 int conv_gn_fused(const ConvGnArgs& q, hipStream_t s) {
     CgsArgs a{};
-    a.x = q.x; a.wp = q.w_planes; a.gamma = q.gamma; a.beta = q.beta; a.residual = q.residual; a.y = q.y;
+    a.x = q.x; a.wq = q.w_planes; a.gamma = q.gamma; a.beta = q.beta; a.residual = q.residual; a.y = q.y;
     a.raw = q.raw; a.mean = q.mean; a.rstd = q.rstd;
     a.B = q.B; a.H = q.H; a.W = q.W; a.C = q.C; a.Cout = q.Cout; a.KH = q.KH; a.KW = q.KW; a.stride = q.stride; a.pad = q.pad;
     a.groups = q.groups; a.relu = q.relu; a.eps = q.eps;
@@ -25,8 +24,8 @@ int conv_gn_fused(const ConvGnArgs& q, hipStream_t s) {
 
 using namespace hab;
 
-extern "C" int hab_split_weight_planes(const float* w_fwd, int64_t n, uint16_t* planes, hipStream_t stream) {
-    return weight_planes(w_fwd, n, planes, stream);
+extern "C" int hab_split_weight_planes(const float* w_fwd, int Cout, int K, uint16_t* planes, hipStream_t stream) {
+    return weight_planes(w_fwd, Cout, K, planes, stream);
 }
 
 extern "C" int hab_conv_gn_fwd(const float* x, const uint16_t* w_planes, const float* gamma, const float* beta, const float* residual,

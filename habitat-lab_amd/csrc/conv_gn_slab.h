@@ -12,14 +12,18 @@
 // Cout / G consecutive channels), so a workgroup that owns ALL pixels of its frames for a SLAB of output channels made of whole groups
 // can finish the layer alone:
 //   * workgroup = (frame group, channel slab of NT x 32 channels); Mt = WM x MT x 32 pixel rows = fpw whole frames;
-//   * 8 waves = WM pixel-tile groups x WK slices of the reduction (taps x input channels); a wave keeps its MT x NT 32 x 32 accumulators;
-//   * NO LDS and NO barrier in the main loop: a wave reads its MFMA fragments straight from global / L2 in fragment order --
-//     weights as three bf16 planes split ONCE per optimiser step (hab_split_weight_planes: the 129 steps of a rollout share them),
-//     16 bytes per plane and lane; activations as 32 contiguous bytes of one NHWC pixel per lane (8 channels of a tap), split in
-//     registers (exact 3-term split, igemm_bf3.h); D k-steps of loads are kept in flight in a register ring;
-//   * the WK partial tiles meet in LDS and are summed in wave order (deterministic); GroupNorm: exact two-pass statistics per
-//     (frame, group) by wave reductions over the folded tile, then y = (x - mean) * rstd * gamma + beta [+ residual] [ReLU] with one
-//     16-byte store per thread.  The pre-normalisation output / mean / rstd are written only when the caller keeps them for a backward.
+//   * the INPUT of those frames (<= 64 KB) is read once with whole-row 16-byte loads, split once (exact 3-term split, igemm_bf3.h) and
+//     kept in LDS as three bf16 planes [pixel][C + 8] (pitch C/2 + 4 dwords: the 16-byte fragment reads of 16 consecutive pixels hit
+//     all 64 banks); a filter tap is a row offset into that image, out-of-image taps read a zero row;
+//   * 8 waves = WM pixel-tile groups x WK slices of the reduction (taps x input channels); a wave keeps its MT x NT 32 x 32
+//     accumulators and runs its k-steps WITHOUT barriers: activations from LDS, weights from global / L2 in FRAGMENT ORDER -- three
+//     bf16 planes split once per optimiser step (hab_split_weight_planes; the 129 steps of a rollout share them), stored so that the
+//     64 lanes of an MFMA operand are 1 KB contiguous (the first version read [co][k] rows: 32 cache lines per load instruction, the
+//     L1's one-tag-per-cycle rate made 18-32 us kernels out of 3 us of MFMA work); D k-steps of weight loads stay in flight;
+//   * the WK partial tiles meet in LDS (over the dead input image) and are summed in wave order (deterministic); GroupNorm: exact
+//     two-pass statistics per (frame, group) by wave reductions over the folded tile, then y = (x - mean) * rstd * gamma + beta
+//     [+ residual] [ReLU], one 16-byte store per thread.  The pre-normalisation output / mean / rstd are written only when the caller
+//     keeps them for a backward pass.
 // Sign schedule as everywhere on the split path: every second workgroup accumulates the negated sum.
 #pragma once
 #include "bf3_split.h"
@@ -30,7 +34,7 @@ typedef __bf16 cgs_bf16x8 __attribute__((ext_vector_type(8)));
 
 struct CgsArgs {
     const float* x;            // [B][H][W][C] NHWC, C % 16 == 0
-    const unsigned short* wp;  // [3 planes][Cout][K] bf16, K = KH*KW*C in (kh, kw, ci) order (the forward packing, split)
+    const unsigned short* wq;  // fragment-ordered weight planes [3][Cout/32][K/16][64 lanes][8] bf16 (cgs_split_weights)
     const float* gamma; const float* beta;
     const float* residual;     // [B][Ho*Wo][Cout] or null, added before the ReLU
     float* y;                  // [B][Ho*Wo][Cout]
@@ -41,6 +45,9 @@ struct CgsArgs {
     int groups, gs;            // GroupNorm groups, channels per group
     int fpw;                   // frames per workgroup
     int nslab;                 // Cout / (NT * 32)
+    int sub;                   // 1x1 convolution: the LDS image holds the (strided) pixels the outputs read, row = output pixel
+    int prow;                  // pixel rows of the LDS image (the zero row is row `prow`)
+    int region0_bytes;         // max(input image, partial tiles)
     int relu, sign_schedule;
     float eps;
 };
@@ -50,7 +57,6 @@ struct CgsCfg {
     static constexpr int Mt = WM * MT * 32, Nt = NT * 32, NQ = Nt / 4, RED_LD = Nt + 4;
     static constexpr int NQUADS = Mt * NQ, QPT = (NQUADS + 511) / 512;
     static constexpr size_t RED_FLOATS = (size_t)WK * Mt * RED_LD, QS_FLOATS = (size_t)NQUADS;
-    __host__ __device__ static constexpr size_t lds_bytes(int npairs) { return (RED_FLOATS + QS_FLOATS + 2 * (size_t)npairs) * sizeof(float); }
     static_assert(WM * WK == 8, "eight waves");
 };
 
@@ -59,8 +65,9 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
     using Cfg = CgsCfg<MT, NT, WM, WK>;
     constexpr int Mt = Cfg::Mt, Nt = Cfg::Nt, NQ = Cfg::NQ, RED_LD = Cfg::RED_LD, QPT = Cfg::QPT;
     extern __shared__ __attribute__((aligned(16))) float cgs_sm[];
-    float* red = cgs_sm;                         // [WK][Mt][RED_LD]
-    float* qs = red + Cfg::RED_FLOATS;           // [Mt][NQ]
+    unsigned short* xs = reinterpret_cast<unsigned short*>(cgs_sm);   // [3][prow + 1][C + 8] bf16, then reused as
+    float* red = cgs_sm;                                               // [WK][Mt][RED_LD]
+    float* qs = reinterpret_cast<float*>(reinterpret_cast<char*>(cgs_sm) + a.region0_bytes);  // [Mt][NQ]
     float* mu_s = qs + Cfg::QS_FLOATS;           // [npairs]
     const int gpn = Nt / a.gs;                   // groups per slab
     const int npairs = a.fpw * gpn;
@@ -74,63 +81,110 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
     const int co0 = slab * Nt;
     const bool flip = a.sign_schedule && ((slab + fg) & 1);
     const unsigned sgn2 = flip ? 0x80008000u : 0u;
+    const int PITCH = a.C + 8;
+    const int plane = (a.prow + 1) * PITCH;  // bf16 elements per plane of the LDS image
+
+    // k-steps of this wave: an even cut of KS over the WK slices
+    const int s_begin = (int)(((long long)a.KS * wk) / WK), s_end = (int)(((long long)a.KS * (wk + 1)) / WK);
+
+    // ---- weight fragments: register ring of D k-steps, first loads in flight before the input image is staged ----
+    struct WStage { u32x4 w[NT][3]; };
+    WStage st[D];
+    const size_t wplane = (size_t)(a.Cout >> 5) * a.KS * 512;
+    const unsigned short* wbase = a.wq + (size_t)(slab * NT) * a.KS * 512 + lane * 8;
+    auto wload = [&](WStage& g, int s) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const unsigned short* p = wbase + ((size_t)j * a.KS + s) * 512;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) g.w[j][pl] = *reinterpret_cast<const u32x4*>(p + pl * wplane);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (s_begin + d < s_end) wload(st[d], s_begin + d);
+
+    // ---- stage the input image of this workgroup's frames: fp32 NHWC -> three bf16 planes in LDS ----
+    {
+        const int C4 = a.C >> 2, HW = a.H * a.W;
+        const int rows_per_frame = a.sub ? a.HoWo : HW;
+        const int units = a.prow * C4;
+        constexpr int UB = 4;  // loads in flight per thread
+        for (int u0 = t; u0 < units; u0 += 512 * UB) {
+            f32x4 v[UB];
+            int dsto[UB];
+#pragma unroll
+            for (int j = 0; j < UB; ++j) {
+                const int u = u0 + j * 512;
+                dsto[j] = -1;
+                v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (u < units) {
+                    const int row = u / C4, c4 = u - row * C4;
+                    const int fl = row / rows_per_frame, rem = row - fl * rows_per_frame;
+                    const int frame = fg * a.fpw + fl;
+                    dsto[j] = row * PITCH + c4 * 4;
+                    if (frame < a.B) {
+                        int pin = rem;
+                        if (a.sub) { const int ho = rem / a.Wo, wo = rem - ho * a.Wo; pin = ho * a.stride * a.W + wo * a.stride; }
+                        v[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)frame * HW + pin) * a.C + c4 * 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UB; ++j)
+                if (dsto[j] >= 0) {
+                    unsigned short* dst = xs + dsto[j];
+                    unsigned a1, a2, a3, b1, b2, b3;
+                    bf3_split2(v[j][0], v[j][1], a1, a2, a3);
+                    bf3_split2(v[j][2], v[j][3], b1, b2, b3);
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{a1, b1};
+                    *reinterpret_cast<u32x2*>(dst + plane) = u32x2{a2, b2};
+                    *reinterpret_cast<u32x2*>(dst + 2 * plane) = u32x2{a3, b3};
+                }
+        }
+        for (int e = t; e < 3 * PITCH; e += 512) {  // the zero row of every plane
+            const int pl = e / PITCH;
+            xs[(size_t)pl * plane + a.prow * PITCH + (e - pl * PITCH)] = 0;
+        }
+    }
 
     // ---- this lane's pixel rows (operand B of the swapped MFMA: n = pixel) ----
-    const float* xb[MT];
-    int h0[MT], w0[MT];
+    int rbase[MT], h0[MT], w0[MT];
     bool rv[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int pl = (wm * MT + i) * 32 + li;
         const int fl = pl / a.HoWo, pix = pl - fl * a.HoWo;
-        const int frame = fg * a.fpw + fl;
-        rv[i] = (fl < a.fpw) & (frame < a.B);
+        rv[i] = (fl < a.fpw) & (fg * a.fpw + fl < a.B);
         const int ho = pix / a.Wo, wo = pix - ho * a.Wo;
         h0[i] = ho * a.stride - a.pad;
         w0[i] = wo * a.stride - a.pad;
-        xb[i] = a.x + (size_t)(rv[i] ? frame : 0) * a.H * a.W * a.C + 8 * hi;
+        rbase[i] = a.sub ? pl : fl * a.H * a.W;
     }
-    // ---- this lane's weight rows (operand A: m = output channel), 8 reduction elements per k-step and plane ----
-    const unsigned short* wrow[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) wrow[j] = a.wp + (size_t)(co0 + j * 32 + li) * a.K + 8 * hi;
-    const size_t wplane = (size_t)a.Cout * a.K;
-
-    // k-steps of this wave: an even cut of KS over the WK slices
-    const int s_begin = (int)(((long long)a.KS * wk) / WK), s_end = (int)(((long long)a.KS * (wk + 1)) / WK);
-
-    struct Stage {
-        u32x4 w[NT][3];
-        f32x4 x[MT][2];
-        unsigned ok;
-    };
-    Stage st[D];
-    // position of the NEXT k-step to be loaded: tap (kh, kw) and first channel
-    int l_s = s_begin, l_c, l_kh, l_kw;
+    // position of the NEXT activation fragment to be read: tap (kh, kw) and first channel
+    int l_c, l_kh, l_kw;
     {
         const int kk = s_begin * 16, tap = kk / a.C;
         l_c = kk - tap * a.C;
         l_kh = tap / a.KW;
         l_kw = tap - l_kh * a.KW;
     }
-    auto load = [&](Stage& g) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const unsigned short* p = wrow[j] + (size_t)l_s * 16;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) g.w[j][pl] = *reinterpret_cast<const u32x4*>(p + pl * wplane);
-        }
-        g.ok = 0;
+    struct AFrag { cgs_bf16x8 p[MT][3]; };
+    auto aread = [&](AFrag& f) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int hin = h0[i] + l_kh, win = w0[i] + l_kw;
-            const bool ok = rv[i] & ((unsigned)hin < (unsigned)a.H) & ((unsigned)win < (unsigned)a.W);
-            const float* p = xb[i] + (ok ? ((size_t)hin * a.W + win) * a.C + l_c : 0);
-            g.x[i][0] = *reinterpret_cast<const f32x4*>(p);
-            g.x[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
-            g.ok |= ok ? (1u << i) : 0u;
+            int r;
+            if (a.sub) {
+                r = rv[i] ? rbase[i] : a.prow;
+            } else {
+                const int hin = h0[i] + l_kh, win = w0[i] + l_kw;
+                const bool ok = rv[i] & ((unsigned)hin < (unsigned)a.H) & ((unsigned)win < (unsigned)a.W);
+                r = ok ? rbase[i] + hin * a.W + win : a.prow;
+            }
+            const unsigned short* src = xs + r * PITCH + l_c + 8 * hi;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) f.p[i][pl] = *reinterpret_cast<const cgs_bf16x8*>(src + pl * plane);
         }
-        ++l_s;
         l_c += 16;
         if (l_c >= a.C) {
             l_c = 0;
@@ -146,21 +200,8 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    auto compute = [&](const Stage& g) {
-        cgs_bf16x8 af[MT][3], bw[NT][3];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const bool ok = (g.ok >> i) & 1u;
-            f32x4 v0 = g.x[i][0], v1 = g.x[i][1];
-            if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-            unsigned p[3][4];
-            bf3_split2(v0[0], v0[1], p[0][0], p[1][0], p[2][0]);
-            bf3_split2(v0[2], v0[3], p[0][1], p[1][1], p[2][1]);
-            bf3_split2(v1[0], v1[1], p[0][2], p[1][2], p[2][2]);
-            bf3_split2(v1[2], v1[3], p[0][3], p[1][3], p[2][3]);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) af[i][pl] = __builtin_bit_cast(cgs_bf16x8, u32x4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]});
-        }
+    auto compute = [&](const AFrag& f, const WStage& g) {
+        cgs_bf16x8 bw[NT][3];
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -175,22 +216,26 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)  // operands swapped: D[m = output channel][n = pixel]
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][PW[q]], af[i][PX[q]], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[j][PW[q]], f.p[i][PX[q]], acc[i][j], 0, 0, 0);
     };
 
-    // ---- main loop: register ring of D k-steps ----
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (s_begin + d < s_end) load(st[d]);
+    __syncthreads();  // the input image is complete
+
+    // ---- main loop: no barriers; the next step's activation fragments are read before this step's MFMAs ----
+    AFrag cur, nxt;
+    if (s_begin < s_end) aread(cur);
     for (int s = s_begin; s < s_end; s += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             if (s + d < s_end) {
-                compute(st[d]);
-                if (s + d + D < s_end) load(st[d]);
+                if (s + d + 1 < s_end) aread(nxt);
+                compute(cur, st[d]);
+                if (s + d + D < s_end) wload(st[d], s + d + D);
+                cur = nxt;
             }
         }
     }
+    __syncthreads();  // every wave is done with the input image: the partial tiles go over it
 
     // ---- the WK partial tiles -> LDS.  lane (pixel li): channels j*32 + 8 g + 4 hi .. +3 in acc[i][j][4 g .. 4 g + 3] ----
 #pragma unroll
@@ -294,19 +339,28 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
     (void)qpix;
 }
 
-// fp32 [n] (n % 2 == 0) -> three bf16 planes [3][n]: plane p at out + p * n
-__global__ void cgs_split_planes_kernel(const float* __restrict__ w, unsigned* __restrict__ out, long long npairs) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < npairs; e += (long long)gridDim.x * blockDim.x) {
+// Forward-packed weight wf [Cout][K] (K = KH*KW*C in (kh, kw, ci) order, Cout % 32 == 0, K % 16 == 0) -> the three bf16 planes of its
+// exact split in MFMA FRAGMENT order: plane p, channel tile ct = co / 32, k-step s = k / 16 occupy 1 KB
+//   out[((p * Cout/32 + ct) * K/16 + s) * 512 + lane * 8 + e] = plane_p(wf[ct * 32 + (lane & 31)][s * 16 + 8 * (lane >> 5) + e])
+// so that the 64 lanes of a wave read one operand fragment as 1 KB of contiguous memory.
+__global__ void cgs_split_weights_kernel(const float* __restrict__ wf, unsigned* __restrict__ out, int Cout, int K) {
+    const int KS = K >> 4;
+    const long long npairs = (long long)Cout * K / 2, plane_pairs = npairs;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (long long)gridDim.x * blockDim.x) {
+        const int ep = (int)(q & 3), lane = (int)((q >> 2) & 63);
+        const long long blk = q >> 8;  // (ct, s)
+        const int s = (int)(blk % KS), ct = (int)(blk / KS);
+        const int co = ct * 32 + (lane & 31), k = s * 16 + 8 * (lane >> 5) + 2 * ep;
         unsigned p0, p1, p2;
-        bf3_split2(w[2 * e], w[2 * e + 1], p0, p1, p2);
-        out[e] = p0; out[npairs + e] = p1; out[2 * npairs + e] = p2;
+        bf3_split2(wf[(size_t)co * K + k], wf[(size_t)co * K + k + 1], p0, p1, p2);
+        out[q] = p0; out[plane_pairs + q] = p1; out[2 * plane_pairs + q] = p2;
     }
 }
 
-inline int split_weight_planes(const float* w, long long n, unsigned short* planes, hipStream_t stream) {
-    if (!w || !planes || n <= 0 || (n & 1)) return HAB_ERR_ARG;
-    const long long np = n >> 1;
-    cgs_split_planes_kernel<<<(int)(np + 255 < 256LL * 1024 ? (np + 255) / 256 : 1024), 256, 0, stream>>>(w, reinterpret_cast<unsigned*>(planes), np);
+inline int cgs_split_weights(const float* wf, int Cout, int K, unsigned short* planes, hipStream_t stream) {
+    if (!wf || !planes || Cout <= 0 || K <= 0 || (Cout & 31) || (K & 15)) return HAB_ERR_ARG;
+    const long long np = (long long)Cout * K / 2;
+    cgs_split_weights_kernel<<<(int)(np + 255 < 256LL * 1024 ? (np + 255) / 256 : 1024), 256, 0, stream>>>(wf, reinterpret_cast<unsigned*>(planes), Cout, K);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -322,19 +376,37 @@ inline bool conv_gn_slab_shape(int C, int Cout, int HoWo, int groups) {
     if (nt > 32 && HoWo > 32) return false;  // the wide slabs exist for the 32-row tile only
     return true;
 }
+constexpr int CGS_LDS_MAX = 160 * 1024;
+// LDS bytes of a launch: (input image | partial tiles) + quad sums + statistics; 0 when the input image of one workgroup does not fit
+template <int MT, int NT, int WM, int WK>
+inline size_t cgs_lds(const CgsArgs& a, int* region0, int* prow_out) {
+    using Cfg = CgsCfg<MT, NT, WM, WK>;
+    const int fpw = Cfg::Mt / a.HoWo;
+    const bool sub = a.KH == 1 && a.KW == 1;
+    const long long prow = (long long)fpw * (sub ? a.HoWo : a.H * a.W);
+    const long long image = (prow + 1) * (a.C + 8) * 2 * 3;
+    long long r0 = (long long)(Cfg::RED_FLOATS * sizeof(float));
+    if (image > r0) r0 = image;
+    r0 = (r0 + 15) & ~15LL;
+    const long long total = r0 + (long long)(Cfg::QS_FLOATS + 2 * (size_t)fpw * (Cfg::Nt / a.gs)) * (long long)sizeof(float);
+    if (total > CGS_LDS_MAX) return 0;
+    *region0 = (int)r0;
+    *prow_out = (int)prow;
+    return (size_t)total;
+}
 
 template <int MT, int NT, int WM, int WK, int D>
 inline int cgs_launch(CgsArgs& a, hipStream_t stream) {
     using Cfg = CgsCfg<MT, NT, WM, WK>;
     a.fpw = Cfg::Mt / a.HoWo;
     a.nslab = a.Cout / Cfg::Nt;
-    const int npairs = a.fpw * (Cfg::Nt / a.gs);
-    const size_t lds = Cfg::lds_bytes(npairs);
-    if (lds > 160 * 1024) return 1;
+    a.sub = (a.KH == 1 && a.KW == 1) ? 1 : 0;
+    const size_t lds = cgs_lds<MT, NT, WM, WK>(a, &a.region0_bytes, &a.prow);
+    if (lds == 0) return 1;
     auto kern = conv_gn_slab_kernel<MT, NT, WM, WK, D>;
     // set once per process and instantiation (thread-safe static initialisation: engines of several inference workers call this concurrently)
     static const hipError_t attr_err =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, CGS_LDS_MAX);
     if (attr_err != hipSuccess) return (int)attr_err;
     const int nfg = (a.B + a.fpw - 1) / a.fpw;
     kern<<<nfg * a.nslab, 512, lds, stream>>>(a);
@@ -342,20 +414,41 @@ inline int cgs_launch(CgsArgs& a, hipStream_t stream) {
     return HAB_OK;
 }
 
-// 1: geometry not covered (the caller runs the unfused path).
-inline int conv_gn_slab(CgsArgs a, hipStream_t stream) {
-    if (!a.x || !a.wp || !a.gamma || !a.beta || !a.y || a.B <= 0) return HAB_ERR_ARG;
-    if ((a.mean == nullptr) != (a.rstd == nullptr)) return HAB_ERR_ARG;
+inline int cgs_prepare(CgsArgs& a) {
     a.Ho = (a.H + 2 * a.pad - a.KH) / a.stride + 1;
     a.Wo = (a.W + 2 * a.pad - a.KW) / a.stride + 1;
     a.HoWo = a.Ho * a.Wo;
     if (a.Ho <= 0 || a.Wo <= 0 || !conv_gn_slab_shape(a.C, a.Cout, a.HoWo, a.groups)) return 1;
-    if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.wp) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.gamma) |
-         reinterpret_cast<uintptr_t>(a.beta) | reinterpret_cast<uintptr_t>(a.residual) | reinterpret_cast<uintptr_t>(a.raw)) & 15)
-        return 1;
+    if (a.KH == 1 && a.KW == 1 && a.pad != 0) return 1;
     a.K = a.KH * a.KW * a.C;
     a.KS = a.K / 16;
     a.gs = a.Cout / a.groups;
+    return HAB_OK;
+}
+
+// does the geometry run on the fused kernel (shape covered AND the input image of a workgroup fits LDS)?
+inline bool conv_gn_slab_covers(int C, int Cout, int H, int W, int KH, int KW, int stride, int pad, int groups) {
+    CgsArgs a{};
+    a.H = H; a.W = W; a.C = C; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.groups = groups;
+    if (cgs_prepare(a) != HAB_OK) return false;
+    int r0, pr;
+    if (a.gs > 64) return cgs_lds<1, 4, 1, 8>(a, &r0, &pr) != 0;
+    if (a.gs > 32) return cgs_lds<1, 2, 1, 8>(a, &r0, &pr) != 0;
+    if (a.HoWo <= 32) return cgs_lds<1, 1, 1, 8>(a, &r0, &pr) != 0;
+    if (a.HoWo <= 64) return cgs_lds<2, 1, 1, 8>(a, &r0, &pr) != 0;
+    if (a.HoWo <= 128) return cgs_lds<2, 1, 2, 4>(a, &r0, &pr) != 0;
+    return cgs_lds<2, 1, 4, 2>(a, &r0, &pr) != 0;
+}
+
+// 1: geometry not covered (the caller runs the unfused path).
+inline int conv_gn_slab(CgsArgs a, hipStream_t stream) {
+    if (!a.x || !a.wq || !a.gamma || !a.beta || !a.y || a.B <= 0) return HAB_ERR_ARG;
+    if ((a.mean == nullptr) != (a.rstd == nullptr)) return HAB_ERR_ARG;
+    const int rc = cgs_prepare(a);
+    if (rc != HAB_OK) return rc;
+    if ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.wq) | reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.gamma) |
+         reinterpret_cast<uintptr_t>(a.beta) | reinterpret_cast<uintptr_t>(a.residual) | reinterpret_cast<uintptr_t>(a.raw)) & 15)
+        return 1;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");
     a.sign_schedule = sign_schedule;
     if (a.gs > 64) return cgs_launch<1, 4, 1, 8, 2>(a, stream);

@@ -353,7 +353,7 @@ int resnet_repack(hab_policy* e, hipStream_t s) {
     };
     auto planes = [&](const RnConv& c) {
         if (c.pk_p < 0) return (int)HAB_OK;
-        return weight_planes(e->PK + c.pk_f, (long long)c.cd.Cout * c.cd.KH * c.cd.KW * c.cd.C, reinterpret_cast<unsigned short*>(e->PK + c.pk_p), s);
+        return weight_planes(e->PK + c.pk_f, c.cd.Cout, c.cd.KH * c.cd.KW * c.cd.C, reinterpret_cast<unsigned short*>(e->PK + c.pk_p), s);
     };
     HAB_TRY(rp(r->stem, r->creal));
     for (const auto& c : r->convs) { HAB_TRY(rp(c, c.cd.C)); HAB_TRY(planes(c)); }

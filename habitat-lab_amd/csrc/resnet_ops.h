@@ -69,7 +69,7 @@ int rmv_normalize(float* x, long long npix, int cpad, int C, const float* mean, 
 // conv_gn_ops.hip -- convolution (bias-free) + GroupNorm (+ residual, + ReLU) in one launch for the small-batch passes (conv_gn_slab.h)
 struct ConvGnArgs {
     const float* x;                 // [B][H][W][C]
-    const unsigned short* w_planes; // forward-packed weight [Cout][KH*KW*C] as three bf16 planes (weight_planes)
+    const unsigned short* w_planes; // forward-packed weight [Cout][KH*KW*C] as three fragment-ordered bf16 planes (weight_planes)
     const float* gamma; const float* beta; const float* residual;
     float* y;
     float* raw = nullptr; float* mean = nullptr; float* rstd = nullptr;  // kept for a backward pass when given
@@ -77,7 +77,7 @@ struct ConvGnArgs {
     float eps;
 };
 int conv_gn_fused_ok(int C, int Cout, int H, int W, int KH, int KW, int stride, int pad, int groups);
-int weight_planes(const float* w, long long n, unsigned short* planes, hipStream_t s);
+int weight_planes(const float* w, int Cout, int K, unsigned short* planes, hipStream_t s);  // fragment-ordered bf16 planes of the exact split
 int conv_gn_fused(const ConvGnArgs& a, hipStream_t s);  // 1: geometry not covered
 int groupnorm_forward(const GnArgs& a, hipStream_t s);
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s);

@@ -248,14 +248,18 @@ int hab_groupnorm_bwd(const float* x, const float* dy, const float* relu_out, fl
  * ReLU of BasicBlock / Bottleneck / downsample / compression (rl/ddppo/policy/resnet.py:19-34,51-69,129-152,207-219;
  * resnet_policy.py:213-234) as PPOTrainer._compute_actions_and_step_envs reaches them once per environment step
  * (rl/ppo/ppo_trainer.py:343-399).
- *   hab_split_weight_planes: forward-packed weight w_fwd [Cout][KH*KW*C] (n = its element count, even) -> its exact three-term bf16
- *       split as planes [3][n] uint16 (x = p0 + p1 + p2); done once per optimiser step, shared by every step of a rollout.
+ *   hab_split_weight_planes: forward-packed weight w_fwd [Cout][K = KH*KW*C] (Cout % 32 == 0, K % 16 == 0) -> its exact three-term
+ *       bf16 split (x = p0 + p1 + p2) as three planes of Cout*K uint16 in MFMA fragment order:
+ *       planes[((p * Cout/32 + co/32) * K/16 + k/16) * 512 + ((k % 16) / 8 * 32 + co % 32) * 8 + k % 8] = plane p of w_fwd[co][k],
+ *       so the 64 lanes of a wave read an operand fragment as 1 KB of contiguous memory; done once per optimiser step, shared by
+ *       every step of a rollout.
  *   hab_conv_gn_fwd: x NHWC [B][H][W][C] (C % 16 == 0), w_planes from above; y [B][Ho*Wo][Cout]; residual (nullable) same shape as y;
  *       raw / mean / rstd (nullable, mean and rstd together): convolution output before the normalisation and the statistics
  *       [B][groups], kept for hab_groupnorm_bwd.  Covered: Ho*Wo <= 256, Cout % 32 == 0, group size Cout / groups in {4 .. 128}
- *       (> 32 only for Ho*Wo <= 32); anything else returns HAB_ERR_UNSUPPORTED and the caller runs hab_conv2d_fwd + hab_groupnorm_fwd.
+ *       (> 32 only for Ho*Wo <= 32), the input of one workgroup's frames (256 / (Ho*Wo) frames x H*W*C, 1x1: x Ho*Wo*C) <= ~25 K
+ *       elements; anything else returns HAB_ERR_UNSUPPORTED and the caller runs hab_conv2d_fwd + hab_groupnorm_fwd.
  *   fp32 in / out, fp32-equivalent arithmetic (csrc/igemm_bf3.h), exact two-pass statistics; deterministic. */
-int hab_split_weight_planes(const float* w_fwd, int64_t n, uint16_t* planes, hipStream_t stream);
+int hab_split_weight_planes(const float* w_fwd, int Cout, int K, uint16_t* planes, hipStream_t stream);
 int hab_conv_gn_fwd(const float* x, const uint16_t* w_planes, const float* gamma, const float* beta, const float* residual, float* y,
                     float* raw, float* mean, float* rstd, int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad,
                     int groups, int relu, float eps, hipStream_t stream);
