@@ -452,11 +452,11 @@ inline int conv_gn_slab(CgsArgs a, hipStream_t stream) {
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");
     a.sign_schedule = sign_schedule;
     if (a.gs > 64) return cgs_launch<1, 4, 1, 8, 2>(a, stream);
-    if (a.gs > 32) return cgs_launch<1, 2, 1, 8, 3>(a, stream);
-    if (a.HoWo <= 32) return cgs_launch<1, 1, 1, 8, 4>(a, stream);
-    if (a.HoWo <= 64) return cgs_launch<2, 1, 1, 8, 4>(a, stream);
-    if (a.HoWo <= 128) return cgs_launch<2, 1, 2, 4, 4>(a, stream);
-    return cgs_launch<2, 1, 4, 2, 4>(a, stream);
+    if (a.gs > 32) return cgs_launch<1, 2, 1, 8, 4>(a, stream);
+    if (a.HoWo <= 32) return cgs_launch<1, 1, 1, 8, 8>(a, stream);
+    if (a.HoWo <= 64) return cgs_launch<2, 1, 1, 8, 8>(a, stream);
+    if (a.HoWo <= 128) return cgs_launch<2, 1, 2, 4, 8>(a, stream);
+    return cgs_launch<2, 1, 4, 2, 8>(a, stream);
 }
 
 }  // namespace hab

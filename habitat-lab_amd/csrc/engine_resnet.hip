@@ -484,10 +484,13 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
     const hab_policy_desc& d = e->d;
     float* x0 = W + r->w_x0;
     if ((d.has_rgb && !obs->rgb) || (d.has_depth && !obs->depth) || (d.has_semantic && !obs->semantic)) return HAB_ERR_ARG;
+    // evaluation mode: RunningMeanAndVar is a fixed affine per channel -> applied by the ingest itself (one launch, one pass less)
+    const bool fused_norm = d.normalize_visual_inputs && !e->training;
     HAB_TRY(ingest_pool(d.has_rgb ? obs->rgb : nullptr, d.has_depth ? obs->depth : nullptr, d.has_semantic ? obs->semantic : nullptr, rows,
-                        x0, B, d.H, d.W, r->cpad, r->c_rgb, r->c_depth, r->c_sem, s));
+                        x0, B, d.H, d.W, r->cpad, r->c_rgb, r->c_depth, r->c_sem, s, fused_norm ? e->p(r->i_mean) : nullptr,
+                        fused_norm ? e->p(r->i_var) : nullptr));
     const long long npix = (long long)B * r->H2 * r->W2;
-    if (d.normalize_visual_inputs) {
+    if (d.normalize_visual_inputs && !fused_norm) {
         float* st = W + r->w_stats;  // [0..7] batch mean, [8] batch count (frames), [16..23] batch var
         if (e->training) {
             double* ds = reinterpret_cast<double*>(W + r->w_dscratch);
@@ -505,9 +508,29 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
         HAB_TRY(rmv_normalize(x0, npix, r->cpad, r->creal, e->p(r->i_mean), e->p(r->i_var), s));
     }
     // stem
-    HAB_TRY(conv_gn_forward(e, r->stem, x0, nullptr, 1, B, s));
-    HAB_TRY(maxpool_forward(W + r->stem.w_out, W + r->w_pool, reinterpret_cast<uint8_t*>(W + r->w_pool_idx), B, r->stem.cd.Ho(),
-                            r->stem.cd.Wo(), r->stem.cd.Cout, s));
+    bool stem_done = false;
+    if (!e->save_acts) {  // act / encode: GroupNorm + ReLU + max-pool in one pass, the normalised frame is never written
+        ConvDesc cd = r->stem.cd;
+        cd.B = B;
+        HAB_TRY(conv_fwd(cd, x0, e->PK + r->stem.pk_f, nullptr, W + r->stem.w_raw, 0, W + e->w_ws, e->ws_floats, s));
+        GnArgs g;
+        g.x = W + r->stem.w_raw; g.y = nullptr; g.gamma = e->p(r->stem.i_gamma); g.beta = e->p(r->stem.i_beta); g.residual = nullptr;
+        g.mean = nullptr; g.rstd = nullptr; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = r->stem.groups; g.relu = 1;
+        g.eps = 1e-5f; g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
+        const int rc = groupnorm_relu_maxpool_forward(g, cd.Ho(), cd.Wo(), W + r->w_pool, s);
+        if (rc != 0 && rc != 1) return rc;
+        if (rc == 1) {  // small frames: the register-resident GroupNorm, then the pool
+            g.y = W + r->stem.w_out; g.mean = W + r->stem.w_mean; g.rstd = W + r->stem.w_rstd;
+            HAB_TRY(groupnorm_forward(g, s));
+            HAB_TRY(maxpool_forward(W + r->stem.w_out, W + r->w_pool, reinterpret_cast<uint8_t*>(W + r->w_pool_idx), B, cd.Ho(), cd.Wo(), cd.Cout, s));
+        }
+        stem_done = true;
+    }
+    if (!stem_done) {
+        HAB_TRY(conv_gn_forward(e, r->stem, x0, nullptr, 1, B, s));
+        HAB_TRY(maxpool_forward(W + r->stem.w_out, W + r->w_pool, reinterpret_cast<uint8_t*>(W + r->w_pool_idx), B, r->stem.cd.Ho(),
+                                r->stem.cd.Wo(), r->stem.cd.Cout, s));
+    }
     for (const auto& blk : r->blocks) {
         const float* in = W + blk.w_in;
         const float* residual = in;

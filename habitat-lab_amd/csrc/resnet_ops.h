@@ -60,7 +60,7 @@ struct EmbedBwdArgs {
 };
 
 int ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic, const int* rows, float* y, int B, int H, int W, int cpad,
-                int c_rgb, int c_depth, int c_sem, hipStream_t s);
+                int c_rgb, int c_depth, int c_sem, hipStream_t s, const float* norm_mean = nullptr, const float* norm_var = nullptr);
 int chan_moment(const float* x, long long npix, int cpad, int mode, const float* mean, float* out, double* scratch, int scratch_len,
                 hipStream_t s, float mean_div = 1.f, float* count_out = nullptr, float count_val = 0.f);
 int rmv_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C, hipStream_t s,
@@ -81,6 +81,7 @@ int weight_planes(const float* w, int Cout, int K, unsigned short* planes, hipSt
 int conv_gn_fused(const ConvGnArgs& a, hipStream_t s);  // 1: geometry not covered
 int groupnorm_forward(const GnArgs& a, hipStream_t s);
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s);
+int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, hipStream_t s);  // 1: not applicable
 int maxpool_forward(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t s);
 int maxpool_backward(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t s);
 // Squeeze-and-excitation gate of SEBottleneck (resnet.py:92-113,155-187): pooled[b][c] = mean_hw x;  y = relu(gate[b][c] * x + residual);

@@ -16,8 +16,20 @@ namespace hab {
 __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
                                                           const int32_t* __restrict__ semantic, const int* __restrict__ rows,
                                                           float* __restrict__ y, int B, int H, int W, int cpad, int c_rgb, int c_depth,
-                                                          int c_sem) {
+                                                          int c_sem, const float* __restrict__ nmean, const float* __restrict__ nvar, int creal) {
 #pragma clang fp contract(off)  // the reference rounds the uint8 scaling and every addition of the 2x2 average separately
+    // optional RunningMeanAndVar normalisation of the result (evaluation mode: a fixed affine per channel; rmv_normalize_kernel's
+    // arithmetic: fma(x, inv_std, -mean * inv_std))
+    __shared__ float na[8], nb[8];
+    if (nmean) {
+        if (threadIdx.x < 8) {
+            const int c = threadIdx.x;
+            float a_ = 0.f, b_ = 0.f;
+            if (c < creal) { b_ = rsqrtf(fmaxf(nvar[c], 1e-2f)); a_ = -nmean[c] * b_; }
+            na[c] = a_; nb[c] = b_;
+        }
+        __syncthreads();
+    }
     const int Ho = H / 2, Wo = W / 2;
     const long long total = (long long)B * Ho * Wo;
     const float inv255 = (float)(1.0 / 255.0);
@@ -59,20 +71,25 @@ __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restr
                 for (int dw = 0; dw < 2; ++dw) s = s + (float)semantic[(srow * H + 2 * ho + dh) * W + 2 * wo + dw];
             out[c_sem] = s * 0.25f;
         }
+        if (nmean) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) out[c] = __builtin_fmaf(out[c], nb[c], na[c]);
+        }
         float* o = y + (size_t)e * cpad;
         for (int c = 0; c < cpad; c += 4) *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(out + c);
     }
 }
 
 int ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic, const int* rows, float* y, int B, int H, int W, int cpad,
-                int c_rgb, int c_depth, int c_sem, hipStream_t s) {
+                int c_rgb, int c_depth, int c_sem, hipStream_t s, const float* norm_mean, const float* norm_var) {
     if ((!rgb && !depth && !semantic) || !y || B <= 0 || H < 2 || W < 2 || (cpad != 4 && cpad != 8)) return HAB_ERR_ARG;
+    if ((norm_mean == nullptr) != (norm_var == nullptr)) return HAB_ERR_ARG;
     const int n = (rgb ? 3 : 0) + (depth ? 1 : 0) + (semantic ? 1 : 0);
     if (n > cpad || (rgb && (c_rgb < 0 || c_rgb + 3 > n)) || (depth && (c_depth < 0 || c_depth >= n)) || (semantic && (c_sem < 0 || c_sem >= n)))
         return HAB_ERR_ARG;
     const long long total = (long long)B * (H / 2) * (W / 2);
     ingest_pool_kernel<<<(int)fmin(8192.0, (double)cdivl(total, 256)), 256, 0, s>>>(rgb, depth, semantic, rows, y, B, H, W, cpad, c_rgb,
-                                                                                     c_depth, c_sem);
+                                                                                     c_depth, c_sem, norm_mean, norm_var, n);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -168,7 +185,7 @@ __global__ void __launch_bounds__(256) rmv_normalize_kernel(float* __restrict__ 
     __syncthreads();
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n_elems; e += (long long)gridDim.x * 256) {
         const int c = (int)(e % cpad);
-        x[e] = a[c] + x[e] * b[c];
+        x[e] = __builtin_fmaf(x[e], b[c], a[c]);
     }
 }
 int rmv_normalize(float* x, long long npix, int cpad, int C, const float* mean, const float* var, hipStream_t s) {
@@ -595,6 +612,69 @@ __global__ void __launch_bounds__(NT) gn_chunk_apply_kernel(const GnArgs a, int 
     }
 }
 
+// Second kernel of the chunk-parallel forward for a stem whose activations are not kept (rollout `act`): merge the chunk statistics,
+// then GroupNorm-apply + ReLU + MaxPool2d(3, 2, 1) in one pass -- the normalised frame (stem.w_out, 512 KB per frame at 256^2) is
+// neither written nor re-read, no arg-max bytes.  thread = (pooled pixel, 4 channels); max(relu(.)) == relu(max(.)).
+// Replaces resnet.py:207-220 (GroupNorm, ReLU, MaxPool2d of `conv1`) inside the rollout's policy.act (ppo_trainer.py:343-399).
+template <int NT, int NV>
+__global__ void __launch_bounds__(256) gn_chunk_apply_pool_kernel(const GnArgs a, int nchunks, const float* __restrict__ part, int H, int W,
+                                                                  float* __restrict__ pool, int blocks_per_frame) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
+    const int F4 = a.HW * C4;
+    const int f = blockIdx.x / blocks_per_frame, bk = blockIdx.x % blocks_per_frame, t = threadIdx.x;
+    float* mu_s = sm;
+    float* rs_s = sm + G;
+    if (t < G) {  // the merge of gn_chunk_apply_kernel (same order, same arithmetic)
+        const float* p = part + ((size_t)f * nchunks * G + t) * 2;
+        const float n = (float)(a.HW * cpg);
+        float mean = 0.f;
+        for (int k = 0; k < nchunks; ++k) {
+            const float nk = (float)((min(NT * NV, F4 - k * NT * NV) / C4) * cpg);
+            mean += nk * p[(size_t)k * G * 2];
+        }
+        mean /= n;
+        float m2 = 0.f;
+        for (int k = 0; k < nchunks; ++k) {
+            const float nk = (float)((min(NT * NV, F4 - k * NT * NV) / C4) * cpg);
+            const float d = p[(size_t)k * G * 2] - mean;
+            m2 += p[(size_t)k * G * 2 + 1] + nk * d * d;
+        }
+        mu_s[t] = mean;
+        rs_s[t] = rsqrtf(m2 / n + a.eps);
+    }
+    __syncthreads();
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int total = Ho * Wo * C4;
+    const float* x = a.x + (size_t)f * a.HW * C;
+    for (int e = bk * 256 + t; e < total; e += blocks_per_frame * 256) {
+        const int c4 = e % C4, pp = e / C4, wo = pp % Wo, ho = pp / Wo;
+        f32x4 sc, sh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c4 * 4 + k, g = c / cpg;
+            sc[k] = rs_s[g] * a.gamma[c];
+            sh[k] = a.beta[c] - mu_s[g] * sc[k];
+        }
+        f32x4 best = {0.f, 0.f, 0.f, 0.f};  // ReLU: every window holds at least one in-image pixel
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = ho * 2 - 1 + kh;
+            if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = wo * 2 - 1 + kw;
+                if ((unsigned)w >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)h * W + w) * C + c4 * 4) * sc + sh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] > best[k] || v[k] != v[k]) best[k] = v[k];
+            }
+        }
+        *reinterpret_cast<f32x4*>(pool + ((size_t)f * Ho * Wo + pp) * C + c4 * 4) = best;
+    }
+}
+
 // backward, kernel 1: per-channel partial sums S1 = sum dy', S2 = sum dy' * xhat of the chunk (+ optional dy' write-out)
 template <int NT, int NV>
 __global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a, int nchunks, float* __restrict__ part) {
@@ -789,6 +869,24 @@ int groupnorm_forward(const GnArgs& a, hipStream_t s) {
     }
     const size_t lds = (size_t)(1024 + a.C + 2 * a.groups) * sizeof(float);
     groupnorm_fwd_kernel<<<a.B, 256, lds, s>>>(a);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// GroupNorm + ReLU + MaxPool2d(3, 2, 1) with nothing kept for a backward pass; 1: frame not on the chunk-parallel path (the caller
+// runs groupnorm_forward + maxpool_forward).
+int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, hipStream_t s) {
+    if (!a.x || !a.gamma || !a.beta || !pool || a.HW != H * W || a.residual || !a.relu) return HAB_ERR_ARG;
+    HAB_TRY(gn_check(a.B, a.C, a.groups));
+    int nt, nv, nchunks;
+    if (gn_reg_cfg(a.HW, a.C, nt, nv)) return 1;
+    if (!a.scratch || !gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.groups * 2, a.scratch_floats, GNC_NT * GNC_NV_F, nchunks)) return 1;
+    const size_t lds1 = (size_t)(GNC_NT * 4 + a.C + a.groups) * sizeof(float);
+    gn_chunk_stats_kernel<GNC_NT, GNC_NV_F><<<a.B * nchunks, GNC_NT, lds1, s>>>(a, nchunks, a.scratch);
+    HAB_LAUNCH_CHECK();
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int bpf = max(1, min(64, cdiv(Ho * Wo * (a.C / 4), 256 * 4)));
+    gn_chunk_apply_pool_kernel<GNC_NT, GNC_NV_F><<<a.B * bpf, 256, 2 * a.groups * sizeof(float), s>>>(a, nchunks, a.scratch, H, W, pool, bpf);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
