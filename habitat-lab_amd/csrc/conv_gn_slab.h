@@ -50,6 +50,7 @@ struct CgsArgs {
     int region0_bytes;         // max(input image, partial tiles)
     int relu, sign_schedule;
     float eps;
+    int ablate;                // development (HAB_CGS_ABLATE, tools/bench_conv_gn.py): 1 no input staging, 2 no MFMAs, 4 no weight loads, 8 no statistics
 };
 
 template <int MT, int NT, int WM, int WK>
@@ -93,6 +94,7 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
     const size_t wplane = (size_t)(a.Cout >> 5) * a.KS * 512;
     const unsigned short* wbase = a.wq + (size_t)(slab * NT) * a.KS * 512 + lane * 8;
     auto wload = [&](WStage& g, int s) {
+        if (a.ablate & 4) return;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const unsigned short* p = wbase + ((size_t)j * a.KS + s) * 512;
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
         const int rows_per_frame = a.sub ? a.HoWo : HW;
         const int units = a.prow * C4;
         constexpr int UB = 4;  // loads in flight per thread
-        for (int u0 = t; u0 < units; u0 += 512 * UB) {
+        for (int u0 = t; u0 < ((a.ablate & 1) ? 0 : units); u0 += 512 * UB) {
             f32x4 v[UB];
             int dsto[UB];
 #pragma unroll
@@ -201,6 +203,7 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
     auto compute = [&](const AFrag& f, const WStage& g) {
+        if (a.ablate & 2) return;
         cgs_bf16x8 bw[NT][3];
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
         if (a.raw && qok[u]) *reinterpret_cast<f32x4*>(a.raw + qout[u]) = s;
     }
     __syncthreads();
-    const int nmem = a.HoWo * qpg;
+    const int nmem = (a.ablate & 8) ? 0 : a.HoWo * qpg;
     const float inv_n = 1.0f / (float)(a.HoWo * a.gs);
     // mean per (frame, group): wave w takes pairs w, w + 8, ...
     for (int pr = wave; pr < npairs; pr += 8) {
@@ -451,6 +454,8 @@ inline int conv_gn_slab(CgsArgs a, hipStream_t stream) {
         return 1;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");
     a.sign_schedule = sign_schedule;
+    static const int ablate = hab_env_int("HAB_CGS_ABLATE", 0);
+    a.ablate = ablate;
     if (a.gs > 64) return cgs_launch<1, 4, 1, 8, 2>(a, stream);
     if (a.gs > 32) return cgs_launch<1, 2, 1, 8, 4>(a, stream);
     if (a.HoWo <= 32) return cgs_launch<1, 1, 1, 8, 8>(a, stream);

@@ -393,9 +393,13 @@ static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, cons
     float* W = e->WK;
     ConvDesc cd = c.cd;
     cd.B = B;
-    // small batches (the rollout's act, encode, small minibatches): convolution + GroupNorm in one launch (conv_gn_slab.h)
+    // the rollout's act / encode (small batches, nothing kept for a backward): convolution + GroupNorm in one launch (conv_gn_slab.h).
+    // Small evaluate minibatches keep the unfused pair -- the kernels every update-sized minibatch runs, so that the golden update tests
+    // exercise the production learner path; HAB_CGS_EVAL=1 (development) sends them through the fused kernel too (it writes the
+    // pre-normalisation output and the statistics for the backward pass: tests/test_gpu_conv_gn.py).
     static const int cgs_max_b = hab_env_int("HAB_CGS_MAX_B", 256);
-    if (c.pk_p >= 0 && B <= cgs_max_b) {
+    static const int cgs_eval = hab_env_int("HAB_CGS_EVAL", 0);
+    if (c.pk_p >= 0 && B <= cgs_max_b && (!e->save_acts || cgs_eval)) {
         ConvGnArgs q;
         q.x = in; q.w_planes = reinterpret_cast<const unsigned short*>(e->PK + c.pk_p); q.gamma = e->p(c.i_gamma); q.beta = e->p(c.i_beta);
         q.residual = residual; q.y = W + c.w_out;
