@@ -106,6 +106,28 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
     for (int d = 0; d < D; ++d)
         if (s_begin + d < s_end) wload(st[d], s_begin + d);
 
+    // ---- epilogue role of this thread: QPT quads (pixel, 4 consecutive channels).  Their residual / gamma / beta loads are issued NOW:
+    //      a dependent HBM round trip (~2 us) at the end of a ~10 us kernel otherwise ----
+    const int qpg = a.gs >> 2;  // quads per group
+    int qcq[QPT], qpair[QPT];
+    bool qok[QPT], qin[QPT];
+    size_t qout[QPT];
+    f32x4 qres[QPT], qga[QPT], qbe[QPT];
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+        const int q = t + u * 512;
+        qin[u] = (Cfg::NQUADS % 512 == 0) || q < Cfg::NQUADS;
+        const int pixl = qin[u] ? q / NQ : 0, cq = qin[u] ? q - pixl * NQ : 0;
+        const int fl = pixl / a.HoWo, pix = pixl - fl * a.HoWo, frame = fg * a.fpw + fl;
+        qok[u] = qin[u] & (fl < a.fpw) & (frame < a.B);
+        qcq[u] = cq;
+        qpair[u] = min(fl, a.fpw - 1) * gpn + (cq * 4) / a.gs;
+        qout[u] = ((size_t)frame * a.HoWo + pix) * a.Cout + co0 + cq * 4;
+        qres[u] = (a.residual && qok[u]) ? *reinterpret_cast<const f32x4*>(a.residual + qout[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        qga[u] = *reinterpret_cast<const f32x4*>(a.gamma + co0 + cq * 4);
+        qbe[u] = *reinterpret_cast<const f32x4*>(a.beta + co0 + cq * 4);
+    }
+
     // ---- stage the input image of this workgroup's frames: fp32 NHWC -> three bf16 planes in LDS ----
     {
         const int C4 = a.C >> 2, HW = a.H * a.W;
@@ -254,27 +276,17 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
     __syncthreads();
 
     // ---- fold in wave order; thread owns QPT quads (pixel, 4 consecutive channels) ----
-    const int qpg = a.gs >> 2;  // quads per group
     f32x4 v[QPT];
-    int qpix[QPT], qcq[QPT], qpair[QPT];
-    bool qok[QPT];
-    size_t qout[QPT];
 #pragma unroll
     for (int u = 0; u < QPT; ++u) {
         const int q = t + u * 512;
-        const bool in = (Cfg::NQUADS % 512 == 0) || q < Cfg::NQUADS;
-        const int pixl = in ? q / NQ : 0, cq = in ? q - pixl * NQ : 0;
+        const int pixl = qin[u] ? q / NQ : 0, cq = qcq[u];
         f32x4 s = *reinterpret_cast<const f32x4*>(red + (size_t)pixl * RED_LD + cq * 4);
 #pragma unroll
         for (int w = 1; w < WK; ++w) s += *reinterpret_cast<const f32x4*>(red + ((size_t)w * Mt + pixl) * RED_LD + cq * 4);
         if (flip) s = -s;
-        const int fl = pixl / a.HoWo, pix = pixl - fl * a.HoWo, frame = fg * a.fpw + fl;
-        qok[u] = in & (fl < a.fpw) & (frame < a.B);
         v[u] = s;
-        qpix[u] = pixl; qcq[u] = cq;
-        qpair[u] = min(fl, a.fpw - 1) * gpn + (cq * 4) / a.gs;
-        qout[u] = ((size_t)frame * a.HoWo + pix) * a.Cout + co0 + cq * 4;
-        if (in) qs[q] = qok[u] ? (s[0] + s[1]) + (s[2] + s[3]) : 0.f;
+        if (qin[u]) qs[q] = qok[u] ? (s[0] + s[1]) + (s[2] + s[3]) : 0.f;
         if (a.raw && qok[u]) *reinterpret_cast<f32x4*>(a.raw + qout[u]) = s;
     }
     __syncthreads();
@@ -295,10 +307,9 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
 #pragma unroll
     for (int u = 0; u < QPT; ++u) {
         const int q = t + u * 512;
-        const bool in = (Cfg::NQUADS % 512 == 0) || q < Cfg::NQUADS;
         const float mu = mu_s[qpair[u]];
         const f32x4 d = v[u] - f32x4{mu, mu, mu, mu};
-        if (in) qs[q] = qok[u] ? (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]) : 0.f;
+        if (qin[u]) qs[q] = qok[u] ? (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]) : 0.f;
     }
     __syncthreads();
     for (int pr = wave; pr < npairs; pr += 8) {
@@ -323,23 +334,21 @@ __global__ void __launch_bounds__(512) conv_gn_slab_kernel(const CgsArgs a) {
 #pragma unroll
     for (int u = 0; u < QPT; ++u) {
         if (!qok[u]) continue;
-        const int c = co0 + qcq[u] * 4;
         const float mu = mu_s[qpair[u]], rs = rs_s[qpair[u]];
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + c), be = *reinterpret_cast<const f32x4*>(a.beta + c);
+        const f32x4 ga = qga[u], be = qbe[u];
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float sc = rs * ga[k], sh = be[k] - mu * sc;  // the arithmetic of groupnorm_fwd_reg_kernel
             o[k] = v[u][k] * sc + sh;
         }
-        if (a.residual) o += *reinterpret_cast<const f32x4*>(a.residual + qout[u]);
+        if (a.residual) o += qres[u];
         if (a.relu) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : 0.f;
         }
         *reinterpret_cast<f32x4*>(a.y + qout[u]) = o;
     }
-    (void)qpix;
 }
 
 // Forward-packed weight wf [Cout][K] (K = KH*KW*C in (kh, kw, ci) order, Cout % 32 == 0, K % 16 == 0) -> the three bf16 planes of its
@@ -457,11 +466,11 @@ inline int conv_gn_slab(CgsArgs a, hipStream_t stream) {
     static const int ablate = hab_env_int("HAB_CGS_ABLATE", 0);
     a.ablate = ablate;
     if (a.gs > 64) return cgs_launch<1, 4, 1, 8, 2>(a, stream);
-    if (a.gs > 32) return cgs_launch<1, 2, 1, 8, 4>(a, stream);
-    if (a.HoWo <= 32) return cgs_launch<1, 1, 1, 8, 8>(a, stream);
-    if (a.HoWo <= 64) return cgs_launch<2, 1, 1, 8, 8>(a, stream);
-    if (a.HoWo <= 128) return cgs_launch<2, 1, 2, 4, 8>(a, stream);
-    return cgs_launch<2, 1, 4, 2, 8>(a, stream);
+    if (a.gs > 32) return cgs_launch<1, 2, 1, 8, 3>(a, stream);
+    if (a.HoWo <= 32) return cgs_launch<1, 1, 1, 8, 4>(a, stream);
+    if (a.HoWo <= 64) return cgs_launch<2, 1, 1, 8, 4>(a, stream);
+    if (a.HoWo <= 128) return cgs_launch<2, 1, 2, 4, 4>(a, stream);
+    return cgs_launch<2, 1, 4, 2, 4>(a, stream);
 }
 
 }  // namespace hab
