@@ -1,5 +1,6 @@
 // conv_gn_ops.hip -- launchers / C ABI of the fused convolution + GroupNorm kernel of the small-batch ResNet passes (conv_gn_slab.h).
 #include "conv_gn_slab.h"
+#include "stem_conv_strip.h"
 #include "resnet_ops.h"
 #include "../../include/habitat_amd.h"
 
@@ -20,9 +21,21 @@ int conv_gn_fused(const ConvGnArgs& q, hipStream_t s) {
     return conv_gn_slab(a, s);
 }
 
+int stem_conv_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad) { return stem_conv_strip_covers(H, W, C, Cout, KH, KW, stride, pad); }
+int stem_weight_planes(const float* wf, unsigned short* planes, hipStream_t s) { return stem_split_weights(wf, planes, s); }
+int stem_conv_forward(const float* x, const unsigned short* planes, float* y, int B, int H, int W, hipStream_t s) {
+    return stem_conv_strip(x, planes, y, B, H, W, s);
+}
+
 }  // namespace hab
 
 using namespace hab;
+
+extern "C" int hab_stem_split_weights(const float* w_fwd, uint16_t* planes, hipStream_t stream) { return stem_weight_planes(w_fwd, planes, stream); }
+extern "C" int hab_stem_conv_fwd(const float* x, const uint16_t* w_planes, float* y, int B, int H, int W, hipStream_t stream) {
+    const int rc = stem_conv_forward(x, w_planes, y, B, H, W, stream);
+    return rc == 1 ? HAB_ERR_UNSUPPORTED : rc;
+}
 
 extern "C" int hab_split_weight_planes(const float* w_fwd, int Cout, int K, uint16_t* planes, hipStream_t stream) {
     return weight_planes(w_fwd, Cout, K, planes, stream);

@@ -266,6 +266,7 @@ int build_resnet(hab_policy* e) {
             c.pk_p = pk.take((3 * n + 1) / 2);  // 3 planes x 2 bytes per weight
     };
     pack_conv(r->stem, false);
+    if (stem_conv_ok(r->stem.cd.H, r->stem.cd.W, r->stem.cd.C, r->stem.cd.Cout, 7, 7, 2, 3)) r->stem.pk_p = pk.take(STEM_PLANE_FLOATS);
     for (auto& c : r->convs) pack_conv(c, true);
     pack_conv(r->comp, true);
     r->pk_fc = pk.take((int64_t)H * r->fc_in);
@@ -356,6 +357,7 @@ int resnet_repack(hab_policy* e, hipStream_t s) {
         return weight_planes(e->PK + c.pk_f, c.cd.Cout, c.cd.KH * c.cd.KW * c.cd.C, reinterpret_cast<unsigned short*>(e->PK + c.pk_p), s);
     };
     HAB_TRY(rp(r->stem, r->creal));
+    if (r->stem.pk_p >= 0) HAB_TRY(stem_weight_planes(e->PK + r->stem.pk_f, reinterpret_cast<unsigned short*>(e->PK + r->stem.pk_p), s));
     for (const auto& c : r->convs) { HAB_TRY(rp(c, c.cd.C)); HAB_TRY(planes(c)); }
     HAB_TRY(rp(r->comp, r->comp.cd.C));
     HAB_TRY(planes(r->comp));
@@ -393,6 +395,17 @@ static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, cons
     float* W = e->WK;
     ConvDesc cd = c.cd;
     cd.B = B;
+    if (&c == &e->rn->stem && c.pk_p >= 0) {  // stem: input strip resident in LDS (stem_conv_strip.h)
+        static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
+        const int rc = stem_strip ? stem_conv_forward(in, reinterpret_cast<const unsigned short*>(e->PK + c.pk_p), W + c.w_raw, B, cd.H, cd.W, s) : 1;
+        if (rc != 0 && rc != 1) return rc;
+        if (rc == 1) HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, W + c.w_raw, 0, W + e->w_ws, e->ws_floats, s));
+        GnArgs g;
+        g.x = W + c.w_raw; g.y = W + c.w_out; g.gamma = e->p(c.i_gamma); g.beta = e->p(c.i_beta); g.residual = residual;
+        g.mean = W + c.w_mean; g.rstd = W + c.w_rstd; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = c.groups;
+        g.relu = relu; g.eps = 1e-5f; g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
+        return groupnorm_forward(g, s);
+    }
     // the rollout's act / encode (small batches, nothing kept for a backward): convolution + GroupNorm in one launch (conv_gn_slab.h).
     // Small evaluate minibatches keep the unfused pair -- the kernels every update-sized minibatch runs, so that the golden update tests
     // exercise the production learner path; HAB_CGS_EVAL=1 (development) sends them through the fused kernel too (it writes the
@@ -516,7 +529,11 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
     if (!e->save_acts) {  // act / encode: GroupNorm + ReLU + max-pool in one pass, the normalised frame is never written
         ConvDesc cd = r->stem.cd;
         cd.B = B;
-        HAB_TRY(conv_fwd(cd, x0, e->PK + r->stem.pk_f, nullptr, W + r->stem.w_raw, 0, W + e->w_ws, e->ws_floats, s));
+        static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
+        const int rcs = (stem_strip && r->stem.pk_p >= 0)
+                            ? stem_conv_forward(x0, reinterpret_cast<const unsigned short*>(e->PK + r->stem.pk_p), W + r->stem.w_raw, B, cd.H, cd.W, s) : 1;
+        if (rcs != 0 && rcs != 1) return rcs;
+        if (rcs == 1) HAB_TRY(conv_fwd(cd, x0, e->PK + r->stem.pk_f, nullptr, W + r->stem.w_raw, 0, W + e->w_ws, e->ws_floats, s));
         GnArgs g;
         g.x = W + r->stem.w_raw; g.y = nullptr; g.gamma = e->p(r->stem.i_gamma); g.beta = e->p(r->stem.i_beta); g.residual = nullptr;
         g.mean = nullptr; g.rstd = nullptr; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = r->stem.groups; g.relu = 1;

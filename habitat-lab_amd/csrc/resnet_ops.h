@@ -79,6 +79,11 @@ struct ConvGnArgs {
 int conv_gn_fused_ok(int C, int Cout, int H, int W, int KH, int KW, int stride, int pad, int groups);
 int weight_planes(const float* w, int Cout, int K, unsigned short* planes, hipStream_t s);  // fragment-ordered bf16 planes of the exact split
 int conv_gn_fused(const ConvGnArgs& a, hipStream_t s);  // 1: geometry not covered
+// stem convolution 7x7 / 2 / 3, 4 -> 32 channels with the input strip resident in LDS (stem_conv_strip.h)
+constexpr int STEM_PLANE_FLOATS = 3 * 14 * 1024 / 4;  // fragment-ordered bf16 planes of the filter, in floats of the packed arena
+int stem_conv_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad);
+int stem_weight_planes(const float* wf, unsigned short* planes, hipStream_t s);
+int stem_conv_forward(const float* x, const unsigned short* planes, float* y, int B, int H, int W, hipStream_t s);  // 1: not covered
 int groupnorm_forward(const GnArgs& a, hipStream_t s);
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s);
 int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, hipStream_t s);  // 1: not applicable

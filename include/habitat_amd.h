@@ -260,6 +260,14 @@ int hab_groupnorm_bwd(const float* x, const float* dy, const float* relu_out, fl
  *       elements; anything else returns HAB_ERR_UNSUPPORTED and the caller runs hab_conv2d_fwd + hab_groupnorm_fwd.
  *   fp32 in / out, fp32-equivalent arithmetic (csrc/igemm_bf3.h), exact two-pass statistics; deterministic. */
 int hab_split_weight_planes(const float* w_fwd, int Cout, int K, uint16_t* planes, hipStream_t stream);
+/* Stem convolution of the GroupNorm-ResNet (7x7 / stride 2 / padding 3, 4 input channels -> 32, bias-free; resnet.py:207-219 `conv1`
+ * on the 2x2-averaged observation of resnet_policy.py:259-272) with the input strip resident in LDS (csrc/stem_conv_strip.h).
+ *   hab_stem_split_weights: forward-packed filter w_fwd [32][7][7][4] -> 3 x 14 x 512 uint16: its exact three-term bf16 split in MFMA
+ *       fragment order (k-step 2 kh + j holds reduction slots 16 j .. 16 j + 15 of filter row kh = (kw, ci) pairs, kw = 7 zero-padded).
+ *   hab_stem_conv_fwd: x NHWC [B][H][W][4] -> y [B][Ho][Wo][32], Ho = (H - 1) / 2 + 1; covered: Wo <= 64 (observations up to 256 wide);
+ *       wider inputs return HAB_ERR_UNSUPPORTED (the caller runs hab_conv2d_fwd). */
+int hab_stem_split_weights(const float* w_fwd, uint16_t* planes, hipStream_t stream);
+int hab_stem_conv_fwd(const float* x, const uint16_t* w_planes, float* y, int B, int H, int W, hipStream_t stream);
 int hab_conv_gn_fwd(const float* x, const uint16_t* w_planes, const float* gamma, const float* beta, const float* residual, float* y,
                     float* raw, float* mean, float* rstd, int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad,
                     int groups, int relu, float eps, hipStream_t stream);

@@ -138,3 +138,36 @@ def test_conv_gn_fused_refuses_inputs_larger_than_lds(L):
     g = torch.ones(64, device="cuda")
     y = torch.zeros(2, 16, 16, 64, device="cuda")
     assert L.hab_conv_gn_fwd(P(x), P(pl), P(g), P(g), None, P(y), None, None, None, 2, 32, 32, 32, 64, 3, 3, 2, 1, 16, 1, 1e-5, S()) == -2
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 128, 128), (2, 64, 64), (5, 31, 42), (2, 21, 128), (1, 9, 7)])
+def test_stem_conv_strip_vs_float64(L, B, H, W):
+    """csrc/stem_conv_strip.h (7x7 / 2 / 3, 4 -> 32, input strip in LDS) against float64 and against the im2col contraction."""
+    torch.manual_seed(H * 7 + W)
+    x = torch.randn(B, 4, H, W) * torch.rand(B, 4, H, W).pow(2) * 3
+    w = torch.randn(32, 4, 7, 7) / 14.0
+    ref = F.conv2d(x.double(), w.double(), None, stride=2, padding=3).permute(0, 2, 3, 1)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wf = w.permute(0, 2, 3, 1).contiguous().cuda()
+    planes = torch.zeros(3 * 14 * 512, dtype=torch.int16, device="cuda")
+    _lib.check(L.hab_stem_split_weights(P(wf), P(planes), S()))
+    y = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
+    _lib.check(L.hab_stem_conv_fwd(P(xd), P(planes), P(y), B, H, W, S()))
+    torch.cuda.synchronize()
+    e1 = ((y.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    ws = torch.zeros(1 << 22, device="cuda")
+    y2 = torch.zeros_like(y)
+    _lib.check(L.hab_conv2d_fwd(P(xd), P(wf), None, P(y2), B, H, W, 4, 32, 7, 7, 2, 3, 0, P(ws), ws.numel(), S()))
+    e0 = ((y2.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert e1 <= 2 * e0 + 2e-7 and e1 < 3e-6, (e0, e1)
+    y3 = torch.zeros_like(y)
+    _lib.check(L.hab_stem_conv_fwd(P(xd), P(planes), P(y3), B, H, W, S()))
+    assert torch.equal(y, y3)
+
+
+def test_stem_conv_strip_refuses_wide_inputs(L):
+    x = torch.zeros(1, 8, 300, 4, device="cuda")
+    planes = torch.zeros(3 * 14 * 512, dtype=torch.int16, device="cuda")
+    y = torch.zeros(1, 4, 150, 32, device="cuda")
+    assert L.hab_stem_conv_fwd(P(x), P(planes), P(y), 1, 8, 300, S()) == -2
