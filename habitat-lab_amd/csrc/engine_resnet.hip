@@ -73,6 +73,10 @@ struct ResNetPlan {
     int64_t gdense_floats = 0;
     int cmax = 0;
     int nlayers[4] = {2, 2, 2, 2};
+    // stem of the last forward: GroupNorm + ReLU + max-pool ran fused (the normalised stem output was not stored); stem_act_valid: it
+    // has been materialised since (a debug tap asked for it) -- the backward then takes the unfused form, which reads it as the ReLU
+    // mask (so that activations patched through the tap are honoured, oracle/parity.py::MaskInjector)
+    bool stem_fused = false, stem_act_valid = true;
 };
 
 static int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
@@ -538,7 +542,7 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
         g.x = W + r->stem.w_raw; g.y = nullptr; g.gamma = e->p(r->stem.i_gamma); g.beta = e->p(r->stem.i_beta); g.residual = nullptr;
         g.mean = nullptr; g.rstd = nullptr; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = r->stem.groups; g.relu = 1;
         g.eps = 1e-5f; g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
-        const int rc = groupnorm_relu_maxpool_forward(g, cd.Ho(), cd.Wo(), W + r->w_pool, s);
+        const int rc = groupnorm_relu_maxpool_forward(g, cd.Ho(), cd.Wo(), W + r->w_pool, nullptr, s);
         if (rc != 0 && rc != 1) return rc;
         if (rc == 1) {  // small frames: the register-resident GroupNorm, then the pool
             g.y = W + r->stem.w_out; g.mean = W + r->stem.w_mean; g.rstd = W + r->stem.w_rstd;
@@ -547,10 +551,29 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
         }
         stem_done = true;
     }
+    static const int stem_fuse = hab_env_int("HAB_STEM_FUSE", 1);
+    if (!stem_done && stem_fuse && groupnorm_pool_fusable(B, r->stem.cd.Ho() * r->stem.cd.Wo(), r->stem.cd.Cout, r->stem.groups, e->ws_floats)) {
+        // training forward: the same fused pass, keeping the statistics and the arg-max bytes; the ReLU mask is recomputed in the backward
+        ConvDesc cd = r->stem.cd;
+        cd.B = B;
+        static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
+        const int rcs = (stem_strip && r->stem.pk_p >= 0)
+                            ? stem_conv_forward(x0, reinterpret_cast<const unsigned short*>(e->PK + r->stem.pk_p), W + r->stem.w_raw, B, cd.H, cd.W, s) : 1;
+        if (rcs != 0 && rcs != 1) return rcs;
+        if (rcs == 1) HAB_TRY(conv_fwd(cd, x0, e->PK + r->stem.pk_f, nullptr, W + r->stem.w_raw, 0, W + e->w_ws, e->ws_floats, s));
+        GnArgs g;
+        g.x = W + r->stem.w_raw; g.y = nullptr; g.gamma = e->p(r->stem.i_gamma); g.beta = e->p(r->stem.i_beta); g.residual = nullptr;
+        g.mean = W + r->stem.w_mean; g.rstd = W + r->stem.w_rstd; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = r->stem.groups;
+        g.relu = 1; g.eps = 1e-5f; g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
+        HAB_TRY(groupnorm_relu_maxpool_forward(g, cd.Ho(), cd.Wo(), W + r->w_pool, reinterpret_cast<uint8_t*>(W + r->w_pool_idx), s));
+        r->stem_fused = true; r->stem_act_valid = false;
+        stem_done = true;
+    }
     if (!stem_done) {
         HAB_TRY(conv_gn_forward(e, r->stem, x0, nullptr, 1, B, s));
         HAB_TRY(maxpool_forward(W + r->stem.w_out, W + r->w_pool, reinterpret_cast<uint8_t*>(W + r->w_pool_idx), B, r->stem.cd.Ho(),
                                 r->stem.cd.Wo(), r->stem.cd.Cout, s));
+        r->stem_fused = false; r->stem_act_valid = true;
     }
     for (const auto& blk : r->blocks) {
         const float* in = W + blk.w_in;
@@ -738,9 +761,25 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
     // maxpool + stem
     float* d_n0 = W + r->w_gstem[0];
     float* d_raw0 = W + r->w_gstem[1];
-    HAB_TRY(maxpool_backward(d_out, reinterpret_cast<const uint8_t*>(W + r->w_pool_idx), d_n0, B, r->stem.cd.Ho(), r->stem.cd.Wo(),
-                             r->stem.cd.Cout, s));
-    HAB_TRY(gn_backward(e, r->stem, d_n0, W + r->stem.w_out, d_raw0, nullptr, B, s));
+    if (r->stem_fused && !r->stem_act_valid) {
+        // fused stem: the max-pool gradient is gathered and the ReLU mask recomputed inside the GroupNorm backward kernels -- the
+        // gradient of the (never stored) normalised stem output is not materialised either
+        const RnConv& c = r->stem;
+        GnBwdArgs g;
+        g.x = W + c.w_raw; g.dy = nullptr; g.relu_out = nullptr; g.dx = d_raw0; g.dy_masked = nullptr; g.gamma = e->p(c.i_gamma);
+        g.mean = W + c.w_mean; g.rstd = W + c.w_rstd; g.chan_sums = W + r->w_chansums; g.B = B; g.HW = c.cd.Ho() * c.cd.Wo();
+        g.C = c.cd.Cout; g.groups = c.groups; g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
+        g.pool_dy = d_out; g.pool_idx = reinterpret_cast<const uint8_t*>(W + r->w_pool_idx); g.beta = e->p(c.i_beta);
+        g.pH = c.cd.Ho(); g.pW = c.cd.Wo();
+        HAB_TRY(groupnorm_backward(g, s));
+        const int C = c.cd.Cout;
+        HAB_TRY(colsum(W + r->w_chansums, 2 * C, B, C, e->g(c.i_beta), 0, W + e->w_ws, e->ws_floats, s));
+        HAB_TRY(colsum(W + r->w_chansums + C, 2 * C, B, C, e->g(c.i_gamma), 0, W + e->w_ws, e->ws_floats, s));
+    } else {
+        HAB_TRY(maxpool_backward(d_out, reinterpret_cast<const uint8_t*>(W + r->w_pool_idx), d_n0, B, r->stem.cd.Ho(), r->stem.cd.Wo(),
+                                 r->stem.cd.Cout, s));
+        HAB_TRY(gn_backward(e, r->stem, d_n0, W + r->stem.w_out, d_raw0, nullptr, B, s));
+    }
     ConvDesc c0 = r->stem.cd;
     c0.B = B;
     HAB_TRY(conv_wgrad(c0, W + r->w_x0, d_raw0, e->g(r->stem.i_w), nullptr, ws, e->ws_floats, s));
@@ -753,7 +792,19 @@ int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats) {
     const int64_t B = e->last_B;
     switch (which) {
         case HAB_TAP_ENC_IN: *ptr = W + r->w_x0; *floats = B * r->H2 * r->W2 * r->cpad; return HAB_OK;
-        case HAB_TAP_STEM: *ptr = W + r->stem.w_out; *floats = B * r->stem.out_floats(); return HAB_OK;
+        case HAB_TAP_STEM:
+            if (r->stem_fused && !r->stem_act_valid) {  // the fused forward skipped it: build it from the kept GroupNorm input + statistics
+                const RnConv& c = r->stem;
+                GnArgs g;
+                g.x = W + c.w_raw; g.y = W + c.w_out; g.gamma = e->p(c.i_gamma); g.beta = e->p(c.i_beta); g.residual = nullptr;
+                g.mean = W + c.w_mean; g.rstd = W + c.w_rstd; g.B = (int)B; g.HW = c.cd.Ho() * c.cd.Wo(); g.C = c.cd.Cout; g.groups = c.groups;
+                g.relu = 1; g.eps = 1e-5f;
+                if (hipDeviceSynchronize() != hipSuccess) return HAB_ERR_ARG;
+                HAB_TRY(groupnorm_relu_materialize(g, nullptr));
+                if (hipDeviceSynchronize() != hipSuccess) return HAB_ERR_ARG;
+                r->stem_act_valid = true;  // the backward now reads it as its ReLU mask (unfused form)
+            }
+            *ptr = W + r->stem.w_out; *floats = B * r->stem.out_floats(); return HAB_OK;
         case HAB_TAP_POOL: *ptr = W + r->w_pool; *floats = B * r->poolH * r->poolW * r->stem.cd.Cout; return HAB_OK;
         case HAB_TAP_COMPRESSION: *ptr = W + r->comp.w_out; *floats = B * r->comp.out_floats(); return HAB_OK;
         case HAB_TAP_POOL_IDX: *ptr = W + r->w_pool_idx; *floats = (B * r->poolH * r->poolW * r->stem.cd.Cout + 3) / 4; return HAB_OK;

@@ -23,6 +23,11 @@ struct GnBwdArgs {
     int B, HW, C, groups;
     float* scratch = nullptr;           // optional, >= B * ceil(HW*C / 8192) * 2 * C floats (chunk-parallel path)
     size_t scratch_floats = 0;
+    // Stem form (groupnorm_relu_maxpool_forward): the layer's output went through ReLU + MaxPool2d(3, 2, 1) and was never stored.
+    // dy is then GATHERED from the gradient of the pooled tensor (pool_dy [B][Ho][Wo][C], arg-max bytes pool_idx) and the ReLU mask is
+    // recomputed from x, mean, rstd, gamma, beta with the forward's arithmetic; `dy` / `relu_out` are ignored.  Chunk-parallel path only.
+    const float* pool_dy = nullptr; const uint8_t* pool_idx = nullptr; const float* beta = nullptr;
+    int pH = 0, pW = 0;                 // spatial size of x (pooled: (pH + 1) / 2 x (pW + 1) / 2)
 };
 // 1-D sensor embeddings of PointNavResNetNet.forward (resnet_policy.py:662-753), each 32 wide, written side by side into
 // the RNN input.  Slot kinds:
@@ -86,7 +91,11 @@ int stem_weight_planes(const float* wf, unsigned short* planes, hipStream_t s);
 int stem_conv_forward(const float* x, const unsigned short* planes, float* y, int B, int H, int W, hipStream_t s);  // 1: not covered
 int groupnorm_forward(const GnArgs& a, hipStream_t s);
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s);
-int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, hipStream_t s);  // 1: not applicable
+// GroupNorm + ReLU + MaxPool2d(3, 2, 1) in one pass over the GroupNorm input; the normalised frame is never written.  idx (nullable):
+// arg-max bytes for the backward pass; a.mean / a.rstd (nullable) are written when given.  1: frame not on the chunk-parallel path.
+int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, uint8_t* idx, hipStream_t s);
+bool groupnorm_pool_fusable(int B, int HW, int C, int groups, size_t scratch_floats);  // forward AND backward chunk-parallel forms exist
+int groupnorm_relu_materialize(const GnArgs& a, hipStream_t s);  // y = relu(GroupNorm(x)) from the SAVED a.mean / a.rstd (debug taps)
 int maxpool_forward(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t s);
 int maxpool_backward(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, hipStream_t s);
 // Squeeze-and-excitation gate of SEBottleneck (resnet.py:92-113,155-187): pooled[b][c] = mean_hw x;  y = relu(gate[b][c] * x + residual);

@@ -612,13 +612,21 @@ __global__ void __launch_bounds__(NT) gn_chunk_apply_kernel(const GnArgs a, int 
     }
 }
 
-// Second kernel of the chunk-parallel forward for a stem whose activations are not kept (rollout `act`): merge the chunk statistics,
-// then GroupNorm-apply + ReLU + MaxPool2d(3, 2, 1) in one pass -- the normalised frame (stem.w_out, 512 KB per frame at 256^2) is
-// neither written nor re-read, no arg-max bytes.  thread = (pooled pixel, 4 channels); max(relu(.)) == relu(max(.)).
-// Replaces resnet.py:207-220 (GroupNorm, ReLU, MaxPool2d of `conv1`) inside the rollout's policy.act (ppo_trainer.py:343-399).
+// y = x * sc + sh as ONE fused multiply-add per element: the stem's ReLU mask is recomputed by the backward pass from the same
+// operands, so forward and backward must round identically whatever the compiler's contraction choices
+__device__ __forceinline__ f32x4 gn_affine4(const f32x4 x, const f32x4 sc, const f32x4 sh) {
+    return f32x4{__builtin_fmaf(x[0], sc[0], sh[0]), __builtin_fmaf(x[1], sc[1], sh[1]), __builtin_fmaf(x[2], sc[2], sh[2]),
+                 __builtin_fmaf(x[3], sc[3], sh[3])};
+}
+
+// Second kernel of the chunk-parallel forward for the stem: merge the chunk statistics, then GroupNorm-apply + ReLU +
+// MaxPool2d(3, 2, 1) in one pass -- the normalised frame (512 KB per frame at 256^2 observations) is neither written nor re-read.
+// thread = (pooled pixel, 4 channels).  idx (nullable): window offset of the first maximum in scan order (ATen), for the backward
+// pass; a.mean / a.rstd (nullable): the merged statistics.  Bit-identical to GroupNorm -> ReLU -> max-pool over a stored tensor.
+// Replaces resnet.py:207-220 (GroupNorm, ReLU, MaxPool2d of `conv1`).
 template <int NT, int NV>
 __global__ void __launch_bounds__(256) gn_chunk_apply_pool_kernel(const GnArgs a, int nchunks, const float* __restrict__ part, int H, int W,
-                                                                  float* __restrict__ pool, int blocks_per_frame) {
+                                                                  float* __restrict__ pool, uint8_t* __restrict__ idx, int blocks_per_frame) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
     const int F4 = a.HW * C4;
@@ -640,8 +648,10 @@ __global__ void __launch_bounds__(256) gn_chunk_apply_pool_kernel(const GnArgs a
             const float d = p[(size_t)k * G * 2] - mean;
             m2 += p[(size_t)k * G * 2 + 1] + nk * d * d;
         }
+        const float rs = rsqrtf(m2 / n + a.eps);
         mu_s[t] = mean;
-        rs_s[t] = rsqrtf(m2 / n + a.eps);
+        rs_s[t] = rs;
+        if (bk == 0 && a.mean) { a.mean[(size_t)f * G + t] = mean; a.rstd[(size_t)f * G + t] = rs; }
     }
     __syncthreads();
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
@@ -656,7 +666,8 @@ __global__ void __launch_bounds__(256) gn_chunk_apply_pool_kernel(const GnArgs a
             sc[k] = rs_s[g] * a.gamma[c];
             sh[k] = a.beta[c] - mu_s[g] * sc[k];
         }
-        f32x4 best = {0.f, 0.f, 0.f, 0.f};  // ReLU: every window holds at least one in-image pixel
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int h = ho * 2 - 1 + kh;
@@ -665,14 +676,66 @@ __global__ void __launch_bounds__(256) gn_chunk_apply_pool_kernel(const GnArgs a
             for (int kw = 0; kw < 3; ++kw) {
                 const int w = wo * 2 - 1 + kw;
                 if ((unsigned)w >= (unsigned)W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)h * W + w) * C + c4 * 4) * sc + sh;
+                f32x4 v = gn_affine4(*reinterpret_cast<const f32x4*>(x + ((size_t)h * W + w) * C + c4 * 4), sc, sh);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (v[k] > best[k] || v[k] != v[k]) best[k] = v[k];
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = v[k] > 0.f ? v[k] : 0.f;  // ReLU
+                    if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; bi[k] = kh * 3 + kw; }
+                }
             }
         }
-        *reinterpret_cast<f32x4*>(pool + ((size_t)f * Ho * Wo + pp) * C + c4 * 4) = best;
+        const size_t o = ((size_t)f * Ho * Wo + pp) * C + c4 * 4;
+        *reinterpret_cast<f32x4*>(pool + o) = best;
+        if (idx) *reinterpret_cast<uint32_t*>(idx + o) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     }
+}
+
+// y = relu(GroupNorm(x)) from the saved statistics (materialises the stem output for the debug taps when the fused forward skipped it)
+__global__ void __launch_bounds__(256) gn_relu_from_stats_kernel(const GnArgs a) {
+    const int C = a.C, cpg = C / a.groups, C4 = C >> 2;
+    const long long total = (long long)a.B * a.HW * C4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c4 = (int)(e % C4);
+        const int f = (int)(e / ((long long)a.HW * C4));
+        f32x4 sc, sh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c4 * 4 + k, g = c / cpg;
+            sc[k] = a.rstd[(size_t)f * a.groups + g] * a.gamma[c];
+            sh[k] = a.beta[c] - a.mean[(size_t)f * a.groups + g] * sc[k];
+        }
+        f32x4 v = gn_affine4(*reinterpret_cast<const f32x4*>(a.x + e * 4), sc, sh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        *reinterpret_cast<f32x4*>(a.y + e * 4) = v;
+    }
+}
+
+// Gradient reaching pixel `pix` of the (never stored) stem output through ReLU + MaxPool2d(3, 2, 1): the sum over the <= 4 pooling
+// windows that contain the pixel and chose it (maxpool_bwd_kernel's gather, same order), masked by relu'(y), y recomputed from x.
+__device__ __forceinline__ f32x4 gn_pool_dy(const GnBwdArgs& a, int f, int pix, int c4, const f32x4 xv, const f32x4 sc, const f32x4 sh) {
+    const int H = a.pH, W = a.pW, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int h = pix / W, w = pix - h * W;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
+        if (ho >= Ho) continue;
+        const int kh = h - (ho * 2 - 1);
+        for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
+            if (wo >= Wo) continue;
+            const int kw = w - (wo * 2 - 1);
+            const size_t o = (((size_t)f * Ho + ho) * Wo + wo) * a.C + c4 * 4;
+            const uint32_t id = *reinterpret_cast<const uint32_t*>(a.pool_idx + o);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(a.pool_dy + o);
+            const uint32_t me = (uint32_t)(kh * 3 + kw);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (((id >> (8 * k)) & 0xffu) == me) s[k] += d[k];
+        }
+    }
+    const f32x4 y = gn_affine4(xv, sc, sh);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = y[k] > 0.f ? s[k] : 0.f;
+    return s;
 }
 
 // backward, kernel 1: per-channel partial sums S1 = sum dy', S2 = sum dy' * xhat of the chunk (+ optional dy' write-out)
@@ -687,12 +750,17 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a
     float* c1 = sm + NT * 4;
     const size_t fb = (size_t)f * a.HW * C;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + fb);
-    const f32x4* dy4 = reinterpret_cast<const f32x4*>(a.dy + fb);
-    const f32x4* ro4 = a.relu_out ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
+    const bool pooled = a.pool_dy != nullptr;
+    const f32x4* dy4 = pooled ? nullptr : reinterpret_cast<const f32x4*>(a.dy + fb);
+    const f32x4* ro4 = (a.relu_out && !pooled) ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
     f32x4* dym4 = a.dy_masked ? reinterpret_cast<f32x4*>(a.dy_masked + fb) : nullptr;
-    f32x4 mu, rs;
+    f32x4 mu, rs, psc = {0.f, 0.f, 0.f, 0.f}, psh = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int g = (col * 4 + k) / cpg; mu[k] = a.mean[(size_t)f * G + g]; rs[k] = a.rstd[(size_t)f * G + g]; }
+    if (pooled) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { psc[k] = rs[k] * a.gamma[col * 4 + k]; psh[k] = a.beta[col * 4 + k] - mu[k] * psc[k]; }
+    }
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     f32x4 xv[NV], dv[NV];
 #pragma unroll
@@ -700,7 +768,14 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a
         const int i = base + t + j * NT;
         const bool ok = i < F4;
         xv[j] = ok ? x4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        dv[j] = ok ? dy4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!pooled) dv[j] = ok ? dy4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (pooled) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = base + t + j * NT;
+            dv[j] = i < F4 ? gn_pool_dy(a, f, i / C4, col, xv[j], psc, psh) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     if (ro4) {
 #pragma unroll
@@ -768,8 +843,9 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, 
     const size_t fb = (size_t)f * a.HW * C;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + fb);
     // the masked gradient was written out by kernel 1 when the caller wanted it: read that instead of dy + relu_out
-    const f32x4* dy4 = reinterpret_cast<const f32x4*>((a.dy_masked ? a.dy_masked : a.dy) + fb);
-    const f32x4* ro4 = (a.relu_out && !a.dy_masked) ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
+    const bool pooled = a.pool_dy != nullptr && !a.dy_masked;
+    const f32x4* dy4 = pooled ? nullptr : reinterpret_cast<const f32x4*>((a.dy_masked ? a.dy_masked : a.dy) + fb);
+    const f32x4* ro4 = (a.relu_out && !a.dy_masked && !pooled) ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
     f32x4* dx4 = reinterpret_cast<f32x4*>(a.dx + fb);
     f32x4 xv[NV], dv[NV];
 #pragma unroll
@@ -777,7 +853,17 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, 
         const int i = base + t + j * NT;
         const bool ok = i < F4;
         xv[j] = ok ? x4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        dv[j] = ok ? dy4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!pooled) dv[j] = ok ? dy4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (pooled) {
+        f32x4 psc, psh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { psc[k] = rs[k] * ga[k]; psh[k] = a.beta[col * 4 + k] - mu[k] * psc[k]; }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = base + t + j * NT;
+            dv[j] = i < F4 ? gn_pool_dy(a, f, i / C4, col, xv[j], psc, psh) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     if (ro4) {
 #pragma unroll
@@ -873,10 +959,11 @@ int groupnorm_forward(const GnArgs& a, hipStream_t s) {
     return HAB_OK;
 }
 
-// GroupNorm + ReLU + MaxPool2d(3, 2, 1) with nothing kept for a backward pass; 1: frame not on the chunk-parallel path (the caller
-// runs groupnorm_forward + maxpool_forward).
-int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, hipStream_t s) {
+// GroupNorm + ReLU + MaxPool2d(3, 2, 1) in one pass; 1: frame not on the chunk-parallel path (the caller runs groupnorm_forward +
+// maxpool_forward).
+int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, uint8_t* idx, hipStream_t s) {
     if (!a.x || !a.gamma || !a.beta || !pool || a.HW != H * W || a.residual || !a.relu) return HAB_ERR_ARG;
+    if ((a.mean == nullptr) != (a.rstd == nullptr)) return HAB_ERR_ARG;
     HAB_TRY(gn_check(a.B, a.C, a.groups));
     int nt, nv, nchunks;
     if (gn_reg_cfg(a.HW, a.C, nt, nv)) return 1;
@@ -886,7 +973,20 @@ int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, h
     HAB_LAUNCH_CHECK();
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int bpf = max(1, min(64, cdiv(Ho * Wo * (a.C / 4), 256 * 4)));
-    gn_chunk_apply_pool_kernel<GNC_NT, GNC_NV_F><<<a.B * bpf, 256, 2 * a.groups * sizeof(float), s>>>(a, nchunks, a.scratch, H, W, pool, bpf);
+    gn_chunk_apply_pool_kernel<GNC_NT, GNC_NV_F><<<a.B * bpf, 256, 2 * a.groups * sizeof(float), s>>>(a, nchunks, a.scratch, H, W, pool, idx, bpf);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+bool groupnorm_pool_fusable(int B, int HW, int C, int groups, size_t scratch_floats) {
+    int nt, nv, n1, n2;
+    if (gn_check(B, C, groups) != HAB_OK || gn_reg_cfg(HW, C, nt, nv)) return false;
+    return gn_chunk_cfg(B, HW, C, (size_t)groups * 2, scratch_floats, GNC_NT * GNC_NV_F, n1) &&
+           gn_chunk_cfg(B, HW, C, (size_t)C * 2, scratch_floats, GNC_NT * GNC_NV_B, n2);
+}
+int groupnorm_relu_materialize(const GnArgs& a, hipStream_t s) {
+    if (!a.x || !a.y || !a.gamma || !a.beta || !a.mean || !a.rstd || a.B <= 0 || (a.C & 3) || a.C % a.groups) return HAB_ERR_ARG;
+    const long long total = (long long)a.B * a.HW * (a.C / 4);
+    gn_relu_from_stats_kernel<<<(int)fmin(32768.0, (double)cdivl(total, 256)), 256, 0, s>>>(a);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -978,11 +1078,12 @@ __global__ void __launch_bounds__(256) groupnorm_bwd_kernel(const GnBwdArgs a) {
 }
 
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s) {
-    if (!a.x || !a.dy || !a.dx || !a.gamma || !a.mean || !a.rstd || !a.chan_sums) return HAB_ERR_ARG;
+    if (!a.x || (!a.dy && !a.pool_dy) || !a.dx || !a.gamma || !a.mean || !a.rstd || !a.chan_sums) return HAB_ERR_ARG;
     if (a.dx == a.dy && a.dy_masked) return HAB_ERR_ARG;
     HAB_TRY(gn_check(a.B, a.C, a.groups));
     int nt, nv;
     if (gn_reg_cfg(a.HW, a.C, nt, nv)) {
+        if (a.pool_dy) return HAB_ERR_UNSUPPORTED;  // the stem form exists on the chunk-parallel path only (groupnorm_pool_fusable)
         const size_t lds_r = (size_t)(nt * 4 + 2 * a.C + 2 * a.groups) * sizeof(float);
         HAB_GN_REG_DISPATCH(groupnorm_bwd_reg_kernel, a, lds_r);
         HAB_LAUNCH_CHECK();
@@ -991,6 +1092,7 @@ int groupnorm_backward(const GnBwdArgs& a, hipStream_t s) {
     int nchunks;
     if (a.scratch && gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.C * 2, a.scratch_floats, GNC_NT * GNC_NV_B, nchunks)) {
         const size_t lds1 = (size_t)(GNC_NT * 4 + a.C) * sizeof(float);
+        if (a.pool_dy && (!a.pool_idx || !a.beta || a.pH * a.pW != a.HW)) return HAB_ERR_ARG;
         gn_chunk_bwd_sums_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds1, s>>>(a, nchunks, a.scratch);
         HAB_LAUNCH_CHECK();
         const size_t lds2 = (size_t)(2 * a.C + 2 * a.groups) * sizeof(float);
@@ -998,6 +1100,7 @@ int groupnorm_backward(const GnBwdArgs& a, hipStream_t s) {
         HAB_LAUNCH_CHECK();
         return HAB_OK;
     }
+    if (a.pool_dy) return HAB_ERR_UNSUPPORTED;  // the stem form exists on the chunk-parallel path only (groupnorm_pool_fusable)
     const size_t lds = (size_t)(1024 + 2 * a.C + 2 * a.groups) * sizeof(float);
     groupnorm_bwd_kernel<<<a.B, 256, lds, s>>>(a);
     HAB_LAUNCH_CHECK();
