@@ -14,9 +14,11 @@ hyper-parameters of config/pointnav/ppo_pointnav_habitat_iccv19.yaml (E=4, M=4).
 max-over-ranks wall time, observations generated on the device (inputs never cross PCIe).
 
 Extra objects on the JSON line (rank 0; the sub-records only at N = 1, all measured in THIS run, after the timed region):
-  roofline      the call site with the largest share of the GPU time (conv1 forward: obs ingest + 8x8/4 convolution), HIP-event timed
-                on the launch stream inside the timed region; `kernels` = the same figure for every contraction call site + the
-                recurrent layers, from one extra (untimed) cycle with all probes on
+  roofline      the call site with the largest share of the step ON THE CRITICAL STREAM -- chosen in this run from one untimed
+                cycle with every probe on (`kernels`: ms, share, roofline position of every contraction call site), then HIP-event timed on
+                its launch stream inside the timed region.  The recurrent layers run on the engine's second stream underneath the
+                encoder (csrc/engine.hip): they are reported as `roofline.overlapped` (summed kernel time, launches, serial chain
+                length) and are not candidates for the critical-stream site
   cpu_baseline  the CPU oracle restatement of the reference path over a FULL 64 envs x 128 steps update cycle (kind "port": the
                 reference itself cannot travel to the GPU box; tests/golden pins the oracle to it), torch threads stated
   parity        the same rollout the CPU leg produced, pushed through the HIP path: relative error of the update's losses, of
@@ -350,7 +352,7 @@ def hbm_traffic(workload, probe):
     same command (the newest committed round); null when the probed call site has no entry."""
     if workload != "c2" or probe not in PROBE_KERNELS:
         return None, None
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_c2_hbm_traffic.json")
         if not os.path.exists(path):
             continue
@@ -393,6 +395,7 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop WORLD_SIZE and let bench.py start them)")
     import torch
+    auto_probe = a.probe is None and a.workload == "c2" and world == 1  # site chosen from the all-probes cycle below
     if a.probe is None:
         a.probe = "conv1_fwd" if a.workload == "c2" else ("enc_fwd" if a.workload == "c3_frozen" else "enc_bwd")
     if a.workload == "c5" and a.probe.startswith("enc_"):
@@ -413,6 +416,58 @@ def main():
 
     for _ in range(a.warmup):
         trainer.run_update_cycle()
+    ppo = cfg.habitat_baselines.rl.ppo
+    n_envs, n_steps = WORKLOADS[a.workload].get("envs", NUM_ENVS), WORKLOADS[a.workload].get("steps", NUM_STEPS)
+
+    def frames_seen(probe, local_steps, cycles):  # frames that passed a call site: E update passes (+ rollout + bootstrap for forward sites)
+        f = local_steps * ppo.ppo_epoch
+        return f + (local_steps + n_envs * cycles if probe.endswith("_fwd") and not probe.startswith("rnn") else 0)
+
+    table, overlapped = None, None
+    if a.workload == "c2" and world == 1:
+        # per-call-site table from ONE untimed cycle with every probe on (~1400 event records), BEFORE the timed region: it decides which
+        # site the timed probe brackets.  Single-rank runs only (an extra cycle per rank is fine, but the table is rank 0's business).
+        tags = {k: PROBES[k] for k in C2_TABLE}
+        eng.probe_enable_mask([t for t, _ in tags.values()])
+        l0 = trainer.local_steps_done
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        trainer.run_update_cycle()
+        torch.cuda.synchronize()
+        cyc_ms = (time.perf_counter() - c0) * 1e3
+        ls = trainer.local_steps_done - l0
+        table = []
+        for k, (t_, fl) in tags.items():
+            ms, cnt = eng.probe_read_tag(t_)
+            if cnt:
+                fs = frames_seen(k, ls, 1)
+                sr = site_roofline(k, fl, fs, ms)
+                row = {"site": k, "ms": round(ms, 2), "calls": cnt, "share": round(ms / cyc_ms, 4),
+                       "tflops": sr.get("fp32_equiv_tflops", sr["achieved"]), "bound": sr["bound"], "achieved": sr["achieved"],
+                       "peak": sr["peak"], "unit": sr["unit"], "frac": sr["frac"], "stream": "second (overlapped)" if k.startswith("rnn") else "critical"}
+                if "frac_of_split_ceiling" in sr:
+                    row["frac_of_split_ceiling"] = sr["frac_of_split_ceiling"]
+                # HBM bytes of the update-sized launch (committed --pmc passes of this command) over its algorithmic bytes
+                tr, _ = hbm_traffic(a.workload, k)
+                if tr is not None and k in SITE_MODEL:
+                    upd_frames = fs / cnt if k in PERSISTENT_GRID_SITES else n_envs * n_steps // ppo.num_mini_batch // site_chunks(k)
+                    row["traffic"] = tr
+                    row["traffic_ratio"] = round(tr / (SITE_MODEL[k][0] * upd_frames), 3)
+                table.append(row)
+        eng.probe_read()
+        eng.probe_enable(-1)
+        table.sort(key=lambda r: -r["ms"])
+        rnn = [r for r in table if r["site"].startswith("rnn")]
+        if rnn:
+            # the recurrence of a minibatch is a chain of dependent step launches (T forward + T backward per layer) on the second stream
+            overlapped = {"sites": rnn, "summed_kernel_ms_per_cycle": round(sum(r["ms"] for r in rnn), 2),
+                          "serial_chain_launches_per_cycle": int(ppo.ppo_epoch * ppo.num_mini_batch * 2 * n_steps),
+                          "note": "recurrent layers: time-major chunks on the engine's second stream underneath the encoder (forward) / the "
+                                  "data-gradient chain (backward); event pairs are per layer call, so `ms` is the wall time of the chained "
+                                  "launches beside the convolutions, not exclusive GPU time"}
+        crit = [r for r in table if not r["site"].startswith("rnn")]
+        if auto_probe and crit:
+            a.probe = crit[0]["site"]
     tag, flops_per_frame = PROBES[a.probe]
     eng.probe_enable(tag)
     barrier()
@@ -435,18 +490,11 @@ def main():
     if rank != 0:
         torch.distributed.destroy_process_group()
         return
-    ppo = cfg.habitat_baselines.rl.ppo
-    n_envs, n_steps = WORKLOADS[a.workload].get("envs", NUM_ENVS), WORKLOADS[a.workload].get("steps", NUM_STEPS)
     # env-steps actually collected over all ranks (the trainer's all-reduced counter): equals world * n_envs * n_steps * K unless
     # DD-PPO's preemptive straggler rule cut a rollout short (ppo_trainer.py:641-653), in which case only the collected steps count
     steps_total = trainer.num_steps_done - steps_before
     assert 0 < steps_total <= world * n_envs * n_steps * a.steps
     local_steps = trainer.local_steps_done - local_before
-
-    def frames_seen(probe, local_steps, cycles):  # frames that passed a call site: E update passes (+ rollout + bootstrap for forward sites)
-        f = local_steps * ppo.ppo_epoch
-        return f + (local_steps + n_envs * cycles if probe.endswith("_fwd") and not probe.startswith("rnn") else 0)
-
     frames = frames_seen(a.probe, local_steps, a.steps)
     if a.probe.startswith("enc_"):
         kname = f"resnet encoder {a.probe[4:]} (all kernels)"
@@ -493,43 +541,16 @@ def main():
                                           # against the pipe in use: bf16 MFMA peak / 6 partial products (conv1: 3.75, priced at 6 here)
                                           "frac_of_split_ceiling": round(rate * f_exec / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12), 4),
                                           "split_ceiling_tflops": round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)}
-    if a.workload == "c2" and world == 1:
-        # per-call-site table from ONE extra cycle with every probe on (outside the timed region: ~1400 event records per cycle).
-        # Single-rank runs only: the other ranks of a multi-rank run have left by now and an extra cycle would wait on their
-        # collectives forever.
-        tags = {k: PROBES[k] for k in C2_TABLE}
-        eng.probe_enable_mask([t for t, _ in tags.values()])
-        l0 = trainer.local_steps_done
-        c0 = time.perf_counter()
-        trainer.run_update_cycle()
-        torch.cuda.synchronize()
-        cyc_ms = (time.perf_counter() - c0) * 1e3
-        ls = trainer.local_steps_done - l0
-        table = []
-        for k, (t_, fl) in tags.items():
-            ms, cnt = eng.probe_read_tag(t_)
-            if cnt:
-                fs = frames_seen(k, ls, 1)
-                sr = site_roofline(k, fl, fs, ms)
-                row = {"site": k, "ms": round(ms, 2), "calls": cnt, "share": round(ms / cyc_ms, 4),
-                       "tflops": sr.get("fp32_equiv_tflops", sr["achieved"]), "bound": sr["bound"], "achieved": sr["achieved"],
-                       "peak": sr["peak"], "unit": sr["unit"], "frac": sr["frac"]}
-                if "frac_of_split_ceiling" in sr:
-                    row["frac_of_split_ceiling"] = sr["frac_of_split_ceiling"]
-                # HBM bytes of the update-sized launch (committed --pmc passes of this command) over its algorithmic bytes
-                tr, _ = hbm_traffic(a.workload, k)
-                if tr is not None and k in SITE_MODEL:
-                    upd_frames = fs / cnt if k in PERSISTENT_GRID_SITES else n_envs * n_steps // ppo.num_mini_batch // site_chunks(k)
-                    row["traffic"] = tr
-                    row["traffic_ratio"] = round(tr / (SITE_MODEL[k][0] * upd_frames), 3)
-                table.append(row)
-        eng.probe_read()
-        eng.probe_enable(-1)
-        out["roofline"]["kernels"] = sorted(table, key=lambda r: -r["ms"])
+    if table is not None:
+        out["roofline"]["kernels"] = table
+        out["roofline"]["site_choice"] = ("largest share of the step among the call sites of the critical stream in this run's all-probes cycle"
+                                          if auto_probe else "--probe")
+    if overlapped is not None:
+        out["roofline"]["overlapped"] = overlapped
     if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         base, par = cpu_baseline_and_parity(trainer, cfg, cpu_threads=(os.cpu_count() or 1) if a.cpu_threads < 0 else a.cpu_threads)
-        other = os.path.join(ROOT, "profiles", "r03_cpu_leg_threads.json")
-        if os.path.exists(other):  # the same leg timed once at every thread setting on the GPU box's host (committed measurement)
+        other = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{t_}_cpu_leg_threads.json") for t_ in ("r04", "r03")) if os.path.exists(p_)), "")
+        if other:  # the same leg timed once at every thread setting on the GPU box's host (committed measurement)
             base["thread_settings_measured"] = json.load(open(other))
         out["cpu_baseline"] = base
         if par:
@@ -538,7 +559,7 @@ def main():
         del trainer, eng
         torch.cuda.empty_cache()
         if not a.no_extras:
-            out["c3"] = run_cycles("c3", 3, 1)
+            out["c3"] = run_cycles("c3", 10, 2)
             out["encoder_r18_b8192"] = encoder_record()
     if world > 1:
         out["note"] = ("n_gpus > 1: `cpu_baseline`, `parity`, the per-site `kernels` table and the c3 / encoder sub-records are reported by the "

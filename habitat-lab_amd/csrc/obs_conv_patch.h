@@ -17,7 +17,7 @@
 // = the 60 MFMAs of obs_conv_bf3.h, with one fragment read per three of them on the A side.
 // Two groups of four waves alternate between a matrix interval and a memory interval (see the kernel).  Measured at 2048 frames:
 // 0.80-0.84 ms against 0.96 (obs_conv_bf3_ws.h) and 1.0 (obs_conv_bf3.h); ablation (HAB_OCP_ABLATE): MFMAs alone 0.45, loads + conversion 0.29,
-// stores 0.16 -- the two sides still overlap only partly (profiles/r03_conv1_patch.txt).
+// stores 0.16 -- the two sides still overlap only partly.
 #pragma once
 #include <utility>
 

@@ -6,18 +6,18 @@
 #       FETCH_SIZE, WRITE_SIZE (C2 and C3)            -> tools/pmc_traffic.py -> HBM bytes per launch
 #       SQ busy / MFMA-busy / wait / instruction mix  -> tools/pmc_sq.py      -> per-kernel matrix-pipe utilisation (C2: all three
 #                                                        counter groups; C3, C5: the busy / MFMA-busy group)
-#   * the CPU leg of bench.py once more with every host core (the default line uses 16 threads) -> <tag>_cpu_leg_threads.json
+#   * the CPU leg of bench.py at 32 and 64 host threads as well (the default line uses 16) -> <tag>_cpu_leg_threads.json
 # Every profiler pass runs under `timeout`: a rocprofv3 --pmc pass of the C3 command once hung until gpurun's limit.
 # usage: tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>_*   (copy what is to be judged into profiles/)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 python bench.py > $O/${TAG}_c2_bench.json 2> $O/${TAG}_c2_bench.err
-python bench.py --workload c3 --steps 3 --warmup 1 > $O/${TAG}_c3_bench.json 2> $O/${TAG}_c3_bench.err
-python bench.py --workload c5 --steps 3 --warmup 1 > $O/${TAG}_c5_bench.json 2> $O/${TAG}_c5_bench.err
+python bench.py --workload c3 --steps 10 --warmup 2 > $O/${TAG}_c3_bench.json 2> $O/${TAG}_c3_bench.err
+python bench.py --workload c5 --steps 5 --warmup 2 > $O/${TAG}_c5_bench.json 2> $O/${TAG}_c5_bench.err
 cd /tmp
 for W in c2 c3 c5; do
   rm -rf /tmp/prof_${TAG}_$W
@@ -45,16 +45,20 @@ for W in c3 c5; do
   python tools/pmc_sq.py /tmp/pmcsq_${TAG}_$W $O/${TAG}_${W}_sq_counters.txt > /dev/null
   rm -rf /tmp/pmcsq_${TAG}_$W
 done
-timeout 400 python bench.py --steps 1 --warmup 1 --no-extras --cpu-threads -1 > $O/${TAG}_c2_cpu_allcores.json 2> $O/${TAG}_c2_cpu_allcores.err
+# the CPU leg at further thread settings (the default line uses 16; every core of the 256-thread host did not finish in 400 s in round 3)
+for TH in 32 64; do
+  timeout 300 python bench.py --steps 1 --warmup 1 --no-extras --cpu-threads $TH > $O/${TAG}_c2_cpu_${TH}.json 2> $O/${TAG}_c2_cpu_${TH}.err
+done
 python - <<PY
 import json
 rows = []
-for f in ("$O/${TAG}_c2_bench.json", "$O/${TAG}_c2_cpu_allcores.json"):
+for f in ("$O/${TAG}_c2_bench.json", "$O/${TAG}_c2_cpu_32.json", "$O/${TAG}_c2_cpu_64.json"):
     try:
         c = json.loads(open(f).read().strip().splitlines()[-1])["cpu_baseline"]
         rows.append({"threads": c["cores"], "env_steps_per_s": c["value"]})
     except Exception as e:
         print("cpu leg missing in", f, e)
+rows.append({"threads": 256, "env_steps_per_s": None, "note": "not finished after 400 s (round 3 measurement, < 20.5 env-steps/s)"})
 json.dump(rows, open("$O/${TAG}_cpu_leg_threads.json", "w"))
 print(rows)
 PY
