@@ -192,12 +192,9 @@ inline int conv2_dgrad_strip(const ConvDesc& d, const float* dy, const float* wd
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");
     a.sign_schedule = sign_schedule;
     auto kern = conv2_dgrad_strip_kernel<R2>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    if (attr_err != hipSuccess) return (int)attr_err;
     int grid = 256;
     while (grid > 8 && grid > a.items) grid -= 8;
     kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(a);

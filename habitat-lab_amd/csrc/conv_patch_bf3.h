@@ -328,24 +328,18 @@ inline int conv_patch_bf3_launch(const P& p, PatchGeom gq, float* ws, size_t ws_
     hipError_t e = hipSuccess;
     if (pre) {
         auto kern = conv_patch_bf3_kernel<P, TW, WM, WN, TN, BT, true>;
-        static bool attr_set = false;
-        if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
+        static const hipError_t attr_err = (Cfg::LDS_BYTES > 64 * 1024) ? hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES) : hipSuccess;
+        if (attr_err != hipSuccess) return (int)attr_err;
         unsigned short* planes = reinterpret_cast<unsigned short*>(ws);
         cpb_split_weights<<<(unsigned)((wn_elems + 255) / 256), 256, 0, stream>>>(p.w, wn_elems, planes);
         HAB_LAUNCH_CHECK();
         kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, gq, sign_schedule, planes, wn_elems);
     } else {
         auto kern = conv_patch_bf3_kernel<P, TW, WM, WN, TN, BT, false>;
-        static bool attr_set = false;
-        if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
+        static const hipError_t attr_err = (Cfg::LDS_BYTES > 64 * 1024) ? hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES) : hipSuccess;
+        if (attr_err != hipSuccess) return (int)attr_err;
         kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, gq, sign_schedule, nullptr, 0);
     }
     HAB_LAUNCH_CHECK();

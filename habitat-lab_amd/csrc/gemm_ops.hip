@@ -17,6 +17,8 @@
 #include "prob_build.h"
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "../../include/habitat_amd.h"
 
 namespace hab {
@@ -33,14 +35,20 @@ static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); ret
 // bit 4: input-patch-resident stride-1 3x3 convolutions (conv_patch_bf3.h), bit 5: producer / consumer waves where they won
 // (igemm_bf3_ws.h: long-K 128 x 128 forward-form tiles; obs_conv_bf3_ws.h: the observation-ingest convolution), bit 6: the
 // observation-ingest convolution with the input patch resident in LDS (obs_conv_patch.h)
-static int g_bf3_mode = -1;
+static std::atomic<int> g_bf3_mode{-1};  // engines of several inference-worker threads dispatch concurrently
 static int bf3_mode() {
-    if (g_bf3_mode < 0) g_bf3_mode = hab_env_int("HAB_BF3", 1023);
-    return g_bf3_mode;
+    int m = g_bf3_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        static const int from_env = hab_env_int("HAB_BF3", 1023);
+        int expected = -1;
+        g_bf3_mode.compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
+        m = g_bf3_mode.load(std::memory_order_relaxed);
+    }
+    return m;
 }
 extern "C" int hab_set_matrix_path(int mode) {
     const int prev = bf3_mode();
-    if (mode >= 0) g_bf3_mode = mode;
+    if (mode >= 0) g_bf3_mode.store(mode, std::memory_order_relaxed);
     return prev;
 }
 

@@ -431,12 +431,9 @@ inline int igemm_bf3_launch(const P& p, float* ws, size_t ws_floats, int target_
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return HAB_ERR_ARG;
     const IgemmPlan pl = igemm_plan(Cfg::BM, Cfg::BN, p.M, p.N, p.K, target_blocks, 4096, ws ? ws_floats : 0);
     auto kern = igemm_bf3_kernel<P, TM, TN, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
+    static const hipError_t attr_err = (Cfg::LDS_BYTES > 64 * 1024) ? hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES) : hipSuccess;
+    if (attr_err != hipSuccess) return (int)attr_err;
     const int ntiles = cdiv(p.M, Cfg::BM) * cdiv(p.N, Cfg::BN);
     const int grid = pl.splits >= 16 ? ntiles * ((pl.splits + 7) / 8 * 8) : ntiles * pl.splits;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");  // development: measure the cost of the sign schedule

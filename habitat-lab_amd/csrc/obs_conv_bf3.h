@@ -250,12 +250,9 @@ inline int obs_conv_bf3_launch(const ObsConvFwdProb& p, float* ws, size_t ws_flo
     obs_conv_bf3_split_weights<<<cdiv(2 * NP * p.K, 256), 256, 0, stream>>>(p.w, p.N, p.K, NP, planes);
     HAB_LAUNCH_CHECK();
     auto kern = obs_conv_bf3_kernel<TM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    if (attr_err != hipSuccess) return (int)attr_err;
     static const int wg_per_cu = hab_env_int("HAB_OBF_WGS", 2);
     const int ntiles = cdiv(p.M, Cfg::BM) * cdiv(p.N, 32);
     const int grid = ntiles < 256 * wg_per_cu ? ntiles : 256 * wg_per_cu;

@@ -278,12 +278,9 @@ inline int obs_conv_bf3_ws_launch(const ObsConvFwdProb& p, float* ws, size_t ws_
     unsigned short* planes = reinterpret_cast<unsigned short*>(ws);
     obs_conv_bf3_split_weights<<<cdiv(2 * NPAD * p.K, 256), 256, 0, stream>>>(p.w, p.N, p.K, NPAD, planes);
     HAB_LAUNCH_CHECK();
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(obs_conv_bf3_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(obs_conv_bf3_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    if (attr_err != hipSuccess) return (int)attr_err;
     const int ntiles = cdiv(p.M, Cfg::BM);
     const int grid = ntiles < 256 ? ntiles : 256;  // persistent: one workgroup per CU
     obs_conv_bf3_ws_kernel<<<(grid + 7) / 8 * 8, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, planes, NPAD);

@@ -348,12 +348,9 @@ inline int obs_conv_patch_launch(const ObsConvFwdProb& p, float* ws, size_t ws_f
     obs_patch_split_weights<<<32, 256, 0, stream>>>(p.w, p.N, wimg);
     HAB_LAUNCH_CHECK();
     auto kern = obs_conv_patch_kernel<5>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_err != hipSuccess) return (int)attr_err;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");
     static const int ablate = hab_env_int("HAB_OCP_ABLATE", 0);
     const int pairs = (gq.ntiles + 1) / 2;

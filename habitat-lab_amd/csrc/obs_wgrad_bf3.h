@@ -216,13 +216,9 @@ inline int obs_wgrad_bf3_launch(const ObsConvWgradProb& p, float* ws, size_t ws_
     if ((size_t)wgs * MP * p.N > ws_floats) return 1;
     gg.tiles_per_wg = cdiv(gg.tiles, wgs);
     wgs = cdiv(gg.tiles, gg.tiles_per_wg);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(obs_wgrad_bf3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)OWG_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
+    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(obs_wgrad_bf3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)OWG_LDS_BYTES);
+    if (attr_err != hipSuccess) return (int)attr_err;
     obs_wgrad_bf3_kernel<<<wgs, 256, OWG_LDS_BYTES, stream>>>(p, gg, ws);
     HAB_LAUNCH_CHECK();
     if (wgs > 1) {

@@ -253,12 +253,9 @@ inline int wgrad3x3_bf3_run(const ConvWgradProb& p, float* ws, size_t ws_floats,
     a.sign_schedule = sign_schedule;
     a.colsum = p.colsum != nullptr;
     auto kern = wgrad3x3_bf3_kernel<C32, N32, W, PAD, KHW, S, R, KS, NS>;
-    static bool attr_set = false;
-    if (!attr_set && Cfg::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
+    static const hipError_t attr_err = (Cfg::LDS_BYTES > 64 * 1024) ? hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES) : hipSuccess;
+    if (attr_err != hipSuccess) return (int)attr_err;
     const size_t MN = (size_t)(KHW * KHW * Cfg::C + (a.colsum ? 1 : 0)) * Cfg::N;
     const int per_cu = (int)std::min<size_t>(Cfg::NT <= 192 ? 4 : 2, (160 * 1024) / Cfg::LDS_BYTES);
     int grid = 256 * std::max(per_cu, 1);

@@ -351,7 +351,11 @@ class InferenceWorkerPool:
                 iw.try_one_step()
                 iw.update_should_end_early()
                 self.check()
-            iw.finish_rollout()
+            try:
+                iw.finish_rollout()
+            except threading.BrokenBarrierError:
+                self.check()  # a worker thread failed and aborted the barrier: surface ITS error, not the broken barrier
+                raise
         while not self.sync.rollout_done.wait(timeout=0.5):
             self.check()
         self.check()

@@ -123,7 +123,8 @@ class PreemptionDecider:
 
     def update(self, num_next_steps: int) -> None:
         all_num_next_steps = self._gather(np.array([num_next_steps], dtype=np.int64))
-        my_step_averages = np.array([v.mean if v.count else 0.0 for v in self.step_averages], dtype=np.float64)
+        with self._lock:  # the inference-worker threads add to the averages (policy_step)
+            my_step_averages = np.array([v.mean if v.count else 0.0 for v in self.step_averages], dtype=np.float64)
         all_step_averages = self._gather(my_step_averages)
         lt = max(self._reduce_mean(float(self.learner_time_avg.mean) if self.learner_time_avg.count else 0.0), 0.01)
         target_length_time, max_possible_steps = -1.0, 0.0
@@ -148,11 +149,13 @@ class PreemptionDecider:
 
     def start_rollout(self, start_time: Optional[float] = None) -> None:
         start_time = time.perf_counter() if start_time is None else start_time
-        self.start_time = self._all_reduce(start_time - self.my_t_zero, op=torch.distributed.ReduceOp.MIN)
-        self.n_rollouts_started += 1
-        self.last_step_times[:] = -1.0
-        self.started = True
-        self.rollout_ends.time = self.my_t_zero + self.start_time + self.opt_rollout_time_avg.mean if self._ready() else -1.0
+        t_min = self._all_reduce(start_time - self.my_t_zero, op=torch.distributed.ReduceOp.MIN)  # (collective: outside the lock)
+        with self._lock:  # policy_step runs on the inference-worker threads (the reference serialises all events through one queue)
+            self.start_time = t_min
+            self.n_rollouts_started += 1
+            self.last_step_times[:] = -1.0
+            self.started = True
+            self.rollout_ends.time = self.my_t_zero + self.start_time + self.opt_rollout_time_avg.mean if self._ready() else -1.0
 
     def end_rollout(self, num_next_steps: int, end_steps_time: Optional[float] = None) -> None:
         end_steps_time = time.perf_counter() if end_steps_time is None else end_steps_time
@@ -162,13 +165,15 @@ class PreemptionDecider:
                                                 expected_steps_collected=self.expected_steps_collected,
                                                 real_rollout_time=(end_steps_time - self.start_time) * 1e3,
                                                 expected_rollout_time=self.opt_rollout_time_avg.mean * 1e3))
-        if self.rollout_ends.time > 0:
-            self.preemption_error_time_avg += (end_steps_time - self.start_time) - self.opt_rollout_time_avg.mean
-        self.started = False
-        self.rollout_ends.time = -1.0
-        self.rollout_ends.steps = -1.0
+        with self._lock:
+            if self.rollout_ends.time > 0:
+                self.preemption_error_time_avg += (end_steps_time - self.start_time) - self.opt_rollout_time_avg.mean
+            self.started = False
+            self.rollout_ends.time = -1.0
+            self.rollout_ends.steps = -1.0
         self.update(num_next_steps)
-        self.real_steps_collected = 0
+        with self._lock:
+            self.real_steps_collected = 0
 
     def learner_time(self, learner_time: float) -> None:
         self.learner_time_avg += learner_time

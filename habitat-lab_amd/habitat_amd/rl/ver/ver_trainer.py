@@ -205,8 +205,17 @@ class VERTrainer(PPOTrainer):
                     self._published.publish(self._agent.actor_critic.engine)
                 if not self._overlap:
                     self.learning_rollouts.after_update()
+                    # The version moves BEFORE the workers are released: a private-engine worker reloads the published weights only
+                    # when it sees `cpu_current_policy_version` change, and the holder of the replay requests steps the moment it
+                    # wakes up -- released first, it would act (values that bootstrap the returns, the actions that open the next
+                    # rollout) on the previous parameters while stamping the steps with the new version.  The workers are parked
+                    # here, so nothing races the increment (the reference's non-overlapped workers share the learner's live tensors).
+                    self._agent.rollouts.increment_policy_version()
+                    if self._decider is not None:
+                        self._decider.start_rollout()  # armed before the first batch of the rollout is stepped (its step times count)
                     self._iw_pool.start_next(self.device)  # after the buffer reordering has drained: worker streams write slots next
-                self._agent.rollouts.increment_policy_version()
+                else:
+                    self._agent.rollouts.increment_policy_version()
         self._learning_time = (time.perf_counter() - t1) + t_returns
         self._agent.after_update()
         if self._decider is not None:
@@ -218,8 +227,8 @@ class VERTrainer(PPOTrainer):
         ro = self._agent.rollouts
         if self._main_is_iw:
             self._agent.eval()
-        if self._decider is not None and not self._overlap:
-            self._decider.start_rollout()
+        if self._decider is not None and not self._overlap and not self._decider.started:
+            self._decider.start_rollout()  # the very first rollout (later ones are armed in _update_agent, before the workers wake)
         with self.timer.avg_time("rollout"):
             self._iw_pool.collect(ro)
             ro.after_rollout()

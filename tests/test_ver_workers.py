@@ -168,9 +168,14 @@ class Harness:
             self.published.publish(self.learner_policy.engine)
         if not self.overlap:
             self.learning.after_update()
+            # VERTrainer._update_agent: the version moves BEFORE the parked workers are released (a private engine reloads the
+            # published weights only when it sees the version change; the holder of the replay requests steps as soon as it wakes)
+            self.ro.cpu_current_policy_version += 1
+            self.ro.current_policy_version += 1
             self.pool.start_next()
-        self.ro.cpu_current_policy_version += 1
-        self.ro.current_policy_version += 1
+        else:
+            self.ro.cpu_current_policy_version += 1
+            self.ro.current_policy_version += 1
         return out
 
 
@@ -344,5 +349,26 @@ def test_rollouts_that_end_at_the_preemption_deadline_lose_nothing(n_workers, ov
         for e in range(N):                                  # ... and no step of any environment went missing
             te = sorted(b for a, b in seen_pairs if a == e)
             assert te == list(range(len(te))), (e, te)
+    finally:
+        h.pool.shutdown()
+
+
+@pytest.mark.parametrize("n_workers", [2, 3])
+def test_non_overlapped_workers_never_act_on_stale_parameters(n_workers):
+    """with private-engine workers and no overlap, every step of rollout k + 1 -- including the replayed final batch
+    that opens it and bootstraps the returns -- must be computed with the parameters of the version it is stamped with.  The stand-in
+    policy encodes its engine's parameter arena in the value estimate (w * 1e6, w = number of updates = version - 1)."""
+    N, T = 6, 5
+    h = Harness(N, T, n_workers, False, [20.0, 10.0, 2.0, 20.0, 4.0, 0.25], seed=7)
+    try:
+        def learn(st):
+            B = st.buffers
+            n = int(st.ptr[0])
+            w = torch.floor(B["value_preds"].view(-1)[:n] / 1e6).long()
+            ver = B["policy_version"].view(-1)[:n]
+            assert torch.equal(w, ver - 1), (w.tolist(), ver.tolist())
+            return int(ver.max())
+        tops = [h.cycle(learn) for _ in range(6)]
+        assert tops[-1] >= 5, tops  # the later rollouts were collected under the later versions
     finally:
         h.pool.shutdown()
