@@ -160,9 +160,9 @@ class InferenceWorker:
         ro, tr = self.rollouts, self.transport
         version = int(ro.cpu_current_policy_version[0, 0])
         if version != self._current_policy_version:
-            self._current_policy_version = version
             if self.published is not None:  # private engine: take over the parameters of the version that was just completed
                 self.published.load_into(self.actor_critic.engine)
+            self._current_policy_version = version  # after the load: an observer never sees the new version beside the old parameters
         current_steps = ro.current_steps.copy()
         final_batch = False
         slots = None
