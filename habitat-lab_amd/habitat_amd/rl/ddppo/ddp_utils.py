@@ -123,6 +123,32 @@ def init_distrib_slurm(backend: str = "nccl"):
     return local_rank, tcp_store
 
 
+def rank_cpu_block(cpus, local_rank: int, local_world: int):
+    """The CPUs of local rank r of w: the r-th of w contiguous blocks of the sorted CPU list (contiguous ranges share a NUMA node and,
+    on SMT hosts, lie on one side of the sibling split).  Falls back to the whole list when there are fewer CPUs than ranks."""
+    cpus = sorted(cpus)
+    if local_world <= 1 or len(cpus) < local_world:
+        return cpus
+    per = len(cpus) // local_world
+    return cpus[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank_affinity(local_rank: int, local_world: Optional[int] = None):
+    """One process per GPU, each enqueueing ~7 500 launches per update cycle: without pinning, 8 ranks' host threads migrate across the
+    sockets of the node and share cores with each other's environment workers.  Restricts this process (and the threads / workers it
+    starts afterwards) to its block of the CPUs it may run on.  HAB_NO_AFFINITY=1 leaves the affinity alone.  Returns the chosen CPUs."""
+    if os.environ.get("HAB_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+        return None
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("SLURM_NTASKS_PER_NODE", "1")) or 1)
+    block = rank_cpu_block(os.sched_getaffinity(0), local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, block)
+    except OSError:
+        return None
+    return block
+
+
 def rank0_only(fn: Optional[Callable] = None):
     """Predicate (`rank0_only()`) and decorator (`@rank0_only`) -- ddp_utils.py:100-138."""
     if fn is None:

@@ -29,7 +29,7 @@ from habitat_amd.common.env_factory import instantiate
 from habitat_amd.common.obs_transformers import (apply_obs_transforms_batch, apply_obs_transforms_obs_space,
                                                  get_active_obs_transforms)
 from habitat_amd.config.default import read_write
-from habitat_amd.rl.ddppo.ddp_utils import (EXIT, StoreCounterPoller, get_distrib_size, init_distrib_slurm, load_resume_state, rank0_only,
+from habitat_amd.rl.ddppo.ddp_utils import (EXIT, StoreCounterPoller, get_distrib_size, init_distrib_slurm, load_resume_state, pin_rank_affinity, rank0_only,
                                             requeue_job, save_resume_state)
 from habitat_amd.rl.ppo.policy import VISUAL_FEATURES_KEY
 from habitat_amd.rl.ppo.single_agent_access_mgr import EnvironmentSpec
@@ -115,6 +115,7 @@ class PPOTrainer(BaseRLTrainer):
         self._add_preemption_signal_handlers()
         if self._is_distributed:
             local_rank, tcp_store = init_distrib_slurm(hb.rl.ddppo.distrib_backend)
+            pin_rank_affinity(local_rank)  # each rank's launch thread (and its env workers) on its own block of host cores
             if rank0_only():
                 logger.info("Initialized DD-PPO with {} workers".format(torch.distributed.get_world_size()))
             with read_write(self.config):

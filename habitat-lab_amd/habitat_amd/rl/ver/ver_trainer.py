@@ -14,10 +14,12 @@ the workers act with the parameters of the last COMPLETED policy version, which 
 Environment workers are the process-per-environment VectorEnv workers (shared-memory observation plane) or, for the synthetic
 benchmark source, the device-resident generator.
 
-Straggler preemption (ver_trainer.py:224-233, rl/ver/preemption_decider.py): the schedule and the early-end mechanics are built and
-checked on the CPU (arithmetic against the reference's own function, the worker protocol with deadlines, the collectives at world size 2)
-but have not run on a multi-GPU node yet, so they are OFF unless HAB_VER_PREEMPTION=1: by default a rollout collects its full step
-quota, and under VER + DD-PPO every rank waits at the barrier of `_update_agent` for the slowest rank's quota (no effect on results)."""
+Straggler preemption (ver_trainer.py:158,224-233, rl/ver/preemption_decider.py): started whenever `variable_experience` is on, as the
+reference does.  Checked on the CPU: the schedule's arithmetic against the reference's own function, the worker protocol with deadlines,
+the collectives at world sizes 2 and 8 with an injected 3x slower rank (tests/test_distributed_gloo.py); on one GPU the trainer runs with
+it (tests/test_gpu_ver.py).  HAB_VER_PREEMPTION=0 switches it off: every rollout then collects its full step quota and under VER +
+DD-PPO every rank waits at the barrier of `_update_agent` for the slowest rank's quota (runs that must reproduce a rollout bit for bit
+across modes -- the overlapped-vs-sequential test -- do that, since a deadline depends on wall-clock step times)."""
 from __future__ import annotations
 
 import contextlib
@@ -131,7 +133,7 @@ class VERTrainer(PPOTrainer):
         self._iw_queue = RequestQueue(self.transport)
         self._published = PublishedWeights(self._agent.actor_critic.engine) if (n_iw > 1 or overlap) else None
         self._decider = None
-        if os.environ.get("HAB_VER_PREEMPTION") == "1" and self.ver_config.variable_experience:
+        if os.environ.get("HAB_VER_PREEMPTION", "1") != "0" and self.ver_config.variable_experience:
             world = torch.distributed.get_world_size() if self._is_distributed else 1
             rank = torch.distributed.get_rank() if self._is_distributed else 0
             # host-side numpy arrays travel: a gloo group next to the RCCL one (the reference's decider opens its own, :331-334)

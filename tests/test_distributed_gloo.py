@@ -104,25 +104,32 @@ def _worker(rank, world, port, q):
     losses = t._coalesce_post_step(dict(value_loss=1.0 + rank, action_loss=-2.0 * (rank + 1)), 64 * (rank + 1))
     out["losses"], out["steps"] = losses, t.num_steps_done
     out["win_count"] = t.window_episode_stats["count"][-1].clone()
-    # preemptive sync: before 25% of the rollout never; afterwards once >= sync_frac * world ranks are done
+    # preemptive sync: before 25% of the rollout never; afterwards once >= sync_frac * world ranks are done (k = 0 .. world finished)
     T = cfg.habitat_baselines.rl.ppo.num_steps
     dist.barrier()
-    early_before = t.should_end_early(T // 4 - 1)
-    none_done = t.should_end_early(T // 2)
-    dist.barrier()
-    if rank == 0:
-        t.num_rollouts_done_store.add("num_done", 1)  # rank 0 finished its rollout
-    dist.barrier()
-    one_done = t.should_end_early(T // 2)  # 1 < 0.6 * 2
-    dist.barrier()
-    if rank == 0:
-        t.num_rollouts_done_store.add("num_done", 1)
-    dist.barrier()
-    two_done = t.should_end_early(T // 2)
-    out["early"] = (early_before, none_done, one_done, two_done)
-    q.put((rank, out))
+    early = [t.should_end_early(T // 4 - 1), t.should_end_early(T // 2)]
+    for k in range(1, world + 1):
+        dist.barrier()
+        if rank == 0:
+            t.num_rollouts_done_store.add("num_done", 1)  # one more rank finished its rollout
+        dist.barrier()
+        early.append(t.should_end_early(T // 2))
+    out["early"] = tuple(early)
+    # rank -> device and seed (ppo_trainer.py:203-211): the unique per-environment seeds of rank r start at seed + r * num_environments
+    out["seed_offset"] = rank * cfg.habitat_baselines.num_environments
+    out["local_rank"] = local_rank
+    from habitat_amd.rl.ddppo.ddp_utils import rank_cpu_block
+    out["cpus"] = rank_cpu_block(list(range(64)), rank, world)
+    # plain numpy through the queue: a tensor travels as a shared-memory handle that dies with this process
+    q.put((rank, {k: (v.numpy().copy() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _collect(q, world, timeout):
+    import numpy as np
+    res = dict(q.get(timeout=timeout) for _ in range(world))
+    return {r: {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in o.items()} for r, o in res.items()}
 
 
 def test_ddppo_host_logic_world2_gloo():
@@ -132,7 +139,7 @@ def test_ddppo_host_logic_world2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
+    res = _collect(q, world, 120)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -149,6 +156,39 @@ def test_ddppo_host_logic_world2_gloo():
     assert a["early"] == b["early"] == (False, False, False, True)
 
 
+def test_ddppo_host_logic_world8_gloo():
+    """The same host logic at the world size the node has: 8 ranks.  Rank 0's parameters everywhere, gradients =
+    the sum over the 8 ranks on every rank (early tails + head), distributed mean / variance over 8 shards, statistics coalescing, the
+    preemptive straggler rule (sync_frac 0.6 of 8 ranks: the rollout ends early once 5 have finished, not at 4), rank -> local rank /
+    seed offset / disjoint CPU blocks."""
+    world, port = 8, find_free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(q, world, 300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    r0 = res[0]
+    g_sum = sum(res[r]["g_local"] for r in range(world))
+    allx = torch.cat([res[r]["x"] for r in range(world)])
+    for r in range(world):
+        o = res[r]
+        assert torch.equal(o["params"], FakeEngine(0).params_flat) and o["repacked"] == 1
+        assert torch.equal(o["grads"], r0["grads"]) and torch.allclose(o["grads"], g_sum, atol=1e-5)
+        assert torch.equal(o["mean"], r0["mean"]) and torch.allclose(o["mean"], allx.mean().view(1), atol=1e-6)
+        assert torch.allclose(o["var"], allx.var(unbiased=False).view(1), atol=1e-6)
+        assert o["losses"] == r0["losses"] and abs(o["losses"]["value_loss"] - 4.5) < 1e-6  # mean of 1 .. 8
+        assert o["steps"] == 64 * 36 and torch.equal(o["win_count"], torch.full((3, 1), 36.0))
+        #            < 25 %  none   1      2      3      4      5     6     7     8 ranks finished
+        assert o["early"] == (False, False, False, False, False, False, True, True, True, True), (r, o["early"])
+        assert o["local_rank"] == r and o["seed_offset"] == r * 4  # (ddppo_pointnav.yaml: num_environments = 4)
+    blocks = [set(res[r]["cpus"]) for r in range(world)]
+    assert all(len(b) == 8 for b in blocks) and len(set().union(*blocks)) == 64  # disjoint, covering
+
+
 def _preemption_worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "habitat-lab_amd")):
         sys.path.insert(0, p)
@@ -162,7 +202,7 @@ def _preemption_worker(rank, world, port, q):
         num_environments=N, rl=types.SimpleNamespace(ppo=types.SimpleNamespace(num_steps=T),
                                                      ver=types.SimpleNamespace(overlap_rollouts_and_learn=False))))
     d = PreemptionDecider(cfg, my_t_zero=0.0, world_rank=rank, world_size=world, group=group)
-    speed = np.array([0.010, 0.012, 0.011, 0.013]) * (1.0 if rank == 0 else 3.0)  # rank 1 is the straggler: 3x slower environments
+    speed = np.array([0.010, 0.012, 0.011, 0.013]) * (3.0 if rank == 1 else 1.0)  # rank 1 is the straggler: 3x slower environments
     now, deadlines = 1.0 + 0.001 * rank, []
     for rollout in range(8):
         d.start_rollout(now)
@@ -182,23 +222,30 @@ def _preemption_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_ver_preemption_decider_world2_gloo():
-    """rl/ver/preemption_decider.py at world size 2 (its gather / reduce / broadcast on a gloo group): both ranks arrive at the SAME
-    rollout length, the deadline (common start + length) is identical on both, and within it the rank with 3x slower environments is
-    scheduled for about a third of the steps of the fast rank -- it is the one the deadline cuts off."""
-    world, port = 2, find_free_port()
+@pytest.mark.parametrize("world", [2, 8])
+def test_ver_preemption_decider_gloo(world):
+    """rl/ver/preemption_decider.py at world size 2 and 8 (its gather / reduce / broadcast on a gloo group) with an injected straggler
+    (rank 1: 3x slower environments): every rank arrives at the SAME rollout length, the deadline (common start + length) is identical
+    everywhere, and within it the slow rank is scheduled for about a third of the steps of a fast rank -- it is the one the deadline
+    cuts off.  This is what lets VERTrainer start the decider by default (ver_trainer.py:158 of the reference always does)."""
+    port = find_free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_preemption_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
+    res = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    a, b = res[0], res[1]
-    assert a["opt_time"] == b["opt_time"] and a["opt_time"] > 0
-    assert a["start_time"] == b["start_time"]                      # MIN over ranks of the rollout starts
+    a, slow = res[0], res[1]
+    assert a["opt_time"] > 0
     active = [i for i, t in enumerate(a["deadlines"]) if t > 0]
-    assert len(active) >= 2 and all(a["deadlines"][i] == b["deadlines"][i] for i in range(len(a["deadlines"])))
-    assert a["my_steps"] > 2.5 * b["my_steps"] > 0, (a["my_steps"], b["my_steps"])
+    assert len(active) >= 2
+    for r in range(world):
+        o = res[r]
+        assert o["opt_time"] == a["opt_time"]
+        assert o["start_time"] == a["start_time"]                      # MIN over ranks of the rollout starts
+        assert all(o["deadlines"][i] == a["deadlines"][i] for i in range(len(a["deadlines"])))
+        if r != 1:
+            assert o["my_steps"] > 2.5 * slow["my_steps"] > 0, (r, o["my_steps"], slow["my_steps"])

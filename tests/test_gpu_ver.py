@@ -227,12 +227,13 @@ def test_ver_trainer_update_cycles(env_source, n_iw, overlap, tmp_path):
     trainer.envs.close()
 
 
-def test_ver_overlapped_run_hands_the_learner_the_same_rollouts_as_the_sequential_run(tmp_path):
+def test_ver_overlapped_run_hands_the_learner_the_same_rollouts_as_the_sequential_run(tmp_path, monkeypatch):
     """Fixed arrival order (device source, every step arrives at the next poll, one inference worker) and a learning rate of zero
     (the acting parameters are the same whichever policy version an engine holds): the overlapped run (worker thread on its own
     stream with a private engine, learner on its copy of the arena) must hand the learner bit-identical rollouts to the sequential
     run -- observations, actions, log-probs, values, rewards, masks, ids, hidden states -- cycle after cycle; only the policy-version
     stamps differ (a rollout of the overlapped run starts before the previous update has finished)."""
+    monkeypatch.setenv("HAB_VER_PREEMPTION", "0")  # a preemption deadline depends on wall-clock step times: two runs would legitimately differ
     from habitat_amd.config.default import get_config
     from habitat_amd.common.baseline_registry import baseline_registry
     import habitat_amd.rl.ver.ver_trainer  # noqa: F401
@@ -296,13 +297,13 @@ def test_ver_overlapped_run_hands_the_learner_the_same_rollouts_as_the_sequentia
 
 
 def test_ver_trainer_with_the_preemption_decider_enabled(tmp_path, monkeypatch):
-    """HAB_VER_PREEMPTION=1 on one rank: the decider is fed by the workers' step reports, becomes ready after five learner times, sets
+    """The default (HAB_VER_PREEMPTION unset = on) on one rank: the decider is fed by the workers' step reports, becomes ready after five learner times, sets
     deadlines, and the trainer keeps producing finite updates with rollouts of at most the step quota (on one rank with variable
     experience the optimum is normally the full quota: fast environments fill it)."""
     from habitat_amd.config.default import get_config
     from habitat_amd.common.baseline_registry import baseline_registry
     import habitat_amd.rl.ver.ver_trainer  # noqa: F401
-    monkeypatch.setenv("HAB_VER_PREEMPTION", "1")
+    monkeypatch.delenv("HAB_VER_PREEMPTION", raising=False)
     N, T, size = 4, 8, 64
     ov = [f"habitat_baselines.num_environments={N}", f"habitat_baselines.rl.ppo.num_steps={T}", "habitat_baselines.num_updates=8",
           "habitat_baselines.total_num_steps=-1", "habitat_baselines.num_checkpoints=-1", "habitat_baselines.checkpoint_interval=1000000",
