@@ -455,3 +455,39 @@ def test_conv2_strip_resident_data_gradient_as_accurate_as_fp32_path(L, B, with_
     assert e2 <= 2 * e0 + 2e-7 and e2 < 3e-6, (e0, e2)
     assert float((d_strip.double().cpu() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
     assert torch.equal(d_strip, _with_path(L, 1 | 512, run)), "not reproducible"
+
+
+def test_non_finite_operands_on_the_split_path_are_pinned(L):
+    """DESIGN.md 4 / INTEGRATION.md: the 3-term split of +-Inf is (+-Inf, NaN, NaN), so on the split-bf16 path an Inf or NaN operand
+    yields NaN in EVERY output it contributes to and nowhere else; the fp32 MFMA path (hab_set_matrix_path(0)) propagates +-Inf through
+    products with finite non-zero factors.  Pinned so that a change of the split (or of the dispatch) that alters this shows up."""
+    torch.manual_seed(0)
+    B, H, W, Cc, Cout, K = 2, 12, 12, 32, 32, 3
+    x = torch.rand(B, H, W, Cc) + 0.5
+    w = torch.rand(Cout, K, K, Cc) + 0.1  # strictly positive: an Inf input reaches every output of its receptive field with weight > 0
+    hit = (1, 5, 6, 7)  # (image, row, column, channel) of the non-finite input
+    ws = torch.zeros(1 << 20, device="cuda")
+    wf = w.cuda()
+
+    def run(xin, mode):
+        prev = L.hab_set_matrix_path(mode)
+        try:
+            y = torch.zeros(B, H, W, Cout, device="cuda")
+            _lib.check(L.hab_conv2d_fwd(P(xin.cuda()), P(wf), None, P(y), B, H, W, Cc, Cout, K, K, 1, 1, 0, P(ws), ws.numel(), S()))
+            return y.cpu()
+        finally:
+            L.hab_set_matrix_path(prev)
+
+    reach = torch.zeros(B, H, W, dtype=torch.bool)
+    reach[hit[0], hit[1] - 1:hit[1] + 2, hit[2] - 1:hit[2] + 2] = True  # 3x3, padding 1: the 9 output pixels that read the input pixel
+    clean = {m: run(x, m) for m in (0, 1)}
+    for bad in (float("inf"), float("-inf"), float("nan")):
+        xb = x.clone()
+        xb[hit] = bad
+        for mode in (0, 1):
+            y = run(xb, mode)
+            assert torch.isfinite(y[~reach]).all() and torch.equal(y[~reach], clean[mode][~reach]), (bad, mode)
+            if mode == 1 or bad != bad:
+                assert torch.isnan(y[reach]).all(), (bad, mode)  # split path: NaN wherever the operand is read
+            else:
+                assert (y[reach] == bad).all(), (bad, mode)      # fp32 MFMA path: the infinity itself

@@ -83,3 +83,64 @@ def test_full_minibatch_at_benchmark_shape_vs_oracle(workload, frames):
     bad2 = [(k, e, nw) for k, (e, nw) in per2.items() if nw > 1e-4]
     assert not bad2, bad2  # ... every gradient agrees
     trainer.envs.close()
+
+
+def test_benchmark_shape_minibatch_agrees_on_every_matrix_path():
+    """C2 at the benchmark shape (one 2048-frame minibatch of 256 x 256 RGB-D) through the engine under every kernel-selection mask of
+    hab_set_matrix_path that production can end up on: fp32 MFMA everywhere (0), the plain split-bf16 contraction alone (1), the default
+    minus the kernels hard-wired to this geometry (what other observation sizes run).  The default path is pinned to the oracle by
+    test_full_minibatch_at_benchmark_shape_vs_oracle[c2-2048]; every other path must reproduce ITS outputs to 1e-4 and its gradients
+    norm-wise (1e-4 behind the encoder, 3e-2 inside it: a few ReLU decisions within round-off of zero legitimately differ)."""
+    import bench
+    from habitat_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(1234)
+    trainer, cfg = bench.make_trainer("c2", 3)
+    trainer._init_train()
+    ppo_cfg = cfg.habitat_baselines.rl.ppo
+    agent = trainer._agent
+    st = agent.rollouts
+    agent.eval()
+    assert trainer.collect_rollout() == 64 * 128
+    last = st.get_last_step()
+    nv = agent.actor_critic.get_value({k: v.contiguous() for k, v in last["observations"].items()}, last["recurrent_hidden_states"],
+                                      last["prev_actions"], last["masks"])
+    st.compute_returns(nv, ppo_cfg.use_gae, ppo_cfg.gamma, ppo_cfg.tau)
+    agent.train()
+    adv = agent.updater.get_advantages(st)
+    torch.manual_seed(99)
+    batch = next(st.data_generator(adv, ppo_cfg.num_mini_batch))
+    eng = agent.actor_critic.engine
+    Bf, obs = st.buffers, st.buffers["observations"]
+    Bn = batch.T * batch.n
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dv, dlp, dent = (torch.randn(Bn, device="cuda", generator=g) * 1e-3 for _ in range(3))
+
+    def run():
+        v, lp, ent = (torch.zeros(Bn, device="cuda") for _ in range(3))
+        eng.evaluate(obs.get("rgb"), obs.get("depth"), obs.get("pointgoal_with_gps_compass"), batch.rows, Bf["recurrent_hidden_states"],
+                     Bf["masks"], Bf["actions"], batch.pack, Bn, batch.n, value=v, log_prob=lp, entropy=ent, prev_actions=Bf["prev_actions"])
+        eng.backward(obs.get("rgb"), obs.get("depth"), obs.get("pointgoal_with_gps_compass"), batch.rows, Bf["actions"], batch.pack, dv, dlp,
+                     dent, prev_actions=Bf["prev_actions"])
+        torch.cuda.synchronize()
+        return (v.clone(), lp.clone(), ent.clone()), {k: t.detach().clone() for k, t in eng.grad_views.items() if k not in eng.buffer_names}
+
+    prev = L.hab_set_matrix_path(-1)
+    try:
+        ref_out, ref_g = run()
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+        for name, mode in (("fp32_mfma", 0), ("split_bf16_igemm_only", 1), ("no_256x256_strip_kernels", 1023 & ~(64 | 256 | 512))):
+            L.hab_set_matrix_path(mode)
+            out, grads = run()
+            for a, b, what in zip(out, ref_out, ("value", "log_prob", "entropy")):
+                assert rel(a, b) <= 1e-4, (name, what, rel(a, b))
+            bad = []
+            for k, gr in grads.items():
+                nw = float((gr - ref_g[k]).norm() / ref_g[k].norm().clamp_min(1e-20))
+                deep = ("visual_encoder" in k)
+                if nw > (3e-2 if deep else 1e-4):
+                    bad.append((k, nw))
+            assert not bad, (name, bad)
+    finally:
+        L.hab_set_matrix_path(prev)
+        trainer.envs.close()

@@ -335,6 +335,27 @@ def test_resnet_golden_mask_flip_accounting(case):
     assert not bad, (bad, flips)
 
 
+# hab_set_matrix_path masks (include/habitat_amd.h): everything on the fp32 MFMA kernels (0); the plain split-bf16 contraction alone (1:
+# weight gradients, the observation convolution, every patch / strip kernel on their fp32 forms); the default minus the three kernels
+# hard-wired to the 256 x 256 benchmark geometry (observation patch, conv2 forward / data-gradient strips): what an observation size
+# other than 256 x 256 runs in production
+MATRIX_PATHS = {"fp32_mfma": 0, "split_bf16_igemm_only": 1, "no_256x256_strip_kernels": 1023 & ~(64 | 256 | 512)}
+
+
+@pytest.mark.parametrize("path", list(MATRIX_PATHS))
+@pytest.mark.parametrize("case", ["baseline_rgbd44", "c1_depth84_h512_4x32", "resnet18_rgbd256"])
+def test_full_ppo_update_vs_reference_golden_on_every_matrix_path(case, path, monkeypatch):
+    """The golden update through the ENGINE with the kernel-selection mask of hab_set_matrix_path off its default: the fp32 MFMA path
+    and the im2col fallbacks stay pinned to the reference at engine level, not just kernel by kernel."""
+    from habitat_amd import _lib
+    L = _lib.lib()
+    prev = L.hab_set_matrix_path(MATRIX_PATHS[path])
+    try:
+        test_full_ppo_update_vs_reference_golden(case, monkeypatch)
+    finally:
+        L.hab_set_matrix_path(prev)
+
+
 @pytest.mark.parametrize("case", list(CASES))
 def test_full_ppo_update_vs_reference_golden(case, monkeypatch):
     """PPO.update on the golden rollout with the golden minibatch permutations: learner metrics and every
