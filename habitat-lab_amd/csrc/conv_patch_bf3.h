@@ -317,12 +317,12 @@ inline int conv_patch_bf3_launch(const P& p, PatchGeom gq, float* ws, size_t ws_
     gq.nt_n = cdiv(p.N, Cfg::BN);
     const int ntiles = gq.nt_m * gq.nt_n;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");
-    static const int wgs_per_cu = hab_env_int("HAB_CPB_WGS", 2);
+    constexpr int wgs_per_cu = 2;  // measured (round 2): two persistent workgroups per CU
     const int occ = (int)(160 * 1024 / Cfg::LDS_BYTES) < wgs_per_cu ? (int)(160 * 1024 / Cfg::LDS_BYTES) : wgs_per_cu;
     int grid = 256 * (occ > 0 ? occ : 1);
     if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
     // weights as bf16 planes once per call when the launch is large enough to pay for the extra kernel
-    static const int pre_min = hab_env_int("HAB_CPB_PRE_MIN", 131072);
+    constexpr int pre_min = 131072;
     const size_t wn_elems = cpb_w_elems(p);
     const bool pre = ws && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0) && ws_floats * 4 >= wn_elems * 12 && p.M >= pre_min && (wn_elems % 4 == 0);
     hipError_t e = hipSuccess;

@@ -57,13 +57,12 @@ extern "C" int hab_set_matrix_path(int mode) {
 // arithmetic and bit-identical results (profiles/r03_ws_vs_base_layers.txt): the 128 x 128 forward-form tiles with a long reduction gain
 // (3x3 256->256 at 4x4: 128 -> 163 TFLOP/s-eq forward and data gradient, fc 25088->512 forward 132 -> 150), every other shape loses
 // (32- / 64-column tiles -10..-45 %, i/j-contiguous operands -30 %, K = 256 merged data gradient -18 %: the longer prologue and the
-// halved MFMA wave count are not paid back).  It is therefore selected only where it won; HAB_BF3_WS_ALL=1 forces it everywhere
-// the plain kernel runs (development: reproduces the comparison).
+// halved MFMA wave count are not paid back).  It is therefore selected only where it won.
 template <class P, int TM, int TN, int WM, int WN>
 static int bf3_launch(const P& p, float* ws, size_t ws_floats, int target_blocks, hipStream_t stream) {
     constexpr bool WS_SHAPE = P::A_RC && P::B_RC && TM == 2 && TN == 2 && WM == 2 && WN == 2;
     if constexpr (WS_SHAPE) {
-        static const int ws_min_k = hab_env_int("HAB_BF3_WS_MIN_K", 2048);
+        constexpr int ws_min_k = 2048;
         if ((bf3_mode() & 32) && p.K >= ws_min_k) return igemm_bf3_ws_launch<P, TM, TN, WM, WN, 4>(p, ws, ws_floats, target_blocks, stream);
     }
     return igemm_bf3_launch<P, TM, TN, WM, WN>(p, ws, ws_floats, target_blocks, stream);
@@ -76,8 +75,6 @@ static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream
     // (measured: target 1024 -> 256 is +4 % on C2, +6 % on C3, all of it in the 64-frame rollout forward passes).  Weight
     // gradients (tiny M*N, K in the millions) keep the deeper split.
     if (P::A_RC || P::B_RC) target_blocks = 256;
-    static const int wg_target = hab_env_int("HAB_TARGET_BLOCKS_WG", 0);
-    if (wg_target > 0 && !P::A_RC && !P::B_RC) target_blocks = wg_target;
     constexpr bool WG = !P::A_RC && !P::B_RC && AKv<P>::value == 4;  // weight-gradient form
     if constexpr (P::A_RC && P::B_RC) {
         if ((bf3_mode() & 1) && p.M > 64) {
@@ -85,8 +82,7 @@ static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream
             if (p.N <= 64) {
                 // 256 x 64 tiles halve the weight traffic per output row: +12 % on the 3x3 64 -> 64 convolutions of ResNet layer2
                 // (0.089 -> 0.079 ms at 512 frames, forward and data gradient), nothing on SimpleCNN conv2 (K = 512: 0.308 vs 0.312 ms)
-                static const int tall64 = hab_env_int("HAB_BF3_TALL64", 1);
-                if (tall64 && p.M >= 256 * 512 && p.K >= 576) return bf3_launch<P, 2, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
+                if (p.M >= 256 * 512 && p.K >= 576) return bf3_launch<P, 2, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
                 return bf3_launch<P, 1, 2, 4, 1>(p, ws, ws_floats, target_blocks, stream);
             }
             return bf3_launch<P, 2, 2, 2, 2>(p, ws, ws_floats, target_blocks, stream);
@@ -167,8 +163,7 @@ int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const f
         if (rc != 1) return rc;
     }
     if ((bf3_mode() & 2) && p.quad && p.M > 64) {  // uint8 x split-bf16 weights on the matrix pipe (obs_conv_bf3.h)
-        static const int tm = hab_env_int("HAB_OBF_TM", 2);
-        const int rc = tm == 4 ? obs_conv_bf3_launch<4>(p, ws, ws_floats, stream) : obs_conv_bf3_launch<2>(p, ws, ws_floats, stream);
+        const int rc = obs_conv_bf3_launch<2>(p, ws, ws_floats, stream);
         if (rc != 1) return rc;
     }
     return run_igemm(p, ws, ws_floats, stream);

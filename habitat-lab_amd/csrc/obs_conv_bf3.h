@@ -253,7 +253,7 @@ inline int obs_conv_bf3_launch(const ObsConvFwdProb& p, float* ws, size_t ws_flo
     // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
     static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     if (attr_err != hipSuccess) return (int)attr_err;
-    static const int wg_per_cu = hab_env_int("HAB_OBF_WGS", 2);
+    constexpr int wg_per_cu = 2;
     const int ntiles = cdiv(p.M, Cfg::BM) * cdiv(p.N, 32);
     const int grid = ntiles < 256 * wg_per_cu ? ntiles : 256 * wg_per_cu;
     kern<<<(grid + 7) / 8 * 8, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, planes, NP);

@@ -209,7 +209,7 @@ inline int obs_wgrad_bf3_launch(const ObsConvWgradProb& p, float* ws, size_t ws_
     gg.tiles = g.B * g.Ho * gg.WB;
     gg.dWB = FastDiv(gg.WB);
     gg.dHo = FastDiv(g.Ho);
-    static const int wgs_env = hab_env_int("HAB_OWG_WGS", 512);
+    constexpr int wgs_env = 512;
     int wgs = gg.tiles < wgs_env ? gg.tiles : wgs_env;
     const int MP = p.M + (p.colsum ? 1 : 0);
     while (wgs > 1 && (size_t)wgs * MP * p.N > ws_floats) wgs >>= 1;
