@@ -69,6 +69,11 @@ struct hab_policy {
     int world_size = 1;
     hab_grad_ready_fn grad_ready_cb = nullptr;          // optional: tail of the gradient arena is final (early DD-PPO all-reduce)
     void* grad_ready_ctx = nullptr;
+    // device-side exchange (comm.hip): when set, the gradient tails and the RunningMeanAndVar moments are all-reduced on this RCCL
+    // communicator from inside backward / forward instead of through the two callbacks above
+    struct hab_comm* comm = nullptr;
+    int64_t comm_first = -1;                            // grads[comm_first ..) has been enqueued for exchange in this backward (-1: nothing)
+    hipStream_t cur_stream = nullptr;                   // stream of the running hab_policy_backward
     // probe
     uint64_t probe_mask = 0;  // bit t set: call site HAB_PROBE_<t> is bracketed by HIP events on the launch stream
     struct ProbeEv { int tag; hipEvent_t first, second; };
@@ -98,6 +103,8 @@ int build_resnet(hab_policy* e);
 void destroy_resnet(hab_policy* e);
 int resnet_repack(hab_policy* e, hipStream_t s);
 void grad_tail_ready(hab_policy* e, int first_param);
+int comm_exchange_async(struct hab_comm* c, float* buf, int64_t first, int64_t count, hipStream_t compute);
+extern "C" int hab_comm_allreduce_sum(struct hab_comm* c, float* buf, int64_t count, hipStream_t stream);
 int resnet_feature_shape(const hab_policy* e, int* c, int* hf, int* wf);
 int resnet_encode(hab_policy* e, const hab_obs* obs, int n, float* out, hipStream_t s);
 int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s);

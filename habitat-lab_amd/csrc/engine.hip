@@ -163,6 +163,12 @@ extern "C" int hab_policy_set_grad_ready(hab_policy* e, hab_grad_ready_fn fn, vo
 }
 // Everything from parameter `first_param` to the end of the gradient arena has been written (enqueued) for this backward.
 void grad_tail_ready(hab_policy* e, int first_param) {
+    if (e->comm) {  // device-side exchange: this tail goes out on the communicator's stream now, beside the rest of backward
+        const int64_t first = e->g(first_param) - e->G;
+        const int64_t end = e->comm_first < 0 ? (int64_t)e->param_floats : e->comm_first;
+        if (first < end && comm_exchange_async(e->comm, e->G, first, end - first, e->cur_stream) == HAB_OK) e->comm_first = first;
+        return;
+    }
     if (!e->grad_ready_cb) return;
     const int64_t first = e->g(first_param) - e->G;
     e->grad_ready_cb(first, (int64_t)e->param_floats - first, e->grad_ready_ctx);
@@ -534,6 +540,8 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
     float* W = e->WK;
     float* ws = W + e->w_ws;
     const int H = e->d.hidden, L = e->L, B = e->last_B, A = e->d.num_actions;
+    e->cur_stream = stream;
+    e->comm_first = -1;
     PackInfo pk;
     pk.select_inds = pack->select_inds; pk.step_offsets = pack->step_offsets_host; pk.num_seqs_at_step = pack->num_seqs_at_step_host;
     pk.frag_env = pack->frag_env; pk.frag_start = pack->frag_start; pk.P = pack->P; pk.F = pack->F; pk.max_len = pack->max_len;

@@ -518,12 +518,17 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
             // running_mean_and_var.py:38-49: all_reduce(new_mean), all_reduce(new_count), new_mean /= world; all_reduce(new_var),
             // new_var /= world.  The callback only SUMS (scale 1); the divisions happen where the sums are consumed, and the count is
             // the real all-reduced number of frames (ranks hold different numbers of frames after a preempted rollout).
-            const bool dist = e->allreduce_cb && e->world_size > 1;
+            const bool dist = (e->allreduce_cb || e->comm) && e->world_size > 1;
+            auto sum_ranks = [&](float* buf, int n) -> int {  // device-side on the compute stream (comm.hip), else the host callback
+                if (e->comm) return hab_comm_allreduce_sum(e->comm, buf, n, s);
+                e->allreduce_cb(buf, n, 1.0f, e->allreduce_ctx);
+                return HAB_OK;
+            };
             const float div = dist ? (float)e->world_size : 1.f;
             HAB_TRY(chan_moment(x0, npix, r->cpad, 0, nullptr, st, ds, 1024 * 8, s, 1.f, st + 8, (float)B));
-            if (dist) e->allreduce_cb(st, 9, 1.0f, e->allreduce_ctx);
+            if (dist) HAB_TRY(sum_ranks(st, 9));
             HAB_TRY(chan_moment(x0, npix, r->cpad, 1, st, st + 16, ds, 1024 * 8, s, div));
-            if (dist) e->allreduce_cb(st + 16, 8, 1.0f, e->allreduce_ctx);
+            if (dist) HAB_TRY(sum_ranks(st + 16, 8));
             HAB_TRY(rmv_update(e->p(r->i_mean), e->p(r->i_var), e->p(r->i_count), st, st + 16, (float)B, r->creal, s, st + 8, div));
         }
         HAB_TRY(rmv_normalize(x0, npix, r->cpad, r->creal, e->p(r->i_mean), e->p(r->i_var), s));

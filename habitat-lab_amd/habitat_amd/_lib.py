@@ -103,6 +103,14 @@ SIGNATURES = {
     "hab_policy_param_info": (c_int, [vp, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int64)]),
     "hab_policy_param_is_buffer": (c_int, [vp, c_int]),
     "hab_policy_set_training": (c_int, [vp, c_int]),
+    "hab_comm_available": (c_int, []),
+    "hab_comm_unique_id": (c_int, [vp]),
+    "hab_comm_create": (c_int, [vp, c_int, c_int, vp]),
+    "hab_comm_destroy": (None, [vp]),
+    "hab_comm_world_size": (c_int, [vp]),
+    "hab_comm_allreduce_sum": (c_int, [vp, vp, c_int64, vp]),
+    "hab_policy_set_comm": (c_int, [vp, vp]),
+    "hab_policy_grad_sync": (c_int, [vp, vp]),
     "hab_policy_set_grad_ready": (c_int, [vp, GRAD_READY_FN, vp]),
     "hab_policy_set_allreduce": (c_int, [vp, ALLREDUCE_FN, vp, c_int]),
     "hab_policy_param_floats": (c_int64, [vp]),

@@ -431,6 +431,27 @@ int hab_policy_set_allreduce(hab_policy* p, hab_allreduce_fn fn, void* ctx, int 
  * (DistributedDataParallel's bucket overlap, ddppo.py:128-140, with one bucket) and reduces [0, first) after backward returns. */
 typedef void (*hab_grad_ready_fn)(int64_t first, int64_t count, void* ctx);
 int hab_policy_set_grad_ready(hab_policy* p, hab_grad_ready_fn fn, void* ctx);
+/* DD-PPO, device-side form of the two hooks above (csrc/comm.hip): an RCCL communicator owned by the library.  Replaces what
+ * DistributedDataParallel's reducer does for the reference (rl/ddppo/algo/ddppo.py:128-140: buckets all-reduced from autograd hooks
+ * while backward runs) and the all_reduce calls of rl/ddppo/policy/running_mean_and_var.py:38-49, with no interpreter in between.
+ *   hab_comm_available    1 when librccl's symbols were found (dlopen; the copy PyTorch loaded when there is one)
+ *   hab_comm_unique_id    rank 0: 128 bytes to hand to every rank (e.g. through torch.distributed's store)
+ *   hab_comm_create       ncclCommInitRank on the CURRENT device + a private high-priority stream for the exchange
+ *   hab_comm_allreduce_sum  in-place fp32 sum over the ranks, in order on `stream` (self-test, statistics)
+ *   hab_policy_set_comm   from now on hab_policy_backward enqueues the all-reduce of every finished tail of the gradient arena on
+ *                         the communicator's stream the moment it is final, and the training forward sums the RunningMeanAndVar
+ *                         moments on the compute stream; the hab_policy_set_allreduce / _set_grad_ready callbacks are not called
+ *   hab_policy_grad_sync  after hab_policy_backward: exchanges the rest of the arena (its head) and makes `stream` wait for all of
+ *                         it; the arena then holds the SUMS over ranks (1 / world_size goes into hab_clip_adam_step's grad_scale) */
+typedef struct hab_comm hab_comm;
+int hab_comm_available(void);
+int hab_comm_unique_id(uint8_t* out128);
+int hab_comm_create(const uint8_t* id128, int world, int rank, hab_comm** out);
+void hab_comm_destroy(hab_comm* c);
+int hab_comm_world_size(const hab_comm* c);
+int hab_comm_allreduce_sum(hab_comm* c, float* buf, int64_t count, hipStream_t stream);
+int hab_policy_set_comm(hab_policy* p, hab_comm* c);
+int hab_policy_grad_sync(hab_policy* p, hipStream_t stream);
 /* The visual encoder alone (ResNetEncoder.forward, resnet_policy.py:255-276) on n frames: out (n, C, Hf, Wf) fp32 NCHW, the tensor
  * ppo_trainer.py:271-279,467-471 stores under "visual_features" when the encoder is frozen.  Uses the current training flag
  * (RunningMeanAndVar statistics are updated iff training, exactly like calling the module).  arch 1 only. */

@@ -326,7 +326,8 @@ def test_ver_trainer_with_the_preemption_decider_enabled(tmp_path, monkeypatch):
         assert all(np.isfinite(v) for v in losses.values()), losses
         steps.append(trainer.num_steps_done - before)
     assert steps[0] == (T + 1) * N and all(0 < s <= N * T for s in steps[1:]), steps
-    assert d.learner_time_avg.count == 5 and d.n_rollouts_started == 8 and d.real_steps_collected == 0
+    # 8 finished rollouts + the next one, armed in _update_agent BEFORE the parked workers are released (its first batches count)
+    assert d.learner_time_avg.count == 5 and d.n_rollouts_started == 9
     assert sum(v.count for v in d.step_averages) > 0  # the workers' step reports arrived
     trainer.shutdown()
     trainer.envs.close()
