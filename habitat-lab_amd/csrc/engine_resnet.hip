@@ -518,7 +518,7 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
             // running_mean_and_var.py:38-49: all_reduce(new_mean), all_reduce(new_count), new_mean /= world; all_reduce(new_var),
             // new_var /= world.  The callback only SUMS (scale 1); the divisions happen where the sums are consumed, and the count is
             // the real all-reduced number of frames (ranks hold different numbers of frames after a preempted rollout).
-            const bool dist = (e->allreduce_cb || e->comm) && e->world_size > 1;
+            const bool dist = e->comm != nullptr || (e->allreduce_cb && e->world_size > 1);  // (a 1-rank communicator still runs: identity)
             auto sum_ranks = [&](float* buf, int n) -> int {  // device-side on the compute stream (comm.hip), else the host callback
                 if (e->comm) return hab_comm_allreduce_sum(e->comm, buf, n, s);
                 e->allreduce_cb(buf, n, 1.0f, e->allreduce_ctx);

@@ -206,7 +206,19 @@ class PolicyEngine:
             self._grad_ready_cb = _lib.GRAD_READY_FN(_cb)
         check(self.L.hab_policy_set_grad_ready(self.h, self._grad_ready_cb, None), "hab_policy_set_grad_ready")
 
+    # ---- device-side exchange (csrc/comm.hip) ----
+    def set_comm(self, comm: "NativeComm | None"):
+        """From now on backward() enqueues the all-reduce of every finished tail of the gradient arena on the communicator's stream and
+        the training forward sums the RunningMeanAndVar moments on the compute stream; the Python callbacks are no longer called."""
+        self._comm = comm  # keeps the communicator alive as long as the engine uses it
+        check(self.L.hab_policy_set_comm(self.h, comm.h if comm is not None else None), "hab_policy_set_comm")
+
+    def grad_sync(self):
+        """After backward(): exchange the rest of the gradient arena and make the current stream wait for all of it (sums over ranks)."""
+        check(self.L.hab_policy_grad_sync(self.h, stream_ptr()), "hab_policy_grad_sync")
+
     _cb_error = None
+    _comm = None
 
     def _raise_cb_error(self):
         if self._cb_error is not None:
@@ -302,3 +314,40 @@ class PolicyEngine:
         ms, cnt = C.c_double(0), C.c_int(0)
         check(self.L.hab_policy_probe_read(self.h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+
+class NativeComm:
+    """RCCL communicator owned by libhabitat_amd (csrc/comm.hip).  The 128-byte unique id is created by rank 0 and travels through
+    `exchange(list_of_one_object, src)` -- torch.distributed.broadcast_object_list for a process group, identity for one rank."""
+
+    def __init__(self, world: int, rank: int, exchange=None):
+        L = _lib.lib()
+        if not L.hab_comm_available():
+            raise _lib.HabError("librccl was not found: no device-side exchange")
+        ident = [None]
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            check(L.hab_comm_unique_id(buf), "hab_comm_unique_id")
+            ident[0] = bytes(buf)
+        if exchange is not None:
+            exchange(ident)
+        raw = (C.c_uint8 * 128).from_buffer_copy(ident[0])
+        h = C.c_void_p()
+        check(L.hab_comm_create(raw, int(world), int(rank), C.byref(h)), "hab_comm_create")
+        self.L, self.h, self.world, self.rank = L, h, int(world), int(rank)
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        check(self.L.hab_comm_allreduce_sum(self.h, ptr(t), t.numel(), stream_ptr()), "hab_comm_allreduce_sum")
+        return t
+
+    def close(self):
+        if self.h is not None:
+            self.L.hab_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass

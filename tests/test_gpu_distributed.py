@@ -328,3 +328,66 @@ def test_ddppo_reduce_reference_configuration(unused_params):
         p.join(300)
         assert p.exitcode == 0, [p.exitcode for p in procs]
     assert sorted(q.get(timeout=5) for _ in range(world)) == [0, 1]
+
+
+def _native_comm_worker(port, q, native):
+    """One rank on the `nccl` backend (RCCL with a single rank: the 1-GPU box cannot host two RCCL ranks), C3-small, two update cycles."""
+    for p in (ROOT, os.path.join(ROOT, "habitat-lab_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(LOCAL_RANK="0", RANK="0", WORLD_SIZE="1", MAIN_ADDR="127.0.0.1", MAIN_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      HAB_NATIVE_COMM="1" if native else "0", HAB_FORCE_GRAD_OVERLAP="1")
+    os.environ.pop("MASTER_PORT", None)
+    os.environ.pop("HAB_NO_GRAD_OVERLAP", None)
+    import torch.distributed as dist
+    import habitat_amd.rl.ppo.ppo_trainer as tr
+    from habitat_amd.config.default import read_write
+    torch.manual_seed(7)
+    cfg = _cfg("c3", 4, 8)
+    with read_write(cfg):
+        cfg.habitat_baselines.rl.ddppo.distrib_backend = "NCCL"
+    trainer = tr.PPOTrainer(cfg)
+    trainer._init_train()
+    upd, eng = trainer._agent.updater, trainer._agent.actor_critic.engine
+    assert dist.get_backend() == "nccl" and (upd._native_comm is not None) == native
+    if native:  # the communicator itself: in-place sum over the one rank = identity, on the current stream
+        t = torch.arange(1000, device="cuda", dtype=torch.float32)
+        assert torch.equal(upd._native_comm.all_reduce_sum_(t.clone()), t)
+    for _ in range(2):
+        losses = trainer.run_update_cycle()
+        assert all(np.isfinite(v) for v in losses.values()), losses
+    torch.cuda.synchronize()
+    q.put({"p_final": eng.params_flat.cpu().numpy(), "rmv": np.concatenate([v.cpu().numpy().reshape(-1) for k, v in
+                                                                             trainer._agent.actor_critic.state_dict().items() if "running_mean_and_var" in k]),
+           "losses": {k: float(v) for k, v in losses.items()}})
+    trainer.shutdown()
+    dist.destroy_process_group()
+    trainer.envs.close()
+
+
+def test_device_side_exchange_on_rccl_matches_the_callback_form():
+    """csrc/comm.hip: with HAB_NATIVE_COMM the library's own RCCL communicator carries the gradient exchange (tails enqueued by the
+    engine inside backward, head + join in hab_policy_grad_sync) and the RunningMeanAndVar sums (inside the training forward).  On the
+    `nccl` backend with one rank -- all this box can host -- two full update cycles of the ResNet18 policy must leave bit-identical
+    parameters and statistics to the callback form through torch.distributed (every stream dependency and range of the exchange is
+    exercised; the sums themselves are RCCL's)."""
+    res = []
+    for native in (True, False):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        p = ctx.Process(target=_native_comm_worker, args=(find_free_port(), q, native))
+        p.start()
+        import queue
+        import time
+        t0, got = time.time(), None
+        while got is None:
+            try:
+                got = q.get(timeout=2)
+            except queue.Empty:
+                if p.exitcode not in (None, 0) or time.time() - t0 > 420:
+                    p.kill()
+                    raise AssertionError(f"rank process failed / timed out (exit code {p.exitcode}, native={native})")
+        p.join(120)
+        assert p.exitcode == 0
+        res.append(got)
+    a, b = res
+    assert np.array_equal(a["p_final"], b["p_final"]) and np.array_equal(a["rmv"], b["rmv"]) and a["losses"] == b["losses"]
