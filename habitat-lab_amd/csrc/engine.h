@@ -107,7 +107,7 @@ int comm_exchange_async(struct hab_comm* c, float* buf, int64_t first, int64_t c
 extern "C" int hab_comm_allreduce_sum(struct hab_comm* c, float* buf, int64_t count, hipStream_t stream);
 int resnet_feature_shape(const hab_policy* e, int* c, int* hf, int* wf);
 int resnet_encode(hab_policy* e, const hab_obs* obs, int n, float* out, hipStream_t s);
-int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s);
+int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s, int f0 = 0, int nB = -1);
 int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s);
 int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats);
 

@@ -255,7 +255,7 @@ extern "C" int hab_policy_probe_read_tag(hab_policy* e, int tag, double* total_m
 // ------------------------------------------------------------------------------------------
 // f0 / nB: frames [f0, f0 + nB) of the minibatch only (the time-major chunked evaluate); rows may be null (dense frames: act)
 static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s, int f0 = 0, int nB = -1) {
-    if (e->rn) { Probe pr(e, HAB_PROBE_ENC_FWD, s); return resnet_encoder_forward(e, obs, masks, rows, B, s); }
+    if (e->rn) { Probe pr(e, HAB_PROBE_ENC_FWD, s); return resnet_encoder_forward(e, obs, masks, rows, B, s, f0, nB); }
     if (nB < 0) nB = B;
     float* W = e->WK;
     float* ws = W + e->w_ws;
@@ -426,7 +426,8 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
     // Time-major chunked form (rnn.hip): a regular T x n minibatch of the SimpleCNN policy is cut into time chunks; the encoder of
     // chunk c + 1 runs on `stream` while the recurrence walks chunk c on the engine's second stream.  Bit-identical to the packed form.
     const int T = B / n;
-    int NC = (!e->rn && e->Cin > 0 && rows && !pack->env_first_frame && (B % n) == 0 && T >= 2 && e->w_ws2 >= 0 && (int64_t)L * 2 * n <= 3 * (int64_t)e->d.max_frames)
+    // (ResNet policies too since round 4: their encoder runs per chunk behind a whole-batch ingest, engine_resnet.hip)
+    int NC = (e->Cin > 0 && rows && !pack->env_first_frame && (B % n) == 0 && T >= 2 && e->w_ws2 >= 0 && (int64_t)L * 2 * n <= 3 * (int64_t)e->d.max_frames)
                  ? tm_chunks_cfg() : 0;
     if (NC > T) NC = T;
     const float* x = W + e->w_rnnin;
@@ -573,6 +574,42 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
     ConvDesc c1 = e->c1, c2 = e->c2, c3 = e->c3;
     c1.B = c2.B = c3.B = B;
     const float* dfc = W + e->w_drnnin;
+    if (e->last_tm > 0 && e->rn) {
+        // ResNet policy, time-major form: BPTT walks the chunks on the second stream, the recurrent weight gradients follow there, and
+        // the encoder's backward (whose weight gradients reduce over ALL frames: one pass over the whole minibatch) starts once
+        // d_rnnin is complete.  The forward is where this form pays for the ResNets: the recurrence of chunk c runs under the encoder
+        // of chunk c + 1.
+        const int n = e->last_n, T = B / n, NC = e->last_tm, Tc = (T + NC - 1) / NC;
+        hipStream_t sB = e->s2;
+        const uint8_t* fmask = reinterpret_cast<const uint8_t*>(W + e->w_fmask);
+        const int* iota = reinterpret_cast<const int*>(W + e->w_iota);
+        float* ws2 = W + e->w_ws2;
+        HAB_TRY(tm_order(e, NC + 1, stream, sB));  // the head gradients are in place
+        for (int c = NC - 1; c >= 0; --c) {
+            const int t0 = c * Tc, t1 = std::min(T, t0 + Tc);
+            if (t0 >= t1) continue;
+            for (int l = L - 1; l >= 0; --l) {
+                RnnLayerParams lp = layer_params(e, l);
+                RnnWork wk = layer_work(e, l);
+                const float* dout = l == L - 1 ? W + e->w_dfeat : W + e->w_dlayer[l + 1];
+                const float* xin = l == 0 ? W + e->w_rnnin : W + e->w_out[l - 1];
+                const int ldx = l == 0 ? e->rnn_ld : H;
+                float* dx = l == 0 ? W + e->w_drnnin : W + e->w_dlayer[l];
+                Probe pr(e, HAB_PROBE_RNN_BWD, sB);
+                HAB_TRY(rnn_tm_layer_backward(e->d.rnn_type, H, lp, wk, dout, dx, ldx, l == 0 ? xin : nullptr, ldx, H, fmask, iota, n, T, t0, t1,
+                                              W + e->w_scratch + (size_t)l * 2 * n * H, ws2, e->ws2_floats, sB));
+            }
+        }
+        for (int l = L - 1; l >= 0; --l) {
+            RnnLayerParams lp = layer_params(e, l);
+            RnnWork wk = layer_work(e, l);
+            HAB_TRY(rnn_tm_layer_param_grads(e->d.rnn_type, H, lp, wk, l == 0 ? W + e->w_rnnin : W + e->w_out[l - 1], l == 0 ? e->rnn_ld : H, B, ws2,
+                                             e->ws2_floats, sB));
+        }
+        HAB_TRY(tm_order(e, 2 * NC + 3, sB, stream));  // d_rnnin and the recurrent gradients are final
+        Probe pr(e, HAB_PROBE_ENC_BWD, stream);
+        return resnet_encoder_backward(e, obs, e->last_masks, rows, B, stream);
+    }
     if (e->last_tm > 0 && !e->rn) {
         // Time-major chunked backward: BPTT walks the chunks from the last to the first on the second stream; behind each chunk the
         // DATA-gradient chain of its frames (fc, conv3, conv2 -- per-frame work) runs on `stream`; the weight gradients, which reduce over

@@ -337,6 +337,12 @@ int build_resnet(hab_policy* e) {
     e->w_step_h = wk.take((int64_t)d.max_envs * H * 2);
     e->ws_floats = (int64_t)32 << 20;
     e->w_ws = wk.take(e->ws_floats);
+    // second stream of the time-major chunked recurrence (engine.hip): its own split-K scratch (same cap: the split-K plans, hence the
+    // bits, must not depend on the stream), the dense per-frame episode-start mask, an iota
+    e->ws2_floats = e->ws_floats;
+    e->w_ws2 = wk.take(e->ws2_floats);
+    e->w_fmask = wk.take((B + 3) / 4 + 64);
+    e->w_iota = wk.take(B + 64);
     e->work_floats = wk.used;
     return HAB_OK;
 }
@@ -394,19 +400,24 @@ static int fill_embed_slots(hab_policy* e, const hab_obs* obs, EmbedSlot* sl, bo
     return (ok && n == r->nslots) ? HAB_OK : HAB_ERR_ARG;
 }
 
-// conv -> raw, GroupNorm (+residual, +ReLU) -> out
-static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, const float* residual, int relu, int B, hipStream_t s) {
+// conv -> raw, GroupNorm (+residual, +ReLU) -> out.  f0: first frame of the workspace buffers this call works on (time-major chunks of
+// a minibatch, engine.hip); `in` / `residual` are already offset by the caller.
+static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, const float* residual, int relu, int B, hipStream_t s, int f0 = 0) {
     float* W = e->WK;
     ConvDesc cd = c.cd;
     cd.B = B;
+    float* raw = W + c.w_raw + (int64_t)f0 * c.out_floats();
+    float* out = W + c.w_out + (int64_t)f0 * c.out_floats();
+    float* mean = W + c.w_mean + (int64_t)f0 * c.groups;
+    float* rstd = W + c.w_rstd + (int64_t)f0 * c.groups;
     if (&c == &e->rn->stem && c.pk_p >= 0) {  // stem: input strip resident in LDS (stem_conv_strip.h)
         static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
-        const int rc = stem_strip ? stem_conv_forward(in, reinterpret_cast<const unsigned short*>(e->PK + c.pk_p), W + c.w_raw, B, cd.H, cd.W, s) : 1;
+        const int rc = stem_strip ? stem_conv_forward(in, reinterpret_cast<const unsigned short*>(e->PK + c.pk_p), raw, B, cd.H, cd.W, s) : 1;
         if (rc != 0 && rc != 1) return rc;
-        if (rc == 1) HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, W + c.w_raw, 0, W + e->w_ws, e->ws_floats, s));
+        if (rc == 1) HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, raw, 0, W + e->w_ws, e->ws_floats, s));
         GnArgs g;
-        g.x = W + c.w_raw; g.y = W + c.w_out; g.gamma = e->p(c.i_gamma); g.beta = e->p(c.i_beta); g.residual = residual;
-        g.mean = W + c.w_mean; g.rstd = W + c.w_rstd; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = c.groups;
+        g.x = raw; g.y = out; g.gamma = e->p(c.i_gamma); g.beta = e->p(c.i_beta); g.residual = residual;
+        g.mean = mean; g.rstd = rstd; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = c.groups;
         g.relu = relu; g.eps = 1e-5f; g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
         return groupnorm_forward(g, s);
     }
@@ -419,17 +430,17 @@ static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, cons
     if (c.pk_p >= 0 && B <= cgs_max_b && (!e->save_acts || cgs_eval)) {
         ConvGnArgs q;
         q.x = in; q.w_planes = reinterpret_cast<const unsigned short*>(e->PK + c.pk_p); q.gamma = e->p(c.i_gamma); q.beta = e->p(c.i_beta);
-        q.residual = residual; q.y = W + c.w_out;
-        if (e->save_acts) { q.raw = W + c.w_raw; q.mean = W + c.w_mean; q.rstd = W + c.w_rstd; }
+        q.residual = residual; q.y = out;
+        if (e->save_acts) { q.raw = raw; q.mean = mean; q.rstd = rstd; }
         q.B = B; q.H = cd.H; q.W = cd.W; q.C = cd.C; q.Cout = cd.Cout; q.KH = cd.KH; q.KW = cd.KW; q.stride = cd.stride; q.pad = cd.pad;
         q.groups = c.groups; q.relu = relu; q.eps = 1e-5f;
         const int rc = conv_gn_fused(q, s);
         if (rc != 1) return rc;
     }
-    HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, W + c.w_raw, 0, W + e->w_ws, e->ws_floats, s));
+    HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, raw, 0, W + e->w_ws, e->ws_floats, s));
     GnArgs g;
-    g.x = W + c.w_raw; g.y = W + c.w_out; g.gamma = e->p(c.i_gamma); g.beta = e->p(c.i_beta); g.residual = residual;
-    g.mean = W + c.w_mean; g.rstd = W + c.w_rstd; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = c.groups;
+    g.x = raw; g.y = out; g.gamma = e->p(c.i_gamma); g.beta = e->p(c.i_beta); g.residual = residual;
+    g.mean = mean; g.rstd = rstd; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = c.groups;
     g.relu = relu; g.eps = 1e-5f;
     g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;  // chunk-parallel statistics for frames > 128 KB
     return groupnorm_forward(g, s);
@@ -474,32 +485,49 @@ int resnet_encode(hab_policy* e, const hab_obs* obs, int n, float* out, hipStrea
     return HAB_OK;
 }
 
-int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s) {
+static int resnet_ingest(hab_policy* e, const hab_obs* obs, const int* rows, int B, hipStream_t s);
+static int resnet_layers_forward(hab_policy* e, int Btot, int f0, int nB, hipStream_t s);
+
+// Encoder forward of frames [f0, f0 + nB) of a B-frame batch (time-major chunks of a minibatch, engine.hip; f0 = 0, nB = B: the whole
+// batch).  The observation ingest and RunningMeanAndVar -- whose batch statistics span ALL B frames (running_mean_and_var.py:33-49) --
+// run for the whole batch with the first chunk; everything behind them is per frame.
+int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s, int f0, int nB) {
     ResNetPlan* r = e->rn;
     float* W = e->WK;
     const int H = e->d.hidden;
+    if (nB < 0) nB = B;
+    if (f0 < 0 || nB <= 0 || f0 + nB > B || (f0 > 0 && !rows)) return HAB_ERR_ARG;
     if (obs->visual_features) {  // frozen encoder: the rollout already holds its output (resnet_policy.py:636-646)
-        const long long total = (long long)B * r->fc_in;
-        feats_nchw_to_nhwc_kernel<<<(int)cdivl(total, 256), 256, 0, s>>>(obs->visual_features, rows, W + r->comp.w_out, B, r->comp_c,
-                                                                         r->comp_hw);
-        HAB_LAUNCH_CHECK();
+        if (f0 == 0) {
+            const long long total = (long long)B * r->fc_in;
+            feats_nchw_to_nhwc_kernel<<<(int)cdivl(total, 256), 256, 0, s>>>(obs->visual_features, rows, W + r->comp.w_out, B, r->comp_c,
+                                                                             r->comp_hw);
+            HAB_LAUNCH_CHECK();
+        }
     } else {
-        HAB_TRY(resnet_backbone_forward(e, obs, rows, B, s));
+        if (f0 == 0) HAB_TRY(resnet_ingest(e, obs, rows, B, s));
+        HAB_TRY(resnet_layers_forward(e, B, f0, nB, s));
     }
     // visual_fc (Flatten in NCHW order -> packed weight is permuted) + ReLU, written into rnn_in[:, :H]
     float* ws = W + e->w_ws;
-    HAB_TRY(linear_fwd(W + r->comp.w_out, r->fc_in, e->PK + r->pk_fc, r->fc_in, e->p(r->i_fcb), W + e->w_rnnin, e->rnn_ld, B, H,
+    float* rin = W + e->w_rnnin + (int64_t)f0 * e->rnn_ld;
+    HAB_TRY(linear_fwd(W + r->comp.w_out + (int64_t)f0 * r->fc_in, r->fc_in, e->PK + r->pk_fc, r->fc_in, e->p(r->i_fcb), rin, e->rnn_ld, nB, H,
                        r->fc_in, 1, 0, ws, e->ws_floats, s));
     EmbedArgs ea;
     HAB_TRY(fill_embed_slots(e, obs, ea.slot, false));
-    ea.nslots = r->nslots; ea.masks = masks; ea.rows = rows;
-    ea.out = W + e->w_rnnin; ea.ld = e->rnn_ld; ea.col0 = H; ea.B = B; ea.saved = W + r->w_embsave;
+    ea.nslots = r->nslots; ea.masks = masks; ea.rows = rows ? rows + f0 : nullptr;
+    ea.out = rin; ea.ld = e->rnn_ld; ea.col0 = H; ea.B = nB; ea.saved = W + r->w_embsave + (int64_t)f0 * r->nslots * 4;
     if (!masks) return HAB_ERR_ARG;
     return embed_forward(ea, s);
 }
 
-// input normalisation + backbone + compression: obs -> comp.w_out [B][Hf*Wf][C]
 static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int* rows, int B, hipStream_t s) {
+    HAB_TRY(resnet_ingest(e, obs, rows, B, s));
+    return resnet_layers_forward(e, B, 0, B, s);
+}
+
+// observation ingest + RunningMeanAndVar over the WHOLE batch: obs -> x0 [B][H/2][W/2][cpad]
+static int resnet_ingest(hab_policy* e, const hab_obs* obs, const int* rows, int B, hipStream_t s) {
     ResNetPlan* r = e->rn;
     float* W = e->WK;
     const hab_policy_desc& d = e->d;
@@ -533,82 +561,96 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
         }
         HAB_TRY(rmv_normalize(x0, npix, r->cpad, r->creal, e->p(r->i_mean), e->p(r->i_var), s));
     }
-    // stem
+    return HAB_OK;
+}
+
+// stem, blocks, compression on frames [f0, f0 + B) of a Btot-frame batch: x0 -> comp.w_out [frame][Hf*Wf][C].  Every workspace buffer
+// is [frame][...], so a chunk works at frame offset f0 of each; decisions that the backward (which sees the whole batch) must share --
+// the fused stem -- are taken for Btot.
+static int resnet_layers_forward(hab_policy* e, int Btot, int f0, int B, hipStream_t s) {
+    ResNetPlan* r = e->rn;
+    float* W = e->WK;
+    const int64_t F0 = f0;
+    const RnConv& st = r->stem;
+    const int64_t stem_out = st.out_floats(), pool_floats = (int64_t)r->poolH * r->poolW * st.cd.Cout;
+    float* x0 = W + r->w_x0 + F0 * r->H2 * r->W2 * r->cpad;
+    float* stem_raw = W + st.w_raw + F0 * stem_out;
+    float* stem_act = W + st.w_out + F0 * stem_out;
+    float* pool = W + r->w_pool + F0 * pool_floats;
+    uint8_t* pool_idx = reinterpret_cast<uint8_t*>(W + r->w_pool_idx) + F0 * pool_floats;  // one byte per pooled element
+    ConvDesc scd = st.cd;
+    scd.B = B;
+    static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
+    static const int stem_fuse = hab_env_int("HAB_STEM_FUSE", 1);
+    auto stem_conv = [&]() -> int {
+        const int rcs = (stem_strip && st.pk_p >= 0) ? stem_conv_forward(x0, reinterpret_cast<const unsigned short*>(e->PK + st.pk_p), stem_raw, B, scd.H, scd.W, s) : 1;
+        if (rcs != 0 && rcs != 1) return rcs;
+        if (rcs == 1) HAB_TRY(conv_fwd(scd, x0, e->PK + st.pk_f, nullptr, stem_raw, 0, W + e->w_ws, e->ws_floats, s));
+        return HAB_OK;
+    };
+    GnArgs g;
+    g.x = stem_raw; g.y = nullptr; g.gamma = e->p(st.i_gamma); g.beta = e->p(st.i_beta); g.residual = nullptr;
+    g.mean = nullptr; g.rstd = nullptr; g.B = B; g.HW = scd.Ho() * scd.Wo(); g.C = scd.Cout; g.groups = st.groups; g.relu = 1;
+    g.eps = 1e-5f; g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
     bool stem_done = false;
     if (!e->save_acts) {  // act / encode: GroupNorm + ReLU + max-pool in one pass, the normalised frame is never written
-        ConvDesc cd = r->stem.cd;
-        cd.B = B;
-        static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
-        const int rcs = (stem_strip && r->stem.pk_p >= 0)
-                            ? stem_conv_forward(x0, reinterpret_cast<const unsigned short*>(e->PK + r->stem.pk_p), W + r->stem.w_raw, B, cd.H, cd.W, s) : 1;
-        if (rcs != 0 && rcs != 1) return rcs;
-        if (rcs == 1) HAB_TRY(conv_fwd(cd, x0, e->PK + r->stem.pk_f, nullptr, W + r->stem.w_raw, 0, W + e->w_ws, e->ws_floats, s));
-        GnArgs g;
-        g.x = W + r->stem.w_raw; g.y = nullptr; g.gamma = e->p(r->stem.i_gamma); g.beta = e->p(r->stem.i_beta); g.residual = nullptr;
-        g.mean = nullptr; g.rstd = nullptr; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = r->stem.groups; g.relu = 1;
-        g.eps = 1e-5f; g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
-        const int rc = groupnorm_relu_maxpool_forward(g, cd.Ho(), cd.Wo(), W + r->w_pool, nullptr, s);
+        HAB_TRY(stem_conv());
+        const int rc = groupnorm_relu_maxpool_forward(g, scd.Ho(), scd.Wo(), pool, nullptr, s);
         if (rc != 0 && rc != 1) return rc;
         if (rc == 1) {  // small frames: the register-resident GroupNorm, then the pool
-            g.y = W + r->stem.w_out; g.mean = W + r->stem.w_mean; g.rstd = W + r->stem.w_rstd;
+            g.y = stem_act; g.mean = W + st.w_mean + F0 * st.groups; g.rstd = W + st.w_rstd + F0 * st.groups;
             HAB_TRY(groupnorm_forward(g, s));
-            HAB_TRY(maxpool_forward(W + r->stem.w_out, W + r->w_pool, reinterpret_cast<uint8_t*>(W + r->w_pool_idx), B, cd.Ho(), cd.Wo(), cd.Cout, s));
+            HAB_TRY(maxpool_forward(stem_act, pool, pool_idx, B, scd.Ho(), scd.Wo(), scd.Cout, s));
         }
         stem_done = true;
     }
-    static const int stem_fuse = hab_env_int("HAB_STEM_FUSE", 1);
-    if (!stem_done && stem_fuse && groupnorm_pool_fusable(B, r->stem.cd.Ho() * r->stem.cd.Wo(), r->stem.cd.Cout, r->stem.groups, e->ws_floats)) {
+    // (the fused form needs its chunk-parallel kernels for the chunk AND for the whole batch the backward runs on)
+    if (!stem_done && stem_fuse && groupnorm_pool_fusable(B, g.HW, g.C, g.groups, e->ws_floats) &&
+        groupnorm_pool_fusable(Btot, g.HW, g.C, g.groups, e->ws_floats)) {
         // training forward: the same fused pass, keeping the statistics and the arg-max bytes; the ReLU mask is recomputed in the backward
-        ConvDesc cd = r->stem.cd;
-        cd.B = B;
-        static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
-        const int rcs = (stem_strip && r->stem.pk_p >= 0)
-                            ? stem_conv_forward(x0, reinterpret_cast<const unsigned short*>(e->PK + r->stem.pk_p), W + r->stem.w_raw, B, cd.H, cd.W, s) : 1;
-        if (rcs != 0 && rcs != 1) return rcs;
-        if (rcs == 1) HAB_TRY(conv_fwd(cd, x0, e->PK + r->stem.pk_f, nullptr, W + r->stem.w_raw, 0, W + e->w_ws, e->ws_floats, s));
-        GnArgs g;
-        g.x = W + r->stem.w_raw; g.y = nullptr; g.gamma = e->p(r->stem.i_gamma); g.beta = e->p(r->stem.i_beta); g.residual = nullptr;
-        g.mean = W + r->stem.w_mean; g.rstd = W + r->stem.w_rstd; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = r->stem.groups;
-        g.relu = 1; g.eps = 1e-5f; g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
-        HAB_TRY(groupnorm_relu_maxpool_forward(g, cd.Ho(), cd.Wo(), W + r->w_pool, reinterpret_cast<uint8_t*>(W + r->w_pool_idx), s));
+        HAB_TRY(stem_conv());
+        g.mean = W + st.w_mean + F0 * st.groups; g.rstd = W + st.w_rstd + F0 * st.groups;
+        HAB_TRY(groupnorm_relu_maxpool_forward(g, scd.Ho(), scd.Wo(), pool, pool_idx, s));
         r->stem_fused = true; r->stem_act_valid = false;
         stem_done = true;
     }
     if (!stem_done) {
-        HAB_TRY(conv_gn_forward(e, r->stem, x0, nullptr, 1, B, s));
-        HAB_TRY(maxpool_forward(W + r->stem.w_out, W + r->w_pool, reinterpret_cast<uint8_t*>(W + r->w_pool_idx), B, r->stem.cd.Ho(),
-                                r->stem.cd.Wo(), r->stem.cd.Cout, s));
+        HAB_TRY(conv_gn_forward(e, st, x0, nullptr, 1, B, s, f0));
+        HAB_TRY(maxpool_forward(stem_act, pool, pool_idx, B, scd.Ho(), scd.Wo(), scd.Cout, s));
         r->stem_fused = false; r->stem_act_valid = true;
     }
+    int64_t in_floats = pool_floats;  // per-frame size of the current block's input
     for (const auto& blk : r->blocks) {
-        const float* in = W + blk.w_in;
+        const float* in = W + blk.w_in + F0 * in_floats;
         const float* residual = in;
         if (blk.ds >= 0) {
-            HAB_TRY(conv_gn_forward(e, r->convs[blk.ds], in, nullptr, 0, B, s));
-            residual = W + r->convs[blk.ds].w_out;
+            const RnConv& dc = r->convs[blk.ds];
+            HAB_TRY(conv_gn_forward(e, dc, in, nullptr, 0, B, s, f0));
+            residual = W + dc.w_out + F0 * dc.out_floats();
         }
         const float* cur = in;
         for (size_t q = 0; q < blk.convs.size(); ++q) {
             const RnConv& c = r->convs[blk.convs[q]];
             const bool last = q + 1 == blk.convs.size();
-            if (last && blk.se_c) HAB_TRY(conv_gn_forward(e, c, cur, nullptr, 0, B, s));  // un-gated: the SE gate comes next
-            else HAB_TRY(conv_gn_forward(e, c, cur, last ? residual : nullptr, 1, B, s));
-            cur = W + c.w_out;
+            if (last && blk.se_c) HAB_TRY(conv_gn_forward(e, c, cur, nullptr, 0, B, s, f0));  // un-gated: the SE gate comes next
+            else HAB_TRY(conv_gn_forward(e, c, cur, last ? residual : nullptr, 1, B, s, f0));
+            cur = W + c.w_out + F0 * c.out_floats();
         }
+        const RnConv& lc = r->convs[blk.convs.back()];
         if (blk.se_c) {  // out = relu(sigmoid(W2 relu(W1 mean_hw(y) + b1) + b2) * y + identity)
-            const RnConv& c = r->convs[blk.convs.back()];
-            const int HW = c.cd.Ho() * c.cd.Wo(), C = blk.se_c, R = blk.se_r;
+            const int HW = lc.cd.Ho() * lc.cd.Wo(), C = blk.se_c, R = blk.se_r;
             float* ws = W + e->w_ws;
-            HAB_TRY(se_pool(W + c.w_out, W + blk.w_se_pool, B, HW, C, s));
-            HAB_TRY(linear_fwd(W + blk.w_se_pool, C, e->p(blk.i_se1w), C, e->p(blk.i_se1b), W + blk.w_se_h, R, B, R, C, 1, 0, ws,
-                               e->ws_floats, s));
-            HAB_TRY(linear_fwd(W + blk.w_se_h, R, e->p(blk.i_se2w), R, e->p(blk.i_se2b), W + blk.w_se_gate, C, B, C, R, 0, 0, ws,
-                               e->ws_floats, s));
-            HAB_TRY(sigmoid_inplace(W + blk.w_se_gate, (long long)B * C, s));
-            HAB_TRY(se_apply_forward(W + c.w_out, W + blk.w_se_gate, residual, W + blk.w_out, B, HW, C, s));
+            float* y = W + lc.w_out + F0 * lc.out_floats();
+            float* sp = W + blk.w_se_pool + F0 * C; float* sh = W + blk.w_se_h + F0 * R; float* sg = W + blk.w_se_gate + F0 * C;
+            HAB_TRY(se_pool(y, sp, B, HW, C, s));
+            HAB_TRY(linear_fwd(sp, C, e->p(blk.i_se1w), C, e->p(blk.i_se1b), sh, R, B, R, C, 1, 0, ws, e->ws_floats, s));
+            HAB_TRY(linear_fwd(sh, R, e->p(blk.i_se2w), R, e->p(blk.i_se2b), sg, C, B, C, R, 0, 0, ws, e->ws_floats, s));
+            HAB_TRY(sigmoid_inplace(sg, (long long)B * C, s));
+            HAB_TRY(se_apply_forward(y, sg, residual, W + blk.w_out + F0 * lc.out_floats(), B, HW, C, s));
         }
+        in_floats = lc.out_floats();
     }
-    return conv_gn_forward(e, r->comp, W + r->blocks.back().w_out, nullptr, 1, B, s);
+    return conv_gn_forward(e, r->comp, W + r->blocks.back().w_out + F0 * in_floats, nullptr, 1, B, s, f0);
 }
 
 namespace {
