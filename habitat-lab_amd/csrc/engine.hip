@@ -289,6 +289,18 @@ static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
 
 // ---- time-major chunked recurrence: second stream + events ----
 static int tm_chunks_cfg() { static const int v = hab_env_int("HAB_RNN_CHUNKS", 4); return v; }
+// ResNet policies: built, bit-identical to the packed form at one chunk (tests/test_gpu_determinism.py), and measured SLOWER on the C3
+// benchmark (ResNet18 + 2-layer LSTM, 32 environments per minibatch): 28.5 k env-steps/s with 1, 2 or 3 chunks against 29.1 k packed on the
+// same box.  The packed form walks max_len ~ 107 steps of the ~215 episode fragments, the time-major form all T = 128 steps of 32 rows --
+// both latency-bound per step, so the packed form is 16 % shorter; every extra chunk is another pass through ~60 encoder kernels at a
+// quarter of the frames; and the encoder's weight gradients reduce over all frames, so the backward cannot follow chunk by chunk the way
+// SimpleCNN's data-gradient chain does.  Default: packed (0); HAB_RNN_CHUNKS_RESNET = k > 0 selects k chunks (HAB_RNN_CHUNKS = 0 / 1 still
+// selects the packed form / one chunk for both policies).
+static int tm_chunks_resnet_cfg() {
+    static const int v = hab_env_int("HAB_RNN_CHUNKS_RESNET", 0);
+    const int base = tm_chunks_cfg();
+    return base <= 1 ? base : v;
+}
 static int tm_setup(hab_policy* e, int nev) {
     if (!e->s2) {
         // highest priority: the recurrence is a chain of ~7 us launches; each must be dispatched ahead of the queued waves of the large
@@ -428,7 +440,7 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
     const int T = B / n;
     // (ResNet policies too since round 4: their encoder runs per chunk behind a whole-batch ingest, engine_resnet.hip)
     int NC = (e->Cin > 0 && rows && !pack->env_first_frame && (B % n) == 0 && T >= 2 && e->w_ws2 >= 0 && (int64_t)L * 2 * n <= 3 * (int64_t)e->d.max_frames)
-                 ? tm_chunks_cfg() : 0;
+                 ? (e->rn ? tm_chunks_resnet_cfg() : tm_chunks_cfg()) : 0;
     if (NC > T) NC = T;
     const float* x = W + e->w_rnnin;
     int ldx = e->rnn_ld;

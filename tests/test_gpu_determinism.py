@@ -83,9 +83,13 @@ def test_time_major_chunked_recurrence_vs_the_packed_form(workload):
     assert _digest_in_subprocess(workload, 1, {"HAB_RNN_CHUNKS": "1"}) == packed
     tol = 1e-5 if workload == "c2" else 1e-4
     for chunks in (("4", "7") if workload == "c2" else ("4",)):
-        d = _digest_in_subprocess(workload, 1, {"HAB_RNN_CHUNKS": chunks})
+        env = {"HAB_RNN_CHUNKS": chunks, "HAB_RNN_CHUNKS_RESNET": chunks}  # (the ResNet policies default to the packed form: measured faster)
+        d = _digest_in_subprocess(workload, 1, env)
         assert d["actions"] == packed["actions"]
         for k, v in d["losses"][0].items():
             a, b = float.fromhex(v), float.fromhex(packed["losses"][0][k])
-            assert abs(a - b) <= tol * max(abs(b), 1e-3), (chunks, k, a, b)
-        assert d == _digest_in_subprocess(workload, 1, {"HAB_RNN_CHUNKS": chunks}), "not reproducible"
+            # the three losses to `tol`; the min / mean / max statistics of the deep-encoder policy are taken after Adam steps whose
+            # gradients carry a few legitimately different ReLU decisions (tests/test_gpu_policy.py): 10x
+            t_k = tol if (workload == "c2" or k in ("value_loss", "action_loss", "dist_entropy")) else 10 * tol
+            assert abs(a - b) <= t_k * max(abs(b), 1e-3), (chunks, k, a, b)
+        assert d == _digest_in_subprocess(workload, 1, env), "not reproducible"
