@@ -829,7 +829,12 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
     }
     ConvDesc c0 = r->stem.cd;
     c0.B = B;
-    HAB_TRY(conv_wgrad(c0, W + r->w_x0, d_raw0, e->g(r->stem.i_w), nullptr, ws, e->ws_floats, s));
+    static const int stem_wg = hab_env_int("HAB_STEM_WGRAD", 1);
+    int rcw = 1;
+    if (stem_wg && r->cpad == 4 && c0.Cout == 32)  // strip-resident form (stem_wgrad_strip.h); 1: geometry not covered
+        rcw = stem_conv_wgrad(W + r->w_x0, d_raw0, e->g(r->stem.i_w), B, c0.H, c0.W, r->creal, ws, e->ws_floats, s);
+    if (rcw != 0 && rcw != 1) return rcw;
+    if (rcw == 1) HAB_TRY(conv_wgrad(c0, W + r->w_x0, d_raw0, e->g(r->stem.i_w), nullptr, ws, e->ws_floats, s));
     return HAB_OK;
 }
 

@@ -89,6 +89,8 @@ constexpr int STEM_PLANE_FLOATS = 3 * 14 * 1024 / 4;  // fragment-ordered bf16 p
 int stem_conv_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad);
 int stem_weight_planes(const float* wf, unsigned short* planes, hipStream_t s);
 int stem_conv_forward(const float* x, const unsigned short* planes, float* y, int B, int H, int W, hipStream_t s);  // 1: not covered
+// its weight gradient, both operands resident in LDS, transpose reads (stem_wgrad_strip.h); ws >= 256 * 7 * 1024 floats; 1: not covered
+int stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats, hipStream_t s);
 int groupnorm_forward(const GnArgs& a, hipStream_t s);
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s);
 // GroupNorm + ReLU + MaxPool2d(3, 2, 1) in one pass over the GroupNorm input; the normalised frame is never written.  idx (nullable):

@@ -268,6 +268,12 @@ int hab_split_weight_planes(const float* w_fwd, int Cout, int K, uint16_t* plane
  *       wider inputs return HAB_ERR_UNSUPPORTED (the caller runs hab_conv2d_fwd). */
 int hab_stem_split_weights(const float* w_fwd, uint16_t* planes, hipStream_t stream);
 int hab_stem_conv_fwd(const float* x, const uint16_t* w_planes, float* y, int B, int H, int W, hipStream_t stream);
+/* Its weight gradient (csrc/stem_wgrad_strip.h; the autograd backward of resnet.py:207-219 `conv1` under rl/ppo/ppo.py:253): x NHWC
+ * [B][H][W][4] (channels >= creal are padding), dy [B][Ho][Wo][32] -> dw_oihw [32][creal][7][7] (overwritten).  Both operands are
+ * resident in LDS, fragments come from transpose reads; covered: Wo a multiple of 16, <= 64; ws >= 256 * 7168 floats of scratch;
+ * otherwise HAB_ERR_UNSUPPORTED (the caller runs hab_conv2d_wgrad). */
+int hab_stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats,
+                        hipStream_t stream);
 int hab_conv_gn_fwd(const float* x, const uint16_t* w_planes, const float* gamma, const float* beta, const float* residual, float* y,
                     float* raw, float* mean, float* rstd, int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad,
                     int groups, int relu, float eps, hipStream_t stream);

@@ -171,3 +171,40 @@ def test_stem_conv_strip_refuses_wide_inputs(L):
     planes = torch.zeros(3 * 14 * 512, dtype=torch.int16, device="cuda")
     y = torch.zeros(1, 4, 150, 32, device="cuda")
     assert L.hab_stem_conv_fwd(P(x), P(planes), P(y), 1, 8, 300, S()) == -2
+
+
+@pytest.mark.parametrize("B,H,W,creal", [(3, 128, 128, 4), (300, 32, 32, 4), (2, 63, 64, 1), (5, 30, 96, 3)])
+def test_stem_wgrad_strip_vs_float64(L, B, H, W, creal):
+    """csrc/stem_wgrad_strip.h (weight gradient of the 7x7 / 2 / 3 stem, operands in LDS, transpose reads) against float64 and against
+    the implicit-GEMM weight gradient."""
+    torch.manual_seed(H + W + B)
+    x = torch.randn(B, 4, H, W) * torch.rand(B, 4, H, W).pow(2) * 3
+    x[:, creal:] = 0  # padding channels of the encoder input are zero
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(B, 32, Ho, Wo) * torch.rand(B, 32, Ho, Wo).pow(2)
+    xr = x[:, :creal].double().requires_grad_(False)
+    w = torch.zeros(32, creal, 7, 7, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, w, None, stride=2, padding=3).backward(dy.double())
+    ref = w.grad
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    ws = torch.zeros(1 << 22, device="cuda")
+    dw = torch.full((32, creal, 7, 7), float("nan"), device="cuda")
+    _lib.check(L.hab_stem_conv_wgrad(P(xd), P(dyd), P(dw), B, H, W, creal, P(ws), ws.numel(), S()))
+    torch.cuda.synchronize()
+    e1 = ((dw.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    dw2 = torch.zeros(32, 4, 7, 7, device="cuda")
+    _lib.check(L.hab_conv2d_wgrad(P(xd), P(dyd), P(dw2), None, B, H, W, 4, 32, 7, 7, 2, 3, P(ws), ws.numel(), S()))
+    e0 = ((dw2[:, :creal].double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert e1 <= 2 * e0 + 2e-7 and e1 < 3e-6, (e0, e1)
+    dw3 = torch.zeros_like(dw)
+    _lib.check(L.hab_stem_conv_wgrad(P(xd), P(dyd), P(dw3), B, H, W, creal, P(ws), ws.numel(), S()))
+    assert torch.equal(dw, dw3)
+
+
+def test_stem_wgrad_strip_refuses_uncovered_widths(L):
+    x = torch.zeros(1, 42, 42, 4, device="cuda")
+    dy = torch.zeros(1, 21, 21, 32, device="cuda")
+    dw = torch.zeros(32, 4, 7, 7, device="cuda")
+    ws = torch.zeros(1 << 21, device="cuda")
+    assert L.hab_stem_conv_wgrad(P(x), P(dy), P(dw), 1, 42, 42, 4, P(ws), ws.numel(), S()) == -2  # Wo = 21: not a multiple of 16
