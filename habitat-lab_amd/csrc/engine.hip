@@ -36,7 +36,7 @@ static int build_baseline(hab_policy* e) {
     if (!blind && (h3 <= 0 || w3 <= 0)) return HAB_ERR_ARG;
     e->fc_in = blind ? 0 : 32 * h3 * w3;
     e->rnn_in = (blind ? 0 : H) + d.goal_dim;  // policy.py:532-535
-    e->rnn_ld = (e->rnn_in + 3) & ~3;
+    e->rnn_ld = (e->rnn_in + 15) & ~15;  // rows padded (with zeros) to a multiple of 16: the K-chunk of the fused step projection (rnn.hip)
     const std::string ve = "net.visual_encoder.cnn.";
     if (!blind) {
         e->i_c1w = add_param(e, ve + "0.weight", {32, e->Cin, 8, 8});
@@ -72,6 +72,7 @@ static int build_baseline(hab_policy* e) {
     e->pk_c3d = pk.take(32 * 9 * 64);
     e->pk_fc = pk.take((int64_t)H * std::max(e->fc_in, 4));
     for (int l = 0; l < d.rnn_layers; ++l) e->pk_whht.push_back(pk.take((int64_t)e->G_ * H * H));
+    e->pk_wih0 = pk.take((int64_t)e->G_ * H * e->rnn_ld);  // layer 0's W_ih with rows padded to rnn_ld (fused step projection of `act`)
     e->packed_floats = pk.used;
 
     Arena wk;
@@ -196,6 +197,7 @@ extern "C" int hab_policy_repack(hab_policy* e, hipStream_t stream) {
     if (!e || !e->P) return HAB_ERR_ARG;
     if (e->rn) return resnet_repack(e, stream);
     const int H = e->d.hidden;
+    if (e->pk_wih0 >= 0) HAB_TRY(pad_rows(e->p(e->i_wih[0]), e->PK + e->pk_wih0, e->G_ * H, e->rnn_in, e->rnn_ld, stream));
     if (e->Cin == 0) {  // blind baseline policy: only the recurrent weights have a kernel-layout copy
         for (int l = 0; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_whh[l]), e->PK + e->pk_whht[l], e->G_ * H, H, stream));
         return HAB_OK;
@@ -333,6 +335,8 @@ static RnnLayerParams layer_params(hab_policy* e, int l) {
     if (e->G) { lp.dw_ih = e->g(e->i_wih[l]); lp.dw_hh = e->g(e->i_whh[l]); lp.db_ih = e->g(e->i_bih[l]); lp.db_hh = e->g(e->i_bhh[l]); }
     else { lp.dw_ih = lp.dw_hh = lp.db_ih = lp.db_hh = nullptr; }
     lp.in_dim = l == 0 ? e->rnn_in : e->d.hidden;
+    if (l == 0 && e->pk_wih0 >= 0) { lp.w_ih_pad = e->PK + e->pk_wih0; lp.w_ih_ld = e->rnn_ld; }
+    else if (l > 0 && (e->d.hidden & 15) == 0) { lp.w_ih_pad = lp.w_ih; lp.w_ih_ld = e->d.hidden; }
     return lp;
 }
 static RnnWork layer_work(hab_policy* e, int l) {

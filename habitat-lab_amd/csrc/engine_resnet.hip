@@ -238,7 +238,8 @@ int build_resnet(hab_policy* e) {
     r->i_fcb = add_param(e, "net.visual_fc.1.bias", {H});
     e->fc_in = r->fc_in;
     e->rnn_in = H + 32 * r->nslots;
-    e->rnn_ld = (e->rnn_in + 3) & ~3;
+    e->rnn_ld = (e->rnn_in + 15) & ~15;
+    if (e->rnn_ld != e->rnn_in) return HAB_ERR_UNSUPPORTED;  // (32-wide embedding slots behind a hidden size % 64 == 0: never padded)
     const std::string rn = "net.state_encoder.rnn.";
     for (int l = 0; l < d.rnn_layers; ++l) {
         const int in = l == 0 ? e->rnn_in : H;
@@ -275,6 +276,7 @@ int build_resnet(hab_policy* e) {
     pack_conv(r->comp, true);
     r->pk_fc = pk.take((int64_t)H * r->fc_in);
     for (int l = 0; l < d.rnn_layers; ++l) e->pk_whht.push_back(pk.take((int64_t)e->G_ * H * H));
+    e->pk_wih0 = pk.take((int64_t)e->G_ * H * e->rnn_ld);
     e->packed_floats = pk.used;
 
     // ---- workspace ----
@@ -373,6 +375,7 @@ int resnet_repack(hab_policy* e, hipStream_t s) {
     HAB_TRY(planes(r->comp));
     HAB_TRY(repack_flatten(e->p(r->i_fcw), e->PK + r->pk_fc, H, r->comp_c, r->comp_hw, s));
     for (int l = 0; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_whh[l]), e->PK + e->pk_whht[l], e->G_ * H, H, s));
+    HAB_TRY(pad_rows(e->p(e->i_wih[0]), e->PK + e->pk_wih0, e->G_ * H, e->rnn_in, e->rnn_ld, s));
     return HAB_OK;
 }
 

@@ -410,6 +410,21 @@ __global__ void transpose_kernel(const float* __restrict__ w, float* __restrict_
         if (c < C && r < R) wt[(size_t)c * R + r] = tile[threadIdx.x][j];
     }
 }
+__global__ void pad_rows_kernel(const float* __restrict__ w, float* __restrict__ wp, int R, int C, int ld) {
+    const long long total = (long long)R * ld;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % ld);
+        const long long r = e / ld;
+        wp[e] = c < C ? w[r * C + c] : 0.f;
+    }
+}
+int pad_rows(const float* w, float* wp, int R, int C, int ld, hipStream_t stream) {
+    if (!w || !wp || R <= 0 || C <= 0 || ld < C) return HAB_ERR_ARG;
+    const long long total = (long long)R * ld;
+    pad_rows_kernel<<<(int)fmin(2048.0, (double)cdivl(total, 256)), 256, 0, stream>>>(w, wp, R, C, ld);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
 int transpose2d(const float* w, float* wt, int R, int C, hipStream_t stream) {
     if (!w || !wt || R <= 0 || C <= 0) return HAB_ERR_ARG;
     transpose_kernel<<<dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, stream>>>(w, wt, R, C);

@@ -33,6 +33,7 @@ int colsum(const float* a, int lda, int M, int N, float* out, int accumulate, fl
 int repack_conv(const float* w_oihw, float* wf, float* wd, int Cout, int Cin, int KH, int KW, int cpad, hipStream_t stream);
 int repack_flatten(const float* w, float* wp, int N, int C, int HW, hipStream_t stream);
 int transpose2d(const float* w, float* wt, int R, int C, hipStream_t stream);
+int pad_rows(const float* w, float* wp, int R, int C, int ld, hipStream_t stream);  // wp[r][0 .. ld) = w[r][0 .. C) then zeros
 
 // rnn.hip -- packed-sequence recurrent encoder (GRU / LSTM)
 struct PackInfo {          // device copies of build_pack_info_from_dones (rnn_state_encoder.py:35-168)
@@ -49,6 +50,10 @@ struct RnnLayerParams {
     const float* w_hh_t;                                                          // [H][G*H] transposed copy
     float* dw_ih; float* dw_hh; float* db_ih; float* db_hh;
     int in_dim;
+    // inference step with the input projection inside the step kernel (rnn.hip): W_ih with rows of w_ih_ld floats (a multiple of 16,
+    // zero beyond in_dim; 16-byte aligned rows) -- null: the projection is a separate contraction
+    const float* w_ih_pad = nullptr;
+    int w_ih_ld = 0;
 };
 
 struct RnnWork {  // per-layer activations saved by the forward for BPTT; all [P][...] in FRAME order

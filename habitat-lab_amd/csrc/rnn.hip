@@ -55,6 +55,10 @@ struct StepArgs {
     float* gates; float* hn; float* hprev; float* cprev; float* c; // saved for BPTT (may be null in inference)
     float* out; int out_stride;                                // h' per frame
     float* c_out; int c_out_stride;                            // LSTM c' (inference path); training uses `c`
+    // Inference form with the INPUT PROJECTION inside the step (rollout `act`: 64 rows): x row q, W_ih rows padded to a multiple of 16
+    // columns (x_dim, zero beyond in_dim), b_ih.  `gi` is then unused: the separate M = 64 contraction + its split-K second pass (two
+    // launches per layer and environment step) disappear.
+    const float* x_base = nullptr; int x_stride = 0; const float* w_ih = nullptr; int w_ih_ld = 0; int x_dim = 0; const float* b_ih = nullptr;
 };
 
 // One workgroup = 16 rows x 16 hidden units x G gates; NW waves split K = H.  The recurrence is latency-bound (a step is a
@@ -62,8 +66,12 @@ struct StepArgs {
 // trips instead of one per chunk.
 template <int G, int NW>
 __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
-    __shared__ float red[NW][G][256];
+    // (four accumulators in the fused-projection form of BOTH cell types: LSTM i, f, g, o with x- and h-parts summed; GRU r, z summed,
+    //  the n gate's h-part and x-part apart -- n = tanh(gi_n + r * gh_n))
+    constexpr int GA = 4;
+    __shared__ float red[NW][GA][256];
     constexpr int U = 4;
+    const bool fused_x = a.x_base != nullptr;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
     const int i = lane & 15, kg = lane >> 4;
@@ -89,13 +97,13 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
         if constexpr (G == 4) cp_pre = kept_ ? a.cp_base[(size_t)(a.cp_idx ? a.cp_idx[qq_] : qq_) * a.cp_stride + u0 + u_] : 0.f;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            gi_pre[g] = a.gi[(size_t)f_pre * G * H + g * H + u0 + u_];
+            gi_pre[g] = fused_x ? a.b_ih[g * H + u0 + u_] : a.gi[(size_t)f_pre * G * H + g * H + u0 + u_];
             bhh_pre[g] = a.b_hh[g * H + u0 + u_];
         }
     }
-    f32x4 acc[G];
+    f32x4 acc[GA];
 #pragma unroll
-    for (int g = 0; g < G; ++g) { acc[g][0] = 0.f; acc[g][1] = 0.f; acc[g][2] = 0.f; acc[g][3] = 0.f; }
+    for (int g = 0; g < GA; ++g) { acc[g][0] = 0.f; acc[g][1] = 0.f; acc[g][2] = 0.f; acc[g][3] = 0.f; }
     const float* wrow[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) wrow[g] = a.w_hh + (size_t)(g * H + u0 + i) * H;
@@ -127,11 +135,41 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[g][s], acc[g], 0, 0, 0);
     }
+    if (fused_x) {  // + W_ih x: K-chunks of 16 dealt round-robin over the waves, two chunks of loads in flight
+        const float* xrow = a.x_base + (size_t)q * a.x_stride;
+        const float* wi[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) wi[g] = a.w_ih + (size_t)(g * H + u0 + i) * a.w_ih_ld;
+        const int nch = a.x_dim >> 4;
+        for (int c0 = wave; c0 < nch; c0 += 2 * NW) {
+            f32x4 xv[2], wv[2][G];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cc = c0 + j * NW;
+                const int k = (cc < nch ? cc : c0) * 16 + 4 * kg;
+                xv[j] = *reinterpret_cast<const f32x4*>(xrow + k);
+#pragma unroll
+                for (int g = 0; g < G; ++g) wv[j][g] = *reinterpret_cast<const f32x4*>(wi[g] + k);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (c0 + j * NW >= nch) continue;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int slot = (G == 3 && g == 2) ? 3 : g;  // GRU: the n gate's input part stays apart
+                        acc[slot] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[j][s], wv[j][g][s], acc[slot], 0, 0, 0);
+                    }
+            }
+        }
+    }
     // D layout (16x16): col = lane & 15 (unit), row = (lane >> 4) * 4 + v
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int g = 0; g < GA; ++g)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) red[wave][g][(kg * 4 + v) * 16 + i] = acc[g][v];
+        for (int v = 0; v < 4; ++v)
+            if (g < G || fused_x) red[wave][g][(kg * 4 + v) * 16 + i] = acc[g][v];
     __syncthreads();
     if (t >= 256) return;
     const int r = t >> 4, u = t & 15;  // one (row, unit) per thread
@@ -144,6 +182,12 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
 #pragma unroll
         for (int w = 0; w < NW; w += 4) sum += (red[w][g][t] + red[w + 1][g][t]) + (red[w + 2][g][t] + red[w + 3][g][t]);
         gh[g] = sum + bhh_pre[g];
+    }
+    if (G == 3 && fused_x) {  // gi_n = W_in x + b_in (gi_pre holds the bias; for r, z -- and every LSTM gate -- the x-part is inside gh)
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4) sum += (red[w][3][t] + red[w + 1][3][t]) + (red[w + 2][3][t] + red[w + 3][3][t]);
+        gi_pre[2] += sum;
     }
     const int f = f_pre;
     const int uu = u0 + u;
@@ -226,8 +270,14 @@ int rnn_step_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const 
                            const float* c_in, int c_in_stride, const uint8_t* masks, int n, float* gi_scratch, float* h_out,
                            int h_out_stride, float* c_out, int c_out_stride, float* ws, size_t ws_floats, hipStream_t stream) {
     const int G = rnn_type == RNN_GRU ? 3 : 4;
-    HAB_TRY(linear_fwd(x, ldx, lp.w_ih, lp.in_dim, lp.b_ih, gi_scratch, G * H, n, G * H, lp.in_dim, 0, 0, ws, ws_floats, stream));
+    // input projection inside the step kernel when the engine supplies W_ih with padded, aligned rows: x rows must be readable (and
+    // zero where W_ih's padding is, or at least finite) up to w_ih_ld
+    static const int fuse_cfg = hab_env_int("HAB_RNN_FUSE_PROJ", 1);
+    const bool fuse = fuse_cfg && lp.w_ih_pad && lp.w_ih_ld > 0 && (lp.w_ih_ld & 15) == 0 && ldx >= lp.w_ih_ld && (ldx & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(lp.w_ih_pad)) & 15) == 0;
+    if (!fuse) HAB_TRY(linear_fwd(x, ldx, lp.w_ih, lp.in_dim, lp.b_ih, gi_scratch, G * H, n, G * H, lp.in_dim, 0, 0, ws, ws_floats, stream));
     StepArgs a;
+    if (fuse) { a.x_base = x; a.x_stride = ldx; a.w_ih = lp.w_ih_pad; a.w_ih_ld = lp.w_ih_ld; a.x_dim = lp.w_ih_ld; a.b_ih = lp.b_ih; }
     a.R = n; a.H = H;
     a.hp_base = h_in; a.hp_idx = nullptr; a.hp_stride = h_in_stride;
     a.cp_base = c_in; a.cp_idx = nullptr; a.cp_stride = c_in_stride;
