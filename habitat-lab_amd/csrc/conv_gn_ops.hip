@@ -2,7 +2,6 @@
 #include "conv_gn_slab.h"
 #include "stem_conv_strip.h"
 #include "stem_wgrad_strip.h"
-#include "conv3x3_strip.h"
 #include "resnet_ops.h"
 #include "../../include/habitat_amd.h"
 
@@ -32,24 +31,9 @@ int stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int 
     return stem_wgrad_strip(x, dy, dw_oihw, B, H, W, creal, ws, ws_floats, s);
 }
 
-int conv3x3_strip_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad) { return conv3x3_strip_covers(H, W, C, Cout, KH, KW, stride, pad); }
-int conv3x3_strip_planes(const float* w_packed, int flip, unsigned short* planes, hipStream_t s) { return conv3x3_strip_weights(w_packed, flip, planes, s); }
-int conv3x3_strip_run(const float* x, const unsigned short* planes, const float* mask, const float* add, float* y, int B, int H, int W, hipStream_t s) {
-    return conv3x3_strip(x, planes, mask, add, y, B, H, W, s);
-}
-
 }  // namespace hab
 
 using namespace hab;
-
-extern "C" int hab_conv3x3_c32_split_weights(const float* w_packed, int data_gradient, uint16_t* planes, hipStream_t stream) {
-    return conv3x3_strip_planes(w_packed, data_gradient ? 1 : 0, planes, stream);
-}
-extern "C" int hab_conv3x3_c32(const float* x, const uint16_t* w_planes, const float* relu_mask, const float* add, float* y, int B, int H, int W,
-                               hipStream_t stream) {
-    const int rc = conv3x3_strip_run(x, w_planes, relu_mask, add, y, B, H, W, stream);
-    return rc == 1 ? HAB_ERR_UNSUPPORTED : rc;
-}
 
 extern "C" int hab_stem_split_weights(const float* w_fwd, uint16_t* planes, hipStream_t stream) { return stem_weight_planes(w_fwd, planes, stream); }
 extern "C" int hab_stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats,

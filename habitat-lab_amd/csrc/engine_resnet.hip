@@ -25,7 +25,6 @@ struct RnConv {
     int i_w = -1, i_gamma = -1, i_beta = -1;
     int64_t pk_f = -1, pk_d = -1;   // packed weights (pk_d < 0: no data gradient needed)
     int64_t pk_p = -1;              // forward weights as three bf16 planes for the fused small-batch kernel (conv_gn_slab.h), or -1
-    int64_t pk_s = -1, pk_sd = -1;  // 3x3 32 -> 32 layers: fragment-ordered planes of the forward / data-gradient filter (conv3x3_strip.h)
     int64_t w_raw = -1, w_mean = -1, w_rstd = -1, w_out = -1;
     int cgroups = 1;             // ResNeXt: groups of the 3x3 convolution (weight parameter is (Cout, C / cgroups, 3, 3))
     int64_t out_floats() const { return (int64_t)cd.Ho() * cd.Wo() * cd.Cout; }
@@ -270,10 +269,6 @@ int build_resnet(hab_policy* e) {
         if (need_d) c.pk_d = pk.take(n);
         if (conv_gn_fused_ok(c.cd.C, c.cd.Cout, c.cd.H, c.cd.W, c.cd.KH, c.cd.KW, c.cd.stride, c.cd.pad, c.groups))
             c.pk_p = pk.take((3 * n + 1) / 2);  // 3 planes x 2 bytes per weight
-        if (need_d && c.cgroups == 1 && conv3x3_strip_ok(c.cd.H, c.cd.W, c.cd.C, c.cd.Cout, c.cd.KH, c.cd.KW, c.cd.stride, c.cd.pad)) {
-            c.pk_s = pk.take(C3S_PLANE_FLOATS);
-            c.pk_sd = pk.take(C3S_PLANE_FLOATS);
-        }
     };
     pack_conv(r->stem, false);
     if (stem_conv_ok(r->stem.cd.H, r->stem.cd.W, r->stem.cd.C, r->stem.cd.Cout, 7, 7, 2, 3)) r->stem.pk_p = pk.take(STEM_PLANE_FLOATS);
@@ -370,10 +365,6 @@ int resnet_repack(hab_policy* e, hipStream_t s) {
                            c.cd.C, s);
     };
     auto planes = [&](const RnConv& c) {
-        if (c.pk_s >= 0) {
-            HAB_TRY(conv3x3_strip_planes(e->PK + c.pk_f, 0, reinterpret_cast<unsigned short*>(e->PK + c.pk_s), s));
-            HAB_TRY(conv3x3_strip_planes(e->PK + c.pk_d, 1, reinterpret_cast<unsigned short*>(e->PK + c.pk_sd), s));
-        }
         if (c.pk_p < 0) return (int)HAB_OK;
         return weight_planes(e->PK + c.pk_f, c.cd.Cout, c.cd.KH * c.cd.KW * c.cd.C, reinterpret_cast<unsigned short*>(e->PK + c.pk_p), s);
     };
@@ -449,12 +440,7 @@ static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, cons
         const int rc = conv_gn_fused(q, s);
         if (rc != 1) return rc;
     }
-    static const int c3s_on = hab_env_int("HAB_C3X3_STRIP", 1);
-    int rcs = 1;
-    if (c3s_on && c.pk_s >= 0 && B >= 16)  // layer1: input strip in LDS, two pixel tiles per wave (conv3x3_strip.h); 1: not covered
-        rcs = conv3x3_strip_run(in, reinterpret_cast<const unsigned short*>(e->PK + c.pk_s), nullptr, nullptr, raw, B, cd.H, cd.W, s);
-    if (rcs != 0 && rcs != 1) return rcs;
-    if (rcs == 1) HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, raw, 0, W + e->w_ws, e->ws_floats, s));
+    HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, raw, 0, W + e->w_ws, e->ws_floats, s));
     GnArgs g;
     g.x = raw; g.y = out; g.gamma = e->p(c.i_gamma); g.beta = e->p(c.i_beta); g.residual = residual;
     g.mean = mean; g.rstd = rstd; g.B = B; g.HW = cd.Ho() * cd.Wo(); g.C = cd.Cout; g.groups = c.groups;
@@ -703,17 +689,6 @@ static int gn_backward(hab_policy* e, const RnConv& c, const float* dy, const fl
     return HAB_OK;
 }
 
-// data gradient of conv c: the strip kernel for the 3x3 32 -> 32 layers, the generic dispatch otherwise
-static int conv_dgrad_of(hab_policy* e, const RnConv& c, const ConvDesc& cd, const float* dy, const float* mask, const float* add, float* dx,
-                         hipStream_t s) {
-    static const int c3s_on = hab_env_int("HAB_C3X3_STRIP", 1);
-    if (c3s_on && c.pk_sd >= 0 && cd.B >= 16) {
-        const int rc = conv3x3_strip_run(dy, reinterpret_cast<const unsigned short*>(e->PK + c.pk_sd), mask, add, dx, cd.B, cd.H, cd.W, s);
-        if (rc != 1) return rc;
-    }
-    return conv_dgrad(cd, dy, e->PK + c.pk_d, mask, add, dx, e->WK + e->w_ws, e->ws_floats, s);
-}
-
 int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s) {
     ResNetPlan* r = e->rn;
     float* W = e->WK;
@@ -793,7 +768,7 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
             }
             float* tmp = gp.get();
             if (!tmp) return HAB_ERR_ARG;
-            HAB_TRY(conv_dgrad_of(e, c, c2, cur, W + pc.w_out /* ReLU mask */, nullptr, tmp, s));
+            HAB_TRY(conv_dgrad(c2, cur, e->PK + c.pk_d, W + pc.w_out /* ReLU mask */, nullptr, tmp, ws, e->ws_floats, s));
             gp.put(cur);
             float* nxt = gp.get();
             if (!nxt) return HAB_ERR_ARG;
@@ -823,7 +798,7 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
         HAB_TRY(conv_wgrad(c2, in, cur, e->g(c0.i_w), nullptr, ws, e->ws_floats, s));
         float* d_in = gp.get();
         if (!d_in) return HAB_ERR_ARG;
-        HAB_TRY(conv_dgrad_of(e, c0, c2, cur, nullptr, add_ptr, d_in, s));
+        HAB_TRY(conv_dgrad(c2, cur, e->PK + c0.pk_d, nullptr, add_ptr, d_in, ws, e->ws_floats, s));
         gp.put(cur);
         gp.put(add_ptr);
         d_out = d_in;

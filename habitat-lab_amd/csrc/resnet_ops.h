@@ -89,13 +89,6 @@ constexpr int STEM_PLANE_FLOATS = 3 * 14 * 1024 / 4;  // fragment-ordered bf16 p
 int stem_conv_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad);
 int stem_weight_planes(const float* wf, unsigned short* planes, hipStream_t s);
 int stem_conv_forward(const float* x, const unsigned short* planes, float* y, int B, int H, int W, hipStream_t s);  // 1: not covered
-// 3x3 / 1 / 1 convolution 32 -> 32 channels (ResNet layer1), forward and data gradient, input strip resident in LDS, two pixel tiles
-// per wave (conv3x3_strip.h); planes: 3 x 18 x 512 uint16 per direction (conv3x3_strip_planes: flip = 1 for the data gradient from the
-// dgrad-packed weight); 1: geometry not covered
-constexpr int C3S_PLANE_FLOATS = 3 * 18 * 512 / 2;
-int conv3x3_strip_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad);
-int conv3x3_strip_planes(const float* w_packed, int flip, unsigned short* planes, hipStream_t s);
-int conv3x3_strip_run(const float* x, const unsigned short* planes, const float* mask, const float* add, float* y, int B, int H, int W, hipStream_t s);
 // its weight gradient, both operands resident in LDS, transpose reads (stem_wgrad_strip.h); ws >= 256 * 7 * 1024 floats; 1: not covered
 int stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats, hipStream_t s);
 int groupnorm_forward(const GnArgs& a, hipStream_t s);

@@ -274,15 +274,6 @@ int hab_stem_conv_fwd(const float* x, const uint16_t* w_planes, float* y, int B,
  * otherwise HAB_ERR_UNSUPPORTED (the caller runs hab_conv2d_wgrad). */
 int hab_stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats,
                         hipStream_t stream);
-/* 3x3 / stride 1 / padding 1 convolution with 32 input and 32 output channels (ResNet layer1: resnet.py:19-34 conv3x3 inside BasicBlock
- * :37-69), forward and data gradient, input strip resident in LDS with two pixel tiles per wave (csrc/conv3x3_strip.h).
- *   hab_conv3x3_c32_split_weights: w_packed = hab_repack_conv_weight's w_fwd (data_gradient = 0) or w_dgrad (data_gradient = 1: the taps
- *       are visited in reverse) -> 3 x 18 x 512 uint16, the exact three-term bf16 split in MFMA fragment order
- *   hab_conv3x3_c32: y = conv(x) [+ add] [* (relu_mask > 0)], x / y / add / relu_mask NHWC [B][H][W][32]; covered: 16 < W <= 32; other
- *       widths return HAB_ERR_UNSUPPORTED (the caller runs hab_conv2d_fwd / hab_conv2d_dgrad). */
-int hab_conv3x3_c32_split_weights(const float* w_packed, int data_gradient, uint16_t* planes, hipStream_t stream);
-int hab_conv3x3_c32(const float* x, const uint16_t* w_planes, const float* relu_mask, const float* add, float* y, int B, int H, int W,
-                    hipStream_t stream);
 int hab_conv_gn_fwd(const float* x, const uint16_t* w_planes, const float* gamma, const float* beta, const float* residual, float* y,
                     float* raw, float* mean, float* rstd, int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad,
                     int groups, int relu, float eps, hipStream_t stream);

@@ -208,51 +208,3 @@ def test_stem_wgrad_strip_refuses_uncovered_widths(L):
     dw = torch.zeros(32, 4, 7, 7, device="cuda")
     ws = torch.zeros(1 << 21, device="cuda")
     assert L.hab_stem_conv_wgrad(P(x), P(dy), P(dw), 1, 42, 42, 4, P(ws), ws.numel(), S()) == -2  # Wo = 21: not a multiple of 16
-
-
-@pytest.mark.parametrize("B,H,W", [(3, 32, 32), (40, 32, 32), (2, 37, 24), (1, 5, 17)])
-def test_conv3x3_strip_forward_and_data_gradient_vs_float64(L, B, H, W):
-    """csrc/conv3x3_strip.h (3x3 / 1 / 1, 32 -> 32, input strip in LDS, two pixel tiles per wave): forward and data gradient (with the
-    residual-add and ReLU-mask epilogue) against float64 and against the generic kernels."""
-    torch.manual_seed(B * 100 + H + W)
-    x = torch.randn(B, 32, H, W) * torch.rand(B, 32, H, W).pow(2) * 3
-    w = torch.randn(32, 32, 3, 3) / 17.0
-    ref = F.conv2d(x.double(), w.double(), None, padding=1).permute(0, 2, 3, 1)
-    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
-    wf = torch.zeros(32 * 9 * 32, device="cuda")
-    wd = torch.zeros(32 * 9 * 32, device="cuda")
-    _lib.check(L.hab_repack_conv_weight(P(w.cuda().contiguous()), P(wf), P(wd), 32, 32, 3, 3, 32, S()))
-    pf = torch.zeros(3 * 18 * 512, dtype=torch.int16, device="cuda")
-    pd = torch.zeros(3 * 18 * 512, dtype=torch.int16, device="cuda")
-    _lib.check(L.hab_conv3x3_c32_split_weights(P(wf), 0, P(pf), S()))
-    _lib.check(L.hab_conv3x3_c32_split_weights(P(wd), 1, P(pd), S()))
-    ws = torch.zeros(1 << 22, device="cuda")
-    y = torch.full((B, H, W, 32), float("nan"), device="cuda")
-    _lib.check(L.hab_conv3x3_c32(P(xd), P(pf), None, None, P(y), B, H, W, S()))
-    y2 = torch.zeros_like(y)
-    _lib.check(L.hab_conv2d_fwd(P(xd), P(wf), None, P(y2), B, H, W, 32, 32, 3, 3, 1, 1, 0, P(ws), ws.numel(), S()))
-    torch.cuda.synchronize()
-    e1 = ((y.double().cpu() - ref).abs().max() / ref.abs().max()).item()
-    e0 = ((y2.double().cpu() - ref).abs().max() / ref.abs().max()).item()
-    assert e1 <= 2 * e0 + 2e-7 and e1 < 3e-6, ("fwd", e0, e1)
-    # data gradient of the same convolution: dx = conv_transpose(dy) + add, masked
-    dy = torch.randn(B, 32, H, W) * torch.rand(B, 32, H, W).pow(2)
-    add = torch.randn(B, 32, H, W)
-    mask = torch.randn(B, 32, H, W)
-    xg = x.double().requires_grad_(True)
-    F.conv2d(xg, w.double(), None, padding=1).backward(dy.double())
-    refd = ((xg.grad + add.double()) * (mask > 0)).permute(0, 2, 3, 1)
-    nh = lambda t_: t_.permute(0, 2, 3, 1).contiguous().cuda()
-    dyd, addd, maskd = nh(dy), nh(add), nh(mask)
-    dx = torch.full((B, H, W, 32), float("nan"), device="cuda")
-    _lib.check(L.hab_conv3x3_c32(P(dyd), P(pd), P(maskd), P(addd), P(dx), B, H, W, S()))
-    dx2 = torch.zeros_like(dx)
-    _lib.check(L.hab_conv2d_dgrad(P(dyd), P(wd), P(maskd), P(addd), P(dx2), B, H, W, 32, 32, 3, 3, 1, 1, P(ws), ws.numel(), S()))
-    torch.cuda.synchronize()
-    e1 = ((dx.double().cpu() - refd).abs().max() / refd.abs().max()).item()
-    e0 = ((dx2.double().cpu() - refd).abs().max() / refd.abs().max()).item()
-    assert e1 <= 2 * e0 + 2e-7 and e1 < 3e-6, ("dgrad", e0, e1)
-    dx3 = torch.zeros_like(dx)
-    _lib.check(L.hab_conv3x3_c32(P(dyd), P(pd), P(maskd), P(addd), P(dx3), B, H, W, S()))
-    assert torch.equal(dx, dx3)
-    assert L.hab_conv3x3_c32(P(xd), P(pf), None, None, P(y), B, H, 16, S()) == -2  # width 16: not covered
