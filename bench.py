@@ -97,6 +97,11 @@ SITE_MODEL = {
 }
 
 
+# algorithmic bytes of a call site that do not scale with the frames of a launch: the 25088 x 512 weight matrix of the visual fc (read by the
+# forward and the data gradient, written once by the weight gradient) -- 51 MB per launch, as much as 2000 frames of its activations
+SITE_LAUNCH_BYTES = {"fc_fwd": 25088 * 512 * 4, "fc_dgrad": 25088 * 512 * 4, "fc_wgrad": 25088 * 512 * 4}
+
+
 def site_roofline(site, flops_per_frame, frames, ms):
     """Which roofline bounds the call site (time per frame at the HBM peak vs at the split-bf16 MFMA ceiling) and where it is."""
     tfl = flops_per_frame * frames / (ms * 1e-3) / 1e12
@@ -256,6 +261,10 @@ def cpu_baseline_and_parity(trainer, cfg, sample_envs=NUM_ENVS, sample_steps=NUM
         torch.randperm = orig
     for k in ("value_loss", "action_loss", "dist_entropy", "grad_norm"):
         out[k + "_rel"] = abs(got[k] - ref_metrics[k]) / max(1e-6, abs(ref_metrics[k]))
+    # the oracle's own figures beside the relative errors: the action loss of a normalised-advantage minibatch is a mean near zero
+    # (|.| ~ 1e-3), so its RELATIVE error is an absolute error of ~1e-9 .. 1e-6 divided by that
+    out["reference"] = {k: float(f"{ref_metrics[k]:.6e}") for k in ("value_loss", "action_loss", "dist_entropy", "grad_norm")}
+    out["action_loss_abs_err"] = abs(got["action_loss"] - ref_metrics["action_loss"])
     pd = max(float((v.detach().cpu() - p[k].detach()).abs().max()) for k, v in pol.state_dict().items())
     out["post_update_param_max_abs_diff"] = pd
     out["what"] = (f"HIP path vs the CPU oracle on the SAME {N} x {T} rollout (the one `cpu_baseline` timed), same parameters, same "
@@ -452,7 +461,7 @@ def main():
                 if tr is not None and k in SITE_MODEL:
                     upd_frames = fs / cnt if k in PERSISTENT_GRID_SITES else n_envs * n_steps // ppo.num_mini_batch // site_chunks(k)
                     row["traffic"] = tr
-                    row["traffic_ratio"] = round(tr / (SITE_MODEL[k][0] * upd_frames), 3)
+                    row["traffic_ratio"] = round(tr / (SITE_MODEL[k][0] * upd_frames + SITE_LAUNCH_BYTES.get(k, 0)), 3)
                 table.append(row)
         eng.probe_read()
         eng.probe_enable(-1)
@@ -524,9 +533,10 @@ def main():
     if traffic is not None and a.probe in SITE_MODEL and probe_cnt:
         upd_frames = (frames / probe_cnt if a.probe in PERSISTENT_GRID_SITES else
                       n_envs * n_steps // ppo.num_mini_batch // site_chunks(a.probe))
-        out["roofline"]["traffic_ratio"] = round(traffic / (SITE_MODEL[a.probe][0] * upd_frames), 3)
+        out["roofline"]["traffic_ratio"] = round(traffic / (SITE_MODEL[a.probe][0] * upd_frames + SITE_LAUNCH_BYTES.get(a.probe, 0)), 3)
         out["roofline"]["traffic_basis"] = (f"{'mean' if a.probe in PERSISTENT_GRID_SITES else 'update-sized'} launch of {upd_frames:.1f} frames; "
-                                            f"algorithmic bytes {SITE_MODEL[a.probe][0]} per frame")
+                                            f"algorithmic bytes {SITE_MODEL[a.probe][0]} per frame"
+                                            + (f" + {SITE_LAUNCH_BYTES[a.probe]} per launch (weights)" if a.probe in SITE_LAUNCH_BYTES else ""))
     if a.workload in ("c2", "c3"):
         # FLOPs per env-step of the contractions that are EXECUTED: F = 2 MAC_fwd (1 + 1/T) + E (2 (3 MAC_fwd - MAC_first_dgrad)) -- the data
         # gradient of the first convolution (wrt the observation) is never computed.  SURVEY.md 8(d)'s formula counts it (C2 2.365,
