@@ -2,11 +2,18 @@
 """Splits a rocprofv3 --kernel-trace (rocpd sqlite .db) of bench.py into rollout steps and learner phases and reports, for each,
 wall time, GPU-busy time (union of kernel intervals) and launches: the evidence for "launch-bound" vs "kernel-bound".
 
-A rollout step ends with the action-head kernel (heads_fwd_kernel / gauss_heads_fwd_kernel); a window between two of those that
-contains a ppo_loss kernel is learner time.  usage: tools/trace_phases.py <results.db> [out.txt]"""
+Windows end with the action-head kernel (heads_fwd_kernel / gauss_heads_fwd_kernel).  A window is a ROLLOUT STEP when it holds the synthetic
+environments' step kernels (synth_images / rollout_step_stats: action of step t sampled, environments stepped, policy of step t + 1) and no
+ppo_loss; every other window is learner time: [GAE + first minibatch forward], [loss + backward + Adam + next minibatch forward] ..., and the
+last one [loss + backward + Adam of the last minibatch + the first policy call of the next rollout].  (Up to round 4's first collection the
+window [GAE + first minibatch forward] was counted into the rollout run: "87.5 ms" there is rollout + one 15 ms minibatch forward.)
+usage: tools/trace_phases.py <results.db> [out.txt]"""
 import re
 import sqlite3
 import sys
+
+
+ENV_STEP = re.compile(r"synth_images_kernel|rollout_step_stats_kernel")
 
 
 def busy(iv):
@@ -36,7 +43,8 @@ def main():
     tail = cur
     roll, learn = [], []
     for w in windows:
-        (learn if any("ppo_loss" in n for n, _, _ in w) else roll).append(w)
+        is_step = any(ENV_STEP.search(n) for n, _, _ in w) and not any("ppo_loss" in n for n, _, _ in w)
+        (roll if is_step else learn).append(w)
     out = [f"# {sys.argv[1]}: {len(rows)} dispatches, {len(roll)} rollout steps, {len(learn)} windows containing learner work"]
 
     def stats(ws, label):
