@@ -24,12 +24,16 @@ int conv_gn_fused(const ConvGnArgs& q, hipStream_t s) {
 
 int stem_conv_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad) { return stem_conv_strip_covers(H, W, C, Cout, KH, KW, stride, pad); }
 int stem_weight_planes(const float* wf, unsigned short* planes, hipStream_t s) { return stem_split_weights(wf, planes, s); }
-int stem_conv_forward(const float* x, const unsigned short* planes, float* y, int B, int H, int W, hipStream_t s) {
-    return stem_conv_strip(x, planes, y, B, H, W, s);
+int stem_conv_forward(const float* x, const unsigned short* planes, float* y, int B, int H, int W, hipStream_t s, const float* norm, float* gn_part,
+                      int gn_groups) {
+    static_assert(STEM_STAT_ROWS == STEM_TH, "statistics chunks are the kernel's strips");
+    return stem_conv_strip(x, planes, y, B, H, W, s, norm, gn_part, gn_groups);
 }
-int stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats, hipStream_t s) {
-    return stem_wgrad_strip(x, dy, dw_oihw, B, H, W, creal, ws, ws_floats, s);
+int stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats, hipStream_t s,
+                    const float* norm) {
+    return stem_wgrad_strip(x, dy, dw_oihw, B, H, W, creal, ws, ws_floats, s, norm);
 }
+int stem_wgrad_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad) { return stem_wgrad_strip_covers(H, W, C, Cout, KH, KW, stride, pad); }
 
 }  // namespace hab
 
@@ -37,12 +41,13 @@ using namespace hab;
 
 extern "C" int hab_stem_split_weights(const float* w_fwd, uint16_t* planes, hipStream_t stream) { return stem_weight_planes(w_fwd, planes, stream); }
 extern "C" int hab_stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats,
-                                   hipStream_t stream) {
-    const int rc = stem_conv_wgrad(x, dy, dw_oihw, B, H, W, creal, ws, ws_floats, stream);
+                                   const float* norm, hipStream_t stream) {
+    const int rc = stem_conv_wgrad(x, dy, dw_oihw, B, H, W, creal, ws, ws_floats, stream, norm);
     return rc == 1 ? HAB_ERR_UNSUPPORTED : rc;
 }
-extern "C" int hab_stem_conv_fwd(const float* x, const uint16_t* w_planes, float* y, int B, int H, int W, hipStream_t stream) {
-    const int rc = stem_conv_forward(x, w_planes, y, B, H, W, stream);
+extern "C" int hab_stem_conv_fwd(const float* x, const uint16_t* w_planes, float* y, int B, int H, int W, const float* norm, float* gn_part,
+                                 int gn_groups, hipStream_t stream) {
+    const int rc = stem_conv_forward(x, w_planes, y, B, H, W, stream, norm, gn_part, gn_groups);
     return rc == 1 ? HAB_ERR_UNSUPPORTED : rc;
 }
 

@@ -48,6 +48,8 @@ struct hab_policy {
     // packed offsets
     int64_t pk_c1f, pk_c2f, pk_c2d, pk_c3f, pk_c3d, pk_fc;
     std::vector<int64_t> pk_whht;
+    std::vector<int64_t> pk_wiht;  // layers >= 1: W_ih transposed [H][G*H] (layer wavefront BPTT, rnn.hip); entry 0 unused (-1)
+    bool last_wave = false;        // the last evaluate ran the recurrent layers as a wavefront (the backward must mirror it)
     int64_t pk_wih0 = -1;  // layer 0 W_ih, rows padded with zeros to rnn_ld floats (fused input projection of the rollout step, rnn.hip)
     // workspace offsets (floats)
     int64_t w_a1, w_a2, w_a3, w_rnnin, w_da1, w_da2, w_da3, w_drnnin, w_hinit, w_cinit, w_feat_d, w_probs, w_logitsn, w_dzv,

@@ -72,6 +72,7 @@ static int build_baseline(hab_policy* e) {
     e->pk_c3d = pk.take(32 * 9 * 64);
     e->pk_fc = pk.take((int64_t)H * std::max(e->fc_in, 4));
     for (int l = 0; l < d.rnn_layers; ++l) e->pk_whht.push_back(pk.take((int64_t)e->G_ * H * H));
+    for (int l = 0; l < d.rnn_layers; ++l) e->pk_wiht.push_back(l == 0 ? -1 : pk.take((int64_t)e->G_ * H * H));
     e->pk_wih0 = pk.take((int64_t)e->G_ * H * e->rnn_ld);  // layer 0's W_ih with rows padded to rnn_ld (fused step projection of `act`)
     e->packed_floats = pk.used;
 
@@ -91,7 +92,7 @@ static int build_baseline(hab_policy* e) {
         e->w_dlayer.push_back(wk.take(B * H));
     }
     e->w_probs = wk.take(B * 8); e->w_logitsn = wk.take(B * 8); e->w_dzv = wk.take(B * 8); e->w_dv = wk.take(B);
-    e->w_dfeat = wk.take(B * H); e->w_scratch = wk.take(3 * F * H);
+    e->w_dfeat = wk.take(B * H); e->w_scratch = wk.take((int64_t)std::max(3, 2 * d.rnn_layers) * F * H);
     e->w_value = wk.take(B); e->w_logp = wk.take(B); e->w_ent = wk.take(B);
     e->w_hmask = wk.take((int64_t)2 * d.rnn_layers * d.max_envs * H);
     e->w_gistep = wk.take((int64_t)d.max_envs * e->G_ * H);
@@ -200,6 +201,7 @@ extern "C" int hab_policy_repack(hab_policy* e, hipStream_t stream) {
     if (e->pk_wih0 >= 0) HAB_TRY(pad_rows(e->p(e->i_wih[0]), e->PK + e->pk_wih0, e->G_ * H, e->rnn_in, e->rnn_ld, stream));
     if (e->Cin == 0) {  // blind baseline policy: only the recurrent weights have a kernel-layout copy
         for (int l = 0; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_whh[l]), e->PK + e->pk_whht[l], e->G_ * H, H, stream));
+        for (int l = 1; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_wih[l]), e->PK + e->pk_wiht[l], e->G_ * H, H, stream));
         return HAB_OK;
     }
     HAB_TRY(repack_conv(e->p(e->i_c1w), e->PK + e->pk_c1f, nullptr, 32, e->Cin, 8, 8, e->Cin, stream));
@@ -207,6 +209,7 @@ extern "C" int hab_policy_repack(hab_policy* e, hipStream_t stream) {
     HAB_TRY(repack_conv(e->p(e->i_c3w), e->PK + e->pk_c3f, e->PK + e->pk_c3d, 32, 64, 3, 3, 64, stream));
     HAB_TRY(repack_flatten(e->p(e->i_fcw), e->PK + e->pk_fc, H, 32, e->fc_in / 32, stream));
     for (int l = 0; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_whh[l]), e->PK + e->pk_whht[l], e->G_ * H, H, stream));
+    for (int l = 1; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_wih[l]), e->PK + e->pk_wiht[l], e->G_ * H, H, stream));
     return HAB_OK;
 }
 
@@ -497,6 +500,26 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
         if (e->d.rnn_type == HAB_RNN_LSTM)
             HAB_TRY(rnn_frag_init(hidden0 + (size_t)(L + l) * H, rows, hidden_env_stride, masks, rows, pk.frag_env,
                                   pk.frag_start, pk.F, H, cinit, stream, pack->env_first_frame));
+    }
+    // several layers: one launch per packed step for ALL layers (layer l one step behind layer l - 1), rnn.hip
+    static const int wave_cfg = hab_env_int("HAB_RNN_WAVE", 1);
+    e->last_wave = false;
+    if (wave_cfg && L >= 2 && L <= 4) {
+        RnnLayerParams lps[4]; RnnWork wks[4]; const float* hin[4]; const float* cin[4];
+        for (int l = 0; l < L; ++l) {
+            lps[l] = layer_params(e, l); wks[l] = layer_work(e, l);
+            hin[l] = W + e->w_hinit + (size_t)l * pk.F * H; cin[l] = W + e->w_cinit + (size_t)l * pk.F * H;
+        }
+        Probe pr(e, HAB_PROBE_RNN_FWD, stream);
+        const int rcw = rnn_seq_wave_forward(e->d.rnn_type, H, L, lps, wks, x, ldx, hin, cin, pk, W + e->w_ws, e->ws_floats, stream);
+        if (rcw != 0 && rcw != 1) return rcw;
+        e->last_wave = rcw == 0;
+        if (e->last_wave) { x = wks[L - 1].out; ldx = H; }
+    }
+    if (!e->last_wave)
+    for (int l = 0; l < L; ++l) {
+        float* hinit = W + e->w_hinit + (size_t)l * pk.F * H;
+        float* cinit = W + e->w_cinit + (size_t)l * pk.F * H;
         RnnLayerParams lp = layer_params(e, l);
         RnnWork wk = layer_work(e, l);
         Probe pr(e, HAB_PROBE_RNN_FWD, stream);
@@ -681,7 +704,19 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
     } else {
     // recurrent layers, top down
     const float* dout = W + e->w_dfeat;
-    for (int l = L - 1; l >= 0; --l) {
+    bool waved = false;
+    if (e->last_wave) {  // the forward ran the layers as a wavefront (upper layers' wk.gi do not exist): mirror it
+        RnnLayerParams lps[4]; RnnWork wks[4]; const float* wiht[4];
+        for (int l = 0; l < L; ++l) { lps[l] = layer_params(e, l); wks[l] = layer_work(e, l); wiht[l] = l ? e->PK + e->pk_wiht[l] : nullptr; }
+        const bool blind0 = !e->rn && e->Cin == 0;
+        const float* x0 = W + e->w_rnnin;
+        Probe pr(e, HAB_PROBE_RNN_BWD, stream);
+        const int rcw = rnn_seq_wave_backward(e->d.rnn_type, H, L, lps, wiht, wks, x0, e->rnn_ld, dout, blind0 ? nullptr : W + e->w_drnnin, e->rnn_ld,
+                                              blind0 ? nullptr : x0, e->rnn_ld, blind0 ? 0 : H, pk, W + e->w_scratch, ws, e->ws_floats, stream);
+        if (rcw != 0) return rcw == 1 ? HAB_ERR_UNSUPPORTED : rcw;
+        waved = true;
+    }
+    for (int l = L - 1; l >= 0 && !waved; --l) {
         RnnLayerParams lp = layer_params(e, l);
         RnnWork wk = layer_work(e, l);
         const float* x = l == 0 ? W + e->w_rnnin : W + e->w_out[l - 1];

@@ -77,6 +77,10 @@ struct ResNetPlan {
     // has been materialised since (a debug tap asked for it) -- the backward then takes the unfused form, which reads it as the ReLU
     // mask (so that activations patched through the tap are honoured, oracle/parity.py::MaskInjector)
     bool stem_fused = false, stem_act_valid = true;
+    // training-mode RunningMeanAndVar with both stem kernels of the strip family: the ingest leaves x0 UN-normalised (it accumulates the batch
+    // moments in the same pass) and the stem forward / weight gradient apply the per-channel affine while staging (w_stats + 32: 16 floats).
+    // x0_raw: x0 of the last forward is in that state (a debug tap of the encoder input normalises it in place and clears the flag).
+    bool stem_takes_raw = false, x0_raw = false;
 };
 
 static int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
@@ -272,10 +276,14 @@ int build_resnet(hab_policy* e) {
     };
     pack_conv(r->stem, false);
     if (stem_conv_ok(r->stem.cd.H, r->stem.cd.W, r->stem.cd.C, r->stem.cd.Cout, 7, 7, 2, 3)) r->stem.pk_p = pk.take(STEM_PLANE_FLOATS);
+    r->stem_takes_raw = r->stem.pk_p >= 0 && r->cpad == 4 && r->stem.cd.Cout == 32 &&
+                        stem_wgrad_ok(r->stem.cd.H, r->stem.cd.W, r->stem.cd.C, r->stem.cd.Cout, 7, 7, 2, 3) &&
+                        hab_env_int("HAB_STEM_STRIP", 1) && hab_env_int("HAB_STEM_WGRAD", 1) && hab_env_int("HAB_STEM_RAW", 1);
     for (auto& c : r->convs) pack_conv(c, true);
     pack_conv(r->comp, true);
     r->pk_fc = pk.take((int64_t)H * r->fc_in);
     for (int l = 0; l < d.rnn_layers; ++l) e->pk_whht.push_back(pk.take((int64_t)e->G_ * H * H));
+    for (int l = 0; l < d.rnn_layers; ++l) e->pk_wiht.push_back(l == 0 ? -1 : pk.take((int64_t)e->G_ * H * H));
     e->pk_wih0 = pk.take((int64_t)e->G_ * H * e->rnn_ld);
     e->packed_floats = pk.used;
 
@@ -316,7 +324,7 @@ int build_resnet(hab_policy* e) {
     for (int k = 0; k < 6; ++k) r->w_gbuf.push_back(wk.take(B * r->gbuf_floats));
     r->w_chansums = wk.take(B * 2 * r->cmax);
     r->w_stats = wk.take(64);
-    r->w_dscratch = wk.take(2 * 1024 * 8);  // 1024 blocks x 8 channels of double
+    r->w_dscratch = wk.take(2 * (INGEST_MOM_MAX_BLOCKS * 16 + 16));  // doubles: per-workgroup moment partials of the ingest + their totals
     r->w_embsave = wk.take(B * 4 * EMB_MAX_SLOTS);
     if (se) r->w_se_scr = wk.take(B * ((int64_t)3 * r->cmax + r->cmax / 16 + 16));
     if (r->gdense_floats) r->w_gdense = wk.take(r->gdense_floats);
@@ -331,7 +339,7 @@ int build_resnet(hab_policy* e) {
         e->w_dlayer.push_back(wk.take(B * H));
     }
     e->w_probs = wk.take(B * 8); e->w_logitsn = wk.take(B * 8); e->w_dzv = wk.take(B * 8); e->w_dv = wk.take(B);
-    e->w_dfeat = wk.take(B * H); e->w_scratch = wk.take(3 * F * H);
+    e->w_dfeat = wk.take(B * H); e->w_scratch = wk.take((int64_t)std::max(3, 2 * d.rnn_layers) * F * H);
     e->w_value = wk.take(B); e->w_logp = wk.take(B); e->w_ent = wk.take(B);
     if (gauss) e->w_gsaved = wk.take(B * 16);
     e->w_hmask = wk.take((int64_t)2 * d.rnn_layers * d.max_envs * H);
@@ -375,6 +383,7 @@ int resnet_repack(hab_policy* e, hipStream_t s) {
     HAB_TRY(planes(r->comp));
     HAB_TRY(repack_flatten(e->p(r->i_fcw), e->PK + r->pk_fc, H, r->comp_c, r->comp_hw, s));
     for (int l = 0; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_whh[l]), e->PK + e->pk_whht[l], e->G_ * H, H, s));
+    for (int l = 1; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_wih[l]), e->PK + e->pk_wiht[l], e->G_ * H, H, s));
     HAB_TRY(pad_rows(e->p(e->i_wih[0]), e->PK + e->pk_wih0, e->G_ * H, e->rnn_in, e->rnn_ld, s));
     return HAB_OK;
 }
@@ -415,7 +424,10 @@ static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, cons
     float* rstd = W + c.w_rstd + (int64_t)f0 * c.groups;
     if (&c == &e->rn->stem && c.pk_p >= 0) {  // stem: input strip resident in LDS (stem_conv_strip.h)
         static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
-        const int rc = stem_strip ? stem_conv_forward(in, reinterpret_cast<const unsigned short*>(e->PK + c.pk_p), raw, B, cd.H, cd.W, s) : 1;
+        if (e->rn->x0_raw && !stem_strip) return HAB_ERR_ARG;
+        const int rc = stem_strip ? stem_conv_forward(in, reinterpret_cast<const unsigned short*>(e->PK + c.pk_p), raw, B, cd.H, cd.W, s,
+                                                      e->rn->x0_raw ? W + e->rn->w_stats + 32 : nullptr) : 1;
+        if (rc == 1 && e->rn->x0_raw) return HAB_ERR_UNSUPPORTED;
         if (rc != 0 && rc != 1) return rc;
         if (rc == 1) HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, raw, 0, W + e->w_ws, e->ws_floats, s));
         GnArgs g;
@@ -538,31 +550,36 @@ static int resnet_ingest(hab_policy* e, const hab_obs* obs, const int* rows, int
     if ((d.has_rgb && !obs->rgb) || (d.has_depth && !obs->depth) || (d.has_semantic && !obs->semantic)) return HAB_ERR_ARG;
     // evaluation mode: RunningMeanAndVar is a fixed affine per channel -> applied by the ingest itself (one launch, one pass less)
     const bool fused_norm = d.normalize_visual_inputs && !e->training;
+    const bool moments = d.normalize_visual_inputs && e->training;
+    double* ds = reinterpret_cast<double*>(W + r->w_dscratch);  // [0..15] totals, then the per-workgroup partials
+    int mom_blocks = 0;
     HAB_TRY(ingest_pool(d.has_rgb ? obs->rgb : nullptr, d.has_depth ? obs->depth : nullptr, d.has_semantic ? obs->semantic : nullptr, rows,
                         x0, B, d.H, d.W, r->cpad, r->c_rgb, r->c_depth, r->c_sem, s, fused_norm ? e->p(r->i_mean) : nullptr,
-                        fused_norm ? e->p(r->i_var) : nullptr));
+                        fused_norm ? e->p(r->i_var) : nullptr, moments ? e->p(r->i_mean) : nullptr, moments ? ds + 16 : nullptr, &mom_blocks));
     const long long npix = (long long)B * r->H2 * r->W2;
-    if (d.normalize_visual_inputs && !fused_norm) {
-        float* st = W + r->w_stats;  // [0..7] batch mean, [8] batch count (frames), [16..23] batch var
-        if (e->training) {
-            double* ds = reinterpret_cast<double*>(W + r->w_dscratch);
-            // running_mean_and_var.py:38-49: all_reduce(new_mean), all_reduce(new_count), new_mean /= world; all_reduce(new_var),
-            // new_var /= world.  The callback only SUMS (scale 1); the divisions happen where the sums are consumed, and the count is
-            // the real all-reduced number of frames (ranks hold different numbers of frames after a preempted rollout).
-            const bool dist = e->comm != nullptr || (e->allreduce_cb && e->world_size > 1);  // (a 1-rank communicator still runs: identity)
-            auto sum_ranks = [&](float* buf, int n) -> int {  // device-side on the compute stream (comm.hip), else the host callback
-                if (e->comm) return hab_comm_allreduce_sum(e->comm, buf, n, s);
-                e->allreduce_cb(buf, n, 1.0f, e->allreduce_ctx);
-                return HAB_OK;
-            };
-            const float div = dist ? (float)e->world_size : 1.f;
-            HAB_TRY(chan_moment(x0, npix, r->cpad, 0, nullptr, st, ds, 1024 * 8, s, 1.f, st + 8, (float)B));
-            if (dist) HAB_TRY(sum_ranks(st, 9));
-            HAB_TRY(chan_moment(x0, npix, r->cpad, 1, st, st + 16, ds, 1024 * 8, s, div));
-            if (dist) HAB_TRY(sum_ranks(st + 16, 8));
-            HAB_TRY(rmv_update(e->p(r->i_mean), e->p(r->i_var), e->p(r->i_count), st, st + 16, (float)B, r->creal, s, st + 8, div));
-        }
-        HAB_TRY(rmv_normalize(x0, npix, r->cpad, r->creal, e->p(r->i_mean), e->p(r->i_var), s));
+    r->x0_raw = false;
+    if (moments) {
+        // training mode (running_mean_and_var.py:24-70): batch moments -> Chan merge into the running ones -> normalise with the UPDATED
+        // statistics.  The moments were accumulated by the ingest about the running mean as pivot (resnet_ops.hip); under DD-PPO
+        // (:38-49) all_reduce(new_mean), all_reduce(new_count), new_mean /= world; all_reduce(new_var), new_var /= world: the variance is
+        // about the CROSS-RANK mean, which the pivot form gives without a second pass.  The callback only SUMS (scale 1); the divisions
+        // happen where the sums are consumed, and the count is the real all-reduced number of frames (ranks hold different numbers of
+        // frames after a preempted rollout).
+        float* st = W + r->w_stats;  // [0..7] batch mean, [8] batch count (frames), [16..23] batch var, [32..47] affine of the new statistics
+        const bool dist = e->comm != nullptr || (e->allreduce_cb && e->world_size > 1);  // (a 1-rank communicator still runs: identity)
+        auto sum_ranks = [&](float* buf, int n) -> int {  // device-side on the compute stream (comm.hip), else the host callback
+            if (e->comm) return hab_comm_allreduce_sum(e->comm, buf, n, s);
+            e->allreduce_cb(buf, n, 1.0f, e->allreduce_ctx);
+            return HAB_OK;
+        };
+        const float div = dist ? (float)e->world_size : 1.f;
+        HAB_TRY(moment_finish_mean(ds + 16, mom_blocks, r->cpad, e->p(r->i_mean), r->creal, npix, ds, st, st + 8, (float)B, s));
+        if (dist) HAB_TRY(sum_ranks(st, 9));
+        HAB_TRY(moment_finish_var(ds, e->p(r->i_mean), r->creal, r->cpad, st, div, npix, st + 16, s));
+        if (dist) HAB_TRY(sum_ranks(st + 16, 8));
+        HAB_TRY(rmv_update(e->p(r->i_mean), e->p(r->i_var), e->p(r->i_count), st, st + 16, (float)B, r->creal, s, st + 8, div, st + 32));
+        if (r->stem_takes_raw) r->x0_raw = true;  // the stem kernels normalise while staging
+        else HAB_TRY(rmv_normalize(x0, npix, r->cpad, r->creal, e->p(r->i_mean), e->p(r->i_var), s));
     }
     return HAB_OK;
 }
@@ -585,9 +602,20 @@ static int resnet_layers_forward(hab_policy* e, int Btot, int f0, int B, hipStre
     scd.B = B;
     static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
     static const int stem_fuse = hab_env_int("HAB_STEM_FUSE", 1);
-    auto stem_conv = [&]() -> int {
-        const int rcs = (stem_strip && st.pk_p >= 0) ? stem_conv_forward(x0, reinterpret_cast<const unsigned short*>(e->PK + st.pk_p), stem_raw, B, scd.H, scd.W, s) : 1;
+    // the strip kernel leaves the GroupNorm partial statistics of its strips (8 output rows) with the output: no statistics pass
+    static const int stem_stats = hab_env_int("HAB_STEM_STATS", 1);
+    const int stat_chunks = (scd.Ho() + STEM_STAT_ROWS - 1) / STEM_STAT_ROWS;
+    float* gn_part = W + e->w_ws;
+    bool have_part = false;
+    auto stem_conv = [&](bool want_part) -> int {
+        want_part = want_part && stem_stats && (st.groups == 8 || st.groups == 16 || st.groups == 32) &&
+                    (size_t)B * stat_chunks * st.groups * 2 <= e->ws_floats;
+        const int rcs = (stem_strip && st.pk_p >= 0) ? stem_conv_forward(x0, reinterpret_cast<const unsigned short*>(e->PK + st.pk_p), stem_raw, B,
+                                                                         scd.H, scd.W, s, r->x0_raw ? W + r->w_stats + 32 : nullptr,
+                                                                         want_part ? gn_part : nullptr, st.groups) : 1;
+        have_part = want_part && rcs == 0;
         if (rcs != 0 && rcs != 1) return rcs;
+        if (rcs == 1 && r->x0_raw) return HAB_ERR_UNSUPPORTED;  // (stem_takes_raw was decided on the same coverage predicates)
         if (rcs == 1) HAB_TRY(conv_fwd(scd, x0, e->PK + st.pk_f, nullptr, stem_raw, 0, W + e->w_ws, e->ws_floats, s));
         return HAB_OK;
     };
@@ -597,8 +625,8 @@ static int resnet_layers_forward(hab_policy* e, int Btot, int f0, int B, hipStre
     g.eps = 1e-5f; g.scratch = W + e->w_ws; g.scratch_floats = e->ws_floats;
     bool stem_done = false;
     if (!e->save_acts) {  // act / encode: GroupNorm + ReLU + max-pool in one pass, the normalised frame is never written
-        HAB_TRY(stem_conv());
-        const int rc = groupnorm_relu_maxpool_forward(g, scd.Ho(), scd.Wo(), pool, nullptr, s);
+        HAB_TRY(stem_conv(groupnorm_pool_fusable(B, g.HW, g.C, g.groups, e->ws_floats)));
+        const int rc = groupnorm_relu_maxpool_forward(g, scd.Ho(), scd.Wo(), pool, nullptr, s, have_part ? gn_part : nullptr, STEM_STAT_ROWS);
         if (rc != 0 && rc != 1) return rc;
         if (rc == 1) {  // small frames: the register-resident GroupNorm, then the pool
             g.y = stem_act; g.mean = W + st.w_mean + F0 * st.groups; g.rstd = W + st.w_rstd + F0 * st.groups;
@@ -611,9 +639,9 @@ static int resnet_layers_forward(hab_policy* e, int Btot, int f0, int B, hipStre
     if (!stem_done && stem_fuse && groupnorm_pool_fusable(B, g.HW, g.C, g.groups, e->ws_floats) &&
         groupnorm_pool_fusable(Btot, g.HW, g.C, g.groups, e->ws_floats)) {
         // training forward: the same fused pass, keeping the statistics and the arg-max bytes; the ReLU mask is recomputed in the backward
-        HAB_TRY(stem_conv());
+        HAB_TRY(stem_conv(true));
         g.mean = W + st.w_mean + F0 * st.groups; g.rstd = W + st.w_rstd + F0 * st.groups;
-        HAB_TRY(groupnorm_relu_maxpool_forward(g, scd.Ho(), scd.Wo(), pool, pool_idx, s));
+        HAB_TRY(groupnorm_relu_maxpool_forward(g, scd.Ho(), scd.Wo(), pool, pool_idx, s, have_part ? gn_part : nullptr, STEM_STAT_ROWS));
         r->stem_fused = true; r->stem_act_valid = false;
         stem_done = true;
     }
@@ -835,8 +863,10 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
     static const int stem_wg = hab_env_int("HAB_STEM_WGRAD", 1);
     int rcw = 1;
     if (stem_wg && r->cpad == 4 && c0.Cout == 32)  // strip-resident form (stem_wgrad_strip.h); 1: geometry not covered
-        rcw = stem_conv_wgrad(W + r->w_x0, d_raw0, e->g(r->stem.i_w), B, c0.H, c0.W, r->creal, ws, e->ws_floats, s);
+        rcw = stem_conv_wgrad(W + r->w_x0, d_raw0, e->g(r->stem.i_w), B, c0.H, c0.W, r->creal, ws, e->ws_floats, s,
+                              r->x0_raw ? W + r->w_stats + 32 : nullptr);
     if (rcw != 0 && rcw != 1) return rcw;
+    if (rcw == 1 && r->x0_raw) return HAB_ERR_UNSUPPORTED;
     if (rcw == 1) HAB_TRY(conv_wgrad(c0, W + r->w_x0, d_raw0, e->g(r->stem.i_w), nullptr, ws, e->ws_floats, s));
     return HAB_OK;
 }
@@ -846,7 +876,14 @@ int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats) {
     float* W = e->WK;
     const int64_t B = e->last_B;
     switch (which) {
-        case HAB_TAP_ENC_IN: *ptr = W + r->w_x0; *floats = B * r->H2 * r->W2 * r->cpad; return HAB_OK;
+        case HAB_TAP_ENC_IN:
+            if (r->x0_raw) {  // the stem kernels normalised while staging: do it in place now (the backward then reads it as it is)
+                if (hipDeviceSynchronize() != hipSuccess) return HAB_ERR_ARG;
+                HAB_TRY(rmv_normalize(W + r->w_x0, B * r->H2 * r->W2, r->cpad, r->creal, e->p(r->i_mean), e->p(r->i_var), nullptr));
+                if (hipDeviceSynchronize() != hipSuccess) return HAB_ERR_ARG;
+                r->x0_raw = false;
+            }
+            *ptr = W + r->w_x0; *floats = B * r->H2 * r->W2 * r->cpad; return HAB_OK;
         case HAB_TAP_STEM:
             if (r->stem_fused && !r->stem_act_valid) {  // the fused forward skipped it: build it from the kept GroupNorm input + statistics
                 const RnConv& c = r->stem;

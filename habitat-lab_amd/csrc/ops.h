@@ -74,6 +74,13 @@ int rnn_frag_init(const float* h0, const int* env_rows, int env_stride, const ui
 int rnn_seq_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx,
                           const float* hinit, const float* cinit, const PackInfo& pk, float* ws, size_t ws_floats,
                           hipStream_t stream);
+// the L layers as a wavefront (one launch per packed step for all layers): 1 = form not applicable
+int rnn_seq_wave_forward(int rnn_type, int H, int L, const RnnLayerParams* lp, const RnnWork* wk, const float* x, int ldx,
+                         const float* const* hinit, const float* const* cinit, const PackInfo& pk, float* ws, size_t ws_floats,
+                         hipStream_t stream);
+int rnn_seq_wave_backward(int rnn_type, int H, int L, const RnnLayerParams* lp, const float* const* w_ih_t, const RnnWork* wk, const float* x0,
+                          int ldx0, const float* dout, float* dx0, int lddx0, const float* dx_mask, int ldmask, int mask_cols,
+                          const PackInfo& pk, float* scratch /* 2*L*F*H floats */, float* ws, size_t ws_floats, hipStream_t stream);
 int rnn_step_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const float* x, int ldx, const float* h_in, int h_in_stride,
                            const float* c_in, int c_in_stride, const uint8_t* masks, int n, float* gi_scratch, float* h_out,
                            int h_out_stride, float* c_out, int c_out_stride, float* ws, size_t ws_floats, hipStream_t stream);

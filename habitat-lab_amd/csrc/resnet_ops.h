@@ -65,11 +65,18 @@ struct EmbedBwdArgs {
 };
 
 int ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic, const int* rows, float* y, int B, int H, int W, int cpad,
-                int c_rgb, int c_depth, int c_sem, hipStream_t s, const float* norm_mean = nullptr, const float* norm_var = nullptr);
+                int c_rgb, int c_depth, int c_sem, hipStream_t s, const float* norm_mean = nullptr, const float* norm_var = nullptr,
+                const float* pivot = nullptr, double* mom_partial = nullptr, int* mom_blocks = nullptr);
+// fused moments of the ingest (training-mode RunningMeanAndVar): mom_partial holds [<= INGEST_MOM_MAX_BLOCKS][16] doubles
+constexpr int INGEST_MOM_MAX_BLOCKS = 2048;
+int moment_finish_mean(const double* partial, int nblocks, int cpad, const float* pivot, int creal, long long npix, double* sums,
+                       float* mean_out, float* count_out, float count_val, hipStream_t s);
+int moment_finish_var(const double* sums, const float* pivot, int creal, int cpad, const float* mean_sum, float mean_div, long long npix,
+                      float* var_out, hipStream_t s);
 int chan_moment(const float* x, long long npix, int cpad, int mode, const float* mean, float* out, double* scratch, int scratch_len,
                 hipStream_t s, float mean_div = 1.f, float* count_out = nullptr, float count_val = 0.f);
 int rmv_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C, hipStream_t s,
-               const float* n_dev = nullptr, float div = 1.f);
+               const float* n_dev = nullptr, float div = 1.f, float* aff = nullptr);
 int rmv_normalize(float* x, long long npix, int cpad, int C, const float* mean, const float* var, hipStream_t s);
 // conv_gn_ops.hip -- convolution (bias-free) + GroupNorm (+ residual, + ReLU) in one launch for the small-batch passes (conv_gn_slab.h)
 struct ConvGnArgs {
@@ -88,14 +95,19 @@ int conv_gn_fused(const ConvGnArgs& a, hipStream_t s);  // 1: geometry not cover
 constexpr int STEM_PLANE_FLOATS = 3 * 14 * 1024 / 4;  // fragment-ordered bf16 planes of the filter, in floats of the packed arena
 int stem_conv_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad);
 int stem_weight_planes(const float* wf, unsigned short* planes, hipStream_t s);
-int stem_conv_forward(const float* x, const unsigned short* planes, float* y, int B, int H, int W, hipStream_t s);  // 1: not covered
+int stem_conv_forward(const float* x, const unsigned short* planes, float* y, int B, int H, int W, hipStream_t s, const float* norm = nullptr,
+                      float* gn_part = nullptr, int gn_groups = 0);  // gn_part: [B][ceil(Ho / STEM_STAT_ROWS)][groups][2] partial statistics
+constexpr int STEM_STAT_ROWS = 8;  // 1: not covered
 // its weight gradient, both operands resident in LDS, transpose reads (stem_wgrad_strip.h); ws >= 256 * 7 * 1024 floats; 1: not covered
-int stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats, hipStream_t s);
+int stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats, hipStream_t s,
+                    const float* norm = nullptr);
+int stem_wgrad_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad);
 int groupnorm_forward(const GnArgs& a, hipStream_t s);
 int groupnorm_backward(const GnBwdArgs& a, hipStream_t s);
 // GroupNorm + ReLU + MaxPool2d(3, 2, 1) in one pass over the GroupNorm input; the normalised frame is never written.  idx (nullable):
 // arg-max bytes for the backward pass; a.mean / a.rstd (nullable) are written when given.  1: frame not on the chunk-parallel path.
-int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, uint8_t* idx, hipStream_t s);
+int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, uint8_t* idx, hipStream_t s, const float* ext_part = nullptr,
+                                   int ext_rows = 0);
 bool groupnorm_pool_fusable(int B, int HW, int C, int groups, size_t scratch_floats);  // forward AND backward chunk-parallel forms exist
 int groupnorm_relu_materialize(const GnArgs& a, hipStream_t s);  // y = relu(GroupNorm(x)) from the SAVED a.mean / a.rstd (debug taps)
 int maxpool_forward(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, hipStream_t s);

@@ -13,10 +13,16 @@ namespace hab {
 // Ingest (resnet_policy.py:259-271): per visual key permute -> uint8 * fp32(1/255) -> cat -> avg_pool2d(2).
 // Output y[f][h/2][w/2][cpad]: channels rgb(3), depth(1), zero padding up to cpad.
 // ------------------------------------------------------------------------------------------------------
+// MOM (training mode, RunningMeanAndVar): the same pass also accumulates, per channel, S1 = sum (x - p) and S2 = sum (x - p)^2 in double
+// about a pivot p (the running mean: any value works), one partial pair per workgroup in a fixed order -- the batch mean is p + S1 / n and
+// the variance about ANY later mean m (the all-reduced one under DD-PPO) is (S2 - 2 (m - p) S1 + n (m - p)^2) / n, so the two extra read
+// passes over the pooled tensor (chan_moment modes 0 and 1) are not needed.  mom_partial: [gridDim.x][2][8] doubles.
+template <bool MOM>
 __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restrict__ rgb, const float* __restrict__ depth,
                                                           const int32_t* __restrict__ semantic, const int* __restrict__ rows,
                                                           float* __restrict__ y, int B, int H, int W, int cpad, int c_rgb, int c_depth,
-                                                          int c_sem, const float* __restrict__ nmean, const float* __restrict__ nvar, int creal) {
+                                                          int c_sem, const float* __restrict__ nmean, const float* __restrict__ nvar, int creal,
+                                                          const float* __restrict__ pivot, double* __restrict__ mom_partial) {
 #pragma clang fp contract(off)  // the reference rounds the uint8 scaling and every addition of the 2x2 average separately
     // optional RunningMeanAndVar normalisation of the result (evaluation mode: a fixed affine per channel; rmv_normalize_kernel's
     // arithmetic: fma(x, inv_std, -mean * inv_std))
@@ -33,6 +39,15 @@ __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restr
     const int Ho = H / 2, Wo = W / 2;
     const long long total = (long long)B * Ho * Wo;
     const float inv255 = (float)(1.0 / 255.0);
+    // moments: fp32 accumulators over runs of 32 pixels of this thread (about the pivot the first moment is a short random walk and the
+    // second a sum of 32 positive terms: relative error of a run ~1e-7, unbiased), flushed into doubles
+    double s1[MOM ? 8 : 1], s2[MOM ? 8 : 1];
+    float f1[MOM ? 8 : 1], f2[MOM ? 8 : 1], pv[MOM ? 8 : 1];
+    int run = 0;
+    if constexpr (MOM) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { s1[c] = 0.0; s2[c] = 0.0; f1[c] = 0.f; f2[c] = 0.f; pv[c] = c < creal ? pivot[c] : 0.f; }
+    }
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int wo = (int)(e % Wo);
         const long long t = e / Wo;
@@ -75,21 +90,113 @@ __global__ void __launch_bounds__(256) ingest_pool_kernel(const uint8_t* __restr
 #pragma unroll
             for (int c = 0; c < 8; ++c) out[c] = __builtin_fmaf(out[c], nb[c], na[c]);
         }
+        if constexpr (MOM) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < cpad) { const float d = out[c] - pv[c]; f1[c] = f1[c] + d; f2[c] = __builtin_fmaf(d, d, f2[c]); }
+            if (++run == 32) {
+                run = 0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c < cpad) { s1[c] += (double)f1[c]; s2[c] += (double)f2[c]; f1[c] = 0.f; f2[c] = 0.f; }
+            }
+        }
         float* o = y + (size_t)e * cpad;
         for (int c = 0; c < cpad; c += 4) *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(out + c);
+    }
+    if constexpr (MOM) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < cpad) { s1[c] += (double)f1[c]; s2[c] += (double)f2[c]; }
+        // fixed-order reduction: xor tree inside the wave, then the four waves in order
+        __shared__ double red[4][16];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < cpad) {
+#pragma unroll
+                for (int off = 32; off; off >>= 1) { s1[c] += __shfl_xor(s1[c], off); s2[c] += __shfl_xor(s2[c], off); }
+                if (lane == 0) { red[wave][c] = s1[c]; red[wave][8 + c] = s2[c]; }
+            }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const int c = threadIdx.x & 7;
+            double tsum = 0.0;
+            if (c < cpad) tsum = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+            mom_partial[(size_t)blockIdx.x * 16 + threadIdx.x] = tsum;
+        }
     }
 }
 
 int ingest_pool(const uint8_t* rgb, const float* depth, const int32_t* semantic, const int* rows, float* y, int B, int H, int W, int cpad,
-                int c_rgb, int c_depth, int c_sem, hipStream_t s, const float* norm_mean, const float* norm_var) {
+                int c_rgb, int c_depth, int c_sem, hipStream_t s, const float* norm_mean, const float* norm_var, const float* pivot,
+                double* mom_partial, int* mom_blocks) {
     if ((!rgb && !depth && !semantic) || !y || B <= 0 || H < 2 || W < 2 || (cpad != 4 && cpad != 8)) return HAB_ERR_ARG;
     if ((norm_mean == nullptr) != (norm_var == nullptr)) return HAB_ERR_ARG;
+    if (mom_partial && (!pivot || !mom_blocks || norm_mean)) return HAB_ERR_ARG;  // moments are those of the un-normalised tensor
     const int n = (rgb ? 3 : 0) + (depth ? 1 : 0) + (semantic ? 1 : 0);
     if (n > cpad || (rgb && (c_rgb < 0 || c_rgb + 3 > n)) || (depth && (c_depth < 0 || c_depth >= n)) || (semantic && (c_sem < 0 || c_sem >= n)))
         return HAB_ERR_ARG;
     const long long total = (long long)B * (H / 2) * (W / 2);
-    ingest_pool_kernel<<<(int)fmin(8192.0, (double)cdivl(total, 256)), 256, 0, s>>>(rgb, depth, semantic, rows, y, B, H, W, cpad, c_rgb,
-                                                                                     c_depth, c_sem, norm_mean, norm_var, n);
+    if (mom_partial) {
+        const int blocks = (int)fmin((double)INGEST_MOM_MAX_BLOCKS, (double)cdivl(total, 256));
+        *mom_blocks = blocks;
+        ingest_pool_kernel<true><<<blocks, 256, 0, s>>>(rgb, depth, semantic, rows, y, B, H, W, cpad, c_rgb, c_depth, c_sem, nullptr, nullptr,
+                                                        n, pivot, mom_partial);
+    } else {
+        ingest_pool_kernel<false><<<(int)fmin(8192.0, (double)cdivl(total, 256)), 256, 0, s>>>(rgb, depth, semantic, rows, y, B, H, W, cpad,
+                                                                                                c_rgb, c_depth, c_sem, norm_mean, norm_var, n,
+                                                                                                nullptr, nullptr);
+    }
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
+// Finish of the fused moments (ingest_pool_kernel<true>): one workgroup; thread (q, v) sums the partials b = q, q + 16, ... of value v
+// (v < 8: S1 of channel v, else S2 of channel v - 8), the 16 q's are then added in order.  sums[0..15] keeps S1 / S2 for the variance;
+// mean_out[c] = p + S1 / n.
+__global__ void __launch_bounds__(256) moment_finish_mean_kernel(const double* __restrict__ partial, int nblocks, int cpad,
+                                                                 const float* __restrict__ pivot, int creal, double inv_n,
+                                                                 double* __restrict__ sums, float* __restrict__ mean_out,
+                                                                 float* __restrict__ count_out, float count_val) {
+    __shared__ double sm[16][16];
+    const int v = threadIdx.x & 15, q = threadIdx.x >> 4;
+    double t = 0.0;
+    for (int b = q; b < nblocks; b += 16) t += partial[(size_t)b * 16 + v];
+    sm[q][v] = t;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double tot = 0.0;
+        for (int k = 0; k < 16; ++k) tot += sm[k][v];
+        sums[v] = tot;
+        if (v < 8 && v < cpad) mean_out[v] = v < creal ? (float)((double)pivot[v] + tot * inv_n) : 0.f;
+    }
+    if (threadIdx.x == 0 && count_out) *count_out = count_val;
+}
+// var_out[c] = biased variance of this rank's pixels about m = mean_sum[c] / mean_div (the cross-rank mean under DD-PPO)
+__global__ void moment_finish_var_kernel(const double* __restrict__ sums, const float* __restrict__ pivot, int creal, int cpad,
+                                         const float* __restrict__ mean_sum, float mean_div, double n, float* __restrict__ var_out) {
+    const int c = threadIdx.x;
+    if (c >= cpad) return;
+    float out = 0.f;
+    if (c < creal) {
+        const float m = mean_sum[c] / mean_div;  // `new_mean /= world_size` (exact IEEE division)
+        const double d = (double)m - (double)pivot[c];
+        out = (float)((sums[8 + c] - 2.0 * d * sums[c] + n * d * d) / n);
+    }
+    var_out[c] = out;
+}
+int moment_finish_mean(const double* partial, int nblocks, int cpad, const float* pivot, int creal, long long npix, double* sums,
+                       float* mean_out, float* count_out, float count_val, hipStream_t s) {
+    if (!partial || nblocks < 1 || !pivot || !sums || !mean_out || npix <= 0 || cpad > 8 || creal > cpad) return HAB_ERR_ARG;
+    moment_finish_mean_kernel<<<1, 256, 0, s>>>(partial, nblocks, cpad, pivot, creal, 1.0 / (double)npix, sums, mean_out, count_out, count_val);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+int moment_finish_var(const double* sums, const float* pivot, int creal, int cpad, const float* mean_sum, float mean_div, long long npix,
+                      float* var_out, hipStream_t s) {
+    if (!sums || !pivot || !mean_sum || !var_out || npix <= 0 || cpad > 8 || creal > cpad || !(mean_div >= 1.f)) return HAB_ERR_ARG;
+    moment_finish_var_kernel<<<1, 64, 0, s>>>(sums, pivot, creal, cpad, mean_sum, mean_div, (double)npix, var_out);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -147,7 +254,7 @@ int chan_moment(const float* x, long long npix, int cpad, int mode, const float*
 // batch count is the all-reduced number of frames *n_dev -- ranks may hold different numbers of frames (preempted rollouts).
 __global__ void rmv_update_kernel(float* __restrict__ r_mean, float* __restrict__ r_var, float* __restrict__ r_count,
                                   const float* __restrict__ b_mean, const float* __restrict__ b_var, float n_host,
-                                  const float* __restrict__ n_dev, float div, int C) {
+                                  const float* __restrict__ n_dev, float div, int C, float* __restrict__ aff) {
     const int c = threadIdx.x;
     const float count = r_count[0];
     const float n = n_dev ? n_dev[0] : n_host;
@@ -156,16 +263,22 @@ __global__ void rmv_update_kernel(float* __restrict__ r_mean, float* __restrict_
         const float m_a = var * count, m_b = nv * n;
         const float d = nm - mean;
         const float M2 = m_a + m_b + d * d * count * n / (count + n);
-        r_var[c] = M2 / (count + n);
-        r_mean[c] = (count * mean + n * nm) / (count + n);
-    }
+        const float v_new = M2 / (count + n), m_new = (count * mean + n * nm) / (count + n);
+        r_var[c] = v_new;
+        r_mean[c] = m_new;
+        if (aff) {  // the normalisation as the consumers apply it: fma(x, aff[c], aff[8 + c]) (rmv_normalize_kernel's arithmetic)
+            const float inv = rsqrtf(fmaxf(v_new, 1e-2f));
+            aff[c] = inv;
+            aff[8 + c] = -m_new * inv;
+        }
+    } else if (aff && c < 8) { aff[c] = 0.f; aff[8 + c] = 0.f; }
     __syncthreads();
     if (c == 0) r_count[0] = count + n;
 }
 int rmv_update(float* r_mean, float* r_var, float* r_count, const float* b_mean, const float* b_var, float n, int C, hipStream_t s,
-               const float* n_dev, float div) {
-    if (!r_mean || !r_var || !r_count || !b_mean || !b_var || C <= 0 || C > 64 || !(div >= 1.f)) return HAB_ERR_ARG;
-    rmv_update_kernel<<<1, 64, 0, s>>>(r_mean, r_var, r_count, b_mean, b_var, n, n_dev, div, C);
+               const float* n_dev, float div, float* aff) {
+    if (!r_mean || !r_var || !r_count || !b_mean || !b_var || C <= 0 || C > 64 || !(div >= 1.f) || (aff && C > 8)) return HAB_ERR_ARG;
+    rmv_update_kernel<<<1, 64, 0, s>>>(r_mean, r_var, r_count, b_mean, b_var, n, n_dev, div, C, aff);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }
@@ -626,7 +739,8 @@ __device__ __forceinline__ f32x4 gn_affine4(const f32x4 x, const f32x4 sc, const
 // Replaces resnet.py:207-220 (GroupNorm, ReLU, MaxPool2d of `conv1`).
 template <int NT, int NV>
 __global__ void __launch_bounds__(256) gn_chunk_apply_pool_kernel(const GnArgs a, int nchunks, const float* __restrict__ part, int H, int W,
-                                                                  float* __restrict__ pool, uint8_t* __restrict__ idx, int blocks_per_frame) {
+                                                                  float* __restrict__ pool, uint8_t* __restrict__ idx, int blocks_per_frame,
+                                                                  int chunk4 /* float4s per chunk of `part` */) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
     const int F4 = a.HW * C4;
@@ -638,13 +752,13 @@ __global__ void __launch_bounds__(256) gn_chunk_apply_pool_kernel(const GnArgs a
         const float n = (float)(a.HW * cpg);
         float mean = 0.f;
         for (int k = 0; k < nchunks; ++k) {
-            const float nk = (float)((min(NT * NV, F4 - k * NT * NV) / C4) * cpg);
+            const float nk = (float)((min(chunk4, F4 - k * chunk4) / C4) * cpg);
             mean += nk * p[(size_t)k * G * 2];
         }
         mean /= n;
         float m2 = 0.f;
         for (int k = 0; k < nchunks; ++k) {
-            const float nk = (float)((min(NT * NV, F4 - k * NT * NV) / C4) * cpg);
+            const float nk = (float)((min(chunk4, F4 - k * chunk4) / C4) * cpg);
             const float d = p[(size_t)k * G * 2] - mean;
             m2 += p[(size_t)k * G * 2 + 1] + nk * d * d;
         }
@@ -961,19 +1075,30 @@ int groupnorm_forward(const GnArgs& a, hipStream_t s) {
 
 // GroupNorm + ReLU + MaxPool2d(3, 2, 1) in one pass; 1: frame not on the chunk-parallel path (the caller runs groupnorm_forward +
 // maxpool_forward).
-int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, uint8_t* idx, hipStream_t s) {
+// ext_part / ext_rows: the partial statistics already exist -- (mean, M2) per (frame, chunk of ext_rows image rows, group), written by the
+// producing convolution's epilogue (stem_conv_strip.h) -- and the statistics pass over the tensor is skipped.
+int groupnorm_relu_maxpool_forward(const GnArgs& a, int H, int W, float* pool, uint8_t* idx, hipStream_t s, const float* ext_part, int ext_rows) {
     if (!a.x || !a.gamma || !a.beta || !pool || a.HW != H * W || a.residual || !a.relu) return HAB_ERR_ARG;
     if ((a.mean == nullptr) != (a.rstd == nullptr)) return HAB_ERR_ARG;
     HAB_TRY(gn_check(a.B, a.C, a.groups));
     int nt, nv, nchunks;
     if (gn_reg_cfg(a.HW, a.C, nt, nv)) return 1;
-    if (!a.scratch || !gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.groups * 2, a.scratch_floats, GNC_NT * GNC_NV_F, nchunks)) return 1;
-    const size_t lds1 = (size_t)(GNC_NT * 4 + a.C + a.groups) * sizeof(float);
-    gn_chunk_stats_kernel<GNC_NT, GNC_NV_F><<<a.B * nchunks, GNC_NT, lds1, s>>>(a, nchunks, a.scratch);
-    HAB_LAUNCH_CHECK();
+    const float* part = a.scratch;
+    int chunk4 = GNC_NT * GNC_NV_F;
+    if (ext_part) {
+        if (ext_rows < 1) return HAB_ERR_ARG;
+        part = ext_part;
+        chunk4 = ext_rows * W * (a.C / 4);
+        nchunks = cdiv(H, ext_rows);
+    } else {
+        if (!a.scratch || !gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.groups * 2, a.scratch_floats, GNC_NT * GNC_NV_F, nchunks)) return 1;
+        const size_t lds1 = (size_t)(GNC_NT * 4 + a.C + a.groups) * sizeof(float);
+        gn_chunk_stats_kernel<GNC_NT, GNC_NV_F><<<a.B * nchunks, GNC_NT, lds1, s>>>(a, nchunks, a.scratch);
+        HAB_LAUNCH_CHECK();
+    }
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int bpf = max(1, min(64, cdiv(Ho * Wo * (a.C / 4), 256 * 4)));
-    gn_chunk_apply_pool_kernel<GNC_NT, GNC_NV_F><<<a.B * bpf, 256, 2 * a.groups * sizeof(float), s>>>(a, nchunks, a.scratch, H, W, pool, idx, bpf);
+    gn_chunk_apply_pool_kernel<GNC_NT, GNC_NV_F><<<a.B * bpf, 256, 2 * a.groups * sizeof(float), s>>>(a, nchunks, part, H, W, pool, idx, bpf, chunk4);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }

@@ -59,13 +59,20 @@ struct StepArgs {
     // columns (x_dim, zero beyond in_dim), b_ih.  `gi` is then unused: the separate M = 64 contraction + its split-K second pass (two
     // launches per layer and environment step) disappear.
     const float* x_base = nullptr; int x_stride = 0; const float* w_ih = nullptr; int w_ih_ld = 0; int x_dim = 0; const float* b_ih = nullptr;
+    const int* x_idx = nullptr;                                // row q -> row of x_base (null = q): the layer below's output frames
+};
+// The steps that one launch of a layer wavefront runs side by side (blockIdx.z = layer): layer l works on packed step w - l while
+// layer l - 1 works on step w -- it only needs the layer below's output of ITS step, which the previous launch wrote.
+constexpr int RNN_MAX_WAVE_LAYERS = 4;
+struct StepArgsN {
+    StepArgs l[RNN_MAX_WAVE_LAYERS];
 };
 
 // One workgroup = 16 rows x 16 hidden units x G gates; NW waves split K = H.  The recurrence is latency-bound (a step is a
 // few MFLOP): each wave issues its loads in batches of U K-chunks before the dependent MFMAs, so a step costs ~1-2 L2 round
 // trips instead of one per chunk.
 template <int G, int NW>
-__global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
+__device__ __forceinline__ void rnn_step_body(const StepArgs& a) {
     // (four accumulators in the fused-projection form of BOTH cell types: LSTM i, f, g, o with x- and h-parts summed; GRU r, z summed,
     //  the n gate's h-part and x-part apart -- n = tanh(gi_n + r * gh_n))
     constexpr int GA = 4;
@@ -76,6 +83,7 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
     const int row0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
     const int i = lane & 15, kg = lane >> 4;
     const int H = a.H;
+    if (row0 >= a.R) return;  // (a wavefront launch is sized for its widest layer)
     const int q = min(row0 + i, a.R - 1);
     const float* hrow = a.hp_base + (size_t)(a.hp_idx ? a.hp_idx[q] : q) * a.hp_stride;
     const float keep = (a.row_mask && !a.row_mask[q]) ? 0.f : 1.f;  // h * mask (rnn_state_encoder.py:308-311), applied to the operand
@@ -136,7 +144,7 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
             for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[g][s], acc[g], 0, 0, 0);
     }
     if (fused_x) {  // + W_ih x: K-chunks of 16 dealt round-robin over the waves, two chunks of loads in flight
-        const float* xrow = a.x_base + (size_t)q * a.x_stride;
+        const float* xrow = a.x_base + (size_t)(a.x_idx ? a.x_idx[q] : q) * a.x_stride;
         const float* wi[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) wi[g] = a.w_ih + (size_t)(g * H + u0 + i) * a.w_ih_ld;
@@ -224,6 +232,11 @@ __global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) {
     }
 }
 
+template <int G, int NW>
+__global__ void __launch_bounds__(64 * NW) rnn_step_kernel(const StepArgs a) { rnn_step_body<G, NW>(a); }
+template <int G, int NW>
+__global__ void __launch_bounds__(64 * NW) rnn_step_wave_kernel(const StepArgsN a) { rnn_step_body<G, NW>(a.l[blockIdx.z]); }
+
 static int launch_step(int rnn_type, const StepArgs& a, hipStream_t stream) {
     if (a.R <= 0) return HAB_OK;
     if (a.H % 64) return HAB_ERR_UNSUPPORTED;
@@ -261,6 +274,62 @@ int rnn_seq_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const R
         a.gates = wk.gates; a.hn = wk.hn; a.hprev = wk.hprev; a.cprev = wk.cprev; a.c = wk.c;
         a.out = wk.out; a.out_stride = H; a.c_out = nullptr; a.c_out_stride = 0;
         HAB_TRY(launch_step(rnn_type, a, stream));
+    }
+    return HAB_OK;
+}
+
+// The L layers of the packed recurrence as a WAVEFRONT: launch w runs step w - l of layer l for every layer at once (grid z = layer),
+// max_len + L - 1 launches instead of L * max_len -- the chain of dependent ~9 us launches is what the recurrent encoder costs.
+// Layer 0 reads its input projection from the one large contraction over all frames, as in rnn_seq_layer_forward; a layer above cannot
+// (its input is finished step by step), so its projection runs inside the step kernel (the rollout's fused form) on the rows the layer
+// below wrote in the previous launch.  Saves for BPTT as in the layer-by-layer form; wk[l].gi of the upper layers is not written.
+// Returns 1 when the form does not apply (the caller runs layer by layer).
+int rnn_seq_wave_forward(int rnn_type, int H, int L, const RnnLayerParams* lp, const RnnWork* wk, const float* x, int ldx,
+                         const float* const* hinit, const float* const* cinit, const PackInfo& pk, float* ws, size_t ws_floats,
+                         hipStream_t stream) {
+    const int G = rnn_type == RNN_GRU ? 3 : 4;
+    if (L < 2 || L > RNN_MAX_WAVE_LAYERS || (H % 64) || pk.max_len < 1) return 1;
+    for (int l = 1; l < L; ++l)
+        if (!lp[l].w_ih_pad || lp[l].w_ih_ld != H || (reinterpret_cast<uintptr_t>(lp[l].w_ih_pad) & 15)) return 1;
+    HAB_TRY(linear_fwd(x, ldx, lp[0].w_ih, lp[0].in_dim, lp[0].b_ih, wk[0].gi, G * H, pk.P, G * H, lp[0].in_dim, 0, 0, ws, ws_floats, stream));
+    const bool wide = H % 128 == 0;
+    for (int w = 0; w < pk.max_len + L - 1; ++w) {
+        StepArgsN n{};
+        int rmax = 0;
+        for (int l = 0; l < L; ++l) {
+            StepArgs& a = n.l[l];
+            const int s = w - l;
+            a.H = H;
+            a.R = (s >= 0 && s < pk.max_len) ? pk.num_seqs_at_step[s] : 0;
+            if (a.R <= 0) { a.R = 0; continue; }
+            rmax = std::max(rmax, a.R);
+            if (s == 0) {
+                a.hp_base = hinit[l]; a.hp_idx = nullptr; a.hp_stride = H;
+                a.cp_base = cinit[l]; a.cp_idx = nullptr; a.cp_stride = H;
+            } else {
+                a.hp_base = wk[l].out; a.hp_idx = pk.select_inds + pk.step_offsets[s - 1]; a.hp_stride = H;
+                a.cp_base = wk[l].c; a.cp_idx = a.hp_idx; a.cp_stride = H;
+            }
+            a.row_mask = nullptr;
+            a.out_idx = pk.select_inds + pk.step_offsets[s];
+            a.gi = wk[l].gi; a.w_hh = lp[l].w_hh; a.b_hh = lp[l].b_hh;
+            a.gates = wk[l].gates; a.hn = wk[l].hn; a.hprev = wk[l].hprev; a.cprev = wk[l].cprev; a.c = wk[l].c;
+            a.out = wk[l].out; a.out_stride = H; a.c_out = nullptr; a.c_out_stride = 0;
+            if (l > 0) {
+                a.x_base = wk[l - 1].out; a.x_stride = H; a.x_idx = a.out_idx; a.w_ih = lp[l].w_ih_pad; a.w_ih_ld = H; a.x_dim = H;
+                a.b_ih = lp[l].b_ih;
+            }
+        }
+        if (rmax == 0) continue;
+        const dim3 grid(cdiv(rmax, 16), H / 16, L);
+        if (rnn_type == RNN_GRU) {
+            if (wide) rnn_step_wave_kernel<3, 8><<<grid, 512, 0, stream>>>(n);
+            else rnn_step_wave_kernel<3, 4><<<grid, 256, 0, stream>>>(n);
+        } else {
+            if (wide) rnn_step_wave_kernel<4, 8><<<grid, 512, 0, stream>>>(n);
+            else rnn_step_wave_kernel<4, 4><<<grid, 256, 0, stream>>>(n);
+        }
+        HAB_LAUNCH_CHECK();
     }
     return HAB_OK;
 }
@@ -308,16 +377,27 @@ struct BwdStepArgs {
     float* dc_carry;       // LSTM [F][H] in/out
     const float* gates; const float* hn; const float* hprev; const float* cprev; const float* c;
     float* dgi; float* dgh;  // [frames][K]; LSTM: dgh == dgi
+    // Layer wavefront (rnn_seq_wave_backward): the gradient wrt this layer's output is the data gradient of the layer ABOVE,
+    // dgi_up[frame] * W_ih_up, computed here for the rows of this step (the layer above finished this step in the previous launch)
+    // instead of by one contraction over all frames after the layer above has walked its whole chain.  `dout` may then be null.
+    const float* up_dgi = nullptr;     // [frames][K]
+    const float* up_w_ih_t = nullptr;  // [H][K]: W_ih of the layer above, transposed
+};
+struct BwdStepArgsN {
+    BwdStepArgs l[RNN_MAX_WAVE_LAYERS];
 };
 
 template <int G, int NW>
-__global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs a) {
+__device__ __forceinline__ void rnn_bwd_step_body(const BwdStepArgs& a) {
     __shared__ float red[NW][256];
+    __shared__ float red_up[NW][256];
     constexpr int U = 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
     const int H = a.H;
+    if (row0 >= a.R) return;  // (a wavefront launch is sized for its widest layer)
     const bool has_carry = row0 < a.R_next;  // workgroup-uniform
+    const bool has_up = a.up_dgi != nullptr;
     // gate-phase operands of this thread's (row, unit) element, fetched underneath the carry mat-vec (see rnn_step_kernel)
     const int r_ = t >> 4, uu_ = u0 + (t & 15), q_ = row0 + r_;
     const bool gate_thread = (t < 256) & (q_ < a.R);
@@ -328,7 +408,7 @@ __global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs
     if (gate_thread) {
         f_pre = a.idx[q_];
         const size_t qo_ = (size_t)q_ * H + uu_, fo_ = (size_t)f_pre * H + uu_;
-        dout_pre = a.dout[fo_];
+        dout_pre = a.dout ? a.dout[fo_] : 0.f;
         if (q_ < a.R_next && (!a.next_keep || a.next_keep[q_])) {
             if constexpr (G == 3) dhd_pre = a.dh_direct[qo_];
             else dcc_pre = a.dc_carry[qo_];
@@ -338,11 +418,9 @@ __global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs
         if constexpr (G == 3) { hp_pre = a.hprev[fo_]; hn_pre = a.hn[fo_]; }
         else { cn_pre = a.c[fo_]; cp_pre = a.cprev[fo_]; }
     }
-    if (has_carry) {
+    // tile[16 rows][16 units] = A[rows][K] * B[units][K]^T, K split over the waves, partial tiles into `out`
+    auto matvec = [&](const float* arow, const float* brow, float (*out)[256]) {
         const int i = lane & 15, kg = lane >> 4;
-        const int q = min(row0 + i, a.R_next - 1);
-        const float* arow = a.dgh + (size_t)a.idx_next[q] * a.K;
-        const float* brow = a.w_hh_t + (size_t)(u0 + i) * a.K;
         const int kq = a.K / NW, kb = wave * kq;
         f32x4 acc;
         acc[0] = 0.f; acc[1] = 0.f; acc[2] = 0.f; acc[3] = 0.f;
@@ -368,15 +446,31 @@ __global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs
             for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) red[wave][(kg * 4 + v) * 16 + i] = acc[v];
-        __syncthreads();
+        for (int v = 0; v < 4; ++v) out[wave][(kg * 4 + v) * 16 + i] = acc[v];
+    };
+    if (has_up) {  // gradient wrt this layer's output at the frames of THIS step
+        const int i = lane & 15;
+        const int q = min(row0 + i, a.R - 1);
+        matvec(a.up_dgi + (size_t)a.idx[q] * a.K, a.up_w_ih_t + (size_t)(u0 + i) * a.K, red_up);
     }
+    if (has_carry) {
+        const int i = lane & 15;
+        const int q = min(row0 + i, a.R_next - 1);
+        matvec(a.dgh + (size_t)a.idx_next[q] * a.K, a.w_hh_t + (size_t)(u0 + i) * a.K, red);
+    }
+    if (has_up || has_carry) __syncthreads();
     if (t >= 256) return;
     const int r = t >> 4, uu = u0 + (t & 15), q = row0 + r;
     if (q >= a.R) return;
     const int f = f_pre;
     const size_t qo = (size_t)q * H + uu;
     float dh = dout_pre;
+    if (has_up) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4) sum += (red_up[w][t] + red_up[w + 1][t]) + (red_up[w + 2][t] + red_up[w + 3][t]);
+        dh += sum;
+    }
     const bool carried = (q < a.R_next) && (!a.next_keep || a.next_keep[q]);
     if (carried) {
         float sum = 0.f;
@@ -416,6 +510,11 @@ __global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs
     }
 }
 
+template <int G, int NW>
+__global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs a) { rnn_bwd_step_body<G, NW>(a); }
+template <int G, int NW>
+__global__ void __launch_bounds__(64 * NW) rnn_bwd_step_wave_kernel(const BwdStepArgsN a) { rnn_bwd_step_body<G, NW>(a.l[blockIdx.z]); }
+
 int rnn_seq_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx,
                            const float* dout, float* dx, int lddx, const float* dx_mask, int ldmask, int mask_cols,
                            const PackInfo& pk, float* scratch /* 3*F*H floats */, float* ws, size_t ws_floats, hipStream_t stream) {
@@ -452,6 +551,68 @@ int rnn_seq_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const 
     HAB_TRY(colsum(wk.dgi, G * H, pk.P, G * H, lp.db_ih, 0, ws, ws_floats, stream));
     HAB_TRY(colsum(dgh, G * H, pk.P, G * H, lp.db_hh, 0, ws, ws_floats, stream));
     if (dx) HAB_TRY(linear_dgrad(wk.dgi, G * H, lp.w_ih, lp.in_dim, dx_mask, ldmask, mask_cols, dx, lddx, pk.P, lp.in_dim, G * H, 0, ws, ws_floats, stream));
+    return HAB_OK;
+}
+
+// BPTT of the L packed layers as a wavefront (the mirror of rnn_seq_wave_forward): launch w runs, for every layer at once, step
+// max_len - 1 - (w - (L - 1 - l)) of layer l.  The top layer reads `dout` (the heads' gradient wrt the features); a layer below computes
+// the gradient wrt its output inside its step kernel from the layer above's dgi of the same step (BwdStepArgs::up_dgi) -- the data
+// gradient contraction of the upper layers is gone.  Then the parameter gradients of every layer and layer 0's data gradient as in
+// rnn_seq_layer_backward.  w_ih_t[l]: W_ih of layer l transposed, [H][G * H] (l >= 1).  scratch: L * 2 * F * H floats.
+// Returns 1 when the form does not apply.
+int rnn_seq_wave_backward(int rnn_type, int H, int L, const RnnLayerParams* lp, const float* const* w_ih_t, const RnnWork* wk, const float* x0,
+                          int ldx0, const float* dout, float* dx0, int lddx0, const float* dx_mask, int ldmask, int mask_cols,
+                          const PackInfo& pk, float* scratch, float* ws, size_t ws_floats, hipStream_t stream) {
+    const int G = rnn_type == RNN_GRU ? 3 : 4;
+    if (L < 2 || L > RNN_MAX_WAVE_LAYERS || (H % 64) || pk.max_len < 1) return 1;
+    for (int l = 1; l < L; ++l)
+        if (!w_ih_t[l] || lp[l].in_dim != H || (reinterpret_cast<uintptr_t>(w_ih_t[l]) & 15)) return 1;
+    const int K = G * H;
+    const bool wide = K % 128 == 0;
+    for (int w = 0; w < pk.max_len + L - 1; ++w) {
+        BwdStepArgsN n{};
+        int rmax = 0;
+        for (int l = 0; l < L; ++l) {
+            BwdStepArgs& g = n.l[l];
+            const int s = pk.max_len - 1 - (w - (L - 1 - l));
+            g.H = H; g.K = K;
+            g.R = (s >= 0 && s < pk.max_len) ? pk.num_seqs_at_step[s] : 0;
+            if (g.R <= 0) { g.R = 0; continue; }
+            rmax = std::max(rmax, g.R);
+            g.R_next = (s + 1 < pk.max_len) ? pk.num_seqs_at_step[s + 1] : 0;
+            g.idx = pk.select_inds + pk.step_offsets[s];
+            g.idx_next = g.R_next ? pk.select_inds + pk.step_offsets[s + 1] : g.idx;
+            g.next_keep = nullptr;
+            g.dout = (l == L - 1) ? dout : nullptr;
+            g.w_hh_t = lp[l].w_hh_t;
+            g.dh_direct = scratch + (size_t)l * 2 * pk.F * H;
+            g.dc_carry = g.dh_direct + (size_t)pk.F * H;
+            g.gates = wk[l].gates; g.hn = wk[l].hn; g.hprev = wk[l].hprev; g.cprev = wk[l].cprev; g.c = wk[l].c;
+            g.dgi = wk[l].dgi; g.dgh = (rnn_type == RNN_GRU) ? wk[l].dgh : wk[l].dgi;
+            if (l < L - 1) { g.up_dgi = wk[l + 1].dgi; g.up_w_ih_t = w_ih_t[l + 1]; }
+        }
+        if (rmax == 0) continue;
+        const dim3 grid(cdiv(rmax, 16), H / 16, L);
+        if (rnn_type == RNN_GRU) {
+            if (wide) rnn_bwd_step_wave_kernel<3, 8><<<grid, 512, 0, stream>>>(n);
+            else rnn_bwd_step_wave_kernel<3, 4><<<grid, 256, 0, stream>>>(n);
+        } else {
+            if (wide) rnn_bwd_step_wave_kernel<4, 8><<<grid, 512, 0, stream>>>(n);
+            else rnn_bwd_step_wave_kernel<4, 4><<<grid, 256, 0, stream>>>(n);
+        }
+        HAB_LAUNCH_CHECK();
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const float* x = l == 0 ? x0 : wk[l - 1].out;
+        const int ldx = l == 0 ? ldx0 : H;
+        float* dgh = (rnn_type == RNN_GRU) ? wk[l].dgh : wk[l].dgi;
+        HAB_TRY(linear_wgrad(wk[l].dgi, K, x, ldx, lp[l].dw_ih, lp[l].in_dim, pk.P, K, lp[l].in_dim, 0, 0, 0, ws, ws_floats, stream));
+        HAB_TRY(linear_wgrad(dgh, K, wk[l].hprev, H, lp[l].dw_hh, H, pk.P, K, H, 0, 0, 0, ws, ws_floats, stream));
+        HAB_TRY(colsum(wk[l].dgi, K, pk.P, K, lp[l].db_ih, 0, ws, ws_floats, stream));
+        HAB_TRY(colsum(dgh, K, pk.P, K, lp[l].db_hh, 0, ws, ws_floats, stream));
+    }
+    if (dx0) HAB_TRY(linear_dgrad(wk[0].dgi, K, lp[0].w_ih, lp[0].in_dim, dx_mask, ldmask, mask_cols, dx0, lddx0, pk.P, lp[0].in_dim, K, 0, ws,
+                                  ws_floats, stream));
     return HAB_OK;
 }
 

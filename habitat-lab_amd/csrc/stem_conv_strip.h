@@ -32,15 +32,23 @@ struct StemArgs {
     int B, H, W, Ho, Wo, PW;   // PW: pixels per LDS image row (even, >= 2 Wo + 6)
     int strips;                // ceil(Ho / 8)
     int sign_schedule;
+    float* part;               // CPG > 0: GroupNorm partial statistics [B][strips][32 / CPG][2] = (mean, M2) of the strip's outputs per group
+    const float* norm;         // null, or the RunningMeanAndVar affine of the 4 input channels applied while staging: fma(x, norm[c],
+                               // norm[8 + c]) on the pixels inside the image (rmv_normalize_kernel's arithmetic; the zero padding stays zero)
 };
 
 constexpr int STEM_TH = 8, STEM_ROWS = 2 * STEM_TH + 5, STEM_KS = 14;
 constexpr size_t STEM_W_BYTES = (size_t)3 * STEM_KS * 1024;
 
+// CPG: 0, or the channels per GroupNorm group (1, 2, 4) of the GroupNorm that follows -- the strip's per-group (mean, M2) then leave
+// with the outputs (the chunk statistics gn_chunk_stats_kernel would compute in a separate pass over the 2 KB-per-pixel-row tensor:
+// exact local two-pass on the accumulators, merged later by Chan's formula, resnet_ops.hip).
+constexpr int STEM_STAT_FLOATS = 8 * 32 + 32;
+template <int CPG>
 __global__ void __launch_bounds__(512) stem_conv_strip_kernel(const StemArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned short stem_sm[];
     unsigned short* ws = stem_sm;                                   // [3][14][64][8]
-    unsigned short* xs = stem_sm + STEM_W_BYTES / 2;                // [3][STEM_ROWS][PW][4]
+    unsigned short* xs = stem_sm + STEM_W_BYTES / 2;                // [3][STEM_ROWS][PW][4]   (+ STEM_STAT_FLOATS floats behind it)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, hi = lane >> 5;
@@ -59,6 +67,8 @@ __global__ void __launch_bounds__(512) stem_conv_strip_kernel(const StemArgs a) 
     {
         const int units = STEM_ROWS * a.PW;
         const float* xb = a.x + (size_t)img * a.H * a.W * 4;
+        f32x4 nb = {1.f, 1.f, 1.f, 1.f}, na = {0.f, 0.f, 0.f, 0.f};
+        if (a.norm) { nb = *reinterpret_cast<const f32x4*>(a.norm); na = *reinterpret_cast<const f32x4*>(a.norm + 8); }
         constexpr int UB = 6;
         for (int u0 = t; u0 < units; u0 += 512 * UB) {
             f32x4 v[UB];
@@ -77,6 +87,14 @@ __global__ void __launch_bounds__(512) stem_conv_strip_kernel(const StemArgs a) 
             for (int j = 0; j < UB; ++j) {
                 const int u = u0 + j * 512;
                 if (u < units) {
+                    if (a.norm) {  // (after the batch of loads, so that they stay in flight together)
+                        const int r = u / a.PW, c = u - r * a.PW;
+                        const int hin = 2 * ho0 - 3 + r, win = c - 3;
+                        if (((unsigned)hin < (unsigned)a.H) & ((unsigned)win < (unsigned)a.W)) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[j][q] = __builtin_fmaf(v[j][q], nb[q], na[q]);
+                        }
+                    }
                     unsigned a1, a2, a3, b1, b2, b3;
                     bf3_split2(v[j][0], v[j][1], a1, a2, a3);
                     bf3_split2(v[j][2], v[j][3], b1, b2, b3);
@@ -97,8 +115,8 @@ __global__ void __launch_bounds__(512) stem_conv_strip_kernel(const StemArgs a) 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+    const int ntile = a.Wo > 32 ? 2 : 1;
     if (ho < a.Ho) {
-        const int ntile = a.Wo > 32 ? 2 : 1;
         // element offset of this lane's fragment inside an image row: 2 pixels starting at column 2 wo + 4 j + 2 hi
         int coff[2];
 #pragma unroll
@@ -121,7 +139,9 @@ __global__ void __launch_bounds__(512) stem_conv_strip_kernel(const StemArgs a) 
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[PW_[q]], af[0][PX[q]], acc[0], 0, 0, 0);
-                    if (ntile > 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[PW_[q]], af[1][PX[q]], acc[1], 0, 0, 0);
+                    // (also when Wo <= 32: the second tile then recomputes the clamped last pixel and is dropped -- a branch here
+                    //  makes the compiler shuffle the accumulator registers around every MFMA)
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[PW_[q]], af[1][PX[q]], acc[1], 0, 0, 0);
                 }
             }
         }
@@ -138,6 +158,65 @@ __global__ void __launch_bounds__(512) stem_conv_strip_kernel(const StemArgs a) 
                     *reinterpret_cast<f32x4*>(o + 8 * g) = s;
                 }
             }
+        }
+    }
+    if constexpr (CPG > 0) {
+        // lane value j: quad g = j / QG (channels 8 g + 4 hi .. + 3), sub-group j % QG inside the quad -> group (8 g + 4 hi) / CPG + j % QG
+        constexpr int QG = 4 / CPG, NJ = 4 * QG, G = 32 / CPG;
+        float* red = reinterpret_cast<float*>(xs + (size_t)3 * plane);  // [8 waves][32]
+        float* mu = red + 8 * 32;
+        const float sg = flip ? -1.f : 1.f;
+        bool ok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ok[i] = (ho < a.Ho) & (i < ntile) & (32 * i + li < a.Wo);
+        float sj[NJ];
+        auto wave_total = [&](float* v) {  // over the 32 pixels of each half-wave (the halves hold different channels): fixed xor tree
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) v[j] += __shfl_xor(v[j], off);
+            if (li == 0) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) red[wave * 32 + (8 * (j / QG) + 4 * hi) / CPG + j % QG] = v[j];
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            sj[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < CPG; ++k) sj[j] += ok[i] ? sg * acc[i][4 * (j / QG) + (j % QG) * CPG + k] : 0.f;
+        }
+        wave_total(sj);
+        __syncthreads();
+        const int rows = min(STEM_TH, a.Ho - ho0);
+        if (t < G) {
+            float tot = 0.f;
+            for (int w = 0; w < STEM_TH; ++w) tot += red[w * 32 + t];
+            mu[t] = tot / (float)(rows * a.Wo * CPG);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float m = mu[(8 * (j / QG) + 4 * hi) / CPG + j % QG];
+            sj[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < CPG; ++k) {
+                    const float d = sg * acc[i][4 * (j / QG) + (j % QG) * CPG + k] - m;
+                    sj[j] += ok[i] ? d * d : 0.f;
+                }
+        }
+        wave_total(sj);
+        __syncthreads();
+        if (t < G) {
+            float m2 = 0.f;
+            for (int w = 0; w < STEM_TH; ++w) m2 += red[w * 32 + t];
+            float* o = a.part + ((size_t)blockIdx.x * G + t) * 2;
+            o[0] = mu[t];
+            o[1] = m2;
         }
     }
 }
@@ -173,27 +252,42 @@ inline bool stem_conv_strip_covers(int H, int W, int C, int Cout, int KH, int KW
     const int Wo = (W + 6 - 7) / 2 + 1;
     if (Wo > 64) return false;
     const int PW = (2 * Wo + 6 + 1) & ~1;
-    return STEM_W_BYTES + (size_t)3 * STEM_ROWS * PW * 8 <= 160 * 1024;
+    return STEM_W_BYTES + (size_t)3 * STEM_ROWS * PW * 8 + STEM_STAT_FLOATS * sizeof(float) <= 160 * 1024;
 }
 
 // 1: geometry not covered.
-inline int stem_conv_strip(const float* x, const unsigned short* wq, float* y, int B, int H, int W, hipStream_t stream) {
-    if (!x || !wq || !y || B <= 0) return HAB_ERR_ARG;
+// part / groups: GroupNorm partial statistics of the output per (frame, strip of 8 rows, group), see the kernel; groups in {8, 16, 32}
+inline int stem_conv_strip(const float* x, const unsigned short* wq, float* y, int B, int H, int W, hipStream_t stream,
+                           const float* norm = nullptr, float* part = nullptr, int groups = 0) {
+    if (!x || !wq || !y || B <= 0 || (reinterpret_cast<uintptr_t>(norm) & 15)) return HAB_ERR_ARG;
+    if (part && groups != 8 && groups != 16 && groups != 32) return HAB_ERR_ARG;
     if (!stem_conv_strip_covers(H, W, 4, 32, 7, 7, 2, 3)) return 1;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(y)) & 15) return 1;
     StemArgs a;
-    a.x = x; a.wq = wq; a.y = y; a.B = B; a.H = H; a.W = W;
+    a.x = x; a.wq = wq; a.y = y; a.B = B; a.H = H; a.W = W; a.norm = norm; a.part = part;
     a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1;
     a.PW = (2 * a.Wo + 6 + 1) & ~1;
     a.strips = (a.Ho + STEM_TH - 1) / STEM_TH;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");
     a.sign_schedule = sign_schedule;
-    const size_t lds = STEM_W_BYTES + (size_t)3 * STEM_ROWS * a.PW * 8;
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_strip_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t lds = STEM_W_BYTES + (size_t)3 * STEM_ROWS * a.PW * 8 + STEM_STAT_FLOATS * sizeof(float);
+    static const hipError_t attr_err = [] {
+        hipError_t e = hipSuccess;
+        const void* ks[4] = {reinterpret_cast<const void*>(stem_conv_strip_kernel<0>), reinterpret_cast<const void*>(stem_conv_strip_kernel<1>),
+                             reinterpret_cast<const void*>(stem_conv_strip_kernel<2>), reinterpret_cast<const void*>(stem_conv_strip_kernel<4>)};
+        for (const void* k : ks) {
+            const hipError_t r = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (r != hipSuccess) e = r;
+        }
+        return e;
+    }();
     if (attr_err != hipSuccess) return (int)attr_err;
     if ((long long)B * a.strips > 0x7fffffffLL) return 1;
-    stem_conv_strip_kernel<<<B * a.strips, 512, lds, stream>>>(a);
+    const int cpg = part ? 32 / groups : 0;
+    if (cpg == 0) stem_conv_strip_kernel<0><<<B * a.strips, 512, lds, stream>>>(a);
+    else if (cpg == 1) stem_conv_strip_kernel<1><<<B * a.strips, 512, lds, stream>>>(a);
+    else if (cpg == 2) stem_conv_strip_kernel<2><<<B * a.strips, 512, lds, stream>>>(a);
+    else stem_conv_strip_kernel<4><<<B * a.strips, 512, lds, stream>>>(a);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }

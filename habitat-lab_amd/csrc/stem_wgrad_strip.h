@@ -35,6 +35,7 @@ struct StemWgArgs {
     int B, H, W, Ho, Wo, PW;
     int strips, items;
     int sign_schedule;
+    const float* norm;  // null, or the RunningMeanAndVar affine applied to x while staging (stem_conv_strip.h: StemArgs::norm)
 };
 
 constexpr int SWG_TH = 4, SWG_XROWS = 2 * SWG_TH + 5, SWG_NT = 448;
@@ -71,6 +72,8 @@ __global__ void __launch_bounds__(SWG_NT) stem_wgrad_strip_kernel(const StemWgAr
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
 
     f32x4 xr[SWG_XPT], yr[SWG_YPT];
+    f32x4 nb = {1.f, 1.f, 1.f, 1.f}, na = {0.f, 0.f, 0.f, 0.f};
+    if (a.norm) { nb = *reinterpret_cast<const f32x4*>(a.norm); na = *reinterpret_cast<const f32x4*>(a.norm + 8); }
     int pf_ho0 = 0;
     // fetch only ISSUES the loads (out-of-image pixels load the tensor's first bytes): the zeros go in at stage()
     auto fetch = [&](int item) {
@@ -101,7 +104,14 @@ __global__ void __launch_bounds__(SWG_NT) stem_wgrad_strip_kernel(const StemWgAr
             const int r = u / a.PW, c = u - r * a.PW;
             const int hin = 2 * pf_ho0 - 3 + r, win = c - 3;
             const bool ok = ((unsigned)hin < (unsigned)a.H) & ((unsigned)win < (unsigned)a.W);
-            const f32x4 v = ok ? xr[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                v = xr[j];
+                if (a.norm) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = __builtin_fmaf(v[q], nb[q], na[q]);
+                }
+            }
             unsigned a1, a2, a3, b1, b2, b3;
             bf3_split2(v[0], v[1], a1, a2, a3);
             bf3_split2(v[2], v[3], b1, b2, b3);
@@ -200,12 +210,12 @@ inline bool stem_wgrad_strip_covers(int H, int W, int C, int Cout, int KH, int K
 
 // 1: geometry not covered (or the scratch is too small).  ws: >= 256 * 7 * 1024 floats.
 inline int stem_wgrad_strip(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats,
-                            hipStream_t stream) {
-    if (!x || !dy || !dw_oihw || B <= 0 || creal < 1 || creal > 4) return HAB_ERR_ARG;
+                            hipStream_t stream, const float* norm = nullptr) {
+    if (!x || !dy || !dw_oihw || B <= 0 || creal < 1 || creal > 4 || (reinterpret_cast<uintptr_t>(norm) & 15)) return HAB_ERR_ARG;
     if (!stem_wgrad_strip_covers(H, W, 4, 32, 7, 7, 2, 3) || !ws) return 1;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(ws)) & 15) return 1;
     StemWgArgs a;
-    a.x = x; a.dy = dy; a.slabs = ws; a.B = B; a.H = H; a.W = W;
+    a.x = x; a.dy = dy; a.slabs = ws; a.B = B; a.H = H; a.W = W; a.norm = norm;
     a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1;
     a.PW = (2 * a.Wo + 6 + 1) & ~1;
     a.strips = (a.Ho + SWG_TH - 1) / SWG_TH;

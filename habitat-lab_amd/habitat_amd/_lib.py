@@ -89,8 +89,8 @@ SIGNATURES = {
     "hab_groupnorm_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, c_int64, vp]),
     "hab_split_weight_planes": (c_int, [vp, c_int, c_int, vp, vp]),
     "hab_stem_split_weights": (c_int, [vp, vp, vp]),
-    "hab_stem_conv_wgrad": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp, c_size_t, vp]),
-    "hab_stem_conv_fwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp]),
+    "hab_stem_conv_wgrad": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp, c_size_t, vp, vp]),
+    "hab_stem_conv_fwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, vp, vp, c_int, vp]),
     "hab_conv_gn_fwd": (c_int, [vp] * 9 + [c_int] * 11 + [c_float, vp]),
     "hab_maxpool3x3s2_fwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),
     "hab_maxpool3x3s2_bwd": (c_int, [vp, vp, vp, c_int, c_int, c_int, c_int, vp]),

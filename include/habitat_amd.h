@@ -265,15 +265,22 @@ int hab_split_weight_planes(const float* w_fwd, int Cout, int K, uint16_t* plane
  *   hab_stem_split_weights: forward-packed filter w_fwd [32][7][7][4] -> 3 x 14 x 512 uint16: its exact three-term bf16 split in MFMA
  *       fragment order (k-step 2 kh + j holds reduction slots 16 j .. 16 j + 15 of filter row kh = (kw, ci) pairs, kw = 7 zero-padded).
  *   hab_stem_conv_fwd: x NHWC [B][H][W][4] -> y [B][Ho][Wo][32], Ho = (H - 1) / 2 + 1; covered: Wo <= 64 (observations up to 256 wide);
- *       wider inputs return HAB_ERR_UNSUPPORTED (the caller runs hab_conv2d_fwd). */
+ *       wider inputs return HAB_ERR_UNSUPPORTED (the caller runs hab_conv2d_fwd).  norm: NULL, or 16 floats (16-byte aligned) of the
+ *       RunningMeanAndVar normalisation (running_mean_and_var.py:72-78) applied to x while it is staged -- x_hat[c] = fma(x[c], norm[c],
+ *       norm[8 + c]) with norm[c] = rsqrt(max(var[c], 1e-2)), norm[8 + c] = -mean[c] * norm[c] -- so that the training forward does not
+ *       write a normalised copy of the observation tensor (bit-identical to hab_running_mean_var_normalize followed by norm = NULL).
+ *       gn_part: NULL, or [B][ceil(Ho / 8)][gn_groups][2] floats: per frame, strip of 8 output rows and GroupNorm group (gn_groups in
+ *       {8, 16, 32}) the mean and the centred sum of squares M2 of the strip's outputs (exact local two-pass on the accumulators), which
+ *       the GroupNorm that follows (resnet.py:215) merges with Chan's formula instead of reading the output tensor for its statistics. */
 int hab_stem_split_weights(const float* w_fwd, uint16_t* planes, hipStream_t stream);
-int hab_stem_conv_fwd(const float* x, const uint16_t* w_planes, float* y, int B, int H, int W, hipStream_t stream);
+int hab_stem_conv_fwd(const float* x, const uint16_t* w_planes, float* y, int B, int H, int W, const float* norm, float* gn_part, int gn_groups,
+                      hipStream_t stream);
 /* Its weight gradient (csrc/stem_wgrad_strip.h; the autograd backward of resnet.py:207-219 `conv1` under rl/ppo/ppo.py:253): x NHWC
  * [B][H][W][4] (channels >= creal are padding), dy [B][Ho][Wo][32] -> dw_oihw [32][creal][7][7] (overwritten).  Both operands are
  * resident in LDS, fragments come from transpose reads; covered: Wo a multiple of 16, <= 64; ws >= 256 * 7168 floats of scratch;
- * otherwise HAB_ERR_UNSUPPORTED (the caller runs hab_conv2d_wgrad). */
+ * otherwise HAB_ERR_UNSUPPORTED (the caller runs hab_conv2d_wgrad).  norm: as for hab_stem_conv_fwd. */
 int hab_stem_conv_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int creal, float* ws, size_t ws_floats,
-                        hipStream_t stream);
+                        const float* norm, hipStream_t stream);
 int hab_conv_gn_fwd(const float* x, const uint16_t* w_planes, const float* gamma, const float* beta, const float* residual, float* y,
                     float* raw, float* mean, float* rstd, int B, int H, int W, int C, int Cout, int KH, int KW, int stride, int pad,
                     int groups, int relu, float eps, hipStream_t stream);

@@ -140,6 +140,26 @@ def test_conv_gn_fused_refuses_inputs_larger_than_lds(L):
     assert L.hab_conv_gn_fwd(P(x), P(pl), P(g), P(g), None, P(y), None, None, None, 2, 32, 32, 32, 64, 3, 3, 2, 1, 16, 1, 1e-5, S()) == -2
 
 
+def _rmv_affine(xd, creal=4):
+    """16 floats of the staging-time normalisation (include/habitat_amd.h: hab_stem_conv_fwd) for made-up statistics, and the tensor
+    normalised by hab_running_mean_var_normalize with the same statistics."""
+    L = _lib.lib()
+    mean = torch.tensor([0.4, -0.2, 0.1, 0.7], device="cuda")[:creal].contiguous()
+    var = torch.tensor([0.5, 2.0, 0.003, 1.3], device="cuda")[:creal].contiguous()  # (0.003: below the 1e-2 floor)
+    # the two coefficients as the DEVICE computes them (rsqrtf): normalising 1 with mean 0 gives the scale, normalising 0 the offset
+    one, zero = torch.zeros(1, 4, device="cuda"), torch.zeros(1, 4, device="cuda")
+    one[:, :creal] = 1.0
+    _lib.check(L.hab_running_mean_var_normalize(P(one), 1, 4, creal, P(torch.zeros_like(mean)), P(var), S()))
+    _lib.check(L.hab_running_mean_var_normalize(P(zero), 1, 4, creal, P(mean), P(var), S()))
+    norm = torch.zeros(16, device="cuda")
+    norm[:4] = one[0]
+    norm[8:12] = zero[0]
+    xn = xd.clone()
+    _lib.check(L.hab_running_mean_var_normalize(P(xn), xn.numel() // 4, 4, creal, P(mean), P(var), S()))
+    torch.cuda.synchronize()
+    return norm, xn
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 128, 128), (2, 64, 64), (5, 31, 42), (2, 21, 128), (1, 9, 7)])
 def test_stem_conv_strip_vs_float64(L, B, H, W):
     """csrc/stem_conv_strip.h (7x7 / 2 / 3, 4 -> 32, input strip in LDS) against float64 and against the im2col contraction."""
@@ -153,7 +173,7 @@ def test_stem_conv_strip_vs_float64(L, B, H, W):
     planes = torch.zeros(3 * 14 * 512, dtype=torch.int16, device="cuda")
     _lib.check(L.hab_stem_split_weights(P(wf), P(planes), S()))
     y = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
-    _lib.check(L.hab_stem_conv_fwd(P(xd), P(planes), P(y), B, H, W, S()))
+    _lib.check(L.hab_stem_conv_fwd(P(xd), P(planes), P(y), B, H, W, None, None, 0, S()))
     torch.cuda.synchronize()
     e1 = ((y.double().cpu() - ref).abs().max() / ref.abs().max()).item()
     ws = torch.zeros(1 << 22, device="cuda")
@@ -162,7 +182,27 @@ def test_stem_conv_strip_vs_float64(L, B, H, W):
     e0 = ((y2.double().cpu() - ref).abs().max() / ref.abs().max()).item()
     assert e1 <= 2 * e0 + 2e-7 and e1 < 3e-6, (e0, e1)
     y3 = torch.zeros_like(y)
-    _lib.check(L.hab_stem_conv_fwd(P(xd), P(planes), P(y3), B, H, W, S()))
+    _lib.check(L.hab_stem_conv_fwd(P(xd), P(planes), P(y3), B, H, W, None, None, 0, S()))
+    assert torch.equal(y, y3)
+    # GroupNorm partial statistics of the strips of 8 output rows, written with the output
+    for groups in (8, 16, 32):
+        nstrips = (Ho + 7) // 8
+        part = torch.full((B, nstrips, groups, 2), float("nan"), device="cuda")
+        _lib.check(L.hab_stem_conv_fwd(P(xd), P(planes), P(y3), B, H, W, None, P(part), groups, S()))
+        torch.cuda.synchronize()
+        assert torch.equal(y, y3)
+        yd = y.double().cpu()
+        for k in range(nstrips):
+            blk = yd[:, 8 * k:8 * k + 8].reshape(B, -1, groups, 32 // groups)
+            mean = blk.mean(dim=(1, 3))
+            m2 = ((blk - mean[:, None, :, None]) ** 2).sum(dim=(1, 3))
+            pk = part[:, k].double().cpu()
+            assert (pk[..., 0] - mean).abs().max() <= 1e-6 * blk.abs().max(), (groups, k)
+            assert ((pk[..., 1] - m2).abs() <= 1e-5 * m2 + 1e-9).all(), (groups, k)
+    # RunningMeanAndVar applied while staging == the normalised tensor through the plain kernel, bit for bit
+    norm, xn = _rmv_affine(xd)
+    _lib.check(L.hab_stem_conv_fwd(P(xn), P(planes), P(y), B, H, W, None, None, 0, S()))
+    _lib.check(L.hab_stem_conv_fwd(P(xd), P(planes), P(y3), B, H, W, P(norm), None, 0, S()))
     assert torch.equal(y, y3)
 
 
@@ -170,7 +210,7 @@ def test_stem_conv_strip_refuses_wide_inputs(L):
     x = torch.zeros(1, 8, 300, 4, device="cuda")
     planes = torch.zeros(3 * 14 * 512, dtype=torch.int16, device="cuda")
     y = torch.zeros(1, 4, 150, 32, device="cuda")
-    assert L.hab_stem_conv_fwd(P(x), P(planes), P(y), 1, 8, 300, S()) == -2
+    assert L.hab_stem_conv_fwd(P(x), P(planes), P(y), 1, 8, 300, None, None, 0, S()) == -2
 
 
 @pytest.mark.parametrize("B,H,W,creal", [(3, 128, 128, 4), (300, 32, 32, 4), (2, 63, 64, 1), (5, 30, 96, 3)])
@@ -190,7 +230,7 @@ def test_stem_wgrad_strip_vs_float64(L, B, H, W, creal):
     dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
     ws = torch.zeros(1 << 22, device="cuda")
     dw = torch.full((32, creal, 7, 7), float("nan"), device="cuda")
-    _lib.check(L.hab_stem_conv_wgrad(P(xd), P(dyd), P(dw), B, H, W, creal, P(ws), ws.numel(), S()))
+    _lib.check(L.hab_stem_conv_wgrad(P(xd), P(dyd), P(dw), B, H, W, creal, P(ws), ws.numel(), None, S()))
     torch.cuda.synchronize()
     e1 = ((dw.double().cpu() - ref).abs().max() / ref.abs().max()).item()
     dw2 = torch.zeros(32, 4, 7, 7, device="cuda")
@@ -198,7 +238,11 @@ def test_stem_wgrad_strip_vs_float64(L, B, H, W, creal):
     e0 = ((dw2[:, :creal].double().cpu() - ref).abs().max() / ref.abs().max()).item()
     assert e1 <= 2 * e0 + 2e-7 and e1 < 3e-6, (e0, e1)
     dw3 = torch.zeros_like(dw)
-    _lib.check(L.hab_stem_conv_wgrad(P(xd), P(dyd), P(dw3), B, H, W, creal, P(ws), ws.numel(), S()))
+    _lib.check(L.hab_stem_conv_wgrad(P(xd), P(dyd), P(dw3), B, H, W, creal, P(ws), ws.numel(), None, S()))
+    assert torch.equal(dw, dw3)
+    norm, xn = _rmv_affine(xd, creal)
+    _lib.check(L.hab_stem_conv_wgrad(P(xn), P(dyd), P(dw), B, H, W, creal, P(ws), ws.numel(), None, S()))
+    _lib.check(L.hab_stem_conv_wgrad(P(xd), P(dyd), P(dw3), B, H, W, creal, P(ws), ws.numel(), P(norm), S()))
     assert torch.equal(dw, dw3)
 
 
@@ -207,4 +251,4 @@ def test_stem_wgrad_strip_refuses_uncovered_widths(L):
     dy = torch.zeros(1, 21, 21, 32, device="cuda")
     dw = torch.zeros(32, 4, 7, 7, device="cuda")
     ws = torch.zeros(1 << 21, device="cuda")
-    assert L.hab_stem_conv_wgrad(P(x), P(dy), P(dw), 1, 42, 42, 4, P(ws), ws.numel(), S()) == -2  # Wo = 21: not a multiple of 16
+    assert L.hab_stem_conv_wgrad(P(x), P(dy), P(dw), 1, 42, 42, 4, P(ws), ws.numel(), None, S()) == -2  # Wo = 21: not a multiple of 16

@@ -79,11 +79,16 @@ def test_time_major_chunked_recurrence_vs_the_packed_form(workload):
     choose other split-K plans / sign-schedule phases (fp32 summation order): same rollout (bit-identical actions -- the rollout does
     not use the form), losses within 1e-5 (c3: 1e-4, a 20-layer GroupNorm encoder behind them), and bitwise reproducible for a given
     chunk count (the default is part of test_update_cycles_are_bitwise_reproducible)."""
-    packed = _digest_in_subprocess(workload, 1, {"HAB_RNN_CHUNKS": "0"})
+    # (c3's two LSTM layers run the packed form as a layer WAVEFRONT by default -- the upper layer's input projection then happens inside
+    #  its step kernel, another summation order; the operand-for-operand statement is about the layer-by-layer form: HAB_RNN_WAVE=0)
+    packed = _digest_in_subprocess(workload, 1, {"HAB_RNN_CHUNKS": "0", "HAB_RNN_WAVE": "0"})
     assert _digest_in_subprocess(workload, 1, {"HAB_RNN_CHUNKS": "1"}) == packed
     tol = 1e-5 if workload == "c2" else 1e-4
-    for chunks in (("4", "7") if workload == "c2" else ("4",)):
-        env = {"HAB_RNN_CHUNKS": chunks, "HAB_RNN_CHUNKS_RESNET": chunks}  # (the ResNet policies default to the packed form: measured faster)
+    variants = [{"HAB_RNN_CHUNKS": c, "HAB_RNN_CHUNKS_RESNET": c} for c in (("4", "7") if workload == "c2" else ("4",))]
+    if workload == "c3":
+        variants.append({"HAB_RNN_CHUNKS": "0"})  # the default: packed, layer wavefront
+    for env in variants:  # (the ResNet policies default to the packed form: measured faster)
+        chunks = env["HAB_RNN_CHUNKS"]
         d = _digest_in_subprocess(workload, 1, env)
         assert d["actions"] == packed["actions"]
         for k, v in d["losses"][0].items():

@@ -48,17 +48,20 @@ def test_trace_phases_splits_rollout_and_learner(tmp_path):
     con.execute("create table kernels (name text, start integer, end integer)")
     t = 0
     rows = []
-    for step in range(3):  # three rollout steps: conv, rnn, heads
-        for nm, d in (("void hab::igemm_bf3_kernel<ConvFwdProb>", 20000), ("void hab::rnn_step_kernel<3, 8>", 6000), ("hab::heads_fwd_kernel(HeadsArgs)", 10000)):
+    for step in range(3):  # three rollout steps: environments stepped, conv, rnn, heads
+        for nm, d in (("hab::synth_images_kernel(unsigned char*)", 7000), ("void hab::igemm_bf3_kernel<ConvFwdProb>", 20000),
+                      ("void hab::rnn_step_kernel<3, 8>", 6000), ("hab::heads_fwd_kernel(HeadsArgs)", 10000)):
             rows.append((nm, t, t + d)); t += d + 1000
-    for nm, d in (("hab::ppo_loss_kernel(LossArgs)", 5000), ("void hab::igemm_bf3_kernel<ConvWgradProb>", 900000), ("hab::heads_fwd_kernel(HeadsArgs)", 10000)):
+    # learner: [GAE + first minibatch forward] (no environment kernels, no loss yet), then [loss + backward + next forward]
+    for nm, d in (("hab::gae_kernel(GaeArgs)", 5000), ("void hab::igemm_bf3_kernel<ConvFwdProb>", 700000), ("hab::heads_fwd_kernel(HeadsArgs)", 10000),
+                  ("hab::ppo_loss_kernel(LossArgs)", 5000), ("void hab::igemm_bf3_kernel<ConvWgradProb>", 900000), ("hab::heads_fwd_kernel(HeadsArgs)", 10000)):
         rows.append((nm, t, t + d)); t += d + 1000
     con.executemany("insert into kernels values (?, ?, ?)", rows)
     con.commit(); con.close()
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_phases.py"), str(db)], capture_output=True, text=True, check=True).stdout
-    assert "3 rollout steps, 1 windows containing learner work" in out
+    assert "3 rollout steps, 2 windows containing learner work" in out
     assert "rollout run of 3 steps" in out and "learner window" in out
-    assert "launches/window median 3" in out
+    assert "launches/window median 4" in out
 
 
 def test_pmc_sq_table(tmp_path):
