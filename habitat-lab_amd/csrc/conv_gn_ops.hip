@@ -1,5 +1,6 @@
 // conv_gn_ops.hip -- launchers / C ABI of the fused convolution + GroupNorm kernel of the small-batch ResNet passes (conv_gn_slab.h).
 #include "conv_gn_slab.h"
+#include "conv1x1_gn_stream.h"
 #include "stem_conv_strip.h"
 #include "stem_wgrad_strip.h"
 #include "resnet_ops.h"
@@ -8,7 +9,8 @@
 namespace hab {
 
 int conv_gn_fused_ok(int C, int Cout, int H, int W, int KH, int KW, int stride, int pad, int groups) {
-    return conv_gn_slab_covers(C, Cout, H, W, KH, KW, stride, pad, groups);
+    return conv_gn_slab_covers(C, Cout, H, W, KH, KW, stride, pad, groups) ||
+           conv1x1_gn_stream_covers(C, Cout, H, W, KH, KW, stride, pad, groups);
 }
 
 int weight_planes(const float* w, int Cout, int K, unsigned short* planes, hipStream_t s) { return cgs_split_weights(w, Cout, K, planes, s); }
@@ -19,7 +21,15 @@ int conv_gn_fused(const ConvGnArgs& q, hipStream_t s) {
     a.raw = q.raw; a.mean = q.mean; a.rstd = q.rstd;
     a.B = q.B; a.H = q.H; a.W = q.W; a.C = q.C; a.Cout = q.Cout; a.KH = q.KH; a.KW = q.KW; a.stride = q.stride; a.pad = q.pad;
     a.groups = q.groups; a.relu = q.relu; a.eps = q.eps;
-    return conv_gn_slab(a, s);
+    const int rc = conv_gn_slab(a, s);
+    static const int stream_cfg = hab_env_int("HAB_CGS_STREAM", 1);
+    if (rc != 1 || q.KH != 1 || q.KW != 1 || q.pad != 0 || !stream_cfg) return rc;
+    // 1x1 convolutions whose frames do not fit LDS (the bottleneck net's 32 x 32-pixel layers): activations streamed from memory
+    C1gArgs b{};
+    b.x = q.x; b.wq = q.w_planes; b.gamma = q.gamma; b.beta = q.beta; b.residual = q.residual; b.y = q.y;
+    b.raw = q.raw; b.mean = q.mean; b.rstd = q.rstd;
+    b.B = q.B; b.H = q.H; b.W = q.W; b.C = q.C; b.Cout = q.Cout; b.stride = q.stride; b.groups = q.groups; b.relu = q.relu; b.eps = q.eps;
+    return conv1x1_gn_stream(b, s);
 }
 
 int stem_conv_ok(int H, int W, int C, int Cout, int KH, int KW, int stride, int pad) { return stem_conv_strip_covers(H, W, C, Cout, KH, KW, stride, pad); }

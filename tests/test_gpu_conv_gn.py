@@ -1,4 +1,4 @@
-"""Fused convolution + GroupNorm (+ residual, + ReLU) of the small-batch ResNet passes (csrc/conv_gn_slab.h) against a float64
+"""Fused convolution + GroupNorm (+ residual, + ReLU) of the small-batch ResNet passes (csrc/conv_gn_slab.h, conv1x1_gn_stream.h) against a float64
 evaluation of the reference's op chain (nn.Conv2d(bias=False) -> nn.GroupNorm -> + identity -> ReLU; rl/ddppo/policy/resnet.py:51-69)
 and against the unfused kernels of this library."""
 import ctypes as C
@@ -47,6 +47,17 @@ CASES = [
     (3, 15, 8, 64, 64, 3, 1, 1, 16),      # 120 pixels per frame (128-row tile, 8 idle rows)
     (10, 5, 3, 48, 96, 3, 1, 1, 12),      # 15 pixels, 2 frames per tile, C not a power of two, groups of 8
     (4, 2, 2, 256, 256, 3, 1, 1, 16),     # 4 pixels per frame: 8 frames per tile
+    # 1x1 convolutions whose frames do not fit LDS -> csrc/conv1x1_gn_stream.h (activations streamed, whole frame in the accumulators)
+    (5, 32, 32, 32, 32, 1, 1, 0, 16),     # ResNet50 layer1.0 conv1: 1024 pixels, groups of 2
+    (3, 32, 32, 32, 128, 1, 1, 0, 16),    # layer1 expansion / downsample: groups of 8, 4 channel slabs per frame
+    (3, 16, 32, 128, 32, 1, 1, 0, 16),    # K = 128, 512 pixels (the 1024-pixel form of layer1.1 conv1 stays on the unfused pair)
+    (2, 32, 16, 128, 64, 1, 1, 0, 16),    # groups of 4
+    (3, 32, 32, 128, 256, 1, 2, 0, 16),   # layer2.0 downsample: stride 2, 256 output pixels, groups of 16
+    (2, 30, 30, 64, 64, 1, 1, 0, 2),      # 900 pixels (idle lanes in the last tile), groups of 32
+    (2, 10, 25, 256, 96, 1, 1, 0, 24),    # 250 pixels, two channel chunks
+    (2, 20, 25, 128, 96, 1, 1, 0, 24),    # 500 pixels: two tiles per wave
+    (3, 16, 16, 256, 64, 1, 1, 0, 16),    # ResNet50 layer2.1 conv1: 256 pixels x 256 channels (one tile per wave, all channels in one batch)
+    (2, 15, 15, 256, 512, 1, 2, 0, 16),   # layer3.0 downsample form on odd geometry: stride 2, 64 output pixels of a 225-pixel frame
 ]
 
 
@@ -117,6 +128,16 @@ def test_conv_gn_fused_vs_float64(L, case, with_res, relu, save):
     _lib.check(L.hab_conv_gn_fwd(P(xd), P(planes), P(g), P(b), P(resd), P(y3), None, None, None, B, H, W, Cc, Cout, K, K, s, p, groups,
                                  relu, 1e-5, S()))
     assert torch.equal(y, y3)
+
+
+def test_conv_gn_fused_leaves_large_1x1_frames_to_the_unfused_pair(L):
+    # layer1.1 conv1 of ResNet50 (1x1, 128 -> 32 at 32 x 32): one workgroup would stream 512 KB -- slower than the contraction spread
+    # over the chip + GroupNorm (tools/bench_conv_gn.py); refused, the engine runs the unfused pair
+    x = torch.zeros(2, 32, 32, 128, device="cuda")
+    pl = torch.zeros(3 * 32 * 128, dtype=torch.int16, device="cuda")
+    g = torch.ones(32, device="cuda")
+    y = torch.zeros(2, 32, 32, 32, device="cuda")
+    assert L.hab_conv_gn_fwd(P(x), P(pl), P(g), P(g), None, P(y), None, None, None, 2, 32, 32, 128, 32, 1, 1, 1, 0, 16, 1, 1e-5, S()) == -2
 
 
 def test_conv_gn_fused_refuses_uncovered_geometries(L):
