@@ -1,4 +1,5 @@
-// conv2_dgrad_strip.h -- data gradient of SimpleCNN's second convolution (4x4 / stride 2, 32 -> 64 channels, 63 x 63 <- 30 x 30) with the
+// conv2_dgrad_strip.h -- data gradient of SimpleCNN's second convolution (4x4 / stride 2, 32 -> 64 channels; 63 x 63 <- 30 x 30 at 256^2
+// observations, any input up to 63 x 63 through the runtime-geometry instantiation) with the
 // dY STRIP resident in LDS and the FILTER slices resident in registers: the scheme of conv2_fwd_strip.h applied to the merged-stride-class
 // form of the data gradient (problems.h ConvDgradMergedProb).
 //
@@ -28,6 +29,7 @@ struct C2dArgs {
     int B;
     int strips, items;
     int sign_schedule;
+    int H, W, Ho, Wo;   // runtime-geometry instantiation (RT): dX is H x W (<= 63 x 63), dY is Ho x Wo
 };
 
 template <int R2>
@@ -42,10 +44,14 @@ struct C2dCfg {
     static_assert(CELLS % R2 == 0, "");
 };
 
-template <int R2>
+// RT = false: the benchmark geometry, every index a compile-time constant; RT = true: H, W, Ho, Wo from the arguments (W <= 63: one
+// 32-cell tile per cell row, the LDS image keeps its 33 pixel columns -- the columns beyond Wo stay zero).
+template <int R2, bool RT>
 __global__ void __launch_bounds__(512) conv2_dgrad_strip_kernel(const C2dArgs a) {
     using Cfg = C2dCfg<R2>;
-    constexpr int NT = Cfg::NT, Wo = Cfg::Wo, H = Cfg::H;
+    constexpr int NT = Cfg::NT;
+    const int H = RT ? a.H : Cfg::H, W = RT ? a.W : Cfg::H, Ho = RT ? a.Ho : Cfg::Ho, Wo = RT ? a.Wo : Cfg::Wo;
+    const int YU = Cfg::YRS * Wo * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     unsigned short* ys = smem16;                                                             // [plane][YPIX][64], swizzled
     float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(smem16) + Cfg::Y_BYTES);    // [8][32][RED_LD]
@@ -94,8 +100,8 @@ __global__ void __launch_bounds__(512) conv2_dgrad_strip_kernel(const C2dArgs a)
         for (int j = 0; j < Cfg::YPT; ++j) {
             const int u = t + j * NT;
             const int r = u / (Wo * 16), row = h20 - 1 + r;
-            const bool ok = (Cfg::YU % NT == 0 || u < Cfg::YU) && (unsigned)row < (unsigned)Cfg::Ho;
-            const size_t off = ok ? ((size_t)img * Cfg::Ho + row) * (size_t)(Wo * 64) + (size_t)(u - r * (Wo * 16)) * 4 : 0;
+            const bool ok = (RT ? u < YU : (Cfg::YU % NT == 0 || u < Cfg::YU)) && (unsigned)row < (unsigned)Ho;
+            const size_t off = ok ? ((size_t)img * Ho + row) * (size_t)(Wo * 64) + (size_t)(u - r * (Wo * 16)) * 4 : 0;
             yr[j] = *reinterpret_cast<const f32x4*>(a.dy + off);
         }
     };
@@ -103,11 +109,11 @@ __global__ void __launch_bounds__(512) conv2_dgrad_strip_kernel(const C2dArgs a)
 #pragma unroll
         for (int j = 0; j < Cfg::YPT; ++j) {
             const int u = t + j * NT;
-            if (Cfg::YU % NT != 0 && u >= Cfg::YU) continue;
+            if (RT ? u >= YU : (Cfg::YU % NT != 0 && u >= Cfg::YU)) continue;
             const int r = u / (Wo * 16), rem = u - r * (Wo * 16), w = rem >> 4, c4 = rem & 15;
             const int pixidx = r * Cfg::YCOLS + w + 1;
             unsigned short* dst = ys + pixidx * 64 + (((c4 >> 1) ^ ((pixidx >> 1) & 7)) << 3) + (c4 & 1) * 4;
-            const bool in_image = (unsigned)(pf_h20 - 1 + r) < (unsigned)Cfg::Ho;
+            const bool in_image = (unsigned)(pf_h20 - 1 + r) < (unsigned)Ho;
             bf3_store4(in_image ? yr[j] : f32x4{0.f, 0.f, 0.f, 0.f}, dst, dst + Cfg::Y_PLANE, dst + 2 * Cfg::Y_PLANE);
         }
     };
@@ -162,8 +168,8 @@ __global__ void __launch_bounds__(512) conv2_dgrad_strip_kernel(const C2dArgs a)
                     s += *reinterpret_cast<const f32x4*>(red + (size_t)((2 * t4 + rph) * 32 + cell) * Cfg::RED_LD + cq * 4);
                 if (flip) s = -s;
                 const int h = 2 * h2 + rph, w = 2 * cell + (cq >> 3);
-                if (h < H && w < H) {
-                    const size_t off = (((size_t)img * H + h) * H + w) * 32 + (cq & 7) * 4;
+                if (h < H && w < W) {
+                    const size_t off = (((size_t)img * H + h) * W + w) * 32 + (cq & 7) * 4;
                     if (a.mask) {
                         const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + off);
 #pragma unroll
@@ -177,27 +183,39 @@ __global__ void __launch_bounds__(512) conv2_dgrad_strip_kernel(const C2dArgs a)
     }
 }
 
+inline bool conv2_dgrad_strip_covers(const ConvDesc& d) {
+    return d.KH == 4 && d.KW == 4 && d.stride == 2 && d.pad == 0 && d.C == 32 && d.Cout == 64 && d.H >= 4 && d.W >= 4 && d.H <= 63 && d.W <= 63;
+}
+
 // 1: shape not covered.
 inline int conv2_dgrad_strip(const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add, float* dx,
                              hipStream_t stream) {
-    if (!(d.KH == 4 && d.KW == 4 && d.stride == 2 && d.pad == 0 && d.C == 32 && d.Cout == 64 && d.H == 63 && d.W == 63)) return 1;
+    if (!conv2_dgrad_strip_covers(d)) return 1;
     if (add || d.B < 16 || !dy || !wd || !dx) return 1;
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wd) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(mask)) & 15) return 1;
     constexpr int R2 = 2;
     using Cfg = C2dCfg<R2>;
     C2dArgs a;
     a.dy = dy; a.wd = wd; a.mask = mask; a.dx = dx; a.B = d.B;
-    a.strips = Cfg::CELLS / R2;
+    a.H = d.H; a.W = d.W; a.Ho = (d.H - 4) / 2 + 1; a.Wo = (d.W - 4) / 2 + 1;
+    a.strips = ((d.H + 1) / 2 + R2 - 1) / R2;  // cell rows = ceil(H / 2)
+    if ((long long)d.B * a.strips > 0x7fffffffLL) return 1;
     a.items = d.B * a.strips;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");
     a.sign_schedule = sign_schedule;
-    auto kern = conv2_dgrad_strip_kernel<R2>;
     // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    static const hipError_t attr_err = [] {
+        const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_strip_kernel<R2, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_strip_kernel<R2, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        return e0 != hipSuccess ? e0 : e1;
+    }();
     if (attr_err != hipSuccess) return (int)attr_err;
     int grid = 256;
     while (grid > 8 && grid > a.items) grid -= 8;
-    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(a);
+    if (d.H == 63 && d.W == 63) conv2_dgrad_strip_kernel<R2, false><<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(a);
+    else conv2_dgrad_strip_kernel<R2, true><<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(a);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }

@@ -1,5 +1,6 @@
-// conv2_fwd_strip.h -- forward of SimpleCNN's second convolution (4x4 / stride 2, 32 -> 64 channels, 63 x 63 -> 30 x 30; simple_cnn.py:70-83)
-// with the INPUT STRIP resident in LDS and the WEIGHTS resident in registers.
+// conv2_fwd_strip.h -- forward of SimpleCNN's second convolution (4x4 / stride 2, 32 -> 64 channels; simple_cnn.py:70-83: 63 x 63 -> 30 x 30
+// at 256 x 256 observations, any input up to 63 pixels wide -- 20 x 20 at 84^2, 31 x 31 at 128^2, 55 x 55 at 224^2 -- through the
+// runtime-geometry instantiation) with the INPUT STRIP resident in LDS and the WEIGHTS resident in registers.
 //
 // Why: the implicit-GEMM form (igemm_bf3.h, 128 x 64 tiles) re-reads every input element 4x (16 taps / stride^2) and the whole 128 KB
 // filter once per 128 output pixels through L2 -- 5.5 GB of L2 -> LDS traffic per 2048 frames, the bound of that kernel (DESIGN.md 5c:
@@ -30,6 +31,7 @@ struct C2fArgs {
     int B;
     int strips, items;
     int relu, sign_schedule;
+    int H, W, Ho, Wo;   // runtime-geometry instantiation (RT): input H x W (W <= 63), output Ho x Wo
 };
 
 template <int R>
@@ -46,13 +48,19 @@ struct C2fCfg {
     __host__ __device__ static constexpr int xcol(int w) { return (w & 1) * WH + (w >> 1); }
 };
 
-template <int R>
+// RT = false: the benchmark geometry (63 x 63 -> 30 x 30), every index a compile-time constant.  RT = true: H, W, Ho, Wo from the
+// arguments (W <= 63: the register prefetch and the LDS image are sized for 63); the last strip may hold one output row, input rows
+// below the image are staged as zeros and never fetched.
+template <int R, bool RT>
 __global__ void __launch_bounds__(512) conv2_fwd_strip_kernel(const C2fArgs a) {
     using Cfg = C2fCfg<R>;
-    constexpr int W = Cfg::W, Wo = Cfg::Wo, NT = Cfg::NT;
+    constexpr int NT = Cfg::NT;
+    const int W = RT ? a.W : Cfg::W, H = RT ? a.H : Cfg::W, Wo = RT ? a.Wo : Cfg::Wo, Ho = RT ? a.Ho : Cfg::Ho;
+    const int WH = (W + 1) / 2, X_PLANE = Cfg::XRS * W * 32, XU = Cfg::XRS * W * 8, NPIX = R * Wo, NPT = (NPIX + 31) / 32;
+    auto xcol = [&](int w) { return (w & 1) * WH + (w >> 1); };
     extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
     unsigned short* xs = smem16;                                                        // [plane][XROWS][32], swizzled
-    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(smem16) + Cfg::X_BYTES);  // [8][32][RED_LD]
+    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(smem16) + (size_t)3 * X_PLANE * 2);  // [8][32][RED_LD]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int kh = wave >> 1, kwp = wave & 1;
@@ -87,24 +95,27 @@ __global__ void __launch_bounds__(512) conv2_fwd_strip_kernel(const C2fArgs a) {
         }
 
     f32x4 xr[Cfg::XPT];
+    int pf_units = XU;  // RT: units of the prefetched strip that lie inside the image (whole input rows)
     auto fetch = [&](int item) {  // issues the loads only (see wgrad3x3_bf3.h)
         const int img = item / a.strips, ho0 = (item - img * a.strips) * R;
-        const float* xb = a.x + ((size_t)img * W + ho0 * 2) * (size_t)(W * 32);
+        const float* xb = a.x + ((size_t)img * H + ho0 * 2) * (size_t)(W * 32);
+        if (RT) pf_units = min(Cfg::XRS, H - 2 * ho0) * W * 8;
 #pragma unroll
         for (int j = 0; j < Cfg::XPT; ++j) {
             const int u = t + j * NT;
-            xr[j] = *reinterpret_cast<const f32x4*>(xb + ((Cfg::XU % NT == 0 || u < Cfg::XU) ? (size_t)u * 4 : 0));
+            const bool in = RT ? u < pf_units : (Cfg::XU % NT == 0 || u < Cfg::XU);
+            xr[j] = *reinterpret_cast<const f32x4*>(xb + (in ? (size_t)u * 4 : 0));
         }
     };
     auto stage = [&]() {
 #pragma unroll
         for (int j = 0; j < Cfg::XPT; ++j) {
             const int u = t + j * NT;
-            if (Cfg::XU % NT != 0 && u >= Cfg::XU) continue;
+            if (RT ? u >= XU : (Cfg::XU % NT != 0 && u >= Cfg::XU)) continue;
             const int c4 = u & 7, pix = u >> 3, w = pix % W, hh = pix / W;
-            const int row = hh * W + Cfg::xcol(w);
+            const int row = hh * W + xcol(w);
             unsigned short* dst = xs + row * 32 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 3) + (c4 & 1) * 4;
-            bf3_store4(xr[j], dst, dst + Cfg::X_PLANE, dst + 2 * Cfg::X_PLANE);
+            bf3_store4((!RT || u < pf_units) ? xr[j] : f32x4{0.f, 0.f, 0.f, 0.f}, dst, dst + X_PLANE, dst + 2 * X_PLANE);
         }
     };
 
@@ -119,12 +130,13 @@ __global__ void __launch_bounds__(512) conv2_fwd_strip_kernel(const C2fArgs a) {
         __syncthreads();
         if (item + 1 < last) fetch(item + 1);
         const int img = item / a.strips, ho0 = (item - img * a.strips) * R;
-        float* yb = a.y + ((size_t)img * Cfg::Ho + ho0) * (size_t)(Wo * 64);
+        float* yb = a.y + ((size_t)img * Ho + ho0) * (size_t)(Wo * 64);
+        const int npix_here = RT ? min(R, Ho - ho0) * Wo : NPIX;  // (RT: the last strip of an odd Ho holds one row)
 #pragma unroll 1
-        for (int pt = 0; pt < Cfg::NPT; ++pt) {
+        for (int pt = 0; pt < NPT; ++pt) {
             // ---- this wave's share of the tile: pixels pt*32 .. +31, its two taps ----
             const int p = pt * 32 + li;
-            const int pc = (Cfg::NPIX % 32 == 0 || p < Cfg::NPIX) ? p : 0;
+            const int pc = (!RT && Cfg::NPIX % 32 == 0) || p < NPIX ? p : 0;
             const int hol = pc / Wo, wo = pc - hol * Wo;
             const int row0 = (hol * 2 + kh) * W + wo;  // + the tap's column class offset
             f32x16 acc[2];
@@ -135,12 +147,12 @@ __global__ void __launch_bounds__(512) conv2_fwd_strip_kernel(const C2fArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int kw = 2 * kwp + (j >> 1);
-                const int row = row0 + (kw & 1) * Cfg::WH + (kw >> 1);
+                const int row = row0 + (kw & 1) * WH + (kw >> 1);
                 const int chunk = (j & 1) * 2 + hi;
                 const unsigned short* src = xs + row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3);
                 bf16x8 af[3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(src + pl * Cfg::X_PLANE);
+                for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(src + pl * X_PLANE);
                 constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest weight first (A: input, B: filter)
 #pragma unroll
                 for (int q = 0; q < 6; ++q)
@@ -169,34 +181,47 @@ __global__ void __launch_bounds__(512) conv2_fwd_strip_kernel(const C2fArgs a) {
                 for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.f ? s[e] : 0.f;
             }
             const int op = pt * 32 + rpix;
-            if (Cfg::NPIX % 32 == 0 || op < Cfg::NPIX) *reinterpret_cast<f32x4*>(yb + (size_t)op * 64 + rco) = s;
+            if (RT ? op < npix_here : (Cfg::NPIX % 32 == 0 || op < Cfg::NPIX)) *reinterpret_cast<f32x4*>(yb + (size_t)op * 64 + rco) = s;
         }
         __syncthreads();  // every wave is done with this strip's image (and with `red`)
     }
 }
 
+inline bool conv2_fwd_strip_covers(const ConvGeom& g) {
+    return g.KH == 4 && g.KW == 4 && g.stride == 2 && g.pad == 0 && g.C == 32 && g.Cout == 64 && g.H >= 4 && g.W >= 4 && g.W <= 63;
+}
+
 // 1: shape not covered.
 inline int conv2_fwd_strip(const ConvFwdProb& p, float* /*ws*/, size_t /*ws_floats*/, hipStream_t stream) {
     const ConvGeom& g = p.g;
-    if (!(g.KH == 4 && g.KW == 4 && g.stride == 2 && g.pad == 0 && g.C == 32 && g.Cout == 64 && g.H == 63 && g.W == 63)) return 1;
+    if (!conv2_fwd_strip_covers(g)) return 1;
     if ((p.ldy != 0 && p.ldy != 64) || g.B < 16) return 1;
     if ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.w) | reinterpret_cast<uintptr_t>(p.y) | reinterpret_cast<uintptr_t>(p.bias)) & 15) return 1;
     constexpr int R = 2;
     using Cfg = C2fCfg<R>;
     C2fArgs a;
     a.x = p.x; a.wf = p.w; a.bias = p.bias; a.y = p.y; a.B = g.B;
-    a.strips = Cfg::Ho / R;
+    a.H = g.H; a.W = g.W; a.Ho = (g.H - 4) / 2 + 1; a.Wo = (g.W - 4) / 2 + 1;
+    a.strips = (a.Ho + R - 1) / R;
+    if ((long long)g.B * a.strips > 0x7fffffffLL) return 1;
     a.items = g.B * a.strips;
     a.relu = p.relu;
     static const int sign_schedule = !hab_env_flag("HAB_BF3_NOSIGN");
     a.sign_schedule = sign_schedule;
-    auto kern = conv2_fwd_strip_kernel<R>;
+    const bool bench_geom = g.H == 63 && g.W == 63;
     // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
-    static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    static const hipError_t attr_err = [] {
+        const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_fwd_strip_kernel<R, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_fwd_strip_kernel<R, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        return e0 != hipSuccess ? e0 : e1;
+    }();
     if (attr_err != hipSuccess) return (int)attr_err;
     int grid = 256;
     while (grid > 8 && grid > a.items) grid -= 8;
-    kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(a);
+    if (bench_geom) conv2_fwd_strip_kernel<R, false><<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(a);
+    else conv2_fwd_strip_kernel<R, true><<<grid, Cfg::NT, (size_t)3 * Cfg::XRS * g.W * 32 * 2 + Cfg::RED_BYTES, stream>>>(a);
     HAB_LAUNCH_CHECK();
     return HAB_OK;
 }

@@ -147,9 +147,10 @@ def test_weight_gradient_strip_maps(cfg):
 
 # ---- conv2_fwd_strip.h ------------------------------------------------------------------------------------------------------------
 def conv2_fwd_strip_model(x, wf, bias, relu, R=2, strips=None):
-    """x [B][63][63][32], wf [64][4][4][32] -> y [B][30][30][64] through the kernel's maps (strips: subset of strip indices)."""
-    Bn = x.shape[0]
-    W, Wo, Ho, WH = 63, 30, 30, 32
+    """x [B][H][W][32] (W <= 63), wf [64][4][4][32] -> y [B][Ho][Wo][64] through the kernel's maps (strips: subset of strip indices).
+    63 x 63 is the compile-time instantiation; other geometries run the same maps with H, W, Ho, Wo from the arguments."""
+    Bn, H, W = x.shape[0], x.shape[1], x.shape[2]
+    Wo, Ho, WH = (W - 4) // 2 + 1, (H - 4) // 2 + 1, (W + 1) // 2
     XRS = 2 * (R - 1) + 4
     XROWS, NPIX = XRS * W, R * Wo
     NPT = (NPIX + 31) // 32
@@ -157,15 +158,17 @@ def conv2_fwd_strip_model(x, wf, bias, relu, R=2, strips=None):
     xcol = lambda w: (w & 1) * WH + (w >> 1)
     y = np.full((Bn, Ho, Wo, 64), np.nan)
     for img in range(Bn):
-        for strip in (range(Ho // R) if strips is None else strips):
+        for strip in (range((Ho + R - 1) // R) if strips is None else strips):
             ho0 = strip * R
-            xs = np.zeros(XROWS * 32)
+            xs = np.full(XROWS * 32, np.nan)
+            in_units = min(XRS, H - 2 * ho0) * W * 8  # whole input rows inside the image; the rest is staged as zeros
             for u in range(XRS * W * 8):
                 c4, pix = u & 7, u >> 3
                 w, hh = pix % W, pix // W
                 row = hh * W + xcol(w)
                 dst = row * 32 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 3) + (c4 & 1) * 4
-                xs[dst: dst + 4] = x[img, ho0 * 2 + hh, w, 4 * c4: 4 * c4 + 4]
+                xs[dst: dst + 4] = x[img, ho0 * 2 + hh, w, 4 * c4: 4 * c4 + 4] if u < in_units else 0.0
+            npix_here = min(R, Ho - ho0) * Wo
             for pt in range(NPT):
                 red = np.zeros(8 * 32 * RED_LD)
                 for wave in range(8):
@@ -202,7 +205,7 @@ def conv2_fwd_strip_model(x, wf, bias, relu, R=2, strips=None):
                     if relu:
                         s = np.maximum(s, 0)
                     op = pt * 32 + rpix
-                    if op < NPIX:
+                    if op < npix_here:
                         y[img, ho0 + op // Wo, op % Wo, rco: rco + 4] = s
     return y
 
@@ -222,6 +225,25 @@ def test_conv2_forward_strip_maps():
     for s in strips:
         assert np.array_equal(y[0, 2 * s: 2 * s + 2], ref[2 * s: 2 * s + 2]), s
     assert np.isnan(y[0, 2]).all()  # strips that were not run stay untouched
+
+
+@pytest.mark.parametrize("H,W", [(20, 20), (31, 31), (21, 14), (4, 5)])
+def test_conv2_forward_strip_maps_at_runtime_geometries(H, W):
+    """The runtime-geometry instantiation (84^2 / 128^2 observations, non-square, the smallest input): odd Ho leaves a one-row last strip
+    whose second output row reads input rows below the image -- staged as zeros, never stored."""
+    rng = np.random.default_rng(H * 64 + W)
+    x = rng.integers(-3, 4, (1, H, W, 32)).astype(np.float64)
+    wf = rng.integers(-2, 3, (64, 4, 4, 32)).astype(np.float64)
+    Ho, Wo = (H - 4) // 2 + 1, (W - 4) // 2 + 1
+    strips = sorted({0, (Ho + 1) // 2 - 1})
+    y = conv2_fwd_strip_model(x, wf, None, relu=False, strips=strips)
+    ref = np.zeros((Ho, Wo, 64))
+    for kh in range(4):
+        for kw in range(4):
+            ref += np.einsum("hwc,nc->hwn", x[0, kh: kh + 2 * Ho - 1: 2, kw: kw + 2 * Wo - 1: 2], wf[:, kh, kw])
+    for s_ in strips:
+        rows = slice(2 * s_, min(2 * s_ + 2, Ho))
+        assert np.array_equal(y[0, rows], ref[rows]), s_
 
 
 def test_lds_read_patterns_are_conflict_free():
@@ -252,14 +274,16 @@ def test_lds_read_patterns_are_conflict_free():
 
 
 # ---- conv2_dgrad_strip.h ----------------------------------------------------------------------------------------------------------
-def conv2_dgrad_strip_model(dy, wd, mask, R2=2, strips=None):
-    """dy [B][30][30][64], wd [32 ci][4][4][64 co], mask [B][63][63][32] or None -> dx [B][63][63][32] through the kernel's maps."""
+def conv2_dgrad_strip_model(dy, wd, mask, R2=2, strips=None, H=63, W=63):
+    """dy [B][Ho][Wo][64], wd [32 ci][4][4][64 co], mask [B][H][W][32] or None -> dx [B][H][W][32] through the kernel's maps
+    (H, W <= 63; 63 x 63 is the compile-time instantiation)."""
     Bn = dy.shape[0]
-    H, Ho, Wo, YCOLS, RED_LD = 63, 30, 30, 33, 68
+    Ho, Wo, YCOLS, RED_LD = dy.shape[1], dy.shape[2], 33, 68
+    assert Ho == (H - 4) // 2 + 1 and Wo == (W - 4) // 2 + 1
     YRS = R2 + 1
-    dx = np.full((Bn, H, H, 32), np.nan)
+    dx = np.full((Bn, H, W, 32), np.nan)
     for img in range(Bn):
-        for strip in (range(32 // R2) if strips is None else strips):
+        for strip in (range(((H + 1) // 2 + R2 - 1) // R2) if strips is None else strips):
             h20 = strip * R2
             ys = np.zeros(YRS * YCOLS * 64)
             for u in range(YRS * Wo * 16):
@@ -302,7 +326,7 @@ def conv2_dgrad_strip_model(dy, wd, mask, R2=2, strips=None):
                         s = sum(red[((2 * t4 + rph) * 32 + cell) * RED_LD + cq * 4: ((2 * t4 + rph) * 32 + cell) * RED_LD + cq * 4 + 4]
                                 for t4 in range(4))
                         h, w = 2 * h2 + rph, 2 * cell + (cq >> 3)
-                        if h < H and w < H:
+                        if h < H and w < W:
                             c0 = (cq & 7) * 4
                             if mask is not None:
                                 s = np.where(mask[img, h, w, c0: c0 + 4] > 0, s, 0.0)
@@ -336,3 +360,18 @@ def test_conv2_data_gradient_strip_maps():
                 byte = pixidx * 128 + ((chunk ^ ((pixidx >> 1) & 7)) << 4)
                 banks += [((byte >> 2) + q) & 63 for q in range(4)]
             assert sorted(banks) == list(range(64)), (base, chunk)
+
+
+@pytest.mark.parametrize("H,W", [(20, 20), (31, 31), (21, 14), (4, 5)])
+def test_conv2_data_gradient_strip_maps_at_runtime_geometries(H, W):
+    rng = np.random.default_rng(H * 64 + W + 1)
+    Ho, Wo = (H - 4) // 2 + 1, (W - 4) // 2 + 1
+    dy = rng.integers(-3, 4, (1, Ho, Wo, 64)).astype(np.float64)
+    w = rng.integers(-2, 3, (64, 32, 4, 4)).astype(np.float64)
+    wd = np.ascontiguousarray(w.transpose(1, 2, 3, 0))
+    dx = conv2_dgrad_strip_model(dy, wd, None, H=H, W=W)
+    ref = np.zeros((H, W, 32))
+    for kh in range(4):
+        for kw in range(4):
+            ref[kh: kh + 2 * Ho - 1: 2, kw: kw + 2 * Wo - 1: 2] += np.einsum("hwn,nc->hwc", dy[0], w[:, :, kh, kw])
+    assert np.array_equal(dx[0], ref)
