@@ -23,6 +23,7 @@ Extra objects on the JSON line (rank 0; the sub-records only at N = 1, all measu
                 reference itself cannot travel to the GPU box; tests/golden pins the oracle to it), torch threads stated
   parity        the same rollout the CPU leg produced, pushed through the HIP path: relative error of the update's losses, of
                 the GAE returns, and of one full-size minibatch's values / log-probs
+  phases        rollout / update split of the timed cycles (HIP events around collect_rollout; also in the c3 sub-record)
   c3            BASELINE.json configs[2] (ResNet18 + 2-layer LSTM) cycles: env-steps/s, ms
   encoder_r18_b8192   the north-star kernel target: ResNet18 encoder alone on 2 x 4096 frames, forward / backward TFLOP/s and
                 fraction of the fp32 MFMA peak
@@ -327,11 +328,45 @@ def encoder_record(frames=4096, calls=2):
     return rec
 
 
+def time_rollouts(trainer):
+    """Brackets every collect_rollout of `trainer` with a HIP event pair on the stream the engine launches on (no synchronisation is
+    added); the returned function gives the mean GPU time of a rollout in ms once the stream has been synchronised."""
+    import torch
+    pairs = []
+    inner = trainer.collect_rollout
+
+    def timed():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = inner()
+        e1.record()
+        pairs.append((e0, e1))
+        return r
+
+    trainer.collect_rollout = timed
+
+    def mean_ms(last_n):
+        sel = pairs[-last_n:]
+        return sum(a.elapsed_time(b) for a, b in sel) / max(1, len(sel))
+
+    return mean_ms
+
+
+def phase_record(rollout_ms, cycle_ms, ppo):
+    upd = cycle_ms - rollout_ms
+    nmb = ppo.ppo_epoch * ppo.num_mini_batch
+    return {"rollout_ms": round(rollout_ms, 2), "update_ms": round(upd, 2), "minibatches": nmb, "update_ms_per_minibatch": round(upd / nmb, 2),
+            "rollout_share": round(rollout_ms / cycle_ms, 4),
+            "how": "HIP events around collect_rollout on the engine's stream (mean over the timed cycles); update = cycle - rollout "
+                   "(GAE, E x M minibatch passes, Adam, statistics)"}
+
+
 def run_cycles(workload, steps, warmup):
     """A second workload inside the same run (sub-record): (env-steps/s, ms per cycle)."""
     import torch
     trainer, cfg = make_trainer(workload, warmup + steps + 1)
     trainer._init_train()
+    rollout_ms = time_rollouts(trainer)
     for _ in range(warmup):
         trainer.run_update_cycle()
     torch.cuda.synchronize()
@@ -344,7 +379,7 @@ def run_cycles(workload, steps, warmup):
     n = trainer.num_steps_done - s0
     trainer.envs.close()
     rec = {"workload": WORKLOADS[workload]["name"], "value": round(n / dt, 1), "unit": "env-steps/s", "steps": steps, "warmup": warmup,
-           "ms_per_step": round(dt / steps * 1e3, 2),
+           "ms_per_step": round(dt / steps * 1e3, 2), "phases": phase_record(rollout_ms(steps), dt / steps * 1e3, cfg.habitat_baselines.rl.ppo),
            "frac_of_mfma_roofline": round(n / dt * 2.2632e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if workload == "c3" else None,
            "frac_of_split_ceiling": round(n / dt * 2.2632e9 / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12), 4) if workload == "c3" else None,
            "frac_basis": "executed contraction FLOPs (2.263 GFLOP per env-step: the stem's data gradient is not computed) / fp32 MFMA peak 157.3; "
@@ -479,6 +514,7 @@ def main():
             a.probe = crit[0]["site"]
     tag, flops_per_frame = PROBES[a.probe]
     eng.probe_enable(tag)
+    rollout_ms = time_rollouts(trainer)
     barrier()
     steps_before, local_before = trainer.num_steps_done, getattr(trainer, "local_steps_done", 0)
     t0 = time.perf_counter()
@@ -488,6 +524,7 @@ def main():
     dt = time.perf_counter() - t0
     probe_ms, probe_cnt = eng.probe_read()
     eng.probe_enable(-1)
+    phases = phase_record(rollout_ms(a.steps), dt / a.steps * 1e3, ppo)  # (this rank's; before the max over ranks)
     if dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -518,7 +555,7 @@ def main():
                   "env-steps/sec (SPS) ObjectNav RGB-D+semantic 256x256, 32 envs x 64 rollout",
         "value": round(steps_total / dt, 1), "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "phases": phases,
         # ranks that took part, read from the process group after init (1 without one): a launcher that silently started fewer
         # ranks than --gpus would show here
         "ranks_seen": torch.distributed.get_world_size() if dist else 1,
