@@ -145,13 +145,19 @@ class PPOTrainer(BaseRLTrainer):
         self._is_static_encoder = not hb.rl.ddppo.train_encoder
         self._encoder = self._agent.actor_critic.visual_encoder if self._is_static_encoder else None
         self._device_envs = hasattr(self.envs, "step_into_obs") and self.device.type == "cuda"
-        if self._device_envs and self.obs_transforms:
-            raise ValueError("obs_transforms are applied on the host-env path; the device env source emits the policy's sensor size")
         st = self._agent.rollouts
         N = self.envs.num_envs
+        # obs transforms on the device-env path (ppo_trainer.py:421 `apply_obs_transforms_batch` after every env step): the env source
+        # writes the sensors at their own size into a staging row, the transforms (device kernels, common/obs_transformers.py) write
+        # the rollout row
+        self._raw_obs = None
+        if self._device_envs and self.obs_transforms:
+            raw_space = self.envs.observation_spaces[0]
+            self._raw_obs = {k: torch.zeros((N,) + tuple(sp.shape), dtype=getattr(torch, np.dtype(sp.dtype).name), device=self.device)
+                             for k, sp in raw_space.spaces.items()}
         if self._device_envs:
             o0 = st.buffers["observations"]
-            self.envs.reset_into_obs({k: v[0] for k, v in o0.items() if k != VISUAL_FEATURES_KEY})
+            self._device_obs_into({k: v[0] for k, v in o0.items() if k != VISUAL_FEATURES_KEY}, self.envs.reset_into_obs)
             if self._is_static_encoder:
                 self._agent.actor_critic.encode_visual({k: v[0] for k, v in o0.items()}, out=o0[VISUAL_FEATURES_KEY][0])
             stat_dev = self.device
@@ -192,6 +198,17 @@ class PPOTrainer(BaseRLTrainer):
             q = torch.stack([torch.empty(N, A).exponential_(1) for _ in range(T)])
         return q.pin_memory().to(self.device, non_blocking=True)
 
+    def _device_obs_into(self, rows, emit):
+        """`emit(dict of (N, ...) device tensors)` writes the env source's observations; with obs transforms they go through a
+        sensor-sized staging row and the transforms write the (transformed-size) rollout rows."""
+        if self._raw_obs is None:
+            emit(rows)
+            return
+        emit(self._raw_obs)
+        out = apply_obs_transforms_batch(dict(self._raw_obs), self.obs_transforms)
+        for k, v in rows.items():
+            v.copy_(out[k])
+
     def _device_rollout_step(self, t: int, noise: torch.Tensor):
         st = self._agent.rollouts
         B = st.buffers
@@ -203,7 +220,8 @@ class PPOTrainer(BaseRLTrainer):
                    out=dict(values=B["value_preds"][t], actions=B["actions"][t], action_log_probs=B["action_log_probs"][t],
                             rnn_hidden_states=B["recurrent_hidden_states"][t + 1]))
         with g_timer.avg_time("trainer.step_env"):
-            self.envs.step_into_obs({k: v[t + 1] for k, v in obs.items() if k != VISUAL_FEATURES_KEY}, B["rewards"][t], B["masks"][t + 1])
+            self._device_obs_into({k: v[t + 1] for k, v in obs.items() if k != VISUAL_FEATURES_KEY},
+                                  lambda rows: self.envs.step_into_obs(rows, B["rewards"][t], B["masks"][t + 1]))
             if self._is_static_encoder:  # ppo_trainer.py:467-471
                 ac.encode_visual({k: v[t + 1] for k, v in obs.items()}, out=obs[VISUAL_FEATURES_KEY][t + 1])
         with g_timer.avg_time("trainer.update_stats"):

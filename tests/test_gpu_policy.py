@@ -863,6 +863,56 @@ def test_trainer_host_path_applies_obs_transforms():
 
 
 @pytest.mark.gpu
+def test_trainer_device_path_applies_obs_transforms():
+    """N4 on the device-env path: the env source writes 96x128 sensors into a staging row, ResizeShortestEdge(64) -> CenterCropper(64)
+    (device kernels) write the 64x64 rollout rows -- equal to the oracle's transform of what an identically seeded env source emits."""
+    from habitat_amd.config.default import get_config
+    from habitat_amd.common.baseline_registry import baseline_registry
+    from habitat_amd.common.env_factory import SyntheticVectorEnv
+    import habitat_amd.rl.ppo.ppo_trainer  # noqa: F401
+    N, T = 3, 3
+    pre = "habitat_baselines.rl.policy.main_agent.obs_transforms"
+    ov = [f"habitat_baselines.num_environments={N}", f"habitat_baselines.rl.ppo.num_steps={T}", "habitat_baselines.num_updates=2",
+          "habitat_baselines.total_num_steps=-1", "habitat_baselines.num_checkpoints=-1", "habitat_baselines.checkpoint_interval=1000000",
+          "habitat_baselines.rl.ppo.hidden_size=64", "habitat_baselines.checkpoint_folder=/tmp/habitat_amd_test_ckpt",
+          "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000",
+          f"{pre}.resize.type=ResizeShortestEdge", f"{pre}.resize.size=64",
+          f"{pre}.crop.type=CenterCropper", f"{pre}.crop.height=64", f"{pre}.crop.width=64"]
+    for sname in ("rgb", "depth"):
+        ov += [f"habitat.simulator.sensors.{sname}.height=96", f"habitat.simulator.sensors.{sname}.width=128"]
+    cfg = get_config("pointnav/ppo_pointnav_example.yaml", ov)
+    cfg.habitat.simulator.sensors.pop("semantic", None)
+    trainer = baseline_registry.get_trainer(cfg.habitat_baselines.trainer_name)(cfg)
+    trainer._init_train()
+    try:
+        assert trainer._device_envs and trainer._raw_obs is not None
+        B = trainer._agent.rollouts.buffers
+        assert tuple(B["observations"]["rgb"].shape[2:]) == (64, 64, 3) and tuple(B["observations"]["depth"].shape[2:]) == (64, 64, 1)
+        trainer._agent.eval()
+        assert trainer.collect_rollout() == N * T
+        twin = SyntheticVectorEnv(N, 96, 128, seed=int(cfg.habitat.seed), num_actions=len(cfg.habitat.task.actions))
+        rgb = torch.zeros(N, 96, 128, 3, dtype=torch.uint8, device="cuda")
+        depth = torch.zeros(N, 96, 128, 1, device="cuda")
+        goal = torch.zeros(N, 2, device="cuda")
+        rew, nd = torch.zeros(N, device="cuda"), torch.zeros(N, dtype=torch.uint8, device="cuda")
+
+        def tf(x):
+            return O.center_crop(O.resize_shortest_edge(x.cpu(), 64), 64).numpy()
+
+        twin.reset_into(rgb, depth, goal)
+        for t in range(T + 1):
+            assert np.array_equal(B["observations"]["rgb"][t].cpu().numpy(), tf(rgb)), t
+            assert np.array_equal(B["observations"]["depth"][t].cpu().numpy(), tf(depth)), t
+            assert np.array_equal(B["observations"][GOAL][t].cpu().numpy(), goal.cpu().numpy()), t
+            if t < T:
+                twin.step_into(rgb, depth, goal, rew, nd)
+        losses = trainer._update_agent()
+        assert all(np.isfinite(v) for v in losses.values()), losses
+    finally:
+        trainer.envs.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("backbone,rnn_type,layers", [("resnet18", "LSTM", 2), ("resnet50", "GRU", 1)])
 def test_frozen_encoder_visual_features_vs_oracle(backbone, rnn_type, layers):
     """N3, rl.ddppo.train_encoder=False: (1) `visual_encoder(batch)` alone equals the oracle's ResNetEncoder in eval mode and leaves
