@@ -430,7 +430,9 @@ def test_autograd_bridge_matches_fused_path():
         assert rel_ok(p_.grad.cpu().numpy(), ref, tol=1e-4, floor=1e-4), k
 
 
-@pytest.mark.parametrize("rnn_type,layers,hidden", [("LSTM", 2, 64), ("GRU", 2, 64), ("GRU", 1, 512), ("LSTM", 1, 256)])
+# (2 and 3 layers run the packed recurrence as a layer wavefront, csrc/rnn.hip: 64 -> 4 waves per workgroup, 128 / 512 -> 8)
+@pytest.mark.parametrize("rnn_type,layers,hidden", [("LSTM", 2, 64), ("GRU", 2, 64), ("GRU", 1, 512), ("LSTM", 1, 256), ("LSTM", 3, 128),
+                                                    ("GRU", 3, 64)])
 def test_engine_lstm_gru_multilayer_vs_oracle(rnn_type, layers, hidden):
     """The engine also runs LSTM / multi-layer encoders on the baseline net; checked against the oracle's
     masked-scan restatement incl. all gradients (autograd on the oracle).  hidden 512 / 256 = the benchmark width: the
