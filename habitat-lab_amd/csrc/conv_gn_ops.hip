@@ -22,8 +22,7 @@ int conv_gn_fused(const ConvGnArgs& q, hipStream_t s) {
     a.B = q.B; a.H = q.H; a.W = q.W; a.C = q.C; a.Cout = q.Cout; a.KH = q.KH; a.KW = q.KW; a.stride = q.stride; a.pad = q.pad;
     a.groups = q.groups; a.relu = q.relu; a.eps = q.eps;
     const int rc = conv_gn_slab(a, s);
-    static const int stream_cfg = hab_env_int("HAB_CGS_STREAM", 1);
-    if (rc != 1 || q.KH != 1 || q.KW != 1 || q.pad != 0 || !stream_cfg) return rc;
+    if (rc != 1 || q.KH != 1 || q.KW != 1 || q.pad != 0) return rc;
     // 1x1 convolutions whose frames do not fit LDS (the bottleneck net's 32 x 32-pixel layers): activations streamed from memory
     C1gArgs b{};
     b.x = q.x; b.wq = q.w_planes; b.gamma = q.gamma; b.beta = q.beta; b.residual = q.residual; b.y = q.y;

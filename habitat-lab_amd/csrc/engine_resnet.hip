@@ -277,8 +277,7 @@ int build_resnet(hab_policy* e) {
     pack_conv(r->stem, false);
     if (stem_conv_ok(r->stem.cd.H, r->stem.cd.W, r->stem.cd.C, r->stem.cd.Cout, 7, 7, 2, 3)) r->stem.pk_p = pk.take(STEM_PLANE_FLOATS);
     r->stem_takes_raw = r->stem.pk_p >= 0 && r->cpad == 4 && r->stem.cd.Cout == 32 &&
-                        stem_wgrad_ok(r->stem.cd.H, r->stem.cd.W, r->stem.cd.C, r->stem.cd.Cout, 7, 7, 2, 3) &&
-                        hab_env_int("HAB_STEM_STRIP", 1) && hab_env_int("HAB_STEM_WGRAD", 1) && hab_env_int("HAB_STEM_RAW", 1);
+                        stem_wgrad_ok(r->stem.cd.H, r->stem.cd.W, r->stem.cd.C, r->stem.cd.Cout, 7, 7, 2, 3);
     for (auto& c : r->convs) pack_conv(c, true);
     pack_conv(r->comp, true);
     r->pk_fc = pk.take((int64_t)H * r->fc_in);
@@ -423,10 +422,8 @@ static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, cons
     float* mean = W + c.w_mean + (int64_t)f0 * c.groups;
     float* rstd = W + c.w_rstd + (int64_t)f0 * c.groups;
     if (&c == &e->rn->stem && c.pk_p >= 0) {  // stem: input strip resident in LDS (stem_conv_strip.h)
-        static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
-        if (e->rn->x0_raw && !stem_strip) return HAB_ERR_ARG;
-        const int rc = stem_strip ? stem_conv_forward(in, reinterpret_cast<const unsigned short*>(e->PK + c.pk_p), raw, B, cd.H, cd.W, s,
-                                                      e->rn->x0_raw ? W + e->rn->w_stats + 32 : nullptr) : 1;
+        const int rc = stem_conv_forward(in, reinterpret_cast<const unsigned short*>(e->PK + c.pk_p), raw, B, cd.H, cd.W, s,
+                                         e->rn->x0_raw ? W + e->rn->w_stats + 32 : nullptr);
         if (rc == 1 && e->rn->x0_raw) return HAB_ERR_UNSUPPORTED;
         if (rc != 0 && rc != 1) return rc;
         if (rc == 1) HAB_TRY(conv_fwd(cd, in, e->PK + c.pk_f, nullptr, raw, 0, W + e->w_ws, e->ws_floats, s));
@@ -438,15 +435,13 @@ static int conv_gn_forward(hab_policy* e, const RnConv& c, const float* in, cons
     }
     // the rollout's act / encode (small batches, nothing kept for a backward): convolution + GroupNorm in one launch (conv_gn_slab.h).
     // Small evaluate minibatches keep the unfused pair -- the kernels every update-sized minibatch runs, so that the golden update tests
-    // exercise the production learner path; HAB_CGS_EVAL=1 (development) sends them through the fused kernel too (it writes the
-    // pre-normalisation output and the statistics for the backward pass: tests/test_gpu_conv_gn.py).
-    static const int cgs_max_b = hab_env_int("HAB_CGS_MAX_B", 256);
-    static const int cgs_eval = hab_env_int("HAB_CGS_EVAL", 0);
-    if (c.pk_p >= 0 && B <= cgs_max_b && (!e->save_acts || cgs_eval)) {
+    // exercise the production learner path (the fused kernels can also write the pre-normalisation output and the statistics a backward
+    // pass needs: tests/test_gpu_conv_gn.py).
+    constexpr int cgs_max_b = 256;
+    if (c.pk_p >= 0 && B <= cgs_max_b && !e->save_acts) {
         ConvGnArgs q;
         q.x = in; q.w_planes = reinterpret_cast<const unsigned short*>(e->PK + c.pk_p); q.gamma = e->p(c.i_gamma); q.beta = e->p(c.i_beta);
         q.residual = residual; q.y = out;
-        if (e->save_acts) { q.raw = raw; q.mean = mean; q.rstd = rstd; }
         q.B = B; q.H = cd.H; q.W = cd.W; q.C = cd.C; q.Cout = cd.Cout; q.KH = cd.KH; q.KW = cd.KW; q.stride = cd.stride; q.pad = cd.pad;
         q.groups = c.groups; q.relu = relu; q.eps = 1e-5f;
         const int rc = conv_gn_fused(q, s);
@@ -600,17 +595,14 @@ static int resnet_layers_forward(hab_policy* e, int Btot, int f0, int B, hipStre
     uint8_t* pool_idx = reinterpret_cast<uint8_t*>(W + r->w_pool_idx) + F0 * pool_floats;  // one byte per pooled element
     ConvDesc scd = st.cd;
     scd.B = B;
-    static const int stem_strip = hab_env_int("HAB_STEM_STRIP", 1);
-    static const int stem_fuse = hab_env_int("HAB_STEM_FUSE", 1);
     // the strip kernel leaves the GroupNorm partial statistics of its strips (8 output rows) with the output: no statistics pass
-    static const int stem_stats = hab_env_int("HAB_STEM_STATS", 1);
     const int stat_chunks = (scd.Ho() + STEM_STAT_ROWS - 1) / STEM_STAT_ROWS;
     float* gn_part = W + e->w_ws;
     bool have_part = false;
     auto stem_conv = [&](bool want_part) -> int {
-        want_part = want_part && stem_stats && (st.groups == 8 || st.groups == 16 || st.groups == 32) &&
+        want_part = want_part && (st.groups == 8 || st.groups == 16 || st.groups == 32) &&
                     (size_t)B * stat_chunks * st.groups * 2 <= e->ws_floats;
-        const int rcs = (stem_strip && st.pk_p >= 0) ? stem_conv_forward(x0, reinterpret_cast<const unsigned short*>(e->PK + st.pk_p), stem_raw, B,
+        const int rcs = st.pk_p >= 0 ? stem_conv_forward(x0, reinterpret_cast<const unsigned short*>(e->PK + st.pk_p), stem_raw, B,
                                                                          scd.H, scd.W, s, r->x0_raw ? W + r->w_stats + 32 : nullptr,
                                                                          want_part ? gn_part : nullptr, st.groups) : 1;
         have_part = want_part && rcs == 0;
@@ -636,7 +628,7 @@ static int resnet_layers_forward(hab_policy* e, int Btot, int f0, int B, hipStre
         stem_done = true;
     }
     // (the fused form needs its chunk-parallel kernels for the chunk AND for the whole batch the backward runs on)
-    if (!stem_done && stem_fuse && groupnorm_pool_fusable(B, g.HW, g.C, g.groups, e->ws_floats) &&
+    if (!stem_done && groupnorm_pool_fusable(B, g.HW, g.C, g.groups, e->ws_floats) &&
         groupnorm_pool_fusable(Btot, g.HW, g.C, g.groups, e->ws_floats)) {
         // training forward: the same fused pass, keeping the statistics and the arg-max bytes; the ReLU mask is recomputed in the backward
         HAB_TRY(stem_conv(true));
@@ -860,9 +852,8 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
     }
     ConvDesc c0 = r->stem.cd;
     c0.B = B;
-    static const int stem_wg = hab_env_int("HAB_STEM_WGRAD", 1);
     int rcw = 1;
-    if (stem_wg && r->cpad == 4 && c0.Cout == 32)  // strip-resident form (stem_wgrad_strip.h); 1: geometry not covered
+    if (r->cpad == 4 && c0.Cout == 32)  // strip-resident form (stem_wgrad_strip.h); 1: geometry not covered
         rcw = stem_conv_wgrad(W + r->w_x0, d_raw0, e->g(r->stem.i_w), B, c0.H, c0.W, r->creal, ws, e->ws_floats, s,
                               r->x0_raw ? W + r->w_stats + 32 : nullptr);
     if (rcw != 0 && rcw != 1) return rcw;

@@ -341,8 +341,7 @@ int rnn_step_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const 
     const int G = rnn_type == RNN_GRU ? 3 : 4;
     // input projection inside the step kernel when the engine supplies W_ih with padded, aligned rows: x rows must be readable (and
     // zero where W_ih's padding is, or at least finite) up to w_ih_ld
-    static const int fuse_cfg = hab_env_int("HAB_RNN_FUSE_PROJ", 1);
-    const bool fuse = fuse_cfg && lp.w_ih_pad && lp.w_ih_ld > 0 && (lp.w_ih_ld & 15) == 0 && ldx >= lp.w_ih_ld && (ldx & 3) == 0 &&
+    const bool fuse = lp.w_ih_pad && lp.w_ih_ld > 0 && (lp.w_ih_ld & 15) == 0 && ldx >= lp.w_ih_ld && (ldx & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(lp.w_ih_pad)) & 15) == 0;
     if (!fuse) HAB_TRY(linear_fwd(x, ldx, lp.w_ih, lp.in_dim, lp.b_ih, gi_scratch, G * H, n, G * H, lp.in_dim, 0, 0, ws, ws_floats, stream));
     StepArgs a;
