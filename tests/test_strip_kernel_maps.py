@@ -375,3 +375,168 @@ def test_conv2_data_gradient_strip_maps_at_runtime_geometries(H, W):
         for kw in range(4):
             ref[kh: kh + 2 * Ho - 1: 2, kw: kw + 2 * Wo - 1: 2] += np.einsum("hwn,nc->hwc", dy[0], w[:, :, kh, kw])
     assert np.array_equal(dx[0], ref)
+
+
+# ---- conv1x1_gn_stream.h ----------------------------------------------------------------------------------------------------------
+def conv1x1_gn_stream_model(x, w, gamma, beta, groups, stride, relu, residual=None, eps=1e-5):
+    """x [H][W][C] (one frame), w [Cout][C] -> y [Ho*Wo][Cout] through the kernel's maps: workgroup = slab of 32 output channels, wave =
+    MT tiles of 32 pixels, activations staged per (tile, channel chunk) into a wave-private [32][CH + 4] LDS tile by units u = lane + 64 j,
+    fragments = 8 consecutive channels of the lane's pixel, weights in the fragment order of cgs_split_weights, statistics by per-lane
+    entries -> half-wave totals -> groups."""
+    H, W, C = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    HoWo = Ho * Wo
+    MT = 1 if HoWo <= 256 else (2 if HoWo <= 512 else 4)
+    CH = 128 if C >= 128 else C
+    NCH = C // CH
+    CP, QPP, KSC = CH + 4, CH // 4, CH // 16
+    NU, KS = QPP // 2, (CH // 16) * NCH
+    gs = Cout // groups
+    gsh = gs.bit_length() - 1
+    ng = 32 >> gsh
+    # fragment-ordered weight planes (cgs_split_weights_kernel): [ct][s][lane][8]
+    wq = np.zeros((Cout // 32) * KS * 512)
+    for co in range(Cout):
+        for k in range(C):
+            ct, s_, lane, e = co // 32, k // 16, ((k % 16) // 8) * 32 + co % 32, k % 8
+            wq[(ct * KS + s_) * 512 + lane * 8 + e] = w[co, k]
+    xf = x.reshape(H * W, C)
+    y = np.full((HoWo, Cout), np.nan)
+    for slab in range(Cout // 32):
+        acc = np.zeros((8, MT, 64, 16))
+        for wave in range(8):
+            offs = np.zeros((MT, 32), dtype=np.int64)
+            for m in range(MT):
+                for li in range(32):
+                    p = (wave * MT + m) * 32 + li
+                    pc = p if p < HoWo else HoWo - 1
+                    offs[m, li] = (pc // Wo * stride) * W + (pc % Wo) * stride
+            for st in range(MT * NCH):
+                m, kc = st // NCH, st % NCH
+                xs = np.full(32 * CP, np.nan)
+                for lane in range(64):
+                    for j in range(NU):
+                        u = lane + 64 * j
+                        pix, quad = u // QPP, u % QPP
+                        xs[pix * CP + quad * 4: pix * CP + quad * 4 + 4] = xf[offs[m, pix], kc * CH + quad * 4: kc * CH + quad * 4 + 4]
+                for ks in range(KSC):
+                    af = np.zeros((64, 8)); bw = np.zeros((64, 8))
+                    for lane in range(64):
+                        li, hi = lane & 31, lane >> 5
+                        af[lane] = xs[li * CP + 16 * ks + 8 * hi: li * CP + 16 * ks + 8 * hi + 8]
+                        base = ((slab * KS + kc * KSC + ks) * 64 + lane) * 8
+                        bw[lane] = wq[base: base + 8]
+                    mfma_32x32x16(bw, af, acc[wave, m])  # operands swapped: rows = output channels, columns = pixels
+        # statistics: lane entries -> half-wave totals -> groups
+        pairs = gs == 2
+        nent = 8 if pairs else 4
+        okm = np.zeros((8, MT, 64), dtype=bool)
+        for wave in range(8):
+            for m in range(MT):
+                for lane in range(64):
+                    okm[wave, m, lane] = (wave * MT + m) * 32 + (lane & 31) < HoWo
+
+        def entry_val(vals16, j):
+            if pairs:
+                return vals16[4 * (j >> 1) + 2 * (j & 1)] + vals16[4 * (j >> 1) + 2 * (j & 1) + 1]
+            return vals16[4 * j: 4 * j + 4].sum()
+
+        def group_total(red, grp):
+            if pairs:
+                e = ((grp >> 1) & 1) * 8 + 2 * (grp >> 2) + (grp & 1)
+                return sum(red[w_][e] for w_ in range(8))
+            nq, q0 = gs >> 2, grp * (gs >> 2)
+            return sum(red[w_][((q0 + i) & 1) * 8 + ((q0 + i) >> 1)] for w_ in range(8) for i in range(nq))
+
+        def entry_group(h, j):
+            return 4 * (j >> 1) + 2 * h + (j & 1) if pairs else (8 * j + 4 * h) >> gsh
+
+        red = np.zeros((8, 16))
+        for wave in range(8):
+            for hi in range(2):
+                for j in range(nent):
+                    red[wave, hi * 8 + j] = sum(entry_val(acc[wave, m, 32 * hi + li], j) for m in range(MT) for li in range(32)
+                                                if okm[wave, m, 32 * hi + li])
+        n = HoWo * gs
+        mu = np.array([group_total(red, g_) / n for g_ in range(ng)])
+        red2 = np.zeros((8, 16))
+        for wave in range(8):
+            for hi in range(2):
+                for j in range(nent):
+                    t_ = 0.0
+                    for m in range(MT):
+                        for li in range(32):
+                            if not okm[wave, m, 32 * hi + li]:
+                                continue
+                            v = acc[wave, m, 32 * hi + li]
+                            idx = [4 * (j >> 1) + 2 * (j & 1), 4 * (j >> 1) + 2 * (j & 1) + 1] if pairs else list(range(4 * j, 4 * j + 4))
+                            t_ += sum((v[i] - mu[entry_group(hi, j)]) ** 2 for i in idx)
+                    red2[wave, hi * 8 + j] = t_
+        rs = np.array([1.0 / np.sqrt(group_total(red2, g_) / n + eps) for g_ in range(ng)])
+        for wave in range(8):
+            for m in range(MT):
+                for lane in range(64):
+                    if not okm[wave, m, lane]:
+                        continue
+                    li, hi = lane & 31, lane >> 5
+                    p = (wave * MT + m) * 32 + li
+                    for g_ in range(4):
+                        for k in range(4):
+                            c0 = 8 * g_ + 4 * hi + k
+                            grp = c0 >> gsh
+                            sc = rs[grp] * gamma[slab * 32 + c0]
+                            o = acc[wave, m, lane, 4 * g_ + k] * sc + (beta[slab * 32 + c0] - mu[grp] * sc)
+                            if residual is not None:
+                                o += residual[p, slab * 32 + c0]
+                            y[p, slab * 32 + c0] = max(o, 0.0) if relu else o
+    return y
+
+
+@pytest.mark.parametrize("H,W,C,Cout,groups,stride", [(8, 8, 32, 32, 16, 1), (6, 7, 64, 64, 16, 1), (18, 18, 32, 64, 8, 1), (32, 32, 32, 32, 2, 1),
+                                                       (9, 10, 256, 32, 1, 2), (5, 5, 128, 96, 24, 1)])
+def test_conv1x1_gn_stream_maps(H, W, C, Cout, groups, stride):
+    """Every group size the kernel takes (2 .. 32), one / two / four tiles per wave, two channel chunks (C = 256), stride 2, a ragged
+    last tile: conv + GroupNorm (+ residual, ReLU) through the kernel's maps == the direct evaluation."""
+    rng = np.random.default_rng(H * 1000 + C + Cout)
+    x = rng.integers(-3, 4, (H, W, C)).astype(np.float64)
+    w = rng.integers(-2, 3, (Cout, C)).astype(np.float64)
+    gamma, beta = rng.uniform(0.5, 1.5, Cout), rng.uniform(-0.3, 0.3, Cout)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = rng.standard_normal((Ho * Wo, Cout))
+    y = conv1x1_gn_stream_model(x, w, gamma, beta, groups, stride, relu=True, residual=res)
+    raw = np.einsum("hwc,nc->hwn", x[::stride, ::stride], w).reshape(Ho * Wo, Cout)
+    g = raw.reshape(Ho * Wo, groups, Cout // groups)
+    mean, var = g.mean(axis=(0, 2)), g.var(axis=(0, 2))
+    ref = ((g - mean[None, :, None]) / np.sqrt(var[None, :, None] + 1e-5)).reshape(Ho * Wo, Cout) * gamma + beta + res
+    ref = np.maximum(ref, 0.0)
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("CH", [32, 64, 128])
+def test_conv1x1_gn_stream_lds_bank_pattern(CH):
+    """64 banks x 4 bytes; a 16-byte access is served in phases of 16 lanes.  (a) staging writes: lanes l .. l + 15 of an instruction write
+    consecutive units -- [pixel][CH + 4] rows, quads of a pixel contiguous (conflict-free except a 2-way overlap on 4 banks at CH = 32);
+    (b) fragment reads (the accesses of the main loop): the 16 lanes of a phase are 16 consecutive
+    pixels at one channel offset, row stride CH + 4 floats = 4 banks (mod 64) -> every bank exactly once."""
+    CP, QPP = CH + 4, CH // 4
+    for phase in range(4):
+        banks = []
+        for lane in range(16 * phase, 16 * phase + 16):
+            u = lane  # j = 0; j > 0 shifts every lane by the same multiple of 64 units
+            a = (u // QPP) * CP + (u % QPP) * 4
+            banks += [(a + i) % 64 for i in range(4)]
+        # CH = 32: a phase covers two 32-float pixel rows 36 floats apart -> 4 of the 64 banks are hit twice (a 2-way conflict on a
+        # write that happens once per tile); CH = 64 / 128: one pixel row or part of one -> conflict-free
+        assert max(banks.count(b) for b in set(banks)) == (2 if CH == 32 else 1), ("write", CH, phase)
+        assert len(set(banks)) == (60 if CH == 32 else 64), ("write", CH, phase)
+    for ks in range(CH // 16):
+        for hi in range(2):
+            for half in range(2):  # the two 16-byte reads of a fragment
+                for phase in range(2):
+                    banks = []
+                    for li in range(16 * phase, 16 * phase + 16):
+                        a = li * CP + 16 * ks + 8 * hi + 4 * half
+                        banks += [(a + i) % 64 for i in range(4)]
+                    assert len(set(banks)) == 64, ("read", CH, ks, hi, half, phase)
