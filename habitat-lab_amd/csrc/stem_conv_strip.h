@@ -17,6 +17,9 @@
 //     (42 KB): one conflict-free 16-byte read per plane and k-step;
 //   * wave w owns output row w of the strip: two 32-pixel tiles x 32 channels, 14 k-steps x 12 MFMAs, no reduction across waves; the
 //     operands are swapped so that a lane ends with 4 consecutive channels of one pixel -> 16-byte stores.
+//   * round 4, second half: the RunningMeanAndVar normalisation of the training forward is applied while the strip is staged
+//     (StemArgs::norm: one fma per element on the pixels inside the image -- the 1 GB normalised copy of the observation tensor is never
+//     written), and the GroupNorm that follows gets its per-strip partial statistics from the epilogue (StemArgs::part, template CPG).
 // Sign schedule as everywhere on the split path: every second workgroup accumulates the negated sum.
 #pragma once
 #include "bf3_split.h"
