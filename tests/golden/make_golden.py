@@ -399,6 +399,9 @@ def main():
         se_resnext_case(ns)
         se_resnext_case(ns, seed=SE_SEED_UNSELECTED, name="se_resnext50_rgbd128_seed7")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "nonsquare":
+        baseline_nonsquare_case(load_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "gaussian":
         gaussian_case(load_reference())
         return
@@ -424,6 +427,7 @@ def main():
     cfg2 = make_config(clip_param=0.2, ppo_epoch=1, num_mini_batch=1, max_grad_norm=0.2, num_steps=5,
                        use_normalized_advantage=False, hidden_size=64, use_clipped_value_loss=False)
     run_case(ns, "baseline_depth84", pol2, space2, cfg2, T=5, N=3, seed=7, H=84, W=84, rgb=False)
+    baseline_nonsquare_case(ns)
     # B: PointNavResNetPolicy (resnet18 GroupNorm encoder + 2-layer LSTM, RunningMeanAndVar on), 256x256 RGB-D (BASELINE.json
     # configs[2] geometry), hidden 64, ddppo_pointnav hyper-parameters.  Large tensors are stored as strided samples + norms.
     space3 = obs_space(ns, 256, 256)
@@ -447,6 +451,17 @@ def main():
     gaussian_case(ns)
     se_resnext_case(ns)
     se_resnext_case(ns, seed=SE_SEED_UNSELECTED, name="se_resnext50_rgbd128_seed7")
+
+
+def baseline_nonsquare_case(ns):
+    """A3: SimpleCNN + GRU on 96 x 128 RGB-D (simple_cnn.py:35-93 takes any size): conv1 -> 23 x 31, conv2 -> 10 x 14, conv3 -> 8 x 12.
+    16-frame minibatches: the geometry-general instantiations of the strip kernels run at engine level against the reference."""
+    space = obs_space(ns, 96, 128)
+    torch.manual_seed(0)
+    pol = ns.policy.PointNavBaselinePolicy(space, ns.spaces.Discrete(4), hidden_size=64)
+    cfg = make_config(clip_param=0.1, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.5, num_steps=8,
+                      use_normalized_advantage=True, hidden_size=64, lr=2.5e-4, eps=1e-5)
+    run_case(ns, "baseline_rgbd96x128", pol, space, cfg, T=8, N=4, seed=61, H=96, W=128)
 
 
 SE_SEED = 124  # of seeds 0..699 the one whose smallest |pre-ReLU| over the stored minibatch is largest (3.9e-6; `make_golden.py se-seeds`)

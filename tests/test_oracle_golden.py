@@ -89,6 +89,11 @@ CASES = {
     "baseline_depth84": dict(H=84, W=84, rgb=False, depth=True, T=5, N=3, seed=7, hidden=64,
                              cfg=dict(clip_param=0.2, ppo_epoch=1, num_mini_batch=1, max_grad_norm=0.2,
                                       use_normalized_advantage=False, use_clipped_value_loss=False)),
+    # non-square observations (96 x 128): conv2 / conv3 inputs 23 x 31 / 10 x 14 -- the runtime-geometry instantiations of the strip kernels
+    # at engine level (16-frame minibatches)
+    "baseline_rgbd96x128": dict(H=96, W=128, rgb=True, depth=True, T=8, N=4, seed=61, hidden=64,
+                                cfg=dict(clip_param=0.1, ppo_epoch=2, num_mini_batch=2, max_grad_norm=0.5,
+                                         use_normalized_advantage=True, use_clipped_value_loss=True)),
     # BASELINE.json configs[0] exactly: 4 envs x 32 steps, 84x84 depth, hidden 512, ppo_pointnav_example.yaml hyper-parameters
     "c1_depth84_h512_4x32": dict(H=84, W=84, rgb=False, depth=True, T=32, N=4, seed=41, hidden=512, sampled=True, exact=True,
                                  cfg=dict(clip_param=0.1, ppo_epoch=1, num_mini_batch=1, max_grad_norm=0.5,
