@@ -78,7 +78,7 @@ def test_time_major_chunked_recurrence_vs_the_packed_form(workload):
     to HAB_RNN_CHUNKS=0 (packed sequences, rl/models/rnn_state_encoder.py:187-277).  With several chunks the chunk-sized contractions
     choose other split-K plans / sign-schedule phases (fp32 summation order): same rollout (bit-identical actions -- the rollout does
     not use the form), losses within 1e-5 (c3: 1e-4, a 20-layer GroupNorm encoder behind them), and bitwise reproducible for a given
-    chunk count (the default is part of test_update_cycles_are_bitwise_reproducible)."""
+    chunk count (checked at 4 chunks; the default forms are part of test_update_cycles_are_bitwise_reproducible)."""
     # (c3's two LSTM layers run the packed form as a layer WAVEFRONT by default -- the upper layer's input projection then happens inside
     #  its step kernel, another summation order; the operand-for-operand statement is about the layer-by-layer form: HAB_RNN_WAVE=0)
     packed = _digest_in_subprocess(workload, 1, {"HAB_RNN_CHUNKS": "0", "HAB_RNN_WAVE": "0"})
@@ -97,4 +97,5 @@ def test_time_major_chunked_recurrence_vs_the_packed_form(workload):
             # gradients carry a few legitimately different ReLU decisions (tests/test_gpu_policy.py): 10x
             t_k = tol if (workload == "c2" or k in ("value_loss", "action_loss", "dist_entropy")) else 10 * tol
             assert abs(a - b) <= t_k * max(abs(b), 1e-3), (chunks, k, a, b)
-        assert d == _digest_in_subprocess(workload, 1, env), "not reproducible"
+        if chunks == "4":  # (the default forms are run twice by test_update_cycles_are_bitwise_reproducible; one non-default chunk count here)
+            assert d == _digest_in_subprocess(workload, 1, env), "not reproducible"
