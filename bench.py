@@ -140,12 +140,12 @@ def site_chunks(site):
     return chunks if (site.endswith("_fwd") or site.endswith("_dgrad")) else 1
 
 
-def make_trainer(workload: str, total_updates: int):
+def make_trainer(workload: str, total_updates: int, envs: int = 0, steps: int = 0):
     from habitat_amd.config.default import get_config
     import habitat_amd.rl.ppo.ppo_trainer as tr
     w = WORKLOADS[workload]
-    cfg = get_config(w["yaml"], [f"habitat_baselines.num_environments={w.get('envs', NUM_ENVS)}",
-                                 f"habitat_baselines.rl.ppo.num_steps={w.get('steps', NUM_STEPS)}",
+    cfg = get_config(w["yaml"], [f"habitat_baselines.num_environments={envs or w.get('envs', NUM_ENVS)}",
+                                 f"habitat_baselines.rl.ppo.num_steps={steps or w.get('steps', NUM_STEPS)}",
                                  f"habitat_baselines.num_updates={total_updates}", "habitat_baselines.total_num_steps=-1",
                                  "habitat_baselines.num_checkpoints=-1", f"habitat_baselines.checkpoint_interval={10 ** 9}",
                                  "habitat_baselines.rl.ddppo.distrib_backend=" + os.environ.get("HAB_BENCH_DISTRIB_BACKEND", "NCCL"),
@@ -161,118 +161,103 @@ def make_trainer(workload: str, total_updates: int):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # CPU leg + parity leg (rank 0, N = 1)
 # ---------------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_and_parity(trainer, cfg, sample_envs=NUM_ENVS, sample_steps=NUM_STEPS, parity=True, cpu_threads=0):
+def cpu_baseline_and_parity(trainer, cfg, sample_envs=NUM_ENVS, sample_steps=NUM_STEPS, parity=True, cpu_threads=0, workload="c2"):
     """(a) `cpu_baseline`: the oracle (oracle/functional.py: CPU restatement of the reference PPOTrainer path, pinned to the live
-    reference by tests/golden) runs ONE full update cycle of the workload -- rollout of 64 envs x 128 steps with policy.act per step,
-    GAE, PPO update E=4 x M=4 -- on the host cores and is timed.  (b) `parity`: the rollout the oracle produced (observations,
-    actions, old log-probs / values, rewards, masks, hidden states) is loaded into a device RolloutStorage and the HIP path does
-    the same update with the same minibatch permutations from the same parameters; the two sets of learner metrics, the GAE returns
-    and one minibatch's per-frame outputs are compared."""
+    reference by tests/golden) runs ONE full update cycle of the workload -- rollout of `sample_envs` x `sample_steps` with policy.act
+    per step, GAE, PPO update E x M -- on the host cores and is timed.  (b) `parity`: the rollout the oracle produced (observations,
+    actions, old log-probs / values, rewards, masks, hidden states) is loaded into a device RolloutStorage and the HIP path does the
+    same update with the same minibatch permutations from the same parameters: GAE returns, one minibatch's per-frame outputs, and
+    the whole update twice (oracle/parity.py::update_parity) -- TEACHER-FORCED (every minibatch step starts from the oracle's
+    pre-step parameters + Adam moments: per-step loss / gradient-norm / parameter-step errors that chaos cannot amplify) and
+    free-running (how the trainer runs it: the drift before each step and the clip decisions that flipped)."""
     import types
     import numpy as np
     import torch
-    from oracle import functional as O
-    from oracle import synth
-    from oracle.fixtures import synth_rollout_inputs
+    from oracle import parity as PR
     # default 16 threads: more slow the small-batch CPU convolutions of the rollout down (both settings were timed:
     # profiles/r03_cpu_leg_threads.json, --cpu-threads)
     threads = cpu_threads if cpu_threads > 0 else min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    N, T, hidden = sample_envs, sample_steps, 512
+    N, T = sample_envs, sample_steps
     pol = trainer._agent.actor_critic
+    hidden, hl = pol.recurrent_hidden_size, pol.num_recurrent_layers
     params = {k: v.detach().cpu().clone() for k, v in pol.state_dict().items()}  # the policy as the timed cycles left it
-    spec = O.NetSpec(kind="baseline", hidden=hidden)
+    spec = PR.spec_of(pol)
+    trainable = [k for k, p_ in pol.named_parameters() if p_.requires_grad]
     ppo = cfg.habitat_baselines.rl.ppo
     ocfg = types.SimpleNamespace(clip_param=ppo.clip_param, ppo_epoch=ppo.ppo_epoch, num_mini_batch=ppo.num_mini_batch,
                                  value_loss_coef=ppo.value_loss_coef, entropy_coef=ppo.entropy_coef, lr=ppo.lr, eps=ppo.eps,
                                  max_grad_norm=ppo.max_grad_norm, use_normalized_advantage=ppo.use_normalized_advantage,
                                  use_clipped_value_loss=ppo.use_clipped_value_loss, gamma=ppo.gamma, tau=ppo.tau)
     t0 = time.perf_counter()
-    envs = synth.SyntheticEnvs(N, OBS, OBS, seed=4242)
-    obs, rew, done = synth_rollout_inputs(envs, T)
-    t_env = time.perf_counter() - t0
-    torch.manual_seed(7)
-    noise = torch.stack([torch.empty(N, 4).exponential_(1) for _ in range(T)])
-    perms = [list(torch.randperm(N).chunk(ocfg.num_mini_batch)) for _ in range(ocfg.ppo_epoch)]
-    t0 = time.perf_counter()
-    buf = dict(observations={k: torch.from_numpy(np.stack([o[k] for o in obs])) for k in obs[0]})
-    del obs
-    buf["recurrent_hidden_states"] = torch.zeros(T + 1, N, 1, hidden)
-    buf["rewards"] = torch.zeros(T + 1, N, 1)
-    buf["rewards"][:T] = torch.from_numpy(rew).unsqueeze(-1)
-    buf["masks"] = torch.zeros(T + 1, N, 1, dtype=torch.bool)
-    buf["masks"][1:] = torch.from_numpy(~done).unsqueeze(-1)
-    for k in ("value_preds", "action_log_probs"):
-        buf[k] = torch.zeros(T + 1, N, 1)
-    buf["actions"] = torch.zeros(T + 1, N, 1, dtype=torch.long)
-    buf["prev_actions"] = torch.zeros(T + 1, N, 1, dtype=torch.long)
-    with torch.no_grad():
-        for t in range(T):
-            r = O.act(params, spec, {k: v[t] for k, v in buf["observations"].items()}, buf["recurrent_hidden_states"][t],
-                      buf["prev_actions"][t], buf["masks"][t], exp_noise=noise[t])
-            buf["actions"][t], buf["action_log_probs"][t], buf["value_preds"][t] = r["actions"], r["action_log_probs"], r["values"]
-            buf["recurrent_hidden_states"][t + 1], buf["prev_actions"][t + 1] = r["rnn_hidden_states"], r["actions"]
-        feats, _ = O.net_forward(params, spec, {k: v[T] for k, v in buf["observations"].items()}, buf["recurrent_hidden_states"][T],
-                                 buf["prev_actions"][T], buf["masks"][T])
-        nv = O.heads(params, feats)[2]
-    buf["returns"], buf["value_preds"] = O.compute_returns(buf["rewards"], buf["value_preds"], buf["masks"], nv, T, True, ocfg.gamma, ocfg.tau)
-    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    opt = dict(step=0, m={k: torch.zeros_like(v) for k, v in p.items()}, v={k: torch.zeros_like(v) for k, v in p.items()})
-    ref_metrics = O.ppo_update(p, spec, buf, T, ocfg, opt, list(p.keys()), perms=perms)
-    dt = time.perf_counter() - t0
+    buf, nv, perms, t_env = PR.oracle_rollout(params, spec, N, T, OBS, OBS, hidden, hl, ocfg)
+    ref_metrics, trace, final = PR.oracle_update_trace(params, spec, buf, T, ocfg, trainable, perms)
+    dt = time.perf_counter() - t0 - t_env
     base = {"value": round(N * T / dt, 2), "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"one FULL update cycle of the workload ({N} envs x {T} steps, 256x256 RGB-D, SimpleCNN+GRU, E={ocfg.ppo_epoch} x "
-                      f"M={ocfg.num_mini_batch}): oracle/functional.py (CPU restatement of the reference path, pinned to the reference by "
-                      f"tests/golden; the reference itself is absent on the GPU box) on torch-CPU fp32 with {threads} threads of "
-                      f"{os.cpu_count()} host cores, {dt:.1f} s (synthetic obs generation {t_env:.1f} s excluded)"}
+            "sample": f"one FULL update cycle of the workload ({N} envs x {T} steps, 256x256 RGB-D, {WORKLOADS[workload]['name'].split(',')[0]}, "
+                      f"E={ocfg.ppo_epoch} x M={ocfg.num_mini_batch}): oracle/functional.py (CPU restatement of the reference path, pinned to the "
+                      f"reference by tests/golden; the reference itself is absent on the GPU box) on torch-CPU fp32 with {threads} threads of "
+                      f"{os.cpu_count()} host cores, {dt:.1f} s (synthetic obs generation {t_env:.1f} s excluded; the per-step state snapshots "
+                      f"of the parity leg, ~0.1 s each, included)"}
     if not parity:
         return base, None
     # ---- the same rollout through the HIP path ----------------------------------------------------------------------------------
-    from habitat_amd.common.rollout_storage import MiniBatch, RolloutStorage
+    from habitat_amd.common.rollout_storage import MiniBatch
     from habitat_amd.rl.ppo import PPO
-    from oracle import parity as PR
     es = trainer._env_spec
-    trainer._agent._rollouts = None  # release the trainer's 3.8 GB arena before allocating this one
+    trainer._agent._rollouts = None  # release the trainer's arena before allocating this one
     torch.cuda.empty_cache()
-    st = RolloutStorage(T, N, es.observation_space, es.action_space, pol, device=trainer.device, gae_variant="scan")
+    st = PR.storage_from_oracle(buf, nv, T, N, es.observation_space, es.action_space, pol, trainer.device, ocfg)  # GAE: the scan kernel
     B = st.buffers
-    for k, v in buf["observations"].items():
-        B["observations"][k].copy_(v)
-    for k in ("actions", "prev_actions", "action_log_probs", "rewards", "masks", "recurrent_hidden_states"):
-        B[k].copy_(buf[k])
-    B["value_preds"].copy_(buf["value_preds"])
-    st.current_rollout_step_idxs = [T]
-    st.compute_returns(nv.to(trainer.device), True, ocfg.gamma, ocfg.tau)  # the GAE variant the timed cycles use, on the oracle's values
     out = {"returns_max_rel": PR.rel(B["returns"].cpu().numpy()[:T], buf["returns"].numpy()[:T])}
     pol.load_state_dict(params)
     pol.train()
     upd = PPO.from_config(pol, ocfg)
-    adv = upd.get_advantages(st)
-    batch = MiniBatch(st, perms[0][0], T, adv, torch.logical_not(B["masks"]).cpu().view(-1, N).numpy())  # first minibatch of epoch 0
-    mb = PR.minibatch_parity(pol, upd, st, batch, ocfg, env_chunk=8, with_grads=False)
-    out.update({"minibatch_frames": mb["frames"], "value_max_rel": mb["value_max_rel"], "log_prob_max_rel": mb["log_prob_max_rel"],
-                "minibatch_value_loss_rel": mb["value_loss_rel"], "minibatch_action_loss_rel": mb["action_loss_rel"]})
-    flat = [c for e in perms for c in e]
-    orig = torch.randperm
-    it = iter([torch.cat(e) for e in perms])
-    torch.randperm = lambda n, **kw: next(it)
-    try:
-        got = upd.update(st)
-    finally:
-        torch.randperm = orig
+    if workload == "c2":  # one minibatch's per-frame outputs against the chunked oracle evaluation (the c3 leg reads them off the trace)
+        adv = upd.get_advantages(st)
+        batch = MiniBatch(st, perms[0][0], T, adv, torch.logical_not(B["masks"]).cpu().view(-1, N).numpy())  # first minibatch of epoch 0
+        mb = PR.minibatch_parity(pol, upd, st, batch, ocfg, env_chunk=8, with_grads=False)
+        out.update({"minibatch_frames": mb["frames"], "value_max_rel": mb["value_max_rel"], "log_prob_max_rel": mb["log_prob_max_rel"],
+                    "minibatch_value_loss_rel": mb["value_loss_rel"], "minibatch_action_loss_rel": mb["action_loss_rel"]})
+        pol.load_state_dict(params)  # (RunningMeanAndVar-free policy: nothing changed; kept for symmetry with the ResNet leg)
+    up = PR.update_parity(pol, upd, st, buf, trace, final, T, ocfg, trainable)
+    out["teacher_forced"] = up["teacher_forced"]
+    out["teacher_forced_max_rel"] = up["teacher_forced"]["max_rel"]
+    out["free_running"] = up["free_running"]
+    fr = up["free_running"]
+    # the four figures earlier rounds' lines carried under these names (free-running, means over the update's steps)
     for k in ("value_loss", "action_loss", "dist_entropy", "grad_norm"):
-        out[k + "_rel"] = abs(got[k] - ref_metrics[k]) / max(1e-6, abs(ref_metrics[k]))
+        out[k + "_rel"] = fr[k + "_rel_of_update_means"]
+    out["post_update_param_max_abs_diff"] = fr["post_update_param_max_abs_diff"]
     # the oracle's own figures beside the relative errors: the action loss of a normalised-advantage minibatch is a mean near zero
     # (|.| ~ 1e-3), so its RELATIVE error is an absolute error of ~1e-9 .. 1e-6 divided by that
     out["reference"] = {k: float(f"{ref_metrics[k]:.6e}") for k in ("value_loss", "action_loss", "dist_entropy", "grad_norm")}
-    out["action_loss_abs_err"] = abs(got["action_loss"] - ref_metrics["action_loss"])
-    pd = max(float((v.detach().cpu() - p[k].detach()).abs().max()) for k, v in pol.state_dict().items())
-    out["post_update_param_max_abs_diff"] = pd
-    out["what"] = (f"HIP path vs the CPU oracle on the SAME {N} x {T} rollout (the one `cpu_baseline` timed), same parameters, same "
-                   f"minibatch permutations: losses averaged over the {len(flat)} minibatch steps of the update, GAE returns "
-                   f"(scan kernel), per-frame values / log-probs of one {mb['frames']}-frame minibatch")
+    out["what"] = (f"HIP path vs the CPU oracle on the SAME {N} x {T} rollout (the one the oracle produced), same parameters, same minibatch "
+                   f"permutations, {len(trace)} minibatch steps of {T * N // ocfg.num_mini_batch} frames.  teacher_forced: every step "
+                   f"restarted from the oracle's pre-step parameters and Adam moments (per-step arrays; max_rel = worst of value loss, "
+                   f"action loss / mean |surrogate|, entropy, gradient norm; bar 1e-4).  free_running: the update as the trainer runs "
+                   f"it; `*_rel` = relative error of the update's MEAN figures (what earlier rounds reported), per-step drift and flipped "
+                   f"clip decisions explain it.  GAE returns: scan kernel")
     out = {k: (float(f"{v:.3e}") if isinstance(v, float) else v) for k, v in out.items()}
     return base, out
+
+
+def c3_parity_record(state, envs=8, steps=NUM_STEPS):
+    """Whole-update parity of the ResNet18 + 2-layer LSTM policy (BASELINE.json configs[2]) on a BOUNDED sample: `envs` x 128 steps of
+    256x256 RGB-D, E = 2 x M = 2 -> 4 minibatch steps of envs / 2 x 128 frames (the CPU oracle needs ~20 s per 1000 frames of
+    forward + backward), from the parameters the c3 sub-record's cycles left (`state`).  RunningMeanAndVar updates every step."""
+    import torch
+    trainer, cfg = make_trainer("c3", 2, envs=envs, steps=steps)
+    trainer._init_train()
+    trainer._agent.actor_critic.load_state_dict(state)
+    t0 = time.perf_counter()
+    _, par = cpu_baseline_and_parity(trainer, cfg, sample_envs=envs, sample_steps=steps, workload="c3")
+    par["oracle_and_hip_seconds"] = round(time.perf_counter() - t0, 1)
+    par["sample"] = f"{envs} envs x {steps} steps (bounded: the full 64 x 128 update takes the CPU oracle ~6 min)"
+    trainer.envs.close()
+    del trainer
+    torch.cuda.empty_cache()
+    return par
 
 
 def encoder_record(frames=4096, calls=2):
@@ -361,8 +346,9 @@ def phase_record(rollout_ms, cycle_ms, ppo):
                    "(GAE, E x M minibatch passes, Adam, statistics)"}
 
 
-def run_cycles(workload, steps, warmup):
-    """A second workload inside the same run (sub-record): (env-steps/s, ms per cycle)."""
+def run_cycles(workload, steps, warmup, keep_state=None):
+    """A second workload inside the same run (sub-record): (env-steps/s, ms per cycle).  keep_state: dict that receives a CPU copy of
+    the policy's state_dict as the cycles left it (the c3 parity leg starts from it)."""
     import torch
     trainer, cfg = make_trainer(workload, warmup + steps + 1)
     trainer._init_train()
@@ -378,6 +364,8 @@ def run_cycles(workload, steps, warmup):
     dt = time.perf_counter() - t0
     n = trainer.num_steps_done - s0
     trainer.envs.close()
+    if keep_state is not None:
+        keep_state.update({k: v.detach().cpu().clone() for k, v in trainer._agent.actor_critic.state_dict().items()})
     rec = {"workload": WORKLOADS[workload]["name"], "value": round(n / dt, 1), "unit": "env-steps/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(dt / steps * 1e3, 2), "phases": phase_record(rollout_ms(steps), dt / steps * 1e3, cfg.habitat_baselines.rl.ppo),
            "frac_of_mfma_roofline": round(n / dt * 2.2632e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if workload == "c3" else None,
@@ -606,7 +594,12 @@ def main():
         del trainer, eng
         torch.cuda.empty_cache()
         if not a.no_extras:
-            out["c3"] = run_cycles("c3", 10, 2)
+            c3_state = {}
+            out["c3"] = run_cycles("c3", 10, 2, keep_state=c3_state)
+            if par:
+                out["c3"]["parity"] = c3_parity_record(c3_state)
+            del c3_state
+            out["c5"] = run_cycles("c5", 3, 1)  # BASELINE.json configs[4], per GPU
             out["encoder_r18_b8192"] = encoder_record()
     if world > 1:
         out["note"] = ("n_gpus > 1: `cpu_baseline`, `parity`, the per-site `kernels` table and the c3 / encoder sub-records are reported by the "

@@ -577,11 +577,13 @@ def gather_minibatch(buffers: dict, advantages, inds, num_steps):
 
 
 def ppo_update(params: Params, spec: NetSpec, buffers: dict, num_steps: int, cfg, opt_state: dict,
-               trainable: List[str], perms: Optional[List[List[torch.Tensor]]] = None, record=None):
+               trainable: List[str], perms: Optional[List[List[torch.Tensor]]] = None, record=None, pre_step=None):
     """PPO.update rl/ppo/ppo.py:301-332 + _update_from_batch :164-299 on `buffers` (dict of (T+1,N,..)
     tensors incl. 'returns').  `params` holds leaf tensors (requires_grad for names in `trainable`).
     opt_state: {'step': int, 'm': {name: t}, 'v': {name: t}}.  Updates params in place, returns the
-    averaged learner metrics like the reference does."""
+    averaged learner metrics like the reference does.  `pre_step(k, epoch, inds, params, opt_state)` (optional) is called
+    before minibatch step k touches anything: the teacher-forced parity leg (oracle/parity.py) snapshots the state there;
+    `record` (optional list) receives every step's scalars and per-frame values / log-probs."""
     adv = get_advantages(buffers["returns"], buffers["value_preds"], cfg.use_normalized_advantage)
     metrics: Dict[str, list] = {}
     # adaptive entropy penalty (ppo.py:85-103): alpha is one more Adam parameter (same lr / eps), not clipped (ppo.py:361-364),
@@ -596,6 +598,8 @@ def ppo_update(params: Params, spec: NetSpec, buffers: dict, num_steps: int, cfg
     for epoch in range(cfg.ppo_epoch):
         chunks = perms[epoch] if perms is not None else minibatch_env_indices(N, cfg.num_mini_batch)
         for inds in chunks:
+            if pre_step is not None:
+                pre_step(opt_state["step"], epoch, inds, params, opt_state)
             batch = gather_minibatch(buffers, adv, inds, num_steps)
             for n in trainable:
                 params[n].grad = None
@@ -626,7 +630,11 @@ def ppo_update(params: Params, spec: NetSpec, buffers: dict, num_steps: int, cfg
                     params[pre + "_mean"], params[pre + "_var"], params[pre + "_count"] = rmv["mean"], rmv["var"], rmv["count"]
             if record is not None:
                 record.append(dict(total=total.detach(), value_loss=vl.detach(), action_loss=al.detach(),
-                                   dist_entropy=de.detach(), grad_norm=gnorm.detach(), inds=inds.clone()))
+                                   dist_entropy=de.detach(), grad_norm=gnorm.detach(), inds=inds.clone(), epoch=epoch,
+                                   values=values.detach().float().view(-1).clone(), log_probs=logp.detach().view(-1).clone(),
+                                   # scale of the action loss: the mean magnitude of the clipped surrogate (the loss itself is a
+                                   # mean near zero under normalised advantages, so errors are quoted against this)
+                                   surrogate_abs_mean=(batch["advantages"] * ratio.detach()).abs().mean()))
             v = values.detach().float()
             for name, op in (("min", torch.min), ("mean", torch.mean), ("max", torch.max)):
                 rec(f"value_pred_{name}", op(v))

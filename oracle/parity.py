@@ -226,3 +226,201 @@ def returns_parity(storage, next_value: torch.Tensor, use_gae: bool, gamma: floa
     T = storage.current_rollout_step_idx
     r, _ = O.compute_returns(B["rewards"].cpu(), B["value_preds"].cpu(), B["masks"].cpu(), next_value.cpu().view(-1, 1), T, use_gae, gamma, tau)
     return rel(B["returns"].cpu().numpy()[:T], r.numpy()[:T])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Whole-update parity: teacher-forced (every minibatch step of the HIP path starts from the ORACLE's pre-step state) and free-running
+# ---------------------------------------------------------------------------------------------------------------------------------
+def oracle_rollout(params: dict, spec: O.NetSpec, N: int, T: int, H: int, W: int, hidden: int, hidden_layers: int, cfg, seed: int = 4242):
+    """The oracle collects one rollout of N synthetic envs x T steps (oracle/synth.py observations, policy.act per step with a fixed
+    exponential-noise stream: rl/ppo/ppo_trainer.py:343-399), bootstraps the value of step T and computes the GAE returns
+    (common/rollout_storage.py:174-205).  Returns (buffers shaped like RolloutStorage.buffers, next_value, the E x M env-column
+    permutations of the update, seconds spent generating observations)."""
+    import time as _t
+    from . import synth
+    from .fixtures import synth_rollout_inputs
+    t0 = _t.perf_counter()
+    envs = synth.SyntheticEnvs(N, H, W, seed=seed)
+    obs, rew, done = synth_rollout_inputs(envs, T)
+    t_env = _t.perf_counter() - t0
+    torch.manual_seed(7)
+    noise = torch.stack([torch.empty(N, 4).exponential_(1) for _ in range(T)])
+    perms = [list(torch.randperm(N).chunk(cfg.num_mini_batch)) for _ in range(cfg.ppo_epoch)]
+    buf = dict(observations={k: torch.from_numpy(np.stack([o[k] for o in obs])) for k in obs[0]})
+    del obs
+    buf["recurrent_hidden_states"] = torch.zeros(T + 1, N, hidden_layers, hidden)
+    buf["rewards"] = torch.zeros(T + 1, N, 1)
+    buf["rewards"][:T] = torch.from_numpy(rew).unsqueeze(-1)
+    buf["masks"] = torch.zeros(T + 1, N, 1, dtype=torch.bool)
+    buf["masks"][1:] = torch.from_numpy(~done).unsqueeze(-1)
+    for k in ("value_preds", "action_log_probs"):
+        buf[k] = torch.zeros(T + 1, N, 1)
+    buf["actions"] = torch.zeros(T + 1, N, 1, dtype=torch.long)
+    buf["prev_actions"] = torch.zeros(T + 1, N, 1, dtype=torch.long)
+    with torch.no_grad():
+        for t in range(T):
+            r = O.act(params, spec, {k: v[t] for k, v in buf["observations"].items()}, buf["recurrent_hidden_states"][t],
+                      buf["prev_actions"][t], buf["masks"][t], exp_noise=noise[t])
+            buf["actions"][t], buf["action_log_probs"][t], buf["value_preds"][t] = r["actions"], r["action_log_probs"], r["values"]
+            buf["recurrent_hidden_states"][t + 1], buf["prev_actions"][t + 1] = r["rnn_hidden_states"], r["actions"]
+        feats, _ = O.net_forward(params, spec, {k: v[T] for k, v in buf["observations"].items()}, buf["recurrent_hidden_states"][T],
+                                 buf["prev_actions"][T], buf["masks"][T])
+        nv = O.heads(params, feats)[2]
+    buf["returns"], buf["value_preds"] = O.compute_returns(buf["rewards"], buf["value_preds"], buf["masks"], nv, T, True, cfg.gamma, cfg.tau)
+    return buf, nv, perms, t_env
+
+
+def storage_from_oracle(buf: dict, next_value, T: int, N: int, observation_space, action_space, policy, device, cfg):
+    """A device RolloutStorage holding the oracle's rollout `buf`; the returns are recomputed by the device GAE (scan variant, the
+    one the timed cycles use) from the oracle's value predictions."""
+    from habitat_amd.common.rollout_storage import RolloutStorage
+    st = RolloutStorage(T, N, observation_space, action_space, policy, device=device, gae_variant="scan")
+    B = st.buffers
+    for k, v in buf["observations"].items():
+        B["observations"][k].copy_(v)
+    for k in ("actions", "prev_actions", "action_log_probs", "rewards", "masks", "recurrent_hidden_states", "value_preds"):
+        B[k].copy_(buf[k])
+    st.current_rollout_step_idxs = [T]
+    st.compute_returns(next_value.to(device), True, cfg.gamma, cfg.tau)
+    return st
+
+
+def oracle_update_trace(params: dict, spec: O.NetSpec, buf: dict, T: int, cfg, trainable, perms):
+    """Runs O.ppo_update (rl/ppo/ppo.py:301-332) from `params` with fresh Adam moments and keeps, for every minibatch step k, the
+    state the step STARTED from (parameters + buffers, Adam moments, step count, env columns) and what it produced (loss scalars,
+    gradient norm, per-frame values / log-probs).  Returns (averaged metrics, trace); trace[k]["after"] is the parameter state
+    the step left (= trace[k + 1]["params"], or the final parameters for the last step)."""
+    p = {k: (v.clone().requires_grad_(True) if k in trainable else v.clone()) for k, v in params.items()}
+    opt = dict(step=0, m={k: torch.zeros_like(p[k]) for k in trainable}, v={k: torch.zeros_like(p[k]) for k in trainable})
+    trace, record = [], []
+
+    def pre_step(step, epoch, inds, pp, oo):
+        trace.append(dict(step=int(step), epoch=int(epoch), inds=inds.clone(), params={k: v.detach().clone() for k, v in pp.items()},
+                          m={k: v.clone() for k, v in oo["m"].items()}, v={k: v.clone() for k, v in oo["v"].items()}))
+
+    metrics = O.ppo_update(p, spec, buf, T, cfg, opt, list(trainable), perms=perms, record=record, pre_step=pre_step)
+    final = {k: v.detach().clone() for k, v in p.items()}
+    for k, (tr, rc) in enumerate(zip(trace, record)):
+        tr.update({q: float(rc[q]) for q in ("value_loss", "action_loss", "dist_entropy", "grad_norm", "total", "surrogate_abs_mean")})
+        tr["values"], tr["log_probs"] = rc["values"], rc["log_probs"]
+        tr["after"] = trace[k + 1]["params"] if k + 1 < len(trace) else final
+    return metrics, trace, final
+
+
+def _clip_decisions(values, log_probs, batch, clip):
+    """Which branch of the two `min` / `where` selections of the PPO loss (rl/ppo/ppo.py:212-236) every frame takes: (the clipped
+    surrogate is the active one, the value prediction is clipped)."""
+    ratio = torch.exp(log_probs.view(-1, 1) - batch["action_log_probs"])
+    s1 = batch["advantages"] * ratio
+    s2 = batch["advantages"] * torch.clamp(ratio, 1.0 - clip, 1.0 + clip)
+    return (s2 < s1).view(-1), ((values.view(-1, 1) - batch["value_preds"]).abs() >= clip).view(-1)
+
+
+def _load_step_state(policy, upd, tr, lr_group=None):
+    """Oracle pre-step state -> engine: parameters + buffers through load_state_dict (re-packs the kernel-side weight images),
+    Adam moments scattered into the flat arenas at the engine's parameter offsets, step count."""
+    policy.load_state_dict(tr["params"])
+    opt = upd.optimizer
+    opt.exp_avg.zero_()
+    opt.exp_avg_sq.zero_()
+    for nm, shp, off in policy.engine.specs:
+        if nm in tr["m"]:
+            n = tr["m"][nm].numel()
+            opt.exp_avg[off:off + n].copy_(tr["m"][nm].reshape(-1))
+            opt.exp_avg_sq[off:off + n].copy_(tr["v"][nm].reshape(-1))
+    opt.step_count = tr["step"]
+
+
+def update_parity(policy, upd, storage, buf: dict, trace, final, T: int, cfg, trainable, bar: float = 1e-4) -> Dict[str, object]:
+    """The HIP update against the oracle's trace of the SAME update (same rollout arena `storage` == `buf`, same permutations).
+
+    teacher_forced: for every minibatch step k the engine is loaded with the oracle's pre-step parameters, buffers and Adam moments,
+    runs ONE step (evaluate -> loss -> backward -> clip + Adam) on the same env columns, and is compared on: value loss, action
+    loss (absolute error over the mean |clipped surrogate| -- the loss itself is a mean near zero), entropy, gradient norm (all
+    relative), the parameter STEP it took (max |step_hip - step_oracle| in units of lr, and L2-relative), per-frame values /
+    log-probs, and the number of frames whose ratio-clip / value-clip branch differs.  Nothing a step does can leak into the next
+    comparison, so a defect that only shows after step 1 (moments, bias correction, statistics) is caught, chaos is not amplified.
+
+    free_running: the update as the trainer runs it, from the common start; per step the same figures plus how far the parameters
+    had already drifted from the oracle's before the step."""
+    from habitat_amd.common.rollout_storage import MiniBatch
+    from habitat_amd.rl.ppo.ppo import SLOT_WIDTH
+    dev = storage.device
+    N = storage._num_envs
+    adv_dev = upd.get_advantages(storage)
+    adv_cpu = O.get_advantages(buf["returns"], buf["value_preds"], cfg.use_normalized_advantage)
+    dones = torch.logical_not(storage.buffers["masks"]).cpu().view(-1, N).numpy()
+    lr = float(cfg.lr)
+
+    def one_step(tr, slot):
+        batch = MiniBatch(storage, tr["inds"], T, adv_dev, dones)
+        upd._update_from_batch(batch, tr["epoch"], storage, slot)
+        Bn = T * len(tr["inds"])
+        return upd._wk["v"][:Bn].clone(), upd._wk["lp"][:Bn].clone()
+
+    def compare(tr, slot, v, lp, before, after_ref):
+        h = slot.cpu().double()
+        take = lambda t: t[0:T, tr["inds"]].flatten(0, 1)  # (O.gather_minibatch without the observations: ~1 GB per step at C2's shape)
+        ob = {"action_log_probs": take(buf["action_log_probs"]), "value_preds": take(buf["value_preds"]), "advantages": take(adv_cpu)}
+        v, lp = v.cpu(), lp.cpu()
+        r = {"value_loss_rel": abs(h[0].item() - tr["value_loss"]) / max(1e-6, abs(tr["value_loss"])),
+             "action_loss_err_over_surrogate": abs(h[1].item() - tr["action_loss"]) / max(1e-6, tr["surrogate_abs_mean"]),
+             "dist_entropy_rel": abs(h[2].item() - tr["dist_entropy"]) / max(1e-6, abs(tr["dist_entropy"])),
+             "grad_norm_rel": abs(h[12].item() - tr["grad_norm"]) / max(1e-6, abs(tr["grad_norm"])),
+             "value_max_rel": rel(v.numpy(), tr["values"].numpy()), "log_prob_max_rel": rel(lp.numpy(), tr["log_probs"].numpy())}
+        d_hip = _clip_decisions(v, lp, ob, cfg.clip_param)
+        d_ref = _clip_decisions(tr["values"], tr["log_probs"], ob, cfg.clip_param)
+        r["ratio_clip_flips"] = int((d_hip[0] != d_ref[0]).sum())
+        r["value_clip_flips"] = int((d_hip[1] != d_ref[1]).sum())
+        if before is not None:  # the parameter step of this minibatch against the oracle's, from the same starting point
+            sd = policy.state_dict()
+            worst, num, den = 0.0, 0.0, 0.0
+            for k in trainable:
+                s_hip = sd[k].detach().cpu().double() - before[k].double()
+                s_ref = after_ref[k].double() - before[k].double()
+                worst = max(worst, float((s_hip - s_ref).abs().max()))
+                num += float((s_hip - s_ref).pow(2).sum())
+                den += float(s_ref.pow(2).sum())
+            r["param_step_max_err_over_lr"] = worst / lr
+            r["param_step_rel_l2"] = (num / max(den, 1e-300)) ** 0.5
+        return r
+
+    def fold(rows):
+        keys = [k for k in rows[0]]
+        out = {k: [float(f"{r[k]:.3e}") if isinstance(r[k], float) else r[k] for r in rows] for k in keys}
+        return out
+
+    policy.train()
+    # ---- teacher-forced ------------------------------------------------------------------------------------------------------------
+    rows = []
+    slots = torch.zeros(len(trace), SLOT_WIDTH, device=dev)
+    for k, tr in enumerate(trace):
+        _load_step_state(policy, upd, tr)
+        v, lp = one_step(tr, slots[k])
+        rows.append(compare(tr, slots[k], v, lp, tr["params"], tr["after"]))
+    tf = fold(rows)
+    loss_keys = ("value_loss_rel", "action_loss_err_over_surrogate", "dist_entropy_rel")
+    tf["max_rel_losses"] = max(max(tf[k]) for k in loss_keys)
+    tf["max_rel_grad_norm"] = max(tf["grad_norm_rel"])
+    tf["max_rel"] = max(tf["max_rel_losses"], tf["max_rel_grad_norm"])
+    tf["bar"] = bar
+    tf["within_bar"] = bool(tf["max_rel"] <= bar)
+    # ---- free-running ---------------------------------------------------------------------------------------------------------------
+    _load_step_state(policy, upd, trace[0])
+    rows = []
+    slots = torch.zeros(len(trace), SLOT_WIDTH, device=dev)
+    for k, tr in enumerate(trace):
+        sd = policy.state_dict()
+        drift = max(float((sd[q].detach().cpu() - tr["params"][q]).abs().max()) for q in trainable)
+        v, lp = one_step(tr, slots[k])
+        r = compare(tr, slots[k], v, lp, None, None)
+        r["param_max_abs_drift_before_step"] = drift
+        rows.append(r)
+    fr = fold(rows)
+    sd = policy.state_dict()
+    fr["post_update_param_max_abs_diff"] = float(f"{max(float((sd[q].detach().cpu() - final[q]).abs().max()) for q in trainable):.3e}")
+    host = slots.cpu().double()
+    for i, k in ((0, "value_loss"), (1, "action_loss"), (2, "dist_entropy"), (12, "grad_norm")):
+        ref = sum(tr[k] for tr in trace) / len(trace)
+        fr[k + "_rel_of_update_means"] = float(f"{abs(host[:, i].mean().item() - ref) / max(1e-6, abs(ref)):.3e}")
+    return {"steps": len(trace), "teacher_forced": tf, "free_running": fr}

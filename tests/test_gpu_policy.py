@@ -1242,3 +1242,52 @@ def test_synthetic_env_host_path_double_buffered_halves_advance_once():
     keep = [0, 2, 3]
     assert torch.equal(envs._rgb[keep], rgb_before[keep])
     tr.envs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path,extra,size", [
+    ("pointnav/ppo_pointnav_habitat_iccv19.yaml", (), 64),
+    ("pointnav/ddppo_pointnav.yaml", ("habitat_baselines.rl.ddppo.backbone=resnet18",), 64),
+])
+def test_whole_update_teacher_forced_vs_oracle(path, extra, size):
+    """oracle/parity.py::update_parity (the leg bench.py reports at the benchmark shape) on a small trainer built from the YAML
+    entrypoints: the oracle produces a rollout and traces its update; every minibatch step of the HIP updater, restarted from the
+    oracle's pre-step parameters + Adam moments (+ RunningMeanAndVar buffers for the ResNet policy), must reproduce the step's losses
+    to 1e-4 (north_star), its gradient norm to 1e-4 (SimpleCNN) / 1e-3 (GroupNorm encoder on noise inputs: ReLU-boundary flips, see
+    test_resnet_golden_mask_flip_accounting) and its parameter step to a fraction of lr."""
+    import types
+    from oracle import parity as PR
+    N, T = 4, 16
+    trainer = _small_trainer(extra=("habitat_baselines.rl.ppo.num_mini_batch=2", "habitat_baselines.rl.ppo.ppo_epoch=2") + tuple(extra),
+                             N=N, T=T, size=size, path=path)
+    trainer._init_train()
+    trainer.run_update_cycle()  # (not the initial parameters: moments, statistics and clip decisions are exercised from a moved policy)
+    pol = trainer._agent.actor_critic
+    ppo = trainer.config.habitat_baselines.rl.ppo
+    ocfg = types.SimpleNamespace(clip_param=ppo.clip_param, ppo_epoch=ppo.ppo_epoch, num_mini_batch=ppo.num_mini_batch,
+                                 value_loss_coef=ppo.value_loss_coef, entropy_coef=ppo.entropy_coef, lr=ppo.lr, eps=ppo.eps,
+                                 max_grad_norm=ppo.max_grad_norm, use_normalized_advantage=ppo.use_normalized_advantage,
+                                 use_clipped_value_loss=ppo.use_clipped_value_loss, gamma=ppo.gamma, tau=ppo.tau)
+    params = {k: v.detach().cpu().clone() for k, v in pol.state_dict().items()}
+    spec = PR.spec_of(pol)
+    trainable = [k for k, p_ in pol.named_parameters() if p_.requires_grad]
+    buf, nv, perms, _ = PR.oracle_rollout(params, spec, N, T, size, size, pol.recurrent_hidden_size, pol.num_recurrent_layers, ocfg)
+    ref_metrics, trace, final = PR.oracle_update_trace(params, spec, buf, T, ocfg, trainable, perms)
+    assert len(trace) == 4 and [t["step"] for t in trace] == [0, 1, 2, 3]
+    es = trainer._env_spec
+    st = PR.storage_from_oracle(buf, nv, T, N, es.observation_space, es.action_space, pol, trainer.device, ocfg)
+    assert PR.rel(st.buffers["returns"].cpu().numpy()[:T], buf["returns"].numpy()[:T]) <= 1e-5
+    from habitat_amd.rl.ppo import PPO
+    pol.load_state_dict(params)
+    upd = PPO.from_config(pol, ocfg)
+    rep = PR.update_parity(pol, upd, st, buf, trace, final, T, ocfg, trainable)
+    tf, fr = rep["teacher_forced"], rep["free_running"]
+    print(json.dumps(rep))
+    deep = "ddppo" in path
+    assert tf["max_rel_losses"] <= 1e-4, tf
+    assert tf["max_rel_grad_norm"] <= (1e-3 if deep else 1e-4), tf
+    assert max(tf["value_max_rel"]) <= 1e-4 and max(tf["log_prob_max_rel"]) <= 1e-4, tf
+    assert max(tf["param_step_max_err_over_lr"]) <= (0.5 if deep else 0.05), tf  # (Adam's first steps: g / (|g| + eps) near g = 0)
+    assert fr["param_max_abs_drift_before_step"][0] == 0.0
+    assert fr["post_update_param_max_abs_diff"] <= 4 * ocfg.lr
+    trainer.envs.close()

@@ -437,3 +437,37 @@ def test_oracle_forward_on_odd_geometries_vs_live_reference(H, W, backbone):
     assert feats.shape == feats_ref.shape and rel(feats, feats_ref) < 1e-5, rel(feats, feats_ref)
     assert rel(hid, hid_ref) < 1e-5
     assert rel(value, value_ref) < 1e-5 and float((logits - logits_ref).abs().max()) < 1e-5
+
+
+def test_update_trace_is_the_update():
+    """oracle/parity.py::oracle_update_trace (what the teacher-forced parity leg of bench.py replays on the GPU): same metrics and
+    final parameters as a plain O.ppo_update, every step's `after` state is the next step's starting state, the snapshots are
+    copies (not views of the live parameters), Adam moments of step k are the ones step k starts from."""
+    import types
+    from oracle import parity as PR
+    from oracle.fixtures import baseline_param_shapes, det_params
+    H = W = 44
+    N, T, hidden = 4, 6, 32
+    params = det_params(baseline_param_shapes(4, H, W, hidden), 11)
+    spec = O.NetSpec(kind="baseline", hidden=hidden)
+    cfg = types.SimpleNamespace(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, value_loss_coef=0.5, entropy_coef=0.01, lr=2.5e-4, eps=1e-5,
+                                max_grad_norm=0.5, use_normalized_advantage=True, use_clipped_value_loss=True, gamma=0.99, tau=0.95)
+    buf, nv, perms, _ = PR.oracle_rollout(params, spec, N, T, H, W, hidden, 1, cfg, seed=5)
+    assert buf["returns"].shape == (T + 1, N, 1) and nv.shape == (N, 1)
+    trainable = list(params.keys())
+    metrics, trace, final = PR.oracle_update_trace(params, spec, buf, T, cfg, trainable, perms)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    opt = dict(step=0, m={k: torch.zeros_like(v) for k, v in p.items()}, v={k: torch.zeros_like(v) for k, v in p.items()})
+    plain = O.ppo_update(p, spec, buf, T, cfg, opt, trainable, perms=perms)
+    assert plain == metrics
+    assert len(trace) == 4
+    for k, tr in enumerate(trace):
+        assert tr["step"] == k and tr["epoch"] == k // 2 and torch.equal(tr["inds"], perms[k // 2][k % 2])
+        nxt = trace[k + 1]["params"] if k + 1 < 4 else final
+        assert all(torch.equal(tr["after"][q], nxt[q]) for q in trainable)
+        assert any(not torch.equal(tr["params"][q], tr["after"][q]) for q in trainable)  # a snapshot, and the step moved something
+        assert tr["values"].shape == (T * 2,) and tr["surrogate_abs_mean"] > 0
+    assert all(torch.equal(trace[0]["params"][q], params[q]) for q in trainable)
+    assert all(float(trace[0]["m"][q].abs().max()) == 0.0 for q in trainable) and any(float(trace[1]["m"][q].abs().max()) > 0 for q in trainable)
+    assert all(torch.equal(final[q], p[q].detach()) for q in trainable)
+    assert abs(sum(t["value_loss"] for t in trace) / 4 - metrics["value_loss"]) <= 1e-6 * abs(metrics["value_loss"])
