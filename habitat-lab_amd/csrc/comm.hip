@@ -140,7 +140,10 @@ extern "C" int hab_policy_set_comm(hab_policy* e, hab_comm* c) {
     if (!e) return HAB_ERR_ARG;
     e->comm = c;
     e->comm_first = -1;
-    if (c) e->world_size = c->world;
+    e->comm_err = HAB_OK;
+    // cleared: back to one rank until hab_policy_set_allreduce installs the callback form with its own world size (the RunningMeanAndVar
+    // divisor must not keep the old communicator's)
+    e->world_size = c ? c->world : 1;
     return HAB_OK;
 }
 
@@ -150,6 +153,7 @@ extern "C" int hab_policy_set_comm(hab_policy* e, hab_comm* c) {
 extern "C" int hab_policy_grad_sync(hab_policy* e, hipStream_t stream) {
     if (!e || !e->G) return HAB_ERR_ARG;
     if (!e->comm) return HAB_ERR_UNSUPPORTED;
+    if (e->comm_err != HAB_OK) { const int rc = e->comm_err; e->comm_err = HAB_OK; e->comm_first = -1; return rc; }
     const int64_t head = e->comm_first < 0 ? e->param_floats : e->comm_first;
     e->comm_first = -1;
     HAB_TRY(comm_exchange_async(e->comm, e->G, 0, head, stream));

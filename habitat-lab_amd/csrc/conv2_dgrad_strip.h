@@ -130,6 +130,18 @@ __global__ void __launch_bounds__(512) conv2_dgrad_strip_kernel(const C2dArgs a)
             // dY pixel of cell li under this wave's tap: row (h2 - a) - (h20 - 1) = tr + 1 - ta, column (w2 - b) + 1 = li + 1 - tb
             const int pixidx = (tr + 1 - ta) * Cfg::YCOLS + li + 1 - tb;
             const int swz = (pixidx >> 1) & 7;
+            // ReLU-mask quads of this tile row, requested BEFORE its MFMAs: the epilogue sits behind two barriers, and a load issued
+            // there was a full HBM round trip in front of every store (one workgroup per CU: nothing else to run meanwhile)
+            f32x4 mk[2];
+            if (a.mask) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int idx = t + q * NT, rph = idx >> 9, cell = (idx >> 4) & 31, cq = idx & 15;
+                    const int h = 2 * (h20 + tr) + rph, w = 2 * cell + (cq >> 3);
+                    const bool ok = h < H && w < W;
+                    mk[q] = *reinterpret_cast<const f32x4*>(a.mask + (ok ? (((size_t)img * H + h) * W + w) * 32 + (cq & 7) * 4 : (size_t)0));
+                }
+            }
             f32x16 acc[2];
 #pragma unroll
             for (int pw = 0; pw < 2; ++pw)
@@ -171,7 +183,7 @@ __global__ void __launch_bounds__(512) conv2_dgrad_strip_kernel(const C2dArgs a)
                 if (h < H && w < W) {
                     const size_t off = (((size_t)img * H + h) * W + w) * 32 + (cq & 7) * 4;
                     if (a.mask) {
-                        const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + off);
+                        const f32x4 m = mk[q];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) s[e] = m[e] > 0.f ? s[e] : 0.f;
                     }

@@ -47,6 +47,7 @@ struct hab_policy {
     std::vector<int> i_wih, i_whh, i_bih, i_bhh;
     // packed offsets
     int64_t pk_c1f, pk_c2f, pk_c2d, pk_c3f, pk_c3d, pk_fc;
+    int64_t pk_c1img = -1;  // conv1's bf16 weight image for the patch-resident kernel, rebuilt by every repack (-1: no image for this filter)
     std::vector<int64_t> pk_whht;
     std::vector<int64_t> pk_wiht;  // layers >= 1: W_ih transposed [H][G*H] (layer wavefront BPTT, rnn.hip); entry 0 unused (-1)
     bool last_wave = false;        // the last evaluate ran the recurrent layers as a wavefront (the backward must mirror it)
@@ -75,6 +76,7 @@ struct hab_policy {
     // device-side exchange (comm.hip): when set, the gradient tails and the RunningMeanAndVar moments are all-reduced on this RCCL
     // communicator from inside backward / forward instead of through the two callbacks above
     struct hab_comm* comm = nullptr;
+    int comm_err = 0;                                   // first error of a tail exchange of the current backward (HAB_OK: none)
     int64_t comm_first = -1;                            // grads[comm_first ..) has been enqueued for exchange in this backward (-1: nothing)
     hipStream_t cur_stream = nullptr;                   // stream of the running hab_policy_backward
     // probe
@@ -102,6 +104,8 @@ inline int add_param(hab_policy* e, const std::string& name, std::initializer_li
 }
 
 
+int tm_chunks_cfg();         // time chunks of the time-major recurrence (HAB_RNN_CHUNKS; 0 / 1: packed form / one chunk)
+int tm_chunks_resnet_cfg();  // ... for the ResNet policies (HAB_RNN_CHUNKS_RESNET, default 0 = packed)
 int build_resnet(hab_policy* e);
 void destroy_resnet(hab_policy* e);
 int resnet_repack(hab_policy* e, hipStream_t s);

@@ -66,6 +66,7 @@ static int build_baseline(hab_policy* e) {
 
     Arena pk;
     e->pk_c1f = pk.take(32 * 64 * (blind ? 4 : e->Cin));
+    e->pk_c1img = (!blind && e->Cin == 4) ? pk.take(obs_conv_weight_image_floats()) : -1;
     e->pk_c2f = pk.take(64 * 16 * 32);
     e->pk_c2d = pk.take(64 * 16 * 32);
     e->pk_c3f = pk.take(32 * 9 * 64);
@@ -166,9 +167,15 @@ extern "C" int hab_policy_set_grad_ready(hab_policy* e, hab_grad_ready_fn fn, vo
 // Everything from parameter `first_param` to the end of the gradient arena has been written (enqueued) for this backward.
 void grad_tail_ready(hab_policy* e, int first_param) {
     if (e->comm) {  // device-side exchange: this tail goes out on the communicator's stream now, beside the rest of backward
+        // HAB_NO_GRAD_OVERLAP=1 (rl/ddppo/ddppo.py): nothing is sent early, hab_policy_grad_sync exchanges the whole arena in one message
+        static const bool no_overlap = hab_env_flag("HAB_NO_GRAD_OVERLAP");
+        if (no_overlap || e->comm_err != HAB_OK) return;
         const int64_t first = e->g(first_param) - e->G;
         const int64_t end = e->comm_first < 0 ? (int64_t)e->param_floats : e->comm_first;
-        if (first < end && comm_exchange_async(e->comm, e->G, first, end - first, e->cur_stream) == HAB_OK) e->comm_first = first;
+        if (first >= end) return;
+        const int rc = comm_exchange_async(e->comm, e->G, first, end - first, e->cur_stream);
+        if (rc == HAB_OK) e->comm_first = first;
+        else e->comm_err = rc;  // surfaced by hab_policy_backward / hab_policy_grad_sync
         return;
     }
     if (!e->grad_ready_cb) return;
@@ -205,6 +212,10 @@ extern "C" int hab_policy_repack(hab_policy* e, hipStream_t stream) {
         return HAB_OK;
     }
     HAB_TRY(repack_conv(e->p(e->i_c1w), e->PK + e->pk_c1f, nullptr, 32, e->Cin, 8, 8, e->Cin, stream));
+    if (e->pk_c1img >= 0) {  // (was one launch in front of EVERY conv1 call: 12 -> 11 launches per rollout step)
+        const int rc = obs_conv_weight_image(e->PK + e->pk_c1f, 32, 8, 8, e->Cin, e->PK + e->pk_c1img, stream);
+        if (rc != HAB_OK) return rc == 1 ? HAB_ERR_UNSUPPORTED : rc;
+    }
     HAB_TRY(repack_conv(e->p(e->i_c2w), e->PK + e->pk_c2f, e->PK + e->pk_c2d, 64, 32, 4, 4, 32, stream));
     HAB_TRY(repack_conv(e->p(e->i_c3w), e->PK + e->pk_c3f, e->PK + e->pk_c3d, 32, 64, 3, 3, 64, stream));
     HAB_TRY(repack_flatten(e->p(e->i_fcw), e->PK + e->pk_fc, H, 32, e->fc_in / 32, stream));
@@ -280,7 +291,7 @@ static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
     ConvDesc c1 = e->c1, c2 = e->c2, c3 = e->c3;
     c1.B = c2.B = c3.B = nB;
     { Probe pr(e, HAB_PROBE_CONV1_FWD, s);
-      HAB_TRY(obs_conv_fwd(c1, ov, e->PK + e->pk_c1f, e->p(e->i_c1b), a1, 1, ws, e->ws_floats, s)); }
+      HAB_TRY(obs_conv_fwd(c1, ov, e->PK + e->pk_c1f, e->p(e->i_c1b), a1, 1, ws, e->ws_floats, s, e->pk_c1img >= 0 ? e->PK + e->pk_c1img : nullptr)); }
     { Probe pr(e, HAB_PROBE_CONV2_FWD, s);
       HAB_TRY(conv_fwd(c2, a1, e->PK + e->pk_c2f, e->p(e->i_c2b), a2, 1, ws, e->ws_floats, s)); }
     { Probe pr(e, HAB_PROBE_CONV3_FWD, s);
@@ -293,7 +304,7 @@ static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
 }
 
 // ---- time-major chunked recurrence: second stream + events ----
-static int tm_chunks_cfg() { static const int v = hab_env_int("HAB_RNN_CHUNKS", 4); return v; }
+int tm_chunks_cfg() { static const int v = hab_env_int("HAB_RNN_CHUNKS", 4); return v; }
 // ResNet policies: built, bit-identical to the packed form at one chunk (tests/test_gpu_determinism.py), and measured SLOWER on the C3
 // benchmark (ResNet18 + 2-layer LSTM, 32 environments per minibatch): 28.5 k env-steps/s with 1, 2 or 3 chunks against 29.1 k packed on the
 // same box.  The packed form walks max_len ~ 107 steps of the ~215 episode fragments, the time-major form all T = 128 steps of 32 rows --
@@ -301,7 +312,7 @@ static int tm_chunks_cfg() { static const int v = hab_env_int("HAB_RNN_CHUNKS", 
 // quarter of the frames; and the encoder's weight gradients reduce over all frames, so the backward cannot follow chunk by chunk the way
 // SimpleCNN's data-gradient chain does.  Default: packed (0); HAB_RNN_CHUNKS_RESNET = k > 0 selects k chunks (HAB_RNN_CHUNKS = 0 / 1 still
 // selects the packed form / one chunk for both policies).
-static int tm_chunks_resnet_cfg() {
+int tm_chunks_resnet_cfg() {
     static const int v = hab_env_int("HAB_RNN_CHUNKS_RESNET", 0);
     const int base = tm_chunks_cfg();
     return base <= 1 ? base : v;
@@ -572,11 +583,12 @@ extern "C" int hab_policy_final_hidden(hab_policy* e, float* hidden_out, hipStre
 // Backward of the last hab_policy_evaluate: given dL/dvalue, dL/dlog_prob, dL/dentropy per frame,
 // writes EVERY parameter gradient into the gradient arena (overwrites; no accumulation).
 // ------------------------------------------------------------------------------------------
-extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int* rows, const int64_t* actions,
-                                   const hab_pack_info* pack, const float* d_value, const float* d_log_prob,
-                                   const float* d_entropy, hipStream_t stream) {
+static int policy_backward_impl(hab_policy* e, const hab_obs* obs, const int* rows, const int64_t* actions,
+                                const hab_pack_info* pack, const float* d_value, const float* d_log_prob,
+                                const float* d_entropy, hipStream_t stream) {
     if (!e || !e->P || !e->G || !obs || !actions || !pack || !d_value || !d_log_prob || !d_entropy || e->last_B <= 0)
         return HAB_ERR_ARG;
+    e->comm_err = HAB_OK;
     float* W = e->WK;
     float* ws = W + e->w_ws;
     const int H = e->d.hidden, L = e->L, B = e->last_B, A = e->d.num_actions;
@@ -761,6 +773,14 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
     { Probe pr(e, HAB_PROBE_CONV1_WGRAD, stream);
       HAB_TRY(obs_conv_wgrad(c1, ov, W + e->w_da1, e->g(e->i_c1w), e->g(e->i_c1b), ws, e->ws_floats, stream)); }
     return HAB_OK;
+}
+// A tail exchange that failed to enqueue (event / stream-wait / ncclAllReduce error inside grad_tail_ready) is this call's error: the
+// rank would otherwise go on to issue a different sequence of collectives than its peers.
+extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int* rows, const int64_t* actions,
+                                   const hab_pack_info* pack, const float* d_value, const float* d_log_prob,
+                                   const float* d_entropy, hipStream_t stream) {
+    const int rc = policy_backward_impl(e, obs, rows, actions, pack, d_value, d_log_prob, d_entropy, stream);
+    return (rc == HAB_OK && e && e->comm_err != HAB_OK) ? e->comm_err : rc;
 }
 
 // Debug / test taps into the activation workspace of the last evaluate.

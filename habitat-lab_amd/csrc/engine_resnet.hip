@@ -348,10 +348,14 @@ int build_resnet(hab_policy* e) {
     e->w_ws = wk.take(e->ws_floats);
     // second stream of the time-major chunked recurrence (engine.hip): its own split-K scratch (same cap: the split-K plans, hence the
     // bits, must not depend on the stream), the dense per-frame episode-start mask, an iota
-    e->ws2_floats = e->ws_floats;
-    e->w_ws2 = wk.take(e->ws2_floats);
-    e->w_fmask = wk.take((B + 3) / 4 + 64);
-    e->w_iota = wk.take(B + 64);
+    // -- only when that form is selected (default for ResNet policies: packed; measured slower, engine.hip): every ResNet engine, incl. each
+    // VER inference worker's private one, would otherwise carry 128 MB + 5 bytes per frame for nothing (w_ws2 < 0 keeps the packed form)
+    if (tm_chunks_resnet_cfg() > 0) {
+        e->ws2_floats = e->ws_floats;
+        e->w_ws2 = wk.take(e->ws2_floats);
+        e->w_fmask = wk.take((B + 3) / 4 + 64);
+        e->w_iota = wk.take(B + 64);
+    }
     e->work_floats = wk.used;
     return HAB_OK;
 }

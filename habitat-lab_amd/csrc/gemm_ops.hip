@@ -150,12 +150,16 @@ int conv_fwd(const ConvDesc& d, const float* x, const float* wf, const float* bi
     }
     return run_igemm(p, ws, ws_floats, stream);
 }
+int64_t obs_conv_weight_image_floats() { return ((int64_t)OCP_W_ELEMS + 1) / 2 + 4; }
+int obs_conv_weight_image(const float* wf, int Cout, int KH, int KW, int C, void* img, hipStream_t stream) {
+    return obs_conv_patch_weight_image(wf, Cout, KH, KW, C, reinterpret_cast<unsigned short*>(img), stream);
+}
 int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const float* bias, float* y, int relu, float* ws,
-                 size_t ws_floats, hipStream_t stream) {
+                 size_t ws_floats, hipStream_t stream, const void* wimg) {
     ObsConvFwdProb p;
     HAB_TRY(build(p, d, obs, wf, bias, y, relu));
     if ((bf3_mode() & 64) && (bf3_mode() & 2) && p.quad) {  // observation patch resident in LDS (obs_conv_patch.h): 8x8 / 4 RGB-D -> 32 only
-        const int rc = obs_conv_patch_launch(p, ws, ws_floats, stream);
+        const int rc = obs_conv_patch_launch(p, ws, ws_floats, stream, reinterpret_cast<const unsigned short*>(wimg));
         if (rc != 1) return rc;
     }
     if ((bf3_mode() & 32) && (bf3_mode() & 2) && p.quad && p.M > 64) {  // producer / consumer waves (obs_conv_bf3_ws.h): 133 -> 148-152 TFLOP/s-eq at 1024 frames

@@ -148,7 +148,14 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_bf3_kernel(const P p, const
             kz = blockIdx.x / ntiles;
         }
     }
-    const int tile_n = tile % nt_n, tile_m = tile / nt_n;
+    // Which coordinate runs fastest inside an XCD's contiguous run of tiles decides which operand that XCD's L2 fetches once: with
+    // tile_n fastest an XCD covers a few rows of M-tiles and ALL column tiles (every XCD reads all of B, 1/8 of A: right for the
+    // convolutions, M = pixels >> N = channels); when the COLUMN operand is the large one -- the visual fc's data and weight gradients:
+    // 4 row tiles x 196 column tiles over a 51 MB weight matrix / 205 MB of activations -- tile_m runs fastest, so the row tiles that
+    // share a column block sit on one XCD in consecutive dispatch slots (round 4 counters: 1.69x / 3.5x the algorithmic HBM bytes
+    // with every column block fetched by four XCDs).  A bijection either way; the sign schedule is keyed by tile coordinates.
+    const bool m_fastest = nsplit == 1 && nt_m < nt_n;
+    const int tile_n = m_fastest ? tile / nt_m : tile % nt_n, tile_m = m_fastest ? tile % nt_m : tile / nt_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int k_begin = kz * k_per_split;

@@ -81,7 +81,8 @@ igemm_bf3_ws_kernel(const P p, const int k_per_split, float* __restrict__ partia
         tile = blockIdx.x % ntiles;
         kz = blockIdx.x / ntiles;
     }
-    const int tile_n = tile % nt_n, tile_m = tile / nt_n;
+    const bool m_fastest = nsplit == 1 && nt_m < nt_n;  // the large operand is the column one: see igemm_bf3.h
+    const int tile_n = m_fastest ? tile / nt_m : tile % nt_n, tile_m = m_fastest ? tile % nt_m : tile / nt_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int k_begin = kz * k_per_split;

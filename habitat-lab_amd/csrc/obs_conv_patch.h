@@ -327,13 +327,25 @@ __global__ void __launch_bounds__(512) obs_conv_patch_kernel(const ObsConvFwdPro
     }
 }
 
+// The weight image alone (packed forward weights [N][8][8][4] -> img, OCP_W_ELEMS bf16): what a caller that keeps the weights fixed over
+// many calls builds once.  1: this filter shape has no image.
+inline int obs_conv_patch_weight_image(const float* w_packed, int N, int KH, int KW, int C, unsigned short* img, hipStream_t stream) {
+    if (KH != 8 || KW != 8 || C != 4 || N > 32 || (N & 3) || !w_packed || !img || (reinterpret_cast<uintptr_t>(img) & 15)) return 1;
+    obs_patch_split_weights<<<32, 256, 0, stream>>>(w_packed, N, img);
+    HAB_LAUNCH_CHECK();
+    return HAB_OK;
+}
+
 // returns HAB_OK, an error, or 1 when the problem does not fit this path (caller falls back to the im2col kernels)
-inline int obs_conv_patch_launch(const ObsConvFwdProb& p, float* ws, size_t ws_floats, hipStream_t stream) {
+// wimg_cached: the weight image of p.w built earlier by obs_conv_patch_weight_image (the engine keeps one per optimiser step) or null
+// (built here into the workspace, one more launch per call)
+inline int obs_conv_patch_launch(const ObsConvFwdProb& p, float* ws, size_t ws_floats, hipStream_t stream, const unsigned short* wimg_cached = nullptr) {
     const ConvGeom& g = p.g;
     if (!p.quad || g.KH != 8 || g.KW != 8 || g.stride != 4 || g.pad != 0 || p.N > 32 || (p.N & 3) || p.K != 256 || g.W > 256 || (g.W & 3) || g.Wo > 64 ||
         g.Wo < 1 || p.M <= 0)
         return 1;
-    if (!ws || ws_floats * 4 < (size_t)OCP_W_ELEMS * 2 || (reinterpret_cast<uintptr_t>(ws) & 15)) return 1;
+    if (!wimg_cached && (!ws || ws_floats * 4 < (size_t)OCP_W_ELEMS * 2 || (reinterpret_cast<uintptr_t>(ws) & 15))) return 1;
+    if (reinterpret_cast<uintptr_t>(wimg_cached) & 15) return 1;
     ObsPatchGeom gq;
     gq.W = g.W; gq.H = g.H; gq.Ho = g.Ho; gq.Wo = g.Wo;
     gq.tiles_per_img = cdiv(g.Ho, OCP_TH);
@@ -344,9 +356,13 @@ inline int obs_conv_patch_launch(const ObsConvFwdProb& p, float* ws, size_t ws_f
     gq.patch_elems = OCP_R * g.W * 6 + 64;
     const size_t lds = ((size_t)2 * 32 * OCP_KP + 32 * OCP_DP + 64 + (size_t)2 * gq.patch_elems) * 2;
     if (lds > 160 * 1024) return 1;
-    unsigned short* wimg = reinterpret_cast<unsigned short*>(ws);
-    obs_patch_split_weights<<<32, 256, 0, stream>>>(p.w, p.N, wimg);
-    HAB_LAUNCH_CHECK();
+    const unsigned short* wimg = wimg_cached;
+    if (!wimg) {
+        unsigned short* built = reinterpret_cast<unsigned short*>(ws);
+        obs_patch_split_weights<<<32, 256, 0, stream>>>(p.w, p.N, built);
+        HAB_LAUNCH_CHECK();
+        wimg = built;
+    }
     auto kern = obs_conv_patch_kernel<5>;
     // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
     static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

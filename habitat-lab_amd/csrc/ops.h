@@ -15,8 +15,11 @@ struct ObsView;
 // gemm_ops.hip
 int conv_fwd(const ConvDesc& d, const float* x, const float* wf, const float* bias, float* y, int relu, float* ws,
              size_t ws_floats, hipStream_t stream);
+// wimg: bf16 weight image of wf for the patch-resident kernel (obs_conv_weight_image; obs_conv_weight_image_floats() floats), or null
 int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const float* bias, float* y, int relu, float* ws,
-                 size_t ws_floats, hipStream_t stream);
+                 size_t ws_floats, hipStream_t stream, const void* wimg = nullptr);
+int64_t obs_conv_weight_image_floats();
+int obs_conv_weight_image(const float* wf, int Cout, int KH, int KW, int C, void* img, hipStream_t stream);  // 1: no image for this filter
 int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add, float* dx,
                float* ws, size_t ws_floats, hipStream_t stream);
 int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oihw, float* dbias, float* ws, size_t ws_floats,

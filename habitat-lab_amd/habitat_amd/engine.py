@@ -317,24 +317,38 @@ class PolicyEngine:
 
 
 class NativeComm:
-    """RCCL communicator owned by libhabitat_amd (csrc/comm.hip).  The 128-byte unique id is created by rank 0 and travels through
-    `exchange(list_of_one_object, src)` -- torch.distributed.broadcast_object_list for a process group, identity for one rank."""
+    """RCCL communicator owned by libhabitat_amd (csrc/comm.hip).  The 128-byte unique id is created by rank 0 (`unique_id()`) and
+    handed to every rank as `ident`; for compatibility `exchange(list_of_one_object)` (torch.distributed.broadcast_object_list for a
+    process group, identity for one rank) may carry it instead."""
 
-    def __init__(self, world: int, rank: int, exchange=None):
+    @staticmethod
+    def unique_id() -> bytes:
         L = _lib.lib()
         if not L.hab_comm_available():
             raise _lib.HabError("librccl was not found: no device-side exchange")
-        ident = [None]
-        if rank == 0:
-            buf = (C.c_uint8 * 128)()
-            check(L.hab_comm_unique_id(buf), "hab_comm_unique_id")
-            ident[0] = bytes(buf)
-        if exchange is not None:
-            exchange(ident)
-        raw = (C.c_uint8 * 128).from_buffer_copy(ident[0])
+        buf = (C.c_uint8 * 128)()
+        check(L.hab_comm_unique_id(buf), "hab_comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, world: int, rank: int, exchange=None, ident: bytes = None):
+        L = _lib.lib()
+        if not L.hab_comm_available():
+            raise _lib.HabError("librccl was not found: no device-side exchange")
+        if ident is None:
+            box = [None]
+            if rank == 0:
+                box[0] = NativeComm.unique_id()
+            if exchange is not None:
+                exchange(box)
+            ident = box[0]
+        raw = (C.c_uint8 * 128).from_buffer_copy(ident)
         h = C.c_void_p()
         check(L.hab_comm_create(raw, int(world), int(rank), C.byref(h)), "hab_comm_create")
         self.L, self.h, self.world, self.rank = L, h, int(world), int(rank)
+
+    def world_size(self) -> int:
+        """Ranks of the communicator as the library sees them (hab_comm_world_size)."""
+        return int(self.L.hab_comm_world_size(self.h))
 
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()

@@ -133,15 +133,44 @@ def rank_cpu_block(cpus, local_rank: int, local_world: int):
     return cpus[local_rank * per:(local_rank + 1) * per]
 
 
+def _local_sharers(mask):
+    """World ranks ON THIS HOST whose inherited CPU mask is identical to `mask` (this rank included), ascending -- or None without a
+    process group.  One all_gather_object of (hostname, mask) at start-up."""
+    if not (distrib.is_available() and distrib.is_initialized()):
+        return None
+    import socket
+    mine = (socket.gethostname(), tuple(mask))
+    everyone = [None] * distrib.get_world_size()
+    distrib.all_gather_object(everyone, mine)
+    return [r for r, other in enumerate(everyone) if other == mine]
+
+
 def pin_rank_affinity(local_rank: int, local_world: Optional[int] = None):
     """One process per GPU, each enqueueing ~7 500 launches per update cycle: without pinning, 8 ranks' host threads migrate across the
     sockets of the node and share cores with each other's environment workers.  Restricts this process (and the threads / workers it
-    starts afterwards) to its block of the CPUs it may run on.  HAB_NO_AFFINITY=1 leaves the affinity alone.  Returns the chosen CPUs."""
+    starts afterwards) to its block of the CPUs it may run on -- but ONLY when the mask it inherited is SHARED with other local ranks
+    (torchrun on a whole node).  A launcher that already confined every task to its own CPUs -- SLURM task affinity / cgroups: the
+    reference's README launch gives each of 4 tasks --cpus-per-task 10 -- is left alone: slicing those 10 CPUs by 4 again would leave
+    each rank, and the environment workers that inherit its mask, 2 of them.  Sharing is established by comparing the masks of the
+    ranks on this host (one all_gather_object; without a process group: the mask covers every CPU of the host).
+    HAB_NO_AFFINITY=1 leaves the affinity alone.  Returns the chosen CPUs, or None when nothing was changed."""
     if os.environ.get("HAB_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
         return None
-    if local_world is None:
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("SLURM_NTASKS_PER_NODE", "1")) or 1)
-    block = rank_cpu_block(os.sched_getaffinity(0), local_rank, local_world)
+    mask = sorted(os.sched_getaffinity(0))
+    sharers = _local_sharers(mask)
+    if sharers is not None:
+        if len(sharers) <= 1:
+            return None  # nobody else on this host runs on these CPUs: they are this rank's already
+        me = distrib.get_rank()
+        block = rank_cpu_block(mask, sharers.index(me), len(sharers))
+    else:
+        if len(mask) < (os.cpu_count() or 0):
+            return None  # already confined by the launcher
+        if local_world is None:
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("SLURM_NTASKS_PER_NODE", "1")) or 1)
+        block = rank_cpu_block(mask, local_rank, local_world)
+    if not block or len(block) == len(mask):
+        return None
     try:
         os.sched_setaffinity(0, block)
     except OSError:

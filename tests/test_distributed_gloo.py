@@ -120,10 +120,101 @@ def _worker(rank, world, port, q):
     out["local_rank"] = local_rank
     from habitat_amd.rl.ddppo.ddp_utils import rank_cpu_block
     out["cpus"] = rank_cpu_block(list(range(64)), rank, world)
+    out["affinity"] = _affinity_cases(rank, world)
+    out["native"] = _native_comm_negotiation_cases(rank, world)
     # plain numpy through the queue: a tensor travels as a shared-memory handle that dies with this process
     q.put((rank, {k: (v.numpy().copy() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _affinity_cases(rank, world):
+    """ddp_utils.pin_rank_affinity with the process's mask faked (nothing is really pinned): (a) every rank inherited the same 64
+    CPUs (torchrun on a whole node) -> disjoint blocks; (b) the launcher already gave every rank its own CPUs (SLURM task affinity,
+    ADVICE r04) -> left alone; (c) HAB_NO_AFFINITY."""
+    from habitat_amd.rl.ddppo import ddp_utils
+    res = {}
+    real_get, real_set = os.sched_getaffinity, os.sched_setaffinity
+    chosen = []
+    try:
+        os.sched_setaffinity = lambda pid, cpus: chosen.append(sorted(cpus))
+        os.sched_getaffinity = lambda pid: set(range(64))
+        res["shared"] = ddp_utils.pin_rank_affinity(rank)
+        assert chosen[-1] == res["shared"]
+        os.sched_getaffinity = lambda pid: set(range(10 * rank, 10 * rank + 10))  # --cpus-per-task 10, bound per task
+        n = len(chosen)
+        res["confined"] = ddp_utils.pin_rank_affinity(rank)
+        assert len(chosen) == n  # sched_setaffinity was not called
+        os.environ["HAB_NO_AFFINITY"] = "1"
+        os.sched_getaffinity = lambda pid: set(range(64))
+        res["disabled"] = ddp_utils.pin_rank_affinity(rank)
+        assert len(chosen) == n
+    finally:
+        os.environ.pop("HAB_NO_AFFINITY", None)
+        os.sched_getaffinity, os.sched_setaffinity = real_get, real_set
+    return res
+
+
+class _FakeComm:
+    def __init__(self):
+        self.closed = False
+
+    def close(self):
+        self.closed = True
+
+
+def _native_comm_negotiation_cases(rank, world):
+    """rl/ddppo/ddppo.py::negotiate_native_comm over a real (gloo) process group with injected failures: whatever goes wrong on ONE
+    rank -- librccl missing, the unique id, ncclCommInitRank raising or never returning, the self-test -- every rank ends up without a
+    communicator, nobody hangs, and communicators that were created are closed."""
+    import time
+    from habitat_amd.rl.ddppo.ddppo import negotiate_native_comm
+    last = world - 1
+    made = []
+
+    def create_ok(ident):
+        assert ident == b"id-from-rank-0"
+        made.append(_FakeComm())
+        return made[-1]
+
+    def run(**kw):
+        args = dict(available=lambda: True, make_id=lambda: b"id-from-rank-0", create=create_ok, selftest=lambda c: (True, "fine"), timeout_s=20.0)
+        args.update(kw)
+        t0 = time.monotonic()
+        comm, why = negotiate_native_comm(world, rank, torch.device("cpu"), **args)
+        return comm, why, time.monotonic() - t0
+
+    res = {}
+    comm, why, _ = run()
+    assert isinstance(comm, _FakeComm) and not comm.closed and why == "ok"
+    res["ok"] = True
+    comm, why, _ = run(available=lambda: rank != last)
+    assert comm is None and "librccl" in why
+    n = len(made)
+
+    def bad_id():
+        raise RuntimeError("ncclGetUniqueId failed")
+    comm, why, _ = run(make_id=bad_id)
+    assert comm is None and "unique id" in why and len(made) == n  # nobody went on to create a communicator
+
+    def create_raises(ident):
+        if rank == last:
+            raise RuntimeError("ncclCommInitRank: unhandled system error")
+        return create_ok(ident)
+    comm, why, _ = run(create=create_raises)
+    assert comm is None and (rank == last or made[-1].closed), why
+
+    def create_hangs(ident):
+        if rank == last:
+            time.sleep(30)
+        return create_ok(ident)
+    comm, why, dt = run(create=create_hangs, timeout_s=0.5)
+    assert comm is None and dt < 15, (why, dt)
+    assert ("deadline" in why) == (rank == last)
+    comm, why, _ = run(selftest=lambda c: (rank != 0, "round 3: sums differ"))
+    assert comm is None and "self-test" in why and (rank == 0 or made[-1].closed)
+    res["cases"] = 6
+    return res
 
 
 def _collect(q, world, timeout):
@@ -154,6 +245,9 @@ def test_ddppo_host_logic_world2_gloo():
     assert a["steps"] == b["steps"] == 64 * 3
     assert torch.equal(a["win_count"], torch.full((3, 1), 3.0))
     assert a["early"] == b["early"] == (False, False, False, True)
+    assert a["affinity"]["shared"] == list(range(0, 32)) and b["affinity"]["shared"] == list(range(32, 64))
+    assert a["affinity"]["confined"] is None and b["affinity"]["confined"] is None and a["affinity"]["disabled"] is None
+    assert a["native"] == b["native"] == {"ok": True, "cases": 6}
 
 
 def test_ddppo_host_logic_world8_gloo():
@@ -187,6 +281,9 @@ def test_ddppo_host_logic_world8_gloo():
         assert o["local_rank"] == r and o["seed_offset"] == r * 4  # (ddppo_pointnav.yaml: num_environments = 4)
     blocks = [set(res[r]["cpus"]) for r in range(world)]
     assert all(len(b) == 8 for b in blocks) and len(set().union(*blocks)) == 64  # disjoint, covering
+    pinned = [set(res[r]["affinity"]["shared"]) for r in range(world)]  # pin_rank_affinity on a shared 64-CPU mask: the same blocks
+    assert pinned == blocks and all(res[r]["affinity"]["confined"] is None for r in range(world))
+    assert all(res[r]["native"] == {"ok": True, "cases": 6} for r in range(world))
 
 
 def _preemption_worker(rank, world, port, q):

@@ -352,6 +352,13 @@ def _native_comm_worker(port, q, native):
     if native:  # the communicator itself: in-place sum over the one rank = identity, on the current stream
         t = torch.arange(1000, device="cuda", dtype=torch.float32)
         assert torch.equal(upd._native_comm.all_reduce_sum_(t.clone()), t)
+        assert upd._native_comm.world_size() == 1
+        # 1000 rounds of the start-up self-test: the communicator's all-reduces on two side streams (the tails' and the moments' roles),
+        # alternating with torch.distributed's own RCCL all-reduce on its stream -- event reuse and cross-stream ordering under load
+        from habitat_amd.rl.ddppo.ddppo import _native_comm_selftest
+        os.environ["HAB_NATIVE_COMM_SELFTEST"] = "1000"
+        ok, detail = _native_comm_selftest(upd._native_comm, torch.device("cuda", torch.cuda.current_device()), 120.0)
+        assert ok, detail
     for _ in range(2):
         losses = trainer.run_update_cycle()
         assert all(np.isfinite(v) for v in losses.values()), losses
