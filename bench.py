@@ -98,6 +98,13 @@ SITE_MODEL = {
 }
 
 
+# Bytes per frame the COMPUTATION needs, where that is less than what the kernel is written to read: the data gradients read the
+# producing layer's fp32 activation only for its sign -- a 1-bit mask would do (conv2_dgrad: 63*63*32 bits = 15.9 KB instead of 508 KB).
+# `frac` is quoted on the bytes the kernel moves (SITE_MODEL, what the counters are compared with); `frac_of_bytes_needed` says where the
+# kernel stands against the leaner formulation, so that `frac` cannot flatter a kernel for traffic it chose.
+SITE_NEEDED_BYTES = {"conv2_dgrad": _A2 + _A1 + 63 * 63 * 32 // 8, "conv3_dgrad": _A3 + _A2 + 30 * 30 * 64 // 8}
+
+
 # algorithmic bytes of a call site that do not scale with the frames of a launch: the 25088 x 512 weight matrix of the visual fc (read by the
 # forward and the data gradient, written once by the weight gradient) -- 51 MB per launch, as much as 2000 frames of its activations
 SITE_LAUNCH_BYTES = {"fc_fwd": 25088 * 512 * 4, "fc_dgrad": 25088 * 512 * 4, "fc_wgrad": 25088 * 512 * 4}
@@ -124,6 +131,12 @@ def site_roofline(site, flops_per_frame, frames, ms):
     r["mfma_ceiling_fp32_equiv_tflops"] = round(peak_eq, 1)
     r["frac_of_fp32_mfma_peak"] = round(tfl / PEAK_FP32_MFMA_TFLOPS, 4)  # the round-1 yardstick (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s)
     r["roofline_floor_ms_per_kframe"] = round(max(t_hbm, t_mfma) * 1e6, 4)
+    if site in SITE_NEEDED_BYTES:
+        need = SITE_NEEDED_BYTES[site]
+        t_need = max(need / (PEAK_HBM_GBS * 1e9), t_mfma)  # the roofline of the leaner formulation (may turn MFMA-bound)
+        r["algorithmic_bytes_needed"] = need
+        r["frac_of_bytes_needed"] = round(t_need / (ms * 1e-3 / frames), 4)
+        r["bound_with_bytes_needed"] = "hbm" if need / (PEAK_HBM_GBS * 1e9) >= t_mfma else "mfma"
     return r
 
 
@@ -260,8 +273,26 @@ def c3_parity_record(state, envs=8, steps=NUM_STEPS):
     return par
 
 
+def encoder_record_one_call(frames=8192, timeout_s=240):
+    """The north-star kernel target as ONE 8192-frame call (an engine whose arenas are sized for 8192 frames: ~46 GB of activations and
+    gradients), in a CHILD process: a batch twice the size any training minibatch or test reaches is run where a fault cannot take
+    the benchmark line with it.  Falls back to 2 x 4096 in this process, with the reason in the record."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--encoder-only", str(frames)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        why = f"exit code {r.returncode}: {r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else 'no output'}"
+    except subprocess.TimeoutExpired:
+        why = f"no result within {timeout_s} s"
+    rec = encoder_record(4096, 2)
+    rec["one_call_of_8192"] = f"failed ({why}); this record is 2 calls of 4096 frames"
+    return rec
+
+
 def encoder_record(frames=4096, calls=2):
-    """ResNet18 encoder alone (ingest .. visual_fc) at 2 x 4096 = 8192 frames of 256x256 RGB-D: HIP events around the engine's encoder
+    """ResNet18 encoder alone (ingest .. visual_fc) at `calls` x `frames` frames of 256x256 RGB-D: HIP events around the engine's encoder
     call sites, algorithmic FLOPs of SURVEY.md 8(d) (forward 0.3376 GFLOP/frame; backward = dgrad + wgrad without the stem's dgrad)."""
     import numpy as np
     import torch
@@ -346,30 +377,42 @@ def phase_record(rollout_ms, cycle_ms, ppo):
                    "(GAE, E x M minibatch passes, Adam, statistics)"}
 
 
-def run_cycles(workload, steps, warmup, keep_state=None):
+def run_cycles(workload, steps, warmup, keep_state=None, distributed=False):
     """A second workload inside the same run (sub-record): (env-steps/s, ms per cycle).  keep_state: dict that receives a CPU copy of
     the policy's state_dict as the cycles left it (the c3 parity leg starts from it)."""
     import torch
     trainer, cfg = make_trainer(workload, warmup + steps + 1)
     trainer._init_train()
     rollout_ms = time_rollouts(trainer)
+    def sync():
+        if distributed:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(warmup):
         trainer.run_update_cycle()
-    torch.cuda.synchronize()
+    sync()
     s0 = trainer.num_steps_done
     t0 = time.perf_counter()
     for _ in range(steps):
         trainer.run_update_cycle()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
+    if distributed:  # max over ranks, like the headline figure; num_steps_done is the all-reduced counter
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+        trainer.shutdown()
     n = trainer.num_steps_done - s0
     trainer.envs.close()
     if keep_state is not None:
         keep_state.update({k: v.detach().cpu().clone() for k, v in trainer._agent.actor_critic.state_dict().items()})
-    rec = {"workload": WORKLOADS[workload]["name"], "value": round(n / dt, 1), "unit": "env-steps/s", "steps": steps, "warmup": warmup,
+    world = torch.distributed.get_world_size() if distributed else 1
+    rec = {"workload": WORKLOADS[workload]["name"] + (f", DD-PPO x {world} ranks" if distributed else ""), "n_gpus": world,
+           "value": round(n / dt, 1), "unit": "env-steps/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(dt / steps * 1e3, 2), "phases": phase_record(rollout_ms(steps), dt / steps * 1e3, cfg.habitat_baselines.rl.ppo),
-           "frac_of_mfma_roofline": round(n / dt * 2.2632e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if workload == "c3" else None,
-           "frac_of_split_ceiling": round(n / dt * 2.2632e9 / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12), 4) if workload == "c3" else None,
+           "frac_of_mfma_roofline": round(n / dt / world * 2.2632e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4) if workload == "c3" else None,
+           "frac_of_split_ceiling": round(n / dt / world * 2.2632e9 / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12), 4) if workload == "c3" else None,
            "frac_basis": "executed contraction FLOPs (2.263 GFLOP per env-step: the stem's data gradient is not computed) / fp32 MFMA peak 157.3; "
                          "frac_of_split_ceiling = the same FLOPs / (bf16 MFMA peak / 6 partial products = 416.7)"}
     del trainer
@@ -384,7 +427,7 @@ def hbm_traffic(workload, probe):
     same command (the newest committed round); null when the probed call site has no entry."""
     if workload != "c2" or probe not in PROBE_KERNELS:
         return None, None
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_c2_hbm_traffic.json")
         if not os.path.exists(path):
             continue
@@ -419,7 +462,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg, the parity leg and the sub-records (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the c3 / encoder sub-records only")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU leg (default min(16, host cores); -1 = every host core)")
+    ap.add_argument("--encoder-only", type=int, default=0, help="print the ResNet18 encoder record of ONE call of this many frames and exit")
     a = ap.parse_args()
+    if a.encoder_only:
+        print(json.dumps(encoder_record(a.encoder_only, 1)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -521,14 +568,31 @@ def main():
         pf = eng.params_flat.double()
         print(f"[rank {rank}] params checksum {pf.sum().item():.12e} {pf.abs().sum().item():.12e}", flush=True)
     trainer.shutdown()  # joins the straggler-counter poller before the store goes away
-    if rank != 0:
-        torch.distributed.destroy_process_group()
-        return
+    # which exchange carried the gradients: the library-owned RCCL communicator (csrc/comm.hip; ranks as IT counts them) or the
+    # torch.distributed callbacks -- so that a scaling line says what it measured
+    comm_rec = None
+    if dist:
+        nc = getattr(trainer._agent.updater, "_native_comm", None)
+        comm_rec = {"comm": "rccl-native" if nc is not None else "torch-callbacks", "backend": torch.distributed.get_backend(),
+                    "rccl_ranks": nc.world_size() if nc is not None else None, "process_group_ranks": torch.distributed.get_world_size(),
+                    "grad_overlap": os.environ.get("HAB_NO_GRAD_OVERLAP") is None}
     # env-steps actually collected over all ranks (the trainer's all-reduced counter): equals world * n_envs * n_steps * K unless
     # DD-PPO's preemptive straggler rule cut a rollout short (ppo_trainer.py:641-653), in which case only the collected steps count
     steps_total = trainer.num_steps_done - steps_before
     assert 0 < steps_total <= world * n_envs * n_steps * a.steps
     local_steps = trainer.local_steps_done - local_before
+    c4 = None
+    if world > 1 and a.workload == "c2" and not a.no_extras and not a.no_cpu_baseline:
+        # BASELINE.json configs[3] (the workload north_star's >= 6x scaling target is written on): DD-PPO ResNet18 + 2-layer LSTM, 64 envs per
+        # rank, run by EVERY rank after the headline cycles (same barrier + max-over-ranks timing)
+        trainer.envs.close()
+        trainer._agent._rollouts = None
+        del eng
+        torch.cuda.empty_cache()
+        c4 = run_cycles("c3", 5, 2, distributed=True)
+    if rank != 0:
+        torch.distributed.destroy_process_group()
+        return
     frames = frames_seen(a.probe, local_steps, a.steps)
     if a.probe.startswith("enc_"):
         kname = f"resnet encoder {a.probe[4:]} (all kernels)"
@@ -547,6 +611,7 @@ def main():
         # ranks that took part, read from the process group after init (1 without one): a launcher that silently started fewer
         # ranks than --gpus would show here
         "ranks_seen": torch.distributed.get_world_size() if dist else 1,
+        "exchange": comm_rec,
         "config": {"workload": WORKLOADS[a.workload]["name"], "envs_per_gpu": n_envs, "rollout_steps": n_steps,
                    "ppo_epoch": ppo.ppo_epoch, "num_mini_batch": ppo.num_mini_batch, "parallelism": f"dp{world}",
                    "matrix_path": "fp32 in / fp32 out; exact 3-term bf16 operand split, 6 (uint8 operand: 3) partial products on "
@@ -584,7 +649,7 @@ def main():
         out["roofline"]["overlapped"] = overlapped
     if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         base, par = cpu_baseline_and_parity(trainer, cfg, cpu_threads=(os.cpu_count() or 1) if a.cpu_threads < 0 else a.cpu_threads)
-        other = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{t_}_cpu_leg_threads.json") for t_ in ("r04", "r03")) if os.path.exists(p_)), "")
+        other = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{t_}_cpu_leg_threads.json") for t_ in ("r05", "r04", "r03")) if os.path.exists(p_)), "")
         if other:  # the same leg timed once at every thread setting on the GPU box's host (committed measurement)
             base["thread_settings_measured"] = json.load(open(other))
         out["cpu_baseline"] = base
@@ -600,10 +665,13 @@ def main():
                 out["c3"]["parity"] = c3_parity_record(c3_state)
             del c3_state
             out["c5"] = run_cycles("c5", 3, 1)  # BASELINE.json configs[4], per GPU
-            out["encoder_r18_b8192"] = encoder_record()
+            out["encoder_r18_b8192"] = encoder_record_one_call()
     if world > 1:
-        out["note"] = ("n_gpus > 1: `cpu_baseline`, `parity`, the per-site `kernels` table and the c3 / encoder sub-records are reported by the "
-                       "N = 1 run only (rank 0 would have to run them while the other ranks have left)")
+        if c4 is not None:
+            out["c4"] = c4
+        out["note"] = ("n_gpus > 1: `cpu_baseline`, `parity`, the per-site `kernels` table and the c3 / c5 / encoder sub-records are reported by "
+                       "the N = 1 run only (rank 0 would have to run them while the other ranks have left); `c4` = the ResNet18 + LSTM "
+                       "DD-PPO workload on all ranks")
     print(json.dumps(out), flush=True)
     if dist:
         torch.distributed.destroy_process_group()

@@ -82,6 +82,7 @@ static int build_baseline(hab_policy* e) {
     const int64_t F = d.max_frames;  // worst case: every frame its own fragment
     const int64_t m1 = blind ? 0 : (int64_t)e->c1.Ho() * e->c1.Wo() * 32, m2 = blind ? 0 : (int64_t)e->c2.Ho() * e->c2.Wo() * 64, m3 = e->fc_in;
     e->w_a1 = wk.take(B * m1); e->w_a2 = wk.take(B * m2); e->w_a3 = wk.take(B * m3);
+    e->w_a1bits = wk.take(B * (m1 / 32));  // one word per pixel of a1
     e->w_da1 = wk.take(B * m1); e->w_da2 = wk.take(B * m2); e->w_da3 = wk.take(B * m3);
     e->w_rnnin = wk.take(B * e->rnn_ld); e->w_drnnin = wk.take(B * e->rnn_ld);
     e->w_hinit = wk.take((int64_t)d.rnn_layers * F * H); e->w_cinit = wk.take((int64_t)d.rnn_layers * F * H);
@@ -115,7 +116,7 @@ extern "C" int hab_policy_create(const hab_policy_desc* desc, hab_policy** out) 
     if (!desc || !out) return HAB_ERR_ARG;
     if (desc->hidden <= 0 || desc->hidden % 64 || desc->num_actions <= 0 || desc->num_actions > 8 || desc->max_frames <= 0 ||
         desc->max_envs <= 0 || desc->rnn_layers <= 0 || desc->goal_dim < 0 ||
-        ((desc->has_rgb || desc->has_depth || desc->arch != HAB_ARCH_SIMPLE_CNN) && (desc->H <= 0 || desc->W <= 0)))
+        ((desc->has_rgb || desc->has_depth || desc->has_semantic) && (desc->H <= 0 || desc->W <= 0)))
         return HAB_ERR_ARG;
     if (desc->action_dist != HAB_DIST_CATEGORICAL && (desc->action_dist != HAB_DIST_GAUSSIAN || desc->arch != HAB_ARCH_RESNET))
         return HAB_ERR_UNSUPPORTED;  // PointNavBaselinePolicy never builds a Gaussian head (rl/ppo/policy.py:439-460)
@@ -293,7 +294,17 @@ static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
     { Probe pr(e, HAB_PROBE_CONV1_FWD, s);
       HAB_TRY(obs_conv_fwd(c1, ov, e->PK + e->pk_c1f, e->p(e->i_c1b), a1, 1, ws, e->ws_floats, s, e->pk_c1img >= 0 ? e->PK + e->pk_c1img : nullptr)); }
     { Probe pr(e, HAB_PROBE_CONV2_FWD, s);
-      HAB_TRY(conv_fwd(c2, a1, e->PK + e->pk_c2f, e->p(e->i_c2b), a2, 1, ws, e->ws_floats, s)); }
+      // a training forward also leaves the sign bits of a1 (its input = conv1's ReLU output) for the data gradient: 16 KB per frame
+      // instead of re-reading the 508 KB activation there; valid only if EVERY chunk of the minibatch wrote them
+      if (e->save_acts && e->w_a1bits >= 0) {
+          int wrote = 0;
+          if (f0 == 0) e->a1_bits_valid = 1;
+          HAB_TRY(conv_fwd(c2, a1, e->PK + e->pk_c2f, e->p(e->i_c2b), a2, 1, ws, e->ws_floats, s,
+                           reinterpret_cast<unsigned*>(W + e->w_a1bits) + f0 * (m1 / 32), &wrote));
+          if (!wrote) e->a1_bits_valid = 0;
+      } else {
+          HAB_TRY(conv_fwd(c2, a1, e->PK + e->pk_c2f, e->p(e->i_c2b), a2, 1, ws, e->ws_floats, s));
+      } }
     { Probe pr(e, HAB_PROBE_CONV3_FWD, s);
       HAB_TRY(conv_fwd(c3, a2, e->PK + e->pk_c3f, e->p(e->i_c3b), a3, 0, ws, e->ws_floats, s)); }
     { Probe pr(e, HAB_PROBE_FC_FWD, s);
@@ -699,7 +710,7 @@ static int policy_backward_impl(hab_policy* e, const hab_obs* obs, const int* ro
                                  e->ws_floats, stream)); }
             { Probe pr(e, HAB_PROBE_CONV2_DGRAD, stream);
               HAB_TRY(conv_dgrad(k2, W + e->w_da2 + f0 * m2, e->PK + e->pk_c2d, W + e->w_a1 + f0 * m1, nullptr, W + e->w_da1 + f0 * m1, ws,
-                                 e->ws_floats, stream)); }
+                                 e->ws_floats, stream, e->a1_bits_valid ? reinterpret_cast<const unsigned*>(W + e->w_a1bits) + f0 * (m1 / 32) : nullptr)); }
         }
         for (int l = L - 1; l >= 0; --l) {  // recurrent weight gradients over all frames: second stream, beside the encoder's below
             RnnLayerParams lp = layer_params(e, l);
@@ -720,11 +731,13 @@ static int policy_backward_impl(hab_policy* e, const hab_obs* obs, const int* ro
     if (e->last_wave) {  // the forward ran the layers as a wavefront (upper layers' wk.gi do not exist): mirror it
         RnnLayerParams lps[4]; RnnWork wks[4]; const float* wiht[4];
         for (int l = 0; l < L; ++l) { lps[l] = layer_params(e, l); wks[l] = layer_work(e, l); wiht[l] = l ? e->PK + e->pk_wiht[l] : nullptr; }
-        const bool blind0 = !e->rn && e->Cin == 0;
+        // blind0: the baseline net's rnn_in is the goal vector alone -- no gradient is wanted for it; nofc: no ReLU(visual fc) columns
+        // at the head of rnn_in, i.e. nothing to mask (both blind forms; the blind ResNet net still wants d rnn_in for its embeddings)
+        const bool blind0 = !e->rn && e->Cin == 0, nofc = e->Cin == 0;
         const float* x0 = W + e->w_rnnin;
         Probe pr(e, HAB_PROBE_RNN_BWD, stream);
         const int rcw = rnn_seq_wave_backward(e->d.rnn_type, H, L, lps, wiht, wks, x0, e->rnn_ld, dout, blind0 ? nullptr : W + e->w_drnnin, e->rnn_ld,
-                                              blind0 ? nullptr : x0, e->rnn_ld, blind0 ? 0 : H, pk, W + e->w_scratch, ws, e->ws_floats, stream);
+                                              nofc ? nullptr : x0, e->rnn_ld, nofc ? 0 : H, pk, W + e->w_scratch, ws, e->ws_floats, stream);
         if (rcw != 0) return rcw == 1 ? HAB_ERR_UNSUPPORTED : rcw;
         waved = true;
     }
@@ -737,10 +750,10 @@ static int policy_backward_impl(hab_policy* e, const hab_obs* obs, const int* ro
         const int lddx = l == 0 ? e->rnn_ld : H;
         // layer 0: the first H columns of rnn_in are ReLU(fc) -> mask them here (fused ReLU backward); a blind policy's rnn_in is the
         // goal vector alone: no mask, and no gradient is wanted for it
-        const bool blind0 = !e->rn && e->Cin == 0 && l == 0;
+        const bool blind0 = !e->rn && e->Cin == 0 && l == 0, nofc = e->Cin == 0;
         Probe pr(e, HAB_PROBE_RNN_BWD, stream);
-        HAB_TRY(rnn_seq_layer_backward(e->d.rnn_type, H, lp, wk, x, ldx, dout, blind0 ? nullptr : dx, lddx, (l == 0 && !blind0) ? x : nullptr, ldx,
-                                       blind0 ? 0 : H, pk, W + e->w_scratch, ws, e->ws_floats, stream));
+        HAB_TRY(rnn_seq_layer_backward(e->d.rnn_type, H, lp, wk, x, ldx, dout, blind0 ? nullptr : dx, lddx, (l == 0 && !nofc) ? x : nullptr, ldx,
+                                       nofc ? 0 : H, pk, W + e->w_scratch, ws, e->ws_floats, stream));
         dout = dx;
     }
     if (!e->rn && e->Cin == 0) {  // blind baseline policy: the recurrent encoder and the heads are all there is
@@ -760,7 +773,8 @@ static int policy_backward_impl(hab_policy* e, const hab_obs* obs, const int* ro
     { Probe pr(e, HAB_PROBE_CONV3_DGRAD, stream);
       HAB_TRY(conv_dgrad(c3, W + e->w_da3, e->PK + e->pk_c3d, W + e->w_a2, nullptr, W + e->w_da2, ws, e->ws_floats, stream)); }
     { Probe pr(e, HAB_PROBE_CONV2_DGRAD, stream);
-      HAB_TRY(conv_dgrad(c2, W + e->w_da2, e->PK + e->pk_c2d, W + e->w_a1, nullptr, W + e->w_da1, ws, e->ws_floats, stream)); }
+      HAB_TRY(conv_dgrad(c2, W + e->w_da2, e->PK + e->pk_c2d, W + e->w_a1, nullptr, W + e->w_da1, ws, e->ws_floats, stream,
+                         e->a1_bits_valid ? reinterpret_cast<const unsigned*>(W + e->w_a1bits) : nullptr)); }
     }
     // conv3 (no ReLU after it; its input a2 is post-ReLU -> mask on the data gradient)
     { Probe pr(e, HAB_PROBE_CONV3_WGRAD, stream);
@@ -791,7 +805,9 @@ extern "C" int hab_policy_tap(hab_policy* e, int which, const float** ptr, int64
     if (e->rn && which != HAB_TAP_RNN_IN && which != HAB_TAP_RNN_OUT) return resnet_tap(e, which, ptr, floats);
     if (!e->rn && e->Cin == 0 && (which == HAB_TAP_CONV1 || which == HAB_TAP_CONV2 || which == HAB_TAP_CONV3)) return HAB_ERR_ARG;
     switch (which) {
-        case HAB_TAP_CONV1: *ptr = W + e->w_a1; *floats = B * e->c1.Ho() * e->c1.Wo() * 32; break;
+        // (a caller may patch the activation through the tap -- oracle/parity.py::MaskInjector writes the oracle's ReLU decisions into
+        // it: the backward then reads the ReLU mask from the activation itself, not from the sign bits of the untouched forward)
+        case HAB_TAP_CONV1: *ptr = W + e->w_a1; *floats = B * e->c1.Ho() * e->c1.Wo() * 32; e->a1_bits_valid = 0; break;
         case HAB_TAP_CONV2: *ptr = W + e->w_a2; *floats = B * e->c2.Ho() * e->c2.Wo() * 64; break;
         case HAB_TAP_CONV3: *ptr = W + e->w_a3; *floats = B * e->fc_in; break;
         case HAB_TAP_RNN_IN: *ptr = W + e->w_rnnin; *floats = B * e->rnn_ld; break;

@@ -45,6 +45,9 @@ struct RnBlock {
 }  // namespace
 
 struct ResNetPlan {
+    // blind: no visual sensor reaches the net (`force_blind_policy`, or an observation space without images: resnet_policy.py:553-592,
+    // ResNetEncoder.is_blind :249-251) -- no backbone, no compression, no visual_fc; the recurrent encoder's input is the embeddings alone
+    bool blind = false;
     int cpad = 4, creal = 4, H2 = 0, W2 = 0;
     int64_t w_x0 = -1;
     RnConv stem;
@@ -98,7 +101,8 @@ int build_resnet(hab_policy* e) {
         d.backbone != HAB_BACKBONE_SE_RESNET50 && d.backbone != HAB_BACKBONE_SE_RESNEXT50 && d.backbone != HAB_BACKBONE_SE_RESNEXT101)
         return HAB_ERR_UNSUPPORTED;
     if (d.baseplanes <= 0 || d.baseplanes % 8) return HAB_ERR_UNSUPPORTED;
-    if (d.H < 2 || d.W < 2) return HAB_ERR_UNSUPPORTED;  // odd sizes: avg_pool2d(2) floors, the last row / column is dropped (F.avg_pool2d)
+    const bool blind = !d.has_rgb && !d.has_depth && !d.has_semantic;
+    if (!blind && (d.H < 2 || d.W < 2)) return HAB_ERR_UNSUPPORTED;  // odd sizes: avg_pool2d(2) floors, the last row / column is dropped (F.avg_pool2d)
     if (d.rnn_type != HAB_RNN_GRU && d.rnn_type != HAB_RNN_LSTM) return HAB_ERR_ARG;
     if (d.goal_dim != 0 && d.goal_dim != 2) return HAB_ERR_UNSUPPORTED;  // 2-D polar pointgoal (resnet_policy.py:662-672)
     ResNetPlan* r = new ResNetPlan();
@@ -107,10 +111,10 @@ int build_resnet(hab_policy* e) {
     e->G_ = d.rnn_type == HAB_RNN_GRU ? 3 : 4;
     e->L = d.rnn_layers;
     r->creal = (d.has_rgb ? 3 : 0) + (d.has_depth ? 1 : 0) + (d.has_semantic ? 1 : 0);
-    if (r->creal == 0) return HAB_ERR_UNSUPPORTED;
+    r->blind = blind;
     e->Cin = r->creal;
     r->cpad = r->creal <= 4 ? 4 : 8;
-    {   // channel offsets from the observation-space key order
+    if (!blind) {   // channel offsets from the observation-space key order
         int off = 0, seen = 0;
         int order = d.visual_order ? d.visual_order : (1 | (2 << 2) | (3 << 4));
         for (int q = 0; q < 3; ++q) {
@@ -173,20 +177,22 @@ int build_resnet(hab_policy* e) {
         ++r->nslots;
     }
     const std::string ve = "net.visual_encoder.";
-    if (d.normalize_visual_inputs) {
+    if (d.normalize_visual_inputs && !blind) {
         r->i_mean = add_param(e, ve + "running_mean_and_var._mean", {1, r->creal, 1, 1});
         r->i_var = add_param(e, ve + "running_mean_and_var._var", {1, r->creal, 1, 1});
         r->i_count = add_param(e, ve + "running_mean_and_var._count", {});
         e->params[r->i_mean].is_buffer = e->params[r->i_var].is_buffer = e->params[r->i_count].is_buffer = 1;
     }
     const std::string bb = ve + "backbone.";
+    int inplanes = bp, curH = 0, curW = 0;
+    if (!blind) {
     r->stem.cd = ConvDesc{0, r->H2, r->W2, r->cpad, bp, 7, 7, 2, 3};
     r->stem.cd.Creal = r->creal;
     r->stem.groups = ng;
     add_conv_gn(e, r->stem, bb + "conv1.0", bb + "conv1.1", r->creal);
     const int sh = r->stem.cd.Ho(), sw = r->stem.cd.Wo();
     r->poolH = conv_out(sh, 3, 2, 1); r->poolW = conv_out(sw, 3, 2, 1);
-    int inplanes = bp, curH = r->poolH, curW = r->poolW;
+    curH = r->poolH; curW = r->poolW;
     for (int li = 0; li < 4; ++li) {
         const int planes = (resnext ? 2 * bp : bp) << li;
         for (int bi = 0; bi < layers[li]; ++bi) {
@@ -240,8 +246,9 @@ int build_resnet(hab_policy* e) {
     r->comp_c = ncomp; r->comp_hw = fh * fw; r->comp_fh = fh; r->comp_fw = fw; r->fc_in = ncomp * fh * fw;
     r->i_fcw = add_param(e, "net.visual_fc.1.weight", {H, r->fc_in});
     r->i_fcb = add_param(e, "net.visual_fc.1.bias", {H});
+    }  // !blind
     e->fc_in = r->fc_in;
-    e->rnn_in = H + 32 * r->nslots;
+    e->rnn_in = (blind ? 0 : H) + 32 * r->nslots;
     e->rnn_ld = (e->rnn_in + 15) & ~15;
     if (e->rnn_ld != e->rnn_in) return HAB_ERR_UNSUPPORTED;  // (32-wide embedding slots behind a hidden size % 64 == 0: never padded)
     const std::string rn = "net.state_encoder.rnn.";
@@ -274,6 +281,7 @@ int build_resnet(hab_policy* e) {
         if (conv_gn_fused_ok(c.cd.C, c.cd.Cout, c.cd.H, c.cd.W, c.cd.KH, c.cd.KW, c.cd.stride, c.cd.pad, c.groups))
             c.pk_p = pk.take((3 * n + 1) / 2);  // 3 planes x 2 bytes per weight
     };
+    if (!blind) {
     pack_conv(r->stem, false);
     if (stem_conv_ok(r->stem.cd.H, r->stem.cd.W, r->stem.cd.C, r->stem.cd.Cout, 7, 7, 2, 3)) r->stem.pk_p = pk.take(STEM_PLANE_FLOATS);
     r->stem_takes_raw = r->stem.pk_p >= 0 && r->cpad == 4 && r->stem.cd.Cout == 32 &&
@@ -281,6 +289,7 @@ int build_resnet(hab_policy* e) {
     for (auto& c : r->convs) pack_conv(c, true);
     pack_conv(r->comp, true);
     r->pk_fc = pk.take((int64_t)H * r->fc_in);
+    }
     for (int l = 0; l < d.rnn_layers; ++l) e->pk_whht.push_back(pk.take((int64_t)e->G_ * H * H));
     for (int l = 0; l < d.rnn_layers; ++l) e->pk_wiht.push_back(l == 0 ? -1 : pk.take((int64_t)e->G_ * H * H));
     e->pk_wih0 = pk.take((int64_t)e->G_ * H * e->rnn_ld);
@@ -289,7 +298,7 @@ int build_resnet(hab_policy* e) {
     // ---- workspace ----
     Arena wk;
     const int64_t B = d.max_frames, F = d.max_frames;
-    r->w_x0 = wk.take(B * r->H2 * r->W2 * r->cpad);
+    if (!blind) r->w_x0 = wk.take(B * r->H2 * r->W2 * r->cpad);
     auto place = [&](RnConv& c, bool own_out) {
         c.w_raw = wk.take(B * c.out_floats());
         c.w_mean = wk.take(B * c.groups);
@@ -297,6 +306,7 @@ int build_resnet(hab_policy* e) {
         if (own_out) c.w_out = wk.take(B * c.out_floats());
         r->cmax = std::max(r->cmax, c.cd.Cout);
     };
+    if (!blind) {
     place(r->stem, true);
     r->w_pool = wk.take(B * r->poolH * r->poolW * bp);
     r->w_pool_idx = wk.take((B * r->poolH * r->poolW * bp + 3) / 4);
@@ -324,9 +334,10 @@ int build_resnet(hab_policy* e) {
     r->w_chansums = wk.take(B * 2 * r->cmax);
     r->w_stats = wk.take(64);
     r->w_dscratch = wk.take(2 * (INGEST_MOM_MAX_BLOCKS * 16 + 16));  // doubles: per-workgroup moment partials of the ingest + their totals
-    r->w_embsave = wk.take(B * 4 * EMB_MAX_SLOTS);
     if (se) r->w_se_scr = wk.take(B * ((int64_t)3 * r->cmax + r->cmax / 16 + 16));
     if (r->gdense_floats) r->w_gdense = wk.take(r->gdense_floats);
+    }  // !blind
+    r->w_embsave = wk.take(B * 4 * EMB_MAX_SLOTS);
     // shared tail (RNN, heads) -- same layout as the SimpleCNN engine
     e->w_rnnin = wk.take(B * e->rnn_ld); e->w_drnnin = wk.take(B * e->rnn_ld);
     e->w_hinit = wk.take((int64_t)d.rnn_layers * F * H); e->w_cinit = wk.take((int64_t)d.rnn_layers * F * H);
@@ -379,12 +390,14 @@ int resnet_repack(hab_policy* e, hipStream_t s) {
         if (c.pk_p < 0) return (int)HAB_OK;
         return weight_planes(e->PK + c.pk_f, c.cd.Cout, c.cd.KH * c.cd.KW * c.cd.C, reinterpret_cast<unsigned short*>(e->PK + c.pk_p), s);
     };
-    HAB_TRY(rp(r->stem, r->creal));
-    if (r->stem.pk_p >= 0) HAB_TRY(stem_weight_planes(e->PK + r->stem.pk_f, reinterpret_cast<unsigned short*>(e->PK + r->stem.pk_p), s));
-    for (const auto& c : r->convs) { HAB_TRY(rp(c, c.cd.C)); HAB_TRY(planes(c)); }
-    HAB_TRY(rp(r->comp, r->comp.cd.C));
-    HAB_TRY(planes(r->comp));
-    HAB_TRY(repack_flatten(e->p(r->i_fcw), e->PK + r->pk_fc, H, r->comp_c, r->comp_hw, s));
+    if (!r->blind) {
+        HAB_TRY(rp(r->stem, r->creal));
+        if (r->stem.pk_p >= 0) HAB_TRY(stem_weight_planes(e->PK + r->stem.pk_f, reinterpret_cast<unsigned short*>(e->PK + r->stem.pk_p), s));
+        for (const auto& c : r->convs) { HAB_TRY(rp(c, c.cd.C)); HAB_TRY(planes(c)); }
+        HAB_TRY(rp(r->comp, r->comp.cd.C));
+        HAB_TRY(planes(r->comp));
+        HAB_TRY(repack_flatten(e->p(r->i_fcw), e->PK + r->pk_fc, H, r->comp_c, r->comp_hw, s));
+    }
     for (int l = 0; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_whh[l]), e->PK + e->pk_whht[l], e->G_ * H, H, s));
     for (int l = 1; l < e->L; ++l) HAB_TRY(transpose2d(e->p(e->i_wih[l]), e->PK + e->pk_wiht[l], e->G_ * H, H, s));
     HAB_TRY(pad_rows(e->p(e->i_wih[0]), e->PK + e->pk_wih0, e->G_ * H, e->rnn_in, e->rnn_ld, s));
@@ -485,6 +498,7 @@ static int resnet_backbone_forward(hab_policy* e, const hab_obs* obs, const int*
 
 int resnet_feature_shape(const hab_policy* e, int* c, int* hf, int* wf) {
     const ResNetPlan* r = e->rn;
+    if (r->blind) return HAB_ERR_UNSUPPORTED;  // a blind encoder has no output (resnet_policy.py:255-257 returns None)
     *c = r->comp_c; *hf = r->comp_fh; *wf = r->comp_fw;
     return HAB_OK;
 }
@@ -492,6 +506,7 @@ int resnet_feature_shape(const hab_policy* e, int* c, int* hf, int* wf) {
 // ResNetEncoder.forward alone: obs -> (n, C, Hf, Wf) NCHW (hab_policy_encode)
 int resnet_encode(hab_policy* e, const hab_obs* obs, int n, float* out, hipStream_t s) {
     ResNetPlan* r = e->rn;
+    if (r->blind) return HAB_ERR_UNSUPPORTED;
     HAB_TRY(resnet_backbone_forward(e, obs, nullptr, n, s));
     const long long total = (long long)n * r->fc_in;
     feats_nhwc_to_nchw_kernel<<<(int)cdivl(total, 256), 256, 0, s>>>(e->WK + r->comp.w_out, out, n, r->comp_c, r->comp_hw);
@@ -511,6 +526,15 @@ int resnet_encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
     const int H = e->d.hidden;
     if (nB < 0) nB = B;
     if (f0 < 0 || nB <= 0 || f0 + nB > B || (f0 > 0 && !rows)) return HAB_ERR_ARG;
+    if (r->blind) {  // x = the embeddings alone (resnet_policy.py:647-660 skipped, :662-757)
+        EmbedArgs ea;
+        HAB_TRY(fill_embed_slots(e, obs, ea.slot, false));
+        ea.nslots = r->nslots; ea.masks = masks; ea.rows = rows ? rows + f0 : nullptr;
+        ea.out = W + e->w_rnnin + (int64_t)f0 * e->rnn_ld; ea.ld = e->rnn_ld; ea.col0 = 0; ea.B = nB;
+        ea.saved = W + r->w_embsave + (int64_t)f0 * r->nslots * 4;
+        if (!masks) return HAB_ERR_ARG;
+        return embed_forward(ea, s);
+    }
     if (obs->visual_features) {  // frozen encoder: the rollout already holds its output (resnet_policy.py:636-646)
         if (f0 == 0) {
             const long long total = (long long)B * r->fc_in;
@@ -721,8 +745,12 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
     const float* dfc = W + e->w_drnnin;  // [B][rnn_ld]; first H columns already carry visual_fc's ReLU mask
     EmbedBwdArgs eb;
     HAB_TRY(fill_embed_slots(e, obs, eb.slot, true));
-    eb.nslots = r->nslots; eb.saved = W + r->w_embsave; eb.dout = dfc; eb.ld = e->rnn_ld; eb.col0 = H; eb.B = B;
+    eb.nslots = r->nslots; eb.saved = W + r->w_embsave; eb.dout = dfc; eb.ld = e->rnn_ld; eb.col0 = r->blind ? 0 : H; eb.B = B;
     HAB_TRY(embed_backward(eb, ws, e->ws_floats, s));
+    if (r->blind) {  // embeddings, recurrent encoder and heads are all there is: the whole arena is final
+        grad_tail_ready(e, 0);
+        return HAB_OK;
+    }
     GPool gp;
     for (int i = 0; i < 6; ++i) gp.buf[i] = W + r->w_gbuf[i];
     // visual_fc
@@ -868,6 +896,7 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
 
 int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats) {
     ResNetPlan* r = e->rn;
+    if (r->blind) return HAB_ERR_ARG;  // no visual activations exist
     float* W = e->WK;
     const int64_t B = e->last_B;
     switch (which) {

@@ -109,6 +109,10 @@ def init_distrib_slurm(backend: str = "nccl"):
       * otherwise (SLURM / MAIN_ADDR + MAIN_PORT, as in the reference): an explicit TCPStore hosted by rank 0."""
     assert distrib.is_available(), "torch.distributed must be available"
     local_rank, world_rank, world_size = get_distrib_size()
+    global _STORE
+    if distrib.is_initialized():  # a second trainer in this process (bench.py's sub-records at N > 1): same group, same store
+        from torch.distributed import distributed_c10d
+        return local_rank, (_STORE if _STORE is not None else distributed_c10d._get_default_store())
     if "MASTER_PORT" in os.environ and "MAIN_PORT" not in os.environ and SLURM_JOBID is None:
         os.environ.setdefault("MASTER_ADDR", DEFAULT_MAIN_ADDR)
         distrib.init_process_group(backend.lower(), init_method="env://", rank=world_rank, world_size=world_size)
@@ -120,7 +124,11 @@ def init_distrib_slurm(backend: str = "nccl"):
     main_addr = get_main_addr()
     tcp_store = distrib.TCPStore(main_addr, main_port, world_size, world_rank == 0)
     distrib.init_process_group(backend.lower(), store=tcp_store, rank=world_rank, world_size=world_size)
+    _STORE = tcp_store
     return local_rank, tcp_store
+
+
+_STORE = None  # the explicit TCPStore of the SLURM-style rendezvous (kept for a second trainer of the same process)
 
 
 def rank_cpu_block(cpus, local_rank: int, local_world: int):

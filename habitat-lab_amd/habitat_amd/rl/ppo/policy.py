@@ -236,7 +236,9 @@ class NetPolicy(nn.Module, Policy):
         self.engine, self.device = eng, device
         eng.set_training(self.training)
         ve = self.visual_encoder
-        if ve is not None and self._engine_kwargs.get("arch") == "resnet":
+        if ve is not None and self._engine_kwargs.get("arch") == "resnet" and (self._engine_kwargs.get("has_rgb") or
+                                                                               self._engine_kwargs.get("has_depth") or
+                                                                               self._engine_kwargs.get("has_semantic")):
             # the reference calls `actor_critic.visual_encoder(batch)` and reads `.output_shape` (ppo_trainer.py:271-279)
             ve.output_shape = eng.visual_feature_shape()
             ve.forward = self.encode_visual
@@ -481,7 +483,7 @@ BACKBONES = {"resnet18": (18, "basic", [2, 2, 2, 2], False, False), "resnet50": 
 
 
 def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, baseplanes, H, W, normalize, has_goal=True, n_obj=0,
-                 has_gps=False, has_compass=False, gauss=None, pointgoal_dim=0, proximity_dim=0):
+                 has_gps=False, has_compass=False, gauss=None, pointgoal_dim=0, proximity_dim=0, blind=False):
     """Parameter / buffer values exactly as PointNavResNetPolicy.__init__ produces them: the torch modules are created in
     the reference's order (resnet_policy.py:389-396 embedding, :454-456 tgt_embeding, :578-585 ResNetEncoder [default
     Conv2d / GroupNorm initialisers -- ResNetEncoder.layer_init is never called], :588-595 visual_fc, :597-602 state encoder
@@ -536,9 +538,10 @@ def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, base
         out[prefix_g + ".weight"], out[prefix_g + ".bias"] = gn.weight.detach(), gn.bias.detach()
 
     bb = ve + "backbone."
-    conv_gn(bb + "conv1.0", bb + "conv1.1", n_in, baseplanes, 7, ng)
+    if not blind:
+        conv_gn(bb + "conv1.0", bb + "conv1.1", n_in, baseplanes, 7, ng)
     inplanes = baseplanes
-    for li, nblocks in enumerate(layers):
+    for li, nblocks in enumerate(layers if not blind else ()):
         planes = (2 * baseplanes if resnext else baseplanes) * (2 ** li)  # resnet.py:223-225
         for bi in range(nblocks):
             stride = 2 if (bi == 0 and li > 0) else 1
@@ -567,13 +570,14 @@ def _resnet_init(n_in, hidden, num_actions, rnn_type, rnn_layers, backbone, base
                 out[bp + "se.excite.0.weight"], out[bp + "se.excite.0.bias"] = se_mods[0].weight.detach(), se_mods[0].bias.detach()
                 out[bp + "se.excite.2.weight"], out[bp + "se.excite.2.bias"] = se_mods[1].weight.detach(), se_mods[1].bias.detach()
             inplanes = planes * expansion
-    fh, fw = int(np.ceil((H // 2) / 32.0)), int(np.ceil((W // 2) / 32.0))
-    ncomp = int(round(2048 / (fh * fw)))
-    conv_gn(ve + "compression.0", ve + "compression.1", inplanes, ncomp, 3, 1)
-    fc = nn.Linear(ncomp * fh * fw, hidden)
-    out["net.visual_fc.1.weight"], out["net.visual_fc.1.bias"] = fc.weight.detach(), fc.bias.detach()
+    if not blind:  # (is_blind: no backbone, no compression, no visual_fc -- resnet_policy.py:200-246,586-595)
+        fh, fw = int(np.ceil((H // 2) / 32.0)), int(np.ceil((W // 2) / 32.0))
+        ncomp = int(round(2048 / (fh * fw)))
+        conv_gn(ve + "compression.0", ve + "compression.1", inplanes, ncomp, 3, 1)
+        fc = nn.Linear(ncomp * fh * fw, hidden)
+        out["net.visual_fc.1.weight"], out["net.visual_fc.1.bias"] = fc.weight.detach(), fc.bias.detach()
     rnn_cls = nn.LSTM if rnn_type == "LSTM" else nn.GRU
-    rnn = rnn_cls(input_size=hidden + 32 * n_slots, hidden_size=hidden, num_layers=rnn_layers)
+    rnn = rnn_cls(input_size=(0 if blind else hidden) + 32 * n_slots, hidden_size=hidden, num_layers=rnn_layers)
     for name, param in rnn.named_parameters():
         if "weight" in name:
             nn.init.orthogonal_(param)
@@ -638,8 +642,8 @@ class PointNavResNetPolicy(NetPolicy):
         sp = observation_space.spaces
         if backbone not in BACKBONES:
             raise _lib.HabError(f"backbone {backbone!r} is not one of {sorted(BACKBONES)} (rl/ddppo/policy/resnet.py:296-345)")
-        if force_blind_policy or aux_loss_config:
-            raise _lib.HabError("blind policies / auxiliary losses are outside the accelerated path")
+        if aux_loss_config:
+            raise _lib.HabError("auxiliary losses are outside the accelerated path")
         gauss = gauss_kw = None
         dist = getattr(policy_config, "action_distribution_type", "categorical") if policy_config is not None else "categorical"
         if dist == "gaussian":
@@ -647,17 +651,25 @@ class PointNavResNetPolicy(NetPolicy):
         elif dist != "categorical":
             raise ValueError(f"Action distribution {dist} not supported.")
         visual_keys = [k for k, v in sp.items() if len(v.shape) > 1]  # observation-space order (resnet_policy.py:178-182)
+        # force_blind_policy (resnet_policy.py:553-554): the visual encoder is built on an EMPTY observation space -- the images stay in
+        # the observation dict (the rollout still stores them) but no backbone, compression or visual_fc exists and the recurrent
+        # encoder's input is the embeddings alone.  An observation space without images gives the same net.
+        blind = bool(force_blind_policy) or not visual_keys
+        image_keys, visual_keys = visual_keys, ([] if blind else visual_keys)
+        if blind and normalize_visual_inputs:
+            # the reference builds RunningMeanAndVar(0) there and fails its `assert n_channels > 0` (running_mean_and_var.py:16): a blind
+            # policy exists only without input normalisation (from_config turns it on when the observation space has "rgb")
+            raise AssertionError("normalize_visual_inputs needs at least one visual channel (blind policy)")
         # 1-D sensors with an embedding on the accelerated path (resnet_policy.py:454-515,662-734).  `heading` is refused: the reference's
         # forward embeds sensor_observations[0] -- the FIRST ROW of the batch (:705-713) -- which only type-checks for one environment;
         # `imagegoal` / `instance_imagegoal` build a second ResNetEncoder for the goal image (:517-545)
         known_1d = {GOAL_UUID, POINTGOAL_UUID, "proximity", "objectgoal", "compass", "gps"}
-        other = [k for k in sp.keys() if k not in visual_keys and k not in known_1d]
-        if any(k not in ("rgb", "depth", "semantic") for k in visual_keys) or not visual_keys or other:
+        other = [k for k in sp.keys() if k not in image_keys and k not in known_1d]
+        if any(k not in ("rgb", "depth", "semantic") for k in image_keys) or other:
             raise _lib.HabError("PointNavResNetPolicy on habitat_amd supports the rgb / depth / semantic visual sensors and the "
                                 f"pointgoal_with_gps_compass, pointgoal, proximity, objectgoal, compass, gps 1-D sensors (got {list(sp.keys())})")
         has_rgb, has_depth, has_sem = "rgb" in visual_keys, "depth" in visual_keys, "semantic" in visual_keys
-        vis = sp[visual_keys[0]]
-        H, W = int(vis.shape[0]), int(vis.shape[1])
+        H, W = (int(sp[visual_keys[0]].shape[0]), int(sp[visual_keys[0]].shape[1])) if visual_keys else (0, 0)
         n_in = (3 if has_rgb else 0) + (1 if has_depth else 0) + (1 if has_sem else 0)
         na = get_num_actions(action_space)
         rnn_type = rnn_type.upper()
@@ -682,8 +694,9 @@ class PointNavResNetPolicy(NetPolicy):
                               has_compass=has_compass, has_gps=has_gps, pointgoal_dim=pg_dim, proximity_dim=px_dim, **(gauss_kw or {})),
                          lambda: _resnet_init(n_in, hidden_size, na, rnn_type, num_recurrent_layers, backbone, resnet_baseplanes,
                                               H, W, normalize_visual_inputs, has_goal, n_obj, has_gps, has_compass, gauss,
-                                              pointgoal_dim=pg_dim, proximity_dim=px_dim),
+                                              pointgoal_dim=pg_dim, proximity_dim=px_dim, blind=blind),
                          buffer_names=bufs)
+        self.is_blind = blind
 
     @classmethod
     def from_config(cls, config, observation_space, action_space, **kwargs):

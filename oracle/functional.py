@@ -289,13 +289,18 @@ def net_forward(params: Params, spec: NetSpec, obs, hidden_bf, prev_actions, mas
         else:
             x = goal
     else:
-        if "visual_features" in obs:  # frozen encoder: PRETRAINED_VISUAL_FEATURES_KEY, resnet_policy.py:636-646
-            feats = obs["visual_features"]
+        blind = not spec.visual_keys  # is_blind (resnet_policy.py:249-251,606-608): force_blind_policy or no image sensor -> embeddings alone
+        vis = None
+        if blind:
+            parts = []
         else:
-            feats = resnet_encoder(params, "net.visual_encoder.", {k: obs[k] for k in spec.visual_keys}, spec.visual_keys, spec.backbone,
-                                   spec.baseplanes, training, spec.normalize, taps, rmv_out)
-        vis = F.relu(F.linear(feats.flatten(1), params["net.visual_fc.1.weight"], params["net.visual_fc.1.bias"]))
-        parts = [vis]
+            if "visual_features" in obs:  # frozen encoder: PRETRAINED_VISUAL_FEATURES_KEY, resnet_policy.py:636-646
+                feats = obs["visual_features"]
+            else:
+                feats = resnet_encoder(params, "net.visual_encoder.", {k: obs[k] for k in spec.visual_keys}, spec.visual_keys, spec.backbone,
+                                       spec.baseplanes, training, spec.normalize, taps, rmv_out)
+            vis = F.relu(F.linear(feats.flatten(1), params["net.visual_fc.1.weight"], params["net.visual_fc.1.bias"]))
+            parts = [vis]
         if GOAL_UUID in obs:
             g = obs[GOAL_UUID]
             g = torch.stack([g[:, 0], torch.cos(-g[:, 1]), torch.sin(-g[:, 1])], -1)  # :662-672
@@ -319,7 +324,7 @@ def net_forward(params: Params, spec: NetSpec, obs, hidden_bf, prev_actions, mas
             pa = torch.where(masks.view(-1), pa + 1, torch.zeros_like(pa))  # :747-753
             parts.append(F.embedding(pa, params["net.prev_action_embedding.weight"]))
         x = torch.cat(parts, dim=1)
-        if taps is not None:
+        if taps is not None and vis is not None:
             taps["visual_fc"] = vis
     if taps is not None:
         taps["rnn_in"] = x

@@ -226,13 +226,14 @@ def test_bench_py_launches_two_ranks_and_reports_whole_job_rate():
     """The driver's multi-GPU scaling run is the first time RCCL sees more than one rank; everything around the transport must not be
     able to fail there.  `bench.py --gpus 2` (the self-launching form: torchrun with --master-addr 127.0.0.1) on ONE GPU with the gloo
     transport (HAB_BENCH_DISTRIB_BACKEND=GLOO; both ranks wrap onto device 0): exactly one JSON line, n_gpus = ranks_seen = 2,
-    parallelism dp2, all 2 x 64 x 128 x K env-steps counted, value = env-steps / max-over-ranks time."""
+    parallelism dp2, all 2 x 64 x 128 x K env-steps counted, value = env-steps / max-over-ranks time; the `exchange` record and the
+    `c4` sub-record (ResNet18 + LSTM on both ranks) are there."""
     import json
     import subprocess
     env = dict(os.environ, HAB_BENCH_DISTRIB_BACKEND="GLOO", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -243,6 +244,12 @@ def test_bench_py_launches_two_ranks_and_reports_whole_job_rate():
     steps = 2 * 64 * 128 * 2
     assert abs(out["value"] * out["ms_per_step"] * 2 / 1e3 - steps) <= 0.01 * steps  # whole-job aggregate over both ranks
     assert "cpu_baseline" not in out and "note" in out
+    # the line says which exchange carried the gradients, and carries the DD-PPO ResNet18 + LSTM workload (BASELINE.json configs[3]) run by
+    # both ranks through a SECOND trainer on the same process group
+    assert out["exchange"] == {"comm": "torch-callbacks", "backend": "gloo", "rccl_ranks": None, "process_group_ranks": 2, "grad_overlap": True}
+    c4 = out["c4"]
+    assert c4["n_gpus"] == 2 and "ResNet18" in c4["workload"] and c4["steps"] == 5
+    assert abs(c4["value"] * c4["ms_per_step"] * 5 / 1e3 - 2 * 64 * 128 * 5) <= 0.01 * 2 * 64 * 128 * 5
 
 
 def _reduce_worker(rank, world, port, unused_params, q):

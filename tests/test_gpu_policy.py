@@ -339,7 +339,7 @@ def test_resnet_golden_mask_flip_accounting(case):
 # weight gradients, the observation convolution, every patch / strip kernel on their fp32 forms); the default minus the three kernels
 # hard-wired to the 256 x 256 benchmark geometry (observation patch, conv2 forward / data-gradient strips): what an observation size
 # other than 256 x 256 runs in production
-MATRIX_PATHS = {"fp32_mfma": 0, "split_bf16_igemm_only": 1, "no_256x256_strip_kernels": 1023 & ~(64 | 256 | 512)}
+MATRIX_PATHS = {"fp32_mfma": 0, "split_bf16_igemm_only": 1, "no_256x256_strip_kernels": 2047 & ~(64 | 256 | 512 | 1024)}
 
 
 @pytest.mark.parametrize("path", list(MATRIX_PATHS))
@@ -566,6 +566,70 @@ def test_resnet_policy_pointgoal_and_proximity_embeddings_vs_oracle():
     for k, g in eng.grad_views.items():
         if "_embed" in k:
             assert rel_ok(g.cpu().numpy(), p[k].grad.numpy(), tol=1e-4, floor=1e-5), k
+
+
+@pytest.mark.parametrize("rnn_type,layers,force", [("LSTM", 2, True), ("GRU", 1, False)])
+def test_blind_resnet_policy_vs_oracle(rnn_type, layers, force):
+    """PointNavResNetPolicy with `force_blind_policy` (images in the observation space, ignored: resnet_policy.py:553-554) and with an
+    observation space that has no image at all: the net is embeddings -> GRU / LSTM -> heads (no backbone, compression, visual_fc).
+    evaluate, every gradient and act against the oracle (whose blind forward is pinned to the live reference on CPU:
+    test_blind_resnet_policy_identical_to_live_reference); the layer wavefront of the 2-layer LSTM runs without the ReLU(fc) mask."""
+    from habitat_amd.common import spaces as S
+    from habitat_amd.engine import DevicePackInfo
+    from habitat_amd.rl.ppo import PointNavResNetPolicy
+    hidden, T, n, H, W = 64, 9, 3, 64, 64
+    B = T * n
+    box = lambda d: S.Box(-1e9, 1e9, (d,), np.float32)
+    sp = {GOAL: box(2), "gps": box(2), "compass": box(1), "objectgoal": S.Box(0, 5, (1,), np.int64)}
+    if force:
+        sp = dict({"depth": S.Box(0.0, 1.0, (H, W, 1), np.float32)}, **sp)
+    torch.manual_seed(31)
+    pol = PointNavResNetPolicy(S.Dict(sp), S.Discrete(4), hidden_size=hidden, rnn_type=rnn_type, num_recurrent_layers=layers,
+                               backbone="resnet18", force_blind_policy=force, max_frames=B, max_envs=n)
+    params = {k: v.detach().clone() for k, v in pol.state_dict().items()}
+    assert pol.is_blind and not any("visual" in k for k in params)
+    pol.to("cuda")
+    pol.train()
+    rng = np.random.default_rng(6)
+    f32 = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    obs = {GOAL: f32(B, 2).abs(), "gps": f32(B, 2), "compass": f32(B, 1), "objectgoal": torch.from_numpy(rng.integers(0, 6, (B, 1)))}
+    masks = torch.from_numpy(rng.random((B, 1)) > 0.3)
+    actions = torch.from_numpy(rng.integers(0, 4, (B, 1)))
+    prev_actions = torch.from_numpy(rng.integers(0, 4, (B, 1)))
+    Lh = layers * (2 if rnn_type == "LSTM" else 1)
+    h0 = f32(n, Lh, hidden)
+    spec = O.NetSpec(kind="resnet", rnn_type=rnn_type, num_layers=layers, visual_keys=(), normalize=False, hidden=hidden)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    v, lp, ent, _ = O.evaluate_actions(p, spec, obs, h0, prev_actions, masks, actions, training=True)
+    gv, glp, gent = (f32(B, 1) for _ in range(3))
+    ((v * gv).sum() + (lp * glp).sum() + (ent * gent).sum()).backward()
+    eng = pol.engine
+    pack = DevicePackInfo(np.logical_not(masks.view(T, n).numpy()), "cuda")
+    dv, dl, de = (torch.zeros(B, device="cuda") for _ in range(3))
+    extra = {k: obs[k].cuda() for k in ("gps", "compass", "objectgoal")}
+    eng.evaluate(None, None, obs[GOAL].cuda(), None, h0.cuda(), masks.cuda(), actions.cuda(), pack, B, n, value=dv, log_prob=dl, entropy=de,
+                 prev_actions=prev_actions.cuda(), extra=extra)
+    assert rel_ok(dv.cpu().numpy(), v.detach().numpy().reshape(-1))
+    assert rel_ok(dl.cpu().numpy(), lp.detach().numpy().reshape(-1), floor=1e-6)
+    assert rel_ok(de.cpu().numpy(), ent.detach().numpy().reshape(-1), floor=1e-6)
+    eng.backward(None, None, obs[GOAL].cuda(), None, actions.cuda(), pack, gv.view(-1).cuda(), glp.view(-1).cuda(), gent.view(-1).cuda(),
+                 prev_actions=prev_actions.cuda(), extra=extra)
+    assert set(eng.grad_views) == set(p)
+    bad = [(k, float((g.cpu() - p[k].grad).abs().max()), float(p[k].grad.abs().max())) for k, g in eng.grad_views.items()
+           if not rel_ok(g.cpu().numpy(), p[k].grad.numpy(), tol=1e-4, floor=1e-4)]
+    assert not bad, bad
+    # act through the plugin surface (the observation dict may still carry the images: they are ignored)
+    pol.eval()
+    noise = torch.from_numpy(rng.exponential(1.0, (n, 4)).astype(np.float32))
+    o_n = {k: t[:n].cuda() for k, t in obs.items()}
+    if force:
+        o_n["depth"] = torch.rand(n, H, W, 1, device="cuda")
+    ad = pol.act(o_n, h0.cuda(), prev_actions[:n].cuda(), masks[:n].cuda(), exp_noise=noise.cuda())
+    with torch.no_grad():
+        ref = O.act({k: t.detach() for k, t in p.items()}, spec, {k: t[:n] for k, t in obs.items()}, h0, prev_actions[:n], masks[:n], exp_noise=noise)
+    assert torch.equal(ad.actions.cpu(), ref["actions"])
+    assert rel_ok(ad.values.cpu().numpy(), ref["values"].numpy())
+    assert rel_ok(ad.rnn_hidden_states.cpu().numpy(), ref["rnn_hidden_states"].numpy())
 
 
 RESNET_VARIANTS = [  # backbone, rnn, layers, H, W, visual key order, normalize

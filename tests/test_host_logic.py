@@ -845,3 +845,59 @@ def test_ver_preemption_schedule_identical_to_live_reference():
         assert active >= 3, "the schedule never became active"
         # the deadline cuts the slow environments off: fewer steps than the quota are expected once it is active
         assert 0 < mine.expected_steps_collected <= N * T
+
+
+def test_blind_resnet_policy_identical_to_live_reference():
+    """`force_blind_policy` (resnet_policy.py:553-554,249-251,606-608) and an observation space without images: no backbone, compression
+    or visual_fc, the recurrent encoder's input is the embeddings alone; with input normalisation the reference fails its own
+    `assert n_channels > 0` (running_mean_and_var.py:16) and so does this package.  state_dict names / shapes / seeded values against the
+    live reference, and the ORACLE's blind forward (features, hidden states, value) against the reference policy's own on random inputs."""
+    from habitat_amd.common import spaces as S
+    from habitat_amd.rl.ddppo.policy import PointNavResNetPolicy
+    mk = lambda M, img: M.Dict(dict(({"depth": M.Box(0, 1, (64, 64, 1), np.float32)} if img else {}),
+                                    **{"pointgoal_with_gps_compass": M.Box(-1e9, 1e9, (2,), np.float32), "gps": M.Box(-1e9, 1e9, (2,), np.float32),
+                                       "compass": M.Box(-4, 4, (1,), np.float32)}))
+    kw = dict(hidden_size=64, num_recurrent_layers=2, rnn_type="LSTM", backbone="resnet18", normalize_visual_inputs=False, force_blind_policy=True)
+    torch.manual_seed(11)
+    pol = PointNavResNetPolicy(mk(S, True), S.Discrete(4), **kw)
+    mine = pol.state_dict()
+    assert pol.is_blind and not any("visual_encoder" in k or "visual_fc" in k for k in mine)
+    assert mine["net.state_encoder.rnn.weight_ih_l0"].shape == (4 * 64, 32 * 4)  # previous action, goal, gps, compass
+    torch.manual_seed(12)
+    no_img = PointNavResNetPolicy(mk(S, False), S.Discrete(4), hidden_size=64, backbone="resnet18", normalize_visual_inputs=False)
+    assert no_img.is_blind
+    with pytest.raises(AssertionError):
+        PointNavResNetPolicy(mk(S, True), S.Discrete(4), **dict(kw, normalize_visual_inputs=True))
+    from oracle.ref_loader import load_reference, reference_available
+    if not reference_available():
+        return
+    ns = load_reference()
+    torch.manual_seed(11)
+    ref_pol = ns.resnet_policy.PointNavResNetPolicy(mk(ns.spaces, True), ns.spaces.Discrete(4), **kw)
+    ref = ref_pol.state_dict()
+    assert list(mine.keys()) == list(ref.keys())
+    assert all(mine[k].shape == ref[k].shape and torch.equal(mine[k], ref[k]) for k in ref)
+    with pytest.raises(AssertionError):
+        ns.resnet_policy.PointNavResNetPolicy(mk(ns.spaces, True), ns.spaces.Discrete(4), **dict(kw, normalize_visual_inputs=True))
+    torch.manual_seed(12)
+    ref2 = ns.resnet_policy.PointNavResNetPolicy(mk(ns.spaces, False), ns.spaces.Discrete(4), hidden_size=64, backbone="resnet18",
+                                                 normalize_visual_inputs=False).state_dict()
+    sd2 = no_img.state_dict()
+    assert list(sd2.keys()) == list(ref2.keys()) and all(torch.equal(sd2[k], ref2[k]) for k in ref2)
+    # the oracle's blind forward against the reference's
+    from oracle import functional as O
+    g = torch.Generator().manual_seed(5)
+    n = 6
+    obs = {"depth": torch.rand(n, 64, 64, 1, generator=g), "pointgoal_with_gps_compass": torch.randn(n, 2, generator=g),
+           "gps": torch.randn(n, 2, generator=g), "compass": torch.randn(n, 1, generator=g)}
+    hidden = torch.randn(n, 4, 64, generator=g)
+    prev = torch.randint(0, 4, (n, 1), generator=g)
+    masks = torch.rand(n, 1, generator=g) > 0.3
+    spec = O.NetSpec(kind="resnet", rnn_type="LSTM", num_layers=2, visual_keys=(), normalize=False, hidden=64)
+    params = {k: v.detach().clone() for k, v in ref.items()}
+    with torch.no_grad():
+        feats, h_out = O.net_forward(params, spec, {k: v for k, v in obs.items() if k != "depth"}, hidden, prev, masks)
+        value = O.heads(params, feats)[2]
+        r_feats, r_hidden, _ = ref_pol.net(obs, hidden, prev, masks)
+        r_value = ref_pol.critic(r_feats)
+    assert torch.allclose(feats, r_feats, atol=1e-6) and torch.allclose(h_out, r_hidden, atol=1e-6) and torch.allclose(value, r_value, atol=1e-6)
