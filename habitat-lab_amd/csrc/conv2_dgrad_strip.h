@@ -25,7 +25,6 @@ struct C2dArgs {
     const float* dy;    // [B][30][30][64]
     const float* wd;    // packed filter [32 ci][4][4][64 co] (the engine's data-gradient layout)
     const float* mask;  // [B][63][63][32] or null: dX *= (mask > 0)
-    const unsigned* mask_bits;  // [B][63][63] or null: the same mask as one bit per channel (conv2_fwd_strip.h writes it); preferred
     float* dx;          // [B][63][63][32]
     int B;
     int strips, items;
@@ -134,16 +133,7 @@ __global__ void __launch_bounds__(512) conv2_dgrad_strip_kernel(const C2dArgs a)
             // ReLU-mask quads of this tile row, requested BEFORE its MFMAs: the epilogue sits behind two barriers, and a load issued
             // there was a full HBM round trip in front of every store (one workgroup per CU: nothing else to run meanwhile)
             f32x4 mk[2];
-            unsigned mb[2] = {0u, 0u};
-            if (a.mask_bits) {  // one 4-byte word per pixel (the 8 threads of a pixel read the same one) instead of 128 bytes
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int idx = t + q * NT, rph = idx >> 9, cell = (idx >> 4) & 31, cq = idx & 15;
-                    const int h = 2 * (h20 + tr) + rph, w = 2 * cell + (cq >> 3);
-                    const bool ok = h < H && w < W;
-                    mb[q] = a.mask_bits[ok ? ((size_t)img * H + h) * W + w : (size_t)0];  // (used only in the epilogue: nothing here waits for it)
-                }
-            } else if (a.mask) {
+            if (a.mask) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int idx = t + q * NT, rph = idx >> 9, cell = (idx >> 4) & 31, cq = idx & 15;
@@ -192,11 +182,7 @@ __global__ void __launch_bounds__(512) conv2_dgrad_strip_kernel(const C2dArgs a)
                 const int h = 2 * h2 + rph, w = 2 * cell + (cq >> 3);
                 if (h < H && w < W) {
                     const size_t off = (((size_t)img * H + h) * W + w) * 32 + (cq & 7) * 4;
-                    if (a.mask_bits) {
-                        const unsigned nib = mb[q] >> ((cq & 7) * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s[e] = ((nib >> e) & 1u) ? s[e] : 0.f;
-                    } else if (a.mask) {
+                    if (a.mask) {
                         const f32x4 m = mk[q];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) s[e] = m[e] > 0.f ? s[e] : 0.f;
@@ -215,14 +201,14 @@ inline bool conv2_dgrad_strip_covers(const ConvDesc& d) {
 
 // 1: shape not covered.
 inline int conv2_dgrad_strip(const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add, float* dx,
-                             hipStream_t stream, const unsigned* mask_bits = nullptr) {
+                             hipStream_t stream) {
     if (!conv2_dgrad_strip_covers(d)) return 1;
     if (add || d.B < 16 || !dy || !wd || !dx) return 1;
     if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wd) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(mask)) & 15) return 1;
     constexpr int R2 = 2;
     using Cfg = C2dCfg<R2>;
     C2dArgs a;
-    a.dy = dy; a.wd = wd; a.mask = mask; a.mask_bits = mask_bits; a.dx = dx; a.B = d.B;
+    a.dy = dy; a.wd = wd; a.mask = mask; a.dx = dx; a.B = d.B;
     a.H = d.H; a.W = d.W; a.Ho = (d.H - 4) / 2 + 1; a.Wo = (d.W - 4) / 2 + 1;
     a.strips = ((d.H + 1) / 2 + R2 - 1) / R2;  // cell rows = ceil(H / 2)
     if ((long long)d.B * a.strips > 0x7fffffffLL) return 1;

@@ -3,7 +3,7 @@
 // runtime-geometry instantiation) with the INPUT STRIP resident in LDS and the WEIGHTS resident in registers.
 //
 // Why: the implicit-GEMM form (igemm_bf3.h, 128 x 64 tiles) re-reads every input element 4x (16 taps / stride^2) and the whole 128 KB
-// filter once per 128 output pixels through L2 -- 5.5 GB of L2 -> LDS traffic per 2048 frames, the bound of that kernel (DESIGN.md 5c:
+// filter once per 128 output pixels through L2 -- 5.5 GB of L2 -> LDS traffic per 2048 frames, the bound of that kernel (NOTEBOOK.md 5c:
 // removing its split VALU changes nothing, its DMA-only skeleton takes 0.39 of 0.55 ms).  The filter as three bf16 planes is 196 KB, more
 // than LDS, so the patch-resident scheme of conv_patch_bf3.h does not apply as it stands.  Here the reduction (16 taps x 32 channels = 512)
 // is cut ACROSS THE WAVES of a workgroup instead:
@@ -32,11 +32,6 @@ struct C2fArgs {
     int strips, items;
     int relu, sign_schedule;
     int H, W, Ho, Wo;   // runtime-geometry instantiation (RT): input H x W (W <= 63), output Ho x Wo
-    // by-product for the backward pass, or null: bit c of x_pos_bits[(frame * H + h) * W + w] = (x[frame][h][w][c] > 0).  The input IS the
-    // previous layer's ReLU output, whose sign is all the data gradient of this convolution needs of it (conv2_dgrad_strip.h): 4 bytes
-    // per pixel instead of a second 128-byte read of the activation.  Rows no strip stages (H - 1 when H is odd) stay unwritten: the
-    // data gradient is exactly zero there whatever the bit says.
-    unsigned* x_pos_bits;
 };
 
 template <int R>
@@ -112,30 +107,15 @@ __global__ void __launch_bounds__(512) conv2_fwd_strip_kernel(const C2fArgs a) {
             xr[j] = *reinterpret_cast<const f32x4*>(xb + (in ? (size_t)u * 4 : 0));
         }
     };
-    auto stage = [&](int item) {
-        const int img = item / a.strips, st = item - img * a.strips;
-        // sign bits: the rows this strip is the first to stage (the next strip starts 2 R rows further down; the last one takes the rest)
-        const int own_rows = (st + 1 == a.strips) ? Cfg::XRS : 2 * R;
+    auto stage = [&]() {
 #pragma unroll
         for (int j = 0; j < Cfg::XPT; ++j) {
             const int u = t + j * NT;
-            if (RT ? u >= XU : (Cfg::XU % NT != 0 && u >= Cfg::XU)) continue;  // (uniform over the 8 lanes of a pixel: XU % 8 == 0)
+            if (RT ? u >= XU : (Cfg::XU % NT != 0 && u >= Cfg::XU)) continue;
             const int c4 = u & 7, pix = u >> 3, w = pix % W, hh = pix / W;
             const int row = hh * W + xcol(w);
             unsigned short* dst = xs + row * 32 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 3) + (c4 & 1) * 4;
-            const f32x4 v = (!RT || u < pf_units) ? xr[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            bf3_store4(v, dst, dst + X_PLANE, dst + 2 * X_PLANE);
-            // (rows a later strip stages again are left to it: a third of the units -- whole waves -- skip the bit work)
-            if (a.x_pos_bits && hh < own_rows) {  // the 8 lanes u & 7 = 0 .. 7 hold the 32 channels of one pixel: OR their nibbles together
-                unsigned word = ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (4 * c4);
-                // OR over the 8 lanes with DPP (VALU only: __shfl_xor compiles to ds_bpermute_b32, 18 more LDS operations per thread in a
-                // phase that is LDS-write bound): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror (lane i <- lane 7 - i)
-                word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0xB1, 0xF, 0xF, true);
-                word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x4E, 0xF, 0xF, true);
-                word |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x141, 0xF, 0xF, true);
-                const int h = st * 2 * R + hh;
-                if (c4 == 0 && h < H) a.x_pos_bits[((size_t)img * H + h) * W + w] = word;
-            }
+            bf3_store4((!RT || u < pf_units) ? xr[j] : f32x4{0.f, 0.f, 0.f, 0.f}, dst, dst + X_PLANE, dst + 2 * X_PLANE);
         }
     };
 
@@ -146,7 +126,7 @@ __global__ void __launch_bounds__(512) conv2_fwd_strip_kernel(const C2fArgs a) {
 
     fetch(first);
     for (int item = first; item < last; ++item) {
-        stage(item);
+        stage();
         __syncthreads();
         if (item + 1 < last) fetch(item + 1);
         const int img = item / a.strips, ho0 = (item - img * a.strips) * R;
@@ -212,7 +192,7 @@ inline bool conv2_fwd_strip_covers(const ConvGeom& g) {
 }
 
 // 1: shape not covered.
-inline int conv2_fwd_strip(const ConvFwdProb& p, float* /*ws*/, size_t /*ws_floats*/, hipStream_t stream, unsigned* x_pos_bits = nullptr) {
+inline int conv2_fwd_strip(const ConvFwdProb& p, float* /*ws*/, size_t /*ws_floats*/, hipStream_t stream) {
     const ConvGeom& g = p.g;
     if (!conv2_fwd_strip_covers(g)) return 1;
     if ((p.ldy != 0 && p.ldy != 64) || g.B < 16) return 1;
@@ -220,7 +200,7 @@ inline int conv2_fwd_strip(const ConvFwdProb& p, float* /*ws*/, size_t /*ws_floa
     constexpr int R = 2;
     using Cfg = C2fCfg<R>;
     C2fArgs a;
-    a.x = p.x; a.wf = p.w; a.bias = p.bias; a.y = p.y; a.B = g.B; a.x_pos_bits = x_pos_bits;
+    a.x = p.x; a.wf = p.w; a.bias = p.bias; a.y = p.y; a.B = g.B;
     a.H = g.H; a.W = g.W; a.Ho = (g.H - 4) / 2 + 1; a.Wo = (g.W - 4) / 2 + 1;
     a.strips = (a.Ho + R - 1) / R;
     if ((long long)g.B * a.strips > 0x7fffffffLL) return 1;

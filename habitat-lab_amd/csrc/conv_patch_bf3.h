@@ -4,7 +4,7 @@
 // Why.  In the im2col form (igemm_bf3.h) every activation is gathered, split into its three bf16 terms (4.5 VALU) and written to LDS
 // once per filter tap that touches it: 9x for a 3x3 filter -- and for the 32-channel layers (ResNet layer1, SimpleCNN conv3: N = 32)
 // each split value then feeds only 32 output columns, so those kernels are bound by the split's VALU issue at ~85 TFLOP/s-eq while the
-// matrix pipe idles.  Here a workgroup owns TH output rows x the full width of ONE image: it splits the (TH + 2) x
+// matrix pipe idles (NOTEBOOK.md 4).  Here a workgroup owns TH output rows x the full width of ONE image: it splits the (TH + 2) x
 // (Wo + 2) x 32-channel input patch ONCE, keeps it in LDS as three bf16 planes, and the nine taps are nine shifted views of the
 // same image: an A fragment is one ds_read_b128 per plane at pixel (ty + a, tx + b).  Per 32-channel chunk the VALU work drops from
 // 9 x (BM x 32) to (TH+2)(Wo+2) x 32 splits; only the (small) weight tile is staged per filter row / tap.

@@ -66,8 +66,6 @@ struct hab_policy {
     int last_tm = 0;  // the last evaluate ran the time-major form with this many chunks (0: packed form)
     // ResNet policy (engine_resnet.hip)
     struct ResNetPlan* rn = nullptr;
-    int64_t w_a1bits = -1;  // [B][H1][W1] words: sign bits of conv1's ReLU output, left by conv2's forward for its data gradient
-    int a1_bits_valid = 0;  // ... of the last evaluate are complete (every chunk's forward wrote them, no debug tap handed a1 out since)
     int save_acts = 1;                                  // 0 inside act / encode: no backward follows, the fused kernels skip the saved copies
     int training = 1;                                   // nn.Module.train()/eval(): RunningMeanAndVar updates only in training
     hab_allreduce_fn allreduce_cb = nullptr;            // optional in-place all-reduce of a small device buffer (DD-PPO RMV stats)

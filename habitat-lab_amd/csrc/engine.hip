@@ -82,7 +82,6 @@ static int build_baseline(hab_policy* e) {
     const int64_t F = d.max_frames;  // worst case: every frame its own fragment
     const int64_t m1 = blind ? 0 : (int64_t)e->c1.Ho() * e->c1.Wo() * 32, m2 = blind ? 0 : (int64_t)e->c2.Ho() * e->c2.Wo() * 64, m3 = e->fc_in;
     e->w_a1 = wk.take(B * m1); e->w_a2 = wk.take(B * m2); e->w_a3 = wk.take(B * m3);
-    e->w_a1bits = wk.take(B * (m1 / 32));  // one word per pixel of a1
     e->w_da1 = wk.take(B * m1); e->w_da2 = wk.take(B * m2); e->w_da3 = wk.take(B * m3);
     e->w_rnnin = wk.take(B * e->rnn_ld); e->w_drnnin = wk.take(B * e->rnn_ld);
     e->w_hinit = wk.take((int64_t)d.rnn_layers * F * H); e->w_cinit = wk.take((int64_t)d.rnn_layers * F * H);
@@ -294,17 +293,7 @@ static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
     { Probe pr(e, HAB_PROBE_CONV1_FWD, s);
       HAB_TRY(obs_conv_fwd(c1, ov, e->PK + e->pk_c1f, e->p(e->i_c1b), a1, 1, ws, e->ws_floats, s, e->pk_c1img >= 0 ? e->PK + e->pk_c1img : nullptr)); }
     { Probe pr(e, HAB_PROBE_CONV2_FWD, s);
-      // a training forward also leaves the sign bits of a1 (its input = conv1's ReLU output) for the data gradient: 16 KB per frame
-      // instead of re-reading the 508 KB activation there; valid only if EVERY chunk of the minibatch wrote them
-      if (e->save_acts && e->w_a1bits >= 0) {
-          int wrote = 0;
-          if (f0 == 0) e->a1_bits_valid = 1;
-          HAB_TRY(conv_fwd(c2, a1, e->PK + e->pk_c2f, e->p(e->i_c2b), a2, 1, ws, e->ws_floats, s,
-                           reinterpret_cast<unsigned*>(W + e->w_a1bits) + f0 * (m1 / 32), &wrote));
-          if (!wrote) e->a1_bits_valid = 0;
-      } else {
-          HAB_TRY(conv_fwd(c2, a1, e->PK + e->pk_c2f, e->p(e->i_c2b), a2, 1, ws, e->ws_floats, s));
-      } }
+      HAB_TRY(conv_fwd(c2, a1, e->PK + e->pk_c2f, e->p(e->i_c2b), a2, 1, ws, e->ws_floats, s)); }
     { Probe pr(e, HAB_PROBE_CONV3_FWD, s);
       HAB_TRY(conv_fwd(c3, a2, e->PK + e->pk_c3f, e->p(e->i_c3b), a3, 0, ws, e->ws_floats, s)); }
     { Probe pr(e, HAB_PROBE_FC_FWD, s);
@@ -710,7 +699,7 @@ static int policy_backward_impl(hab_policy* e, const hab_obs* obs, const int* ro
                                  e->ws_floats, stream)); }
             { Probe pr(e, HAB_PROBE_CONV2_DGRAD, stream);
               HAB_TRY(conv_dgrad(k2, W + e->w_da2 + f0 * m2, e->PK + e->pk_c2d, W + e->w_a1 + f0 * m1, nullptr, W + e->w_da1 + f0 * m1, ws,
-                                 e->ws_floats, stream, e->a1_bits_valid ? reinterpret_cast<const unsigned*>(W + e->w_a1bits) + f0 * (m1 / 32) : nullptr)); }
+                                 e->ws_floats, stream)); }
         }
         for (int l = L - 1; l >= 0; --l) {  // recurrent weight gradients over all frames: second stream, beside the encoder's below
             RnnLayerParams lp = layer_params(e, l);
@@ -773,8 +762,7 @@ static int policy_backward_impl(hab_policy* e, const hab_obs* obs, const int* ro
     { Probe pr(e, HAB_PROBE_CONV3_DGRAD, stream);
       HAB_TRY(conv_dgrad(c3, W + e->w_da3, e->PK + e->pk_c3d, W + e->w_a2, nullptr, W + e->w_da2, ws, e->ws_floats, stream)); }
     { Probe pr(e, HAB_PROBE_CONV2_DGRAD, stream);
-      HAB_TRY(conv_dgrad(c2, W + e->w_da2, e->PK + e->pk_c2d, W + e->w_a1, nullptr, W + e->w_da1, ws, e->ws_floats, stream,
-                         e->a1_bits_valid ? reinterpret_cast<const unsigned*>(W + e->w_a1bits) : nullptr)); }
+      HAB_TRY(conv_dgrad(c2, W + e->w_da2, e->PK + e->pk_c2d, W + e->w_a1, nullptr, W + e->w_da1, ws, e->ws_floats, stream)); }
     }
     // conv3 (no ReLU after it; its input a2 is post-ReLU -> mask on the data gradient)
     { Probe pr(e, HAB_PROBE_CONV3_WGRAD, stream);
@@ -805,9 +793,7 @@ extern "C" int hab_policy_tap(hab_policy* e, int which, const float** ptr, int64
     if (e->rn && which != HAB_TAP_RNN_IN && which != HAB_TAP_RNN_OUT) return resnet_tap(e, which, ptr, floats);
     if (!e->rn && e->Cin == 0 && (which == HAB_TAP_CONV1 || which == HAB_TAP_CONV2 || which == HAB_TAP_CONV3)) return HAB_ERR_ARG;
     switch (which) {
-        // (a caller may patch the activation through the tap -- oracle/parity.py::MaskInjector writes the oracle's ReLU decisions into
-        // it: the backward then reads the ReLU mask from the activation itself, not from the sign bits of the untouched forward)
-        case HAB_TAP_CONV1: *ptr = W + e->w_a1; *floats = B * e->c1.Ho() * e->c1.Wo() * 32; e->a1_bits_valid = 0; break;
+        case HAB_TAP_CONV1: *ptr = W + e->w_a1; *floats = B * e->c1.Ho() * e->c1.Wo() * 32; break;
         case HAB_TAP_CONV2: *ptr = W + e->w_a2; *floats = B * e->c2.Ho() * e->c2.Wo() * 64; break;
         case HAB_TAP_CONV3: *ptr = W + e->w_a3; *floats = B * e->fc_in; break;
         case HAB_TAP_RNN_IN: *ptr = W + e->w_rnnin; *floats = B * e->rnn_ld; break;

@@ -39,7 +39,7 @@ static std::atomic<int> g_bf3_mode{-1};  // engines of several inference-worker 
 static int bf3_mode() {
     int m = g_bf3_mode.load(std::memory_order_relaxed);
     if (m < 0) {
-        static const int from_env = hab_env_int("HAB_BF3", 2047);
+        static const int from_env = hab_env_int("HAB_BF3", 1023);
         int expected = -1;
         g_bf3_mode.compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
         m = g_bf3_mode.load(std::memory_order_relaxed);
@@ -134,14 +134,11 @@ static int run_igemm(const P& p, float* ws, size_t ws_floats, hipStream_t stream
 }
 
 int conv_fwd(const ConvDesc& d, const float* x, const float* wf, const float* bias, float* y, int relu, float* ws,
-             size_t ws_floats, hipStream_t stream, unsigned* x_pos_bits, int* bits_written) {
+             size_t ws_floats, hipStream_t stream) {
     ConvFwdProb p;
     HAB_TRY(build(p, d, x, wf, bias, y, relu));
-    if (bits_written) *bits_written = 0;
     if ((bf3_mode() & 256) && (bf3_mode() & 1)) {  // SimpleCNN conv2: input strip in LDS, filter slices in registers (conv2_fwd_strip.h)
-        const bool bits = x_pos_bits && (bf3_mode() & 1024);
-        const int rc = conv2_fwd_strip(p, ws, ws_floats, stream, bits ? x_pos_bits : nullptr);
-        if (rc == HAB_OK && bits && bits_written) *bits_written = 1;
+        const int rc = conv2_fwd_strip(p, ws, ws_floats, stream);
         if (rc != 1) return rc;
     }
     if ((bf3_mode() & 16) && d.stride == 1 && d.KH == 3 && d.KW == 3 && p.M > 64) {  // input patch resident in LDS (conv_patch_bf3.h)
@@ -184,9 +181,9 @@ __global__ void dgrad_empty_class_kernel(ConvDgradProb p) {
 }
 
 int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add, float* dx,
-               float* ws, size_t ws_floats, hipStream_t stream, const unsigned* mask_bits) {
+               float* ws, size_t ws_floats, hipStream_t stream) {
     if ((bf3_mode() & 512) && (bf3_mode() & 1)) {  // SimpleCNN conv2: dY strip in LDS, filter slices in registers (conv2_dgrad_strip.h)
-        const int rc = conv2_dgrad_strip(d, dy, wd, mask, add, dx, stream, (bf3_mode() & 1024) ? mask_bits : nullptr);
+        const int rc = conv2_dgrad_strip(d, dy, wd, mask, add, dx, stream);
         if (rc != 1) return rc;
     }
     if (d.stride > 1 && !no_dma() && !no_merged_dgrad()) {

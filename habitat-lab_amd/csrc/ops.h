@@ -13,18 +13,15 @@ struct ConvDesc {
 struct ObsView;
 
 // gemm_ops.hip
-// x_pos_bits (optional, [B][H][W] words): asks the kernel to leave the sign pattern of its INPUT there, bit c = (x[..][c] > 0), for a
-// later conv_dgrad(mask_bits); *bits_written says whether the kernel that ran did (only the strip-resident forms can: C == 32)
 int conv_fwd(const ConvDesc& d, const float* x, const float* wf, const float* bias, float* y, int relu, float* ws,
-             size_t ws_floats, hipStream_t stream, unsigned* x_pos_bits = nullptr, int* bits_written = nullptr);
+             size_t ws_floats, hipStream_t stream);
 // wimg: bf16 weight image of wf for the patch-resident kernel (obs_conv_weight_image; obs_conv_weight_image_floats() floats), or null
 int obs_conv_fwd(const ConvDesc& d, const ObsView& obs, const float* wf, const float* bias, float* y, int relu, float* ws,
                  size_t ws_floats, hipStream_t stream, const void* wimg = nullptr);
 int64_t obs_conv_weight_image_floats();
 int obs_conv_weight_image(const float* wf, int Cout, int KH, int KW, int C, void* img, hipStream_t stream);  // 1: no image for this filter
-// mask_bits (optional): the ReLU mask as conv_fwd's x_pos_bits; used by the kernels that can read it, `mask` stays the fallback
 int conv_dgrad(const ConvDesc& d, const float* dy, const float* wd, const float* mask, const float* add, float* dx,
-               float* ws, size_t ws_floats, hipStream_t stream, const unsigned* mask_bits = nullptr);
+               float* ws, size_t ws_floats, hipStream_t stream);
 int conv_wgrad(const ConvDesc& d, const float* x, const float* dy, float* dw_oihw, float* dbias, float* ws, size_t ws_floats,
                hipStream_t stream);
 int obs_conv_wgrad(const ConvDesc& d, const ObsView& obs, const float* dy, float* dw_oihw, float* dbias, float* ws,

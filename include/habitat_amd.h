@@ -178,10 +178,7 @@ int hab_sample_actions(const float* probs, const float* exp_noise, int64_t* acti
  *            the filter slices resident in the waves' registers (conv2_fwd_strip.h)
  *     bit 9  (with bit 0) SimpleCNN conv2's data gradient on the same scheme: dY strip in LDS, filter slices in registers, the four taps
  *            of a row class folded in LDS, ReLU mask fused (conv2_dgrad_strip.h)
- *     bit 10 (with bits 8 and 9) the ReLU mask of that data gradient as ONE BIT per element: conv2's forward strip kernel leaves the sign
- *            bits of its input (conv1's ReLU output) while it stages it, the data gradient reads 4 bytes per pixel instead of the
- *            128-byte activation row (engine only: hab_conv2d_* keep the fp32 mask argument); bit-identical results
- *   Default 2047 (all), env HAB_BF3 overrides.  hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one;
+ *   Default 1023 (all), env HAB_BF3 overrides.  hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one;
  *   mode < 0 only queries.  Results are fp32-equivalent on either path (tests/test_gpu_bf3.py: error vs float64 of both).
  * ------------------------------------------------------------------------------------------- */
 int hab_set_matrix_path(int mode);

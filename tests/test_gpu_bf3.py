@@ -468,7 +468,7 @@ def test_conv2_strip_resident_data_gradient_as_accurate_as_fp32_path(L, B, with_
 
 
 def test_non_finite_operands_on_the_split_path_are_pinned(L):
-    """DESIGN.md 4 / INTEGRATION.md: the 3-term split of +-Inf is (+-Inf, NaN, NaN), so on the split-bf16 path an Inf or NaN operand
+    """NOTEBOOK.md 4 / INTEGRATION.md: the 3-term split of +-Inf is (+-Inf, NaN, NaN), so on the split-bf16 path an Inf or NaN operand
     yields NaN in EVERY output it contributes to and nowhere else; the fp32 MFMA path (hab_set_matrix_path(0)) propagates +-Inf through
     products with finite non-zero factors.  Pinned so that a change of the split (or of the dispatch) that alters this shows up."""
     torch.manual_seed(0)
@@ -501,77 +501,3 @@ def test_non_finite_operands_on_the_split_path_are_pinned(L):
                 assert torch.isnan(y[reach]).all(), (bad, mode)  # split path: NaN wherever the operand is read
             else:
                 assert (y[reach] == bad).all(), (bad, mode)      # fp32 MFMA path: the infinity itself
-
-
-@pytest.mark.parametrize("size", [256, 128, 224, 84])
-def test_relu_sign_bits_of_conv2_are_the_float_mask(size):
-    """Matrix-path bit 10 (csrc/conv2_fwd_strip.h -> conv2_dgrad_strip.h): conv2's forward leaves one bit per element of its input
-    (conv1's ReLU output) and the data gradient reads those instead of the fp32 activation.  Engine level, SimpleCNN + GRU on `size` x
-    `size` RGB-D (256: the compile-time 63 x 63 instantiation; 128 / 224 / 84: runtime geometry 31 / 55 / 20, odd and even output
-    heights), a rows-indirected 16 x 4 minibatch cut into four time chunks of 16 frames as the trainer's:
-    (a) every gradient is BIT-IDENTICAL to the run with the bit off (fp32 mask);
-    (b) the bits really are what the backward reads: with conv1's output zeroed BEHIND the engine's back (a stale view, no tap call)
-        conv1's gradients are unchanged -- they only need the sign -- while conv2's weight gradient (which reads the values) is zero;
-    (c) the debug tap of conv1's output switches the backward back to the activation itself (oracle/parity.py's mask injector patches
-        ReLU decisions through it): zeroing the tapped activation now zeroes conv1's gradients too."""
-    from habitat_amd.engine import DevicePackInfo, PolicyEngine
-    from oracle.fixtures import baseline_param_shapes, det_params
-    L = _lib.lib()
-    H = W = size
-    T, n, hidden = 16, 4, 64
-    B = T * n
-    N_arena = 6  # arena of T + 1 rows x 6 envs; the minibatch takes 4 of them through `rows`
-    params = det_params(baseline_param_shapes(4, H, W, hidden), 5)
-    g = torch.Generator(device="cuda").manual_seed(size)
-    A = (T + 1) * N_arena
-    rgb = torch.randint(0, 256, (A, H, W, 3), dtype=torch.uint8, device="cuda", generator=g)
-    depth = torch.rand(A, H, W, 1, device="cuda", generator=g)
-    goal = torch.randn(A, 2, device="cuda", generator=g)
-    masks = torch.rand(A, 1, device="cuda", generator=g) > 0.2
-    actions = torch.randint(0, 4, (A, 1), device="cuda", generator=g)
-    h0 = torch.randn(A, 1, hidden, device="cuda", generator=g)
-    inds = np.array([4, 0, 5, 2])
-    rows = torch.from_numpy((np.arange(T)[:, None] * N_arena + inds[None, :]).reshape(-1).astype(np.int32)).cuda()
-    pack = DevicePackInfo(np.logical_not(masks.view(T + 1, N_arena).cpu().numpy()[:T, inds]), "cuda")
-    dv, dl, de = (torch.randn(B, device="cuda", generator=g) * 1e-2 for _ in range(3))
-    C1W, C2W = "net.visual_encoder.cnn.0.weight", "net.visual_encoder.cnn.2.weight"
-
-    def engine():
-        eng = PolicyEngine(arch="simple_cnn", rnn_type="GRU", rnn_layers=1, hidden=hidden, H=H, W=W, max_frames=B, max_envs=n)
-        eng.load({k: v.cuda() for k, v in params.items()})
-        return eng
-
-    def evaluate(eng):
-        out = [torch.zeros(B, device="cuda") for _ in range(3)]
-        eng.evaluate(rgb, depth, goal, rows, h0, masks, actions, pack, B, n, value=out[0], log_prob=out[1], entropy=out[2])
-        return out
-
-    def backward(eng):
-        eng.backward(rgb, depth, goal, rows, actions, pack, dv, dl, de)
-        torch.cuda.synchronize()
-        return eng.grads_flat.clone(), {k: v.clone() for k, v in eng.grad_views.items()}
-
-    default = L.hab_set_matrix_path(-1)
-    assert default & 1024, "bit 10 is part of the default matrix path"
-    eng = engine()
-    out_bits = evaluate(eng)
-    g_bits, gv_bits = backward(eng)
-    assert float(gv_bits[C1W].abs().max()) > 0 and float(gv_bits[C2W].abs().max()) > 0
-    prev = L.hab_set_matrix_path(default & ~1024)
-    try:
-        eng2 = engine()
-        out_f32 = evaluate(eng2)
-        g_f32, _ = backward(eng2)
-    finally:
-        L.hab_set_matrix_path(prev)
-    assert all(torch.equal(a, b) for a, b in zip(out_bits, out_f32))
-    assert torch.equal(g_bits, g_f32), float((g_bits - g_f32).abs().max())  # (a)
-    a1 = eng.tap(0)          # HAB_TAP_CONV1: a view into the workspace (this call switches THAT evaluate's backward to the activation)
-    evaluate(eng)            # a new forward: the sign bits are current again
-    a1.zero_()               # behind the engine's back
-    _, gv = backward(eng)
-    assert torch.equal(gv[C1W], gv_bits[C1W]) and float(gv[C2W].abs().max()) == 0.0  # (b)
-    evaluate(eng)
-    eng.tap(0).zero_()
-    _, gv = backward(eng)
-    assert float(gv[C1W].abs().max()) == 0.0 and float(gv[C2W].abs().max()) == 0.0  # (c)
