@@ -203,7 +203,7 @@ def cpu_baseline_and_parity(trainer, cfg, sample_envs=NUM_ENVS, sample_steps=NUM
                                  max_grad_norm=ppo.max_grad_norm, use_normalized_advantage=ppo.use_normalized_advantage,
                                  use_clipped_value_loss=ppo.use_clipped_value_loss, gamma=ppo.gamma, tau=ppo.tau)
     t0 = time.perf_counter()
-    buf, nv, perms, t_env = PR.oracle_rollout(params, spec, N, T, OBS, OBS, hidden, hl, ocfg)
+    buf, nv, perms, t_env = PR.oracle_rollout(params, spec, N, T, OBS, OBS, hidden, hl, ocfg, task="objectnav" if workload == "c5" else "pointnav")
     ref_metrics, trace, final = PR.oracle_update_trace(params, spec, buf, T, ocfg, trainable, perms)
     dt = time.perf_counter() - t0 - t_env
     base = {"value": round(N * T / dt, 2), "unit": "env-steps/s", "cores": threads, "kind": "port",
@@ -226,7 +226,7 @@ def cpu_baseline_and_parity(trainer, cfg, sample_envs=NUM_ENVS, sample_steps=NUM
     pol.load_state_dict(params)
     pol.train()
     upd = PPO.from_config(pol, ocfg)
-    if workload == "c2":  # one minibatch's per-frame outputs against the chunked oracle evaluation (the c3 leg reads them off the trace)
+    if workload == "c2":  # one minibatch's per-frame outputs against the chunked oracle evaluation (the c3 / c5 legs read them off the trace)
         adv = upd.get_advantages(st)
         batch = MiniBatch(st, perms[0][0], T, adv, torch.logical_not(B["masks"]).cpu().view(-1, N).numpy())  # first minibatch of epoch 0
         mb = PR.minibatch_parity(pol, upd, st, batch, ocfg, env_chunk=8, with_grads=False)
@@ -255,18 +255,20 @@ def cpu_baseline_and_parity(trainer, cfg, sample_envs=NUM_ENVS, sample_steps=NUM
     return base, out
 
 
-def c3_parity_record(state, envs=8, steps=NUM_STEPS):
-    """Whole-update parity of the ResNet18 + 2-layer LSTM policy (BASELINE.json configs[2]) on a BOUNDED sample: `envs` x 128 steps of
-    256x256 RGB-D, E = 2 x M = 2 -> 4 minibatch steps of envs / 2 x 128 frames (the CPU oracle needs ~20 s per 1000 frames of
-    forward + backward), from the parameters the c3 sub-record's cycles left (`state`).  RunningMeanAndVar updates every step."""
+def c3_parity_record(state, envs=8, steps=NUM_STEPS, workload="c3"):
+    """Whole-update parity of the ResNet policies on a BOUNDED sample, from the parameters the sub-record's cycles left (`state`);
+    RunningMeanAndVar updates every step.  c3 (BASELINE.json configs[2], ResNet18 + 2-layer LSTM): `envs` x 128 steps of 256x256 RGB-D,
+    E = 2 x M = 2 -> 4 minibatch steps of envs / 2 x 128 frames (the CPU oracle needs ~20 s per 1000 frames of forward + backward).
+    c5 (configs[4], ObjectNav ResNet50 on rgb + depth + semantic with objectgoal / compass / gps embeddings): 2 envs x 64 steps,
+    E = 4 x M = 2 -> 8 steps of 64 frames."""
     import torch
-    trainer, cfg = make_trainer("c3", 2, envs=envs, steps=steps)
+    trainer, cfg = make_trainer(workload, 2, envs=envs, steps=steps)
     trainer._init_train()
     trainer._agent.actor_critic.load_state_dict(state)
     t0 = time.perf_counter()
-    _, par = cpu_baseline_and_parity(trainer, cfg, sample_envs=envs, sample_steps=steps, workload="c3")
+    _, par = cpu_baseline_and_parity(trainer, cfg, sample_envs=envs, sample_steps=steps, workload=workload)
     par["oracle_and_hip_seconds"] = round(time.perf_counter() - t0, 1)
-    par["sample"] = f"{envs} envs x {steps} steps (bounded: the full 64 x 128 update takes the CPU oracle ~6 min)"
+    par["sample"] = f"{envs} envs x {steps} steps (bounded: the full update takes the CPU oracle minutes)"
     trainer.envs.close()
     del trainer
     torch.cuda.empty_cache()
@@ -664,7 +666,11 @@ def main():
             if par:
                 out["c3"]["parity"] = c3_parity_record(c3_state)
             del c3_state
-            out["c5"] = run_cycles("c5", 3, 1)  # BASELINE.json configs[4], per GPU
+            c5_state = {}
+            out["c5"] = run_cycles("c5", 3, 1, keep_state=c5_state)  # BASELINE.json configs[4], per GPU
+            if par:
+                out["c5"]["parity"] = c3_parity_record(c5_state, envs=2, steps=64, workload="c5")
+            del c5_state
             out["encoder_r18_b8192"] = encoder_record_one_call()
     if world > 1:
         if c4 is not None:

@@ -231,7 +231,8 @@ def returns_parity(storage, next_value: torch.Tensor, use_gae: bool, gamma: floa
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Whole-update parity: teacher-forced (every minibatch step of the HIP path starts from the ORACLE's pre-step state) and free-running
 # ---------------------------------------------------------------------------------------------------------------------------------
-def oracle_rollout(params: dict, spec: O.NetSpec, N: int, T: int, H: int, W: int, hidden: int, hidden_layers: int, cfg, seed: int = 4242):
+def oracle_rollout(params: dict, spec: O.NetSpec, N: int, T: int, H: int, W: int, hidden: int, hidden_layers: int, cfg, seed: int = 4242,
+                   task: str = "pointnav"):
     """The oracle collects one rollout of N synthetic envs x T steps (oracle/synth.py observations, policy.act per step with a fixed
     exponential-noise stream: rl/ppo/ppo_trainer.py:343-399), bootstraps the value of step T and computes the GAE returns
     (common/rollout_storage.py:174-205).  Returns (buffers shaped like RolloutStorage.buffers, next_value, the E x M env-column
@@ -240,11 +241,11 @@ def oracle_rollout(params: dict, spec: O.NetSpec, N: int, T: int, H: int, W: int
     from . import synth
     from .fixtures import synth_rollout_inputs
     t0 = _t.perf_counter()
-    envs = synth.SyntheticEnvs(N, H, W, seed=seed)
+    envs = synth.SyntheticEnvs(N, H, W, seed=seed, task=task)  # objectnav: + semantic, objectgoal, compass, gps (ddppo_objectnav.yaml)
     obs, rew, done = synth_rollout_inputs(envs, T)
     t_env = _t.perf_counter() - t0
     torch.manual_seed(7)
-    noise = torch.stack([torch.empty(N, 4).exponential_(1) for _ in range(T)])
+    noise = torch.stack([torch.empty(N, spec.num_actions).exponential_(1) for _ in range(T)])
     perms = [list(torch.randperm(N).chunk(cfg.num_mini_batch)) for _ in range(cfg.ppo_epoch)]
     buf = dict(observations={k: torch.from_numpy(np.stack([o[k] for o in obs])) for k in obs[0]})
     del obs

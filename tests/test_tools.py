@@ -24,6 +24,14 @@ def test_site_roofline_picks_the_bound_that_takes_longer():
     r2 = bench.site_roofline("conv2_fwd", bench.PROBES["conv2_fwd"][1], 2048, 1.0)
     assert r2["bound"] == "mfma" and r2["unit"] == "TFLOP/s" and abs(r2["peak"] - 416.7) < 0.1
     assert abs(r2["frac"] - r2["achieved"] / r2["peak"]) < 1e-3
+    # conv2 data gradient: written to read the fp32 activation for its sign (1 246 464 B -> HBM-bound, 0.156 us); the computation needs
+    # a 1-bit mask (754 308 B -> 0.094 us, below the 0.142 us MFMA floor): both positions are on the record
+    r4 = bench.site_roofline("conv2_dgrad", bench.PROBES["conv2_dgrad"][1], 512, 0.2)
+    assert r4["bound"] == "hbm" and r4["algorithmic_bytes_per_frame"] == 1246464
+    assert r4["algorithmic_bytes_needed"] == 30 * 30 * 64 * 4 + 63 * 63 * 32 * 4 + 63 * 63 * 4 and r4["bound_with_bytes_needed"] == "mfma"
+    assert abs(r4["frac_of_bytes_needed"] - (bench.PROBES["conv2_dgrad"][1] / (2500e12 / 6)) / (0.2e-3 / 512)) < 1e-3
+    assert r4["frac_of_bytes_needed"] < r4["frac"]
+    assert "algorithmic_bytes_needed" not in r2
     # a call site without a model (recurrent steps) is priced against the fp32 MFMA peak
     r3 = bench.site_roofline("rnn_fwd", bench.PROBES["rnn_fwd"][1], 2048, 1.0)
     assert r3["peak"] == bench.PEAK_FP32_MFMA_TFLOPS and r3["bound"] == "mfma"

@@ -10,12 +10,12 @@
 # Every profiler pass runs under `timeout`: a rocprofv3 --pmc pass of the C3 command once hung until gpurun's limit.
 # usage: tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>_*   (copy what is to be judged into profiles/)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
-python bench.py > $O/${TAG}_c2_bench.json 2> $O/${TAG}_c2_bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_c2_bench.json 2> $O/${TAG}_c2_bench.err   # the driver's command
 python bench.py --workload c3 --steps 10 --warmup 2 > $O/${TAG}_c3_bench.json 2> $O/${TAG}_c3_bench.err
 python bench.py --workload c5 --steps 5 --warmup 2 > $O/${TAG}_c5_bench.json 2> $O/${TAG}_c5_bench.err
 cd /tmp
