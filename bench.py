@@ -94,7 +94,8 @@ SITE_MODEL = {
     "conv1_fwd": (_A0 + _A1, 3.75), "conv1_wgrad": (_A0 + _A1, 3.75),
     "conv2_fwd": (_A1 + _A2, 6.0), "conv2_wgrad": (_A1 + _A2, 6.0), "conv2_dgrad": (_A2 + 2 * _A1, 6.0),  # dgrad reads the ReLU mask
     "conv3_fwd": (_A2 + _A3, 6.0), "conv3_wgrad": (_A2 + _A3, 6.0), "conv3_dgrad": (_A3 + 2 * _A2, 6.0),
-    "fc_fwd": (_A3 + 2048, 6.0), "fc_wgrad": (_A3 + 2048, 6.0), "fc_dgrad": (_A3 + 2048 + _A3, 6.0),
+    # (no ReLU behind conv3 -- simple_cnn.py:84-86 has it commented out --, so the fc data gradient reads no mask: dY in, dX out)
+    "fc_fwd": (_A3 + 2048, 6.0), "fc_wgrad": (_A3 + 2048, 6.0), "fc_dgrad": (_A3 + 2048, 6.0),
 }
 
 

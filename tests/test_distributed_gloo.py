@@ -346,3 +346,72 @@ def test_ver_preemption_decider_gloo(world):
         assert all(o["deadlines"][i] == a["deadlines"][i] for i in range(len(a["deadlines"])))
         if r != 1:
             assert o["my_steps"] > 2.5 * slow["my_steps"] > 0, (r, o["my_steps"], slow["my_steps"])
+
+
+def _ver_rank_worker(rank, world, port, q):
+    """One rank of a multi-rank VER run on CPU: the production worker pool with THREE inference-worker threads, the preemption decider
+    with its collectives on a gloo group, the rank's threads confined by ddp_utils.pin_rank_affinity (for real: the ranks of this test
+    inherit one shared mask)."""
+    for p in (ROOT, os.path.join(ROOT, "habitat-lab_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import threading
+    import numpy as np
+    from habitat_amd.rl.ddppo import ddp_utils
+    store = dist.TCPStore("127.0.0.1", port, world, rank == 0)
+    dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
+    before = sorted(os.sched_getaffinity(0))
+    block = ddp_utils.pin_rank_affinity(rank)
+    after = sorted(os.sched_getaffinity(0))
+    group = dist.new_group(backend="gloo")
+    import test_ver_workers as V
+    N, T = 4, 6
+    speeds = np.array([20.0, 10.0, 4.0, 20.0]) / (3.0 if rank == 1 else 1.0)  # rank 1: 3x slower environments
+    h = V.Harness(N, T, 3, False, list(speeds), seed=rank, preemption=True, decider_kw=dict(world_rank=rank, world_size=world, group=group))
+    threads_seen = 0
+    try:
+        ends, filled = [], []
+        for k in range(6):
+            filled.append(h.cycle(lambda st: int(st.num_steps_collected[0])))  # what the learner is handed
+            ends.append(float(h.decider.rollout_ends.time))
+            threads_seen = max(threads_seen, sum(1 for t in threading.enumerate() if t.is_alive()))
+    finally:
+        h.pool.shutdown()
+    q.put((rank, dict(before=before, block=block, after=after, threads=threads_seen, ends=ends, filled=filled,
+                      workers_alive=sum(t.is_alive() for t in h.pool.threads))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [8])
+def test_ver_worker_pool_three_threads_per_rank_under_affinity_gloo(world):
+    """a world-8 run of the VER worker protocol with three inference-worker threads per rank (the trainer thread
+    makes four) under pin_rank_affinity -- on a shared mask every rank ends up on its own block of CPUs (here: 8 ranks on the
+    container's cores), the four threads of a rank share that block and the GIL, the decider's gather / reduce / broadcast run on gloo
+    beside them with rank 1 as an injected straggler.  Six cycles complete on every rank, every rollout hands the learner a full
+    buffer, no worker thread is left behind, and once the schedule is active every rank holds the same deadline."""
+    port = find_free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ver_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    shared = res[0]["before"]
+    blocks = []
+    for r in range(world):
+        o = res[r]
+        assert o["before"] == shared                      # torchrun-like: one inherited mask
+        assert len(o["filled"]) == 6 and min(o["filled"]) > 0 and o["workers_alive"] == 0 and o["threads"] >= 3
+        if len(shared) >= world:                          # enough CPUs to give every rank its own block
+            assert o["block"] == o["after"] and len(o["after"]) == len(shared) // world
+            blocks.append(set(o["after"]))
+        else:
+            assert o["block"] is None or o["after"] == shared
+    if blocks:
+        assert sum(len(b) for b in blocks) == len(set().union(*blocks))  # disjoint
+    active = [i for i, t in enumerate(res[0]["ends"]) if t > 0]
+    for i in active:
+        assert len({res[r]["ends"][i] for r in range(world)}) == 1  # one common deadline per rollout

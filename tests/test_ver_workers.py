@@ -112,11 +112,12 @@ def make_config(train_encoder=True, n_envs=1, n_steps=1, overlap=False):
 class Harness:
     """What VERTrainer does around the pool, minus the device-only pieces (returns / importance weights / the PPO update)."""
 
-    def __init__(self, n_envs, n_steps, n_workers, overlap, speeds, seed=0, variable_experience=True, preemption=False):
+    def __init__(self, n_envs, n_steps, n_workers, overlap, speeds, seed=0, variable_experience=True, preemption=False, decider_kw=None):
         self.N, self.T, self.overlap = n_envs, n_steps, overlap
         from habitat_amd.rl.ver.preemption_decider import PreemptionDecider
         cfg = make_config(n_envs=n_envs, n_steps=n_steps, overlap=overlap)
-        self.decider = PreemptionDecider(cfg, time.perf_counter()) if preemption else None
+        # decider_kw: world_rank / world_size / group of a multi-rank run (tests/test_distributed_gloo.py)
+        self.decider = PreemptionDecider(cfg, time.perf_counter(), **(decider_kw or {})) if preemption else None
         osp = S.Dict({"x": S.Box(-1e9, 1e9, (2,), np.float32)})
         self.learner_policy = ClockPolicy()
         mk = lambda: VERRolloutStorage(n_steps, n_envs, osp, S.Discrete(4), self.learner_policy, variable_experience, device="cpu")
