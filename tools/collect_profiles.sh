@@ -28,7 +28,9 @@ for W in c2 c3 c5; do
   grep '^{' $O/prof_${TAG}_$W.log | tail -1 > $O/${TAG}_${W}_profiled_bench.json
   rm -rf /tmp/prof_${TAG}_$W $O/prof_${TAG}_$W.log
 done
-for W in c2 c3 c5; do
+# (C5: `rocprofv3 --pmc` of the ObjectNav command hung in three of four attempts in round 5 -- FETCH_SIZE, WRITE_SIZE and the SQ group each
+#  ran into their `timeout` on different boxes -- and cost 10 GPU-minutes per collection; its counter passes are run only with PMC_C5=1)
+for W in c2 c3 ${PMC_C5:+c5}; do
   rm -rf /tmp/pmc_${TAG}_$W
   for PM in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $PM --kernel-trace -d /tmp/pmc_${TAG}_$W -o $PM --output-format csv -- python $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
@@ -40,7 +42,7 @@ cd $R
 tools/pmc_run.sh /tmp/pmcsq_${TAG} python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline
 python tools/pmc_sq.py /tmp/pmcsq_${TAG} $O/${TAG}_c2_sq_counters.txt > /dev/null
 rm -rf /tmp/pmcsq_${TAG}
-for W in c3 c5; do
+for W in c3 ${PMC_C5:+c5}; do
   PMC_GROUPS=1 tools/pmc_run.sh /tmp/pmcsq_${TAG}_$W python $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline
   python tools/pmc_sq.py /tmp/pmcsq_${TAG}_$W $O/${TAG}_${W}_sq_counters.txt > /dev/null
   rm -rf /tmp/pmcsq_${TAG}_$W
