@@ -141,31 +141,47 @@ def rank_cpu_block(cpus, local_rank: int, local_world: int):
     return cpus[local_rank * per:(local_rank + 1) * per]
 
 
-def _local_sharers(mask):
-    """World ranks ON THIS HOST whose inherited CPU mask is identical to `mask` (this rank included), ascending -- or None without a
-    process group.  One all_gather_object of (hostname, mask) at start-up."""
+_AFFINITY_CALLS = [0]  # per-process count of mask exchanges: every rank makes the same calls, so call k reads call k's keys
+
+
+def _local_sharers(mask, store=None):
+    """World ranks ON THIS HOST whose inherited CPU mask is identical to `mask` (this rank included), ascending -- or None when the ranks
+    cannot be asked.  The masks travel through the rendezvous STORE (plain key / value traffic with rank 0's server), not through a
+    collective: this runs right after init_process_group, BEFORE the rank has selected its GPU, and an object collective on the nccl
+    backend would stage its payload on the current device -- cuda:0 on every rank.  Without a store: a gloo group may use
+    all_gather_object; an nccl group without a store returns None (the caller falls back to the whole-host test)."""
     if not (distrib.is_available() and distrib.is_initialized()):
         return None
+    import json
     import socket
-    mine = (socket.gethostname(), tuple(mask))
-    everyone = [None] * distrib.get_world_size()
-    distrib.all_gather_object(everyone, mine)
+    mine = [socket.gethostname(), list(mask)]
+    world, rank = distrib.get_world_size(), distrib.get_rank()
+    if store is not None:
+        k = _AFFINITY_CALLS[0]
+        _AFFINITY_CALLS[0] += 1
+        store.set(f"hab_affinity/{k}/{rank}", json.dumps(mine))
+        everyone = [json.loads(bytes(store.get(f"hab_affinity/{k}/{r}")).decode()) for r in range(world)]  # get() waits for the key
+    elif distrib.get_backend() == "gloo":
+        everyone = [None] * world
+        distrib.all_gather_object(everyone, mine)
+    else:
+        return None
     return [r for r, other in enumerate(everyone) if other == mine]
 
 
-def pin_rank_affinity(local_rank: int, local_world: Optional[int] = None):
+def pin_rank_affinity(local_rank: int, local_world: Optional[int] = None, store=None):
     """One process per GPU, each enqueueing ~7 500 launches per update cycle: without pinning, 8 ranks' host threads migrate across the
     sockets of the node and share cores with each other's environment workers.  Restricts this process (and the threads / workers it
     starts afterwards) to its block of the CPUs it may run on -- but ONLY when the mask it inherited is SHARED with other local ranks
     (torchrun on a whole node).  A launcher that already confined every task to its own CPUs -- SLURM task affinity / cgroups: the
     reference's README launch gives each of 4 tasks --cpus-per-task 10 -- is left alone: slicing those 10 CPUs by 4 again would leave
     each rank, and the environment workers that inherit its mask, 2 of them.  Sharing is established by comparing the masks of the
-    ranks on this host (one all_gather_object; without a process group: the mask covers every CPU of the host).
+    ranks on this host through the rendezvous `store` (see _local_sharers; without any way to ask: the mask covers every CPU of the host).
     HAB_NO_AFFINITY=1 leaves the affinity alone.  Returns the chosen CPUs, or None when nothing was changed."""
     if os.environ.get("HAB_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
         return None
     mask = sorted(os.sched_getaffinity(0))
-    sharers = _local_sharers(mask)
+    sharers = _local_sharers(mask, store)
     if sharers is not None:
         if len(sharers) <= 1:
             return None  # nobody else on this host runs on these CPUs: they are this rank's already

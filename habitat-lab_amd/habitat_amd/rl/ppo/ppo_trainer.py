@@ -115,7 +115,9 @@ class PPOTrainer(BaseRLTrainer):
         self._add_preemption_signal_handlers()
         if self._is_distributed:
             local_rank, tcp_store = init_distrib_slurm(hb.rl.ddppo.distrib_backend)
-            pin_rank_affinity(local_rank)  # each rank's launch thread (and its env workers) on its own block of host cores
+            # each rank's launch thread (and its env workers) on its own block of host cores; the masks are compared through the store:
+            # no collective may run before the rank has selected its GPU (below)
+            pin_rank_affinity(local_rank, store=tcp_store)
             if rank0_only():
                 logger.info("Initialized DD-PPO with {} workers".format(torch.distributed.get_world_size()))
             with read_write(self.config):

@@ -120,7 +120,7 @@ def _worker(rank, world, port, q):
     out["local_rank"] = local_rank
     from habitat_amd.rl.ddppo.ddp_utils import rank_cpu_block
     out["cpus"] = rank_cpu_block(list(range(64)), rank, world)
-    out["affinity"] = _affinity_cases(rank, world)
+    out["affinity"] = _affinity_cases(rank, world, store)
     out["native"] = _native_comm_negotiation_cases(rank, world)
     # plain numpy through the queue: a tensor travels as a shared-memory handle that dies with this process
     q.put((rank, {k: (v.numpy().copy() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}))
@@ -128,10 +128,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _affinity_cases(rank, world):
+def _affinity_cases(rank, world, store):
     """ddp_utils.pin_rank_affinity with the process's mask faked (nothing is really pinned): (a) every rank inherited the same 64
-    CPUs (torchrun on a whole node) -> disjoint blocks; (b) the launcher already gave every rank its own CPUs (SLURM task affinity,
-    ADVICE r04) -> left alone; (c) HAB_NO_AFFINITY."""
+    CPUs (torchrun on a whole node) -> disjoint blocks, the masks compared through the rendezvous STORE as the trainer does (no
+    collective: on the nccl backend the call runs before the rank has selected its GPU), twice (a second trainer of the same process
+    asks again: fresh keys); (b) the launcher already gave every rank its own CPUs (SLURM task affinity) -> left alone
+    (asked through the gloo group's all_gather_object, the store-less form); (c) HAB_NO_AFFINITY."""
     from habitat_amd.rl.ddppo import ddp_utils
     res = {}
     real_get, real_set = os.sched_getaffinity, os.sched_setaffinity
@@ -139,8 +141,9 @@ def _affinity_cases(rank, world):
     try:
         os.sched_setaffinity = lambda pid, cpus: chosen.append(sorted(cpus))
         os.sched_getaffinity = lambda pid: set(range(64))
-        res["shared"] = ddp_utils.pin_rank_affinity(rank)
+        res["shared"] = ddp_utils.pin_rank_affinity(rank, store=store)
         assert chosen[-1] == res["shared"]
+        assert ddp_utils.pin_rank_affinity(rank, store=store) == res["shared"]  # asked again (still the shared fake mask): same answer
         os.sched_getaffinity = lambda pid: set(range(10 * rank, 10 * rank + 10))  # --cpus-per-task 10, bound per task
         n = len(chosen)
         res["confined"] = ddp_utils.pin_rank_affinity(rank)
@@ -360,7 +363,7 @@ def _ver_rank_worker(rank, world, port, q):
     store = dist.TCPStore("127.0.0.1", port, world, rank == 0)
     dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
     before = sorted(os.sched_getaffinity(0))
-    block = ddp_utils.pin_rank_affinity(rank)
+    block = ddp_utils.pin_rank_affinity(rank, store=store)
     after = sorted(os.sched_getaffinity(0))
     group = dist.new_group(backend="gloo")
     import test_ver_workers as V
