@@ -76,6 +76,9 @@ struct hab_policy {
     // device-side exchange (comm.hip): when set, the gradient tails and the RunningMeanAndVar moments are all-reduced on this RCCL
     // communicator from inside backward / forward instead of through the two callbacks above
     struct hab_comm* comm = nullptr;
+    // gradients wrt `rnn_output` [B][H] / `perception_embed` [B][H] that reach the net from OUTSIDE the fused heads: auxiliary losses
+    // computed by torch modules on the autograd bridge (rl/ppo/policy.py:386-394); consumed and cleared by the next hab_policy_backward
+    const float* xg_feat = nullptr; const float* xg_perc = nullptr;
     int comm_err = 0;                                   // first error of a tail exchange of the current backward (HAB_OK: none)
     int64_t comm_first = -1;                            // grads[comm_first ..) has been enqueued for exchange in this backward (-1: nothing)
     hipStream_t cur_stream = nullptr;                   // stream of the running hab_policy_backward

@@ -583,6 +583,29 @@ extern "C" int hab_policy_final_hidden(hab_policy* e, float* hidden_out, hipStre
 // Backward of the last hab_policy_evaluate: given dL/dvalue, dL/dlog_prob, dL/dentropy per frame,
 // writes EVERY parameter gradient into the gradient arena (overwrites; no accumulation).
 // ------------------------------------------------------------------------------------------
+// dst[i] += src[i]  /  dst[f][c] += src[f][c] * (x[f][c] > 0) for c < H (the ReLU of the visual fc sits between perception_embed and x)
+__global__ void add_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+__global__ void add_masked_cols_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, const float* __restrict__ x, int ldx,
+                                       int B, int H) {
+    const long long n = (long long)B * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(i / H), c = (int)(i % H);
+        if (x[(size_t)f * ldx + c] > 0.f) dst[(size_t)f * ldd + c] += src[i];
+    }
+}
+// Auxiliary-loss hook (rl/ppo/policy.py:253-291,386-394; rl/ppo/ppo.py:248): d_rnn_output / d_perception_embed are [B][H] device
+// arrays in the frame order of the last evaluate (either may be null).  They are added where those tensors sit in the backward chain --
+// behind the heads' gradient wrt the features, and (through the visual fc's ReLU) onto the gradient wrt the recurrent encoder's input --
+// by the NEXT hab_policy_backward, which forgets them.  Packed form only (the autograd bridge evaluates dense batches).
+extern "C" int hab_policy_set_extra_grads(hab_policy* e, const float* d_rnn_output, const float* d_perception_embed) {
+    if (!e) return HAB_ERR_ARG;
+    if (d_perception_embed && e->Cin == 0) return HAB_ERR_ARG;  // a blind net has no perception embedding
+    e->xg_feat = d_rnn_output; e->xg_perc = d_perception_embed;
+    return HAB_OK;
+}
+
 static int policy_backward_impl(hab_policy* e, const hab_obs* obs, const int* rows, const int64_t* actions,
                                 const hab_pack_info* pack, const float* d_value, const float* d_log_prob,
                                 const float* d_entropy, hipStream_t stream) {
@@ -621,6 +644,13 @@ static int policy_backward_impl(hab_policy* e, const hab_obs* obs, const int* ro
         HAB_TRY(linear_wgrad(W + e->w_dv, 1, feats, H, e->g(e->i_cw), H, B, 1, H, 0, 0, 0, ws, e->ws_floats, stream));
         HAB_TRY(colsum(W + e->w_dzv, 8, B, A, e->g(e->i_ab), 0, ws, e->ws_floats, stream));
         HAB_TRY(colsum(W + e->w_dv, 1, B, 1, e->g(e->i_cb), 0, ws, e->ws_floats, stream));
+    }
+    if (e->xg_feat || e->xg_perc) {
+        if (e->last_tm > 0) return HAB_ERR_UNSUPPORTED;  // (time-major chunks consume d_rnnin chunk by chunk: the bridge never takes that form)
+        if (e->xg_feat) {
+            add_rows_kernel<<<(int)std::min<long long>(1024, cdivl((long long)B * H, 256)), 256, 0, stream>>>(W + e->w_dfeat, e->xg_feat, (long long)B * H);
+            HAB_LAUNCH_CHECK();
+        }
     }
     ConvDesc c1 = e->c1, c2 = e->c2, c3 = e->c3;
     c1.B = c2.B = c3.B = B;
@@ -745,6 +775,11 @@ static int policy_backward_impl(hab_policy* e, const hab_obs* obs, const int* ro
                                        nofc ? 0 : H, pk, W + e->w_scratch, ws, e->ws_floats, stream));
         dout = dx;
     }
+    if (e->xg_perc) {  // d rnn_in[:, :H] += d perception_embed, through the ReLU between them (the mask the layer-0 backward applied to its own part)
+        add_masked_cols_kernel<<<(int)std::min<long long>(1024, cdivl((long long)B * H, 256)), 256, 0, stream>>>(
+            W + e->w_drnnin, e->rnn_ld, e->xg_perc, W + e->w_rnnin, e->rnn_ld, B, H);
+        HAB_LAUNCH_CHECK();
+    }
     if (!e->rn && e->Cin == 0) {  // blind baseline policy: the recurrent encoder and the heads are all there is
         grad_tail_ready(e, e->i_wih[0]);
         return HAB_OK;
@@ -782,6 +817,7 @@ extern "C" int hab_policy_backward(hab_policy* e, const hab_obs* obs, const int*
                                    const hab_pack_info* pack, const float* d_value, const float* d_log_prob,
                                    const float* d_entropy, hipStream_t stream) {
     const int rc = policy_backward_impl(e, obs, rows, actions, pack, d_value, d_log_prob, d_entropy, stream);
+    if (e) e->xg_feat = e->xg_perc = nullptr;  // consumed (or refused) by this call
     return (rc == HAB_OK && e && e->comm_err != HAB_OK) ? e->comm_err : rc;
 }
 

@@ -124,6 +124,7 @@ SIGNATURES = {
     "hab_policy_act": (c_int, [vp, POINTER(Obs), vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp, vp]),
     "hab_policy_evaluate": (c_int, [vp, POINTER(Obs), vp, vp, c_int, vp, vp, POINTER(PackInfo), c_int, c_int, vp, vp, vp, vp]),
     "hab_policy_final_hidden": (c_int, [vp, vp, vp]),
+    "hab_policy_set_extra_grads": (c_int, [vp, vp, vp]),
     "hab_policy_backward": (c_int, [vp, POINTER(Obs), vp, vp, POINTER(PackInfo), vp, vp, vp, vp]),
     "hab_policy_probe_enable": (c_int, [vp, c_int]),
     "hab_policy_probe_read": (c_int, [vp, POINTER(c_double), POINTER(c_int)]),

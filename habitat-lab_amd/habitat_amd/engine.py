@@ -290,6 +290,14 @@ class PolicyEngine:
         self._call(lambda: self.L.hab_policy_backward(self.h, C.byref(o), ptr(rows), ptr(actions), C.byref(pack.struct), ptr(d_value),
                                                       ptr(d_log_prob), ptr(d_entropy), stream_ptr()), "hab_policy_backward")
 
+    def set_extra_grads(self, d_rnn_output, d_perception_embed):
+        """Gradients wrt `rnn_output` / `perception_embed` ([B][hidden] fp32, frame order of the last evaluate; either may be None) from
+        auxiliary losses: added inside the NEXT backward() where those tensors sit in its chain.  The caller keeps the tensors alive
+        until that backward has been enqueued."""
+        for t in (d_rnn_output, d_perception_embed):
+            assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
+        check(self.L.hab_policy_set_extra_grads(self.h, ptr(d_rnn_output), ptr(d_perception_embed)), "hab_policy_set_extra_grads")
+
     def tap(self, which: int) -> torch.Tensor:
         p, n = C.c_void_p(), C.c_int64(0)
         check(self.L.hab_policy_tap(self.h, which, C.byref(p), C.byref(n)), "hab_policy_tap")

@@ -128,11 +128,25 @@ class _EvaluateFn(torch.autograd.Function):
     def forward(ctx, policy, call, *params):
         ctx.policy, ctx.call = policy, call
         v, lp, ent = policy._evaluate_dense(call)
-        return v, lp, ent
+        # `aux_loss_state` of the reference's nets (policy.py:565-589, resnet_policy.py:634-767): the recurrent encoder's output and the
+        # visual embedding (ReLU(visual fc); absent for a blind net) -- copies of the engine's activations, differentiable through backward()
+        eng, B, H = policy.engine, call["B"], policy.recurrent_hidden_size
+        feats = eng.tap(4)[:B * H].view(B, H).clone()                                  # HAB_TAP_RNN_OUT
+        blind = getattr(policy, "is_blind", False) or not (policy._engine_kwargs.get("has_rgb") or policy._engine_kwargs.get("has_depth")
+                                                          or policy._engine_kwargs.get("has_semantic"))
+        ctx.has_perc = not blind
+        ctx.use_extra = len(policy.aux_loss_modules) > 0  # (decided here: no device read-back to find out whether a gradient is zero)
+        perc = eng.tap(3).view(B, -1)[:, :H].clone() if not blind else v.new_zeros(B, 0)  # HAB_TAP_RNN_IN[:, :hidden]
+        return v, lp, ent, feats, perc
 
     @staticmethod
-    def backward(ctx, dv, dlp, dent):
+    def backward(ctx, dv, dlp, dent, dfeat, dperc):
         pol, call = ctx.policy, ctx.call
+        if ctx.use_extra:  # gradients that reached the two aux_loss_state tensors from the auxiliary losses
+            xf = dfeat.contiguous() if dfeat is not None else None
+            xp = dperc.contiguous() if (ctx.has_perc and dperc is not None) else None
+            pol.engine.set_extra_grads(xf, xp)
+            ctx.keep = (xf, xp)  # alive until the backward below has been enqueued
         pol._backward_dense(call, dv.contiguous().view(-1), dlp.contiguous().view(-1), dent.contiguous().view(-1))
         if pol._dense_grad_sync is not None:  # DD-PPO: what DistributedDataParallel does inside backward (ddppo.py:110-157)
             pol._dense_grad_sync()
@@ -163,7 +177,7 @@ class NetPolicy(nn.Module, Policy):
                 _attach(self, name, value, buffer=True)
             else:
                 _attach(self, name, nn.Parameter(value))
-        self.aux_loss_modules = nn.ModuleDict()
+        self.aux_loss_modules = nn.ModuleDict()  # filled by _build_aux_modules (subclass ctors): rl/ppo/policy.py:287-289,592-608
         self.train()
 
     # ---- reference properties -----------------------------------------------------------------
@@ -181,7 +195,26 @@ class NetPolicy(nn.Module, Policy):
     def _get_policy_components(self) -> List[nn.Module]:
         return [self._modules["net"], self._modules["critic"], self._modules["action_distribution"]]
 
-    def aux_loss_parameters(self): return {}
+    def aux_loss_parameters(self): return {k: v.parameters() for k, v in self.aux_loss_modules.items()}
+
+    def _build_aux_modules(self, aux_loss_config, action_space) -> None:
+        """get_aux_modules (rl/ppo/policy.py:592-608): one module per entry of habitat_baselines.rl.auxiliary_losses, looked up in the
+        registry (`baseline_registry.register_auxiliary_loss`) and built as `cls(action_space, net, **cfg)`.  `net` is the policy's
+        parameter container with the attributes the reference's losses read off a Net (output_size, perception_embedding_size,
+        num_recurrent_layers, recurrent_hidden_size, is_blind).  The modules are ordinary torch modules: they live outside the flat
+        arena, are called from evaluate_actions on the autograd bridge and optimised by the updater's second Adam (ppo.py)."""
+        if not aux_loss_config:
+            return
+        net = self._modules["net"]
+        net.output_size = net.recurrent_hidden_size = net.perception_embedding_size = self._hidden
+        net.num_recurrent_layers = self.num_recurrent_layers
+        net.is_blind = not (self._engine_kwargs.get("has_rgb") or self._engine_kwargs.get("has_depth") or self._engine_kwargs.get("has_semantic"))
+        items = aux_loss_config.items() if hasattr(aux_loss_config, "items") else aux_loss_config
+        for name, cfg in items:
+            cls = baseline_registry.get_auxiliary_loss(str(name))
+            if cls is None:
+                raise _lib.HabError(f"auxiliary loss '{name}' is not registered (baseline_registry.register_auxiliary_loss)")
+            self.aux_loss_modules[str(name)] = cls(action_space, net, **dict(cfg))
 
     def forward(self, *x):
         raise NotImplementedError
@@ -360,14 +393,22 @@ class NetPolicy(nn.Module, Policy):
         pack = _pack_from_seq_info(rnn_build_seq_info, B, n, self.device)
         call = dict(rgb=rgb, depth=depth, goal=goal, extra=extra, hidden0=rnn_hidden_states.contiguous(), masks=masks.contiguous(),
                     actions=action.contiguous(), prev_actions=prev_actions, pack=pack, B=B, n=n)
+        aux_loss_res = {}
         if torch.is_grad_enabled():
             own = self.engine.grad_views
-            v, lp, ent = _EvaluateFn.apply(self, call, *(p_ for k, p_ in self.named_parameters() if k in own))
+            v, lp, ent, feats, perc = _EvaluateFn.apply(self, call, *(p_ for k, p_ in self.named_parameters() if k in own))
+            if len(self.aux_loss_modules) > 0:  # rl/ppo/policy.py:386-394
+                aux_loss_state = {"rnn_output": feats}
+                if perc.shape[1] > 0:
+                    aux_loss_state["perception_embed"] = perc
+                batch = dict(observations=observations, rnn_hidden_states=rnn_hidden_states, prev_actions=prev_actions, masks=masks,
+                             action=action, rnn_build_seq_info=rnn_build_seq_info)
+                aux_loss_res = {k: m(aux_loss_state, batch) for k, m in self.aux_loss_modules.items()}
         else:
             v, lp, ent = self._evaluate_dense(call)
         hidden = torch.empty(n, self.num_recurrent_layers, self._hidden, device=self.device)
         self.engine.final_hidden(hidden)
-        return v, lp, ent, hidden, {}
+        return v, lp, ent, hidden, aux_loss_res
 
     def _evaluate_dense(self, c):
         dev, B = self.device, c["B"]
@@ -451,8 +492,6 @@ class PointNavBaselinePolicy(NetPolicy):
         if goal_key is None:
             raise _lib.HabError(f"PointNavBaselinePolicy on habitat_amd needs the '{GOAL_UUID}' or the '{POINTGOAL_UUID}' sensor"
                                 + (" (an 'imagegoal' goal encoder is outside the accelerated path)" if "imagegoal" in sp else ""))
-        if aux_loss_config:
-            raise _lib.HabError("auxiliary losses are outside the accelerated path")
         # blind (no rgb / depth, SimpleCNN.is_blind simple_cnn.py:54): the net is goal -> GRU -> heads -- the configuration of the
         # reference's own DD-PPO test (test/test_ddppo_reduce.py:43-56)
         vis = sp["rgb"] if has_rgb else (sp["depth"] if has_depth else None)
@@ -465,6 +504,7 @@ class PointNavBaselinePolicy(NetPolicy):
                               has_depth=has_depth, goal_dim=goal_dim, max_frames=max_frames, max_envs=max_envs),
                          lambda: _baseline_init(cin, H, W, hidden_size, na, goal_dim))
         self.goal_key = goal_key
+        self._build_aux_modules(aux_loss_config, action_space)
 
     @classmethod
     def from_config(cls, config, observation_space, action_space, **kwargs):
@@ -642,8 +682,6 @@ class PointNavResNetPolicy(NetPolicy):
         sp = observation_space.spaces
         if backbone not in BACKBONES:
             raise _lib.HabError(f"backbone {backbone!r} is not one of {sorted(BACKBONES)} (rl/ddppo/policy/resnet.py:296-345)")
-        if aux_loss_config:
-            raise _lib.HabError("auxiliary losses are outside the accelerated path")
         gauss = gauss_kw = None
         dist = getattr(policy_config, "action_distribution_type", "categorical") if policy_config is not None else "categorical"
         if dist == "gaussian":
@@ -697,6 +735,7 @@ class PointNavResNetPolicy(NetPolicy):
                                               pointgoal_dim=pg_dim, proximity_dim=px_dim, blind=blind),
                          buffer_names=bufs)
         self.is_blind = blind
+        self._build_aux_modules(aux_loss_config, action_space)
 
     @classmethod
     def from_config(cls, config, observation_space, action_space, **kwargs):

@@ -285,8 +285,76 @@ class PPO(nn.Module, Updater):
             check(L.hab_advantages(ptr(ret), ptr(vp), ptr(adv), cnt, 3, ptr(self._stats), None, s), "hab_advantages")
         return adv
 
+    # ---- one minibatch with auxiliary losses: the reference's own sequence (ppo.py:164-299) on the autograd bridge --------------
+    def _aux_optimizer(self):
+        """Adam over the auxiliary-loss modules' parameters (the reference optimises them with the policy in ONE Adam, ppo.py:112-137:
+        same lr / eps / betas, lr following the policy optimiser's schedule; they are not part of the clipped norm, ppo.py:361-364)."""
+        if getattr(self, "_aux_opt", None) is None:
+            params = [p for ps in self.actor_critic.aux_loss_parameters().values() for p in ps if p.requires_grad]
+            g = self.optimizer.param_groups[0]
+            self._aux_opt = torch.optim.Adam(params, lr=g["lr"], eps=g["eps"], betas=tuple(g["betas"])) if params else False
+        return self._aux_opt or None
+
+    def _update_from_batch_with_aux_losses(self, batch: MiniBatch, epoch: int, rollouts: RolloutStorage, slot: torch.Tensor):
+        """Policies with `aux_loss_modules`: evaluate_actions on the dense minibatch (autograd bridge: the engine's forward, its
+        activations handed to the auxiliary modules as `aux_loss_state`), the PPO loss in torch ops exactly as rl/ppo/ppo.py:195-250
+        states it, + the auxiliary losses (:248), backward through the bridge (the engine's backward receives the gradients wrt
+        rnn_output / perception_embed through hab_policy_set_extra_grads), then the fused clip + Adam on the policy arena and a torch Adam
+        on the auxiliary modules.  The dense minibatch is a gathered copy (what the reference's data generator makes)."""
+        ac = self.actor_critic
+        if "policy_version" in batch.storage.buffers or isinstance(self.entropy_coef, LagrangeInequalityCoefficient):
+            raise _lib.HabError("auxiliary losses are supported by the PPO / DD-PPO updater with a fixed entropy coefficient (not VER, not the "
+                                "adaptive entropy penalty)")
+        for p in ac.parameters():
+            p.grad = None  # (the arena's gradient views are written by the engine's backward; autograd's own copies are not used)
+        values, logp, ent, _, aux = self._evaluate_actions(batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"],
+                                                           batch["masks"], batch["actions"], batch["rnn_build_seq_info"])
+        old_logp, adv, old_v, ret = batch["action_log_probs"], batch["advantages"], batch["value_preds"], batch["returns"]
+        ratio = torch.exp(logp - old_logp)
+        action_loss = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param))
+        v = values.float()
+        if self.use_clipped_value_loss:
+            delta = v.detach() - old_v
+            v = torch.where(delta.abs() < self.clip_param, v, old_v + delta.clamp(-self.clip_param, self.clip_param))
+        value_loss = 0.5 * (v - ret).pow(2)
+        action_loss, value_loss, entropy = action_loss.mean(), value_loss.mean(), ent.mean()
+        terms = [self.value_loss_coef * value_loss, action_loss, -float(self.entropy_coef) * entropy] + [r["loss"] for r in aux.values()]
+        total = self.before_backward(torch.stack(terms).sum())
+        total.backward()
+        self.after_backward(total)
+        aux_opt = self._aux_optimizer()
+        if aux_opt is not None and self._world_size() > 1:  # what DistributedDataParallel does for every parameter of the wrapped module
+            for grp in aux_opt.param_groups:
+                for p in grp["params"]:
+                    if p.grad is not None:
+                        self._all_reduce_scalar_stats(p.grad)
+                        p.grad.div_(self._world_size())
+        with torch.no_grad():
+            r = ratio.detach()
+            vals = values.detach().float()
+            slot[0:4] = torch.stack([value_loss.detach(), action_loss.detach(), entropy.detach(), total.detach()])
+            slot[4:7] = torch.stack([vals.min(), vals.mean(), vals.max()])
+            slot[7:10] = torch.stack([r.min(), r.mean(), r.max()])
+            slot[10] = (r > 1.0 + self.clip_param).float().mean() + (r < 1.0 - self.clip_param).float().mean()
+            slot[11] = float(r.numel())
+        if getattr(ac, "_dense_grad_sync", None) is None:
+            self.before_step()
+            scale = 1.0 / self._world_size()
+        else:
+            scale = 1.0  # DD-PPO: the bridge's backward already AVERAGED the arena over the ranks (DistributedDataParallel's semantics)
+        self.optimizer.step(max_grad_norm=self.max_grad_norm, grad_scale=scale, grad_norm_out=slot[12:13])
+        if aux_opt is not None:
+            for grp in aux_opt.param_groups:
+                grp["lr"] = self.optimizer.param_groups[0]["lr"]
+            aux_opt.step()
+            aux_opt.zero_grad(set_to_none=True)
+        self.after_step()
+        self.last_aux_losses = {k: r_["loss"].detach() for k, r_ in aux.items()}  # (device scalars: read them after the update)
+
     # ---- one minibatch (ppo.py:164-299) -------------------------------------------------------------
     def _update_from_batch(self, batch: MiniBatch, epoch: int, rollouts: RolloutStorage, slot: torch.Tensor):
+        if len(getattr(self.actor_critic, "aux_loss_modules", ())) > 0:
+            return self._update_from_batch_with_aux_losses(batch, epoch, rollouts, slot)
         eng = self.actor_critic.engine
         L = _lib.lib()
         st: RolloutStorage = batch.storage

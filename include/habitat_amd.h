@@ -484,6 +484,14 @@ int hab_policy_backward(hab_policy* p, const hab_obs* obs, const int* rows, cons
                         const hab_pack_info* pack, const float* d_value, const float* d_log_prob, const float* d_entropy,
                         hipStream_t stream);
 
+/* Auxiliary-loss hook.  NetPolicy.evaluate_actions hands `aux_loss_state` = {rnn_output, perception_embed} to the policy's
+ * aux_loss_modules and adds their losses to the PPO loss (habitat_baselines/rl/ppo/policy.py:253-291,386-394, rl/ppo/ppo.py:248); autograd
+ * then delivers gradients wrt those two tensors next to the heads' own.  d_rnn_output / d_perception_embed: device arrays [B][hidden] in
+ * the frame order of the last hab_policy_evaluate (either may be NULL; the tensors themselves are HAB_TAP_RNN_OUT and the first `hidden`
+ * columns of HAB_TAP_RNN_IN).  The NEXT hab_policy_backward adds them where the tensors sit in its chain and forgets them; the time-major
+ * chunked form (rows-indirected minibatches of the fused updater) returns HAB_ERR_UNSUPPORTED, a blind net refuses d_perception_embed. */
+int hab_policy_set_extra_grads(hab_policy* p, const float* d_rnn_output, const float* d_perception_embed);
+
 /* HIP-event probe around one tagged call site (roofline measurement in bench.py). */
 #define HAB_PROBE_CONV1_FWD 0
 #define HAB_PROBE_CONV2_FWD 1

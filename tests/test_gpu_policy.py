@@ -1355,3 +1355,122 @@ def test_whole_update_teacher_forced_vs_oracle(path, extra, size):
     assert fr["param_max_abs_drift_before_step"][0] == 0.0
     assert fr["post_update_param_max_abs_diff"] <= 4 * ocfg.lr
     trainer.envs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["baseline", "resnet18"])
+def test_auxiliary_loss_hook_vs_oracle(kind):
+    """`aux_loss_modules` (rl/ppo/policy.py:253-291,386-394; rl/ppo/ppo.py:248): a registered auxiliary loss receives `aux_loss_state`
+    = {rnn_output, perception_embed} from evaluate_actions on the autograd bridge, its loss joins the PPO loss and its gradients wrt
+    those two tensors re-enter the engine's backward (hab_policy_set_extra_grads).  Against the oracle's autograd of the SAME total
+    loss: every policy gradient and the module's own parameter gradient <= 1e-4; then a full PPO.update through the aux path moves
+    policy and module parameters with finite metrics."""
+    from habitat_amd.common import spaces as S
+    from habitat_amd.common.baseline_registry import baseline_registry
+    from habitat_amd.common.rollout_storage import RolloutStorage
+    from habitat_amd.rl.ppo import PPO, PointNavBaselinePolicy, PointNavResNetPolicy
+
+    @baseline_registry.register_auxiliary_loss(name="toy_aux")
+    class ToyAux(torch.nn.Module):
+        def __init__(self, action_space, net, loss_scale=0.1, **kw):
+            super().__init__()
+            assert net.output_size == net.perception_embedding_size and not net.is_blind
+            self.scale = float(loss_scale)
+            self.w = torch.nn.Parameter(torch.linspace(0.5, 1.5, net.output_size))
+
+        def forward(self, aux_loss_state, batch):
+            out, pe = aux_loss_state["rnn_output"], aux_loss_state["perception_embed"]
+            assert batch["action"].shape[0] == out.shape[0]
+            return dict(loss=self.scale * ((out * self.w).pow(2).mean() + torch.tanh((pe * self.w).sum(1)).mean()))
+
+    H = W = 64 if kind == "resnet18" else 44
+    T, N, hidden = 6, 4, 64
+    osp = S.Dict({"rgb": S.Box(0, 255, (H, W, 3), np.uint8), "depth": S.Box(0.0, 1.0, (H, W, 1), np.float32),
+                  GOAL: S.Box(-1e9, 1e9, (2,), np.float32)})
+    asp = S.Discrete(4)
+    torch.manual_seed(13)
+    aux_cfg = {"toy_aux": {"loss_scale": 0.2}}
+    if kind == "baseline":
+        pol = PointNavBaselinePolicy(osp, asp, hidden_size=hidden, aux_loss_config=aux_cfg, max_frames=T * N, max_envs=N)
+        spec = O.NetSpec(kind="baseline", hidden=hidden)
+    else:
+        pol = PointNavResNetPolicy(osp, asp, hidden_size=hidden, backbone="resnet18", aux_loss_config=aux_cfg, max_frames=T * N, max_envs=N)
+        spec = O.NetSpec(kind="resnet", rnn_type="GRU", num_layers=1, backbone="resnet18", baseplanes=32, visual_keys=("rgb", "depth"),
+                         normalize=False, hidden=hidden)
+    assert list(pol.aux_loss_modules) == ["toy_aux"] and "aux_loss_modules.toy_aux.w" in pol.state_dict()
+    params = {k: v.detach().clone() for k, v in pol.state_dict().items() if not k.startswith("aux_loss_modules.")}
+    pol.to("cuda")
+    pol.train()
+    assert pol.aux_loss_modules["toy_aux"].w.is_cuda
+    rng = np.random.default_rng(3)
+    st = RolloutStorage(T, N, osp, asp, pol, device="cuda", gae_variant="scan")
+    B = st.buffers
+    B["observations"]["rgb"].copy_(torch.from_numpy(rng.integers(0, 256, (T + 1, N, H, W, 3), dtype=np.uint8)))
+    B["observations"]["depth"].copy_(torch.from_numpy(rng.random((T + 1, N, H, W, 1), dtype=np.float32)))
+    B["observations"][GOAL].copy_(torch.from_numpy(rng.standard_normal((T + 1, N, 2)).astype(np.float32)))
+    B["masks"].copy_(torch.from_numpy(rng.random((T + 1, N, 1)) > 0.2))
+    B["actions"].copy_(torch.from_numpy(rng.integers(0, 4, (T + 1, N, 1))))
+    B["prev_actions"].copy_(torch.from_numpy(rng.integers(0, 4, (T + 1, N, 1))))
+    B["recurrent_hidden_states"].copy_(torch.from_numpy(rng.standard_normal((T + 1, N, 1, hidden)).astype(np.float32)))
+    for k in ("rewards", "value_preds", "returns", "action_log_probs"):
+        B[k].copy_(torch.from_numpy((rng.standard_normal((T + 1, N, 1)) * (0.1 if k != "action_log_probs" else 0.05) -
+                                     (1.3 if k == "action_log_probs" else 0.0)).astype(np.float32)))
+    st.current_rollout_step_idxs = [T]
+    cfg = types.SimpleNamespace(clip_param=0.2, ppo_epoch=1, num_mini_batch=1, value_loss_coef=0.5, entropy_coef=0.01, lr=2.5e-4, eps=1e-5,
+                                max_grad_norm=0.5, use_clipped_value_loss=True, use_normalized_advantage=False)
+    ppo = PPO.from_config(pol, cfg)
+    adv = ppo.get_advantages(st)
+    torch.manual_seed(5)
+    batch = next(st.data_generator(adv, 1))
+    # ---- oracle: the same total loss by autograd ----
+    inds = batch.inds
+    take = lambda t: t[0:T, inds].flatten(0, 1).cpu()
+    obs = {k: take(v) for k, v in B["observations"].items()}
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    w_ref = torch.linspace(0.5, 1.5, hidden).requires_grad_(True)
+    taps = {}
+    v_o, lp_o, ent_o, _ = O.evaluate_actions(p, spec, obs, B["recurrent_hidden_states"][0, inds].cpu(), take(B["prev_actions"]), take(B["masks"]),
+                                             take(B["actions"]), training=True, taps=taps)
+    ob = {"action_log_probs": take(B["action_log_probs"]), "advantages": take(adv), "value_preds": take(B["value_preds"]), "returns": take(B["returns"])}
+    total_o, *_ = O.ppo_loss(v_o, lp_o, ent_o, ob, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)
+    pe = taps["cnn_out"] if kind == "baseline" else taps["visual_fc"]
+    aux_o = 0.2 * ((taps["rnn_out"] * w_ref).pow(2).mean() + torch.tanh((pe * w_ref).sum(1)).mean())
+    (total_o + aux_o).backward()
+    # ---- engine: evaluate_actions on the bridge + the module, torch loss, backward ----
+    for q in pol.parameters():
+        q.grad = None
+    v, lp, ent, _, aux = pol.evaluate_actions(batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"], batch["masks"],
+                                              batch["actions"], batch["rnn_build_seq_info"])
+    assert abs(float(aux["toy_aux"]["loss"]) - float(aux_o)) <= 1e-4 * max(1.0, abs(float(aux_o)))
+    b = {k: batch[k] for k in ("action_log_probs", "advantages", "value_preds", "returns")}
+    total, *_ = O.ppo_loss(v, lp, ent, b, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)
+    (total + aux["toy_aux"]["loss"]).backward()
+    eng = pol.engine
+    tol_n = 1e-4 if kind == "baseline" else 2e-2  # (norm-wise; deep encoder on noise inputs: ReLU-boundary flips upstream, see the golden tests)
+    bad = []
+    for k, g in eng.grad_views.items():
+        if k in eng.buffer_names:
+            continue
+        r = p[k].grad.numpy().astype(np.float64)
+        gg = g.cpu().numpy().astype(np.float64)
+        err = np.linalg.norm(gg - r) / max(1e-30, np.linalg.norm(r))
+        deep = "visual_encoder" in k or "visual_fc" in k
+        if err > (tol_n if deep else 1e-4):
+            bad.append((k, err))
+    assert not bad, bad
+    gw = pol.aux_loss_modules["toy_aux"].w.grad.cpu()
+    assert rel_ok(gw.numpy(), w_ref.grad.numpy(), tol=1e-4, floor=1e-5)
+    # and WITHOUT the hook's gradients the arena would differ: the aux term reaches the encoder (not only the module's own parameter)
+    key = "net.state_encoder.rnn.weight_hh_l0"
+    p2 = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    v2, lp2, ent2, _ = O.evaluate_actions(p2, spec, obs, B["recurrent_hidden_states"][0, inds].cpu(), take(B["prev_actions"]), take(B["masks"]),
+                                          take(B["actions"]), training=True)
+    O.ppo_loss(v2, lp2, ent2, ob, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)[0].backward()
+    assert float((p2[key].grad - p[key].grad).norm()) > 1e-3 * float(p[key].grad.norm())
+    # ---- the updater's aux path end to end ----
+    before = eng.params_flat.clone()
+    w_before = pol.aux_loss_modules["toy_aux"].w.detach().clone()
+    metrics = ppo.update(st)
+    assert all(np.isfinite(x) for x in metrics.values()) and metrics["grad_norm"] > 0
+    assert float((eng.params_flat - before).abs().max()) > 0 and float((pol.aux_loss_modules["toy_aux"].w - w_before).abs().max()) > 0
+    assert torch.isfinite(ppo.last_aux_losses["toy_aux"]).all()
