@@ -444,8 +444,14 @@ class PPO(nn.Module, Updater):
     def after_step(self): pass
 
     def get_resume_state(self):
-        return {"optim_state": self.optimizer.state_dict()}
+        out = {"optim_state": self.optimizer.state_dict()}
+        aux = getattr(self, "_aux_opt", None)
+        if aux:  # (the reference keeps policy and auxiliary-loss parameters in ONE optimiser; here the modules' Adam is a second entry)
+            out["aux_optim_state"] = aux.state_dict()
+        return out
 
     def load_state_dict(self, state):
         if "optim_state" in state:
             self.optimizer.load_state_dict(state["optim_state"])
+        if "aux_optim_state" in state and self._aux_optimizer() is not None:
+            self._aux_opt.load_state_dict(state["aux_optim_state"])
