@@ -901,3 +901,41 @@ def test_blind_resnet_policy_identical_to_live_reference():
         r_feats, r_hidden, _ = ref_pol.net(obs, hidden, prev, masks)
         r_value = ref_pol.critic(r_feats)
     assert torch.allclose(feats, r_feats, atol=1e-6) and torch.allclose(h_out, r_hidden, atol=1e-6) and torch.allclose(value, r_value, atol=1e-6)
+
+
+def test_auxiliary_loss_modules_are_built_from_the_registry_on_cpu():
+    """get_aux_modules (rl/ppo/policy.py:592-608) on the CPU-staged policy: one module per entry of `auxiliary_losses`, built as
+    cls(action_space, net, **cfg) with the Net attributes the reference's losses read; their parameters are part of the policy's
+    state_dict and of aux_loss_parameters(), not of the engine's parameter table; an unknown name is refused."""
+    from habitat_amd._lib import HabError
+    from habitat_amd.common import spaces as S
+    from habitat_amd.common.baseline_registry import baseline_registry
+    from habitat_amd.rl.ppo import PointNavBaselinePolicy
+    from habitat_amd.rl.ddppo.policy import PointNavResNetPolicy
+    seen = {}
+
+    @baseline_registry.register_auxiliary_loss(name="probe_aux")
+    class ProbeAux(torch.nn.Module):
+        def __init__(self, action_space, net, width=3, **kw):
+            super().__init__()
+            seen.update(n=action_space.n, out=net.output_size, pe=net.perception_embedding_size, layers=net.num_recurrent_layers,
+                        blind=net.is_blind)
+            self.proj = torch.nn.Linear(net.output_size, width)
+
+        def forward(self, aux_loss_state, batch):
+            return dict(loss=self.proj(aux_loss_state["rnn_output"]).pow(2).mean())
+
+    osp = S.Dict({"depth": S.Box(0.0, 1.0, (64, 64, 1), np.float32), "pointgoal_with_gps_compass": S.Box(-1e9, 1e9, (2,), np.float32)})
+    pol = PointNavBaselinePolicy(osp, S.Discrete(4), hidden_size=64, aux_loss_config={"probe_aux": {"width": 5}})
+    assert seen == dict(n=4, out=64, pe=64, layers=1, blind=False)
+    assert list(pol.aux_loss_modules) == ["probe_aux"] and pol.aux_loss_modules["probe_aux"].proj.out_features == 5
+    keys = list(pol.state_dict())
+    assert keys[-2:] == ["aux_loss_modules.probe_aux.proj.weight", "aux_loss_modules.probe_aux.proj.bias"]
+    assert [tuple(p.shape) for p in pol.aux_loss_parameters()["probe_aux"]] == [(5, 64), (5,)]
+    assert not any("aux_loss" in nm for nm in [n_ for n_, _ in pol.named_parameters() if n_.startswith("net.")])
+    pol2 = PointNavResNetPolicy(osp, S.Discrete(4), hidden_size=64, num_recurrent_layers=2, rnn_type="LSTM", backbone="resnet18",
+                                aux_loss_config={"probe_aux": {}})
+    assert seen["layers"] == 4 and pol2.aux_loss_modules["probe_aux"].proj.out_features == 3
+    assert PointNavBaselinePolicy(osp, S.Discrete(4), hidden_size=64, aux_loss_config={}).aux_loss_parameters() == {}
+    with pytest.raises(HabError):
+        PointNavBaselinePolicy(osp, S.Discrete(4), hidden_size=64, aux_loss_config={"no_such_loss": {}})
