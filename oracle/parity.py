@@ -332,6 +332,16 @@ def _load_step_state(policy, upd, tr, lr_group=None):
     opt.step_count = tr["step"]
 
 
+def summarize_free_running(fr: dict) -> dict:
+    """Two figures that say at a glance why the free-running means differ from the teacher-forced steps: in how many minibatch steps a
+    frame sat on a clip boundary and came out on the other side, and the largest gradient-norm difference among the steps where none did
+    (a single flipped frame is worth ~1 / sqrt(frames) of a minibatch gradient)."""
+    flips = [a + b for a, b in zip(fr.get("ratio_clip_flips", []), fr.get("value_clip_flips", []))]
+    quiet = [g for g, f in zip(fr.get("grad_norm_rel", []), flips) if not f]
+    return {"steps_with_clip_flips": sum(1 for f in flips if f), "frames_flipped": int(sum(flips)),
+            "max_grad_norm_rel_in_steps_without_flips": (max(quiet) if quiet else None)}
+
+
 def update_parity(policy, upd, storage, buf: dict, trace, final, T: int, cfg, trainable, bar: float = 1e-4) -> Dict[str, object]:
     """The HIP update against the oracle's trace of the SAME update (same rollout arena `storage` == `buf`, same permutations).
 
@@ -418,6 +428,7 @@ def update_parity(policy, upd, storage, buf: dict, trace, final, T: int, cfg, tr
         r["param_max_abs_drift_before_step"] = drift
         rows.append(r)
     fr = fold(rows)
+    fr.update(summarize_free_running(fr))
     sd = policy.state_dict()
     fr["post_update_param_max_abs_diff"] = float(f"{max(float((sd[q].detach().cpu() - final[q]).abs().max()) for q in trainable):.3e}")
     host = slots.cpu().double()

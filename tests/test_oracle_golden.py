@@ -471,3 +471,16 @@ def test_update_trace_is_the_update():
     assert all(float(trace[0]["m"][q].abs().max()) == 0.0 for q in trainable) and any(float(trace[1]["m"][q].abs().max()) > 0 for q in trainable)
     assert all(torch.equal(final[q], p[q].detach()) for q in trainable)
     assert abs(sum(t["value_loss"] for t in trace) / 4 - metrics["value_loss"]) <= 1e-6 * abs(metrics["value_loss"])
+
+
+def test_free_running_summary_counts_clip_flips():
+    """oracle/parity.py::summarize_free_running on the free-running record of the round-5 driver-configuration run
+    (profiles/r05_parity_driver_config.json): three steps with one flipped frame each hold the three large gradient-norm differences."""
+    import json
+    from oracle import parity as PR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fr = json.load(open(os.path.join(root, "profiles", "r05_parity_driver_config.json")))["parity"]["free_running"]
+    out = PR.summarize_free_running(fr)
+    assert out["steps_with_clip_flips"] == 3 and out["frames_flipped"] == 3
+    assert out["max_grad_norm_rel_in_steps_without_flips"] < 1e-3 < min(g for g, f in zip(fr["grad_norm_rel"], fr["ratio_clip_flips"]) if f)
+    assert PR.summarize_free_running({}) == {"steps_with_clip_flips": 0, "frames_flipped": 0, "max_grad_norm_rel_in_steps_without_flips": None}
