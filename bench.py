@@ -592,7 +592,10 @@ def main():
         trainer._agent._rollouts = None
         del eng
         torch.cuda.empty_cache()
-        c4 = run_cycles("c3", 5, 2, distributed=True)
+        try:
+            c4 = run_cycles("c3", 5, 2, distributed=True)
+        except Exception as exc:  # noqa: BLE001 -- a failure every rank shares (e.g. memory) must not take the headline figure with it
+            c4 = {"error": repr(exc)[:300]}
     if rank != 0:
         torch.distributed.destroy_process_group()
         return
