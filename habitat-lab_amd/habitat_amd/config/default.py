@@ -115,6 +115,18 @@ BENCHMARK_PRESETS = {
 }
 
 
+# config group `habitat_baselines/rl/auxiliary_losses` (default_structured_configs.py:332-339,539-544): selected in a YAML's defaults
+# list (`- /habitat_baselines/rl/auxiliary_losses: cpca`) or on the command line (`+habitat_baselines/rl/auxiliary_losses=cpca`)
+AUX_LOSS_PRESETS = {"cpca": dict(k=20, time_subsample=6, future_subsample=2, loss_scale=0.1)}
+_AUX_GROUP = "habitat_baselines/rl/auxiliary_losses"
+
+
+def _select_aux_loss(cfg: dict, name: str):
+    if name not in AUX_LOSS_PRESETS:
+        raise KeyError(f"no auxiliary loss '{name}' in config group {_AUX_GROUP} (known: {sorted(AUX_LOSS_PRESETS)})")
+    cfg["habitat_baselines"]["rl"].setdefault("auxiliary_losses", {})[name] = copy.deepcopy(AUX_LOSS_PRESETS[name])
+
+
 def _merge(dst: dict, src: dict):
     for k, v in src.items():
         if isinstance(v, dict) and isinstance(dst.get(k), dict):
@@ -133,6 +145,10 @@ def _parse_value(s: str) -> Any:
 def _apply_override(cfg: dict, ov: str):
     key, _, val = ov.partition("=")
     key = key.lstrip("+")
+    if key.strip("/") == _AUX_GROUP:
+        for name in (val.strip("[]").split(",") if val else []):
+            _select_aux_loss(cfg, name.strip())
+        return
     node = cfg
     parts = key.split(".")
     for p in parts[:-1]:
@@ -165,6 +181,9 @@ def get_config(config_path: Optional[str] = None, overrides: Optional[List[str]]
                 for grp, name in item.items():
                     if "benchmark" in grp and name in BENCHMARK_PRESETS:
                         _merge(cfg, BENCHMARK_PRESETS[name])
+                    elif grp.strip("/") == _AUX_GROUP:
+                        for nm in (name if isinstance(name, (list, tuple)) else [name]):
+                            _select_aux_loss(cfg, nm)
         _merge(cfg, {k: v for k, v in y.items() if k in ("habitat", "habitat_baselines")})
     for ov in overrides or []:
         _apply_override(cfg, ov)

@@ -314,6 +314,30 @@ def load_reference_ver():
     return ns
 
 
+def load_reference_aux():
+    """Adds the reference's auxiliary loss (rl/ppo/cpc_aux_loss.py) and the action embeddings it is built on
+    (rl/models/action_embedding.py) to the namespace.  habitat.core.spaces.ActionSpace (habitat-lab/habitat/core/spaces.py:33-57: a Dict of
+    per-action argument spaces, sorted by name, `n` = number of actions) is stubbed with those semantics."""
+    ns = load_reference()
+    if getattr(ns, "cpc_aux_loss", None) is not None:
+        return ns
+    hs = sys.modules["habitat.core.spaces"]
+
+    class ActionSpace(Dict):
+        def __init__(self, spaces):
+            super().__init__(sorted(spaces.items()) if isinstance(spaces, dict) else spaces)
+
+        @property
+        def n(self):
+            return len(self.spaces)
+
+    hs.ActionSpace = ActionSpace
+    ns.ActionSpace, ns.EmptySpace = ActionSpace, hs.EmptySpace
+    ns.action_embedding = _load("habitat_baselines.rl.models.action_embedding", "rl/models/action_embedding.py")
+    ns.cpc_aux_loss = _load("habitat_baselines.rl.ppo.cpc_aux_loss", "rl/ppo/cpc_aux_loss.py")
+    return ns
+
+
 def make_config(**ppo_overrides):
     """A plain attribute-tree carrying the config keys the hot path reads
     (default_structured_configs.py:288-316,343-363)."""

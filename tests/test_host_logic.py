@@ -939,3 +939,97 @@ def test_auxiliary_loss_modules_are_built_from_the_registry_on_cpu():
     assert PointNavBaselinePolicy(osp, S.Discrete(4), hidden_size=64, aux_loss_config={}).aux_loss_parameters() == {}
     with pytest.raises(HabError):
         PointNavBaselinePolicy(osp, S.Discrete(4), hidden_size=64, aux_loss_config={"no_such_loss": {}})
+
+
+def _cpca_golden_tools():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_cpca as G
+    return G, np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cpca.npz"))
+
+
+class _NoArgs:
+    pass
+
+
+class _TaskActions:
+    """habitat's ActionSpace of argument-less actions, duck-typed: `.spaces` (sorted by name) and `.n`."""
+    def __init__(self, spaces):
+        self.spaces = dict(sorted(spaces.items()))
+        self.n = len(self.spaces)
+
+
+@pytest.mark.parametrize("case", ["discrete_defaults", "all_futures_kept", "negatives_with_replacement", "box",
+                                  "task_of_argumentless_actions", "nested_dict"])
+def test_cpca_auxiliary_loss_identical_to_reference(case):
+    """`cpca` (rl/ppo/cpc_aux_loss.py:64-355) against the reference module's own outputs (tests/golden/cpca.npz, written by
+    make_golden_cpca.py from the live reference): seeded parameters (names, values: the two-pass orthogonal initialisation consumes the
+    generator in the reference's order), and -- same seed before the call, the reference's rnn_build_seq_info -- the loss and its gradients
+    wrt rnn_output, perception_embed and every parameter.  Equality is exact: same ops on the same draws.  With THIS package's pack
+    arrays (tie order between equally long fragments is its own) the index sets are the same up to the order of the starts."""
+    from habitat_amd.common import spaces as S
+    from habitat_amd.common.baseline_registry import baseline_registry
+    from habitat_amd.engine import DevicePackInfo
+    import habitat_amd.rl.ppo  # noqa: F401  (registers cpca)
+    G, z = _cpca_golden_tools()
+    CPCA = baseline_registry.get_auxiliary_loss("cpca")
+    desc, kw, T, N, H, _ = G.CASES[case]
+    dones, x, e, act, net, seed = G.cpca_case_inputs(case)
+    torch.manual_seed(seed)
+    mine = CPCA(G.action_space(S, desc, _NoArgs, _TaskActions), net, **kw)
+    sd = mine.state_dict()
+    want = [k[len(case) + 7:] for k in z.files if k.startswith(f"{case}/state/")]
+    assert list(sd) == want
+    assert all(np.array_equal(sd[k].numpy(), z[f"{case}/state/{k}"]) for k in want)
+    info = {k: torch.from_numpy(z[f"{case}/info/{k}"]) for k in G.SEQ_KEYS}
+    info["cpu_sequence_lengths"] = info["sequence_lengths"]
+    loss, gx, ge, gp = G.run_module(mine, info, x, e, act, seed)
+    assert np.array_equal(loss.numpy(), z[f"{case}/loss"]) and float(loss) > 0
+    assert np.array_equal(gx.numpy(), z[f"{case}/d_rnn_output"]) and np.array_equal(ge.numpy(), z[f"{case}/d_perception_embed"])
+    assert float(gx.abs().max()) > 0 and float(ge.abs().max()) > 0
+    for k, v in gp.items():
+        assert np.array_equal(v.numpy(), z[f"{case}/grad/{k}"]), k
+    # this package's rnn_build_seq_info (common/rollout_storage.py: arrays of the C++ pack builder) drives the same module: with no random
+    # start selection (time_subsample >= every length) the (action row, target row) columns are the reference's, in another order
+    pk = DevicePackInfo(np.ascontiguousarray(dones, dtype=np.uint8))
+    own = {}
+    for k, arr in pk.arrays.items():
+        own[k] = own["cpu_" + k] = torch.from_numpy(np.ascontiguousarray(arr))
+    every = CPCA(G.action_space(S, desc, _NoArgs, _TaskActions), net, k=5, time_subsample=10 ** 6)
+    cols = lambda a, t, v, w: sorted(zip(torch.where(v, a, -1).T.tolist(), torch.where(w, t, -1).T.tolist()))
+    assert cols(*every._build_inds(own)) == cols(*every._build_inds(info))
+    out = mine({"rnn_output": x, "perception_embed": e}, {"action": act, "rnn_build_seq_info": own})["loss"]
+    assert torch.isfinite(out) and float(out.detach()) > 0
+    from oracle.ref_loader import reference_available
+    if reference_available():  # and the live module, when the reference is on this machine
+        from oracle.ref_loader import load_reference_aux
+        ns = load_reference_aux()
+        torch.manual_seed(seed)
+        ref = ns.cpc_aux_loss.CPCA(G.action_space(ns.spaces, desc, ns.EmptySpace, ns.ActionSpace), net, **kw)
+        live = G.run_module(ref, ns.rnn_state_encoder.build_rnn_build_seq_info(
+            torch.device("cpu"), ns.rnn_state_encoder.build_pack_info_from_dones(dones)), x, e, act, seed)
+        assert torch.equal(live[0], loss) and torch.equal(live[1], gx) and torch.equal(live[2], ge)
+
+
+def test_cpca_is_selected_through_the_config_group_and_refuses_blind_nets():
+    """`+habitat_baselines/rl/auxiliary_losses=cpca` (config group, default_structured_configs.py:539-544) fills CPCALossConfig's defaults
+    (:332-339); the policy builds the module from it (get_aux_modules, rl/ppo/policy.py:592-608); a blind net is refused with the
+    reference's assert (cpc_aux_loss.py:249-251)."""
+    from habitat_amd.common import spaces as S
+    from habitat_amd.config.default import get_config
+    from habitat_amd.rl.ppo import CPCA, PointNavBaselinePolicy
+    cfg = get_config(overrides=["+habitat_baselines/rl/auxiliary_losses=cpca", "habitat_baselines.rl.auxiliary_losses.cpca.k=7"])
+    aux = cfg.habitat_baselines.rl.auxiliary_losses
+    assert dict(aux["cpca"]) == dict(k=7, time_subsample=6, future_subsample=2, loss_scale=0.1)
+    with pytest.raises(KeyError):
+        get_config(overrides=["+habitat_baselines/rl/auxiliary_losses=no_such_loss"])
+    osp = S.Dict({"depth": S.Box(0.0, 1.0, (44, 44, 1), np.float32), "pointgoal_with_gps_compass": S.Box(-1e9, 1e9, (2,), np.float32)})
+    pol = PointNavBaselinePolicy(osp, S.Discrete(4), hidden_size=64, aux_loss_config=aux)
+    m = pol.aux_loss_modules["cpca"]
+    assert isinstance(m, CPCA) and (m.k, m.time_subsample, m.future_subsample, m.num_negatives, m.loss_scale) == (7, 6, 2, 20, 0.1)
+    assert m._future_predictor.hidden_size == 64 and m._predictor_first_layers[1].in_features == 64
+    assert "aux_loss_modules.cpca._action_embed.embedding_modules.0.embedding.weight" in pol.state_dict()
+    assert pol.state_dict()["aux_loss_modules.cpca._action_embed.embedding_modules.0.embedding.weight"].shape == (5, 32)
+    blind = S.Dict({"pointgoal_with_gps_compass": S.Box(-1e9, 1e9, (2,), np.float32)})
+    with pytest.raises(AssertionError, match="visual encoder"):
+        PointNavBaselinePolicy(blind, S.Discrete(4), hidden_size=64, aux_loss_config=aux)

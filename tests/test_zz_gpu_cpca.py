@@ -1,0 +1,149 @@
+"""GPU: the auxiliary loss `cpca` (habitat_amd/rl/ppo/cpc_aux_loss.py; reference rl/ppo/cpc_aux_loss.py:227-355) THROUGH the engine's
+auxiliary-loss hook, against the oracle's autograd of the same total loss with the same module on the CPU.
+
+Unlike the toy loss of test_gpu_policy.py::test_auxiliary_loss_hook_vs_oracle, cpca is not invariant to the ORDER of the rows of
+`aux_loss_state`: it gathers rows of rnn_output / perception_embed through rnn_build_seq_info's select_inds, so this test also pins that the
+bridge hands the two tensors over in the minibatch's frame order.
+
+STATUS: written after round 5's GPU minutes were spent -- the module is pinned bit-exact against the live reference on the CPU
+(tests/test_host_logic.py::test_cpca_auxiliary_loss_identical_to_reference) and the hook on the GPU with the toy loss, but THIS combination
+had not run on hardware when it was committed.  The file sorts last so that `pytest -x` reaches every other GPU test first.
+
+The module's random draws (start steps, kept futures, negatives) are routed through the CPU generator on both sides (`_randperm` /
+`_multinomial` overridden in a subclass), since a CUDA generator and the CPU's produce different streams from one seed.
+"""
+import copy
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import functional as O
+
+GOAL = "pointgoal_with_gps_compass"
+AUX = "cpca_host_draws"
+AUX_CFG = dict(k=4, time_subsample=3, future_subsample=2, num_negatives=6, loss_scale=1.0)
+
+
+def _register():
+    from habitat_amd.common.baseline_registry import baseline_registry
+    from habitat_amd.rl.ppo.cpc_aux_loss import CPCA
+    if baseline_registry.get_auxiliary_loss(AUX) is not None:
+        return
+
+    @baseline_registry.register_auxiliary_loss(name=AUX)
+    class CPCAHostDraws(CPCA):
+        def _randperm(self, n, device): return torch.randperm(n, dtype=torch.int64).to(device)
+        def _multinomial(self, probs, num_samples, replacement):
+            return torch.multinomial(probs.detach().cpu(), num_samples=num_samples, replacement=replacement).to(probs.device)
+
+
+def _fill(B, rng, T, N, H, W, hidden):
+    B["observations"]["rgb"].copy_(torch.from_numpy(rng.integers(0, 256, (T + 1, N, H, W, 3), dtype=np.uint8)))
+    B["observations"]["depth"].copy_(torch.from_numpy(rng.random((T + 1, N, H, W, 1), dtype=np.float32)))
+    B["observations"][GOAL].copy_(torch.from_numpy(rng.standard_normal((T + 1, N, 2)).astype(np.float32)))
+    B["masks"].copy_(torch.from_numpy(rng.random((T + 1, N, 1)) > 0.06))
+    B["actions"].copy_(torch.from_numpy(rng.integers(0, 4, (T + 1, N, 1))))
+    B["prev_actions"].copy_(torch.from_numpy(rng.integers(0, 4, (T + 1, N, 1))))
+    B["recurrent_hidden_states"].copy_(torch.from_numpy(rng.standard_normal((T + 1, N, 1, hidden)).astype(np.float32)))
+    for k in ("rewards", "value_preds", "returns", "action_log_probs"):
+        B[k].copy_(torch.from_numpy((rng.standard_normal((T + 1, N, 1)) * (0.1 if k != "action_log_probs" else 0.05) -
+                                     (1.3 if k == "action_log_probs" else 0.0)).astype(np.float32)))
+
+
+def oracle_total_loss(params, spec, module, obs, h0, prev_actions, masks, actions, ob, info, cfg, kind, draw_seed):
+    """PPO loss + cpca by the oracle's forward and torch autograd on the CPU -> (ppo loss, aux loss, parameter leaves)."""
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    taps = {}
+    v, lp, ent, _ = O.evaluate_actions(p, spec, obs, h0, prev_actions, masks, actions, training=True, taps=taps)
+    total, *_ = O.ppo_loss(v, lp, ent, ob, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)
+    pe = taps["cnn_out"] if kind == "baseline" else taps["visual_fc"]
+    torch.manual_seed(draw_seed)
+    aux = module({"rnn_output": taps["rnn_out"], "perception_embed": pe}, {"action": actions, "rnn_build_seq_info": info})["loss"]
+    return total, aux, p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["baseline", "resnet18"])
+def test_cpca_through_the_engine_hook_vs_oracle(kind):
+    from habitat_amd.common import spaces as S
+    from habitat_amd.common.rollout_storage import RolloutStorage
+    from habitat_amd.rl.ppo import PPO, PointNavBaselinePolicy, PointNavResNetPolicy
+    _register()
+    H = W = 64 if kind == "resnet18" else 44
+    T, N, hidden = 16, 4, 64
+    osp = S.Dict({"rgb": S.Box(0, 255, (H, W, 3), np.uint8), "depth": S.Box(0.0, 1.0, (H, W, 1), np.float32),
+                  GOAL: S.Box(-1e9, 1e9, (2,), np.float32)})
+    asp = S.Discrete(4)
+    torch.manual_seed(17)
+    aux_cfg = {AUX: AUX_CFG}
+    if kind == "baseline":
+        pol = PointNavBaselinePolicy(osp, asp, hidden_size=hidden, aux_loss_config=aux_cfg, max_frames=T * N, max_envs=N)
+        spec = O.NetSpec(kind="baseline", hidden=hidden)
+    else:
+        pol = PointNavResNetPolicy(osp, asp, hidden_size=hidden, backbone="resnet18", aux_loss_config=aux_cfg, max_frames=T * N, max_envs=N)
+        spec = O.NetSpec(kind="resnet", rnn_type="GRU", num_layers=1, backbone="resnet18", baseplanes=32, visual_keys=("rgb", "depth"),
+                         normalize=False, hidden=hidden)
+    params = {k: v.detach().clone() for k, v in pol.state_dict().items() if not k.startswith("aux_loss_modules.")}
+    host_module = copy.deepcopy(pol.aux_loss_modules[AUX])  # the CPU twin: same seeded parameters
+    pol.to("cuda")
+    pol.train()
+    assert all(q.is_cuda for q in pol.aux_loss_modules[AUX].parameters())
+    st = RolloutStorage(T, N, osp, asp, pol, device="cuda", gae_variant="scan")
+    B = st.buffers
+    _fill(B, np.random.default_rng(9), T, N, H, W, hidden)
+    st.current_rollout_step_idxs = [T]
+    cfg = types.SimpleNamespace(clip_param=0.2, ppo_epoch=1, num_mini_batch=1, value_loss_coef=0.5, entropy_coef=0.01, lr=2.5e-4, eps=1e-5,
+                                max_grad_norm=0.5, use_clipped_value_loss=True, use_normalized_advantage=False)
+    ppo = PPO.from_config(pol, cfg)
+    adv = ppo.get_advantages(st)
+    torch.manual_seed(5)
+    batch = next(st.data_generator(adv, 1))
+    inds = batch.inds
+    take = lambda t: t[0:T, inds].flatten(0, 1).cpu()
+    obs = {k: take(v) for k, v in B["observations"].items()}
+    ob = {"action_log_probs": take(B["action_log_probs"]), "advantages": take(adv), "value_preds": take(B["value_preds"]), "returns": take(B["returns"])}
+    seq = batch["rnn_build_seq_info"]
+    info = {k[4:]: seq[k] for k in seq.keys() if k.startswith("cpu_")}
+    info["cpu_sequence_lengths"] = info["sequence_lengths"]
+    assert int((info["sequence_lengths"] - 1 > AUX_CFG["time_subsample"]).sum()) > 0, "no fragment long enough to draw its start steps"
+    total_o, aux_o, p = oracle_total_loss(params, spec, host_module, obs, B["recurrent_hidden_states"][0, inds].cpu(), take(B["prev_actions"]),
+                                          take(B["masks"]), take(B["actions"]), ob, info, cfg, kind, draw_seed=23)
+    (total_o + aux_o).backward()
+    assert float(aux_o) > 0.05  # (large enough that its gradients are visible beside the PPO loss's)
+    # ---- engine: evaluate_actions on the bridge runs the module on the device ----
+    for q in pol.parameters():
+        q.grad = None
+    torch.manual_seed(23)
+    v, lp, ent, _, aux = pol.evaluate_actions(batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"], batch["masks"],
+                                              batch["actions"], batch["rnn_build_seq_info"])
+    got = float(aux[AUX]["loss"])
+    assert abs(got - float(aux_o)) <= 1e-4 * abs(float(aux_o)), (got, float(aux_o))
+    b = {k: batch[k] for k in ("action_log_probs", "advantages", "value_preds", "returns")}
+    total, *_ = O.ppo_loss(v, lp, ent, b, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)
+    (total + aux[AUX]["loss"]).backward()
+    eng = pol.engine
+    tol_deep = 1e-4 if kind == "baseline" else 2e-2  # (norm-wise; deep encoder on noise inputs: ReLU-boundary flips, as in the toy-loss test)
+    bad = []
+    for k, g in eng.grad_views.items():
+        if k in eng.buffer_names:
+            continue
+        r = p[k].grad.numpy().astype(np.float64)
+        err = np.linalg.norm(g.cpu().numpy().astype(np.float64) - r) / max(1e-30, np.linalg.norm(r))
+        if err > (tol_deep if ("visual_encoder" in k or "visual_fc" in k) else 1e-4):
+            bad.append((k, err))
+    assert not bad, bad
+    host_grads = dict(host_module.named_parameters())
+    for k, q in pol.aux_loss_modules[AUX].named_parameters():
+        r = host_grads[k].grad.numpy().astype(np.float64)
+        err = np.linalg.norm(q.grad.cpu().numpy().astype(np.float64) - r) / max(1e-30, np.linalg.norm(r))
+        assert err <= 1e-4, (k, err)
+    # ---- and the updater's path end to end ----
+    before = eng.params_flat.clone()
+    w0 = pol.aux_loss_modules[AUX]._predictor[1].weight.detach().clone()
+    metrics = ppo.update(st)
+    assert all(np.isfinite(x) for x in metrics.values()) and metrics["grad_norm"] > 0
+    assert float((eng.params_flat - before).abs().max()) > 0
+    assert float((pol.aux_loss_modules[AUX]._predictor[1].weight - w0).abs().max()) > 0
+    assert torch.isfinite(ppo.last_aux_losses[AUX]).all()
