@@ -122,7 +122,10 @@ class ActionConditionedForwardModelingLoss(nn.Module):
         action_inds, target_inds, action_valids, target_valids = self._build_inds(batch["rnn_build_seq_info"])
         h0 = gather_rows(aux_loss_state["rnn_output"], action_inds[0], action_valids[0]).unsqueeze(0)
         act = gather_rows(act, action_inds, action_valids)
-        preds, _ = self._future_predictor(act, (h0, h0))
+        # k <= 20 steps of [M, 32 + H] x [.., 4H]: ATen's own recurrent cell + BLAS GEMMs; the vendor RNN library (MIOpen behind the
+        # cudnn flag) would compile and tune kernels at first use for a tensor this small -- the package has no other dependency on it
+        with torch.backends.cudnn.flags(enabled=False):
+            preds, _ = self._future_predictor(act, (h0, h0))
         kept = self._kept_predictions(act.size(0), act.size(1), act)
         return preds, action_inds, target_inds, kept, action_valids, target_valids
 
