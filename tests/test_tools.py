@@ -100,3 +100,26 @@ def test_staged_wave_specialised_schedule_model():
             mod["check"](ntk, ksh)
     for n in range(1, 8):
         mod["check_obs"](n)
+
+
+def test_no_kernel_outside_the_allow_list_spills_registers():
+    """tools/kernel_resources.py on the built library: the code objects' metadata must show no scratch memory and no spilled VGPRs for any
+    kernel except `ppo_loss_kernel` (one 1024-thread workgroup per minibatch, 15 us) -- a spill in a contraction or recurrent kernel is a
+    silent 2-10x on that kernel.  Also pins the register budget that lets the recurrent backward steps share a CU with the strip kernels."""
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "habitat-lab_amd", "habitat_amd", "libhabitat_amd.so")
+    if not (os.path.exists(lib) and os.path.exists("/opt/rocm/lib/llvm/bin/clang-offload-bundler")):
+        pytest.skip("library not built or LLVM tools absent")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py"), lib], capture_output=True, text=True, check=True).stdout
+    rows = [ln.split() for ln in out.splitlines() if ln and not ln.startswith("#")]
+    assert len(rows) > 250
+    col = lambda r, i: int(r[i - 8])  # the eight numeric columns are the last eight fields (kernel names contain spaces)
+    spilling = sorted({r[0] for r in rows if col(r, 4) or col(r, 5)})
+    assert spilling == ["ppo_loss_kernel"], spilling
+    by = {" ".join(r[:-8]): r for r in rows}
+    for k, r in by.items():
+        if k.startswith("rnn_bwd_step"):
+            assert col(r, 0) <= 64, (k, r)  # 8 waves per SIMD
+        if k.startswith("conv2_fwd_strip_kernel") or k.startswith("conv2_dgrad_strip_kernel"):
+            assert col(r, 0) <= 256, (k, r)  # 2 waves per SIMD at 512-thread workgroups
