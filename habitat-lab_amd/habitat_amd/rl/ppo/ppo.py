@@ -350,6 +350,9 @@ class PPO(nn.Module, Updater):
             aux_opt.zero_grad(set_to_none=True)
         self.after_step()
         self.last_aux_losses = {k: r_["loss"].detach() for k, r_ in aux.items()}  # (device scalars: read them after the update)
+        for name, res in aux.items():  # learner metrics `aux_<name>_<key>` (ppo.py:281-283): averaged over the update's minibatches
+            for k_, v_ in res.items():
+                self.__dict__.setdefault("_aux_metrics", {}).setdefault(f"aux_{name}_{k_}", []).append(v_.detach().float().mean())
 
     # ---- one minibatch (ppo.py:164-299) -------------------------------------------------------------
     def _update_from_batch(self, batch: MiniBatch, epoch: int, rollouts: RolloutStorage, slot: torch.Tensor):
@@ -399,6 +402,7 @@ class PPO(nn.Module, Updater):
 
     def update(self, rollouts: RolloutStorage) -> Dict[str, float]:
         advantages = self.get_advantages(rollouts)
+        self._aux_metrics: Dict[str, List[torch.Tensor]] = {}
         nmb = self.ppo_epoch * self.num_mini_batch
         slots = torch.zeros(nmb + 1, SLOT_WIDTH, device=self.device)
         k = 0
@@ -427,6 +431,8 @@ class PPO(nn.Module, Updater):
                 if name.startswith("ver_is_coeffs") and "is_coeffs" not in rollouts.buffers:
                     continue
                 out[name] = float(host[:, i].mean())
+        for name, vals in self._aux_metrics.items():
+            out[name] = float(torch.stack(vals).mean())
         return out
 
     def _evaluate_actions(self, *args, **kwargs):

@@ -147,3 +147,37 @@ def test_cpca_through_the_engine_hook_vs_oracle(kind):
     assert float((eng.params_flat - before).abs().max()) > 0
     assert float((pol.aux_loss_modules[AUX]._predictor[1].weight - w0).abs().max()) > 0
     assert torch.isfinite(ppo.last_aux_losses[AUX]).all()
+    assert metrics[f"aux_{AUX}_loss"] > 0  # learner metric `aux_<name>_<key>` of the reference (ppo.py:281-283)
+
+
+@pytest.mark.gpu
+def test_cpca_training_from_the_config_group():
+    """The reference's own test of this loss (test/test_baseline_trainers.py:155-162): the PointNav example configuration with
+    `+habitat_baselines/rl/auxiliary_losses=cpca`, trained for a few updates through the registered trainer."""
+    from habitat_amd.common.baseline_registry import baseline_registry
+    from habitat_amd.config.default import get_config
+    from habitat_amd.rl.ppo import CPCA
+    import habitat_amd.rl.ppo.ppo_trainer  # noqa: F401  (registers the trainer, policies, updaters, storage)
+    ov = ["+habitat_baselines/rl/auxiliary_losses=cpca", "habitat_baselines.num_environments=4", "habitat_baselines.rl.ppo.num_steps=16",
+          "habitat_baselines.num_updates=3", "habitat_baselines.total_num_steps=-1", "habitat_baselines.num_checkpoints=-1",
+          "habitat_baselines.checkpoint_interval=1000000", "habitat_baselines.rl.ppo.hidden_size=64",
+          "habitat_baselines.checkpoint_folder=/tmp/habitat_amd_test_ckpt", "habitat_baselines.rl.preemption.save_resume_state_interval=1000000000"]
+    for sname in ("rgb", "depth"):
+        ov += [f"habitat.simulator.sensors.{sname}.height=128", f"habitat.simulator.sensors.{sname}.width=128"]
+    cfg = get_config("pointnav/ppo_pointnav_example.yaml", ov)
+    assert "cpca" in cfg.habitat_baselines.rl.auxiliary_losses
+    cfg.habitat.simulator.sensors.pop("semantic", None)
+    trainer = baseline_registry.get_trainer(cfg.habitat_baselines.trainer_name)(cfg)
+    trainer._init_train()
+    pol = trainer._agent.actor_critic
+    assert isinstance(pol.aux_loss_modules["cpca"], CPCA)
+    before = pol.engine.params_flat.clone()
+    w0 = pol.aux_loss_modules["cpca"]._predictor[1].weight.detach().clone()
+    for _ in range(2):
+        losses = trainer.run_update_cycle()
+        assert all(np.isfinite(v) for v in losses.values()), losses
+        assert losses["aux_cpca_loss"] > 0
+    assert trainer.num_steps_done == 2 * 4 * 16 and trainer.num_updates_done == 2
+    assert float((pol.engine.params_flat - before).abs().max()) > 0
+    assert float((pol.aux_loss_modules["cpca"]._predictor[1].weight - w0).abs().max()) > 0
+    trainer.envs.close()
