@@ -44,12 +44,18 @@ import habitat_amd.rl.ver  # noqa: F401  (registers VERRolloutStorage)
 
 def batch_obs(observations, device):
     """utils/common.py:244-310: list of per-env obs dicts -> dict of batched tensors (largest sensor first, pinned
-    staging, non-blocking upload)."""
-    keys = sorted(observations[0].keys(), key=lambda k: -np.asarray(observations[0][k]).nbytes)
+    staging, non-blocking upload).  Sensor values may be numpy arrays / scalars (the simulator's CPU sensors) or torch tensors on any
+    device (GPU-to-GPU sensors): tensors are stacked where they live and moved once."""
+    first = observations[0]
+    size = lambda v: v.numel() * v.element_size() if torch.is_tensor(v) else np.asarray(v).nbytes
+    keys = sorted(first.keys(), key=lambda k: -size(first[k]))
+    device = torch.device(device)
     out = {}
     for k in keys:
-        arr = np.stack([np.asarray(o[k]) for o in observations])
-        t = torch.from_numpy(arr)
+        if torch.is_tensor(first[k]):
+            out[k] = torch.stack([o[k] for o in observations]).to(device, non_blocking=True)
+            continue
+        t = torch.from_numpy(np.stack([np.asarray(o[k]) for o in observations]))
         if device.type == "cuda":
             t = t.pin_memory().to(device, non_blocking=True)
         out[k] = t

@@ -1033,3 +1033,68 @@ def test_cpca_is_selected_through_the_config_group_and_refuses_blind_nets():
     blind = S.Dict({"pointgoal_with_gps_compass": S.Box(-1e9, 1e9, (2,), np.float32)})
     with pytest.raises(AssertionError, match="visual encoder"):
         PointNavBaselinePolicy(blind, S.Discrete(4), hidden_size=64, aux_loss_config=aux)
+
+
+def test_pause_envs_keeps_the_running_environments_in_order():
+    """The reference's test_pausing (test/test_baseline_trainers.py:336-423): dropping environments from the vector env and from every
+    per-environment tensor / list at once; every survivor keeps its own row, order preserved; nothing / everything paused."""
+    import random
+    from habitat_amd.rl.ppo.evaluator import pause_envs
+
+    class Running:
+        def __init__(self, n): self.alive = list(range(n))
+        num_envs = property(lambda self: len(self.alive))
+        def pause_at(self, i): self.alive.pop(i)
+
+    def check(n, paused):
+        ids = torch.arange(n)
+        h = ids.view(n, 1, 1).expand(n, 4, 512)
+        cols = [ids.view(n, 1).clone() for _ in range(3)]
+        batch = {k: ids.view(n, 1, 1, 1).expand(n, 3, 16, 16) for k in ("a", "b")}
+        frames = [[i] for i in range(n)]
+        envs, h, masks, rew, prev, batch, frames = pause_envs(paused, Running(n), h, *cols, batch, frames)
+        keep = [i for i in range(n) if i not in set(paused)]
+        assert envs.alive == keep and [f[0] for f in frames] == keep
+        assert list(h.shape) == [len(keep), 4, 512] and h[:, 0, 0].tolist() == keep
+        assert all(c[:, 0].tolist() == keep for c in (masks, rew, prev))
+        assert all(list(v.shape) == [len(keep), 3, 16, 16] and v[:, 0, 0, 0].tolist() == keep for v in batch.values())
+
+    rnd = random.Random(0)
+    for _ in range(100):
+        n = rnd.randint(1, 13)
+        check(n, sorted(rnd.sample(range(n), rnd.randint(0, n))))
+    check(8, [])
+    check(8, list(range(8)))
+
+
+def test_resume_state_configuration_wins_only_when_asked_for():
+    """The reference's test_eval_config (test/test_baseline_trainers.py:298-333): list-valued overrides parse, and
+    `_get_resume_state_config_or_new_config` returns the checkpoint's configuration iff load_resume_state_config is set."""
+    from habitat_amd.common.base_trainer import BaseRLTrainer
+    from habitat_amd.config.default import get_config
+    path = "pointnav/ppo_pointnav_example.yaml"
+    ckpt_cfg = get_config(path, ["habitat_baselines.eval.video_option=[]", "habitat_baselines.load_resume_state_config=True"])
+    eval_cfg = get_config(path, ["habitat_baselines.eval.video_option=['disk']", "habitat_baselines.load_resume_state_config=False"])
+    assert ckpt_cfg.habitat_baselines.eval.video_option == [] and eval_cfg.habitat_baselines.eval.video_option == ["disk"]
+    got = BaseRLTrainer(get_config(path))._get_resume_state_config_or_new_config(resume_state_config=ckpt_cfg)
+    assert got.habitat_baselines.eval.video_option == []
+    got = BaseRLTrainer(eval_cfg)._get_resume_state_config_or_new_config(resume_state_config=ckpt_cfg)
+    assert got.habitat_baselines.eval.video_option == ["disk"]
+
+
+def test_batch_obs_of_host_sensors():
+    """The reference's test_batch_obs, host case (test/test_baseline_trainers.py:425-452): four environments x four 128 x 128 sensors ->
+    one [4, 128, 128] tensor per sensor, values and environment order kept; numpy arrays and CPU tensors alike."""
+    from habitat_amd.rl.ppo.ppo_trainer import batch_obs
+    g = torch.Generator().manual_seed(0)
+    envs = [{str(s): torch.randn(128, 128, generator=g) for s in range(4)} for _ in range(4)]
+    for as_numpy in (True, False):
+        obs = [{k: (v.numpy() if as_numpy else v) for k, v in e.items()} for e in envs]
+        out = batch_obs(obs, device=torch.device("cpu"))
+        assert sorted(out) == ["0", "1", "2", "3"]
+        for k, v in out.items():
+            assert v.shape == (4, 128, 128) and all(torch.equal(v[i], envs[i][k]) for i in range(4))
+    # the largest sensor is staged first (utils/common.py:262-270), scalars and vectors batch too
+    mixed = [{"gps": np.zeros(2, np.float32), "rgb": np.zeros((8, 8, 3), np.uint8), "collided": np.float32(i)} for i in range(3)]
+    out = batch_obs(mixed, device=torch.device("cpu"))
+    assert list(out) == ["rgb", "gps", "collided"] and out["collided"].tolist() == [0.0, 1.0, 2.0] and out["rgb"].dtype == torch.uint8

@@ -181,3 +181,18 @@ def test_cpca_training_from_the_config_group():
     assert float((pol.engine.params_flat - before).abs().max()) > 0
     assert float((pol.aux_loss_modules["cpca"]._predictor[1].weight - w0).abs().max()) > 0
     trainer.envs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sensor_device", ["cpu", "cuda"])
+def test_batch_obs_onto_the_device(sensor_device):
+    """The reference's test_batch_obs, device cases (test/test_baseline_trainers.py:425-452): host sensors (numpy) and GPU-to-GPU sensors
+    (device tensors) batched onto the GPU."""
+    from habitat_amd.rl.ppo.ppo_trainer import batch_obs
+    g = torch.Generator().manual_seed(0)
+    envs = [{str(s): torch.randn(128, 128, generator=g) for s in range(4)} for _ in range(4)]
+    obs = [{k: (v.numpy() if sensor_device == "cpu" else v.cuda()) for k, v in e.items()} for e in envs]
+    out = batch_obs(obs, device=torch.device("cuda"))
+    torch.cuda.synchronize()
+    for k, v in out.items():
+        assert v.is_cuda and v.shape == (4, 128, 128) and all(torch.equal(v[i].cpu(), envs[i][k]) for i in range(4))
