@@ -76,7 +76,14 @@ def negotiate_native_comm(world: int, rank: int, device, *, available=None, make
     bcast = bcast or (lambda obj: distrib.broadcast_object_list(obj, src=0))
     available = available or (lambda: bool(_lib.lib().hab_comm_available()))
     make_id = make_id or NativeComm.unique_id
-    create = create or (lambda ident: NativeComm(world, rank, ident=ident))
+    def _create_on_device(ident):
+        # the watchdog thread starts with HIP's per-thread default device (0): bind the rank's GPU before ncclCommInitRank and the
+        # communicator's stream are created there (every rank of a torchrun job sees all GPUs)
+        if getattr(device, "type", None) == "cuda":
+            torch.cuda.set_device(device)
+        return NativeComm(world, rank, ident=ident)
+
+    create = create or _create_on_device
     selftest = selftest or (lambda comm: _native_comm_selftest(comm, device, timeout_s))
     try:
         have = bool(available())
@@ -163,6 +170,10 @@ class DecentralizedDistributedMixin:
         eng = self.actor_critic.engine
         distrib.broadcast(eng.params_flat, src=0)
         eng.repack()
+        # every tensor of the policy OUTSIDE the arena too (auxiliary-loss modules: each rank seeded them differently,
+        # ppo_trainer.py:208-211) -- the DDP constructor broadcasts all of actor_critic's parameters and buffers
+        for t in DecentralizedDistributedMixin._tensors_outside_arena(self.actor_critic):
+            distrib.broadcast(t.data, src=0)
         world = distrib.get_world_size()
         self._native_comm = None
         if DecentralizedDistributedMixin._want_native_comm(world):
@@ -200,6 +211,24 @@ class DecentralizedDistributedMixin:
 
         self.actor_critic._dense_grad_sync = _dense_sync
         self._distributed = True
+
+    @staticmethod
+    def _tensors_outside_arena(actor_critic):
+        """Parameters and buffers of actor_critic that are not views of the engine's arena (aux_loss_modules, foreign modules hung on the
+        policy), in a rank-independent order (registration order)."""
+        if not hasattr(actor_critic, "named_parameters"):
+            return []
+        eng = actor_critic.engine
+        lo = eng.params_flat.data_ptr()
+        hi = lo + eng.params_flat.numel() * eng.params_flat.element_size()
+        out = []
+        for _, t in list(actor_critic.named_parameters()) + list(actor_critic.named_buffers()):
+            if t is None or t.numel() == 0:
+                continue
+            if t.device == eng.params_flat.device and lo <= t.data_ptr() < hi:
+                continue
+            out.append(t)
+        return out
 
     @staticmethod
     def _want_native_comm(world: int) -> bool:

@@ -288,7 +288,8 @@ class PPO(nn.Module, Updater):
     # ---- one minibatch with auxiliary losses: the reference's own sequence (ppo.py:164-299) on the autograd bridge --------------
     def _aux_optimizer(self):
         """Adam over the auxiliary-loss modules' parameters (the reference optimises them with the policy in ONE Adam, ppo.py:112-137:
-        same lr / eps / betas, lr following the policy optimiser's schedule; they are not part of the clipped norm, ppo.py:361-364)."""
+        same lr / eps / betas, lr following the policy optimiser's schedule; each loss's parameter group is clipped to max_grad_norm by
+        ITSELF, not as part of the policy's norm, ppo.py:361-364)."""
         if getattr(self, "_aux_opt", None) is None:
             params = [p for ps in self.actor_critic.aux_loss_parameters().values() for p in ps if p.requires_grad]
             g = self.optimizer.param_groups[0]
@@ -346,6 +347,10 @@ class PPO(nn.Module, Updater):
         if aux_opt is not None:
             for grp in aux_opt.param_groups:
                 grp["lr"] = self.optimizer.param_groups[0]["lr"]
+            for ps in ac.aux_loss_parameters().values():  # ppo.py:361-364: one clip per auxiliary loss, after the rank average
+                ps = [p for p in ps if p.grad is not None]
+                if ps:
+                    torch.nn.utils.clip_grad_norm_(ps, self.max_grad_norm)
             aux_opt.step()
             aux_opt.zero_grad(set_to_none=True)
         self.after_step()

@@ -50,7 +50,15 @@ def _worker(rank, world, port, q):
     assert ddp_utils.rank0_only() == (rank == 0)
     out = {}
     # --- DDPPO mixin: broadcast of rank 0's parameters, summed gradients ---
-    upd = types.SimpleNamespace(actor_critic=types.SimpleNamespace(engine=FakeEngine(rank)))
+    class FakePolicy(torch.nn.Module):  # arena-backed engine + an auxiliary-loss module OUTSIDE the arena, seeded per rank
+        def __init__(self):
+            super().__init__()
+            self.engine = FakeEngine(rank)
+            torch.manual_seed(500 + rank)
+            self.aux_loss_modules = torch.nn.ModuleDict({"cpca": torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3))})
+            self.aux_loss_modules["cpca"][1].running_mean.fill_(float(rank + 1))
+
+    upd = types.SimpleNamespace(actor_critic=FakePolicy())
     g_local = upd.actor_critic.engine.grads_flat.clone()
     DecentralizedDistributedMixin.init_distributed(upd)
     # the RunningMeanAndVar hook handed to the engine averages a small buffer over the ranks (running_mean_and_var.py:38-41)
@@ -73,6 +81,9 @@ def _worker(rank, world, port, q):
     DecentralizedDistributedMixin._all_reduce_grads(upd)
     assert torch.equal(g2, torch.full((1000,), float(sum(range(1, world + 1)))))
     out["params"] = upd.actor_critic.engine.params_flat.clone()
+    # the start-up broadcast covers the modules outside the arena too (the DDP ctor broadcasts all of actor_critic)
+    aux = upd.actor_critic.aux_loss_modules["cpca"]
+    out["aux_w"], out["aux_running_mean"] = aux[0].weight.detach().clone(), aux[1].running_mean.clone()
     out["grads"] = g_reduced
     out["g_local"] = g_local
     out["repacked"] = upd.actor_critic.engine.repacked
@@ -241,6 +252,9 @@ def test_ddppo_host_logic_world2_gloo():
     assert torch.equal(a["params"], b["params"]) and torch.equal(a["params"], FakeEngine(0).params_flat)  # rank 0 broadcast
     assert torch.allclose(a["grads"], a["g_local"] + b["g_local"]) and torch.equal(a["grads"], b["grads"])  # summed, identical
     assert a["repacked"] == 1 and b["repacked"] == 1
+    torch.manual_seed(500)
+    assert torch.equal(a["aux_w"], b["aux_w"]) and torch.equal(a["aux_w"], torch.nn.Linear(5, 3).weight.detach())  # rank 0's draw
+    assert torch.equal(a["aux_running_mean"], b["aux_running_mean"]) and float(a["aux_running_mean"][0]) == 1.0
     allx = torch.cat([a["x"], b["x"]])
     assert torch.allclose(a["mean"], allx.mean().view(1), atol=1e-6) and torch.equal(a["mean"], b["mean"])
     assert torch.allclose(a["var"], allx.var(unbiased=False).view(1), atol=1e-6)

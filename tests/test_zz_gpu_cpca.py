@@ -5,9 +5,19 @@ Unlike the toy loss of test_gpu_policy.py::test_auxiliary_loss_hook_vs_oracle, c
 `aux_loss_state`: it gathers rows of rnn_output / perception_embed through rnn_build_seq_info's select_inds, so this test also pins that the
 bridge hands the two tensors over in the minibatch's frame order.
 
-STATUS: written after round 5's GPU minutes were spent -- the module is pinned bit-exact against the live reference on the CPU
-(tests/test_host_logic.py::test_cpca_auxiliary_loss_identical_to_reference) and the hook on the GPU with the toy loss, but THIS combination
-had not run on hardware when it was committed.  The file sorts last so that `pytest -x` reaches every other GPU test first.
+STATUS (round 6): first hardware run in round 5's driver suite failed the ResNet18 case with the policy-side gradients downstream of
+d rnn_output 1.0e-4 .. 1.3e-4 off the oracle's (bar 1e-4).  Bisected on the GPU by tools/diag_cpca.py (profiles/r06_cpca_bisect.txt):
+  (A) the engine's aux_loss_state vs the oracle's: rnn_output 5.2e-7, perception_embed 2.0e-6 (row by row: the frame order is right);
+  (B) the module on the GPU vs on the CPU for identical inputs: loss 1.7e-7, d rnn_output 4.2e-7;
+  (C) the CPU module on the engine's tensors vs the CPU module on the oracle's: d rnn_output **4.4e-4** -- CPU on both sides: this is the
+      conditioning of cpca's input gradient (the positive and the negative BCE terms nearly cancel through a piecewise-linear head at
+      logits ~ 0, and a 5e-7 input difference is amplified ~800x), not a property of any device code;
+  (D) the engine's backward with the oracle's two gradients injected through hab_policy_set_extra_grads: every policy gradient within
+      8.5e-7; (E) the PPO loss alone: 9.1e-7.
+So the engine, the injection and the GPU module are clean and the old end-to-end bar compared two correct evaluations of an
+ill-conditioned function.  The test below therefore checks each link at 1e-4 -- (A), (B), and the end-to-end arena against the oracle's
+autograd with the module LINEARISED AT THE ENGINE'S TENSORS (the CPU module's gradients there enter the oracle's graph as a linear
+term) -- and records (C) instead of asserting it.
 
 The module's random draws (start steps, kept futures, negatives) are routed through the CPU generator on both sides (`_randperm` /
 `_multinomial` overridden in a subclass), since a CUDA generator and the CPU's produce different streams from one seed.
@@ -52,16 +62,18 @@ def _fill(B, rng, T, N, H, W, hidden):
                                      (1.3 if k == "action_log_probs" else 0.0)).astype(np.float32)))
 
 
-def oracle_total_loss(params, spec, module, obs, h0, prev_actions, masks, actions, ob, info, cfg, kind, draw_seed):
-    """PPO loss + cpca by the oracle's forward and torch autograd on the CPU -> (ppo loss, aux loss, parameter leaves)."""
-    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    taps = {}
-    v, lp, ent, _ = O.evaluate_actions(p, spec, obs, h0, prev_actions, masks, actions, training=True, taps=taps)
-    total, *_ = O.ppo_loss(v, lp, ent, ob, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)
-    pe = taps["cnn_out"] if kind == "baseline" else taps["visual_fc"]
+def rel(a, b):
+    a, b = a.detach().cpu().numpy().astype(np.float64), b.detach().cpu().numpy().astype(np.float64)
+    return float(np.linalg.norm(a - b) / max(1e-30, np.linalg.norm(b)))
+
+
+def module_at(module, feats, perc, actions, info, draw_seed):
+    """The auxiliary module evaluated at (feats, perc) as LEAVES -> (loss, d feats, d perc); its parameter gradients accumulate in .grad."""
+    a, b = feats.detach().clone().requires_grad_(True), perc.detach().clone().requires_grad_(True)
     torch.manual_seed(draw_seed)
-    aux = module({"rnn_output": taps["rnn_out"], "perception_embed": pe}, {"action": actions, "rnn_build_seq_info": info})["loss"]
-    return total, aux, p
+    loss = module({"rnn_output": a, "perception_embed": b}, {"action": actions, "rnn_build_seq_info": info})["loss"]
+    loss.backward()
+    return loss.detach(), a.grad, b.grad
 
 
 @pytest.mark.gpu
@@ -108,41 +120,74 @@ def test_cpca_through_the_engine_hook_vs_oracle(kind):
     info = {k[4:]: seq[k] for k in seq.keys() if k.startswith("cpu_")}
     info["cpu_sequence_lengths"] = info["sequence_lengths"]
     assert int((info["sequence_lengths"] - 1 > AUX_CFG["time_subsample"]).sum()) > 0, "no fragment long enough to draw its start steps"
-    total_o, aux_o, p = oracle_total_loss(params, spec, host_module, obs, B["recurrent_hidden_states"][0, inds].cpu(), take(B["prev_actions"]),
-                                          take(B["masks"]), take(B["actions"]), ob, info, cfg, kind, draw_seed=23)
-    (total_o + aux_o).backward()
-    assert float(aux_o) > 0.05  # (large enough that its gradients are visible beside the PPO loss's)
+    actions_cpu = take(B["actions"])
+    # ---- oracle forward (CPU autograd graph kept) ----
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    taps = {}
+    v_o, lp_o, ent_o, _ = O.evaluate_actions(p, spec, obs, B["recurrent_hidden_states"][0, inds].cpu(), take(B["prev_actions"]), take(B["masks"]),
+                                             actions_cpu, training=True, taps=taps)
+    total_o, *_ = O.ppo_loss(v_o, lp_o, ent_o, ob, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)
+    rn_o, pe_o = taps["rnn_out"], (taps["cnn_out"] if kind == "baseline" else taps["visual_fc"])
     # ---- engine: evaluate_actions on the bridge runs the module on the device ----
     for q in pol.parameters():
         q.grad = None
     torch.manual_seed(23)
     v, lp, ent, _, aux = pol.evaluate_actions(batch["observations"], batch["recurrent_hidden_states"], batch["prev_actions"], batch["masks"],
                                               batch["actions"], batch["rnn_build_seq_info"])
+    eng = pol.engine
+    Bf = T * N
+    feats_e = eng.tap(4)[:Bf * hidden].view(Bf, hidden).clone()
+    perc_e = eng.tap(3).view(Bf, -1)[:, :hidden].clone()
+    # (A) the engine hands the module the oracle's tensors, row by row (this is what pins the frame order of aux_loss_state)
+    assert rel(feats_e, rn_o) <= 1e-4 and rel(perc_e, pe_o) <= 1e-4, (rel(feats_e, rn_o), rel(perc_e, pe_o))
+    # (B) the module on the device vs its CPU twin at the SAME (the engine's) tensors: loss, both input gradients, parameter gradients
+    l_cpu, gf_cpu, gp_cpu = module_at(host_module, feats_e.cpu(), perc_e.cpu(), actions_cpu, info, 23)
+    assert float(l_cpu) > 0.05  # (large enough that its gradients are visible beside the PPO loss's)
     got = float(aux[AUX]["loss"])
-    assert abs(got - float(aux_o)) <= 1e-4 * abs(float(aux_o)), (got, float(aux_o))
+    assert abs(got - float(l_cpu)) <= 1e-4 * abs(float(l_cpu)), (got, float(l_cpu))
+    dev_twin = copy.deepcopy(pol.aux_loss_modules[AUX])
+    for q in dev_twin.parameters():
+        q.grad = None
+    l_dev, gf_dev, gp_dev = module_at(dev_twin, feats_e, perc_e, batch["actions"], batch["rnn_build_seq_info"], 23)
+    assert rel(gf_dev, gf_cpu) <= 1e-4 and rel(gp_dev, gp_cpu) <= 1e-4, (rel(gf_dev, gf_cpu), rel(gp_dev, gp_cpu))
+    # (C) recorded, not asserted: the conditioning of the module's input gradient (CPU module at the oracle's tensors vs at the engine's)
+    cond_module = copy.deepcopy(host_module)
+    for q in cond_module.parameters():
+        q.grad = None
+    _, gf_or, _ = module_at(cond_module, rn_o, pe_o, actions_cpu, info, 23)
+    print(f"[{kind}] forward difference rnn_output {rel(feats_e, rn_o):.2e} -> d rnn_output moves by {rel(gf_cpu, gf_or):.2e} (CPU module both sides)")
+    # ---- end to end: the real module through the hook vs the oracle's autograd with the module linearised at the engine's tensors ----
     b = {k: batch[k] for k in ("action_log_probs", "advantages", "value_preds", "returns")}
     total, *_ = O.ppo_loss(v, lp, ent, b, cfg.clip_param, cfg.value_loss_coef, cfg.entropy_coef, cfg.use_clipped_value_loss)
     (total + aux[AUX]["loss"]).backward()
-    eng = pol.engine
+    (total_o + (rn_o * gf_cpu).sum() + (pe_o * gp_cpu).sum()).backward()
     tol_deep = 1e-4 if kind == "baseline" else 2e-2  # (norm-wise; deep encoder on noise inputs: ReLU-boundary flips, as in the toy-loss test)
     bad = []
     for k, g in eng.grad_views.items():
         if k in eng.buffer_names:
             continue
-        r = p[k].grad.numpy().astype(np.float64)
-        err = np.linalg.norm(g.cpu().numpy().astype(np.float64) - r) / max(1e-30, np.linalg.norm(r))
+        err = rel(g, p[k].grad)
         if err > (tol_deep if ("visual_encoder" in k or "visual_fc" in k) else 1e-4):
             bad.append((k, err))
     assert not bad, bad
     host_grads = dict(host_module.named_parameters())
     for k, q in pol.aux_loss_modules[AUX].named_parameters():
-        r = host_grads[k].grad.numpy().astype(np.float64)
-        err = np.linalg.norm(q.grad.cpu().numpy().astype(np.float64) - r) / max(1e-30, np.linalg.norm(r))
+        err = rel(q.grad, host_grads[k].grad)
         assert err <= 1e-4, (k, err)
     # ---- and the updater's path end to end ----
     before = eng.params_flat.clone()
     w0 = pol.aux_loss_modules[AUX]._predictor[1].weight.detach().clone()
+    # each auxiliary loss's parameters are clipped to max_grad_norm by themselves before the step (reference ppo.py:361-364)
+    aux_opt = ppo._aux_optimizer()
+    seen, real_step = [], aux_opt.step
+    def spy_step(*a, **kw):
+        gs = [q.grad for q in pol.aux_loss_modules[AUX].parameters() if q.grad is not None]
+        seen.append(float(torch.norm(torch.stack([g.norm() for g in gs]))))
+        return real_step(*a, **kw)
+    aux_opt.step = spy_step
+    ppo.max_grad_norm = 1e-3  # (far below the module's raw gradient norm: the clip must bite)
     metrics = ppo.update(st)
+    assert seen and all(abs(n - 1e-3) <= 1e-5 for n in seen), seen
     assert all(np.isfinite(x) for x in metrics.values()) and metrics["grad_norm"] > 0
     assert float((eng.params_flat - before).abs().max()) > 0
     assert float((pol.aux_loss_modules[AUX]._predictor[1].weight - w0).abs().max()) > 0
