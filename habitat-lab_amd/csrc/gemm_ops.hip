@@ -5,6 +5,7 @@
 #include "igemm_dma_wgrad.h"
 #include "igemm_bf3.h"
 #include "igemm_bf3_ws.h"
+#include "dense_bf3.h"
 #include "obs_conv_bf3.h"
 #include "obs_conv_bf3_ws.h"
 #include "obs_conv_patch.h"
@@ -34,12 +35,13 @@ static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); ret
 // i/j-contiguous operand (weight gradients, Linear data gradient), bit 3: prefer it over the fp32 patch / DMA weight-gradient kernels,
 // bit 4: input-patch-resident stride-1 3x3 convolutions (conv_patch_bf3.h), bit 5: producer / consumer waves where they won
 // (igemm_bf3_ws.h: long-K 128 x 128 forward-form tiles; obs_conv_bf3_ws.h: the observation-ingest convolution), bit 6: the
-// observation-ingest convolution with the input patch resident in LDS (obs_conv_patch.h)
+// observation-ingest convolution with the input patch resident in LDS (obs_conv_patch.h), bit 7: strip-resident 3x3 weight gradients
+// (wgrad3x3_bf3.h), bit 8 / 9: SimpleCNN conv2 strip kernels, bit 10: the plain dense GEMM kernel for large Linear layers (dense_bf3.h)
 static std::atomic<int> g_bf3_mode{-1};  // engines of several inference-worker threads dispatch concurrently
 static int bf3_mode() {
     int m = g_bf3_mode.load(std::memory_order_relaxed);
     if (m < 0) {
-        static const int from_env = hab_env_int("HAB_BF3", 1023);
+        static const int from_env = hab_env_int("HAB_BF3", 2047);
         int expected = -1;
         g_bf3_mode.compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
         m = g_bf3_mode.load(std::memory_order_relaxed);
@@ -268,22 +270,59 @@ int obs_conv_wgrad(const ConvDesc& d, const ObsView& obs, const float* dy, float
     }
     return run_igemm(p, ws, ws_floats, stream);
 }
+// Large dense layers on dense_bf3.h (matrix-path bit 10).  Returns 1 when the kernel does not apply.
+static bool dense_on() { return (bf3_mode() & 1024) && (bf3_mode() & 1); }
+static bool dense_worth(long long M, long long N, long long K) {
+    // the shapes it was built and measured for: >= ~10 GFLOP contractions (SimpleCNN's visual fc and its gradients); smaller layers keep
+    // the igemm tiles (their launch is shorter than this kernel's 256 x 128 x K prologue / epilogue)
+    static const long long min_flop = (long long)hab_env_int("HAB_DENSE_MIN_MFLOP", 4000) * 1000000LL;
+    return 2 * M * N * K >= min_flop;
+}
 int linear_fwd(const float* x, int ldx, const float* w, int ldw, const float* bias, float* y, int ldy, int M, int N, int K,
                int relu, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
     LinearFwdProb p;
     HAB_TRY(build(p, x, ldx, w, ldw, bias, y, ldy, M, N, K, relu, accumulate));
+    if (dense_on() && dense_worth(M, N, K)) {
+        DenseArgs g{};
+        g.M = M; g.N = N; g.K = K; g.a = x; g.lda = ldx; g.b = w; g.ldb = ldw; g.c = y; g.ldc = ldy; g.bias = bias; g.relu = relu;
+        g.accumulate = accumulate; g.partial = ws;
+        g.a_bytes = ((long long)(M - 1) * ldx + K) * 4; g.b_bytes = ((long long)(N - 1) * ldw + K) * 4;
+        if (dense_bf3_ok(g, false, false)) {
+            g.nsplit = ws ? dense_bf3_splits(g, ws_floats) : 1;
+            HAB_TRY((dense_bf3_launch<0, 0>(g, stream)));
+            if (g.nsplit > 1) {
+                igemm_splitk_reduce<LinearFwdProb>(p, ws, g.nsplit, stream);
+                HAB_LAUNCH_CHECK();
+            }
+            return HAB_OK;
+        }
+    }
     return run_igemm(p, ws, ws_floats, stream);
 }
 int linear_dgrad(const float* dy, int lddy, const float* w, int ldw, const float* mask, int ldmask, int mask_cols, float* dx,
                  int lddx, int M, int Nin, int Kout, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
     LinearDgradProb p;
     HAB_TRY(build(p, dy, lddy, w, ldw, mask, ldmask, mask_cols, dx, lddx, M, Nin, Kout, accumulate));
+    if (dense_on() && !mask && dense_worth(M, Nin, Kout)) {  // dX[M][Nin] = dY[M][Kout] W[Kout][Nin]: W is the k-strided operand
+        DenseArgs g{};
+        g.M = M; g.N = Nin; g.K = Kout; g.a = dy; g.lda = lddy; g.b = w; g.ldb = ldw; g.c = dx; g.ldc = lddx; g.accumulate = accumulate;
+        g.nsplit = 1;
+        g.a_bytes = ((long long)(M - 1) * lddy + Kout) * 4; g.b_bytes = ((long long)(Kout - 1) * ldw + Nin) * 4;
+        if (dense_bf3_ok(g, false, true)) return dense_bf3_launch<0, 1>(g, stream);
+    }
     return run_igemm(p, ws, ws_floats, stream);
 }
 int linear_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int lddw, int Mrows, int Nout, int Kin,
                  int perm_c, int perm_hw, int accumulate, float* ws, size_t ws_floats, hipStream_t stream) {
     LinearWgradProb p;
     HAB_TRY(build(p, dy, lddy, x, ldx, dw, lddw, Mrows, Nout, Kin, perm_c, perm_hw, accumulate));
+    if (dense_on() && dense_worth(Nout, Kin, Mrows)) {  // dW[Nout][Kin] = dY^T X: both operands are indexed by the frame = k-strided
+        DenseArgs g{};
+        g.M = Nout; g.N = Kin; g.K = Mrows; g.a = dy; g.lda = lddy; g.b = x; g.ldb = ldx; g.c = dw; g.ldc = lddw; g.accumulate = accumulate;
+        g.perm_c = perm_c; g.perm_hw = perm_hw; g.nsplit = 1;
+        g.a_bytes = ((long long)(Mrows - 1) * lddy + Nout) * 4; g.b_bytes = ((long long)(Mrows - 1) * ldx + Kin) * 4;
+        if (dense_bf3_ok(g, true, true)) return dense_bf3_launch<1, 1>(g, stream);
+    }
     return run_igemm(p, ws, ws_floats, stream);
 }
 
@@ -507,6 +546,9 @@ extern "C" int hab_linear_wgrad(const float* dy, int lddy, const float* x, int l
                                 int n_in, int perm_c, int perm_hw, int accumulate, float* ws, size_t ws_floats,
                                 hipStream_t stream) {
     return linear_wgrad(dy, lddy, x, ldx, dw, lddw, M, n_out, n_in, perm_c, perm_hw, accumulate, ws, ws_floats, stream);
+}
+extern "C" int hab_debug_dense_trace(long long* out320) {  // development: see dn_trace (dense_bf3.h)
+    return (int)hipMemcpyFromSymbol(out320, HIP_SYMBOL(hab::dn_trace), sizeof(long long) * 8 * 8 * 5);
 }
 extern "C" int hab_colsum(const float* a, int lda, int M, int N, float* out, int accumulate, float* ws, size_t ws_floats,
                           hipStream_t stream) {
