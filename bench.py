@@ -83,8 +83,8 @@ PROBE_KERNELS = {"conv2_dgrad": "conv2_dgrad_strip_kernel", "conv1_fwd": "obs_co
                  "conv1_wgrad": "obs_wgrad_bf3_kernel", "conv2_wgrad": "wgrad3x3_bf3_kernel<1, 2, 63",
                  "conv3_wgrad": "wgrad3x3_bf3_kernel<2, 1, 30", "conv2_fwd": "conv2_fwd_strip_kernel",
                  "conv3_fwd": "conv_patch_bf3_kernel<ConvFwdProb", "conv3_dgrad": "igemm_bf3_kernel<ConvDgradProb",
-                 "fc_fwd": "igemm_bf3_ws_kernel<LinearFwdProb", "fc_dgrad": "igemm_bf3_kernel<LinearDgradProb",
-                 "fc_wgrad": "igemm_bf3_kernel<LinearWgradProb"}
+                 "fc_fwd": "dense_bf3_kernel<0, 0>", "fc_dgrad": "dense_bf3_kernel<0, 1>",
+                 "fc_wgrad": "dense_bf3_kernel<1, 1>"}
 # Roofline model of a contraction call site on the split-bf16 matrix path (csrc/igemm_bf3.h): (algorithmic HBM bytes per frame:
 # every operand read once, the result written once; bf16 MFMA flops issued per useful fp32 flop).  The fp32-equivalent MFMA ceiling
 # of a site is PEAK_BF16 / factor: 6 partial products in general; the observation-ingest convolutions need 3 for the uint8 rgb
@@ -267,13 +267,15 @@ def c3_parity_record(state, envs=8, steps=NUM_STEPS, workload="c3"):
     trainer._init_train()
     trainer._agent.actor_critic.load_state_dict(state)
     t0 = time.perf_counter()
-    _, par = cpu_baseline_and_parity(trainer, cfg, sample_envs=envs, sample_steps=steps, workload=workload)
+    base, par = cpu_baseline_and_parity(trainer, cfg, sample_envs=envs, sample_steps=steps, workload=workload)
     par["oracle_and_hip_seconds"] = round(time.perf_counter() - t0, 1)
     par["sample"] = f"{envs} envs x {steps} steps (bounded: the full update takes the CPU oracle minutes)"
+    base["sample"] = (f"BOUNDED sample of the workload: {envs} envs x {steps} steps instead of the full rollout (same observation size, network, E and M; "
+                      f"the CPU oracle needs minutes for the full update), otherwise as the headline leg: ") + base["sample"]
     trainer.envs.close()
     del trainer
     torch.cuda.empty_cache()
-    return par
+    return par, base
 
 
 def encoder_record_one_call(frames=8192, timeout_s=240):
@@ -380,7 +382,50 @@ def phase_record(rollout_ms, cycle_ms, ppo):
                    "(GAE, E x M minibatch passes, Adam, statistics)"}
 
 
-def run_cycles(workload, steps, warmup, keep_state=None, distributed=False):
+RN_WGRAD_PROBE = 15  # HAB_PROBE_RN_WGRAD_IM2COL (include/habitat_amd.h)
+RN_WGRAD_KERNEL = "igemm_bf3_kernel<ConvWgradProb, 2, 2, 2, 2>"
+
+
+def pmc_kernel_traffic(workload, kernel_substr):
+    """(mean HBM bytes per launch, calls, file) of a kernel in the newest committed --pmc traffic file of the workload (tools/pmc_traffic.py)."""
+    for tag in ("r06", "r05", "r04", "r03"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_{workload}_hbm_traffic.json")
+        if not os.path.exists(path):
+            continue
+        tot, calls = 0.0, 0
+        for k, r in json.load(open(path)).items():
+            if kernel_substr in k:
+                tot += r["calls"] * (r["fetch_bytes_per_call"] + r["write_bytes_per_call"])
+                calls += r["calls"]
+        if calls:
+            return tot / calls, calls, os.path.relpath(path, ROOT)
+    return None, 0, None
+
+
+def resnet_site_roofline(eng, workload, cycle_ms_total):
+    """`roofline` of a ResNet sub-record: the weight gradients on the generic implicit-GEMM kernel -- the largest single kernel of the
+    C3 cycle by summed time (profiles/r0x_c3_kernel_stats.txt) -- HIP-event bracketed per call (incl. its split-K second pass) inside the
+    timed cycles, priced with the work the engine reports for exactly those calls."""
+    ms, cnt = eng.probe_read_tag(RN_WGRAD_PROBE)
+    flops, nbytes = eng.probe_work(RN_WGRAD_PROBE)
+    if not cnt or ms <= 0:
+        return None
+    tfl = flops / (ms * 1e-3) / 1e12
+    peak_eq = PEAK_BF16_MFMA_TFLOPS / 6.0
+    traffic, pcalls, src = pmc_kernel_traffic(workload, RN_WGRAD_KERNEL)
+    rec = {"bound": "mfma", "kernel": f"{RN_WGRAD_KERNEL} + split-K second pass (ResNet layer3 / layer4 / compression and strided 3x3 weight gradients)",
+           "launches": cnt, "avg_launch_ms": round(ms / cnt, 4), "achieved": round(tfl, 2), "peak": round(peak_eq, 1), "unit": "TFLOP/s",
+           "frac": round(tfl / peak_eq, 4), "frac_of_fp32_mfma_peak": round(tfl / PEAK_FP32_MFMA_TFLOPS, 4),
+           "share_of_step": round(ms / cycle_ms_total, 4), "algorithmic_bytes_per_launch": round(nbytes / cnt),
+           "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3), "traffic": round(traffic) if traffic else None, "traffic_source": src,
+           "traffic_ratio": round(traffic / (nbytes / cnt), 3) if traffic else None,
+           "how": "HIP events around every bracketed call on the launch stream inside the timed cycles (probe HAB_PROBE_RN_WGRAD_IM2COL); FLOPs = "
+                  "2 x pixels x Cout x 9 Cin and bytes = x + dY + dW once, both summed by the engine over the bracketed calls; traffic = mean FETCH_SIZE + "
+                  "WRITE_SIZE per launch of the kernel in the committed counter pass (all its launches, the split-K pass not included)"}
+    return rec
+
+
+def run_cycles(workload, steps, warmup, keep_state=None, distributed=False, keep_flat=None):
     """A second workload inside the same run (sub-record): (env-steps/s, ms per cycle).  keep_state: dict that receives a CPU copy of
     the policy's state_dict as the cycles left it (the c3 parity leg starts from it)."""
     import torch
@@ -395,12 +440,21 @@ def run_cycles(workload, steps, warmup, keep_state=None, distributed=False):
     for _ in range(warmup):
         trainer.run_update_cycle()
     sync()
+    eng_ = trainer._agent.actor_critic.engine
+    site = workload in ("c3", "c5") and not distributed
+    if site:
+        eng_.probe_enable(RN_WGRAD_PROBE)
     s0 = trainer.num_steps_done
     t0 = time.perf_counter()
     for _ in range(steps):
         trainer.run_update_cycle()
     sync()
     dt = time.perf_counter() - t0
+    site_rec = resnet_site_roofline(eng_, workload, dt * 1e3) if site else None
+    if site:
+        eng_.probe_read()
+        eng_.probe_enable(-1)
+    del eng_
     if distributed:  # max over ranks, like the headline figure; num_steps_done is the all-reduced counter
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -410,6 +464,10 @@ def run_cycles(workload, steps, warmup, keep_state=None, distributed=False):
     trainer.envs.close()
     if keep_state is not None:
         keep_state.update({k: v.detach().cpu().clone() for k, v in trainer._agent.actor_critic.state_dict().items()})
+    if keep_flat is not None:  # the parameter arena as the cycles left it + which exchange carried the gradients (exchange A/B at N > 1)
+        keep_flat["params"] = trainer._agent.actor_critic.engine.params_flat.detach().clone()
+        nc = getattr(trainer._agent.updater, "_native_comm", None)
+        keep_flat["comm"] = "rccl-native" if nc is not None else "torch-callbacks"
     world = torch.distributed.get_world_size() if distributed else 1
     rec = {"workload": WORKLOADS[workload]["name"] + (f", DD-PPO x {world} ranks" if distributed else ""), "n_gpus": world,
            "value": round(n / dt, 1), "unit": "env-steps/s", "steps": steps, "warmup": warmup,
@@ -418,6 +476,8 @@ def run_cycles(workload, steps, warmup, keep_state=None, distributed=False):
            "frac_of_split_ceiling": round(n / dt / world * 2.2632e9 / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12), 4) if workload == "c3" else None,
            "frac_basis": "executed contraction FLOPs (2.263 GFLOP per env-step: the stem's data gradient is not computed) / fp32 MFMA peak 157.3; "
                          "frac_of_split_ceiling = the same FLOPs / (bf16 MFMA peak / 6 partial products = 416.7)"}
+    if site_rec:
+        rec["roofline"] = site_rec
     del trainer
     torch.cuda.empty_cache()
     return rec
@@ -430,7 +490,7 @@ def hbm_traffic(workload, probe):
     same command (the newest committed round); null when the probed call site has no entry."""
     if workload != "c2" or probe not in PROBE_KERNELS:
         return None, None
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_c2_hbm_traffic.json")
         if not os.path.exists(path):
             continue
@@ -596,6 +656,42 @@ def main():
             c4 = run_cycles("c3", 5, 2, distributed=True)
         except Exception as exc:  # noqa: BLE001 -- a failure every rank shares (e.g. memory) must not take the headline figure with it
             c4 = {"error": repr(exc)[:300]}
+    exchange_ab = None
+    if world > 1 and a.workload == "c2" and not a.no_extras and not a.no_cpu_baseline:
+        # Both gradient exchanges in ONE run: the torch.distributed callbacks (default) and the library-owned RCCL
+        # communicator (HAB_NATIVE_COMM=1; falls back by a vote of all ranks when it cannot be opened), each on a fresh trainer from the
+        # same seeds -- same rollouts, same minibatches -- so the parameter arenas after the cycles must be EQUAL bit for bit on every
+        # rank if the two exchanges sum the same segments in the same order.
+        exchange_ab = {}
+        flats = {}
+        saved = os.environ.get("HAB_NATIVE_COMM")
+        try:
+            for name, env in (("torch-callbacks", None), ("rccl-native", "1")):
+                if env is None:
+                    os.environ.pop("HAB_NATIVE_COMM", None)
+                else:
+                    os.environ["HAB_NATIVE_COMM"] = env
+                kf = {}
+                try:
+                    r_ = run_cycles("c2", 3, 1, distributed=True, keep_flat=kf)
+                    exchange_ab[name] = {"value": r_["value"], "unit": r_["unit"], "ms_per_step": r_["ms_per_step"], "steps": 3, "warmup": 1,
+                                         "exchange_that_ran": kf.get("comm")}
+                    flats[name] = kf.get("params")
+                except Exception as exc:  # noqa: BLE001
+                    exchange_ab[name] = {"error": repr(exc)[:300]}
+        finally:
+            if saved is None:
+                os.environ.pop("HAB_NATIVE_COMM", None)
+            else:
+                os.environ["HAB_NATIVE_COMM"] = saved
+        same = torch.tensor([1 if (len(flats) == 2 and all(v is not None for v in flats.values())
+                                   and torch.equal(flats["torch-callbacks"], flats["rccl-native"])) else 0], device="cuda")
+        torch.distributed.all_reduce(same, op=torch.distributed.ReduceOp.MIN)
+        exchange_ab["bit_identical"] = bool(same.item())
+        exchange_ab["native_ran"] = exchange_ab.get("rccl-native", {}).get("exchange_that_ran") == "rccl-native"
+        exchange_ab["how"] = ("two fresh DD-PPO trainers of the headline workload from the same seeds, 1 warm-up + 3 timed cycles each, barrier + "
+                              "max-over-ranks timing; bit_identical = parameter arenas equal on EVERY rank (MIN over ranks)")
+        del flats
     if rank != 0:
         torch.distributed.destroy_process_group()
         return
@@ -655,7 +751,7 @@ def main():
         out["roofline"]["overlapped"] = overlapped
     if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
         base, par = cpu_baseline_and_parity(trainer, cfg, cpu_threads=(os.cpu_count() or 1) if a.cpu_threads < 0 else a.cpu_threads)
-        other = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{t_}_cpu_leg_threads.json") for t_ in ("r05", "r04", "r03")) if os.path.exists(p_)), "")
+        other = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"{t_}_cpu_leg_threads.json") for t_ in ("r06", "r05", "r04", "r03")) if os.path.exists(p_)), "")
         if other:  # the same leg timed once at every thread setting on the GPU box's host (committed measurement)
             base["thread_settings_measured"] = json.load(open(other))
         out["cpu_baseline"] = base
@@ -668,17 +764,19 @@ def main():
             c3_state = {}
             out["c3"] = run_cycles("c3", 10, 2, keep_state=c3_state)
             if par:
-                out["c3"]["parity"] = c3_parity_record(c3_state)
+                out["c3"]["parity"], out["c3"]["cpu_baseline"] = c3_parity_record(c3_state)
             del c3_state
             c5_state = {}
             out["c5"] = run_cycles("c5", 3, 1, keep_state=c5_state)  # BASELINE.json configs[4], per GPU
             if par:
-                out["c5"]["parity"] = c3_parity_record(c5_state, envs=2, steps=64, workload="c5")
+                out["c5"]["parity"], out["c5"]["cpu_baseline"] = c3_parity_record(c5_state, envs=2, steps=64, workload="c5")
             del c5_state
             out["encoder_r18_b8192"] = encoder_record_one_call()
     if world > 1:
         if c4 is not None:
             out["c4"] = c4
+        if exchange_ab is not None:
+            out["exchange_ab"] = exchange_ab
         out["note"] = ("n_gpus > 1: `cpu_baseline`, `parity`, the per-site `kernels` table and the c3 / c5 / encoder sub-records are reported by "
                        "the N = 1 run only (rank 0 would have to run them while the other ranks have left); `c4` = the ResNet18 + LSTM "
                        "DD-PPO workload on all ranks")

@@ -87,6 +87,7 @@ struct hab_policy {
     struct ProbeEv { int tag; hipEvent_t first, second; };
     std::vector<ProbeEv> probe_events;
     size_t probe_used = 0;
+    double probe_flops[64] = {0}, probe_bytes[64] = {0};  // algorithmic work of the bracketed call sites that report it
 
     float* p(int i) const { return P + params[i].offset; }
     float* g(int i) const { return G + params[i].offset; }
@@ -123,8 +124,9 @@ int resnet_tap(hab_policy* e, int which, const float** ptr, int64_t* floats);
 
 struct Probe {
     hab_policy* e; hipStream_t s; bool on;
-    Probe(hab_policy* e_, int tag, hipStream_t s_) : e(e_), s(s_), on((e_->probe_mask >> tag) & 1) {
+    Probe(hab_policy* e_, int tag, hipStream_t s_, double flops = 0.0, double bytes = 0.0) : e(e_), s(s_), on((e_->probe_mask >> tag) & 1) {
         if (!on) return;
+        e->probe_flops[tag] += flops; e->probe_bytes[tag] += bytes;
         if (e->probe_used == e->probe_events.size()) {
             hipEvent_t a, b;
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);

@@ -229,12 +229,14 @@ extern "C" int hab_policy_probe_enable(hab_policy* e, int tag) {
     if (!e || tag >= 64) return HAB_ERR_ARG;
     e->probe_mask = tag < 0 ? 0 : (uint64_t)1 << tag;
     e->probe_used = 0;
+    for (int i = 0; i < 64; ++i) { e->probe_flops[i] = 0.0; e->probe_bytes[i] = 0.0; }
     return HAB_OK;
 }
 extern "C" int hab_policy_probe_enable_mask(hab_policy* e, uint64_t mask) {
     if (!e) return HAB_ERR_ARG;
     e->probe_mask = mask;
     e->probe_used = 0;
+    for (int i = 0; i < 64; ++i) { e->probe_flops[i] = 0.0; e->probe_bytes[i] = 0.0; }
     return HAB_OK;
 }
 static int probe_sum(hab_policy* e, int tag, double* total_ms, int* count) {
@@ -252,6 +254,11 @@ static int probe_sum(hab_policy* e, int tag, double* total_ms, int* count) {
     }
     *total_ms = t;
     *count = n;
+    return HAB_OK;
+}
+extern "C" int hab_policy_probe_work(hab_policy* e, int tag, double* flops, double* bytes) {
+    if (!e || tag < 0 || tag >= 64 || !flops || !bytes) return HAB_ERR_ARG;
+    *flops = e->probe_flops[tag]; *bytes = e->probe_bytes[tag];
     return HAB_OK;
 }
 extern "C" int hab_policy_probe_read(hab_policy* e, double* total_ms, int* count) {

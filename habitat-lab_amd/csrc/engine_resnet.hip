@@ -737,6 +737,18 @@ static int gn_backward(hab_policy* e, const RnConv& c, const float* dy, const fl
     return HAB_OK;
 }
 
+// Weight gradient of one convolution of the backbone; the call sites that land on the generic implicit-GEMM kernel (no strip-resident
+// form: 3x3 with >= 128 channels on a side, strided, grouped-as-dense) are bracketed by HAB_PROBE_RN_WGRAD_IM2COL with their algorithmic
+// work: FLOPs = 2 x (B Ho Wo) x Cout x (KH KW C), bytes = x + dY read once, dW written once.
+static int rn_conv_wgrad(hab_policy* e, const ConvDesc& c, const float* x, const float* dy, float* dw, float* ws, hipStream_t s) {
+    const bool im2col = c.KH == 3 && (c.stride > 1 || c.C >= 128 || c.Cout >= 128);
+    if (!im2col) return conv_wgrad(c, x, dy, dw, nullptr, ws, e->ws_floats, s);
+    const double pix = (double)c.B * c.Ho() * c.Wo();
+    Probe pr(e, HAB_PROBE_RN_WGRAD_IM2COL, s, 2.0 * pix * c.Cout * c.KH * c.KW * c.C,
+             4.0 * ((double)c.B * c.H * c.W * c.C + pix * c.Cout + (double)c.Cout * c.KH * c.KW * c.C));
+    return conv_wgrad(c, x, dy, dw, nullptr, ws, e->ws_floats, s);
+}
+
 int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* masks, const int* rows, int B, hipStream_t s) {
     ResNetPlan* r = e->rn;
     float* W = e->WK;
@@ -769,7 +781,7 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
     ConvDesc cd = r->comp.cd;
     cd.B = B;
     const float* comp_in = W + r->blocks.back().w_out;
-    HAB_TRY(conv_wgrad(cd, comp_in, d_raw, e->g(r->comp.i_w), nullptr, ws, e->ws_floats, s));
+    HAB_TRY(rn_conv_wgrad(e, cd, comp_in, d_raw, e->g(r->comp.i_w), ws, s));
     float* d_out = gp.get();  // gradient wrt the last block's output (pre ReLU mask)
     HAB_TRY(conv_dgrad(cd, d_raw, e->PK + r->comp.pk_d, nullptr, nullptr, d_out, ws, e->ws_floats, s));
     gp.put(d_raw);
@@ -813,10 +825,10 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
             ConvDesc c2 = c.cd;
             c2.B = B;
             if (c.cgroups > 1) {  // dense weight gradient into scratch, block diagonal gathered into the (Cout, C / groups, 3, 3) gradient
-                HAB_TRY(conv_wgrad(c2, W + pc.w_out, cur, W + r->w_gdense, nullptr, ws, e->ws_floats, s));
+                HAB_TRY(rn_conv_wgrad(e, c2, W + pc.w_out, cur, W + r->w_gdense, ws, s));
                 HAB_TRY(gather_grouped_wgrad(W + r->w_gdense, e->g(c.i_w), c.cd.Cout, c.cd.C, c.cgroups, c.cd.KH, c.cd.KW, s));
             } else {
-                HAB_TRY(conv_wgrad(c2, W + pc.w_out, cur, e->g(c.i_w), nullptr, ws, e->ws_floats, s));
+                HAB_TRY(rn_conv_wgrad(e, c2, W + pc.w_out, cur, e->g(c.i_w), ws, s));
             }
             float* tmp = gp.get();
             if (!tmp) return HAB_ERR_ARG;
@@ -836,7 +848,7 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
             HAB_TRY(gn_backward(e, dc, d_pre, nullptr, t1, nullptr, B, s));
             ConvDesc c2 = dc.cd;
             c2.B = B;
-            HAB_TRY(conv_wgrad(c2, in, t1, e->g(dc.i_w), nullptr, ws, e->ws_floats, s));
+            HAB_TRY(rn_conv_wgrad(e, c2, in, t1, e->g(dc.i_w), ws, s));
             float* t2 = gp.get();
             if (!t2) return HAB_ERR_ARG;
             HAB_TRY(conv_dgrad(c2, t1, e->PK + dc.pk_d, nullptr, nullptr, t2, ws, e->ws_floats, s));
@@ -847,7 +859,7 @@ int resnet_encoder_backward(hab_policy* e, const hab_obs* obs, const uint8_t* ma
         const RnConv& c0 = r->convs[blk.convs[0]];
         ConvDesc c2 = c0.cd;
         c2.B = B;
-        HAB_TRY(conv_wgrad(c2, in, cur, e->g(c0.i_w), nullptr, ws, e->ws_floats, s));
+        HAB_TRY(rn_conv_wgrad(e, c2, in, cur, e->g(c0.i_w), ws, s));
         float* d_in = gp.get();
         if (!d_in) return HAB_ERR_ARG;
         HAB_TRY(conv_dgrad(c2, cur, e->PK + c0.pk_d, nullptr, add_ptr, d_in, ws, e->ws_floats, s));

@@ -36,7 +36,7 @@ static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); ret
 // bit 4: input-patch-resident stride-1 3x3 convolutions (conv_patch_bf3.h), bit 5: producer / consumer waves where they won
 // (igemm_bf3_ws.h: long-K 128 x 128 forward-form tiles; obs_conv_bf3_ws.h: the observation-ingest convolution), bit 6: the
 // observation-ingest convolution with the input patch resident in LDS (obs_conv_patch.h), bit 7: strip-resident 3x3 weight gradients
-// (wgrad3x3_bf3.h), bit 8 / 9: SimpleCNN conv2 strip kernels, bit 10: the plain dense GEMM kernel for large Linear layers (dense_bf3.h)
+// (wgrad3x3_bf3.h), bit 8 / 9: SimpleCNN conv2 strip kernels, bit 10: the plain dense GEMM kernel for large Linear layers (dense_bf3.h), bit 11 (tests): that kernel for every shape it applies to
 static std::atomic<int> g_bf3_mode{-1};  // engines of several inference-worker threads dispatch concurrently
 static int bf3_mode() {
     int m = g_bf3_mode.load(std::memory_order_relaxed);
@@ -273,6 +273,7 @@ int obs_conv_wgrad(const ConvDesc& d, const ObsView& obs, const float* dy, float
 // Large dense layers on dense_bf3.h (matrix-path bit 10).  Returns 1 when the kernel does not apply.
 static bool dense_on() { return (bf3_mode() & 1024) && (bf3_mode() & 1); }
 static bool dense_worth(long long M, long long N, long long K) {
+    if (bf3_mode() & 2048) return true;  // matrix-path bit 11 (tests): every applicable shape
     // the shapes it was built and measured for: >= ~10 GFLOP contractions (SimpleCNN's visual fc and its gradients); smaller layers keep
     // the igemm tiles (their launch is shorter than this kernel's 256 x 128 x K prologue / epilogue)
     static const long long min_flop = (long long)hab_env_int("HAB_DENSE_MIN_MFLOP", 4000) * 1000000LL;
@@ -306,9 +307,17 @@ int linear_dgrad(const float* dy, int lddy, const float* w, int ldw, const float
     if (dense_on() && !mask && dense_worth(M, Nin, Kout)) {  // dX[M][Nin] = dY[M][Kout] W[Kout][Nin]: W is the k-strided operand
         DenseArgs g{};
         g.M = M; g.N = Nin; g.K = Kout; g.a = dy; g.lda = lddy; g.b = w; g.ldb = ldw; g.c = dx; g.ldc = lddx; g.accumulate = accumulate;
-        g.nsplit = 1;
+        g.partial = ws;
         g.a_bytes = ((long long)(M - 1) * lddy + Kout) * 4; g.b_bytes = ((long long)(Kout - 1) * ldw + Nin) * 4;
-        if (dense_bf3_ok(g, false, true)) return dense_bf3_launch<0, 1>(g, stream);
+        if (dense_bf3_ok(g, false, true)) {
+            g.nsplit = ws ? dense_bf3_splits(g, ws_floats) : 1;
+            HAB_TRY((dense_bf3_launch<0, 1>(g, stream)));
+            if (g.nsplit > 1) {
+                igemm_splitk_reduce<LinearDgradProb>(p, ws, g.nsplit, stream);
+                HAB_LAUNCH_CHECK();
+            }
+            return HAB_OK;
+        }
     }
     return run_igemm(p, ws, ws_floats, stream);
 }
@@ -319,9 +328,17 @@ int linear_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, 
     if (dense_on() && dense_worth(Nout, Kin, Mrows)) {  // dW[Nout][Kin] = dY^T X: both operands are indexed by the frame = k-strided
         DenseArgs g{};
         g.M = Nout; g.N = Kin; g.K = Mrows; g.a = dy; g.lda = lddy; g.b = x; g.ldb = ldx; g.c = dw; g.ldc = lddw; g.accumulate = accumulate;
-        g.perm_c = perm_c; g.perm_hw = perm_hw; g.nsplit = 1;
+        g.perm_c = perm_c; g.perm_hw = perm_hw; g.partial = ws;
         g.a_bytes = ((long long)(Mrows - 1) * lddy + Nout) * 4; g.b_bytes = ((long long)(Mrows - 1) * ldx + Kin) * 4;
-        if (dense_bf3_ok(g, true, true)) return dense_bf3_launch<1, 1>(g, stream);
+        if (dense_bf3_ok(g, true, true)) {
+            g.nsplit = ws ? dense_bf3_splits(g, ws_floats) : 1;
+            HAB_TRY((dense_bf3_launch<1, 1>(g, stream)));
+            if (g.nsplit > 1) {  // (the reduction pass applies the flatten permutation and `accumulate`: LinearWgradProb::store)
+                igemm_splitk_reduce<LinearWgradProb>(p, ws, g.nsplit, stream);
+                HAB_LAUNCH_CHECK();
+            }
+            return HAB_OK;
+        }
     }
     return run_igemm(p, ws, ws_floats, stream);
 }

@@ -130,6 +130,7 @@ SIGNATURES = {
     "hab_policy_probe_read": (c_int, [vp, POINTER(c_double), POINTER(c_int)]),
     "hab_policy_probe_enable_mask": (c_int, [vp, C.c_uint64]),
     "hab_policy_probe_read_tag": (c_int, [vp, c_int, POINTER(c_double), POINTER(c_int)]),
+    "hab_policy_probe_work": (c_int, [vp, c_int, POINTER(c_double), POINTER(c_double)]),
     "hab_policy_tap": (c_int, [vp, c_int, POINTER(vp), POINTER(c_int64)]),
 }
 

@@ -318,6 +318,12 @@ class PolicyEngine:
         check(self.L.hab_policy_probe_read_tag(self.h, int(tag), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def probe_work(self, tag: int):
+        """(FLOPs, algorithmic bytes) launched by the call sites of `tag` since the probe was enabled (tags that report it)."""
+        fl, by = C.c_double(0.0), C.c_double(0.0)
+        check(self.L.hab_policy_probe_work(self.h, int(tag), C.byref(fl), C.byref(by)))
+        return fl.value, by.value
+
     def probe_read(self):
         ms, cnt = C.c_double(0), C.c_int(0)
         check(self.L.hab_policy_probe_read(self.h, C.byref(ms), C.byref(cnt)))

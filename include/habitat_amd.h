@@ -508,12 +508,17 @@ int hab_policy_set_extra_grads(hab_policy* p, const float* d_rnn_output, const f
 #define HAB_PROBE_ENC_BWD 12  /* arch 1: whole visual encoder backward */
 #define HAB_PROBE_RNN_FWD 13  /* packed-sequence recurrent layer forward of evaluate (one event pair per layer) */
 #define HAB_PROBE_RNN_BWD 14  /* its BPTT */
+#define HAB_PROBE_RN_WGRAD_IM2COL 15  /* arch 1: the weight gradients that run on the generic implicit-GEMM kernel (3x3 convolutions with
+                                         >= 128 channels on either side and the strided ones: ResNet layer3 / layer4 / compression) */
 int hab_policy_probe_enable(hab_policy* p, int tag /* -1 = off */);
 /* several call sites at once: bit t of mask = HAB_PROBE_<t> (per-kernel table of bench.py, measured outside its timed region) */
 int hab_policy_probe_enable_mask(hab_policy* p, uint64_t mask);
 /* summed duration / number of bracketed calls: of ALL enabled sites (and forgets them), or of one tag (keeps them) */
 int hab_policy_probe_read(hab_policy* p, double* total_ms, int* count);
 int hab_policy_probe_read_tag(hab_policy* p, int tag, double* total_ms, int* count);
+/* algorithmic work (FLOPs: 2 x M x N x K of each bracketed contraction) and bytes (operands read once + result written once) the call
+ * sites of `tag` have launched since the probe was enabled; only the tags whose call sites report it (HAB_PROBE_RN_WGRAD_IM2COL) */
+int hab_policy_probe_work(hab_policy* p, int tag, double* flops, double* bytes);
 
 /* Test taps into the activation workspace of the last evaluate (NHWC). */
 #define HAB_TAP_CONV1 0

@@ -250,6 +250,12 @@ def test_bench_py_launches_two_ranks_and_reports_whole_job_rate():
     c4 = out["c4"]
     assert c4["n_gpus"] == 2 and "ResNet18" in c4["workload"] and c4["steps"] == 5
     assert abs(c4["value"] * c4["ms_per_step"] * 5 / 1e3 - 2 * 64 * 128 * 5) <= 0.01 * 2 * 64 * 128 * 5
+    # both gradient exchanges in one run: on a gloo group the native RCCL communicator is not wanted, so the second
+    # trainer runs the callbacks as well -- two trainers from the same seeds must then end on bit-identical parameter arenas on both ranks
+    ab = out["exchange_ab"]
+    assert ab["bit_identical"] is True and ab["native_ran"] is False, ab
+    for k in ("torch-callbacks", "rccl-native"):
+        assert ab[k]["exchange_that_ran"] == "torch-callbacks" and ab[k]["value"] > 0 and ab[k]["steps"] == 3, ab
 
 
 def _reduce_worker(rank, world, port, unused_params, q):

@@ -129,7 +129,7 @@ def test_benchmark_shape_minibatch_agrees_on_every_matrix_path():
     try:
         ref_out, ref_g = run()
         rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
-        for name, mode in (("fp32_mfma", 0), ("split_bf16_igemm_only", 1), ("no_256x256_strip_kernels", 1023 & ~(64 | 256 | 512))):
+        for name, mode in (("fp32_mfma", 0), ("split_bf16_igemm_only", 1), ("no_256x256_strip_kernels", 1023 & ~(64 | 256 | 512)), ("no_dense_gemm", 1023)):
             L.hab_set_matrix_path(mode)
             out, grads = run()
             for a, b, what in zip(out, ref_out, ("value", "log_prob", "entropy")):

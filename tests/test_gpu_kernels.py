@@ -368,6 +368,45 @@ def test_linear_family(L, M, N, K):
     assert torch.allclose(db.cpu(), (gy * (y_ref > 0)).sum(0), atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,perm", [(512, 512, 3136, True), (300, 384, 1024, False), (256, 128, 256, False), (1100, 260, 608, False),
+                                         (640, 2048, 576, False)])
+def test_dense_gemm_kernel_vs_float64(L, M, N, K, perm):
+    """csrc/dense_bf3.h (matrix-path bits 10 + 11: every applicable shape) through hab_linear_fwd / _dgrad / _wgrad against float64:
+    bias + ReLU and split-K slabs (forward), a k-strided weight operand (data gradient), two k-strided operands + the NHWC-flatten ->
+    NCHW-flatten column permutation + accumulate (weight gradient), ragged M / N tiles.  Same error bar as the igemm kernels."""
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    ws = torch.zeros(1 << 25, device="cuda")
+    prev = L.hab_set_matrix_path(4095)
+    try:
+        ldn = N + 4  # (padded output rows: the vector stores must respect the leading dimension)
+        y = torch.full((M, ldn), 7.0, device="cuda")
+        ck(L.hab_linear_fwd(P(x), K, P(w), K, P(b), P(y), ldn, M, N, K, 1, 0, P(ws), ws.numel(), S()))
+        ref = torch.relu(x.double() @ w.double().t() + b.double())
+        assert float((y[:, :N].double() - ref).norm() / ref.norm()) <= 2e-6 and bool((y[:, N:] == 7.0).all())
+        dx = torch.zeros(M, K, device="cuda")
+        ck(L.hab_linear_dgrad(P(dy), N, P(w), K, None, 0, P(dx), K, M, K, N, 0, P(ws), ws.numel(), S()))
+        ref = dy.double() @ w.double()
+        assert float((dx.double() - ref).norm() / ref.norm()) <= 2e-6
+        old = torch.randn(N, K, device="cuda", generator=g)
+        dw = old.clone()
+        pc, ph = (32, K // 32) if perm else (0, 0)
+        ck(L.hab_linear_wgrad(P(dy), N, P(x), K, P(dw), K, M, N, K, pc, ph, 1, P(ws), ws.numel(), S()))
+        ref = dy.double().t() @ x.double()
+        if perm:  # column hw * 32 + c of x is column c * HW + hw of the reference weight
+            ref = ref.view(N, K // 32, 32).transpose(1, 2).reshape(N, K)
+        assert float((dw.double() - old.double() - ref).norm() / ref.norm()) <= 2e-6
+        # bitwise reproducible (fixed reduction order, no atomics)
+        dw2 = old.clone()
+        ck(L.hab_linear_wgrad(P(dy), N, P(x), K, P(dw2), K, M, N, K, pc, ph, 1, P(ws), ws.numel(), S()))
+        assert torch.equal(dw, dw2)
+    finally:
+        L.hab_set_matrix_path(prev)
+
+
 def test_igemm_transpose_detecting_identity(L):
     """A = I with an asymmetric B: catches swapped fragment rows/cols (cdna guide, rule 16)."""
     M = N = K = 96

@@ -339,7 +339,7 @@ def test_resnet_golden_mask_flip_accounting(case):
 # weight gradients, the observation convolution, every patch / strip kernel on their fp32 forms); the default minus the three kernels
 # hard-wired to the 256 x 256 benchmark geometry (observation patch, conv2 forward / data-gradient strips): what an observation size
 # other than 256 x 256 runs in production
-MATRIX_PATHS = {"fp32_mfma": 0, "split_bf16_igemm_only": 1, "no_256x256_strip_kernels": 1023 & ~(64 | 256 | 512)}
+MATRIX_PATHS = {"fp32_mfma": 0, "split_bf16_igemm_only": 1, "no_256x256_strip_kernels": 1023 & ~(64 | 256 | 512), "no_dense_gemm": 1023}
 
 
 @pytest.mark.parametrize("path", list(MATRIX_PATHS))
