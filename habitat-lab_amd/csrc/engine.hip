@@ -495,7 +495,7 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
                 RnnWork wk = layer_work(e, l);
                 Probe pr(e, HAB_PROBE_RNN_FWD, sB);
                 HAB_TRY(rnn_tm_layer_forward(e->d.rnn_type, H, lp, wk, xl, ldl, W + e->w_hinit + (size_t)l * n * H,
-                                             W + e->w_cinit + (size_t)l * n * H, fmask, n, t0, t1, W + e->w_ws2, e->ws2_floats, sB));
+                                             W + e->w_cinit + (size_t)l * n * H, fmask, n, T, t0, t1, W + e->w_ws2, e->ws2_floats, sB));
                 xl = wk.out;
                 ldl = H;
             }

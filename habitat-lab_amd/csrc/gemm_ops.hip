@@ -36,7 +36,8 @@ static bool no_patch() { static const bool v = hab_env_flag("HAB_NO_PATCH"); ret
 // bit 4: input-patch-resident stride-1 3x3 convolutions (conv_patch_bf3.h), bit 5: producer / consumer waves where they won
 // (igemm_bf3_ws.h: long-K 128 x 128 forward-form tiles; obs_conv_bf3_ws.h: the observation-ingest convolution), bit 6: the
 // observation-ingest convolution with the input patch resident in LDS (obs_conv_patch.h), bit 7: strip-resident 3x3 weight gradients
-// (wgrad3x3_bf3.h), bit 8 / 9: SimpleCNN conv2 strip kernels, bit 10: the plain dense GEMM kernel for large Linear layers (dense_bf3.h), bit 11 (tests): that kernel for every shape it applies to
+// (wgrad3x3_bf3.h), bit 8 / 9: SimpleCNN conv2 strip kernels, bit 10: the plain dense GEMM kernel for large Linear layers (dense_bf3.h), bit 11 (tests): that kernel for every shape it applies to,
+// bit 12 (tests): the time-major recurrence as one launch per step instead of the persistent kernels (rnn_persist.h)
 static std::atomic<int> g_bf3_mode{-1};  // engines of several inference-worker threads dispatch concurrently
 static int bf3_mode() {
     int m = g_bf3_mode.load(std::memory_order_relaxed);
@@ -48,6 +49,7 @@ static int bf3_mode() {
     }
     return m;
 }
+int matrix_path_bits() { return bf3_mode(); }
 extern "C" int hab_set_matrix_path(int mode) {
     const int prev = bf3_mode();
     if (mode >= 0) g_bf3_mode.store(mode, std::memory_order_relaxed);

@@ -91,10 +91,12 @@ int rnn_seq_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const 
                            const float* dout, float* dx, int lddx, const float* dx_mask, int ldmask, int mask_cols,
                            const PackInfo& pk, float* scratch /* 3*F*H floats */, float* ws, size_t ws_floats,
                            hipStream_t stream);
+int matrix_path_bits();  // the current mask of hab_set_matrix_path (gemm_ops.hip)
 // time-major form (regular T x n minibatch), chunkable in time: see rnn.hip
 int rnn_tm_prepare(const uint8_t* masks, const int* rows, int B, uint8_t* frame_mask, int* iota, hipStream_t stream);
 int rnn_tm_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx, const float* hinit,
-                         const float* cinit, const uint8_t* frame_mask, int n, int t0, int t1, float* ws, size_t ws_floats, hipStream_t stream);
+                         const float* cinit, const uint8_t* frame_mask, int n, int T_total, int t0, int t1, float* ws, size_t ws_floats,
+                         hipStream_t stream);
 int rnn_tm_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* dout, float* dx, int lddx,
                           const float* dx_mask, int ldmask, int mask_cols, const uint8_t* frame_mask, const int* iota, int n, int T, int t0,
                           int t1, float* scratch, float* ws, size_t ws_floats, hipStream_t stream);

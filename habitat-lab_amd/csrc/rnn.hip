@@ -15,6 +15,8 @@
 // BPTT runs the steps in reverse (one launch per step: transposed mat-vec of step s+1 fused with the gate gradients of step s) and
 // finishes with three contractions over all frames (dW_ih, dW_hh, dX) and two column sums.
 #include "ops.h"
+#include "rnn_gates.h"
+#include "rnn_persist.h"
 #include "../../include/habitat_amd.h"
 
 namespace hab {
@@ -201,10 +203,8 @@ __device__ __forceinline__ void rnn_step_body(const StepArgs& a) {
     const int uu = u0 + u;
     const float hp = hp_pre;
     if constexpr (G == 3) {
-        const float rg = sigmoidf_(gi_pre[0] + gh[0]);
-        const float zg = sigmoidf_(gi_pre[1] + gh[1]);
-        const float ng = tanhf(gi_pre[2] + rg * gh[2]);
-        const float hnew = (1.0f - zg) * ng + zg * hp;
+        float rg, zg, ng;
+        const float hnew = gru_cell_fwd(gi_pre[0], gi_pre[1], gi_pre[2], gh[0], gh[1], gh[2], hp, rg, zg, ng);
         a.out[(size_t)f * a.out_stride + uu] = hnew;
         if (a.gates) {
             float* gs = a.gates + (size_t)f * 3 * H;
@@ -214,12 +214,8 @@ __device__ __forceinline__ void rnn_step_body(const StepArgs& a) {
         }
     } else {
         const float cp = cp_pre;
-        const float ig = sigmoidf_(gi_pre[0] + gh[0]);
-        const float fg = sigmoidf_(gi_pre[1] + gh[1]);
-        const float gg = tanhf(gi_pre[2] + gh[2]);
-        const float og = sigmoidf_(gi_pre[3] + gh[3]);
-        const float cn = fg * cp + ig * gg;
-        const float hnew = og * tanhf(cn);
+        float ig, fg, gg, og, cn;
+        const float hnew = lstm_cell_fwd(gi_pre[0] + gh[0], gi_pre[1] + gh[1], gi_pre[2] + gh[2], gi_pre[3] + gh[3], cp, ig, fg, gg, og, cn);
         a.out[(size_t)f * a.out_stride + uu] = hnew;
         if (a.c_out) a.c_out[(size_t)f * a.c_out_stride + uu] = cn;
         if (a.gates) {
@@ -386,17 +382,19 @@ struct BwdStepArgsN {
     BwdStepArgs l[RNN_MAX_WAVE_LAYERS];
 };
 
-template <int G, int NW>
+// UP: the launch may carry the layer-above term (layer wavefront); the single-layer forms do not allocate its reduction buffer -- LDS is what
+// decides whether a step workgroup fits on a CU beside a 148 KB workgroup of the encoder's dense / strip kernels (second-stream recurrence).
+template <int G, int NW, bool UP>
 __device__ __forceinline__ void rnn_bwd_step_body(const BwdStepArgs& a) {
     __shared__ float red[NW][256];
-    __shared__ float red_up[NW][256];
+    __shared__ float red_up[UP ? NW : 1][UP ? 256 : 1];
     constexpr int U = 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int row0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
     const int H = a.H;
     if (row0 >= a.R) return;  // (a wavefront launch is sized for its widest layer)
     const bool has_carry = row0 < a.R_next;  // workgroup-uniform
-    const bool has_up = a.up_dgi != nullptr;
+    const bool has_up = UP && a.up_dgi != nullptr;
     // gate-phase operands of this thread's (row, unit) element, fetched underneath the carry mat-vec (see rnn_step_kernel)
     const int r_ = t >> 4, uu_ = u0 + (t & 15), q_ = row0 + r_;
     const bool gate_thread = (t < 256) & (q_ < a.R);
@@ -447,10 +445,12 @@ __device__ __forceinline__ void rnn_bwd_step_body(const BwdStepArgs& a) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) out[wave][(kg * 4 + v) * 16 + i] = acc[v];
     };
-    if (has_up) {  // gradient wrt this layer's output at the frames of THIS step
-        const int i = lane & 15;
-        const int q = min(row0 + i, a.R - 1);
-        matvec(a.up_dgi + (size_t)a.idx[q] * a.K, a.up_w_ih_t + (size_t)(u0 + i) * a.K, red_up);
+    if constexpr (UP) {
+        if (has_up) {  // gradient wrt this layer's output at the frames of THIS step
+            const int i = lane & 15;
+            const int q = min(row0 + i, a.R - 1);
+            matvec(a.up_dgi + (size_t)a.idx[q] * a.K, a.up_w_ih_t + (size_t)(u0 + i) * a.K, red_up);
+        }
     }
     if (has_carry) {
         const int i = lane & 15;
@@ -464,11 +464,13 @@ __device__ __forceinline__ void rnn_bwd_step_body(const BwdStepArgs& a) {
     const int f = f_pre;
     const size_t qo = (size_t)q * H + uu;
     float dh = dout_pre;
-    if (has_up) {
-        float sum = 0.f;
+    if constexpr (UP) {
+        if (has_up) {
+            float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; w += 4) sum += (red_up[w][t] + red_up[w + 1][t]) + (red_up[w + 2][t] + red_up[w + 3][t]);
-        dh += sum;
+            for (int w = 0; w < NW; w += 4) sum += (red_up[w][t] + red_up[w + 1][t]) + (red_up[w + 2][t] + red_up[w + 3][t]);
+            dh += sum;
+        }
     }
     const bool carried = (q < a.R_next) && (!a.next_keep || a.next_keep[q]);
     if (carried) {
@@ -479,40 +481,29 @@ __device__ __forceinline__ void rnn_bwd_step_body(const BwdStepArgs& a) {
         if constexpr (G == 3) dh += dhd_pre;
     }
     if constexpr (G == 3) {
-        const float rg = gs_pre[0], z = gs_pre[1], n = gs_pre[2];
-        const float hp = hp_pre, hn = hn_pre;
-        const float dn = dh * (1.0f - z);
-        const float dz = dh * (hp - n);
-        const float dn_pre = dn * (1.0f - n * n);
-        const float dr = dn_pre * hn;
-        const float dr_pre = dr * rg * (1.0f - rg);
-        const float dz_pre = dz * z * (1.0f - z);
+        float dr_pre, dz_pre, dn_pre, dhn_pre, direct;
+        gru_cell_bwd(dh, gs_pre[0], gs_pre[1], gs_pre[2], hp_pre, hn_pre, dr_pre, dz_pre, dn_pre, dhn_pre, direct);
         float* gi = a.dgi + (size_t)f * 3 * H;
         float* gh = a.dgh + (size_t)f * 3 * H;
         gi[uu] = dr_pre; gi[H + uu] = dz_pre; gi[2 * H + uu] = dn_pre;
-        gh[uu] = dr_pre; gh[H + uu] = dz_pre; gh[2 * H + uu] = dn_pre * rg;
-        a.dh_direct[qo] = dh * z;
+        gh[uu] = dr_pre; gh[H + uu] = dz_pre; gh[2 * H + uu] = dhn_pre;
+        a.dh_direct[qo] = direct;
     } else {
-        const float ig = gs_pre[0], fg = gs_pre[1], gg = gs_pre[2], og = gs_pre[3];
-        const float cn = cn_pre, cp = cp_pre;
-        const float tc = tanhf(cn);
-        float dc = dh * og * (1.0f - tc * tc);
-        if (carried) dc += dcc_pre;
-        const float d_o = dh * tc;
-        const float di = dc * gg, dg = dc * ig, df = dc * cp;
+        float di_pre, df_pre, dg_pre, do_pre, cc;
+        lstm_cell_bwd(dh, carried, dcc_pre, gs_pre[0], gs_pre[1], gs_pre[2], gs_pre[3], cn_pre, cp_pre, di_pre, df_pre, dg_pre, do_pre, cc);
         float* gi = a.dgi + (size_t)f * 4 * H;
-        gi[uu] = di * ig * (1.0f - ig);
-        gi[H + uu] = df * fg * (1.0f - fg);
-        gi[2 * H + uu] = dg * (1.0f - gg * gg);
-        gi[3 * H + uu] = d_o * og * (1.0f - og);
-        a.dc_carry[qo] = dc * fg;
+        gi[uu] = di_pre;
+        gi[H + uu] = df_pre;
+        gi[2 * H + uu] = dg_pre;
+        gi[3 * H + uu] = do_pre;
+        a.dc_carry[qo] = cc;
     }
 }
 
 template <int G, int NW>
-__global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs a) { rnn_bwd_step_body<G, NW>(a); }
+__global__ void __launch_bounds__(64 * NW) rnn_bwd_step_kernel(const BwdStepArgs a) { rnn_bwd_step_body<G, NW, false>(a); }
 template <int G, int NW>
-__global__ void __launch_bounds__(64 * NW) rnn_bwd_step_wave_kernel(const BwdStepArgsN a) { rnn_bwd_step_body<G, NW>(a.l[blockIdx.z]); }
+__global__ void __launch_bounds__(64 * NW) rnn_bwd_step_wave_kernel(const BwdStepArgsN a) { rnn_bwd_step_body<G, NW, true>(a.l[blockIdx.z]); }
 
 int rnn_seq_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx,
                            const float* dout, float* dx, int lddx, const float* dx_mask, int ldmask, int mask_cols,
@@ -642,12 +633,46 @@ int rnn_tm_prepare(const uint8_t* masks, const int* rows, int B, uint8_t* frame_
 
 // steps t0 .. t1-1 of one layer: input projection of the chunk's frames, then the recurrence.  hinit / cinit: [n][H] state entering t = 0
 // (episode-start mask already applied, rnn_frag_init).  ws: split-K scratch private to the calling stream.
+// The persistent form applies to H = 128 / 256 / 512 (8 waves x 1 / 2 / 4 K-chunks), <= 15 row tiles, 32-bit byte offsets into the
+// per-frame arrays.  HAB_RNN_PERSIST=0 selects the step-per-launch form (bit-identical results).
+static bool tm_persist_ok(int rnn_type, int H, int n, int T, const float* ws, size_t ws_floats) {
+    static const bool on = hab_env_int("HAB_RNN_PERSIST", 1) != 0;
+    const int G = rnn_type == RNN_GRU ? 3 : 4;
+    if (!on || (matrix_path_bits() & 4096) || !ws || ws_floats < 64) return false;
+    if (H != 128 && H != 256 && H != 512) return false;
+    if (cdiv(n, 16) > RNNP_MAX_ROW_TILES) return false;
+    if ((size_t)T * n * G * H * 4 >= ((size_t)1 << 31)) return false;
+    return true;
+}
+
 int rnn_tm_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const RnnWork& wk, const float* x, int ldx, const float* hinit,
-                         const float* cinit, const uint8_t* frame_mask, int n, int t0, int t1, float* ws, size_t ws_floats, hipStream_t stream) {
+                         const float* cinit, const uint8_t* frame_mask, int n, int T_total, int t0, int t1, float* ws, size_t ws_floats,
+                         hipStream_t stream) {
     const int G = rnn_type == RNN_GRU ? 3 : 4;
     const size_t f0 = (size_t)t0 * n;
     HAB_TRY(linear_fwd(x + f0 * ldx, ldx, lp.w_ih, lp.in_dim, lp.b_ih, wk.gi + f0 * G * H, G * H, (t1 - t0) * n, G * H, lp.in_dim, 0, 0, ws,
                        ws_floats, stream));
+    if (tm_persist_ok(rnn_type, H, n, T_total, ws, ws_floats) && wk.gates) {  // the chunk's steps as ONE persistent launch (rnn_persist.h)
+        TmPersistFwdArgs a;
+        a.n = n; a.H = H; a.T = T_total; a.t0 = t0; a.t1 = t1;
+        a.hinit = hinit; a.cinit = cinit; a.frame_mask = frame_mask; a.gi = wk.gi; a.w_hh = lp.w_hh; a.b_hh = lp.b_hh;
+        a.gates = wk.gates; a.hn = wk.hn; a.hprev = wk.hprev; a.cprev = wk.cprev; a.c = wk.c; a.out = wk.out;
+        a.counters = reinterpret_cast<rnnp_u64*>(ws);
+        if (hipMemsetAsync(ws, 0, 16 * sizeof(rnnp_u64), stream) != hipSuccess) return HAB_ERR_ARG;
+        const dim3 grid(cdiv(n, 16), H / 16);
+        const int kch = H / 128;
+        if (rnn_type == RNN_GRU) {
+            if (kch == 4) rnn_tm_persist_fwd_kernel<3, 4><<<grid, 512, 0, stream>>>(a);
+            else if (kch == 2) rnn_tm_persist_fwd_kernel<3, 2><<<grid, 512, 0, stream>>>(a);
+            else rnn_tm_persist_fwd_kernel<3, 1><<<grid, 512, 0, stream>>>(a);
+        } else {
+            if (kch == 4) rnn_tm_persist_fwd_kernel<4, 4><<<grid, 512, 0, stream>>>(a);
+            else if (kch == 2) rnn_tm_persist_fwd_kernel<4, 2><<<grid, 512, 0, stream>>>(a);
+            else rnn_tm_persist_fwd_kernel<4, 1><<<grid, 512, 0, stream>>>(a);
+        }
+        HAB_LAUNCH_CHECK();
+        return HAB_OK;
+    }
     for (int t = t0; t < t1; ++t) {
         const size_t f = (size_t)t * n, fp = (size_t)(t - 1) * n;
         StepArgs a;
@@ -680,7 +705,29 @@ int rnn_tm_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const R
     float* dgh = (rnn_type == RNN_GRU) ? wk.dgh : wk.dgi;
     const int K = G * H;
     const bool wide = K % 128 == 0;
-    for (int t = t1 - 1; t >= t0; --t) {
+    bool persisted = false;
+    if (tm_persist_ok(rnn_type, H, n, T, ws, ws_floats) && dout) {  // the chunk's BPTT steps as ONE persistent launch (rnn_persist.h)
+        TmPersistBwdArgs a;
+        a.n = n; a.H = H; a.T = T; a.t0 = t0; a.t1 = t1;
+        a.frame_mask = frame_mask; a.dout = dout; a.w_hh_t = lp.w_hh_t; a.dh_direct = dh_direct; a.dc_carry = dc_carry;
+        a.gates = wk.gates; a.hn = wk.hn; a.hprev = wk.hprev; a.cprev = wk.cprev; a.c = wk.c; a.dgi = wk.dgi; a.dgh = dgh;
+        a.counters = reinterpret_cast<rnnp_u64*>(ws);
+        if (hipMemsetAsync(ws, 0, 16 * sizeof(rnnp_u64), stream) != hipSuccess) return HAB_ERR_ARG;
+        const dim3 grid(cdiv(n, 16), H / 16);
+        const int kch = H / 128;
+        if (rnn_type == RNN_GRU) {
+            if (kch == 4) rnn_tm_persist_bwd_kernel<3, 12><<<grid, 512, 0, stream>>>(a);
+            else if (kch == 2) rnn_tm_persist_bwd_kernel<3, 6><<<grid, 512, 0, stream>>>(a);
+            else rnn_tm_persist_bwd_kernel<3, 3><<<grid, 512, 0, stream>>>(a);
+        } else {
+            if (kch == 4) rnn_tm_persist_bwd_kernel<4, 16><<<grid, 512, 0, stream>>>(a);
+            else if (kch == 2) rnn_tm_persist_bwd_kernel<4, 8><<<grid, 512, 0, stream>>>(a);
+            else rnn_tm_persist_bwd_kernel<4, 4><<<grid, 512, 0, stream>>>(a);
+        }
+        HAB_LAUNCH_CHECK();
+        persisted = true;
+    }
+    for (int t = t1 - 1; t >= t0 && !persisted; --t) {
         BwdStepArgs g;
         g.R = n; g.H = H; g.K = K;
         g.R_next = (t + 1 < T) ? n : 0;

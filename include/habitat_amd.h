@@ -178,7 +178,12 @@ int hab_sample_actions(const float* probs, const float* exp_noise, int64_t* acti
  *            the filter slices resident in the waves' registers (conv2_fwd_strip.h)
  *     bit 9  (with bit 0) SimpleCNN conv2's data gradient on the same scheme: dY strip in LDS, filter slices in registers, the four taps
  *            of a row class folded in LDS, ReLU mask fused (conv2_dgrad_strip.h)
- *   Default 1023 (all), env HAB_BF3 overrides.  hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one;
+ *     bit 10 (with bit 0) large Linear layers (>= 4 GFLOP: SimpleCNN's visual fc forward / data gradient / weight gradient, the ResNet
+ *            policies' recurrent input projection) on the plain dense GEMM kernel: 256 x 128 tiles, double-buffered LDS, transpose-read
+ *            fragments for k-strided operands, LDS-staged epilogue incl. the flatten permutation (dense_bf3.h)
+ *     bit 11 (tests) bit 10's kernel for every shape it applies to
+ *     bit 12 (tests) the time-major recurrence as one launch per step instead of the persistent kernels (rnn_persist.h; bit-identical)
+ *   Default 2047 (bits 0-10), env HAB_BF3 overrides.  hab_set_matrix_path(mode >= 0) sets the mask and returns the previous one;
  *   mode < 0 only queries.  Results are fp32-equivalent on either path (tests/test_gpu_bf3.py: error vs float64 of both).
  * ------------------------------------------------------------------------------------------- */
 int hab_set_matrix_path(int mode);
