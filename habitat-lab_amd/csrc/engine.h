@@ -109,7 +109,7 @@ inline int add_param(hab_policy* e, const std::string& name, std::initializer_li
 
 
 int tm_chunks_cfg();         // time chunks of the time-major recurrence (HAB_RNN_CHUNKS; 0 / 1: packed form / one chunk)
-int tm_chunks_resnet_cfg();  // ... for the ResNet policies (HAB_RNN_CHUNKS_RESNET, default 0 = packed)
+int tm_chunks_resnet_cfg(int frames);  // ... for the ResNet policies (HAB_RNN_CHUNKS_RESNET; default: 2 chunks from 4096 frames on, else packed)
 int build_resnet(hab_policy* e);
 void destroy_resnet(hab_policy* e);
 int resnet_repack(hab_policy* e, hipStream_t s);

@@ -312,17 +312,20 @@ static int encoder_forward(hab_policy* e, const hab_obs* obs, const uint8_t* mas
 
 // ---- time-major chunked recurrence: second stream + events ----
 int tm_chunks_cfg() { static const int v = hab_env_int("HAB_RNN_CHUNKS", 4); return v; }
-// ResNet policies: built, bit-identical to the packed form at one chunk (tests/test_gpu_determinism.py), and measured SLOWER on the C3
-// benchmark (ResNet18 + 2-layer LSTM, 32 environments per minibatch): 28.5 k env-steps/s with 1, 2 or 3 chunks against 29.1 k packed on the
-// same box.  The packed form walks max_len ~ 107 steps of the ~215 episode fragments, the time-major form all T = 128 steps of 32 rows --
-// both latency-bound per step, so the packed form is 16 % shorter; every extra chunk is another pass through ~60 encoder kernels at a
-// quarter of the frames; and the encoder's weight gradients reduce over all frames, so the backward cannot follow chunk by chunk the way
-// SimpleCNN's data-gradient chain does.  Default: packed (0); HAB_RNN_CHUNKS_RESNET = k > 0 selects k chunks (HAB_RNN_CHUNKS = 0 / 1 still
-// selects the packed form / one chunk for both policies).
-int tm_chunks_resnet_cfg() {
-    static const int v = hab_env_int("HAB_RNN_CHUNKS_RESNET", 0);
+// ResNet policies: bit-identical to the packed form at one chunk (tests/test_gpu_determinism.py).  With one launch per step the time-major
+// form measured SLOWER than the packed form on C3 (round 4: 28.5 k vs 29.1 k env-steps/s: all T = 128 steps of 32 rows against max_len ~ 107
+// packed steps, and every chunk is another pass through ~60 encoder kernels).  With the persistent recurrence (rnn_persist.h, round 6) a
+// chunk's steps are one launch per layer on the second stream and the balance tips for large minibatches -- same box, env-steps/s:
+//   C3 (ResNet18, 4096 frames per minibatch): packed 32.27 k / 32.54 k, 1 chunk 32.68 k, 2 chunks 33.15 k / 33.24 k, 3 chunks 32.27 k, 4 chunks 32.87 k
+//   C5 (ResNet50, 1024 frames per minibatch): packed 4.995 k, 1 chunk 5.003 k, 2 chunks 4.92 k, 3 chunks 4.74 k
+// Default (HAB_RNN_CHUNKS_RESNET unset or < 0): 2 chunks from 4096 frames per minibatch on, packed below; k >= 0 forces k chunks
+// (0 = packed).  HAB_RNN_CHUNKS = 0 / 1 still selects the packed form / one chunk for both policies.
+int tm_chunks_resnet_cfg(int frames) {
+    static const int v = hab_env_int("HAB_RNN_CHUNKS_RESNET", -1);
     const int base = tm_chunks_cfg();
-    return base <= 1 ? base : v;
+    if (base <= 1) return base;
+    if (v >= 0) return v;
+    return frames >= 4096 ? 2 : 0;
 }
 static int tm_setup(hab_policy* e, int nev) {
     if (!e->s2) {
@@ -465,7 +468,7 @@ extern "C" int hab_policy_evaluate(hab_policy* e, const hab_obs* obs, const int*
     const int T = B / n;
     // (ResNet policies too since round 4: their encoder runs per chunk behind a whole-batch ingest, engine_resnet.hip)
     int NC = (e->Cin > 0 && rows && !pack->env_first_frame && (B % n) == 0 && T >= 2 && e->w_ws2 >= 0 && (int64_t)L * 2 * n <= 3 * (int64_t)e->d.max_frames)
-                 ? (e->rn ? tm_chunks_resnet_cfg() : tm_chunks_cfg()) : 0;
+                 ? (e->rn ? tm_chunks_resnet_cfg(B) : tm_chunks_cfg()) : 0;
     if (NC > T) NC = T;
     const float* x = W + e->w_rnnin;
     int ldx = e->rnn_ld;

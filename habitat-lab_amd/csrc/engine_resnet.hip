@@ -361,7 +361,7 @@ int build_resnet(hab_policy* e) {
     // bits, must not depend on the stream), the dense per-frame episode-start mask, an iota
     // -- only when that form is selected (default for ResNet policies: packed; measured slower, engine.hip): every ResNet engine, incl. each
     // VER inference worker's private one, would otherwise carry 128 MB + 5 bytes per frame for nothing (w_ws2 < 0 keeps the packed form)
-    if (tm_chunks_resnet_cfg() > 0) {
+    if (tm_chunks_resnet_cfg((int)B) > 0) {  // (B = max_frames: the form this engine can ever select)
         e->ws2_floats = e->ws_floats;
         e->w_ws2 = wk.take(e->ws2_floats);
         e->w_fmask = wk.take((B + 3) / 4 + 64);
