@@ -10,7 +10,7 @@
 # Every profiler pass runs under `timeout`: a rocprofv3 --pmc pass of the C3 command once hung until gpurun's limit.
 # usage: tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>_*   (copy what is to be judged into profiles/)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
