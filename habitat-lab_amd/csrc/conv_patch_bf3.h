@@ -17,6 +17,7 @@
 // K - 1 - pad) share the kernel; weights and epilogues come from the problem functors, so bias / ReLU / residual-add / ReLU-mask
 // epilogues and the output row numbering are those of problems.h.
 #pragma once
+#include <atomic>
 #include "igemm_bf3.h"
 
 namespace hab {
@@ -65,9 +66,13 @@ __global__ void cpb_split_weights(const float* __restrict__ w, size_t n, unsigne
 // PRE: weights arrive as bf16 planes (cpb_split_weights) -- B staging is a copy.  Persistent workgroups: blockIdx -> tiles b, b + G, ...
 // (G a multiple of 8: a workgroup stays on its XCD's run of tiles); the NEXT tile's input patch is gathered into registers while
 // the current tile's MFMAs run.
+constexpr int CPB_DRAW_SLOTS = 64;
+__device__ unsigned cpb_draw_pool[CPB_DRAW_SLOTS * 16];
+
 template <class P, int TW, int WM, int WN, int TN, int BT, bool PRE>
 __global__ void __launch_bounds__(WM* WN * 64) conv_patch_bf3_kernel(const P p, const PatchGeom gq, const int sign_schedule,
-                                                                      const unsigned short* __restrict__ wplanes, const size_t wn_elems) {
+                                                                      const unsigned short* __restrict__ wplanes, const size_t wn_elems,
+                                                                      unsigned* __restrict__ dyn_ctr) {
     using Cfg = ConvPatchCfg<P, TW, WM, WN, TN, BT>;
     constexpr int NT = Cfg::NT, BN = Cfg::BN, BP = Cfg::BP, TH = Cfg::TH;
     constexpr int PU = (Cfg::MAX_PP * (CPB_CC / 4) + NT - 1) / NT;  // patch gather units per thread and chunk
@@ -197,8 +202,31 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_patch_bf3_kernel(const P p, 
         }
     };
 
-    int vb = blockIdx.x;
-    if (vb >= ntiles) return;
+    // Tile order.  Static: workgroup b walks b, b + G, ... .  Dynamic (dyn_ctr, launches with more tiles than workgroups): the workgroups of
+    // an XCD draw the next tile of THEIR XCD's run from a counter -- one that starts late or shares its CU (the persistent recurrence of
+    // the second stream holds 32 CUs for the length of a time chunk: conv3 forward 127 us alone, 194 us beside it with the static order)
+    // simply takes fewer tiles instead of holding the kernel's tail.  A tile's arithmetic does not depend on who computes it.
+    __shared__ int s_draw[2];
+    const bool dyn = dyn_ctr != nullptr;
+    const int xcd = blockIdx.x & 7;
+    const int run_len = (ntiles >> 3) + (xcd < (ntiles & 7) ? 1 : 0);
+    int vb = blockIdx.x, vb_next = blockIdx.x + gridDim.x, it = 0;
+    if (dyn) {
+        if (t == 0) { s_draw[0] = (int)atomicAdd(dyn_ctr + xcd, 1u); s_draw[1] = (int)atomicAdd(dyn_ctr + xcd, 1u); }
+        __syncthreads();
+        const int i0 = s_draw[0], i1 = s_draw[1];
+        __syncthreads();
+        vb = i0 < run_len ? i0 * 8 + xcd : ntiles;
+        vb_next = i1 < run_len ? i1 * 8 + xcd : ntiles;
+    }
+    // (dynamic order: the last workgroup to leave zeroes the counters for the next launch that is handed this slot)
+    auto leave = [&]() {
+        if (dyn && t == 0 && atomicAdd(dyn_ctr + 8, 1u) == gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) dyn_ctr[i] = 0u;
+        }
+    };
+    if (vb >= ntiles) { leave(); return; }
     fetch_patch(tile_of(vb) / gq.nt_n, 0);
     for (;;) {
         const int tile = tile_of(vb);
@@ -206,8 +234,10 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_patch_bf3_kernel(const P p, 
         const int n0 = tile_n * BN;
         const bool flip_all = sign_schedule && (((tile_m + tile_n) & 1) != 0);  // sign schedule (igemm_bf3.h)
         const unsigned sgn = flip_all ? 0x80000000u : 0u;
-        const int vb_next = vb + gridDim.x;
         const bool more = vb_next < ntiles;
+        // the draw for the tile after next: written now, read behind this tile's barriers (two slots: the other one is read at the
+        // end of the PREVIOUS tile, a full tile of barriers ago)
+        if (dyn && more && t == 0) s_draw[it & 1] = (int)atomicAdd(dyn_ctr + xcd, 1u);
 
         f32x16 acc[TN], acc2[TN], tot[TN];
 #pragma unroll
@@ -298,8 +328,11 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_patch_bf3_kernel(const P p, 
                 }
             }
         }
-        if (!more) break;
+        if (!more) { leave(); break; }
         vb = vb_next;
+        if (dyn) { const int i2 = s_draw[it & 1]; vb_next = i2 < run_len ? i2 * 8 + xcd : ntiles; }
+        else vb_next = vb + gridDim.x;
+        ++it;
     }
 }
 
@@ -326,6 +359,17 @@ inline int conv_patch_bf3_launch(const P& p, PatchGeom gq, float* ws, size_t ws_
     const size_t wn_elems = cpb_w_elems(p);
     const bool pre = ws && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0) && ws_floats * 4 >= wn_elems * 12 && p.M >= pre_min && (wn_elems % 4 == 0);
     hipError_t e = hipSuccess;
+    // dynamic tile order for persistent launches: 8 per-XCD counters + a leave counter from a small pool of device slots (zero at load, zeroed
+    // again by the last workgroup of the launch that used them -- no memset on the stream); launches in flight at once get different slots
+    static const bool dyn_on = !hab_env_flag("HAB_NO_DYN_TILES");
+    unsigned* ctr = nullptr;
+    if (dyn_on && grid < ntiles) {
+        static std::atomic<unsigned> next_slot{0};
+        static unsigned* pool = nullptr;
+        static const hipError_t sym_err = hipGetSymbolAddress(reinterpret_cast<void**>(&pool), HIP_SYMBOL(cpb_draw_pool));
+        if (sym_err != hipSuccess || !pool) return HAB_ERR_ARG;
+        ctr = pool + (size_t)(next_slot.fetch_add(1, std::memory_order_relaxed) % CPB_DRAW_SLOTS) * 16;
+    }
     if (pre) {
         auto kern = conv_patch_bf3_kernel<P, TW, WM, WN, TN, BT, true>;
         // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
@@ -334,13 +378,13 @@ inline int conv_patch_bf3_launch(const P& p, PatchGeom gq, float* ws, size_t ws_
         unsigned short* planes = reinterpret_cast<unsigned short*>(ws);
         cpb_split_weights<<<(unsigned)((wn_elems + 255) / 256), 256, 0, stream>>>(p.w, wn_elems, planes);
         HAB_LAUNCH_CHECK();
-        kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, gq, sign_schedule, planes, wn_elems);
+        kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, gq, sign_schedule, planes, wn_elems, ctr);
     } else {
         auto kern = conv_patch_bf3_kernel<P, TW, WM, WN, TN, BT, false>;
         // once per process and instantiation; thread-safe static initialisation (engines of several inference-worker threads launch concurrently)
         static const hipError_t attr_err = (Cfg::LDS_BYTES > 64 * 1024) ? hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES) : hipSuccess;
         if (attr_err != hipSuccess) return (int)attr_err;
-        kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, gq, sign_schedule, nullptr, 0);
+        kern<<<grid, Cfg::NT, Cfg::LDS_BYTES, stream>>>(p, gq, sign_schedule, nullptr, 0, ctr);
     }
     HAB_LAUNCH_CHECK();
     return HAB_OK;
