@@ -603,10 +603,14 @@ def main():
         if rnn:
             # the recurrence of a minibatch is a chain of dependent step launches (T forward + T backward per layer) on the second stream
             overlapped = {"sites": rnn, "summed_kernel_ms_per_cycle": round(sum(r["ms"] for r in rnn), 2),
-                          "serial_chain_launches_per_cycle": int(ppo.ppo_epoch * ppo.num_mini_batch * 2 * n_steps),
+                          # one persistent launch per layer, time chunk and direction (csrc/rnn_persist.h); one launch per step with HAB_RNN_PERSIST=0
+                          "serial_chain_launches_per_cycle": int(ppo.ppo_epoch * ppo.num_mini_batch * 2 *
+                                                                 (n_steps if os.environ.get("HAB_RNN_PERSIST") == "0" else site_chunks("rnn_fwd"))),
+                          "serial_steps_per_cycle": int(ppo.ppo_epoch * ppo.num_mini_batch * 2 * n_steps),
                           "note": "recurrent layers: time-major chunks on the engine's second stream underneath the encoder (forward) / the "
-                                  "data-gradient chain (backward); event pairs are per layer call, so `ms` is the wall time of the chained "
-                                  "launches beside the convolutions, not exclusive GPU time"}
+                                  "data-gradient chain (backward), each chunk ONE persistent launch (state exchange between its workgroups "
+                                  "per step instead of a launch per step); event pairs are per layer call incl. the chunk's input projection "
+                                  "/ data gradient, so `ms` is the wall time beside the convolutions, not exclusive GPU time"}
         crit = [r for r in table if not r["site"].startswith("rnn")]
         if auto_probe and crit:
             a.probe = crit[0]["site"]

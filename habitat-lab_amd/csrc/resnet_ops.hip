@@ -616,6 +616,12 @@ __global__ void __launch_bounds__(NT) groupnorm_bwd_reg_kernel(const GnBwdArgs a
 // `frames` (a 32-frame rollout batch used 32 of 256 CUs).  Backward: kernel 1 = per-channel partial sums, kernel 2 = dx.
 // ------------------------------------------------------------------------------------------------------
 constexpr int GNC_NT = 256, GNC_NV_F = 16, GNC_NV_B = 8;
+// backward: a workgroup walks GNC_REPS_B consecutive sub-chunks of GNC_NT * GNC_NV_B float4 (round 6).  Both backward kernels are
+// memory-latency-bound (SQ_WAIT_ANY 0.64 / 0.77 of wave cycles, profiles/r06_c3_sq_counters.txt) and every workgroup starts with a serial
+// prologue -- merging the frame's partial sums (dx kernel), two LDS column reductions (sums kernel); with 2048 float4 per workgroup the
+// stem's backward launched 65 536 workgroups per pass.
+constexpr int GNC_REPS_B = 4;
+static int gnc_reps_b() { static const int v = std::max(1, hab_env_int("HAB_GN_REPS", GNC_REPS_B)); return v; }
 
 template <int NT, int NV>
 __global__ void __launch_bounds__(NT) gn_chunk_stats_kernel(const GnArgs a, int nchunks, float* __restrict__ part) {
@@ -854,12 +860,11 @@ __device__ __forceinline__ f32x4 gn_pool_dy(const GnBwdArgs& a, int f, int pix, 
 
 // backward, kernel 1: per-channel partial sums S1 = sum dy', S2 = sum dy' * xhat of the chunk (+ optional dy' write-out)
 template <int NT, int NV>
-__global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a, int nchunks, float* __restrict__ part) {
+__global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a, int nchunks, float* __restrict__ part, const int reps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
     const int F4 = a.HW * C4;
     const int f = blockIdx.x / nchunks, ck = blockIdx.x % nchunks, t = threadIdx.x, col = t & (C4 - 1);
-    const int base = ck * NT * NV;
     float* red = sm;
     float* c1 = sm + NT * 4;
     const size_t fb = (size_t)f * a.HW * C;
@@ -876,6 +881,9 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a
         for (int k = 0; k < 4; ++k) { psc[k] = rs[k] * a.gamma[col * 4 + k]; psh[k] = a.beta[col * 4 + k] - mu[k] * psc[k]; }
     }
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int rep = 0; rep < reps; ++rep) {
+    const int base = (ck * reps + rep) * NT * NV;
+    if (base >= F4) break;
     f32x4 xv[NV], dv[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -911,6 +919,7 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a
         s1 += dv[j];
         s2 += dv[j] * xh;
     }
+    }
     float* o = part + (size_t)blockIdx.x * 2 * C;
     gn_col_reduce<NT>(s1, C4, red, c1, C, t);
     for (int c = t; c < C; c += NT) o[c] = c1[c];
@@ -920,12 +929,11 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a
 
 // backward, kernel 2: merge the partial sums of the frame (fixed order), then dx for the chunk
 template <int NT, int NV>
-__global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, int nchunks, const float* __restrict__ part) {
+__global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, int nchunks, const float* __restrict__ part, const int reps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = a.C, G = a.groups, cpg = C / G, C4 = C >> 2;
     const int F4 = a.HW * C4;
     const int f = blockIdx.x / nchunks, ck = blockIdx.x % nchunks, t = threadIdx.x, col = t & (C4 - 1);
-    const int base = ck * NT * NV;
     float* c1 = sm;          // [C]
     float* c2 = sm + C;      // [C]
     float* g1 = c2 + C;      // [G]
@@ -961,6 +969,9 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, 
     const f32x4* dy4 = pooled ? nullptr : reinterpret_cast<const f32x4*>((a.dy_masked ? a.dy_masked : a.dy) + fb);
     const f32x4* ro4 = (a.relu_out && !a.dy_masked && !pooled) ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
     f32x4* dx4 = reinterpret_cast<f32x4*>(a.dx + fb);
+    for (int rep = 0; rep < reps; ++rep) {
+    const int base = (ck * reps + rep) * NT * NV;
+    if (base >= F4) break;
     f32x4 xv[NV], dv[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -995,6 +1006,7 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, 
         const int i = base + t + j * NT;
         const f32x4 xh = (xv[j] - mu) * rs;
         if (i < F4) dx4[i] = rs * (dv[j] * ga - m1 - xh * m2);
+    }
     }
 }
 
@@ -1106,7 +1118,7 @@ bool groupnorm_pool_fusable(int B, int HW, int C, int groups, size_t scratch_flo
     int nt, nv, n1, n2;
     if (gn_check(B, C, groups) != HAB_OK || gn_reg_cfg(HW, C, nt, nv)) return false;
     return gn_chunk_cfg(B, HW, C, (size_t)groups * 2, scratch_floats, GNC_NT * GNC_NV_F, n1) &&
-           gn_chunk_cfg(B, HW, C, (size_t)C * 2, scratch_floats, GNC_NT * GNC_NV_B, n2);
+           gn_chunk_cfg(B, HW, C, (size_t)C * 2, scratch_floats, GNC_NT * GNC_NV_B * gnc_reps_b(), n2);
 }
 int groupnorm_relu_materialize(const GnArgs& a, hipStream_t s) {
     if (!a.x || !a.y || !a.gamma || !a.beta || !a.mean || !a.rstd || a.B <= 0 || (a.C & 3) || a.C % a.groups) return HAB_ERR_ARG;
@@ -1215,13 +1227,13 @@ int groupnorm_backward(const GnBwdArgs& a, hipStream_t s) {
         return HAB_OK;
     }
     int nchunks;
-    if (a.scratch && gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.C * 2, a.scratch_floats, GNC_NT * GNC_NV_B, nchunks)) {
+    if (a.scratch && gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.C * 2, a.scratch_floats, GNC_NT * GNC_NV_B * gnc_reps_b(), nchunks)) {
         const size_t lds1 = (size_t)(GNC_NT * 4 + a.C) * sizeof(float);
         if (a.pool_dy && (!a.pool_idx || !a.beta || a.pH * a.pW != a.HW)) return HAB_ERR_ARG;
-        gn_chunk_bwd_sums_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds1, s>>>(a, nchunks, a.scratch);
+        gn_chunk_bwd_sums_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds1, s>>>(a, nchunks, a.scratch, gnc_reps_b());
         HAB_LAUNCH_CHECK();
         const size_t lds2 = (size_t)(2 * a.C + 2 * a.groups) * sizeof(float);
-        gn_chunk_bwd_dx_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds2, s>>>(a, nchunks, a.scratch);
+        gn_chunk_bwd_dx_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds2, s>>>(a, nchunks, a.scratch, gnc_reps_b());
         HAB_LAUNCH_CHECK();
         return HAB_OK;
     }
