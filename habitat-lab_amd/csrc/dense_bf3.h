@@ -89,6 +89,12 @@ __global__ void __launch_bounds__(DN_NT) dense_bf3_kernel(const DenseArgs g) {
     const int ntk = kt1 - kt0;
     const bool flip = g.sign_schedule && (((tile_m + tile_n + kz) & 1) != 0);
     const unsigned sgn = flip ? 0x80000000u : 0u;
+    // Flatten permutation written by this kernel (no split-K): the tile's 128 columns are 8 consecutive hw x 16 channels (local column
+    // c = hw_l * 16 + cc_l  <->  n = (8 (tile_n / 2) + hw_l) * 32 + 16 (tile_n % 2) + cc_l) instead of 4 hw x 32 channels, so that the 8 hw of a
+    // channel leave as ONE full 32-byte sector of the output row (with 4 hw per tile every sector reached HBM twice, half-filled: 112 MB
+    // written for the 51 MB of SimpleCNN's fc gradient, profiles/r06_c2_hbm_traffic.txt).  The operand is still read 64 contiguous bytes
+    // per hw; the other half of each 128-byte line belongs to the neighbouring tile of the same XCD.
+    const bool ptile = B_IC && g.perm_c > 0 && g.nsplit <= 1 && (g.perm_hw & 7) == 0;
 
     // ---- staging maps (everything per-thread is computed ONCE: on this chip VALU instructions and bf16 MFMAs of the two waves of a SIMD do
     // not overlap -- tools/ubench/bf16mfma_overlap.hip, profiles/r06_bf16mfma_overlap.txt: a wave's VALU stream waits out the other
@@ -119,7 +125,8 @@ __global__ void __launch_bounds__(DN_NT) dense_bf3_kernel(const DenseArgs g) {
 #pragma unroll
     for (int j = 0; j < BU; ++j) {
         if constexpr (B_IC) {
-            const int rq = t & 31, k = (t >> 5) + 16 * j, n = n0 + 4 * rq;
+            const int rq = t & 31, k = (t >> 5) + 16 * j;
+            const int n = ptile ? (8 * (tile_n >> 1) + (rq >> 2)) * 32 + (tile_n & 1) * 16 + 4 * (rq & 3) : n0 + 4 * rq;
             bvoff[j] = n < g.N ? (unsigned)(((size_t)(kt0 * DN_BK + k) * g.ldb + n) * 4) : OOB;
             boff[j] = (rq >> 3) * DN_IC_BLOCK + k * 64 + (rq & 7) * 8;
         } else {
@@ -278,6 +285,20 @@ __global__ void __launch_bounds__(DN_NT) dense_bf3_kernel(const DenseArgs g) {
     const bool split = g.nsplit > 1;
     float* cbase = split ? g.partial + (size_t)kz * g.M * g.N : g.c;
     const long long ldc = split ? g.N : g.ldc;
+    if (ptile) {
+        const int ccl = t & 15, half = (t >> 4) & 1, hw0 = 8 * (tile_n >> 1) + 4 * half, cc = (tile_n & 1) * 16 + ccl;
+        for (int row = t >> 5; row < DN_BM; row += DN_NT / 32) {
+            const int m = m0 + row;
+            if (m >= g.M) break;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = T[row * DN_EPI_LD + (half * 4 + e) * 16 + ccl];
+            float* dst = cbase + (size_t)m * ldc + (size_t)cc * g.perm_hw + hw0;
+            if (g.accumulate) { const f32x4 o = *reinterpret_cast<const f32x4*>(dst); v += o; }
+            *reinterpret_cast<f32x4*>(dst) = v;
+        }
+        return;
+    }
     if (!split && g.perm_c > 0) {
         // n = n0 + hw_l * 32 + cc (perm_c == 32, n0 % 128 == 0): 4 consecutive hw of channel cc are 16 contiguous bytes of the output row
         const int cc = t & 31, hw0 = n0 >> 5;

@@ -369,7 +369,10 @@ def test_linear_family(L, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,perm", [(512, 512, 3136, True), (300, 384, 1024, False), (256, 128, 256, False), (1100, 260, 608, False),
-                                         (640, 2048, 576, False)])
+                                         (640, 2048, 576, False),
+                                         # >= 128 output tiles: the weight gradient runs without split-K and writes the permutation itself
+                                         # (8 hw x 16 channel tile columns, full 32-byte sectors)
+                                         (512, 512, 8192, True)])
 def test_dense_gemm_kernel_vs_float64(L, M, N, K, perm):
     """csrc/dense_bf3.h (matrix-path bits 10 + 11: every applicable shape) through hab_linear_fwd / _dgrad / _wgrad against float64:
     bias + ReLU and split-K slabs (forward), a k-strided weight operand (data gradient), two k-strided operands + the NHWC-flatten ->
