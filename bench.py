@@ -154,7 +154,7 @@ def site_chunks(site):
     return chunks if (site.endswith("_fwd") or site.endswith("_dgrad")) else 1
 
 
-def make_trainer(workload: str, total_updates: int, envs: int = 0, steps: int = 0):
+def make_trainer(workload: str, total_updates: int, envs: int = 0, steps: int = 0, extra_overrides=()):
     from habitat_amd.config.default import get_config
     import habitat_amd.rl.ppo.ppo_trainer as tr
     w = WORKLOADS[workload]
@@ -167,7 +167,7 @@ def make_trainer(workload: str, total_updates: int, envs: int = 0, steps: int = 
                                  "habitat_baselines.checkpoint_folder=/tmp/habitat_amd_bench_ckpt",
                                  f"habitat.simulator.sensors.rgb.height={OBS}", f"habitat.simulator.sensors.rgb.width={OBS}",
                                  f"habitat.simulator.sensors.depth.height={OBS}", f"habitat.simulator.sensors.depth.width={OBS}"] + w["overrides"]
-                     + [o for o in os.environ.get("HAB_BENCH_OVERRIDES", "").split(",") if o])  # development hook
+                     + list(extra_overrides) + [o for o in os.environ.get("HAB_BENCH_OVERRIDES", "").split(",") if o])  # development hook
     trainer = tr.PPOTrainer(cfg)
     return trainer, cfg
 
@@ -429,7 +429,10 @@ def run_cycles(workload, steps, warmup, keep_state=None, distributed=False, keep
     """A second workload inside the same run (sub-record): (env-steps/s, ms per cycle).  keep_state: dict that receives a CPU copy of
     the policy's state_dict as the cycles left it (the c3 parity leg starts from it)."""
     import torch
-    trainer, cfg = make_trainer(workload, warmup + steps + 1)
+    # keep_flat (the exchange A/B): both trainers must collect IDENTICAL rollouts, so DD-PPO's preemptive straggler rule (a rank ends its
+    # rollout early once sync_frac of the ranks are done: timing-dependent) is switched off for these runs (sync_frac > 1 never triggers)
+    trainer, cfg = make_trainer(workload, warmup + steps + 1,
+                                extra_overrides=["habitat_baselines.rl.ddppo.sync_frac=2.0"] if keep_flat is not None else ())
     trainer._init_train()
     rollout_ms = time_rollouts(trainer)
     def sync():
@@ -694,7 +697,8 @@ def main():
         exchange_ab["bit_identical"] = bool(same.item())
         exchange_ab["native_ran"] = exchange_ab.get("rccl-native", {}).get("exchange_that_ran") == "rccl-native"
         exchange_ab["how"] = ("two fresh DD-PPO trainers of the headline workload from the same seeds, 1 warm-up + 3 timed cycles each, barrier + "
-                              "max-over-ranks timing; bit_identical = parameter arenas equal on EVERY rank (MIN over ranks)")
+                              "max-over-ranks timing, preemptive straggler rule off (sync_frac = 2: identical rollouts); bit_identical = parameter arenas "
+                              "equal on EVERY rank (MIN over ranks)")
         del flats
     if rank != 0:
         torch.distributed.destroy_process_group()
