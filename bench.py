@@ -695,6 +695,13 @@ def main():
                                    and torch.equal(flats["torch-callbacks"], flats["rccl-native"])) else 0], device="cuda")
         torch.distributed.all_reduce(same, op=torch.distributed.ReduceOp.MIN)
         exchange_ab["bit_identical"] = bool(same.item())
+        # how far apart, should the two differ (RCCL may pick another algorithm / channel count for the second communicator: a different
+        # summation order is rounding noise, a wrong segment is not)
+        diff = torch.tensor([float("inf")], device="cuda")
+        if len(flats) == 2 and all(v is not None for v in flats.values()):
+            diff = (flats["torch-callbacks"].double() - flats["rccl-native"].double()).abs().max().reshape(1).float()
+        torch.distributed.all_reduce(diff, op=torch.distributed.ReduceOp.MAX)
+        exchange_ab["param_max_abs_diff"] = float(diff.item())
         exchange_ab["native_ran"] = exchange_ab.get("rccl-native", {}).get("exchange_that_ran") == "rccl-native"
         exchange_ab["how"] = ("two fresh DD-PPO trainers of the headline workload from the same seeds, 1 warm-up + 3 timed cycles each, barrier + "
                               "max-over-ranks timing, preemptive straggler rule off (sync_frac = 2: identical rollouts); bit_identical = parameter arenas "

@@ -253,7 +253,7 @@ def test_bench_py_launches_two_ranks_and_reports_whole_job_rate():
     # both gradient exchanges in one run: on a gloo group the native RCCL communicator is not wanted, so the second
     # trainer runs the callbacks as well -- two trainers from the same seeds must then end on bit-identical parameter arenas on both ranks
     ab = out["exchange_ab"]
-    assert ab["bit_identical"] is True and ab["native_ran"] is False, ab
+    assert ab["bit_identical"] is True and ab["native_ran"] is False and ab["param_max_abs_diff"] == 0.0, ab
     for k in ("torch-callbacks", "rccl-native"):
         assert ab[k]["exchange_that_ran"] == "torch-callbacks" and ab[k]["value"] > 0 and ab[k]["steps"] == 3, ab
 
