@@ -49,7 +49,7 @@ def case(kind, M, N, K, reps, perm=False):
     dy = torch.randn(M, N, device="cuda", generator=g)
     ws = torch.zeros(1 << 26, device="cuda")
     out = {}
-    for mode_name, mode in (("igemm", 1023), ("dense", 2047)):
+    for mode_name, mode in (("igemm", 1023), ("dense", 4095 if "--force" in sys.argv else 2047)):
         L.hab_set_matrix_path(mode)
         if kind == "fwd":
             y = torch.zeros(M, N, device="cuda")
@@ -84,6 +84,14 @@ def case(kind, M, N, K, reps, perm=False):
 if __name__ == "__main__":
     quick = "--quick" in sys.argv
     reps = 5 if quick else 20
+    if "--rnn" in sys.argv:  # the recurrent layer's projections and weight gradients at C2's minibatch (2048 rows; GRU 512, input 576)
+        for kk in (512, 576):
+            case("wgrad", 2048, 1536, kk, reps)
+        case("dgrad", 2048, 1536, 576, reps)
+        case("fwd", 512, 1536, 576, reps)
+        case("fwd", 2048, 1536, 576, reps)
+        case("wgrad", 4096, 2048, 512, reps)
+        sys.exit(0)
     case("fwd", 512, 512, 25088, reps)
     case("dgrad", 512, 512, 25088, reps)
     case("wgrad", 2048, 512, 25088, reps, perm=True)
