@@ -659,7 +659,7 @@ int rnn_tm_layer_forward(int rnn_type, int H, const RnnLayerParams& lp, const Rn
         a.gates = wk.gates; a.hn = wk.hn; a.hprev = wk.hprev; a.cprev = wk.cprev; a.c = wk.c; a.out = wk.out;
         a.counters = reinterpret_cast<rnnp_u64*>(ws);
         if (hipMemsetAsync(ws, 0, 16 * sizeof(rnnp_u64), stream) != hipSuccess) return HAB_ERR_ARG;
-        const dim3 grid(cdiv(n, 16), H / 16);
+        const dim3 grid(H / 16, cdiv(n, 16));  // row tile = slow dimension: rnn_persist.h (residency)
         const int kch = H / 128;
         if (rnn_type == RNN_GRU) {
             if (kch == 4) rnn_tm_persist_fwd_kernel<3, 4><<<grid, 512, 0, stream>>>(a);
@@ -713,7 +713,7 @@ int rnn_tm_layer_backward(int rnn_type, int H, const RnnLayerParams& lp, const R
         a.gates = wk.gates; a.hn = wk.hn; a.hprev = wk.hprev; a.cprev = wk.cprev; a.c = wk.c; a.dgi = wk.dgi; a.dgh = dgh;
         a.counters = reinterpret_cast<rnnp_u64*>(ws);
         if (hipMemsetAsync(ws, 0, 16 * sizeof(rnnp_u64), stream) != hipSuccess) return HAB_ERR_ARG;
-        const dim3 grid(cdiv(n, 16), H / 16);
+        const dim3 grid(H / 16, cdiv(n, 16));  // row tile = slow dimension: rnn_persist.h (residency)
         const int kch = H / 128;
         if (rnn_type == RNN_GRU) {
             if (kch == 4) rnn_tm_persist_bwd_kernel<3, 12><<<grid, 512, 0, stream>>>(a);

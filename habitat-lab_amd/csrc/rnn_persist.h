@@ -14,8 +14,13 @@
 //   * everything that does not depend on the recurrence (input projection, saved gates, masks) is loaded BEFORE the wait on the counter.
 // Arithmetic, K order per wave and the cross-wave summation order are exactly rnn_step_kernel's / rnn_bwd_step_kernel's: results are
 // bit-identical to the per-step launches (tests/test_gpu_rnn_persist.py), so every parity figure of the step kernels carries over.
-// Spins are bounded (RNNP_SPIN_LIMIT polls, seconds): a workgroup that gives up leaves its outputs unfinished and raises the error word
-// behind the counters instead of hanging the device.
+// Residency: the H / 16 workgroups of a row tile wait for each other, so they must be resident together.  The row tile is the SLOW grid
+// dimension: workgroups are dispatched in linear order, so every row tile that has a workgroup on the chip has all of its earlier
+// workgroups there too, and the first incomplete row tile is completed by the very next free slots -- a launch larger than the chip
+// (LSTM, H = 512: 154 registers = one workgroup per CU = 256 at a time; 15 row tiles are 480) runs its row tiles in rounds instead of
+// dead-locking on half-resident ones (with the row tile as the fast dimension it would: every tile gets its first units, none its last).
+// Spins are bounded all the same (RNNP_SPIN_LIMIT polls, seconds): a workgroup that gives up raises the error word behind the counters and
+// traps -- the launch fails at the next synchronisation instead of hanging the device or returning unfinished outputs.
 #pragma once
 #include "ops.h"
 #include "bf3_split.h"  // u32x4
@@ -42,19 +47,22 @@ __device__ __forceinline__ bool rnnp_wait(rnnp_u64* ctr, rnnp_u64 target, rnnp_u
     unsigned spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > RNNP_SPIN_LIMIT) { __hip_atomic_store(err, (rnnp_u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        if (++spins > RNNP_SPIN_LIMIT) {  // cannot happen with in-order dispatch (see the header); if it does, fail the launch loudly
+            __hip_atomic_store(err, (rnnp_u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_trap();
+        }
     }
     return true;
 }
 
-// Forward.  grid = (row tiles, H / 16), 512 threads.  KCH = (H / 8) / 16 K-chunks per wave (H = 128 KCH).
+// Forward.  grid = (H / 16, row tiles), 512 threads.  KCH = (H / 8) / 16 K-chunks per wave (H = 128 KCH).
 template <int G, int KCH>
 __global__ void __launch_bounds__(512) rnn_tm_persist_fwd_kernel(const TmPersistFwdArgs a) {
     constexpr int NW = 8;
     __shared__ float red[NW][G][256];
     __shared__ int s_ok;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int rt = blockIdx.x, row0 = rt * 16, u0 = blockIdx.y * 16;
+    const int rt = blockIdx.y, row0 = rt * 16, u0 = blockIdx.x * 16;
     const int i = lane & 15, kg = lane >> 4;
     const int H = a.H, n = a.n;
     const int tiles = H / 16;
@@ -189,7 +197,7 @@ __global__ void __launch_bounds__(512) rnn_tm_persist_bwd_kernel(const TmPersist
     __shared__ float red[NW][256];
     __shared__ int s_ok;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int rt = blockIdx.x, row0 = rt * 16, u0 = blockIdx.y * 16;
+    const int rt = blockIdx.y, row0 = rt * 16, u0 = blockIdx.x * 16;
     const int i = lane & 15, kg = lane >> 4;
     const int H = a.H, n = a.n, K = G * H;
     const int tiles = H / 16;

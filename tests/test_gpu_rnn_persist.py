@@ -39,6 +39,7 @@ def run_engine(eng, inputs, T, n, hidden, Lh):
     ("LSTM", 1, 256, 10, 20, 0.25),
     ("LSTM", 2, 512, 8, 16, 0.15),    # two layers, layer by layer
     ("GRU", 2, 256, 6, 3, 1.0),       # every frame starts an episode
+    ("LSTM", 1, 512, 6, 240, 0.1),    # 15 row tiles x 32 = 480 workgroups of a kernel that fits once per CU: row tiles run in rounds
 ])
 def test_persistent_recurrence_bit_identical_to_step_launches(rnn_type, layers, hidden, T, n, p_start):
     from habitat_amd import _lib
