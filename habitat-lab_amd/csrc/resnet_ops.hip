@@ -833,25 +833,36 @@ __global__ void __launch_bounds__(256) gn_relu_from_stats_kernel(const GnArgs a)
 
 // Gradient reaching pixel `pix` of the (never stored) stem output through ReLU + MaxPool2d(3, 2, 1): the sum over the <= 4 pooling
 // windows that contain the pixel and chose it (maxpool_bwd_kernel's gather, same order), masked by relu'(y), y recomputed from x.
-__device__ __forceinline__ f32x4 gn_pool_dy(const GnBwdArgs& a, int f, int pix, int c4, const f32x4 xv, const f32x4 sc, const f32x4 sh) {
+__device__ __forceinline__ f32x4 gn_pool_dy(const GnBwdArgs& a, int f, int h, int w, int c4, const f32x4 xv, const f32x4 sc, const f32x4 sh) {
     const int H = a.pH, W = a.pW, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const int h = pix / W, w = pix - h * W;
+    // The candidate windows are (h / 2, (h + 1) / 2) x (w / 2, (w + 1) / 2): one per axis for even coordinates, two for odd ones.  All four
+    // (index word, gradient) pairs are fetched up front from clamped coordinates -- eight independent loads instead of a data-dependent
+    // loop nest whose loads wait for each other -- and folded in the loop nest's order, so the sum is bit-identical to maxpool_bwd_kernel's.
+    const int ho0 = h >> 1, ho1 = (h + 1) >> 1, wo0 = w >> 1, wo1 = (w + 1) >> 1;
+    const bool vh[2] = {ho0 < Ho, ho1 != ho0 && ho1 < Ho}, vw[2] = {wo0 < Wo, wo1 != wo0 && wo1 < Wo};
+    const int hh[2] = {min(ho0, Ho - 1), min(ho1, Ho - 1)}, ww[2] = {min(wo0, Wo - 1), min(wo1, Wo - 1)};
+    uint32_t id[2][2];
+    f32x4 d[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const size_t o = (((size_t)f * Ho + hh[p]) * Wo + ww[q]) * a.C + c4 * 4;
+            id[p][q] = *reinterpret_cast<const uint32_t*>(a.pool_idx + o);
+            d[p][q] = *reinterpret_cast<const f32x4*>(a.pool_dy + o);
+        }
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
-        if (ho >= Ho) continue;
-        const int kh = h - (ho * 2 - 1);
-        for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
-            if (wo >= Wo) continue;
-            const int kw = w - (wo * 2 - 1);
-            const size_t o = (((size_t)f * Ho + ho) * Wo + wo) * a.C + c4 * 4;
-            const uint32_t id = *reinterpret_cast<const uint32_t*>(a.pool_idx + o);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(a.pool_dy + o);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kh = h - ((p ? ho1 : ho0) * 2 - 1), kw = w - ((q ? wo1 : wo0) * 2 - 1);
             const uint32_t me = (uint32_t)(kh * 3 + kw);
+            const bool ok = vh[p] && vw[q];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (((id >> (8 * k)) & 0xffu) == me) s[k] += d[k];
+                if (ok && ((id[p][q] >> (8 * k)) & 0xffu) == me) s[k] += d[p][q][k];
         }
-    }
     const f32x4 y = gn_affine4(xv, sc, sh);
 #pragma unroll
     for (int k = 0; k < 4; ++k) s[k] = y[k] > 0.f ? s[k] : 0.f;
@@ -870,6 +881,8 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a
     const size_t fb = (size_t)f * a.HW * C;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + fb);
     const bool pooled = a.pool_dy != nullptr;
+    const int c4_shift = __builtin_ctz(C4), pstep = NT >> c4_shift;           // pooled form: pixels between two units of a thread
+    const int step_h = pooled ? pstep / a.pW : 0, step_w = pooled ? pstep - step_h * a.pW : 0;
     const f32x4* dy4 = pooled ? nullptr : reinterpret_cast<const f32x4*>(a.dy + fb);
     const f32x4* ro4 = (a.relu_out && !pooled) ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
     f32x4* dym4 = a.dy_masked ? reinterpret_cast<f32x4*>(a.dy_masked + fb) : nullptr;
@@ -893,10 +906,16 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a
         if (!pooled) dv[j] = ok ? dy4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (pooled) {
+        // pixel of unit j: (base + t) / C4 + j * (NT / C4); C4 is a power of two (gn_chunk_cfg), the row / column walk forward by a
+        // workgroup-uniform step -- one division per chunk instead of two per element
+        int ph, pw;
+        { const int pix0 = (base + t) >> c4_shift; ph = pix0 / a.pW; pw = pix0 - ph * a.pW; }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = base + t + j * NT;
-            dv[j] = i < F4 ? gn_pool_dy(a, f, i / C4, col, xv[j], psc, psh) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[j] = i < F4 ? gn_pool_dy(a, f, ph, pw, col, xv[j], psc, psh) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ph += step_h; pw += step_w;
+            if (pw >= a.pW) { pw -= a.pW; ++ph; }
         }
     }
     if (ro4) {
@@ -966,6 +985,8 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, 
     const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + fb);
     // the masked gradient was written out by kernel 1 when the caller wanted it: read that instead of dy + relu_out
     const bool pooled = a.pool_dy != nullptr && !a.dy_masked;
+    const int c4_shift = __builtin_ctz(C4), pstep = NT >> c4_shift;
+    const int step_h = pooled ? pstep / a.pW : 0, step_w = pooled ? pstep - step_h * a.pW : 0;
     const f32x4* dy4 = pooled ? nullptr : reinterpret_cast<const f32x4*>((a.dy_masked ? a.dy_masked : a.dy) + fb);
     const f32x4* ro4 = (a.relu_out && !a.dy_masked && !pooled) ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
     f32x4* dx4 = reinterpret_cast<f32x4*>(a.dx + fb);
@@ -984,10 +1005,14 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, 
         f32x4 psc, psh;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { psc[k] = rs[k] * ga[k]; psh[k] = a.beta[col * 4 + k] - mu[k] * psc[k]; }
+        int ph, pw;
+        { const int pix0 = (base + t) >> c4_shift; ph = pix0 / a.pW; pw = pix0 - ph * a.pW; }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = base + t + j * NT;
-            dv[j] = i < F4 ? gn_pool_dy(a, f, i / C4, col, xv[j], psc, psh) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[j] = i < F4 ? gn_pool_dy(a, f, ph, pw, col, xv[j], psc, psh) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ph += step_h; pw += step_w;
+            if (pw >= a.pW) { pw -= a.pW; ++ph; }
         }
     }
     if (ro4) {
@@ -1118,7 +1143,7 @@ bool groupnorm_pool_fusable(int B, int HW, int C, int groups, size_t scratch_flo
     int nt, nv, n1, n2;
     if (gn_check(B, C, groups) != HAB_OK || gn_reg_cfg(HW, C, nt, nv)) return false;
     return gn_chunk_cfg(B, HW, C, (size_t)groups * 2, scratch_floats, GNC_NT * GNC_NV_F, n1) &&
-           gn_chunk_cfg(B, HW, C, (size_t)C * 2, scratch_floats, GNC_NT * GNC_NV_B * gnc_reps_b(), n2);
+           gn_chunk_cfg(B, HW, C, (size_t)C * 2, scratch_floats, GNC_NT * GNC_NV_B, n2);  // (the stem form's backward: one sub-chunk)
 }
 int groupnorm_relu_materialize(const GnArgs& a, hipStream_t s) {
     if (!a.x || !a.y || !a.gamma || !a.beta || !a.mean || !a.rstd || a.B <= 0 || (a.C & 3) || a.C % a.groups) return HAB_ERR_ARG;
@@ -1227,13 +1252,16 @@ int groupnorm_backward(const GnBwdArgs& a, hipStream_t s) {
         return HAB_OK;
     }
     int nchunks;
-    if (a.scratch && gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.C * 2, a.scratch_floats, GNC_NT * GNC_NV_B * gnc_reps_b(), nchunks)) {
+    // sub-chunks per workgroup: the stem form (gathers through the pooling windows per element) measured SLOWER with them (its statistics
+    // kernel 1.22 -> 1.79 ms per 4096 frames: profiles r06, commits 075041b vs b3f3464), the plain form faster (NOTEBOOK R6.8)
+    const int reps = a.pool_dy ? 1 : gnc_reps_b();
+    if (a.scratch && gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.C * 2, a.scratch_floats, GNC_NT * GNC_NV_B * reps, nchunks)) {
         const size_t lds1 = (size_t)(GNC_NT * 4 + a.C) * sizeof(float);
         if (a.pool_dy && (!a.pool_idx || !a.beta || a.pH * a.pW != a.HW)) return HAB_ERR_ARG;
-        gn_chunk_bwd_sums_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds1, s>>>(a, nchunks, a.scratch, gnc_reps_b());
+        gn_chunk_bwd_sums_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds1, s>>>(a, nchunks, a.scratch, reps);
         HAB_LAUNCH_CHECK();
         const size_t lds2 = (size_t)(2 * a.C + 2 * a.groups) * sizeof(float);
-        gn_chunk_bwd_dx_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds2, s>>>(a, nchunks, a.scratch, gnc_reps_b());
+        gn_chunk_bwd_dx_kernel<GNC_NT, GNC_NV_B><<<a.B * nchunks, GNC_NT, lds2, s>>>(a, nchunks, a.scratch, reps);
         HAB_LAUNCH_CHECK();
         return HAB_OK;
     }
