@@ -833,7 +833,9 @@ __global__ void __launch_bounds__(256) gn_relu_from_stats_kernel(const GnArgs a)
 
 // Gradient reaching pixel `pix` of the (never stored) stem output through ReLU + MaxPool2d(3, 2, 1): the sum over the <= 4 pooling
 // windows that contain the pixel and chose it (maxpool_bwd_kernel's gather, same order), masked by relu'(y), y recomputed from x.
-__device__ __forceinline__ f32x4 gn_pool_dy(const GnBwdArgs& a, int f, int h, int w, int c4, const f32x4 xv, const f32x4 sc, const f32x4 sh) {
+// (pidx_f / pdy_f: the frame's slices of pool_idx / pool_dy -- the element offsets below are 32-bit)
+__device__ __forceinline__ f32x4 gn_pool_dy(const GnBwdArgs& a, const uint8_t* __restrict__ pidx_f, const float* __restrict__ pdy_f, int h, int w,
+                                            int c4, const f32x4 xv, const f32x4 sc, const f32x4 sh) {
     const int H = a.pH, W = a.pW, Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     // The candidate windows are (h / 2, (h + 1) / 2) x (w / 2, (w + 1) / 2): one per axis for even coordinates, two for odd ones.  All four
     // (index word, gradient) pairs are fetched up front from clamped coordinates -- eight independent loads instead of a data-dependent
@@ -847,9 +849,9 @@ __device__ __forceinline__ f32x4 gn_pool_dy(const GnBwdArgs& a, int f, int h, in
     for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const size_t o = (((size_t)f * Ho + hh[p]) * Wo + ww[q]) * a.C + c4 * 4;
-            id[p][q] = *reinterpret_cast<const uint32_t*>(a.pool_idx + o);
-            d[p][q] = *reinterpret_cast<const f32x4*>(a.pool_dy + o);
+            const int o = (hh[p] * Wo + ww[q]) * a.C + c4 * 4;
+            id[p][q] = *reinterpret_cast<const uint32_t*>(pidx_f + o);
+            d[p][q] = *reinterpret_cast<const f32x4*>(pdy_f + o);
         }
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -883,6 +885,9 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a
     const bool pooled = a.pool_dy != nullptr;
     const int c4_shift = __builtin_ctz(C4), pstep = NT >> c4_shift;           // pooled form: pixels between two units of a thread
     const int step_h = pooled ? pstep / a.pW : 0, step_w = pooled ? pstep - step_h * a.pW : 0;
+    const size_t pool_f = pooled ? (size_t)f * ((a.pH + 1) / 2) * ((a.pW + 1) / 2) * C : 0;   // MaxPool2d(3, 2, 1): Ho = (H + 1) / 2
+    const uint8_t* pidx_f = pooled ? a.pool_idx + pool_f : nullptr;
+    const float* pdy_f = pooled ? a.pool_dy + pool_f : nullptr;
     const f32x4* dy4 = pooled ? nullptr : reinterpret_cast<const f32x4*>(a.dy + fb);
     const f32x4* ro4 = (a.relu_out && !pooled) ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
     f32x4* dym4 = a.dy_masked ? reinterpret_cast<f32x4*>(a.dy_masked + fb) : nullptr;
@@ -913,7 +918,7 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_sums_kernel(const GnBwdArgs a
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = base + t + j * NT;
-            dv[j] = i < F4 ? gn_pool_dy(a, f, ph, pw, col, xv[j], psc, psh) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[j] = i < F4 ? gn_pool_dy(a, pidx_f, pdy_f, ph, pw, col, xv[j], psc, psh) : f32x4{0.f, 0.f, 0.f, 0.f};
             ph += step_h; pw += step_w;
             if (pw >= a.pW) { pw -= a.pW; ++ph; }
         }
@@ -987,6 +992,9 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, 
     const bool pooled = a.pool_dy != nullptr && !a.dy_masked;
     const int c4_shift = __builtin_ctz(C4), pstep = NT >> c4_shift;
     const int step_h = pooled ? pstep / a.pW : 0, step_w = pooled ? pstep - step_h * a.pW : 0;
+    const size_t pool_f = pooled ? (size_t)f * ((a.pH + 1) / 2) * ((a.pW + 1) / 2) * C : 0;
+    const uint8_t* pidx_f = pooled ? a.pool_idx + pool_f : nullptr;
+    const float* pdy_f = pooled ? a.pool_dy + pool_f : nullptr;
     const f32x4* dy4 = pooled ? nullptr : reinterpret_cast<const f32x4*>((a.dy_masked ? a.dy_masked : a.dy) + fb);
     const f32x4* ro4 = (a.relu_out && !a.dy_masked && !pooled) ? reinterpret_cast<const f32x4*>(a.relu_out + fb) : nullptr;
     f32x4* dx4 = reinterpret_cast<f32x4*>(a.dx + fb);
@@ -1010,7 +1018,7 @@ __global__ void __launch_bounds__(NT) gn_chunk_bwd_dx_kernel(const GnBwdArgs a, 
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = base + t + j * NT;
-            dv[j] = i < F4 ? gn_pool_dy(a, f, ph, pw, col, xv[j], psc, psh) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[j] = i < F4 ? gn_pool_dy(a, pidx_f, pdy_f, ph, pw, col, xv[j], psc, psh) : f32x4{0.f, 0.f, 0.f, 0.f};
             ph += step_h; pw += step_w;
             if (pw >= a.pW) { pw -= a.pW; ++ph; }
         }
@@ -1255,6 +1263,7 @@ int groupnorm_backward(const GnBwdArgs& a, hipStream_t s) {
     // sub-chunks per workgroup: the stem form (gathers through the pooling windows per element) measured SLOWER with them (its statistics
     // kernel 1.22 -> 1.79 ms per 4096 frames: profiles r06, commits 075041b vs b3f3464), the plain form faster (NOTEBOOK R6.8)
     const int reps = a.pool_dy ? 1 : gnc_reps_b();
+    // (2 or 4 units per thread instead of 8 for this form -- more, smaller workgroups -- measured slower: C3 247.7 / 251.2 / 263.6 ms)
     if (a.scratch && gn_chunk_cfg(a.B, a.HW, a.C, (size_t)a.C * 2, a.scratch_floats, GNC_NT * GNC_NV_B * reps, nchunks)) {
         const size_t lds1 = (size_t)(GNC_NT * 4 + a.C) * sizeof(float);
         if (a.pool_dy && (!a.pool_idx || !a.beta || a.pH * a.pW != a.HW)) return HAB_ERR_ARG;
