@@ -51,6 +51,13 @@ constexpr int DN_LDS_BYTES = (2 * DN_BUF > DN_BM * DN_EPI_LD * 4) ? 2 * DN_BUF :
 // development (HAB_DENSE_ABLATE bit 4): shader-clock stamps of workgroup 0's waves at the phase boundaries of k-tiles 8..15
 // [wave][k-tile - 8][5]: iteration start, after the early stage + fetch, after the MFMAs, after the late stage + fetch, after the barrier
 __device__ long long dn_trace[8][8][5];
+// The ablation masks and the stamps are compiled in only with -DHAB_DENSE_DEV (make EXTRA=-DHAB_DENSE_DEV; tools/dense_trace.py,
+// tools/bench_dense.py with HAB_DENSE_ABLATE): the production kernel carries none of their branches.
+#ifdef HAB_DENSE_DEV
+constexpr bool DN_DEV = true;
+#else
+constexpr bool DN_DEV = false;
+#endif
 
 typedef short dn_v4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ dn_v4s dn_tr_read(const unsigned char* p) {
@@ -137,7 +144,7 @@ __global__ void __launch_bounds__(DN_NT) dense_bf3_kernel(const DenseArgs g) {
     }
     const unsigned a_step = (A_IC ? (unsigned)(DN_BK * g.lda) : (unsigned)DN_BK) * 4u, b_step = (B_IC ? (unsigned)(DN_BK * g.ldb) : (unsigned)DN_BK) * 4u;
     auto fetch = [&](int kt) {
-        if (g.ablate & 1) return;
+        if (DN_DEV && (g.ablate & 1)) return;
 #pragma unroll
         for (int j = 0; j < AU; ++j) araw[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)avoff[j], (int)((unsigned)kt * a_step), 0);
 #pragma unroll
@@ -154,7 +161,7 @@ __global__ void __launch_bounds__(DN_NT) dense_bf3_kernel(const DenseArgs g) {
         *reinterpret_cast<u32x2*>(dst + 2 * plane_bytes) = w3;
     };
     auto stage = [&](int buf) {
-        if (g.ablate & 4) return;
+        if (DN_DEV && (g.ablate & 4)) return;
         unsigned char* As = dn_smem + buf * DN_BUF;
         unsigned char* Bs = As + 3 * DN_A_PLANE;
 #pragma unroll
@@ -227,7 +234,7 @@ __global__ void __launch_bounds__(DN_NT) dense_bf3_kernel(const DenseArgs g) {
         const unsigned char* Bs = As + 3 * DN_A_PLANE;
         // (stage / fetch run unconditionally: past the end they rewrite the dead buffer from the last tile's registers / re-read the last tile)
         const int ktf = kt + 2 < ntk ? kt + 2 : ntk - 1;
-        const bool tr = (g.ablate & 16) && blockIdx.x == 0 && kt >= 8 && kt < 16;
+        const bool tr = DN_DEV && (g.ablate & 16) && blockIdx.x == 0 && kt >= 8 && kt < 16;
         if (tr && lane == 0) dn_trace[wave][kt - 8][0] = __builtin_readcyclecounter();
         if (early) {
             stage((kt + 1) & 1);   // (its buffer was last read in iteration kt - 1, behind that iteration's barrier)
@@ -245,7 +252,7 @@ __global__ void __launch_bounds__(DN_NT) dense_bf3_kernel(const DenseArgs g) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bf[j][pl] = frag(Bs + pl * DN_B_PLANE + fb[j][c], B_IC);
-            if (g.ablate & 2) {  // keep the fragments alive without the matrix pipe
+            if (DN_DEV && (g.ablate & 2)) {  // keep the fragments alive without the matrix pipe
                 if (af[0][0][0] == (__bf16)123.f && bf[1][2][7] == (__bf16)77.f) acc[0][0][0] += 1.f;
                 continue;
             }

@@ -1,4 +1,5 @@
-"""Development: phase timeline of workgroup 0 of the dense GEMM kernel (HAB_DENSE_ABLATE=16), shader-clock cycles per phase per wave."""
+"""(needs a library built with the development hooks: make -C habitat-lab_amd/csrc EXTRA=-DHAB_DENSE_DEV)
+Development: phase timeline of workgroup 0 of the dense GEMM kernel (HAB_DENSE_ABLATE=16), shader-clock cycles per phase per wave."""
 import ctypes as C, os, sys
 os.environ["HAB_DENSE_ABLATE"] = os.environ.get("HAB_DENSE_ABLATE", "16")
 os.environ.setdefault("HAB_DENSE_MIN_MFLOP", "0")
